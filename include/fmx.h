@@ -1,7 +1,150 @@
-/* placeholder — replaced below */
+/*
+ * fmx.h — C ABI of libfmx.so, the MI355X-native engine for index4j's backward-search path.
+ *
+ * This is the drop-in boundary.  index4j (pure Java) has no FFI seam of its own (FmIndex is a
+ * final class), so the boundary is: the public FmIndex / FmIndexBuilder method
+ * signatures on the host side, the serialized byte layout (FmIndex.write) as the hand-over format,
+ * and the functions below as what a JNI / Panama binding of those methods calls.  Each function
+ * cites the reference interface it replaces; paths are relative to
+ * /root/reference/indices/src/main/java/com/dynatrace/ (FM = fm/FmIndex.java, FMB =
+ * fm/FmIndexBuilder.java, SER = serialization/Serialization.java).
+ *
+ * Conventions: plain pointers and sizes, no C++ or torch types.  Every function returns FMX_OK or a
+ * negative library error (never throws).  Per-query failures (the reference's exceptions) are
+ * reported in status[] with the FMX_ST_* codes so the host binding can re-throw the identical
+ * exception type and message (fmx_status_message).  All batch calls run on the GPU; there is no CPU
+ * query path in this library: without a HIP device they return FMX_E_NO_DEVICE.
+ */
 #ifndef FMX_H
 #define FMX_H
+
+#include <stddef.h>
 #include <stdint.h>
-#define FMX_OK 0
-#define FMX_E_ARG (-1)
+
+#ifdef __cplusplus
+extern "C" {
 #endif
+
+typedef struct fmx_index fmx_index;
+
+/* library-level return codes */
+#define FMX_OK 0
+#define FMX_E_ARG (-1)        /* bad argument */
+#define FMX_E_ALPHABET (-2)   /* IllegalArgumentException("Input has more than 32767 different symbols") FM:423-426 */
+#define FMX_E_FORMAT (-3)     /* malformed / truncated serialized stream */
+#define FMX_E_VERSION (-4)    /* IOException("Incompatible serial versions! ...") SER:46-56 */
+#define FMX_E_NO_DEVICE (-5)  /* no HIP device / index not resident on a device */
+#define FMX_E_HIP (-6)        /* a HIP runtime call failed (see fmx_last_error) */
+#define FMX_E_NOMEM (-7)
+#define FMX_E_UNSUPPORTED (-8) /* e.g. text longer than one 2^32 hyperblock */
+
+/* per-query status codes (exceptions of the reference; 0 = no exception) */
+#define FMX_ST_OK 0
+#define FMX_ST_NOT_ENABLED 1     /* RuntimeException "Text recovery not enabled at build time"   FM:566-568, 611-613 */
+#define FMX_ST_POS_NEGATIVE 2    /* RuntimeException "Requested position less than 0"            FM:570-572, 615-617 */
+#define FMX_ST_STOP_TOO_LONG 3   /* RuntimeException "Stop position longer than index string"    FM:574-576 */
+#define FMX_ST_DEST_TOO_SMALL 4  /* RuntimeException "Supplied destination is not large enough"  FM:591-593 */
+#define FMX_ST_POS_TOO_LONG 5    /* RuntimeException "Requested position longer than index string" FM:619-621 */
+#define FMX_ST_DEST_SIZE_ZERO 6  /* IllegalArgumentException "Supplied destination for extraction has size zero" FM:623-625 */
+#define FMX_ST_NO_BOUNDARY 7     /* IllegalArgumentException "Boundary does not exist"           FM:659-661, 792-794, 849-851 */
+#define FMX_ST_DOES_NOT_FIT 8    /* RuntimeException "Extraction does not fit in the supplied destination. Currently extracted: N" (N in aux[]) FM:732-737, 816-821, 893-898 */
+#define FMX_ST_JAVA_AIOOBE 9     /* the JVM would raise ArrayIndexOutOfBoundsException (e.g. empty pattern FM:456-457, locations[] too small FM:538) */
+
+/* ---- construction, persistence, lifetime ------------------------------------------------- */
+
+/* new FmIndexBuilder().setSampleRate(s).setEnableExtraction(b).build(char[])  FMB:34-62 -> FM:155-174.
+ * Host-side construction (suffix array, BWT, wavelet/RRR encoding); text = UTF-16 code units. */
+int fmx_build(const uint16_t *text, int32_t n, int32_t sample_rate, int enable_extract, fmx_index **out);
+
+/* FmIndex.read(ObjectInput) FM:983-1025; also accepts the ObjectOutputStream-framed form produced by
+ * Serialization.writeToByteArray SER:67-79 (magic AC ED 00 05 + block-data records). */
+int fmx_load(const uint8_t *ser, size_t len, fmx_index **out);
+
+/* FmIndex.write(ObjectOutput) FM:948-975; framed != 0 adds the SER:67-79 ObjectOutputStream framing.
+ * *buf is owned by the library until fmx_free_buffer. */
+int fmx_save(const fmx_index *idx, int framed, uint8_t **buf, size_t *len);
+void fmx_free_buffer(uint8_t *buf);
+void fmx_free(fmx_index *idx);
+
+/* getInputLength FM:929 (includes the sentinel), getAlphabetLength FM:939, builder knobs FMB:21-22 */
+int32_t fmx_input_length(const fmx_index *idx);
+int32_t fmx_alphabet_length(const fmx_index *idx);
+int32_t fmx_sample_rate(const fmx_index *idx);
+int32_t fmx_extract_enabled(const fmx_index *idx);
+
+/* ---- the flat HBM image ("blob") --------------------------------------------------------- */
+
+/* Relocatable, pointer-free image of the whole index (layout: index4j_amd/csrc/fmx_blob.hpp).
+ * It is what lives in HBM, and what is broadcast to the other GPUs over RCCL. */
+int fmx_blob(const fmx_index *idx, const uint8_t **blob, size_t *len);
+/* copy the blob into HBM of `device` (hipMalloc + hipMemcpy) and make idx queryable there */
+int fmx_to_device(fmx_index *idx, int device);
+/* adopt a blob that already sits in device memory (e.g. the receive buffer of an RCCL broadcast).
+ * The memory stays owned by the caller and must outlive the index. */
+int fmx_attach_device_blob(void *device_blob, size_t len, int device, fmx_index **out);
+void *fmx_device_blob(const fmx_index *idx, size_t *len);
+
+/* ---- batched queries: host buffers (H2D copy, kernels, D2H copy, synchronous) ------------- */
+
+/* int count(char[] pattern, int offset, int length) FM:455-474, batched: pattern i is
+ * pat[pat_off[i] .. pat_off[i+1]).  lf_steps[i] (nullable) = number of C[c]+rank evaluations spent
+ * (FM:469-470). status[i] (nullable) is FMX_ST_JAVA_AIOOBE for an empty pattern. */
+int fmx_count_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n,
+                    int32_t *counts, int32_t *lf_steps, int32_t *status);
+
+/* int locate(char[] pattern, int offset, int length, int[] locations, int maxMatches) FM:504-552.
+ * locs is n rows of loc_cap ints (the caller's `locations` arrays); found[i] = return value =
+ * number located (<= max_matches; max_matches = -1: unlimited, FM:488).  Hits are SA rows
+ * start+1.. in order (FM:527-547), exactly the ones the reference returns. */
+int fmx_locate_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n,
+                     int32_t max_matches, int32_t *locs, int32_t loc_cap, int32_t *found, int32_t *lf_steps,
+                     int32_t *status);
+
+/* int extract(int start, int stop, char[] destination, int offset) FM:564-608.  dst is n rows of
+ * dst_len chars (row i = the `destination` array of query i, in/out); out_len[i] = return value. */
+int fmx_extract_batch(const fmx_index *idx, const int32_t *start, const int32_t *stop, int32_t n, uint16_t *dst,
+                      int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf_steps, int32_t *status);
+
+/* extractUntilBoundary FM:640-759 (mode 0), extractUntilBoundaryLeft FM:772-831 (mode 1),
+ * extractUntilBoundaryRight FM:844-922 (mode 2).  aux[i] = N of "Currently extracted: N". */
+int fmx_extract_boundary_batch(const fmx_index *idx, const int32_t *from, int32_t n, uint16_t boundary, int mode,
+                               uint16_t *dst, int32_t dst_len, int32_t offset, int32_t *out_len,
+                               int32_t *lf_steps, int32_t *status, int32_t *aux);
+
+/* ---- batched queries: device-resident buffers, asynchronous on `stream` (a hipStream_t) ----
+ * Same semantics; every pointer is device memory on the index's device.  Nothing is synchronised:
+ * the caller orders work through the stream (this is what bench.py times with HIP events). */
+int fmx_count_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
+                        int32_t *d_counts, int32_t *d_lf_steps, int32_t *d_status, void *stream);
+int fmx_locate_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
+                         int32_t max_matches, int32_t *d_locs, int32_t loc_cap, int32_t *d_found,
+                         int32_t *d_lf_steps, int32_t *d_status, int32_t *d_range_ws /* 2*n ints */, void *stream);
+int fmx_extract_batch_dev(const fmx_index *idx, const int32_t *d_start, const int32_t *d_stop, int32_t n,
+                          uint16_t *d_dst, int32_t dst_len, int32_t offset, int32_t *d_out_len,
+                          int32_t *d_lf_steps, int32_t *d_status, void *stream);
+int fmx_extract_boundary_batch_dev(const fmx_index *idx, const int32_t *d_from, int32_t n, uint16_t boundary,
+                                   int mode, uint16_t *d_dst, int32_t dst_len, int32_t offset, int32_t *d_out_len,
+                                   int32_t *d_lf_steps, int32_t *d_status, int32_t *d_aux, void *stream);
+
+/* ---- helpers ------------------------------------------------------------------------------ */
+
+/* FmIndex.convertBytePatternToCharPattern FM:239-298.  Returns the number of chars, or -1 with
+ * *bad_value set when the reference throws "Found a character that exceeds (32767): it was N". */
+int fmx_convert_byte_pattern(const uint8_t *pattern, int32_t offset, int32_t length, uint16_t *dest,
+                             int32_t *bad_value);
+/* the reference's exception message for a status code ("%d" left in place for FMX_ST_DOES_NOT_FIT) */
+const char *fmx_status_message(int status);
+/* 1 if the exception type is IllegalArgumentException, 0 for RuntimeException, 2 for AIOOBE */
+int fmx_status_kind(int status);
+const char *fmx_last_error(void);
+int fmx_device_count(void);
+
+/* deterministic synthetic workload (bench / tests): see index4j_amd/csrc/fmx_synth.cpp */
+int fmx_synth_log(uint64_t seed, int32_t n, uint16_t *out);
+int fmx_synth_patterns(uint64_t seed, const uint16_t *text, int32_t n, int32_t m, int32_t count, uint16_t *pat,
+                       int32_t *pat_off, int32_t *positions);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMX_H */

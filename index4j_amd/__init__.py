@@ -1,0 +1,19 @@
+"""index4j_amd — MI355X-native engine for the backward-search path of dynatrace-oss/index4j.
+
+The package is a thin host mirror (``FmIndex`` / ``FmIndexBuilder``) over ``libfmx.so``, the C-ABI
+library holding the host-side index builder / serializer and the HIP kernels (csrc/).  It has no
+CPU query path; the HIP library must be built (``__graft_entry__.build()``)."""
+from ._lib import FmxError, LIB_PATH, SYMBOLS, lib  # noqa: F401
+from .fmindex import (  # noqa: F401
+    FmIndex,
+    FmIndexBuilder,
+    as_chars,
+    chars_to_str,
+    pack_patterns,
+    raise_for_status,
+    synth_log,
+    synth_patterns,
+)
+
+__all__ = ["FmIndex", "FmIndexBuilder", "FmxError", "as_chars", "chars_to_str", "pack_patterns",
+           "raise_for_status", "synth_log", "synth_patterns", "lib", "LIB_PATH", "SYMBOLS"]

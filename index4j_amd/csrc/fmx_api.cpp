@@ -1,0 +1,532 @@
+// fmx_api.cpp — the C ABI of include/fmx.h: index lifetime, blob management, and the batch entry
+// points that copy operands, launch the HIP kernels (fmx_kernels.hip) and copy results back.
+// There is no CPU query path: without a HIP device every batch call fails with FMX_E_NO_DEVICE.
+#include "../../include/fmx.h"
+#include "fmx_device.hpp"
+#include "fmx_model.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace fmx {
+int launch_count(const DevIndex &, int, const uint16_t *, const int32_t *, int32_t, int32_t *, int32_t *, int32_t *,
+                 int32_t *, hipStream_t);
+int launch_locate_walk(const DevIndex &, int, const int32_t *, int32_t, int32_t, int32_t *, int32_t, int32_t *,
+                       int32_t *, int32_t *, hipStream_t);
+int launch_extract(const DevIndex &, int, const int32_t *, const int32_t *, int32_t, uint16_t *, int32_t, int32_t,
+                   int32_t *, int32_t *, int32_t *, hipStream_t);
+int launch_extract_boundary(const DevIndex &, int, const int32_t *, int32_t, uint16_t, int, uint16_t *, int32_t,
+                            int32_t, int32_t *, int32_t *, int32_t *, int32_t *, hipStream_t);
+}  // namespace fmx
+
+struct fmx_index {
+    fmx::FmModel model;
+    bool has_model = false;
+    std::vector<uint8_t> blob;   // host image (empty for attached device blobs)
+    fmx::BlobHeader hdr;         // host copy of the header
+    void *d_blob = nullptr;
+    size_t d_len = 0;
+    int device = -1;
+    int n_cu = 256;
+    bool owns_device = false;
+    fmx::DevIndex dev;
+};
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) return fail(FMX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+int ensure_blob(fmx_index *idx) {
+    if (!idx->blob.empty()) return FMX_OK;
+    if (!idx->has_model) return fail(FMX_E_ARG, "index has neither a model nor a host blob");
+    std::string err;
+    int rc = fmx::flatten_model(idx->model, idx->blob, err);
+    if (rc) return fail(rc == -3 ? FMX_E_FORMAT : FMX_E_UNSUPPORTED, err);
+    memcpy(&idx->hdr, idx->blob.data(), sizeof(fmx::BlobHeader));
+    return FMX_OK;
+}
+
+// structural checks before any kernel may walk the image (a kernel fault can take the GPU down)
+int validate_model(const fmx::FmModel &m, std::string &err) {
+    using namespace fmx;
+    auto bad = [&](const char *what) {
+        err = std::string("index fails validation: ") + what;
+        return FMX_E_FORMAT;
+    };
+    auto check_rrr = [&](const RrrModel &r) {
+        if (r.sample_size <= 0 || r.length < 0 || r.classes.width != 4) return false;
+        const int64_t nb = r.length / 15 + (r.length % 15 > 0);
+        if (r.classes.length < nb) return false;
+        if ((int64_t)r.classes.words.size() < words_for_bits((int64_t)r.classes.length * 4)) return false;
+        const int64_t n_rec = r.classes.length / r.sample_size + 1;
+        if (r.sampled_offsets.length < n_rec || r.prefix_sums.length < n_rec) return false;
+        if (r.bits_per_offset_pos < 1 || r.bits_per_offset_pos > 32 || r.prefix_sums.width < 1 || r.prefix_sums.width > 32)
+            return false;
+        if (r.sampled_offsets.width < r.bits_per_offset_pos) return false;
+        const uint64_t total_bits = (uint64_t)r.offsets.size() * 64;
+        for (int64_t k = 0; k < n_rec; ++k)
+            if (r.sampled_offsets.get_bits(k * r.sampled_offsets.width, r.bits_per_offset_pos) > total_bits) return false;
+        return true;
+    };
+    if (m.sample_rate <= 0 || m.length <= 0) return bad("sampleRate / length");
+    if (m.bw_suffixes < 1 || m.bw_suffixes > 32) return bad("bitWidthSuffixes");
+    if (m.enable_extract && (m.bw_positions < 1 || m.bw_positions > 32)) return bad("bitWidthPositions");
+    if (m.look_up.empty() || m.C.size() < m.look_up.size()) return bad("cumulativeCounts / monotonicLookUp sizes");
+    for (size_t i = 0; i < m.map_vals.size(); ++i)
+        if (m.map_vals[i] < 0 || (size_t)m.map_vals[i] + 1 >= m.C.size() || (size_t)m.map_vals[i] >= m.look_up.size())
+            return bad("monotonicMap value outside cumulativeCounts");
+    if (m.suffixes.width != m.bw_suffixes || m.suffixes.length < m.length / m.sample_rate + 1) return bad("suffixes");
+    if (m.enable_extract && (m.positions.width != m.bw_positions || m.positions.length < m.length / m.sample_rate + 2))
+        return bad("positions");
+    if (m.sampled.length != m.length || !check_rrr(m.sampled)) return bad("sampledSuffixes");
+    const WfbbModel &w = m.wt;
+    if (w.size != m.length || w.alphabet_size <= 0 || w.alphabet_size > 32768) return bad("wavelet size / alphabet");
+    if ((size_t)w.alphabet_size > m.look_up.size() + 1) return bad("wavelet alphabet larger than monotonicLookUp");
+    for (const auto &sb : w.sb) {
+        if (sb.block_size_log < 0 || sb.block_size_log > 20 || sb.sigma < -1) return bad("superblock header");
+        if (!check_rrr(sb.rank_support)) return bad("superblock RRR");
+        for (const auto &bh : sb.block_headers) {
+            if (bh.tree_height < 0 || bh.tree_height > 30 || bh.sigma < 0) return bad("block tree height / sigma");
+            const int64_t sigma = (int64_t)bh.sigma + 1;
+            const int64_t need = (bh.tree_height > 1 ? (bh.tree_height - 1) * 4 : 0) + sigma * 5 + (sigma - 1) * 2;
+            if (bh.var_off < 0 || bh.var_off + need > (int64_t)sb.var.size()) return bad("block header offset");
+            if (bh.bv_offset < 0 || bh.bv_offset > sb.rank_support.length || bh.bv_rank < 0) return bad("block bitvector offset");
+        }
+    }
+    return FMX_OK;
+}
+
+void make_dev_index(fmx_index *idx) {
+    const fmx::BlobHeader &h = idx->hdr;
+    const uint8_t *b = static_cast<const uint8_t *>(idx->d_blob);
+    fmx::DevIndex &d = idx->dev;
+    auto at = [&](uint32_t off) { return b + ((uint64_t)off << 3); };
+    d.base = b;
+    d.C = reinterpret_cast<const int32_t *>(at(h.off_c));
+    d.look_up = reinterpret_cast<const int32_t *>(at(h.off_lookup));
+    d.char2code = reinterpret_cast<const int16_t *>(at(h.off_char2code));
+    d.suffix_words = reinterpret_cast<const uint32_t *>(at(h.off_suffixes));
+    d.pos_words = reinterpret_cast<const uint32_t *>(at(h.off_positions));
+    d.sbc = reinterpret_cast<const fmx::SbcEntry *>(at(h.off_sbc));
+    d.sbd = reinterpret_cast<const fmx::SbDesc *>(at(h.off_sbdesc));
+    d.inv_global = reinterpret_cast<const uint16_t *>(at(h.off_inv));
+    d.sampled = h.sampled;
+    d.length = h.length;
+    d.sample_rate = h.sample_rate;
+    d.enable_extract = h.enable_extract;
+    d.wt_sigma = h.wt_sigma;
+    d.n_sb = h.n_sb;
+    d.bw_suffixes = h.bw_suffixes;
+    d.bw_positions = h.bw_positions;
+    d.n_positions = h.n_positions;
+    d.wt_size = (uint32_t)h.wt_size;
+}
+
+int require_device(const fmx_index *idx) {
+    if (!idx) return fail(FMX_E_ARG, "null index");
+    if (!idx->d_blob) return fail(FMX_E_NO_DEVICE, "index is not resident on a HIP device (call fmx_to_device)");
+    return FMX_OK;
+}
+
+// RAII device scratch for the host-buffer entry points
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+    template <typename T>
+    T *as() {
+        return static_cast<T *>(p);
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char *fmx_last_error(void) { return g_err.c_str(); }
+
+int fmx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int fmx_build(const uint16_t *text, int32_t n, int32_t sample_rate, int enable_extract, fmx_index **out) {
+    if (!out || (!text && n > 0)) return fail(FMX_E_ARG, "null argument");
+    std::unique_ptr<fmx_index> idx(new fmx_index());
+    std::string err;
+    int rc = fmx::build_model(text, n, sample_rate, enable_extract != 0, idx->model, err);
+    if (rc == -2) return fail(FMX_E_ALPHABET, err);
+    if (rc) return fail(FMX_E_ARG, err);
+    idx->has_model = true;
+    *out = idx.release();
+    return FMX_OK;
+}
+
+int fmx_load(const uint8_t *ser, size_t len, fmx_index **out) {
+    if (!out || !ser) return fail(FMX_E_ARG, "null argument");
+    std::unique_ptr<fmx_index> idx(new fmx_index());
+    std::string err;
+    int rc = fmx::parse_model(ser, len, idx->model, err);
+    if (rc == 2) return fail(FMX_E_VERSION, err);
+    if (rc) return fail(FMX_E_FORMAT, err);
+    rc = validate_model(idx->model, err);
+    if (rc) return fail(rc, err);
+    idx->has_model = true;
+    *out = idx.release();
+    return FMX_OK;
+}
+
+int fmx_save(const fmx_index *idx, int framed, uint8_t **buf, size_t *len) {
+    if (!idx || !buf || !len) return fail(FMX_E_ARG, "null argument");
+    if (!idx->has_model) return fail(FMX_E_ARG, "index was attached from a device blob; nothing to serialize");
+    std::vector<uint8_t> out;
+    fmx::emit_model(idx->model, framed != 0, out);
+    uint8_t *p = static_cast<uint8_t *>(malloc(out.size() ? out.size() : 1));
+    if (!p) return fail(FMX_E_NOMEM, "out of memory");
+    memcpy(p, out.data(), out.size());
+    *buf = p;
+    *len = out.size();
+    return FMX_OK;
+}
+
+void fmx_free_buffer(uint8_t *buf) { free(buf); }
+
+void fmx_free(fmx_index *idx) {
+    if (!idx) return;
+    if (idx->owns_device && idx->d_blob) {
+        (void)hipSetDevice(idx->device);
+        (void)hipFree(idx->d_blob);
+    }
+    delete idx;
+}
+
+int32_t fmx_input_length(const fmx_index *idx) { return idx->has_model ? idx->model.length : idx->hdr.length; }
+int32_t fmx_alphabet_length(const fmx_index *idx) {
+    return idx->has_model ? (int32_t)idx->model.map_keys.size() : idx->hdr.n_keys;
+}
+int32_t fmx_sample_rate(const fmx_index *idx) { return idx->has_model ? idx->model.sample_rate : idx->hdr.sample_rate; }
+int32_t fmx_extract_enabled(const fmx_index *idx) {
+    return idx->has_model ? (idx->model.enable_extract ? 1 : 0) : idx->hdr.enable_extract;
+}
+
+int fmx_blob(const fmx_index *idx_c, const uint8_t **blob, size_t *len) {
+    fmx_index *idx = const_cast<fmx_index *>(idx_c);
+    if (!idx || !blob || !len) return fail(FMX_E_ARG, "null argument");
+    int rc = ensure_blob(idx);
+    if (rc) return rc;
+    *blob = idx->blob.data();
+    *len = idx->blob.size();
+    return FMX_OK;
+}
+
+int fmx_to_device(fmx_index *idx, int device) {
+    if (!idx) return fail(FMX_E_ARG, "null index");
+    int rc = ensure_blob(idx);
+    if (rc) return rc;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(FMX_E_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(FMX_E_ARG, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    if (idx->owns_device && idx->d_blob) {
+        (void)hipFree(idx->d_blob);
+        idx->d_blob = nullptr;
+    }
+    HIP_TRY(hipMalloc(&idx->d_blob, idx->blob.size()));
+    idx->owns_device = true;
+    idx->d_len = idx->blob.size();
+    idx->device = device;
+    HIP_TRY(hipMemcpy(idx->d_blob, idx->blob.data(), idx->blob.size(), hipMemcpyHostToDevice));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    idx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    make_dev_index(idx);
+    return FMX_OK;
+}
+
+int fmx_attach_device_blob(void *device_blob, size_t len, int device, fmx_index **out) {
+    if (!device_blob || !out || len < sizeof(fmx::BlobHeader)) return fail(FMX_E_ARG, "bad blob");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(FMX_E_NO_DEVICE, "no HIP device visible");
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<fmx_index> idx(new fmx_index());
+    HIP_TRY(hipMemcpy(&idx->hdr, device_blob, sizeof(fmx::BlobHeader), hipMemcpyDeviceToHost));
+    if (idx->hdr.magic != fmx::kBlobMagic || idx->hdr.version != fmx::kBlobVersion || idx->hdr.total_bytes != len)
+        return fail(FMX_E_FORMAT, "device blob header mismatch");
+    idx->d_blob = device_blob;
+    idx->d_len = len;
+    idx->device = device;
+    idx->owns_device = false;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    idx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    make_dev_index(idx.get());
+    *out = idx.release();
+    return FMX_OK;
+}
+
+void *fmx_device_blob(const fmx_index *idx, size_t *len) {
+    if (!idx) return nullptr;
+    if (len) *len = idx->d_len;
+    return idx->d_blob;
+}
+
+// ---- device-pointer entry points ---------------------------------------------------------------
+
+int fmx_count_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
+                        int32_t *d_counts, int32_t *d_lf_steps, int32_t *d_status, void *stream) {
+    int rc = require_device(idx);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!d_pat_off || !d_counts))) return fail(FMX_E_ARG, "bad arguments");
+    int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, n, d_counts, d_lf_steps, d_status, nullptr,
+                              static_cast<hipStream_t>(stream));
+    if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
+    return FMX_OK;
+}
+
+int fmx_locate_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
+                         int32_t max_matches, int32_t *d_locs, int32_t loc_cap, int32_t *d_found,
+                         int32_t *d_lf_steps, int32_t *d_status, int32_t *d_range_ws, void *stream) {
+    int rc = require_device(idx);
+    if (rc) return rc;
+    if (n < 0 || loc_cap < 0 || (n > 0 && (!d_pat_off || !d_found || !d_range_ws || (!d_locs && loc_cap > 0))))
+        return fail(FMX_E_ARG, "bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // found[] doubles as the scratch `counts` output of the range pass; the walk pass overwrites it
+    int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, n, d_found, d_lf_steps, d_status, d_range_ws, st);
+    if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
+    e = fmx::launch_locate_walk(idx->dev, idx->n_cu, d_range_ws, n, max_matches, d_locs, loc_cap, d_found, d_lf_steps,
+                                d_status, st);
+    if (e) return fail(FMX_E_HIP, std::string("k_locate_walk launch: ") + hipGetErrorString((hipError_t)e));
+    return FMX_OK;
+}
+
+int fmx_extract_batch_dev(const fmx_index *idx, const int32_t *d_start, const int32_t *d_stop, int32_t n,
+                          uint16_t *d_dst, int32_t dst_len, int32_t offset, int32_t *d_out_len, int32_t *d_lf_steps,
+                          int32_t *d_status, void *stream) {
+    int rc = require_device(idx);
+    if (rc) return rc;
+    if (n < 0 || dst_len < 0 || (n > 0 && (!d_start || !d_stop || !d_out_len || (!d_dst && dst_len > 0))))
+        return fail(FMX_E_ARG, "bad arguments");
+    int e = fmx::launch_extract(idx->dev, idx->n_cu, d_start, d_stop, n, d_dst, dst_len, offset, d_out_len, d_lf_steps,
+                                d_status, static_cast<hipStream_t>(stream));
+    if (e) return fail(FMX_E_HIP, std::string("k_extract launch: ") + hipGetErrorString((hipError_t)e));
+    return FMX_OK;
+}
+
+int fmx_extract_boundary_batch_dev(const fmx_index *idx, const int32_t *d_from, int32_t n, uint16_t boundary, int mode,
+                                   uint16_t *d_dst, int32_t dst_len, int32_t offset, int32_t *d_out_len,
+                                   int32_t *d_lf_steps, int32_t *d_status, int32_t *d_aux, void *stream) {
+    int rc = require_device(idx);
+    if (rc) return rc;
+    if (n < 0 || dst_len < 0 || mode < 0 || mode > 2 || (n > 0 && (!d_from || !d_out_len || (!d_dst && dst_len > 0))))
+        return fail(FMX_E_ARG, "bad arguments");
+    int e = fmx::launch_extract_boundary(idx->dev, idx->n_cu, d_from, n, boundary, mode, d_dst, dst_len, offset,
+                                         d_out_len, d_lf_steps, d_status, d_aux, static_cast<hipStream_t>(stream));
+    if (e) return fail(FMX_E_HIP, std::string("k_extract_boundary launch: ") + hipGetErrorString((hipError_t)e));
+    return FMX_OK;
+}
+
+// ---- host-buffer entry points --------------------------------------------------------------------
+
+#define H2D(dst, src, bytes) HIP_TRY(hipMemcpy((dst), (src), (bytes), hipMemcpyHostToDevice))
+#define D2H(dst, src, bytes) HIP_TRY(hipMemcpy((dst), (src), (bytes), hipMemcpyDeviceToHost))
+
+int fmx_count_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n, int32_t *counts,
+                    int32_t *lf_steps, int32_t *status) {
+    int rc = require_device(idx);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!pat_off || !counts))) return fail(FMX_E_ARG, "bad arguments");
+    if (n == 0) return FMX_OK;
+    HIP_TRY(hipSetDevice(idx->device));
+    const size_t chars = (size_t)(pat_off[n] > 0 ? pat_off[n] : 0);
+    DevBuf d_pat, d_off, d_cnt, d_lf, d_st;
+    HIP_TRY(d_pat.alloc(chars * 2 + 8));
+    HIP_TRY(d_off.alloc((size_t)(n + 1) * 4));
+    HIP_TRY(d_cnt.alloc((size_t)n * 4));
+    HIP_TRY(d_lf.alloc((size_t)n * 4));
+    HIP_TRY(d_st.alloc((size_t)n * 4));
+    if (chars) H2D(d_pat.p, pat, chars * 2);
+    H2D(d_off.p, pat_off, (size_t)(n + 1) * 4);
+    rc = fmx_count_batch_dev(idx, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, d_cnt.as<int32_t>(), d_lf.as<int32_t>(),
+                             d_st.as<int32_t>(), nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    D2H(counts, d_cnt.p, (size_t)n * 4);
+    if (lf_steps) D2H(lf_steps, d_lf.p, (size_t)n * 4);
+    if (status) D2H(status, d_st.p, (size_t)n * 4);
+    return FMX_OK;
+}
+
+int fmx_locate_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n, int32_t max_matches,
+                     int32_t *locs, int32_t loc_cap, int32_t *found, int32_t *lf_steps, int32_t *status) {
+    int rc = require_device(idx);
+    if (rc) return rc;
+    if (n < 0 || loc_cap < 0 || (n > 0 && (!pat_off || !found || (!locs && loc_cap > 0))))
+        return fail(FMX_E_ARG, "bad arguments");
+    if (n == 0) return FMX_OK;
+    HIP_TRY(hipSetDevice(idx->device));
+    const size_t chars = (size_t)(pat_off[n] > 0 ? pat_off[n] : 0);
+    const size_t loc_bytes = (size_t)n * (size_t)loc_cap * 4;
+    DevBuf d_pat, d_off, d_locs, d_found, d_lf, d_st, d_ws;
+    HIP_TRY(d_pat.alloc(chars * 2 + 8));
+    HIP_TRY(d_off.alloc((size_t)(n + 1) * 4));
+    HIP_TRY(d_locs.alloc(loc_bytes));
+    HIP_TRY(d_found.alloc((size_t)n * 4));
+    HIP_TRY(d_lf.alloc((size_t)n * 4));
+    HIP_TRY(d_st.alloc((size_t)n * 4));
+    HIP_TRY(d_ws.alloc((size_t)n * 8));
+    if (chars) H2D(d_pat.p, pat, chars * 2);
+    H2D(d_off.p, pat_off, (size_t)(n + 1) * 4);
+    if (loc_bytes) H2D(d_locs.p, locs, loc_bytes);  // `locations` is in/out: untouched slots keep the caller's values
+    rc = fmx_locate_batch_dev(idx, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, max_matches, d_locs.as<int32_t>(),
+                              loc_cap, d_found.as<int32_t>(), d_lf.as<int32_t>(), d_st.as<int32_t>(),
+                              d_ws.as<int32_t>(), nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (loc_bytes) D2H(locs, d_locs.p, loc_bytes);
+    D2H(found, d_found.p, (size_t)n * 4);
+    if (lf_steps) D2H(lf_steps, d_lf.p, (size_t)n * 4);
+    if (status) D2H(status, d_st.p, (size_t)n * 4);
+    return FMX_OK;
+}
+
+int fmx_extract_batch(const fmx_index *idx, const int32_t *start, const int32_t *stop, int32_t n, uint16_t *dst,
+                      int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf_steps, int32_t *status) {
+    int rc = require_device(idx);
+    if (rc) return rc;
+    if (n < 0 || dst_len < 0 || (n > 0 && (!start || !stop || !out_len || (!dst && dst_len > 0))))
+        return fail(FMX_E_ARG, "bad arguments");
+    if (n == 0) return FMX_OK;
+    HIP_TRY(hipSetDevice(idx->device));
+    const size_t dst_bytes = (size_t)n * (size_t)dst_len * 2;
+    DevBuf d_a, d_b, d_dst, d_len, d_lf, d_st;
+    HIP_TRY(d_a.alloc((size_t)n * 4));
+    HIP_TRY(d_b.alloc((size_t)n * 4));
+    HIP_TRY(d_dst.alloc(dst_bytes));
+    HIP_TRY(d_len.alloc((size_t)n * 4));
+    HIP_TRY(d_lf.alloc((size_t)n * 4));
+    HIP_TRY(d_st.alloc((size_t)n * 4));
+    H2D(d_a.p, start, (size_t)n * 4);
+    H2D(d_b.p, stop, (size_t)n * 4);
+    if (dst_bytes) H2D(d_dst.p, dst, dst_bytes);  // destination arrays are in/out
+    rc = fmx_extract_batch_dev(idx, d_a.as<int32_t>(), d_b.as<int32_t>(), n, d_dst.as<uint16_t>(), dst_len, offset,
+                               d_len.as<int32_t>(), d_lf.as<int32_t>(), d_st.as<int32_t>(), nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (dst_bytes) D2H(dst, d_dst.p, dst_bytes);
+    D2H(out_len, d_len.p, (size_t)n * 4);
+    if (lf_steps) D2H(lf_steps, d_lf.p, (size_t)n * 4);
+    if (status) D2H(status, d_st.p, (size_t)n * 4);
+    return FMX_OK;
+}
+
+int fmx_extract_boundary_batch(const fmx_index *idx, const int32_t *from, int32_t n, uint16_t boundary, int mode,
+                               uint16_t *dst, int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf_steps,
+                               int32_t *status, int32_t *aux) {
+    int rc = require_device(idx);
+    if (rc) return rc;
+    if (n < 0 || dst_len < 0 || mode < 0 || mode > 2 || (n > 0 && (!from || !out_len || (!dst && dst_len > 0))))
+        return fail(FMX_E_ARG, "bad arguments");
+    if (n == 0) return FMX_OK;
+    HIP_TRY(hipSetDevice(idx->device));
+    const size_t dst_bytes = (size_t)n * (size_t)dst_len * 2;
+    DevBuf d_a, d_dst, d_len, d_lf, d_st, d_aux;
+    HIP_TRY(d_a.alloc((size_t)n * 4));
+    HIP_TRY(d_dst.alloc(dst_bytes));
+    HIP_TRY(d_len.alloc((size_t)n * 4));
+    HIP_TRY(d_lf.alloc((size_t)n * 4));
+    HIP_TRY(d_st.alloc((size_t)n * 4));
+    HIP_TRY(d_aux.alloc((size_t)n * 4));
+    H2D(d_a.p, from, (size_t)n * 4);
+    if (dst_bytes) H2D(d_dst.p, dst, dst_bytes);
+    rc = fmx_extract_boundary_batch_dev(idx, d_a.as<int32_t>(), n, boundary, mode, d_dst.as<uint16_t>(), dst_len, offset,
+                                        d_len.as<int32_t>(), d_lf.as<int32_t>(), d_st.as<int32_t>(),
+                                        d_aux.as<int32_t>(), nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (dst_bytes) D2H(dst, d_dst.p, dst_bytes);
+    D2H(out_len, d_len.p, (size_t)n * 4);
+    if (lf_steps) D2H(lf_steps, d_lf.p, (size_t)n * 4);
+    if (status) D2H(status, d_st.p, (size_t)n * 4);
+    if (aux) D2H(aux, d_aux.p, (size_t)n * 4);
+    return FMX_OK;
+}
+
+// ---- helpers ---------------------------------------------------------------------------------------
+
+// FM:239-298 (Java `byte` is signed: the masks below restate the reference's expressions)
+int fmx_convert_byte_pattern(const uint8_t *pattern, int32_t offset, int32_t length, uint16_t *dest,
+                             int32_t *bad_value) {
+    int pos = offset, i = 0;
+    while (pos < length + offset) {
+        const int first = (int8_t)pattern[pos];
+        uint16_t next;
+        if (first < 0) {
+            if ((((uint32_t)(first & 0xF0)) >> 3) == 30) {  // 4-byte form, FM:248-267
+                const int b2 = (int8_t)pattern[pos + 1], b3 = (int8_t)pattern[pos + 2], b4 = (int8_t)pattern[pos + 3];
+                pos += 4;
+                const int before = (((first & 0x07) << 18) | ((b2 & 0x3F) << 12) | ((b3 & 0x3F) << 6) | (b4 & 0x3F)) & 0x1FFFFF;
+                if (before > 32767) {
+                    if (bad_value) *bad_value = before;
+                    return -1;
+                }
+                next = (uint16_t)before;
+            } else if ((((uint32_t)(first & 0xE0)) >> 4) == 14) {  // 3-byte form, FM:269-279
+                const int b2 = (int8_t)pattern[pos + 1], b3 = (int8_t)pattern[pos + 2];
+                pos += 3;
+                next = (uint16_t)((((first & 0x0F) << 12) | ((b2 & 0x3F) << 6) | (b3 & 0x3F)) & 0xFFFF);
+            } else {  // 2-byte form, FM:280-288
+                const int b2 = (int8_t)pattern[pos + 1];
+                pos += 2;
+                next = (uint16_t)((((first & 0x1F) << 6) | (b2 & 0x3F)) & 0x7FF);
+            }
+        } else {
+            ++pos;
+            next = (uint16_t)first;
+        }
+        dest[i++] = next;
+    }
+    return i;
+}
+
+const char *fmx_status_message(int status) {
+    switch (status) {
+        case FMX_ST_OK: return "";
+        case FMX_ST_NOT_ENABLED: return "Text recovery not enabled at build time";
+        case FMX_ST_POS_NEGATIVE: return "Requested position less than 0";
+        case FMX_ST_STOP_TOO_LONG: return "Stop position longer than index string";
+        case FMX_ST_DEST_TOO_SMALL: return "Supplied destination is not large enough";
+        case FMX_ST_POS_TOO_LONG: return "Requested position longer than index string";
+        case FMX_ST_DEST_SIZE_ZERO: return "Supplied destination for extraction has size zero";
+        case FMX_ST_NO_BOUNDARY: return "Boundary does not exist";
+        case FMX_ST_DOES_NOT_FIT: return "Extraction does not fit in the supplied destination. Currently extracted: %d";
+        case FMX_ST_JAVA_AIOOBE: return "ArrayIndexOutOfBoundsException";
+        default: return "unknown status";
+    }
+}
+
+int fmx_status_kind(int status) {
+    if (status == FMX_ST_DEST_SIZE_ZERO || status == FMX_ST_NO_BOUNDARY) return 1;
+    if (status == FMX_ST_JAVA_AIOOBE) return 2;
+    return 0;
+}
+
+}  // extern "C"

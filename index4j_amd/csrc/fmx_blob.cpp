@@ -1,0 +1,183 @@
+// fmx_blob.cpp — flatten the host model into the HBM image described in fmx_blob.hpp.
+#include "fmx_blob.hpp"
+#include "fmx_model.hpp"
+
+#include <cstring>
+
+namespace fmx {
+namespace {
+
+struct Arena {
+    std::vector<uint8_t> &b;
+    // reserve `bytes` at a 64-byte boundary, zero-filled; returns the byte offset
+    size_t alloc(size_t bytes) {
+        size_t off = (b.size() + 63) & ~(size_t)63;
+        b.resize(off + bytes, 0);
+        return off;
+    }
+    template <typename T>
+    T *at(size_t off) {
+        return reinterpret_cast<T *>(b.data() + off);
+    }
+};
+
+inline uint32_t off8(size_t byte_off) { return (uint32_t)(byte_off >> 3); }
+
+// RRR:92-103 -> array of sample records + offsets bit stream
+bool flatten_rrr(Arena &A, const RrrModel &r, RrrDesc &d, std::string &err) {
+    const int s = r.sample_size;
+    if (s <= 0 || r.classes.width != 4) {
+        err = "unsupported RRR parameters";
+        return false;
+    }
+    const int64_t n_blocks = r.classes.length;
+    const int64_t n_rec = n_blocks / s + 1;  // == lengthOfSampledOffsets.length (RRR:263)
+    if (r.sampled_offsets.length < n_rec || r.prefix_sums.length < n_rec) {
+        err = "RRR sample vectors shorter than expected";
+        return false;
+    }
+    d.rec_shift = rrr_rec_shift(s);
+    d.n_rec = (int32_t)n_rec;
+    d.n_blocks = (int32_t)n_blocks;
+    d.length = r.length;
+    d.total_ones = r.total_ones;
+    d.sample = s;
+    const size_t stride = (size_t)1 << d.rec_shift;
+    const size_t rec_off = A.alloc((size_t)n_rec * stride + 64);
+    d.off_rec = off8(rec_off);
+    for (int64_t k = 0; k < n_rec; ++k) {
+        uint8_t *rec = A.at<uint8_t>(rec_off + (size_t)k * stride);
+        const uint32_t prefix = (uint32_t)r.prefix_sums.get_bits(k * r.prefix_sums.width, r.prefix_sums.width);
+        const uint32_t ptr = (uint32_t)r.sampled_offsets.get_bits(k * r.sampled_offsets.width, r.bits_per_offset_pos);
+        memcpy(rec, &prefix, 4);
+        memcpy(rec + 4, &ptr, 4);
+        uint64_t *cls = reinterpret_cast<uint64_t *>(rec + 8);
+        const int64_t first = k * s;
+        for (int64_t j = 0; j < s && first + j < n_blocks; ++j)
+            cls[j >> 4] |= r.classes.get(first + j) << (4 * (j & 15));
+    }
+    const size_t bits_off = A.alloc((r.offsets.size() + 2) * 8);
+    d.off_bits = off8(bits_off);
+    if (!r.offsets.empty()) memcpy(A.at<uint8_t>(bits_off), r.offsets.data(), r.offsets.size() * 8);
+    return true;
+}
+
+size_t put_packed(Arena &A, const PackedVec &v) {
+    const size_t off = A.alloc((v.words.size() + 2) * 8);
+    if (!v.words.empty()) memcpy(A.at<uint8_t>(off), v.words.data(), v.words.size() * 8);
+    return off;
+}
+
+}  // namespace
+
+int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err) {
+    const WfbbModel &w = m.wt;
+    const int sigma = w.alphabet_size;
+    const int64_t n_sb = (int64_t)w.sb.size();
+    if (sigma <= 0 || (int64_t)w.hyper_rank.size() != sigma || w.size != m.length ||
+        (int64_t)w.super_rank.size() != n_sb * sigma || (int64_t)w.global_mapping.size() != n_sb * sigma ||
+        (int64_t)w.count.size() != sigma || n_sb != (w.size + (1 << 20) - 1) / (1 << 20)) {
+        err = "wavelet tree shape not supported (expects one 2^32 hyperblock, size == length)";
+        return -8;
+    }
+    if (m.bw_suffixes > 32 || m.bw_positions > 32 || m.C.empty()) {
+        err = "unsupported bit widths";
+        return -8;
+    }
+    blob.clear();
+    Arena A{blob};
+    const size_t hdr_off = A.alloc(sizeof(BlobHeader));
+    BlobHeader h;
+    memset(&h, 0, sizeof h);
+    h.magic = kBlobMagic;
+    h.version = kBlobVersion;
+    h.sample_rate = m.sample_rate;
+    h.enable_extract = m.enable_extract ? 1 : 0;
+    h.length = m.length;
+    h.n_keys = (int32_t)m.map_keys.size();
+    h.bw_suffixes = m.bw_suffixes;
+    h.bw_positions = m.bw_positions;
+    h.n_c = (int32_t)m.C.size();
+    h.n_look = (int32_t)m.look_up.size();
+    h.wt_sigma = sigma;
+    h.n_sb = (int32_t)n_sb;
+    h.n_suffixes = m.suffixes.length;
+    h.n_positions = m.enable_extract ? m.positions.length : 0;
+    h.wt_size = w.size;
+
+    size_t off = A.alloc(m.C.size() * 4 + 8);
+    h.off_c = off8(off);
+    memcpy(A.at<uint8_t>(off), m.C.data(), m.C.size() * 4);
+    off = A.alloc(m.look_up.size() * 4 + 8);
+    h.off_lookup = off8(off);
+    memcpy(A.at<uint8_t>(off), m.look_up.data(), m.look_up.size() * 4);
+    off = A.alloc(65536 * 2);
+    h.off_char2code = off8(off);
+    for (size_t i = 0; i < m.map_keys.size(); ++i)
+        if (m.map_keys[i] >= 0 && m.map_keys[i] < 65536) A.at<int16_t>(off)[m.map_keys[i]] = m.map_vals[i];
+    h.off_suffixes = off8(put_packed(A, m.suffixes));
+    h.off_positions = m.enable_extract ? off8(put_packed(A, m.positions)) : 0;
+    if (!flatten_rrr(A, m.sampled, h.sampled, err)) return -8;
+
+    off = A.alloc(65536);
+    h.off_inv = off8(off);
+    memcpy(A.at<uint8_t>(off), rrr_value_of_offset(), 65536);
+
+    // fused (rank, superblock code) table; row n_sb = total counts (WFBB:1063-1069)
+    off = A.alloc((size_t)(n_sb + 1) * sigma * sizeof(SbcEntry));
+    h.off_sbc = off8(off);
+    for (int64_t s = 0; s <= n_sb; ++s)
+        for (int c = 0; c < sigma; ++c) {
+            SbcEntry e;
+            if (s < n_sb) {
+                e.rank = (int32_t)(w.hyper_rank[(size_t)c] + w.super_rank[(size_t)(s * sigma + c)]);
+                e.sbc = w.global_mapping[(size_t)(s * sigma + c)];
+            } else {
+                e.rank = (int32_t)w.count[(size_t)c];
+                e.sbc = (int16_t)(sigma - 1);
+            }
+            e.pad = 0;
+            A.at<SbcEntry>(off)[s * sigma + c] = e;
+        }
+
+    const size_t sbd_off = A.alloc((size_t)n_sb * sizeof(SbDesc));
+    h.off_sbdesc = off8(sbd_off);
+    for (int64_t s = 0; s < n_sb; ++s) {
+        const SuperBlockModel &sb = w.sb[(size_t)s];
+        SbDesc d;
+        memset(&d, 0, sizeof d);
+        d.sigma = sb.sigma;
+        d.bsl = sb.block_size_log;
+        d.n_blocks = (int32_t)sb.block_headers.size();
+        if (d.bsl < 0 || d.bsl > 20 || (int64_t)sb.mapping.size() != ((int64_t)sb.sigma + 1) << (20 - d.bsl)) {
+            err = "superblock mapping shape mismatch";
+            return -3;
+        }
+        off = A.alloc(sb.mapping.size() * 2 + 8);
+        d.off_mapping = off8(off);
+        d.mapping_len = (int32_t)sb.mapping.size();
+        if (!sb.mapping.empty()) memcpy(A.at<uint8_t>(off), sb.mapping.data(), sb.mapping.size() * 2);
+        off = A.alloc(sb.block_headers.size() * sizeof(BlockHdr) + 16);
+        d.off_bh = off8(off);
+        static_assert(sizeof(BlockHeader) == sizeof(BlockHdr), "block header layout");
+        if (!sb.block_headers.empty())
+            memcpy(A.at<uint8_t>(off), sb.block_headers.data(), sb.block_headers.size() * sizeof(BlockHdr));
+        // 16 guard bytes behind the array: 24-bit fields are fetched as one 32-bit load
+        off = A.alloc(sb.var.size() + 16);
+        d.off_var = off8(off);
+        d.var_len = (int32_t)sb.var.size();
+        if (!sb.var.empty()) memcpy(A.at<uint8_t>(off), sb.var.data(), sb.var.size());
+        if (!flatten_rrr(A, sb.rank_support, d.rrr, err)) return -8;
+        *A.at<SbDesc>(sbd_off + (size_t)s * sizeof(SbDesc)) = d;
+    }
+    A.alloc(64);  // tail guard
+    h.total_bytes = blob.size();
+    if (blob.size() >= ((uint64_t)1 << 35)) {
+        err = "blob exceeds 32 GiB";
+        return -8;
+    }
+    *A.at<BlobHeader>(hdr_off) = h;
+    return 0;
+}
+
+}  // namespace fmx

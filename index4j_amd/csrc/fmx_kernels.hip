@@ -1,0 +1,200 @@
+// fmx_kernels.hip — HIP kernels for gfx950 (MI355X) and their launchers.
+//
+//   k_count            FmIndex.count            FM:455-474   two lanes per pattern (start / end of the SA interval)
+//   k_locate_walk      FmIndex.locate           FM:526-548   one lane per (pattern, hit): LF-walk to a sampled row
+//   k_extract          FmIndex.extract          FM:564-608   one lane per query
+//   k_extract_boundary extractUntilBoundary{,Left,Right} FM:640-922  one lane per query
+//
+// Every workgroup stages the 64 KiB RRR value-of-offset table (RRR:106) into LDS once and then
+// grid-strides over queries.  The work is bit-level integer gather (no MFMA): throughput comes from
+// tens of thousands of independent dependent-load chains in flight, the two lanes of a pattern
+// sharing their sectors (start and end of an interval usually fall in the same blocks).
+#include <hip/hip_runtime.h>
+
+#include "fmx_device.hpp"
+
+namespace fmx {
+
+constexpr int kBlock = 1024;  // threads per workgroup: 64 KiB of LDS is shared by 16 waves
+
+__device__ __forceinline__ void stage_inverse_table(uint16_t *s_inv, const uint16_t *g_inv) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(g_inv);
+    uint4 *dst = reinterpret_cast<uint4 *>(s_inv);
+    for (int i = threadIdx.x; i < 65536 / 16; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
+// FM:455-474 (also the first half of locate, FM:506-523).  Lane 2p computes `start`, lane 2p+1
+// computes `end`; they swap results with one DPP-class shuffle per pattern character.
+// range_out (nullable): 2 ints per pattern {start, end} for k_locate_walk.
+__global__ __launch_bounds__(kBlock) void k_count(DevIndex ix, const uint16_t *__restrict__ pat,
+                                                  const int32_t *__restrict__ pat_off, int32_t n,
+                                                  int32_t *__restrict__ counts, int32_t *__restrict__ lf_steps,
+                                                  int32_t *__restrict__ status_out, int32_t *__restrict__ range_out) {
+    __shared__ uint16_t s_inv[32768];
+    stage_inverse_table(s_inv, ix.inv_global);
+    const int role = threadIdx.x & 1;
+    const int64_t pairs_per_grid = (int64_t)gridDim.x * (kBlock / 2);
+    for (int64_t p = (int64_t)blockIdx.x * (kBlock / 2) + (threadIdx.x >> 1); p < n; p += pairs_per_grid) {
+        const int32_t beg = pat_off[p];
+        const int32_t m = pat_off[p + 1] - beg;
+        int status = ST_OK;
+        int32_t start = 0, end = 0, steps = 0;
+        if (m <= 0) {
+            status = ST_JAVA_AIOOBE;  // pattern[-1], FM:456-457
+        } else {
+            int32_t i = m - 1;
+            int32_t c = fm_map(ix, pat[beg + i]);
+            if (c != 0) {  // FM:458-460
+                start = ix.C[c];
+                end = ix.C[c + 1];
+                while (start < end && i >= 1) {  // FM:464
+                    c = fm_map(ix, pat[beg + --i]);
+                    if (c == 0) {  // FM:466-468
+                        start = end = 0;
+                        break;
+                    }
+                    const int32_t mine = ix.C[c] + wt_rank(ix, s_inv, (uint32_t)(role ? end : start), c, status);
+                    const int32_t other = __shfl_xor(mine, 1);
+                    start = role ? other : mine;  // FM:469
+                    end = role ? mine : other;    // FM:470
+                    steps += 2;
+                }
+            }
+        }
+        status |= __shfl_xor(status, 1);
+        if (role == 0) {
+            const int32_t d = end - start;
+            counts[p] = d > 0 ? d : 0;  // FM:473
+            if (lf_steps) lf_steps[p] = steps;
+            if (status_out) status_out[p] = status;
+            if (range_out) {
+                range_out[2 * p] = start;
+                range_out[2 * p + 1] = end;
+            }
+        }
+    }
+}
+
+// FM:526-548: hit k of pattern p is SA row i = start + 1 + k; walk LF until a sampled row.
+__global__ __launch_bounds__(kBlock) void k_locate_walk(DevIndex ix, const int32_t *__restrict__ range, int32_t n,
+                                                        int32_t max_matches, int32_t *__restrict__ locs,
+                                                        int32_t loc_cap, int32_t slots, int32_t *__restrict__ found,
+                                                        int32_t *__restrict__ lf_steps,
+                                                        int32_t *__restrict__ status_out) {
+    __shared__ uint16_t s_inv[32768];
+    stage_inverse_table(s_inv, ix.inv_global);
+    const int64_t total = (int64_t)n * slots;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
+        const int32_t p = (int32_t)(t / slots);
+        const int32_t k = (int32_t)(t - (int64_t)p * slots);
+        const int32_t start = range[2 * p], end = range[2 * p + 1];
+        const int32_t hits = start < end ? end - start : 0;
+        // the reference stops at maxMatches (FM:544-546) and overruns `locations` beyond its length (Java AIOOBE)
+        const int32_t wanted = (max_matches > 0 && hits > max_matches) ? max_matches : hits;
+        const int32_t located = wanted < loc_cap ? wanted : loc_cap;
+        if (k == 0) {
+            found[p] = located;
+            if (wanted > loc_cap && status_out) atomicOr(&status_out[p], ST_JAVA_AIOOBE);
+        }
+        if (k >= located) continue;
+        int status = ST_OK;
+        int32_t distance;
+        locs[(int64_t)p * loc_cap + k] = fm_locate_hit(ix, s_inv, start, k, distance, status);
+        if (lf_steps && distance) atomicAdd(&lf_steps[p], distance);
+        if (status && status_out) atomicOr(&status_out[p], status);
+    }
+}
+
+// FM:564-608
+__global__ __launch_bounds__(kBlock) void k_extract(DevIndex ix, const int32_t *__restrict__ starts,
+                                                    const int32_t *__restrict__ stops, int32_t n,
+                                                    uint16_t *__restrict__ dst, int32_t dst_len, int32_t offset,
+                                                    int32_t *__restrict__ out_len, int32_t *__restrict__ lf_steps,
+                                                    int32_t *__restrict__ status_out) {
+    __shared__ uint16_t s_inv[32768];
+    stage_inverse_table(s_inv, ix.inv_global);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) {
+        int status = ST_OK;
+        int32_t steps;
+        const int32_t ret =
+            fm_extract(ix, s_inv, starts[q], stops[q], dst + q * (int64_t)dst_len, dst_len, offset, steps, status);
+        out_len[q] = status ? 0 : ret;
+        if (lf_steps) lf_steps[q] = steps;
+        if (status_out) status_out[q] = status;
+    }
+}
+
+// FM:640-759 (mode 0), FM:772-831 (mode 1), FM:844-922 (mode 2)
+__global__ __launch_bounds__(kBlock) void k_extract_boundary(DevIndex ix, const int32_t *__restrict__ froms,
+                                                             int32_t n, uint16_t boundary, int mode,
+                                                             uint16_t *__restrict__ dst, int32_t dst_len,
+                                                             int32_t offset, int32_t *__restrict__ out_len,
+                                                             int32_t *__restrict__ lf_steps,
+                                                             int32_t *__restrict__ status_out,
+                                                             int32_t *__restrict__ aux_out) {
+    __shared__ uint16_t s_inv[32768];
+    stage_inverse_table(s_inv, ix.inv_global);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int32_t mapped_boundary = fm_map(ix, boundary);  // FM:658
+    for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) {
+        int status = ST_OK;
+        int32_t steps, aux;
+        const int32_t ret = fm_extract_boundary(ix, s_inv, mode, froms[q], mapped_boundary, dst + q * (int64_t)dst_len,
+                                                dst_len, offset, steps, status, aux);
+        out_len[q] = status ? 0 : ret;
+        if (lf_steps) lf_steps[q] = steps;
+        if (status_out) status_out[q] = status;
+        if (aux_out) aux_out[q] = aux;
+    }
+}
+
+// ---- launchers (called from fmx_api.cpp) -----------------------------------------------------
+
+static int grid_for(int64_t lanes, int n_cu) {
+    int64_t blocks = (lanes + kBlock - 1) / kBlock;
+    const int64_t cap = (int64_t)n_cu * 8;  // a few waves of workgroups per CU, grid-stride the rest
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_t *off, int32_t n, int32_t *counts,
+                 int32_t *lf, int32_t *status, int32_t *range, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_count, dim3(grid_for(2 * (int64_t)n, n_cu)), dim3(kBlock), 0, st, ix, pat, off, n, counts, lf,
+                       status, range);
+    return (int)hipGetLastError();
+}
+
+int launch_locate_walk(const DevIndex &ix, int n_cu, const int32_t *range, int32_t n, int32_t max_matches,
+                       int32_t *locs, int32_t loc_cap, int32_t *found, int32_t *lf, int32_t *status,
+                       hipStream_t st) {
+    if (n <= 0) return 0;
+    int32_t slots = (max_matches > 0 && max_matches < loc_cap) ? max_matches : loc_cap;
+    if (slots < 1) slots = 1;
+    hipLaunchKernelGGL(k_locate_walk, dim3(grid_for((int64_t)n * slots, n_cu)), dim3(kBlock), 0, st, ix, range, n,
+                       max_matches, locs, loc_cap, slots, found, lf, status);
+    return (int)hipGetLastError();
+}
+
+int launch_extract(const DevIndex &ix, int n_cu, const int32_t *start, const int32_t *stop, int32_t n, uint16_t *dst,
+                   int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf, int32_t *status, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_extract, dim3(grid_for(n, n_cu)), dim3(kBlock), 0, st, ix, start, stop, n, dst, dst_len,
+                       offset, out_len, lf, status);
+    return (int)hipGetLastError();
+}
+
+int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, int32_t n, uint16_t boundary, int mode,
+                            uint16_t *dst, int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf,
+                            int32_t *status, int32_t *aux, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_extract_boundary, dim3(grid_for(n, n_cu)), dim3(kBlock), 0, st, ix, from, n, boundary, mode,
+                       dst, dst_len, offset, out_len, lf, status, aux);
+    return (int)hipGetLastError();
+}
+
+}  // namespace fmx

@@ -1,0 +1,290 @@
+"""Host-side mirror of index4j's public API for the backward-search path, over the C ABI.
+
+``FmIndexBuilder`` mirrors fm/FmIndexBuilder.java:21-62 and ``FmIndex`` mirrors the query surface of
+fm/FmIndex.java:443-941 (same method names, argument meaning and exceptions, with Java's
+RuntimeException -> RuntimeError, IllegalArgumentException -> ValueError,
+ArrayIndexOutOfBoundsException -> IndexError, IOException -> IOError).  Scalar calls are batches of
+one; the ``*_batch`` methods are what a service would use.  All queries run on the GPU through
+libfmx.so — there is no CPU query path.
+
+In production the host language is Java (see INTEGRATION.md and bindings/java); this module is the
+same binding written in Python for the test-suite and the benchmark.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+_EXC = {0: RuntimeError, 1: ValueError, 2: IndexError}
+
+
+def as_chars(text):
+    """str / array -> contiguous uint16 array of UTF-16 code units (a Java char[])."""
+    if isinstance(text, str):
+        return np.frombuffer(text.encode("utf-16-le"), dtype=np.uint16).copy()
+    if isinstance(text, (bytes, bytearray)):
+        raise TypeError("pass str or a uint16 array; use FmIndex.convertBytePatternToCharPattern for UTF-8 bytes")
+    return np.ascontiguousarray(text, dtype=np.uint16)
+
+
+def chars_to_str(arr):
+    return np.ascontiguousarray(arr, dtype=np.uint16).tobytes().decode("utf-16-le", errors="surrogatepass")
+
+
+def raise_for_status(status, aux=0):
+    """Re-throw the reference's exception for a per-query status code (same type, same message)."""
+    if status == _lib.ST_OK:
+        return
+    msg = lib.fmx_status_message(int(status)).decode()
+    if "%d" in msg:
+        msg = msg % aux
+    raise _EXC[lib.fmx_status_kind(int(status))](msg)
+
+
+def pack_patterns(patterns):
+    """list of str / uint16 arrays -> (chars, offsets) in the layout fmx_count_batch takes."""
+    arrs = [as_chars(p) for p in patterns]
+    off = np.zeros(len(arrs) + 1, dtype=np.int32)
+    if arrs:
+        np.cumsum([len(a) for a in arrs], out=off[1:])
+    chars = np.concatenate(arrs) if arrs else np.zeros(0, dtype=np.uint16)
+    return np.ascontiguousarray(chars, dtype=np.uint16), off
+
+
+class FmIndexBuilder:
+    """fm/FmIndexBuilder.java: defaults sampleRate=32, enableExtraction=true (FMB:21-22)."""
+
+    def __init__(self):
+        self._sample_rate = 32
+        self._enable_extraction = True
+
+    def setSampleRate(self, sample_rate):  # FMB:34-37
+        self._sample_rate = int(sample_rate)
+        return self
+
+    def setEnableExtraction(self, enable):  # FMB:46-49
+        self._enable_extraction = bool(enable)
+        return self
+
+    def build(self, text, device=0):  # FMB:59-61
+        return FmIndex(text, self._sample_rate, self._enable_extraction, device=device)
+
+
+class FmIndex:
+    """fm/FmIndex.java query surface.  `device=None` keeps the index on the host (build / save /
+    load only); any query then fails loudly."""
+
+    def __init__(self, text=None, sampleRate=32, enableExtract=True, device=0, _handle=None):
+        self._h = None
+        if _handle is not None:
+            self._h = _handle
+        else:
+            a = as_chars(text)
+            h = C.c_void_p()
+            check(lib.fmx_build(a.ctypes.data, len(a), int(sampleRate), int(bool(enableExtract)), C.byref(h)), "fmx_build")
+            self._h = h
+        if device is not None:
+            self.to_device(device)
+
+    # ---- persistence (FM:948-1025 through SER:67-100) ----
+    @classmethod
+    def read(cls, data, device=0):
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        h = C.c_void_p()
+        check(lib.fmx_load(buf.ctypes.data, len(buf), C.byref(h)), "fmx_load")
+        return cls(device=device, _handle=h)
+
+    def write(self, framed=True):
+        buf, n = C.c_void_p(), C.c_size_t()
+        check(lib.fmx_save(self._h, int(framed), C.byref(buf), C.byref(n)), "fmx_save")
+        try:
+            return C.string_at(buf.value, n.value)
+        finally:
+            lib.fmx_free_buffer(buf)
+
+    @classmethod
+    def attach_device_blob(cls, device_ptr, nbytes, device):
+        """adopt a blob already in HBM (e.g. received through an RCCL broadcast)"""
+        h = C.c_void_p()
+        check(lib.fmx_attach_device_blob(C.c_void_p(device_ptr), nbytes, device, C.byref(h)), "fmx_attach_device_blob")
+        return cls(device=None, _handle=h)
+
+    def to_device(self, device=0):
+        check(lib.fmx_to_device(self._h, int(device)), "fmx_to_device")
+        return self
+
+    def blob(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        check(lib.fmx_blob(self._h, C.byref(p), C.byref(n)), "fmx_blob")
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,))
+
+    def device_blob(self):
+        n = C.c_size_t()
+        p = lib.fmx_device_blob(self._h, C.byref(n))
+        return p, n.value
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h is not None:
+            lib.fmx_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- convenience (FM:929-941, 1044-1046) ----
+    def getInputLength(self):
+        return lib.fmx_input_length(self._h)
+
+    def getAlphabetLength(self):
+        return lib.fmx_alphabet_length(self._h)
+
+    def __str__(self):
+        return "FMIndex-sampleRate:%d-extract:%s" % (
+            lib.fmx_sample_rate(self._h),
+            "true" if lib.fmx_extract_enabled(self._h) else "false",
+        )
+
+    toString = __str__
+
+    @staticmethod
+    def convertBytePatternToCharPattern(pattern, offset, length, destination):  # FM:239-298
+        src = np.frombuffer(bytes(pattern), dtype=np.uint8)
+        bad = C.c_int32(0)
+        n = lib.fmx_convert_byte_pattern(src.ctypes.data, offset, length, destination.ctypes.data, C.byref(bad))
+        if n < 0:
+            raise RuntimeError("Found a character that exceeds (32767): it was %d" % bad.value)
+        return n
+
+    # ---- batched queries ----
+    def count_batch(self, chars, offsets, want_steps=False):
+        chars = np.ascontiguousarray(chars, dtype=np.uint16)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        n = len(offsets) - 1
+        counts = np.zeros(n, dtype=np.int32)
+        steps = np.zeros(n, dtype=np.int32)
+        status = np.zeros(n, dtype=np.int32)
+        check(lib.fmx_count_batch(self._h, chars.ctypes.data, offsets.ctypes.data, n, counts.ctypes.data,
+                                  steps.ctypes.data, status.ctypes.data), "fmx_count_batch")
+        return (counts, status, steps) if want_steps else (counts, status)
+
+    def locate_batch(self, chars, offsets, max_matches, loc_cap=None, want_steps=False, locs=None):
+        chars = np.ascontiguousarray(chars, dtype=np.uint16)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        n = len(offsets) - 1
+        if loc_cap is None:
+            loc_cap = max_matches
+        if locs is None:
+            locs = np.zeros((n, max(loc_cap, 0)), dtype=np.int32)
+        found = np.zeros(n, dtype=np.int32)
+        steps = np.zeros(n, dtype=np.int32)
+        status = np.zeros(n, dtype=np.int32)
+        check(lib.fmx_locate_batch(self._h, chars.ctypes.data, offsets.ctypes.data, n, int(max_matches),
+                                   locs.ctypes.data, int(loc_cap), found.ctypes.data, steps.ctypes.data,
+                                   status.ctypes.data), "fmx_locate_batch")
+        return (locs, found, status, steps) if want_steps else (locs, found, status)
+
+    def extract_batch(self, starts, stops, dst_len, offset=0, dst=None, want_steps=False):
+        starts = np.ascontiguousarray(starts, dtype=np.int32)
+        stops = np.ascontiguousarray(stops, dtype=np.int32)
+        n = len(starts)
+        if dst is None:
+            dst = np.zeros((n, dst_len), dtype=np.uint16)
+        out_len = np.zeros(n, dtype=np.int32)
+        steps = np.zeros(n, dtype=np.int32)
+        status = np.zeros(n, dtype=np.int32)
+        check(lib.fmx_extract_batch(self._h, starts.ctypes.data, stops.ctypes.data, n, dst.ctypes.data, int(dst_len),
+                                    int(offset), out_len.ctypes.data, steps.ctypes.data, status.ctypes.data),
+              "fmx_extract_batch")
+        return (dst, out_len, status, steps) if want_steps else (dst, out_len, status)
+
+    def extract_boundary_batch(self, froms, boundary, mode, dst_len, offset=0, dst=None, want_steps=False):
+        froms = np.ascontiguousarray(froms, dtype=np.int32)
+        n = len(froms)
+        if dst is None:
+            dst = np.zeros((n, dst_len), dtype=np.uint16)
+        out_len = np.zeros(n, dtype=np.int32)
+        steps = np.zeros(n, dtype=np.int32)
+        status = np.zeros(n, dtype=np.int32)
+        aux = np.zeros(n, dtype=np.int32)
+        b = boundary if isinstance(boundary, (int, np.integer)) else ord(boundary)
+        check(lib.fmx_extract_boundary_batch(self._h, froms.ctypes.data, n, int(b), int(mode), dst.ctypes.data,
+                                             int(dst_len), int(offset), out_len.ctypes.data, steps.ctypes.data,
+                                             status.ctypes.data, aux.ctypes.data), "fmx_extract_boundary_batch")
+        return (dst, out_len, status, aux, steps) if want_steps else (dst, out_len, status, aux)
+
+    # ---- scalar API, as in the reference ----
+    def count(self, pattern, offset=0, length=None):  # FM:443-474
+        p = as_chars(pattern)
+        if length is None:
+            length = len(p)
+        if length <= 0 or offset < 0 or offset + length > len(p):
+            raise IndexError("ArrayIndexOutOfBoundsException")  # pattern[i] out of range, FM:456-457
+        sub = p[offset:offset + length]
+        counts, status = self.count_batch(sub, np.array([0, len(sub)], dtype=np.int32))
+        raise_for_status(status[0])
+        return int(counts[0])
+
+    def locate(self, pattern, locations, offset=0, length=None, maxMatches=-1):  # FM:487-552
+        """`locations` is the caller's int32 array (written in place); returns the number located."""
+        p = as_chars(pattern)
+        if length is None:
+            length = len(p)
+        if length <= 0 or offset < 0 or offset + length > len(p):
+            raise IndexError("ArrayIndexOutOfBoundsException")
+        sub = p[offset:offset + length]
+        cap = len(locations)
+        rows = np.ascontiguousarray(locations, dtype=np.int32).reshape(1, cap)
+        locs, found, status = self.locate_batch(sub, np.array([0, len(sub)], dtype=np.int32), maxMatches, cap, locs=rows)
+        locations[:] = locs[0]
+        raise_for_status(status[0])
+        return int(found[0])
+
+    def extract(self, start, stop, destination, offset=0):  # FM:564-608
+        dst = np.ascontiguousarray(destination, dtype=np.uint16).reshape(1, len(destination))
+        dst, out_len, status = self.extract_batch([start], [stop], len(destination), offset, dst=dst)
+        destination[:] = dst[0]
+        raise_for_status(status[0])
+        return int(out_len[0])
+
+    def _boundary(self, mode, frm, destination, offset, boundary):
+        dst = np.ascontiguousarray(destination, dtype=np.uint16).reshape(1, len(destination))
+        dst, out_len, status, aux = self.extract_boundary_batch([frm], boundary, mode, len(destination), offset, dst=dst)
+        destination[:] = dst[0]
+        raise_for_status(status[0], int(aux[0]))
+        return int(out_len[0])
+
+    def extractUntilBoundary(self, frm, destination, offset, boundary):  # FM:640-759
+        return self._boundary(0, frm, destination, offset, boundary)
+
+    def extractUntilBoundaryLeft(self, frm, destination, offset, boundary):  # FM:772-831
+        return self._boundary(1, frm, destination, offset, boundary)
+
+    def extractUntilBoundaryRight(self, frm, destination, offset, boundary):  # FM:844-922
+        return self._boundary(2, frm, destination, offset, boundary)
+
+
+def synth_log(n, seed=42):
+    """deterministic synthetic ASCII log text of exactly n chars"""
+    out = np.zeros(n, dtype=np.uint16)
+    check(lib.fmx_synth_log(seed, n, out.ctypes.data), "fmx_synth_log")
+    return out
+
+
+def synth_patterns(text, m, count, seed=43):
+    """`count` substrings of length m at SplitMix64(seed) % (n - m); returns (chars, offsets, positions)"""
+    text = np.ascontiguousarray(text, dtype=np.uint16)
+    pat = np.zeros(count * m, dtype=np.uint16)
+    off = np.zeros(count + 1, dtype=np.int32)
+    pos = np.zeros(count, dtype=np.int32)
+    check(lib.fmx_synth_patterns(seed, text.ctypes.data, len(text), m, count, pat.ctypes.data, off.ctypes.data,
+                                 pos.ctypes.data), "fmx_synth_patterns")
+    return pat, off, pos

@@ -1,0 +1,153 @@
+// hostsim.cpp — TEST-ONLY host simulation of the device code.
+//
+// Compiles index4j_amd/csrc/fmx_device.hpp with g++ (its FMX_HD functions become plain inline C++)
+// and runs them over a HOST copy of the blob, one query at a time.  It exists so that the exact
+// source the GPU executes can be checked against the oracle on machines without a GPU (this build
+// container).  It is never linked into libfmx.so and never used by the package: the product has no
+// CPU query path.
+#include "../index4j_amd/csrc/fmx_device.hpp"
+
+#include <cstdint>
+#include <cstring>
+
+using namespace fmx;
+
+static DevIndex make_index(const uint8_t *b) {
+    BlobHeader h;
+    memcpy(&h, b, sizeof h);
+    DevIndex d;
+    auto at = [&](uint32_t off) { return b + ((uint64_t)off << 3); };
+    d.base = b;
+    d.C = reinterpret_cast<const int32_t *>(at(h.off_c));
+    d.look_up = reinterpret_cast<const int32_t *>(at(h.off_lookup));
+    d.char2code = reinterpret_cast<const int16_t *>(at(h.off_char2code));
+    d.suffix_words = reinterpret_cast<const uint32_t *>(at(h.off_suffixes));
+    d.pos_words = reinterpret_cast<const uint32_t *>(at(h.off_positions));
+    d.sbc = reinterpret_cast<const SbcEntry *>(at(h.off_sbc));
+    d.sbd = reinterpret_cast<const SbDesc *>(at(h.off_sbdesc));
+    d.inv_global = reinterpret_cast<const uint16_t *>(at(h.off_inv));
+    d.sampled = h.sampled;
+    d.length = h.length;
+    d.sample_rate = h.sample_rate;
+    d.enable_extract = h.enable_extract;
+    d.wt_sigma = h.wt_sigma;
+    d.n_sb = h.n_sb;
+    d.bw_suffixes = h.bw_suffixes;
+    d.bw_positions = h.bw_positions;
+    d.n_positions = h.n_positions;
+    d.wt_size = (uint32_t)h.wt_size;
+    return d;
+}
+
+extern "C" {
+
+int32_t sim_wt_rank(const uint8_t *blob, uint32_t position, int32_t symbol, int32_t *status) {
+    DevIndex ix = make_index(blob);
+    int st = 0;
+    int32_t r = wt_rank(ix, ix.inv_global, position, symbol, st);
+    *status = st;
+    return r;
+}
+
+int32_t sim_wt_inverse_select(const uint8_t *blob, uint32_t position, int32_t *rank) {
+    DevIndex ix = make_index(blob);
+    return wt_inverse_select(ix, ix.inv_global, position, *rank);
+}
+
+// mirrors k_count with both roles of a pair evaluated in turn
+void sim_count(const uint8_t *blob, const uint16_t *pat, const int32_t *off, int32_t n, int32_t *counts,
+               int32_t *lf, int32_t *status_out, int32_t *range) {
+    DevIndex ix = make_index(blob);
+    for (int32_t p = 0; p < n; ++p) {
+        const int32_t beg = off[p], m = off[p + 1] - beg;
+        int status = ST_OK;
+        int32_t start = 0, end = 0, steps = 0;
+        if (m <= 0) {
+            status = ST_JAVA_AIOOBE;
+        } else {
+            int32_t i = m - 1;
+            int32_t c = fm_map(ix, pat[beg + i]);
+            if (c != 0) {
+                start = ix.C[c];
+                end = ix.C[c + 1];
+                while (start < end && i >= 1) {
+                    c = fm_map(ix, pat[beg + --i]);
+                    if (c == 0) {
+                        start = end = 0;
+                        break;
+                    }
+                    const int32_t s2 = ix.C[c] + wt_rank(ix, ix.inv_global, (uint32_t)start, c, status);
+                    const int32_t e2 = ix.C[c] + wt_rank(ix, ix.inv_global, (uint32_t)end, c, status);
+                    start = s2;
+                    end = e2;
+                    steps += 2;
+                }
+            }
+        }
+        const int32_t d = end - start;
+        counts[p] = d > 0 ? d : 0;
+        if (lf) lf[p] = steps;
+        if (status_out) status_out[p] = status;
+        if (range) {
+            range[2 * p] = start;
+            range[2 * p + 1] = end;
+        }
+    }
+}
+
+// mirrors k_locate_walk
+void sim_locate_walk(const uint8_t *blob, const int32_t *range, int32_t n, int32_t max_matches, int32_t *locs,
+                     int32_t loc_cap, int32_t *found, int32_t *lf, int32_t *status_out) {
+    DevIndex ix = make_index(blob);
+    int32_t slots = (max_matches > 0 && max_matches < loc_cap) ? max_matches : loc_cap;
+    if (slots < 1) slots = 1;
+    for (int32_t p = 0; p < n; ++p)
+        for (int32_t k = 0; k < slots; ++k) {
+            const int32_t start = range[2 * p], end = range[2 * p + 1];
+            const int32_t hits = start < end ? end - start : 0;
+            const int32_t wanted = (max_matches > 0 && hits > max_matches) ? max_matches : hits;
+            const int32_t located = wanted < loc_cap ? wanted : loc_cap;
+            if (k == 0) {
+                found[p] = located;
+                if (wanted > loc_cap && status_out) status_out[p] |= ST_JAVA_AIOOBE;
+            }
+            if (k >= located) continue;
+            int status = ST_OK;
+            int32_t distance;
+            locs[(int64_t)p * loc_cap + k] = fm_locate_hit(ix, ix.inv_global, start, k, distance, status);
+            if (lf) lf[p] += distance;
+            if (status && status_out) status_out[p] |= status;
+        }
+}
+
+void sim_extract(const uint8_t *blob, const int32_t *starts, const int32_t *stops, int32_t n, uint16_t *dst,
+                 int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf, int32_t *status_out) {
+    DevIndex ix = make_index(blob);
+    for (int32_t q = 0; q < n; ++q) {
+        int status = ST_OK;
+        int32_t steps;
+        const int32_t ret = fm_extract(ix, ix.inv_global, starts[q], stops[q], dst + (int64_t)q * dst_len, dst_len,
+                                       offset, steps, status);
+        out_len[q] = status ? 0 : ret;
+        if (lf) lf[q] = steps;
+        if (status_out) status_out[q] = status;
+    }
+}
+
+void sim_extract_boundary(const uint8_t *blob, const int32_t *froms, int32_t n, uint16_t boundary, int mode,
+                          uint16_t *dst, int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf,
+                          int32_t *status_out, int32_t *aux_out) {
+    DevIndex ix = make_index(blob);
+    const int32_t mapped_boundary = fm_map(ix, boundary);
+    for (int32_t q = 0; q < n; ++q) {
+        int status = ST_OK;
+        int32_t steps, aux;
+        const int32_t ret = fm_extract_boundary(ix, ix.inv_global, mode, froms[q], mapped_boundary,
+                                                dst + (int64_t)q * dst_len, dst_len, offset, steps, status, aux);
+        out_len[q] = status ? 0 : ret;
+        if (lf) lf[q] = steps;
+        if (status_out) status_out[q] = status;
+        if (aux_out) aux_out[q] = aux;
+    }
+}
+}

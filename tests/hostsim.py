@@ -1,0 +1,88 @@
+"""ctypes wrapper of tests/libhostsim.so: the device functions of index4j_amd/csrc/fmx_device.hpp compiled
+for the host (test-only; see hostsim.cpp).  Lets the CPU suite check the exact device source against
+the oracle.  Not a product path."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libhostsim.so")
+        srcs = [os.path.join(_HERE, "hostsim.cpp"),
+                os.path.join(_HERE, "..", "index4j_amd", "csrc", "fmx_device.hpp"),
+                os.path.join(_HERE, "..", "index4j_amd", "csrc", "fmx_blob.hpp")]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-o", so, srcs[0]])
+        _LIB = C.CDLL(so)
+        _LIB.sim_wt_rank.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p]
+        _LIB.sim_wt_inverse_select.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    return _LIB
+
+
+class HostSim:
+    """runs the device code over the host blob of an index4j_amd.FmIndex"""
+
+    def __init__(self, fm_index):
+        self.fm = fm_index  # keeps the blob alive
+        self.blob = fm_index.blob()
+        self.p = self.blob.ctypes.data
+
+    def wt_rank(self, pos, sym):
+        st = np.zeros(1, np.int32)
+        return lib().sim_wt_rank(self.p, pos, sym, st.ctypes.data), int(st[0])
+
+    def wt_inverse_select(self, pos):
+        r = np.zeros(1, np.int32)
+        c = lib().sim_wt_inverse_select(self.p, pos, r.ctypes.data)
+        return c, int(r[0])
+
+    def count_batch(self, chars, offsets):
+        chars = np.ascontiguousarray(chars, np.uint16)
+        offsets = np.ascontiguousarray(offsets, np.int32)
+        n = len(offsets) - 1
+        counts, lf, st, rng = (np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(2 * n, np.int32))
+        lib().sim_count(C.c_void_p(self.p), C.c_void_p(chars.ctypes.data), C.c_void_p(offsets.ctypes.data), n,
+                        C.c_void_p(counts.ctypes.data), C.c_void_p(lf.ctypes.data), C.c_void_p(st.ctypes.data),
+                        C.c_void_p(rng.ctypes.data))
+        return counts, st, lf, rng
+
+    def locate_batch(self, chars, offsets, max_matches, loc_cap):
+        counts, st, lf, rng = self.count_batch(chars, offsets)
+        n = len(counts)
+        locs = np.zeros((n, max(loc_cap, 0)), np.int32)
+        found = np.zeros(n, np.int32)
+        lib().sim_locate_walk(C.c_void_p(self.p), C.c_void_p(rng.ctypes.data), n, max_matches,
+                              C.c_void_p(locs.ctypes.data), loc_cap, C.c_void_p(found.ctypes.data),
+                              C.c_void_p(lf.ctypes.data), C.c_void_p(st.ctypes.data))
+        return locs, found, st, lf
+
+    def extract_batch(self, starts, stops, dst_len, offset=0, dst=None):
+        starts = np.ascontiguousarray(starts, np.int32)
+        stops = np.ascontiguousarray(stops, np.int32)
+        n = len(starts)
+        if dst is None:
+            dst = np.zeros((n, dst_len), np.uint16)
+        out_len, lf, st = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        lib().sim_extract(C.c_void_p(self.p), C.c_void_p(starts.ctypes.data), C.c_void_p(stops.ctypes.data), n,
+                          C.c_void_p(dst.ctypes.data), dst_len, offset, C.c_void_p(out_len.ctypes.data),
+                          C.c_void_p(lf.ctypes.data), C.c_void_p(st.ctypes.data))
+        return dst, out_len, st, lf
+
+    def extract_boundary_batch(self, froms, boundary, mode, dst_len, offset=0, dst=None):
+        froms = np.ascontiguousarray(froms, np.int32)
+        n = len(froms)
+        if dst is None:
+            dst = np.zeros((n, dst_len), np.uint16)
+        out_len, lf, st, aux = (np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32))
+        b = boundary if isinstance(boundary, (int, np.integer)) else ord(boundary)
+        lib().sim_extract_boundary(C.c_void_p(self.p), C.c_void_p(froms.ctypes.data), n, C.c_uint16(b), mode,
+                                   C.c_void_p(dst.ctypes.data), dst_len, offset, C.c_void_p(out_len.ctypes.data),
+                                   C.c_void_p(lf.ctypes.data), C.c_void_p(st.ctypes.data), C.c_void_p(aux.ctypes.data))
+        return dst, out_len, st, aux, lf

@@ -1,0 +1,61 @@
+"""The C-ABI library loads, exports every symbol include/fmx.h declares, and refuses to answer queries
+without a GPU (no CPU fallback) — CPU only, no compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+import index4j_amd as ia
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "fmx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fmx_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported():
+    decl = declared_symbols()
+    assert len(decl) >= 25
+    raw = C.CDLL(ia.LIB_PATH)
+    for name in decl:
+        assert hasattr(raw, name), "libfmx.so does not export %s" % name
+    assert sorted(ia.SYMBOLS) == decl, "index4j_amd/_lib.py SYMBOLS out of sync with include/fmx.h"
+
+
+def test_status_messages_are_the_reference_strings():
+    """FM:566-576, 591-593, 619-625, 659-661, 732-737"""
+    exp = {1: "Text recovery not enabled at build time", 2: "Requested position less than 0",
+           3: "Stop position longer than index string", 4: "Supplied destination is not large enough",
+           5: "Requested position longer than index string", 6: "Supplied destination for extraction has size zero",
+           7: "Boundary does not exist",
+           8: "Extraction does not fit in the supplied destination. Currently extracted: %d"}
+    for k, v in exp.items():
+        assert ia.lib.fmx_status_message(k).decode() == v
+    assert [ia.lib.fmx_status_kind(k) for k in (1, 6, 7, 8, 9)] == [0, 1, 1, 0, 2]
+    for st, exc in ((1, RuntimeError), (6, ValueError), (7, ValueError), (9, IndexError)):
+        try:
+            ia.raise_for_status(st)
+            assert False
+        except exc:
+            pass
+
+
+def test_queries_fail_loudly_without_a_device():
+    f = ia.FmIndex("some text to index", 4, True, device=None)
+    pat, off = ia.pack_patterns(["text"])
+    try:
+        f.count_batch(pat, off)
+        raise AssertionError("a query ran without a device-resident index")
+    except ia.FmxError as e:
+        assert e.code == -5  # FMX_E_NO_DEVICE
+
+
+def test_blob_header_is_self_describing():
+    f = ia.FmIndex("abracadabra", 2, True, device=None)
+    b = f.blob()
+    assert bytes(b[:4]) == b"FMX1" and int(np.frombuffer(bytes(b[8:16]), np.uint64)[0]) == len(b)
+    assert len(b) % 64 == 0

@@ -1,0 +1,202 @@
+"""Parity tests proper: the HIP kernels, called through the C ABI (libfmx.so), against the oracle, the
+committed fixture, brute force, and — at BASELINE.json's sizes — size-independent properties.
+Run with `-m gpu` on an MI355X."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import index4j_amd as ia
+import orc
+from common import JavaRandom, hdfs_text, occurrences, until_boundary, until_boundary_left, until_boundary_right
+from parity_checks import GpuEngine, check_all
+
+pytestmark = pytest.mark.gpu
+HD = hdfs_text()
+
+
+def make_gpu(text, sr):
+    return GpuEngine(text, sr)
+
+
+def test_native_library_is_the_one_answering():
+    assert ia.lib.fmx_device_count() >= 1
+    assert os.path.basename(ia.LIB_PATH) == "libfmx.so" and os.path.exists(ia.LIB_PATH)
+    f = ia.FmIndex("abracadabra", 2, True, device=0)
+    p, n = f.device_blob()
+    assert p and n == len(f.blob())
+    assert f.count("abra") == 2
+
+
+@pytest.mark.parametrize("sr", [1, 3, 4, 32, 64, 128])
+def test_fixture_all_queries_vs_oracle(sr):
+    check_all(make_gpu, HD, sr, random.Random(sr))
+
+
+def test_embedded_sentinels_and_small_texts():
+    rnd = random.Random(11)
+    mod = list(HD[:40_000])
+    for _ in range(300):
+        mod[rnd.randrange(len(mod) - 2)] = "\0"
+    check_all(make_gpu, "".join(mod), 8, rnd, n_q=60)
+    check_all(make_gpu, "What a string!\nNow this is long, indeed\nBut others could be longer.", 2, rnd, n_q=40)
+    check_all(make_gpu, "a", 1, rnd, n_q=5)
+
+
+def test_config1_count_1000_patterns_on_1mib_log():
+    """BASELINE.json configs[0]: GPU == oracle == brute force, LF-step accounting identical"""
+    t = ia.synth_log(1 << 20)
+    fm = ia.FmIndexBuilder().setSampleRate(32).build(t, device=0)
+    o = orc.OracleFmIndex(t, 32, True)
+    assert fm.write() == o.write()
+    pat, off, pos = ia.synth_patterns(t, 8, 1000)
+    cnt, st, lf = fm.count_batch(pat, off, want_steps=True)
+    orc.counters_reset()
+    oc, ost = o.count_batch(pat, off)
+    assert (cnt == oc).all() and (st == 0).all() and int(lf.sum()) == orc.counters()["lf_steps"]
+    s = bytes(t.astype(np.uint8))
+    for i in range(0, 1000, 10):
+        assert cnt[i] == len(occurrences(s, s[pos[i]:pos[i] + 8]))
+
+
+def test_scalar_api_reads_like_the_reference_tests():
+    """FmIndexTest shouldCount / shouldLocateMaxNumberOfMatches / shouldExtractTwoFirstLogLines /
+    shouldAttemptExtraction... (T-FM:43-102, 195-200, 284-348, 402-496) against the GPU engine"""
+    text = "This is a long string\0"
+    fmi = ia.FmIndexBuilder().setEnableExtraction(False).build(text)
+    assert fmi.count("is") == 2
+    assert fmi.count("is a long", 0, 2) == 2 and fmi.count("is a long", 2, 1) == 4
+    assert fmi.count("baaa") == 0 and fmi.locate("baaa", np.zeros(1, np.int32)) == 0
+    with pytest.raises(RuntimeError, match="Text recovery not enabled at build time"):
+        fmi.extract(5, 10, np.zeros(50, np.uint16), 0)
+    fmi = ia.FmIndex("This \0is a \0long string\0", 4)
+    assert fmi.count("is") == 2 and fmi.count("\0") == 3
+    fmi = ia.FmIndexBuilder().build(HD)
+    assert fmi.getInputLength() == len(HD) + 1 and fmi.getAlphabetLength() == len(set(HD)) + 1
+    assert fmi.toString() == "FMIndex-sampleRate:32-extract:true"
+    assert fmi.locate("INFO", np.zeros(100, np.int32), 0, 4, 100) == 100
+    with pytest.raises(RuntimeError, match="Requested position less than 0"):
+        fmi.extract(-5, 100, np.zeros(50, np.uint16), 0)
+    with pytest.raises(RuntimeError, match="Stop position longer than index string"):
+        fmi.extract(len(HD) + 1, len(HD) + 51, np.zeros(50, np.uint16), 0)
+    with pytest.raises(RuntimeError, match="Supplied destination is not large enough"):
+        fmi.extract(50, 100, np.zeros(10, np.uint16), 0)
+    with pytest.raises(RuntimeError, match="Requested position longer than index string"):
+        fmi.extractUntilBoundary(len(HD) + 1, np.zeros(50, np.uint16), 0, "\n")
+    for fn in (fmi.extractUntilBoundary, fmi.extractUntilBoundaryLeft, fmi.extractUntilBoundaryRight):
+        with pytest.raises(ValueError, match="Boundary does not exist"):
+            fn(50, np.zeros(50, np.uint16), 0, "이")
+    with pytest.raises(ValueError, match="Supplied destination for extraction has size zero"):
+        fmi.extractUntilBoundary(50, np.zeros(0, np.uint16), 0, "\n")
+    for fn, n in ((fmi.extractUntilBoundary, 13), (fmi.extractUntilBoundaryLeft, 10), (fmi.extractUntilBoundaryRight, 11)):
+        with pytest.raises(RuntimeError, match="Currently extracted: %d$" % n):
+            fn(50, np.zeros(10, np.uint16), 0, "\n")
+    dest = np.zeros(300, np.uint16)
+    n = fmi.extractUntilBoundary(5, dest, 0, "\n")
+    dest[n] = 10
+    n += 1
+    n += fmi.extractUntilBoundary(n + 2, dest, n, "\n")
+    assert ia.chars_to_str(dest[:n]) == (
+        "081109 203533 44 INFO root: this file should have 2061 unique characters, including 3 and 4 byte UTF8 encoded\n"
+        "081109 203615 148 INFO dfs.DataNode$PacketResponder: PacketResponder 1 for block blk_38865049064139660 "
+        "由电画留當疾療発 terminating")
+
+
+@pytest.mark.parametrize("sr", [1, 2, 4, 8, 16])
+def test_reference_random_loops_vs_definitional_oracles(sr):
+    """T-FM:104-115, 181-193, 360-374, 498-542 replayed (java.util.Random(42)) against brute force"""
+    fmi = ia.FmIndexBuilder().setSampleRate(sr).build(HD)
+    r = JavaRandom(42)
+    subs = []
+    for _ in range(100):
+        start = r.next_int(len(HD) - 32)
+        subs.append(HD[start:start + r.next_int(1, 32)])
+    ch, off = ia.pack_patterns(subs)
+    cnt, st = fmi.count_batch(ch, off)
+    assert cnt.tolist() == [len(occurrences(HD, s)) for s in subs]
+    locs, found, st = fmi.locate_batch(ch, off, -1, 10_000)
+    for i, s in enumerate(subs):
+        assert sorted(locs[i, :found[i]].tolist()) == occurrences(HD, s)
+    r = JavaRandom(42)
+    a = np.zeros(100, np.int32)
+    b = np.zeros(100, np.int32)
+    for i in range(100):
+        a[i] = r.next_int(len(HD) - 100)
+        b[i] = a[i] + r.next_int(100)
+    dst, ol, st = fmi.extract_batch(a, b, 100)
+    for i in range(100):
+        assert ol[i] == b[i] - a[i] and ia.chars_to_str(dst[i, :ol[i]]) == HD[a[i]:b[i]]
+    r = JavaRandom(42)
+    seeds = np.array([r.next_int(len(HD) - 100) for _ in range(100)], np.int32)
+    for mode, fn in ((0, until_boundary), (1, until_boundary_left), (2, until_boundary_right)):
+        dst, ol, st, aux = fmi.extract_boundary_batch(seeds, "\n", mode, 1 << 15)
+        for i in range(100):
+            assert st[i] == 0 and ia.chars_to_str(dst[i, :ol[i]]) == fn(HD, int(seeds[i]), "\n")
+    dest = np.zeros(len(HD), np.uint16)
+    assert fmi.extract(0, len(HD), dest, 0) == len(HD) and ia.chars_to_str(dest) == HD  # T-FM:350-358
+
+
+def test_serialized_round_trip_then_query():
+    """T-FM:219-242, 544-562: an index4j stream (here minted by the oracle's writer) loaded and queried on the GPU"""
+    o = orc.OracleFmIndex(HD, 8, False)
+    fmi = ia.FmIndex.read(o.write(True))
+    assert fmi.write(True) == o.write(True)
+    rnd = random.Random(3)
+    subs = [HD[s:s + rnd.randrange(1, 32)] for s in (rnd.randrange(len(HD) - 32) for _ in range(100))]
+    ch, off = ia.pack_patterns(subs)
+    locs, found, st = fmi.locate_batch(ch, off, -1, 100_000)
+    for i, s in enumerate(subs):
+        assert sorted(locs[i, :found[i]].tolist()) == occurrences(HD, s)
+
+
+def test_wavelet_quirk_paths_through_count():
+    """texts whose BWT holds run blocks and rare symbols: every absent-symbol / next-block path of WFBB.rank"""
+    rng = np.random.default_rng(3)
+    parts = []
+    for i in range(30):
+        parts.append("".join(chr(97 + int(x)) for x in rng.integers(0, 6 + i, 2500)))
+        parts.append("zq" * 3000)
+    text = "".join(parts)
+    check_all(make_gpu, text, 5, random.Random(5), n_q=150)
+
+
+def test_large_batch_properties_16mib():
+    """size-independent properties on a 16 MiB index with a 262,144-pattern batch: every sampled substring
+    occurs (count >= 1), count == located hits when under the cap, every located position really holds
+    the pattern, extracting a located hit returns the pattern, LF-steps == 2*(m-1) for surviving patterns"""
+    n = 1 << 24
+    t = ia.synth_log(n)
+    fm = ia.FmIndex(t, 32, True, device=0)
+    m, N = 8, 1 << 18
+    pat, off, pos = ia.synth_patterns(t, m, N)
+    cnt, st, lf = fm.count_batch(pat, off, want_steps=True)
+    assert (st == 0).all() and (cnt >= 1).all() and (lf == 2 * (m - 1)).all()
+    K = 20000
+    locs, found, st2 = fm.locate_batch(pat[: K * m], off[: K + 1], 16)
+    assert (found == np.minimum(cnt[:K], 16)).all()
+    P = pat.reshape(N, m)
+    for k in range(16):
+        sel = found > k
+        idx = locs[sel, k]
+        got = t[idx[:, None] + np.arange(m)[None, :]]
+        assert (got == P[:K][sel]).all()
+    dst, ol, st3 = fm.extract_batch(locs[:, 0], locs[:, 0] + m, m)
+    assert (st3 == 0).all() and (dst == P[:K]).all()
+    # checksum of checksums against the oracle on a sample, and determinism across launches
+    o = orc.OracleFmIndex.read(fm.write(False))
+    oc, _ = o.count_batch(pat[: 4000 * m], off[:4001])
+    assert (oc == cnt[:4000]).all()
+    cnt2, _ = fm.count_batch(pat, off)
+    assert (cnt2 == cnt).all()
+    # extractUntilBoundary round trip: the line around each hit, vs a numpy scan for '\\n'
+    fr = locs[:2000, 0].astype(np.int32)
+    dst, ol, st4, aux = fm.extract_boundary_batch(fr, "\n", 0, 1024)
+    nl = np.flatnonzero(t == 10)
+    for i in range(2000):
+        p = int(fr[i])
+        j = np.searchsorted(nl, p)
+        lo = nl[j - 1] + 1 if j > 0 else 0
+        hi = nl[j] if j < len(nl) else n
+        exp = t[lo:hi] if t[p] != 10 else t[0:0]
+        assert st4[i] == 0 and ol[i] == len(exp) and (dst[i, :ol[i]] == exp).all(), i

@@ -1,0 +1,78 @@
+"""The device source (index4j_amd/csrc/fmx_device.hpp) compiled for the host by tests/hostsim.cpp, checked
+against the oracle on CPU.  This is a test-only simulation used to debug without a GPU — the product
+never runs queries on the host; the real parity tests are in test_gpu_parity.py (-m gpu)."""
+import random
+
+import numpy as np
+import pytest
+
+import hostsim
+import index4j_amd as ia
+import orc
+from common import hdfs_text
+from parity_checks import check_all
+
+HD = hdfs_text()
+
+
+def make_sim(text, sr):
+    return hostsim.HostSim(ia.FmIndex(text, sr, True, device=None))
+
+
+@pytest.mark.parametrize("sr", [1, 3, 4, 32, 64, 128])
+def test_fixture(sr):
+    check_all(make_sim, HD, sr, random.Random(sr))
+
+
+def test_synthetic_log_config1():
+    """BASELINE.json configs[0] shape: 1,000 8-char patterns on 1 MiB synthetic log, sampleRate 32"""
+    t = ia.synth_log(1 << 20)
+    f = ia.FmIndex(t, 32, True, device=None)
+    o = orc.OracleFmIndex(t, 32, True)
+    h = hostsim.HostSim(f)
+    pat, off, pos = ia.synth_patterns(t, 8, 1000)
+    cnt, st, lf, _ = h.count_batch(pat, off)
+    orc.counters_reset()
+    oc, ost = o.count_batch(pat, off)
+    assert (cnt == oc).all() and (st == 0).all()
+    assert int(lf.sum()) == orc.counters()["lf_steps"]  # LF-step accounting identical to the oracle's
+    s = bytes(t.astype(np.uint8))
+    for i in range(0, 1000, 25):  # and against brute force
+        assert cnt[i] == len([1 for j in range(len(s) - 7) if s[j:j + 8] == s[pos[i]:pos[i] + 8]]) if i < 50 else True
+
+
+def test_embedded_sentinels_and_small_texts():
+    rnd = random.Random(11)
+    mod = list(HD[:40_000])
+    for _ in range(300):
+        mod[rnd.randrange(len(mod) - 2)] = "\0"
+    check_all(make_sim, "".join(mod), 8, rnd, n_q=60)
+    check_all(make_sim, "What a string!\nNow this is long, indeed\nBut others could be longer.", 2, rnd, n_q=40)
+    check_all(make_sim, "a", 1, rnd, n_q=5)
+
+
+def test_wavelet_rank_all_paths_incl_quirks():
+    """wt_rank / wt_inverse_select vs the oracle at every kind of block: absent symbol, absent-in-block
+    (next block / end of superblock / last superblock), run blocks, out-of-range positions"""
+    rng = np.random.default_rng(3)
+    parts = []
+    for i in range(30):
+        parts.append("".join(chr(97 + int(x)) for x in rng.integers(0, 6 + i, 2500)))
+        parts.append("zq" * 3000)
+    text = "".join(parts)
+    f = ia.FmIndex(text, 5, True, device=None)
+    o = orc.OracleFmIndex(text, 5, True)
+    h = hostsim.HostSim(f)
+    L = f.getInputLength()
+    wh = o.wavelet_handle()
+    st = orc.C.c_int(0)
+    for pos in list(range(0, L + 1, 37)) + [L, L + 5]:
+        for sym in (0, 1, 2, 3, 5, 21, 30, 36, 37, 400):
+            st.value = 0
+            e = orc.lib().orc_wfbb_rank(wh, pos, sym, orc.C.byref(st))
+            r, s2 = h.wt_rank(pos, sym)
+            assert (r, s2) == (e, st.value), (pos, sym)
+    for pos in range(0, L, 61):
+        c, r = h.wt_inverse_select(pos)
+        t = orc.lib().orc_wfbb_inverse_select(wh, pos)
+        assert c == (t & 0xFFFF) and (pos == 0 or r == (t >> 32))
