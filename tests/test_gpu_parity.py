@@ -115,9 +115,13 @@ def test_reference_random_loops_vs_definitional_oracles(sr):
     ch, off = ia.pack_patterns(subs)
     cnt, st = fmi.count_batch(ch, off)
     assert cnt.tolist() == [len(occurrences(HD, s)) for s in subs]
-    locs, found, st = fmi.locate_batch(ch, off, -1, 10_000)
+    locs, found, st = fmi.locate_batch(ch, off, -1, 100_000)  # T-FM:211: int[100_000], maxMatches -1
     for i, s in enumerate(subs):
-        assert sorted(locs[i, :found[i]].tolist()) == occurrences(HD, s)
+        assert st[i] == 0 and sorted(locs[i, :found[i]].tolist()) == occurrences(HD, s)
+    locs, found, st = fmi.locate_batch(ch, off, -1, 50)  # overflowing `locations`: Java raises AIOOBE
+    for i, s in enumerate(subs):
+        n_occ = len(occurrences(HD, s))
+        assert (st[i] == 9 and found[i] == 50) if n_occ > 50 else (st[i] == 0 and found[i] == n_occ)
     r = JavaRandom(42)
     a = np.zeros(100, np.int32)
     b = np.zeros(100, np.int32)
@@ -189,14 +193,19 @@ def test_large_batch_properties_16mib():
     assert (oc == cnt[:4000]).all()
     cnt2, _ = fm.count_batch(pat, off)
     assert (cnt2 == cnt).all()
-    # extractUntilBoundary round trip: the line around each hit, vs a numpy scan for '\\n'
-    fr = locs[:2000, 0].astype(np.int32)
+    # extractUntilBoundary round trip: the line around each hit, vs a numpy scan for '\\n'.  Inside the
+    # unterminated LAST line the reference itself returns a length one short (FM:745-752),
+    # so those seeds are compared with the oracle instead of the scan.
+    fr = np.concatenate([locs[:2000, 0], np.arange(n - 40, n, 3)]).astype(np.int32)
     dst, ol, st4, aux = fm.extract_boundary_batch(fr, "\n", 0, 1024)
     nl = np.flatnonzero(t == 10)
-    for i in range(2000):
+    for i in range(len(fr)):
         p = int(fr[i])
         j = np.searchsorted(nl, p)
-        lo = nl[j - 1] + 1 if j > 0 else 0
-        hi = nl[j] if j < len(nl) else n
-        exp = t[lo:hi] if t[p] != 10 else t[0:0]
-        assert st4[i] == 0 and ol[i] == len(exp) and (dst[i, :ol[i]] == exp).all(), i
+        if j < len(nl):
+            lo = nl[j - 1] + 1 if j > 0 else 0
+            exp = t[lo:nl[j]] if t[p] != 10 else t[0:0]
+            assert st4[i] == 0 and ol[i] == len(exp) and (dst[i, :ol[i]] == exp).all(), i
+        else:
+            en, ed = o.extract_until_boundary(0, p, 1024, 0, "\n")
+            assert st4[i] == 0 and ol[i] == en and (dst[i] == ed).all(), i
