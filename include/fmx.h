@@ -116,6 +116,15 @@ int fmx_extract_boundary_batch(const fmx_index *idx, const int32_t *from, int32_
  * the caller orders work through the stream (this is what bench.py times with HIP events). */
 int fmx_count_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
                         int32_t *d_counts, int32_t *d_lf_steps, int32_t *d_status, void *stream);
+/* The two stages of fmx_count_batch_dev, callable separately (bench.py times the second one alone):
+ * plan = processing order of the batch (device radix sort on the patterns' trailing characters, so
+ * that neighbouring lanes walk the same SA intervals); *d_perm points into per-stream scratch owned by
+ * the index (valid until the next plan on that stream) or is NULL for small batches.
+ * ordered = the k_count kernel over that order; results are written at the ORIGINAL pattern index. */
+int fmx_count_plan_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
+                       const uint32_t **d_perm, void *stream);
+int fmx_count_ordered_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, const uint32_t *d_perm,
+                          int32_t n, int32_t *d_counts, int32_t *d_lf_steps, int32_t *d_status, void *stream);
 int fmx_locate_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
                          int32_t max_matches, int32_t *d_locs, int32_t loc_cap, int32_t *d_found,
                          int32_t *d_lf_steps, int32_t *d_status, int32_t *d_range_ws /* 2*n ints */, void *stream);
@@ -138,6 +147,9 @@ const char *fmx_status_message(int status);
 int fmx_status_kind(int status);
 const char *fmx_last_error(void);
 int fmx_device_count(void);
+/* launch tunables: "block" = threads per workgroup (512 | 1024), "groups_per_cu" = grid cap per CU,
+ * "sort_min" = smallest batch that is processed in suffix-sorted order (0 = never), "sort_bits" = sort key width */
+int fmx_set_option(const char *name, int value);
 
 /* deterministic synthetic workload (bench / tests): see index4j_amd/csrc/fmx_synth.cpp */
 int fmx_synth_log(uint64_t seed, int32_t n, uint16_t *out);

@@ -27,8 +27,8 @@ SYMBOLS = [
     "fmx_input_length", "fmx_alphabet_length", "fmx_sample_rate", "fmx_extract_enabled",
     "fmx_blob", "fmx_to_device", "fmx_attach_device_blob", "fmx_device_blob",
     "fmx_count_batch", "fmx_locate_batch", "fmx_extract_batch", "fmx_extract_boundary_batch",
-    "fmx_count_batch_dev", "fmx_locate_batch_dev", "fmx_extract_batch_dev", "fmx_extract_boundary_batch_dev",
-    "fmx_convert_byte_pattern", "fmx_status_message", "fmx_status_kind", "fmx_last_error", "fmx_device_count",
+    "fmx_count_batch_dev", "fmx_count_plan_dev", "fmx_count_ordered_dev", "fmx_locate_batch_dev", "fmx_extract_batch_dev", "fmx_extract_boundary_batch_dev",
+    "fmx_convert_byte_pattern", "fmx_status_message", "fmx_status_kind", "fmx_last_error", "fmx_device_count", "fmx_set_option",
     "fmx_synth_log", "fmx_synth_patterns",
 ]
 
@@ -63,6 +63,8 @@ def _load():
     L.fmx_extract_batch.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp]
     L.fmx_extract_boundary_batch.argtypes = [vp, vp, i32, u16, C.c_int, vp, i32, i32, vp, vp, vp, vp]
     L.fmx_count_batch_dev.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp]
+    L.fmx_count_plan_dev.argtypes = [vp, vp, vp, i32, P(vp), vp]
+    L.fmx_count_ordered_dev.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp]
     L.fmx_locate_batch_dev.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp]
     L.fmx_extract_batch_dev.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp]
     L.fmx_extract_boundary_batch_dev.argtypes = [vp, vp, i32, u16, C.c_int, vp, i32, i32, vp, vp, vp, vp, vp]
@@ -71,6 +73,7 @@ def _load():
     L.fmx_status_message.restype = C.c_char_p
     L.fmx_status_kind.argtypes = [C.c_int]
     L.fmx_last_error.restype = C.c_char_p
+    L.fmx_set_option.argtypes = [C.c_char_p, C.c_int]
     L.fmx_synth_log.argtypes = [u64, i32, vp]
     L.fmx_synth_patterns.argtypes = [u64, vp, i32, i32, i32, vp, vp, vp]
     return L

@@ -9,20 +9,25 @@
 
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
 
 namespace fmx {
-int launch_count(const DevIndex &, int, const uint16_t *, const int32_t *, int32_t, int32_t *, int32_t *, int32_t *,
-                 int32_t *, hipStream_t);
+int launch_count_plan(const DevIndex &, const uint16_t *, const int32_t *, int32_t, void *, size_t, const uint32_t **,
+                      hipStream_t);
+int launch_count(const DevIndex &, int, const uint16_t *, const int32_t *, const uint32_t *, int32_t, int32_t *,
+                 int32_t *, int32_t *, int32_t *, hipStream_t);
+size_t count_workspace_bytes(int32_t n);
 int launch_locate_walk(const DevIndex &, int, const int32_t *, int32_t, int32_t, int32_t *, int32_t, int32_t *,
                        int32_t *, int32_t *, hipStream_t);
 int launch_extract(const DevIndex &, int, const int32_t *, const int32_t *, int32_t, uint16_t *, int32_t, int32_t,
                    int32_t *, int32_t *, int32_t *, hipStream_t);
 int launch_extract_boundary(const DevIndex &, int, const int32_t *, int32_t, uint16_t, int, uint16_t *, int32_t,
                             int32_t, int32_t *, int32_t *, int32_t *, int32_t *, hipStream_t);
+int set_option(const char *, int);
 }  // namespace fmx
 
 struct fmx_index {
@@ -36,6 +41,9 @@ struct fmx_index {
     int n_cu = 256;
     bool owns_device = false;
     fmx::DevIndex dev;
+    // per-stream scratch for the in-library pattern sort (grow-only; freed with the index)
+    mutable std::mutex ws_mutex;
+    mutable std::map<void *, std::pair<void *, size_t>> ws;
 };
 
 namespace {
@@ -143,6 +151,26 @@ int require_device(const fmx_index *idx) {
     return FMX_OK;
 }
 
+// scratch of at least `bytes` for work enqueued on `stream`; reused across calls on the same stream
+int get_workspace(const fmx_index *idx, void *stream, size_t bytes, void **out) {
+    *out = nullptr;
+    if (bytes == 0) return FMX_OK;
+    std::lock_guard<std::mutex> lock(idx->ws_mutex);
+    auto &slot = idx->ws[stream];
+    if (slot.second < bytes) {
+        if (slot.first) {
+            HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+            (void)hipFree(slot.first);
+            slot = {nullptr, 0};
+        }
+        void *p = nullptr;
+        HIP_TRY(hipMalloc(&p, bytes));
+        slot = {p, bytes};
+    }
+    *out = slot.first;
+    return FMX_OK;
+}
+
 // RAII device scratch for the host-buffer entry points
 struct DevBuf {
     void *p = nullptr;
@@ -161,6 +189,11 @@ struct DevBuf {
 extern "C" {
 
 const char *fmx_last_error(void) { return g_err.c_str(); }
+
+int fmx_set_option(const char *name, int value) {
+    if (!name || fmx::set_option(name, value)) return fail(FMX_E_ARG, "unknown option or bad value");
+    return FMX_OK;
+}
 
 int fmx_device_count(void) {
     int n = 0;
@@ -211,10 +244,10 @@ void fmx_free_buffer(uint8_t *buf) { free(buf); }
 
 void fmx_free(fmx_index *idx) {
     if (!idx) return;
-    if (idx->owns_device && idx->d_blob) {
-        (void)hipSetDevice(idx->device);
-        (void)hipFree(idx->d_blob);
-    }
+    if (idx->device >= 0) (void)hipSetDevice(idx->device);
+    for (auto &kv : idx->ws)
+        if (kv.second.first) (void)hipFree(kv.second.first);
+    if (idx->owns_device && idx->d_blob) (void)hipFree(idx->d_blob);
     delete idx;
 }
 
@@ -290,15 +323,46 @@ void *fmx_device_blob(const fmx_index *idx, size_t *len) {
 
 // ---- device-pointer entry points ---------------------------------------------------------------
 
-int fmx_count_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
-                        int32_t *d_counts, int32_t *d_lf_steps, int32_t *d_status, void *stream) {
+// stage 1 of count/locate: processing order of the batch (suffix-key radix sort) — nullptr when the
+// batch is too small to be worth sorting
+static int plan_order(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n, void *stream,
+                      const uint32_t **perm) {
+    *perm = nullptr;
+    void *ws = nullptr;
+    const size_t ws_bytes = fmx::count_workspace_bytes(n);
+    int rc = get_workspace(idx, stream, ws_bytes, &ws);
+    if (rc) return rc;
+    if (!ws) return FMX_OK;
+    int e = fmx::launch_count_plan(idx->dev, d_pat, d_pat_off, n, ws, ws_bytes, perm, static_cast<hipStream_t>(stream));
+    if (e) return fail(FMX_E_HIP, std::string("pattern sort: ") + hipGetErrorString((hipError_t)e));
+    return FMX_OK;
+}
+
+int fmx_count_plan_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
+                       const uint32_t **d_perm, void *stream) {
+    int rc = require_device(idx);
+    if (rc) return rc;
+    if (n < 0 || !d_perm || (n > 0 && !d_pat_off)) return fail(FMX_E_ARG, "bad arguments");
+    return plan_order(idx, d_pat, d_pat_off, n, stream, d_perm);
+}
+
+int fmx_count_ordered_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, const uint32_t *d_perm,
+                          int32_t n, int32_t *d_counts, int32_t *d_lf_steps, int32_t *d_status, void *stream) {
     int rc = require_device(idx);
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!d_pat_off || !d_counts))) return fail(FMX_E_ARG, "bad arguments");
-    int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, n, d_counts, d_lf_steps, d_status, nullptr,
+    int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, d_perm, n, d_counts, d_lf_steps, d_status, nullptr,
                               static_cast<hipStream_t>(stream));
     if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
     return FMX_OK;
+}
+
+int fmx_count_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
+                        int32_t *d_counts, int32_t *d_lf_steps, int32_t *d_status, void *stream) {
+    const uint32_t *perm = nullptr;
+    int rc = fmx_count_plan_dev(idx, d_pat, d_pat_off, n, &perm, stream);
+    if (rc) return rc;
+    return fmx_count_ordered_dev(idx, d_pat, d_pat_off, perm, n, d_counts, d_lf_steps, d_status, stream);
 }
 
 int fmx_locate_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
@@ -310,7 +374,10 @@ int fmx_locate_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int3
         return fail(FMX_E_ARG, "bad arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
     // found[] doubles as the scratch `counts` output of the range pass; the walk pass overwrites it
-    int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, n, d_found, d_lf_steps, d_status, d_range_ws, st);
+    const uint32_t *perm = nullptr;
+    rc = plan_order(idx, d_pat, d_pat_off, n, stream, &perm);
+    if (rc) return rc;
+    int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, perm, n, d_found, d_lf_steps, d_status, d_range_ws, st);
     if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
     e = fmx::launch_locate_walk(idx->dev, idx->n_cu, d_range_ws, n, max_matches, d_locs, loc_cap, d_found, d_lf_steps,
                                 d_status, st);

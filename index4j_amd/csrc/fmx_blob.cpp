@@ -23,38 +23,40 @@ struct Arena {
 
 inline uint32_t off8(size_t byte_off) { return (uint32_t)(byte_off >> 3); }
 
-// RRR:92-103 -> array of sample records + offsets bit stream
+// RRR:92-103 -> 16-block records + offsets bit stream
 bool flatten_rrr(Arena &A, const RrrModel &r, RrrDesc &d, std::string &err) {
-    const int s = r.sample_size;
-    if (s <= 0 || r.classes.width != 4) {
+    if (r.sample_size <= 0 || r.classes.width != 4) {
         err = "unsupported RRR parameters";
         return false;
     }
+    const uint8_t *bits_needed = rrr_bits_needed();
     const int64_t n_blocks = r.classes.length;
-    const int64_t n_rec = n_blocks / s + 1;  // == lengthOfSampledOffsets.length (RRR:263)
-    if (r.sampled_offsets.length < n_rec || r.prefix_sums.length < n_rec) {
-        err = "RRR sample vectors shorter than expected";
-        return false;
-    }
-    d.rec_shift = rrr_rec_shift(s);
+    const int64_t n_rec = n_blocks / 16 + 1;
     d.n_rec = (int32_t)n_rec;
     d.n_blocks = (int32_t)n_blocks;
     d.length = r.length;
     d.total_ones = r.total_ones;
-    d.sample = s;
-    const size_t stride = (size_t)1 << d.rec_shift;
-    const size_t rec_off = A.alloc((size_t)n_rec * stride + 64);
+    d.sample = r.sample_size;
+    d.pad = 0;
+    const size_t rec_off = A.alloc((size_t)n_rec * sizeof(RrrRecord) + 64);
     d.off_rec = off8(rec_off);
+    uint64_t ones = 0, obits = 0;
     for (int64_t k = 0; k < n_rec; ++k) {
-        uint8_t *rec = A.at<uint8_t>(rec_off + (size_t)k * stride);
-        const uint32_t prefix = (uint32_t)r.prefix_sums.get_bits(k * r.prefix_sums.width, r.prefix_sums.width);
-        const uint32_t ptr = (uint32_t)r.sampled_offsets.get_bits(k * r.sampled_offsets.width, r.bits_per_offset_pos);
-        memcpy(rec, &prefix, 4);
-        memcpy(rec + 4, &ptr, 4);
-        uint64_t *cls = reinterpret_cast<uint64_t *>(rec + 8);
-        const int64_t first = k * s;
-        for (int64_t j = 0; j < s && first + j < n_blocks; ++j)
-            cls[j >> 4] |= r.classes.get(first + j) << (4 * (j & 15));
+        RrrRecord rec;
+        rec.ones_before = (uint32_t)ones;
+        rec.offset_bit = (uint32_t)obits;
+        rec.classes = 0;
+        for (int64_t j = 0; j < 16 && k * 16 + j < n_blocks; ++j) {
+            const uint64_t cls = r.classes.get(k * 16 + j);
+            rec.classes |= cls << (4 * j);
+            ones += cls;
+            obits += bits_needed[cls];
+        }
+        A.at<RrrRecord>(rec_off)[k] = rec;
+    }
+    if (obits > (uint64_t)r.offsets.size() * 64 || obits > 0xffffffffull) {
+        err = "RRR offsets stream shorter than its classes imply";
+        return false;
     }
     const size_t bits_off = A.alloc((r.offsets.size() + 2) * 8);
     d.off_bits = off8(bits_off);
@@ -119,9 +121,9 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
     h.off_positions = m.enable_extract ? off8(put_packed(A, m.positions)) : 0;
     if (!flatten_rrr(A, m.sampled, h.sampled, err)) return -8;
 
-    off = A.alloc(65536);
+    off = A.alloc(kInvEntries * 2);  // classes 0..7 only; 8..15 are complements (fmx_blob.hpp)
     h.off_inv = off8(off);
-    memcpy(A.at<uint8_t>(off), rrr_value_of_offset(), 65536);
+    memcpy(A.at<uint8_t>(off), rrr_value_of_offset(), kInvEntries * 2);
 
     // fused (rank, superblock code) table; row n_sb = total counts (WFBB:1063-1069)
     off = A.alloc((size_t)(n_sb + 1) * sigma * sizeof(SbcEntry));
@@ -156,7 +158,29 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
         off = A.alloc(sb.mapping.size() * 2 + 8);
         d.off_mapping = off8(off);
         d.mapping_len = (int32_t)sb.mapping.size();
-        if (!sb.mapping.empty()) memcpy(A.at<uint8_t>(off), sb.mapping.data(), sb.mapping.size() * 2);
+        {
+            // absent entries (alphabetSize - 1, WFBB:383-387) become skip pointers: -(distance to the next
+            // block to the right holding the symbol, or to the end of the superblock)
+            int16_t *dst = A.at<int16_t>(off);
+            const int64_t per_row = (int64_t)1 << (20 - d.bsl);
+            const int16_t absent = (int16_t)(sigma - 1);
+            for (int64_t row = 0; row <= sb.sigma; ++row) {
+                int64_t next_present = per_row;
+                for (int64_t blk = per_row - 1; blk >= 0; --blk) {
+                    const int16_t v = sb.mapping[(size_t)(row * per_row + blk)];
+                    if (v != absent) {
+                        if (v < 0) {
+                            err = "negative mapping entry";
+                            return -3;
+                        }
+                        next_present = blk;
+                        dst[row * per_row + blk] = v;
+                    } else {
+                        dst[row * per_row + blk] = (int16_t)(-(next_present - blk));
+                    }
+                }
+            }
+        }
         off = A.alloc(sb.block_headers.size() * sizeof(BlockHdr) + 16);
         d.off_bh = off8(off);
         static_assert(sizeof(BlockHeader) == sizeof(BlockHdr), "block header layout");

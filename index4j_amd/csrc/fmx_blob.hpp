@@ -11,14 +11,23 @@
 //                                    fused into one 8-byte load; row n_sb holds count[] (WFBB:1063-1069)
 //       SbDesc[n_sb]                 one 64-byte sector per superblock header (WFBB:1621-1629)
 //   * per superblock: mapping (int16), BlockHeader[] (16 B, as WFBB:1589-1595), variable headers
-//     (bytes as written at WFBB:742-809, + 8 guard bytes), and its RRR vector.
-//   * an RRR vector (RRR:92-103) is stored array-of-records instead of the reference's four separate
-//     bit-packed vectors: record k (one per `sample` 15-bit blocks) = { u32 prefix sum (RRR:101),
-//     u32 offset bit pointer (RRR:99-100), the `sample` 4-bit classes of its blocks (RRR:96) },
-//     padded to a power-of-two stride so a record never straddles a 64-byte sector for sample <= 64:
-//     a rank touches one record sector + one sector of the offsets bit stream (RRR:97-98).
-//   * the 64 KiB value-of-offset table (RRR:106) travels in the blob and is staged into LDS by
-//     every workgroup.
+//     (bytes as written at WFBB:742-809, + 16 guard bytes), and its RRR vector.
+//   * mapping (WFBB:1628): present entries keep the block-local symbol index; an ABSENT entry
+//     (alphabetSize-1 in the reference) is stored as -d, d = distance to the closest block to the
+//     right that holds the symbol (or to the end of the superblock).  The reference finds that block
+//     with a linear scan (WFBB:1051-1059: 27 dependent reads on average on log text); the skip
+//     pointer returns the same block in one read.
+//   * an RRR vector (RRR:92-103) is stored as 16-byte records, one per 16 blocks of 15 bits,
+//     whatever the index's own sampleSize: { u32 ones before the record (the role of prefixSums,
+//     RRR:101), u32 bit pointer into the offsets stream (lengthOfSampledOffsets, RRR:99-100),
+//     u64 = the 16 4-bit classes (RRR:96) }.  One aligned 16-byte load replaces three bit-packed
+//     vector reads and bounds the class scan of RRR:376-380 to 15 nibbles of one word; a rank touches
+//     one record sector + one sector of the offsets bit stream (RRR:97-98).  Same space as the
+//     reference's sampleSize=32 layout padded to 32-byte records.
+//   * value-of-offset table (RRR:106, 64 KiB in the reference): only classes 0..7 are stored
+//     (16,384 entries, 32 KiB) — class 15-k is the bitwise complement in reverse offset order:
+//     value(15-k, off) = ~value(k, C(15,k)-1-off) & 0x7fff.  It travels in the blob and every
+//     workgroup stages it into LDS.
 #pragma once
 
 #include <cstdint>
@@ -26,24 +35,30 @@
 namespace fmx {
 
 constexpr uint32_t kBlobMagic = 0x31584D46u;  // "FMX1"
-constexpr uint32_t kBlobVersion = 1;
+constexpr uint32_t kBlobVersion = 2;
+
+struct RrrRecord {         // 16 bytes: 16 blocks of 15 bits
+    uint32_t ones_before;  // 1-bits in all earlier blocks
+    uint32_t offset_bit;   // bit position of this record's first offset in the offsets stream
+    uint64_t classes;      // block j's class in bits [4j, 4j+4)
+};
 
 struct RrrDesc {           // 32 bytes
-    uint32_t off_rec;      // records, stride 1 << rec_shift bytes
+    uint32_t off_rec;      // RrrRecord[n_rec]
     uint32_t off_bits;     // offsets bit stream, 64-bit words LSB-first (+2 guard words)
     int32_t length;        // RRR:94
     int32_t total_ones;    // RRR:95
-    int32_t rec_shift;
     int32_t n_rec;
     int32_t n_blocks;
-    int32_t sample;        // RRR:93 sampleSize, in 15-bit blocks
+    int32_t sample;        // RRR:93 sampleSize of the source index (informational)
+    int32_t pad;
 };
 
 struct SbDesc {            // 64 bytes
     int16_t sigma;         // WFBB:1623 (superblock alphabet size - 1)
     int16_t bsl;           // WFBB:1624 blockSizeLog
     int32_t n_blocks;
-    uint32_t off_mapping;  // int16[(sigma+1) << (20 - bsl)]
+    uint32_t off_mapping;  // int16[(sigma+1) << (20 - bsl)], absent entries = -(distance to next present)
     uint32_t off_bh;       // BlockHdr[n_blocks]
     uint32_t off_var;      // variable-size block headers
     int32_t var_len;
@@ -77,23 +92,17 @@ struct BlobHeader {        // 256 bytes
     uint32_t off_positions;  // packed words of `positions`            FM:112
     uint32_t off_sbc;        // SbcEntry[(n_sb + 1) * wt_sigma]
     uint32_t off_sbdesc;     // SbDesc[n_sb]
-    uint32_t off_inv;        // uint16[32768] value-of-offset table    RRR:106
+    uint32_t off_inv;        // uint16[16384] value-of-offset table, classes 0..7  RRR:106
     RrrDesc sampled;         // sampledSuffixes                        FM:123
     uint8_t reserved[256 - 8 - 8 - 12 * 4 - 8 - 8 * 4 - 32];
 };
 static_assert(sizeof(RrrDesc) == 32, "RrrDesc");
+static_assert(sizeof(RrrRecord) == 16, "RrrRecord");
 static_assert(sizeof(SbDesc) == 64, "SbDesc");
 static_assert(sizeof(BlockHdr) == 16, "BlockHdr");
 static_assert(sizeof(SbcEntry) == 8, "SbcEntry");
 static_assert(sizeof(BlobHeader) == 256, "BlobHeader");
 
-// record stride (bytes, log2) for an RRR vector sampled every `sample` blocks:
-// 8 header bytes + ceil(sample / 16) class words, rounded up to a power of two
-inline int rrr_rec_shift(int sample) {
-    int bytes = 8 + 8 * ((sample + 15) / 16);
-    int sh = 4;
-    while ((1 << sh) < bytes) ++sh;
-    return sh;
-}
+constexpr int kInvEntries = 16384;  // sum of C(15,k), k = 0..7
 
 }  // namespace fmx

@@ -89,15 +89,21 @@ FMX_HD uint32_t ld_bits(const uint32_t *words, uint64_t bit, int nbits) {
 // BITS_NEEDED_BINOMIAL_COEFFICIENTS (RRR:109-129) = {1,4,7,9,11,12,13,13,13,13,12,11,9,7,4,1}, one nibble each
 constexpr uint64_t kBitsNeededLut = 0x1479BCDDDDCB9741ull;
 FMX_HD int rrr_bits_needed(int cls) { return (int)((kBitsNeededLut >> (4 * cls)) & 15); }
-// CARDINALITY_OFFSETS (RRR:105, literals RRR:8692-8697) = prefix sums of C(15,k), four u16 per word
-FMX_HD uint32_t rrr_class_base(int cls) {
-    const uint64_t w0 = 0x0079001000010000ull;  // 0, 1, 16, 121
-    const uint64_t w1 = 0x26DD135007950240ull;  // 576, 1941, 4944, 9949
-    const uint64_t w2 = 0x786B6CB059234000ull;  // 16384, 22819, 27824, 30827
-    const uint64_t w3 = 0x7FFF7FF07F877DC0ull;  // 32192, 32647, 32752, 32767
+// index into the half value-of-offset table (classes 0..7 stored; class 15-k = complement in reverse
+// offset order).  For cls < 8 the entry is base[cls] + off with base = CARDINALITY_OFFSETS (RRR:105,
+// literals RRR:8692-8697: 0,1,16,121,576,1941,4944,9949); for cls >= 8 it is base[16-cls] - 1 - off
+// and the looked-up value is complemented.  Four u16 per constant word.
+FMX_HD uint32_t rrr_inv_lookup(const uint16_t *inv, int cls, uint32_t off) {
+    const uint64_t w0 = 0x0079001000010000ull;  // cls 0..3 : 0, 1, 16, 121
+    const uint64_t w1 = 0x26DD135007950240ull;  // cls 4..7 : 576, 1941, 4944, 9949
+    const uint64_t w2 = 0x0794134F26DC3FFFull;  // cls 8..11: 16383, 9948, 4943, 1940
+    const uint64_t w3 = 0x0000000F0078023Full;  // cls 12..15: 575, 120, 15, 0
     const uint64_t lo = (cls & 4) ? w1 : w0, hi = (cls & 4) ? w3 : w2;
     const uint64_t w = (cls & 8) ? hi : lo;
-    return (uint32_t)((w >> (16 * (cls & 3))) & 0xffff);
+    const uint32_t b = (uint32_t)((w >> (16 * (cls & 3))) & 0xffff);
+    const bool comp = (cls & 8) != 0;
+    const uint32_t v = inv[comp ? b - off : b + off];
+    return comp ? (~v & 0x7fffu) : v;
 }
 
 // sums over the low `n` nibbles (0 <= n <= 16) of a class word:
@@ -125,28 +131,21 @@ FMX_HD void rrr_scan_word(uint64_t w, int n, uint32_t &ones, uint32_t &obits) {
 }
 
 // decode the 15-bit block that holds bit `position` (0 <= position < length):
-// returns the block value; *prefix = ones before the block (RRR:370-380)
+// returns the block value; prefix = ones before the block (RRR:367-390 over the 16-block records)
 FMX_HD uint32_t rrr_decode(const uint8_t *base, const RrrDesc &d, const uint16_t *inv, uint32_t position,
                            uint32_t &prefix) {
     const uint32_t block_id = position / 15u;  // RRR:367
-    const uint32_t sample = (uint32_t)d.sample;
-    const uint32_t k = ((sample & (sample - 1)) == 0) ? (block_id >> __builtin_ctz(sample)) : (block_id / sample);  // RRR:368
-    const uint32_t j = block_id - k * sample;
-    const uint8_t *rec = base + ((uint64_t)d.off_rec << 3) + ((uint64_t)k << d.rec_shift);
-    const uint64_t hdr = *reinterpret_cast<const uint64_t *>(rec);
-    uint32_t ones = (uint32_t)hdr;           // prefixSums[k]            RRR:370
-    uint32_t obits = (uint32_t)(hdr >> 32);  // lengthOfSampledOffsets[k] RRR:371-372
-    const uint64_t *cw = reinterpret_cast<const uint64_t *>(rec + 8);
-    const uint32_t full = j >> 4;
-    for (uint32_t i = 0; i < full; ++i) rrr_scan_word(cw[i], 16, ones, obits);
-    const uint64_t last = cw[full];
-    rrr_scan_word(last, (int)(j & 15), ones, obits);
-    const int cls = (int)((last >> (4 * (j & 15))) & 15);  // RRR:382
-    const int nb = rrr_bits_needed(cls);                   // RRR:383
+    const uint32_t j = block_id & 15u;
+    const RrrRecord rec = reinterpret_cast<const RrrRecord *>(base + ((uint64_t)d.off_rec << 3))[block_id >> 4];
+    uint32_t ones = rec.ones_before;  // RRR:370
+    uint32_t obits = rec.offset_bit;  // RRR:371-372
+    rrr_scan_word(rec.classes, (int)j, ones, obits);         // RRR:376-380
+    const int cls = (int)((rec.classes >> (4 * j)) & 15);     // RRR:382
+    const int nb = rrr_bits_needed(cls);                      // RRR:383
     const uint32_t *bits = reinterpret_cast<const uint32_t *>(base + ((uint64_t)d.off_bits << 3));
-    const uint32_t off = ld_bits(bits, obits, nb);         // RRR:386
+    const uint32_t off = ld_bits(bits, obits, nb);            // RRR:386
     prefix = ones;
-    return inv[rrr_class_base(cls) + off];                 // RRR:387-390
+    return rrr_inv_lookup(inv, cls, off);                     // RRR:387-390
 }
 
 // RRR:358-396
@@ -232,13 +231,11 @@ FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t positio
     const uint8_t *var = ix.base + ((uint64_t)sd.off_var << 3);
     const uint32_t map_row = (uint32_t)e.sbc << blocks_log;
     int32_t block_c = mapping[map_row + block_id];  // WFBB:1044-1046
-    const int32_t absent = ix.wt_sigma - 1;
 
-    if (block_c == absent) {  // WFBB:1048-1110: answer from the closest block to the right that has the symbol
-        ++block_id;
-        const uint32_t blocks_in_sb = 1u << blocks_log;
-        while (block_id < blocks_in_sb && mapping[map_row + block_id] == absent) ++block_id;
-        if (block_id == blocks_in_sb)  // WFBB:1060-1069 (row n_sb of the table holds count[])
+    if (block_c < 0) {  // WFBB:1048-1110: absent; -block_c = distance to the closest block to the right that
+                        // holds the symbol (what the scan of WFBB:1051-1059 finds), or to the superblock end
+        block_id += (uint32_t)(-block_c);
+        if (block_id == (1u << blocks_log))  // WFBB:1060-1069 (row n_sb of the table holds count[])
             return ix.sbc[(uint64_t)(sb_id + 1) * (uint32_t)ix.wt_sigma + (uint32_t)symbol].rank;
         block_c = mapping[map_row + block_id];
         const BlockHdr bh = bhs[block_id];

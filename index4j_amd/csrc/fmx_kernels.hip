@@ -5,37 +5,49 @@
 //   k_extract          FmIndex.extract          FM:564-608   one lane per query
 //   k_extract_boundary extractUntilBoundary{,Left,Right} FM:640-922  one lane per query
 //
-// Every workgroup stages the 64 KiB RRR value-of-offset table (RRR:106) into LDS once and then
-// grid-strides over queries.  The work is bit-level integer gather (no MFMA): throughput comes from
+// Every workgroup stages the (halved, 32 KiB) RRR value-of-offset table (RRR:106) into LDS once and
+// then grid-strides over queries.  The work is bit-level integer gather (no MFMA): throughput comes from
 // tens of thousands of independent dependent-load chains in flight, the two lanes of a pattern
 // sharing their sectors (start and end of an interval usually fall in the same blocks).
+#include <cstring>
+
 #include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "fmx_device.hpp"
 
 namespace fmx {
 
-constexpr int kBlock = 1024;  // threads per workgroup: 64 KiB of LDS is shared by 16 waves
+// Workgroup size is a template parameter (512 / 1024 threads); 32 KiB of LDS per workgroup.
+// FMX_WAVES_PER_EU asks the register allocator for 8 waves per SIMD (<= 64 VGPRs, <= 80 SGPRs): the
+// kernels are latency-bound chains of dependent loads, so resident waves are what hides latency.
+#define FMX_KERNEL(BLOCK) __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
 
 __device__ __forceinline__ void stage_inverse_table(uint16_t *s_inv, const uint16_t *g_inv) {
     const uint4 *src = reinterpret_cast<const uint4 *>(g_inv);
     uint4 *dst = reinterpret_cast<uint4 *>(s_inv);
-    for (int i = threadIdx.x; i < 65536 / 16; i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i < kInvEntries * 2 / 16; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
 }
 
 // FM:455-474 (also the first half of locate, FM:506-523).  Lane 2p computes `start`, lane 2p+1
 // computes `end`; they swap results with one DPP-class shuffle per pattern character.
 // range_out (nullable): 2 ints per pattern {start, end} for k_locate_walk.
-__global__ __launch_bounds__(kBlock) void k_count(DevIndex ix, const uint16_t *__restrict__ pat,
-                                                  const int32_t *__restrict__ pat_off, int32_t n,
+// perm (nullable): processing order — slot q of the grid handles pattern perm[q].  The launcher sorts
+// the batch by the patterns' last characters so that the lanes of a wave start their backward search
+// in the same SA intervals (same sectors, broadcast loads); results land at the original index.
+template <int kBlock>
+FMX_KERNEL(kBlock) void k_count(DevIndex ix, const uint16_t *__restrict__ pat,
+                                                  const int32_t *__restrict__ pat_off,
+                                                  const uint32_t *__restrict__ perm, int32_t n,
                                                   int32_t *__restrict__ counts, int32_t *__restrict__ lf_steps,
                                                   int32_t *__restrict__ status_out, int32_t *__restrict__ range_out) {
-    __shared__ uint16_t s_inv[32768];
+    __shared__ uint16_t s_inv[kInvEntries];
     stage_inverse_table(s_inv, ix.inv_global);
     const int role = threadIdx.x & 1;
     const int64_t pairs_per_grid = (int64_t)gridDim.x * (kBlock / 2);
-    for (int64_t p = (int64_t)blockIdx.x * (kBlock / 2) + (threadIdx.x >> 1); p < n; p += pairs_per_grid) {
+    for (int64_t q = (int64_t)blockIdx.x * (kBlock / 2) + (threadIdx.x >> 1); q < n; q += pairs_per_grid) {
+        const int64_t p = perm ? (int64_t)perm[q] : q;
         const int32_t beg = pat_off[p];
         const int32_t m = pat_off[p + 1] - beg;
         int status = ST_OK;
@@ -77,12 +89,13 @@ __global__ __launch_bounds__(kBlock) void k_count(DevIndex ix, const uint16_t *_
 }
 
 // FM:526-548: hit k of pattern p is SA row i = start + 1 + k; walk LF until a sampled row.
-__global__ __launch_bounds__(kBlock) void k_locate_walk(DevIndex ix, const int32_t *__restrict__ range, int32_t n,
+template <int kBlock>
+FMX_KERNEL(kBlock) void k_locate_walk(DevIndex ix, const int32_t *__restrict__ range, int32_t n,
                                                         int32_t max_matches, int32_t *__restrict__ locs,
                                                         int32_t loc_cap, int32_t slots, int32_t *__restrict__ found,
                                                         int32_t *__restrict__ lf_steps,
                                                         int32_t *__restrict__ status_out) {
-    __shared__ uint16_t s_inv[32768];
+    __shared__ uint16_t s_inv[kInvEntries];
     stage_inverse_table(s_inv, ix.inv_global);
     const int64_t total = (int64_t)n * slots;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -108,12 +121,13 @@ __global__ __launch_bounds__(kBlock) void k_locate_walk(DevIndex ix, const int32
 }
 
 // FM:564-608
-__global__ __launch_bounds__(kBlock) void k_extract(DevIndex ix, const int32_t *__restrict__ starts,
+template <int kBlock>
+FMX_KERNEL(kBlock) void k_extract(DevIndex ix, const int32_t *__restrict__ starts,
                                                     const int32_t *__restrict__ stops, int32_t n,
                                                     uint16_t *__restrict__ dst, int32_t dst_len, int32_t offset,
                                                     int32_t *__restrict__ out_len, int32_t *__restrict__ lf_steps,
                                                     int32_t *__restrict__ status_out) {
-    __shared__ uint16_t s_inv[32768];
+    __shared__ uint16_t s_inv[kInvEntries];
     stage_inverse_table(s_inv, ix.inv_global);
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) {
@@ -128,14 +142,15 @@ __global__ __launch_bounds__(kBlock) void k_extract(DevIndex ix, const int32_t *
 }
 
 // FM:640-759 (mode 0), FM:772-831 (mode 1), FM:844-922 (mode 2)
-__global__ __launch_bounds__(kBlock) void k_extract_boundary(DevIndex ix, const int32_t *__restrict__ froms,
+template <int kBlock>
+FMX_KERNEL(kBlock) void k_extract_boundary(DevIndex ix, const int32_t *__restrict__ froms,
                                                              int32_t n, uint16_t boundary, int mode,
                                                              uint16_t *__restrict__ dst, int32_t dst_len,
                                                              int32_t offset, int32_t *__restrict__ out_len,
                                                              int32_t *__restrict__ lf_steps,
                                                              int32_t *__restrict__ status_out,
                                                              int32_t *__restrict__ aux_out) {
-    __shared__ uint16_t s_inv[32768];
+    __shared__ uint16_t s_inv[kInvEntries];
     stage_inverse_table(s_inv, ix.inv_global);
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     const int32_t mapped_boundary = fm_map(ix, boundary);  // FM:658
@@ -151,21 +166,108 @@ __global__ __launch_bounds__(kBlock) void k_extract_boundary(DevIndex ix, const 
     }
 }
 
+// sort key of a pattern: its last `chars` characters as alphabet codes, `bits` bits each, the LAST
+// character most significant (it is consumed first, FM:456-457)
+__global__ void k_make_keys(DevIndex ix, const uint16_t *__restrict__ pat, const int32_t *__restrict__ pat_off,
+                            int32_t n, int chars, int bits, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int32_t beg = pat_off[p], m = pat_off[p + 1] - beg;
+    uint32_t key = 0;
+    for (int j = 0; j < chars; ++j) {
+        const uint32_t c = (j < m) ? (uint32_t)fm_map(ix, pat[beg + m - 1 - j]) : 0u;
+        key = (key << bits) | c;
+    }
+    keys[p] = key;
+    vals[p] = (uint32_t)p;
+}
+
 // ---- launchers (called from fmx_api.cpp) -----------------------------------------------------
 
-static int grid_for(int64_t lanes, int n_cu) {
-    int64_t blocks = (lanes + kBlock - 1) / kBlock;
-    const int64_t cap = (int64_t)n_cu * 8;  // a few waves of workgroups per CU, grid-stride the rest
+// tunables (fmx_set_option): workgroup size and how many workgroups per CU the grid is capped at
+static int g_block = 512;
+static int g_groups_per_cu = 8;
+static int g_sort_min = 16384;  // batches at least this large are processed in suffix-sorted order (0 = never)
+static int g_sort_bits = 28;    // key width: floor(sort_bits / bits-per-code) trailing characters
+
+int set_option(const char *name, int value) {
+    if (!strcmp(name, "block")) {
+        if (value != 512 && value != 1024) return -1;
+        g_block = value;
+        return 0;
+    }
+    if (!strcmp(name, "groups_per_cu")) {
+        if (value < 1 || value > 64) return -1;
+        g_groups_per_cu = value;
+        return 0;
+    }
+    if (!strcmp(name, "sort_min")) {
+        if (value < 0) return -1;
+        g_sort_min = value;
+        return 0;
+    }
+    if (!strcmp(name, "sort_bits")) {
+        if (value < 1 || value > 32) return -1;
+        g_sort_bits = value;
+        return 0;
+    }
+    return -1;
+}
+
+static int grid_for(int64_t lanes, int block, int n_cu) {
+    int64_t blocks = (lanes + block - 1) / block;
+    const int64_t cap = (int64_t)n_cu * g_groups_per_cu;  // a few rounds of workgroups per CU, grid-stride the rest
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
 
-int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_t *off, int32_t n, int32_t *counts,
-                 int32_t *lf, int32_t *status, int32_t *range, hipStream_t st) {
+#define FMX_DISPATCH(KERNEL, LANES, ...)                                                                     \
+    do {                                                                                                     \
+        const int blk__ = g_block;                                                                           \
+        const dim3 grid__(grid_for((LANES), blk__, n_cu));                                                   \
+        if (blk__ == 1024)                                                                                   \
+            hipLaunchKernelGGL(KERNEL<1024>, grid__, dim3(1024), 0, st, __VA_ARGS__);                        \
+        else                                                                                                 \
+            hipLaunchKernelGGL(KERNEL<512>, grid__, dim3(512), 0, st, __VA_ARGS__);                          \
+    } while (0)
+
+// bytes of scratch launch_count needs to sort a batch of n patterns (0 = the batch is not sorted)
+size_t count_workspace_bytes(int32_t n) {
+    if (g_sort_min <= 0 || n < g_sort_min) return 0;
+    size_t temp = 0;
+    uint32_t *nul = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, temp, nul, nul, nul, nul, (size_t)n, 0u, 32u, (hipStream_t)0, false);
+    return (size_t)n * 16 + ((temp + 255) & ~(size_t)255) + 256;
+}
+
+// suffix-key sort of the batch: perm_out[q] = index of the q-th pattern in processing order.
+// workspace: count_workspace_bytes(n) bytes.  Returns a hipError_t value.
+int launch_count_plan(const DevIndex &ix, const uint16_t *pat, const int32_t *off, int32_t n, void *workspace,
+                      size_t workspace_bytes, const uint32_t **perm_out, hipStream_t st) {
+    *perm_out = nullptr;
+    if (n <= 0 || !workspace || workspace_bytes < (size_t)n * 16 + 256) return 0;
+    int bits = 1;
+    while ((1 << bits) < ix.wt_sigma && bits < 15) ++bits;
+    int chars = g_sort_bits / bits;
+    if (chars < 1) chars = 1;
+    if (chars * bits > 32) chars = 32 / bits;
+    uint32_t *keys_in = static_cast<uint32_t *>(workspace);
+    uint32_t *keys_out = keys_in + n, *vals_in = keys_out + n, *vals_out = vals_in + n;
+    void *temp = vals_out + n;
+    size_t temp_bytes = workspace_bytes - (size_t)n * 16;
+    hipLaunchKernelGGL(k_make_keys, dim3((n + 255) / 256), dim3(256), 0, st, ix, pat, off, n, chars, bits, keys_in, vals_in);
+    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
+                                             (unsigned)(chars * bits), st, false);
+    if (e != hipSuccess) return (int)e;
+    *perm_out = vals_out;
+    return (int)hipGetLastError();
+}
+
+int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_t *off, const uint32_t *perm, int32_t n,
+                 int32_t *counts, int32_t *lf, int32_t *status, int32_t *range, hipStream_t st) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_count, dim3(grid_for(2 * (int64_t)n, n_cu)), dim3(kBlock), 0, st, ix, pat, off, n, counts, lf,
-                       status, range);
+    FMX_DISPATCH(k_count, 2 * (int64_t)n, ix, pat, off, perm, n, counts, lf, status, range);
     return (int)hipGetLastError();
 }
 
@@ -175,16 +277,14 @@ int launch_locate_walk(const DevIndex &ix, int n_cu, const int32_t *range, int32
     if (n <= 0) return 0;
     int32_t slots = (max_matches > 0 && max_matches < loc_cap) ? max_matches : loc_cap;
     if (slots < 1) slots = 1;
-    hipLaunchKernelGGL(k_locate_walk, dim3(grid_for((int64_t)n * slots, n_cu)), dim3(kBlock), 0, st, ix, range, n,
-                       max_matches, locs, loc_cap, slots, found, lf, status);
+    FMX_DISPATCH(k_locate_walk, (int64_t)n * slots, ix, range, n, max_matches, locs, loc_cap, slots, found, lf, status);
     return (int)hipGetLastError();
 }
 
 int launch_extract(const DevIndex &ix, int n_cu, const int32_t *start, const int32_t *stop, int32_t n, uint16_t *dst,
                    int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf, int32_t *status, hipStream_t st) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_extract, dim3(grid_for(n, n_cu)), dim3(kBlock), 0, st, ix, start, stop, n, dst, dst_len,
-                       offset, out_len, lf, status);
+    FMX_DISPATCH(k_extract, (int64_t)n, ix, start, stop, n, dst, dst_len, offset, out_len, lf, status);
     return (int)hipGetLastError();
 }
 
@@ -192,8 +292,8 @@ int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, i
                             uint16_t *dst, int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf,
                             int32_t *status, int32_t *aux, hipStream_t st) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_extract_boundary, dim3(grid_for(n, n_cu)), dim3(kBlock), 0, st, ix, from, n, boundary, mode,
-                       dst, dst_len, offset, out_len, lf, status, aux);
+    FMX_DISPATCH(k_extract_boundary, (int64_t)n, ix, from, n, boundary, mode, dst, dst_len, offset, out_len, lf, status,
+                 aux);
     return (int)hipGetLastError();
 }
 

@@ -39,6 +39,11 @@ void orc_counters_get(OrcCounters *out) {
     out->wt_levels += g_cnt_total.wt_levels;
     out->quirk_runblock_right += g_cnt_total.quirk_runblock_right;
     out->quirk_clamped_right += g_cnt_total.quirk_clamped_right;
+    out->rank_calls += g_cnt_total.rank_calls;
+    out->absent_superblock += g_cnt_total.absent_superblock;
+    out->absent_block += g_cnt_total.absent_block;
+    out->absent_scan_steps += g_cnt_total.absent_scan_steps;
+    out->run_block += g_cnt_total.run_block;
 }
 #define CNT_BYTES(n) (g_cnt.alg_bytes += (uint64_t)(n))
 
@@ -1042,16 +1047,22 @@ int64_t orc_wfbb_rank(const OrcWfbb *w, int64_t position, int16_t symbol, int *s
     int64_t r_sb = w->super_rank[sb_id * sigma_g + symbol];
     int64_t r_hb = w->hyper_rank[hb_id * sigma_g + symbol];
     CNT_BYTES(2 + 4 + 4 + 8);
+    g_cnt.rank_calls++;
 
-    if (sb_c >= sb_sigma) return r_hb + r_sb; /* WFBB:1040-1042 */
+    if (sb_c >= sb_sigma) { /* WFBB:1040-1042 */
+        g_cnt.absent_superblock++;
+        return r_hb + r_sb;
+    }
 
     int16_t block_c = sb->mapping[((int64_t)sb_c << blocks_in_sb_log) + block_id];
     CNT_BYTES(2);
     if (block_c == sigma_g - 1) { /* WFBB:1048-1110 */
+        g_cnt.absent_block++;
         ++block_id;
         int64_t blocks_in_sb = 1LL << blocks_in_sb_log;
         while (block_id < blocks_in_sb) {
             CNT_BYTES(2);
+            g_cnt.absent_scan_steps++;
             if (sb->mapping[((int64_t)sb_c << blocks_in_sb_log) + block_id] != sigma_g - 1) break;
             ++block_id;
         }
@@ -1094,7 +1105,10 @@ int64_t orc_wfbb_rank(const OrcWfbb *w, int64_t position, int16_t symbol, int *s
     int64_t r_b = rd24(sb->var + vtmp + block_c * 5 + 2);
     CNT_BYTES(16 + 5);
 
-    if (tree_height == 0) return r_hb + r_sb + r_b + block_index; /* WFBB:1141-1146 */
+    if (tree_height == 0) { /* WFBB:1141-1146 */
+        g_cnt.run_block++;
+        return r_hb + r_sb + r_b + block_index;
+    }
 
     int64_t code_result = restore_code_from_block_header(block_c, sb->var, (int)var_off, tree_height);
     int32_t code = (int32_t)((uint64_t)code_result >> 32);
@@ -1765,8 +1779,8 @@ void orc_fm_count_batch(const OrcFmIndex *f, const uint16_t *pat, const int32_t 
     (void)threads;
 #ifdef _OPENMP
     if (threads > 1) {
-        uint64_t lf = 0, ab = 0, lv = 0, q1 = 0, q2 = 0;
-#pragma omp parallel num_threads(threads) reduction(+ : lf, ab, lv, q1, q2)
+        uint64_t lf = 0, ab = 0, lv = 0, q1 = 0, q2 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+#pragma omp parallel num_threads(threads) reduction(+ : lf, ab, lv, q1, q2, c1, c2, c3, c4, c5)
         {
             memset(&g_cnt, 0, sizeof g_cnt);
 #pragma omp for schedule(static)
@@ -1780,6 +1794,11 @@ void orc_fm_count_batch(const OrcFmIndex *f, const uint16_t *pat, const int32_t 
             lv += g_cnt.wt_levels;
             q1 += g_cnt.quirk_runblock_right;
             q2 += g_cnt.quirk_clamped_right;
+            c1 += g_cnt.rank_calls;
+            c2 += g_cnt.absent_superblock;
+            c3 += g_cnt.absent_block;
+            c4 += g_cnt.absent_scan_steps;
+            c5 += g_cnt.run_block;
             memset(&g_cnt, 0, sizeof g_cnt);
         }
         g_cnt_total.lf_steps += lf;
@@ -1787,6 +1806,11 @@ void orc_fm_count_batch(const OrcFmIndex *f, const uint16_t *pat, const int32_t 
         g_cnt_total.wt_levels += lv;
         g_cnt_total.quirk_runblock_right += q1;
         g_cnt_total.quirk_clamped_right += q2;
+        g_cnt_total.rank_calls += c1;
+        g_cnt_total.absent_superblock += c2;
+        g_cnt_total.absent_block += c3;
+        g_cnt_total.absent_scan_steps += c4;
+        g_cnt_total.run_block += c5;
         return;
     }
 #endif

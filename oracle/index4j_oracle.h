@@ -55,6 +55,11 @@ typedef struct {
     uint64_t wt_levels;  /* wavelet-tree levels traversed (RRR rankOnes calls inside WFBB) */
     uint64_t quirk_runblock_right;   /* WFBB:1081 executed with treeHeight==0 (offset -4 read) */
     uint64_t quirk_clamped_right;    /* WFBB:1071-1104 with a clamped mapping entry (no fix-up) */
+    uint64_t rank_calls;             /* WFBB.rank calls that reach the tables */
+    uint64_t absent_superblock;      /* WFBB:1040-1042 exits */
+    uint64_t absent_block;           /* WFBB:1048 taken */
+    uint64_t absent_scan_steps;      /* mapping entries read by the scan of WFBB:1053-1059 */
+    uint64_t run_block;              /* WFBB:1141-1146 exits */
 } OrcCounters;
 
 void orc_counters_reset(void);

@@ -17,6 +17,11 @@ class Counters(C.Structure):
         ("wt_levels", C.c_uint64),
         ("quirk_runblock_right", C.c_uint64),
         ("quirk_clamped_right", C.c_uint64),
+        ("rank_calls", C.c_uint64),
+        ("absent_superblock", C.c_uint64),
+        ("absent_block", C.c_uint64),
+        ("absent_scan_steps", C.c_uint64),
+        ("run_block", C.c_uint64),
     ]
 
 
