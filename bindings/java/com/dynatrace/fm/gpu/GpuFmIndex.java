@@ -1,0 +1,200 @@
+/*
+ * GpuFmIndex — Java host class that keeps index4j's FmIndex query API and forwards the backward-search
+ * path to libfmx.so (MI355X) through JNI.  SOURCE ONLY: the build image has no JDK, so this file has
+ * never been compiled; it documents the binding a maintainer adds (see INTEGRATION.md).
+ *
+ * Drop-in recipe: build (or deserialize) a com.dynatrace.fm.FmIndex exactly as today, then
+ *     GpuFmIndex gpu = GpuFmIndex.fromFmIndex(fmIndex, 0);          // FmIndex.write bytes -> fmx_load -> HBM
+ * and call count / locate / extract / extractUntilBoundary* with the reference's signatures, or the
+ * batch variants.  Exceptions carry the reference's types and messages (FmIndex.java:566-576, 591-593,
+ * 619-625, 659-661, 732-737).
+ */
+package com.dynatrace.fm.gpu;
+
+import com.dynatrace.fm.FmIndex;
+import com.dynatrace.serialization.Serialization;
+import java.io.IOException;
+
+public final class GpuFmIndex implements AutoCloseable {
+
+    static {
+        System.loadLibrary("fmx_jni"); // bindings/jni/fmx_jni.c, linked against libfmx.so
+    }
+
+    private long handle; // fmx_index*
+
+    private GpuFmIndex(long handle) {
+        this.handle = handle;
+    }
+
+    /** Ships FmIndex.write(...) bytes (Serialization.writeToByteArray, SER:67-79) to the GPU. */
+    public static GpuFmIndex fromFmIndex(FmIndex index, int device) throws IOException {
+        byte[] bytes = Serialization.writeToByteArray(FmIndex::write, index);
+        return fromSerialized(bytes, device);
+    }
+
+    public static GpuFmIndex fromSerialized(byte[] bytes, int device) throws IOException {
+        long h = nativeLoad(bytes, device);
+        return new GpuFmIndex(h);
+    }
+
+    /** new FmIndexBuilder().setSampleRate(s).setEnableExtraction(e).build(text) built natively (FMB:34-62). */
+    public static GpuFmIndex build(char[] text, int sampleRate, boolean enableExtraction, int device) {
+        return new GpuFmIndex(nativeBuild(text, sampleRate, enableExtraction, device));
+    }
+
+    // ---- the reference's scalar signatures (FmIndex.java:443-941) ----
+    public int count(char[] pattern) {
+        return count(pattern, 0, pattern.length);
+    }
+
+    public int count(char[] pattern, int offset, int length) {
+        int[] counts = new int[1];
+        int[] status = new int[1];
+        nativeCountBatch(handle, slice(pattern, offset, length), new int[] {0, length}, 1, counts, status);
+        rethrow(status[0], 0);
+        return counts[0];
+    }
+
+    public int locate(char[] pattern, int[] locations) {
+        return locate(pattern, 0, pattern.length, locations, -1);
+    }
+
+    public int locate(char[] pattern, int offset, int length, int[] locations, int maxMatches) {
+        int[] found = new int[1];
+        int[] status = new int[1];
+        nativeLocateBatch(handle, slice(pattern, offset, length), new int[] {0, length}, 1, maxMatches, locations,
+                locations.length, found, status);
+        rethrow(status[0], 0);
+        return found[0];
+    }
+
+    public int extract(int start, int stop, char[] destination, int offset) {
+        int[] len = new int[1];
+        int[] status = new int[1];
+        nativeExtractBatch(handle, new int[] {start}, new int[] {stop}, 1, destination, destination.length, offset, len,
+                status);
+        rethrow(status[0], 0);
+        return len[0];
+    }
+
+    public int extractUntilBoundary(int from, char[] destination, int offset, char boundary) {
+        return boundary(0, from, destination, offset, boundary);
+    }
+
+    public int extractUntilBoundaryLeft(int from, char[] destination, int offset, char boundary) {
+        return boundary(1, from, destination, offset, boundary);
+    }
+
+    public int extractUntilBoundaryRight(int from, char[] destination, int offset, char boundary) {
+        return boundary(2, from, destination, offset, boundary);
+    }
+
+    public int getInputLength() {
+        return nativeInputLength(handle);
+    }
+
+    public int getAlphabetLength() {
+        return nativeAlphabetLength(handle);
+    }
+
+    // ---- batch surface: one kernel launch for the whole batch ----
+    /** patterns concatenated in {@code chars}; pattern i is chars[offsets[i] .. offsets[i+1]). */
+    public int[] countBatch(char[] chars, int[] offsets) {
+        int n = offsets.length - 1;
+        int[] counts = new int[n];
+        int[] status = new int[n];
+        nativeCountBatch(handle, chars, offsets, n, counts, status);
+        for (int s : status) {
+            rethrow(s, 0);
+        }
+        return counts;
+    }
+
+    /** locations: n rows of maxMatches ints; returns the number located per pattern. */
+    public int[] locateBatch(char[] chars, int[] offsets, int maxMatches, int[] locations) {
+        int n = offsets.length - 1;
+        int[] found = new int[n];
+        int[] status = new int[n];
+        nativeLocateBatch(handle, chars, offsets, n, maxMatches, locations, maxMatches, found, status);
+        for (int s : status) {
+            rethrow(s, 0);
+        }
+        return found;
+    }
+
+    @Override
+    public void close() {
+        if (handle != 0) {
+            nativeFree(handle);
+            handle = 0;
+        }
+    }
+
+    private int boundary(int mode, int from, char[] destination, int offset, char boundary) {
+        int[] len = new int[1];
+        int[] status = new int[1];
+        int[] aux = new int[1];
+        nativeExtractBoundaryBatch(handle, new int[] {from}, 1, boundary, mode, destination, destination.length, offset,
+                len, status, aux);
+        rethrow(status[0], aux[0]);
+        return len[0];
+    }
+
+    private static char[] slice(char[] pattern, int offset, int length) {
+        if (offset == 0 && length == pattern.length) {
+            return pattern;
+        }
+        char[] s = new char[Math.max(length, 0)];
+        System.arraycopy(pattern, offset, s, 0, s.length); // throws like pattern[i] would (FM:456-457)
+        return s;
+    }
+
+    /** status codes of include/fmx.h -> the reference's exception types and messages. */
+    private static void rethrow(int status, int aux) {
+        switch (status) {
+            case 0:
+                return;
+            case 1:
+                throw new RuntimeException("Text recovery not enabled at build time");
+            case 2:
+                throw new RuntimeException("Requested position less than 0");
+            case 3:
+                throw new RuntimeException("Stop position longer than index string");
+            case 4:
+                throw new RuntimeException("Supplied destination is not large enough");
+            case 5:
+                throw new RuntimeException("Requested position longer than index string");
+            case 6:
+                throw new IllegalArgumentException("Supplied destination for extraction has size zero");
+            case 7:
+                throw new IllegalArgumentException("Boundary does not exist");
+            case 8:
+                throw new RuntimeException(
+                        "Extraction does not fit in the supplied destination. Currently extracted: " + aux);
+            default:
+                throw new ArrayIndexOutOfBoundsException();
+        }
+    }
+
+    private static native long nativeLoad(byte[] serialized, int device) throws IOException;
+
+    private static native long nativeBuild(char[] text, int sampleRate, boolean enableExtraction, int device);
+
+    private static native void nativeFree(long handle);
+
+    private static native int nativeInputLength(long handle);
+
+    private static native int nativeAlphabetLength(long handle);
+
+    private static native void nativeCountBatch(long handle, char[] chars, int[] offsets, int n, int[] counts, int[] status);
+
+    private static native void nativeLocateBatch(long handle, char[] chars, int[] offsets, int n, int maxMatches,
+            int[] locations, int locCap, int[] found, int[] status);
+
+    private static native void nativeExtractBatch(long handle, int[] start, int[] stop, int n, char[] destination,
+            int dstLen, int offset, int[] outLen, int[] status);
+
+    private static native void nativeExtractBoundaryBatch(long handle, int[] from, int n, char boundary, int mode,
+            char[] destination, int dstLen, int offset, int[] outLen, int[] status, int[] aux);
+}

@@ -1,0 +1,137 @@
+/*
+ * fmx_jni.c — JNI glue between com.dynatrace.fm.gpu.GpuFmIndex and libfmx.so (include/fmx.h).
+ * SOURCE ONLY: never compiled here (no JDK / jni.h in the build image).  Build on a JDK host with
+ *   cc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude \
+ *      bindings/jni/fmx_jni.c -Lindex4j_amd -lfmx -o libfmx_jni.so
+ * Java `char` is an unsigned 16-bit UTF-16 code unit == the uint16_t the C ABI takes; `int` == int32_t.
+ */
+#include <jni.h>
+#include <stdint.h>
+
+#include "fmx.h"
+
+#define CLS "com/dynatrace/fm/gpu/GpuFmIndex"
+
+static void throw_lib_error(JNIEnv *env, int rc) {
+    const char *msg = fmx_last_error();
+    const char *cls = "java/lang/RuntimeException";
+    if (rc == FMX_E_VERSION || rc == FMX_E_FORMAT) cls = "java/io/IOException";           /* SER:46-56 */
+    if (rc == FMX_E_ALPHABET) {                                                             /* FM:423-426 */
+        cls = "java/lang/IllegalArgumentException";
+        msg = "Input has more than 32767 different symbols";
+    }
+    (*env)->ThrowNew(env, (*env)->FindClass(env, cls), msg ? msg : "libfmx error");
+}
+
+JNIEXPORT jlong JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeLoad(JNIEnv *env, jclass c, jbyteArray ser, jint device) {
+    jsize len = (*env)->GetArrayLength(env, ser);
+    jbyte *p = (*env)->GetByteArrayElements(env, ser, NULL);
+    fmx_index *idx = NULL;
+    int rc = fmx_load((const uint8_t *)p, (size_t)len, &idx);
+    (*env)->ReleaseByteArrayElements(env, ser, p, JNI_ABORT);
+    if (rc == FMX_OK) rc = fmx_to_device(idx, device);
+    if (rc != FMX_OK) {
+        fmx_free(idx);
+        throw_lib_error(env, rc);
+        return 0;
+    }
+    return (jlong)(intptr_t)idx;
+}
+
+JNIEXPORT jlong JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeBuild(JNIEnv *env, jclass c, jcharArray text,
+                                                                        jint sampleRate, jboolean extract, jint device) {
+    jsize n = (*env)->GetArrayLength(env, text);
+    jchar *p = (*env)->GetCharArrayElements(env, text, NULL);
+    fmx_index *idx = NULL;
+    int rc = fmx_build((const uint16_t *)p, n, sampleRate, extract ? 1 : 0, &idx);
+    (*env)->ReleaseCharArrayElements(env, text, p, JNI_ABORT);
+    if (rc == FMX_OK) rc = fmx_to_device(idx, device);
+    if (rc != FMX_OK) {
+        fmx_free(idx);
+        throw_lib_error(env, rc);
+        return 0;
+    }
+    return (jlong)(intptr_t)idx;
+}
+
+JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeFree(JNIEnv *env, jclass c, jlong h) {
+    fmx_free((fmx_index *)(intptr_t)h);
+}
+JNIEXPORT jint JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeInputLength(JNIEnv *env, jclass c, jlong h) {
+    return fmx_input_length((const fmx_index *)(intptr_t)h);
+}
+JNIEXPORT jint JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeAlphabetLength(JNIEnv *env, jclass c, jlong h) {
+    return fmx_alphabet_length((const fmx_index *)(intptr_t)h);
+}
+
+JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeCountBatch(JNIEnv *env, jclass c, jlong h, jcharArray chars,
+                                                                            jintArray offsets, jint n, jintArray counts,
+                                                                            jintArray status) {
+    jchar *pc = (*env)->GetCharArrayElements(env, chars, NULL);
+    jint *po = (*env)->GetIntArrayElements(env, offsets, NULL);
+    jint *pn = (*env)->GetIntArrayElements(env, counts, NULL);
+    jint *ps = (*env)->GetIntArrayElements(env, status, NULL);
+    int rc = fmx_count_batch((const fmx_index *)(intptr_t)h, (const uint16_t *)pc, (const int32_t *)po, n, (int32_t *)pn, NULL,
+                             (int32_t *)ps);
+    (*env)->ReleaseCharArrayElements(env, chars, pc, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, offsets, po, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, counts, pn, 0);
+    (*env)->ReleaseIntArrayElements(env, status, ps, 0);
+    if (rc != FMX_OK) throw_lib_error(env, rc);
+}
+
+JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeLocateBatch(JNIEnv *env, jclass c, jlong h, jcharArray chars,
+                                                                             jintArray offsets, jint n, jint maxMatches,
+                                                                             jintArray locations, jint locCap,
+                                                                             jintArray found, jintArray status) {
+    jchar *pc = (*env)->GetCharArrayElements(env, chars, NULL);
+    jint *po = (*env)->GetIntArrayElements(env, offsets, NULL);
+    jint *pl = (*env)->GetIntArrayElements(env, locations, NULL);
+    jint *pf = (*env)->GetIntArrayElements(env, found, NULL);
+    jint *ps = (*env)->GetIntArrayElements(env, status, NULL);
+    int rc = fmx_locate_batch((const fmx_index *)(intptr_t)h, (const uint16_t *)pc, (const int32_t *)po, n, maxMatches,
+                              (int32_t *)pl, locCap, (int32_t *)pf, NULL, (int32_t *)ps);
+    (*env)->ReleaseCharArrayElements(env, chars, pc, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, offsets, po, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, locations, pl, 0);
+    (*env)->ReleaseIntArrayElements(env, found, pf, 0);
+    (*env)->ReleaseIntArrayElements(env, status, ps, 0);
+    if (rc != FMX_OK) throw_lib_error(env, rc);
+}
+
+JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeExtractBatch(JNIEnv *env, jclass c, jlong h, jintArray start,
+                                                                              jintArray stop, jint n, jcharArray dst,
+                                                                              jint dstLen, jint offset, jintArray outLen,
+                                                                              jintArray status) {
+    jint *pa = (*env)->GetIntArrayElements(env, start, NULL);
+    jint *pb = (*env)->GetIntArrayElements(env, stop, NULL);
+    jchar *pd = (*env)->GetCharArrayElements(env, dst, NULL);
+    jint *pl = (*env)->GetIntArrayElements(env, outLen, NULL);
+    jint *ps = (*env)->GetIntArrayElements(env, status, NULL);
+    int rc = fmx_extract_batch((const fmx_index *)(intptr_t)h, (const int32_t *)pa, (const int32_t *)pb, n, (uint16_t *)pd,
+                               dstLen, offset, (int32_t *)pl, NULL, (int32_t *)ps);
+    (*env)->ReleaseIntArrayElements(env, start, pa, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, stop, pb, JNI_ABORT);
+    (*env)->ReleaseCharArrayElements(env, dst, pd, 0);
+    (*env)->ReleaseIntArrayElements(env, outLen, pl, 0);
+    (*env)->ReleaseIntArrayElements(env, status, ps, 0);
+    if (rc != FMX_OK) throw_lib_error(env, rc);
+}
+
+JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeExtractBoundaryBatch(
+    JNIEnv *env, jclass c, jlong h, jintArray from, jint n, jchar boundary, jint mode, jcharArray dst, jint dstLen,
+    jint offset, jintArray outLen, jintArray status, jintArray aux) {
+    jint *pa = (*env)->GetIntArrayElements(env, from, NULL);
+    jchar *pd = (*env)->GetCharArrayElements(env, dst, NULL);
+    jint *pl = (*env)->GetIntArrayElements(env, outLen, NULL);
+    jint *ps = (*env)->GetIntArrayElements(env, status, NULL);
+    jint *px = (*env)->GetIntArrayElements(env, aux, NULL);
+    int rc = fmx_extract_boundary_batch((const fmx_index *)(intptr_t)h, (const int32_t *)pa, n, (uint16_t)boundary, mode,
+                                        (uint16_t *)pd, dstLen, offset, (int32_t *)pl, NULL, (int32_t *)ps, (int32_t *)px);
+    (*env)->ReleaseIntArrayElements(env, from, pa, JNI_ABORT);
+    (*env)->ReleaseCharArrayElements(env, dst, pd, 0);
+    (*env)->ReleaseIntArrayElements(env, outLen, pl, 0);
+    (*env)->ReleaseIntArrayElements(env, status, ps, 0);
+    (*env)->ReleaseIntArrayElements(env, aux, px, 0);
+    if (rc != FMX_OK) throw_lib_error(env, rc);
+}

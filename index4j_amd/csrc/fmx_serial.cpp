@@ -21,6 +21,7 @@ struct Reader {
     const uint8_t *p;
     size_t n, pos = 0;
     int err = 0;  // 1 truncated, 2 bad version, 3 malformed
+    int bad_version = 0;
     size_t left() const { return n - pos; }
     bool need(size_t k) {
         if (err) return false;
@@ -51,7 +52,11 @@ struct Reader {
         return (int64_t)v;
     }
     void version() {  // SER:46-56
-        if (u8() != 0 && !err) err = 2;
+        const int v = u8();
+        if (v != 0 && !err) {
+            err = 2;
+            bad_version = v;
+        }
     }
     // a length prefix that must be satisfiable by the remaining bytes (elem = bytes per element)
     int32_t count(size_t elem) {
@@ -288,7 +293,9 @@ int parse_model(const uint8_t *buf, size_t len, FmModel &m, std::string &err) {
     read_wavelet(r, m.wt);
     if (!r.err && (m.sample_rate <= 0 || m.length <= 0)) r.err = 3;
     if (r.err) {
-        err = r.err == 2 ? "Incompatible serial versions!" : (r.err == 1 ? "truncated stream" : "malformed stream");
+        // SER:35-36: "Incompatible serial versions! Expected version %d but was %d."
+        err = r.err == 2 ? "Incompatible serial versions! Expected version 0 but was " + std::to_string(r.bad_version) + "."
+                         : (r.err == 1 ? "truncated stream" : "malformed stream");
         return r.err;
     }
     return 0;
