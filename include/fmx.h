@@ -117,7 +117,7 @@ int fmx_extract_boundary_batch(const fmx_index *idx, const int32_t *from, int32_
 int fmx_count_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
                         int32_t *d_counts, int32_t *d_lf_steps, int32_t *d_status, void *stream);
 /* The two stages of fmx_count_batch_dev, callable separately (bench.py times the second one alone):
- * plan = processing order of the batch (device radix sort on the patterns' trailing characters, so
+ * plan = processing order of the batch (device bucket sort on the patterns' trailing characters, so
  * that neighbouring lanes walk the same SA intervals); *d_perm points into per-stream scratch owned by
  * the index (valid until the next plan on that stream) or is NULL for small batches.
  * ordered = the k_count kernel over that order; results are written at the ORIGINAL pattern index. */

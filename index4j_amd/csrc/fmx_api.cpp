@@ -20,7 +20,7 @@ int launch_count_plan(const DevIndex &, const uint16_t *, const int32_t *, int32
                       hipStream_t);
 int launch_count(const DevIndex &, int, const uint16_t *, const int32_t *, const uint32_t *, int32_t, int32_t *,
                  int32_t *, int32_t *, int32_t *, hipStream_t);
-size_t count_workspace_bytes(int32_t n);
+size_t count_workspace_bytes(const DevIndex &, int32_t n);
 int launch_locate_walk(const DevIndex &, int, const int32_t *, int32_t, int32_t, int32_t *, int32_t, int32_t *,
                        int32_t *, int32_t *, hipStream_t);
 int launch_extract(const DevIndex &, int, const int32_t *, const int32_t *, int32_t, uint16_t *, int32_t, int32_t,
@@ -329,7 +329,7 @@ static int plan_order(const fmx_index *idx, const uint16_t *d_pat, const int32_t
                       const uint32_t **perm) {
     *perm = nullptr;
     void *ws = nullptr;
-    const size_t ws_bytes = fmx::count_workspace_bytes(n);
+    const size_t ws_bytes = fmx::count_workspace_bytes(idx->dev, n);
     int rc = get_workspace(idx, stream, ws_bytes, &ws);
     if (rc) return rc;
     if (!ws) return FMX_OK;

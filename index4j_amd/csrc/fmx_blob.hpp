@@ -35,7 +35,7 @@
 namespace fmx {
 
 constexpr uint32_t kBlobMagic = 0x31584D46u;  // "FMX1"
-constexpr uint32_t kBlobVersion = 2;
+constexpr uint32_t kBlobVersion = 3;
 
 struct RrrRecord {         // 16 bytes: 16 blocks of 15 bits
     uint32_t ones_before;  // 1-bits in all earlier blocks
@@ -43,7 +43,7 @@ struct RrrRecord {         // 16 bytes: 16 blocks of 15 bits
     uint64_t classes;      // block j's class in bits [4j, 4j+4)
 };
 
-struct RrrDesc {           // 32 bytes
+struct RrrDesc {           // 32 bytes; the first 16 are what a rank needs (one dwordx4 load)
     uint32_t off_rec;      // RrrRecord[n_rec]
     uint32_t off_bits;     // offsets bit stream, 64-bit words LSB-first (+2 guard words)
     int32_t length;        // RRR:94
@@ -54,13 +54,13 @@ struct RrrDesc {           // 32 bytes
     int32_t pad;
 };
 
-struct SbDesc {            // 64 bytes
+struct SbDesc {            // 64 bytes; bytes 0..15 = header of every rank, bytes 32..47 = its RRR vector
     int16_t sigma;         // WFBB:1623 (superblock alphabet size - 1)
     int16_t bsl;           // WFBB:1624 blockSizeLog
-    int32_t n_blocks;
     uint32_t off_mapping;  // int16[(sigma+1) << (20 - bsl)], absent entries = -(distance to next present)
     uint32_t off_bh;       // BlockHdr[n_blocks]
     uint32_t off_var;      // variable-size block headers
+    int32_t n_blocks;
     int32_t var_len;
     int32_t mapping_len;
     int32_t pad;

@@ -67,6 +67,40 @@ FMX_HD int fmx_popc(uint32_t v) { return __builtin_popcount(v); }
 FMX_HD int fmx_popcll(uint64_t v) { return __builtin_popcountll(v); }
 #endif
 
+// keeps the compiler from narrowing a wide load whose value is masked afterwards (a 24-bit field
+// fetched as one dword must not become a byte + a short load: every load instruction is a trip through
+// the texture addresser, the scarce resource of these kernels)
+#if defined(__HIPCC__)
+#define FMX_OPAQUE32(v) asm volatile("" : "+v"(v))
+#define FMX_OPAQUE64(v) asm volatile("" : "+v"(v))
+#else
+#define FMX_OPAQUE32(v) (void)0
+#define FMX_OPAQUE64(v) (void)0
+#endif
+
+// 16 bytes of descriptor in one load
+struct Quad {
+    uint32_t x, y, z, w;
+};
+FMX_HD Quad ld_quad(const void *p) {
+    Quad q;
+    memcpy(&q, p, 16);
+    return q;
+}
+// unaligned 4 / 8 bytes from the variable-size block headers as ONE load
+FMX_HD uint32_t ld32u(const uint8_t *p) {
+    uint32_t v;
+    memcpy(&v, p, 4);
+    FMX_OPAQUE32(v);
+    return v;
+}
+FMX_HD uint64_t ld64u(const uint8_t *p) {
+    uint64_t v;
+    memcpy(&v, p, 8);
+    FMX_OPAQUE64(v);
+    return v;
+}
+
 // unaligned little-endian reads from the variable-size block headers (WFBB:240, 1107)
 FMX_HD uint32_t ld16(const uint8_t *p) {
     uint16_t v;
@@ -130,9 +164,24 @@ FMX_HD void rrr_scan_word(uint64_t w, int n, uint32_t &ones, uint32_t &obits) {
     obits += acc;
 }
 
+// the four fields of an RRR vector a query needs (the first 16 bytes of RrrDesc)
+struct RrrView {
+    uint32_t off_rec, off_bits;
+    int32_t length, total_ones;
+};
+FMX_HD RrrView rrr_view(const RrrDesc &d) {  // one 16-byte load when `d` lives in HBM
+    const Quad q = ld_quad(&d);
+    RrrView v;
+    v.off_rec = q.x;
+    v.off_bits = q.y;
+    v.length = (int32_t)q.z;
+    v.total_ones = (int32_t)q.w;
+    return v;
+}
+
 // decode the 15-bit block that holds bit `position` (0 <= position < length):
 // returns the block value; prefix = ones before the block (RRR:367-390 over the 16-block records)
-FMX_HD uint32_t rrr_decode(const uint8_t *base, const RrrDesc &d, const uint16_t *inv, uint32_t position,
+FMX_HD uint32_t rrr_decode(const uint8_t *base, const RrrView &d, const uint16_t *inv, uint32_t position,
                            uint32_t &prefix) {
     const uint32_t block_id = position / 15u;  // RRR:367
     const uint32_t j = block_id & 15u;
@@ -149,7 +198,7 @@ FMX_HD uint32_t rrr_decode(const uint8_t *base, const RrrDesc &d, const uint16_t
 }
 
 // RRR:358-396
-FMX_HD int32_t rrr_rank1(const uint8_t *base, const RrrDesc &d, const uint16_t *inv, int32_t position) {
+FMX_HD int32_t rrr_rank1(const uint8_t *base, const RrrView &d, const uint16_t *inv, int32_t position) {
     if (position < 0) return 0;
     if (position >= d.length) return d.total_ones;
     uint32_t prefix;
@@ -159,7 +208,7 @@ FMX_HD int32_t rrr_rank1(const uint8_t *base, const RrrDesc &d, const uint16_t *
 }
 
 // RRR:314-349; out-of-range is reported through *status (IllegalArgumentException in the reference)
-FMX_HD bool rrr_access(const uint8_t *base, const RrrDesc &d, const uint16_t *inv, int32_t position, int &status) {
+FMX_HD bool rrr_access(const uint8_t *base, const RrrView &d, const uint16_t *inv, int32_t position, int &status) {
     if (position < 0 || position >= d.length) {
         status = ST_JAVA_AIOOBE;
         return true;  // stops any walk that polls this bit
@@ -170,7 +219,7 @@ FMX_HD bool rrr_access(const uint8_t *base, const RrrDesc &d, const uint16_t *in
 }
 
 // rankOnes(p) and access(p) at the same position p < length: one decode (WFBB:1389-1393)
-FMX_HD int32_t rrr_rank1_access(const uint8_t *base, const RrrDesc &d, const uint16_t *inv, int32_t position,
+FMX_HD int32_t rrr_rank1_access(const uint8_t *base, const RrrView &d, const uint16_t *inv, int32_t position,
                                 bool &bit) {
     if (position >= d.length || position < 0) {  // rankOnes saturates; access would throw — unreachable for a
         bit = false;                             // well-formed tree (the node bit always exists)
@@ -183,15 +232,23 @@ FMX_HD int32_t rrr_rank1_access(const uint8_t *base, const RrrDesc &d, const uin
     return (int32_t)(prefix + (uint32_t)fmx_popc(block & ((1u << t) - 1u)));
 }
 
-// WFBB:250-278: block-local leaf index -> canonical (code, length)
+// WFBB:250-278: block-local leaf index -> canonical (code, length).  The per-level leaf counts are the
+// u16 at stride 4 of the level table; up to four levels come from one 16-byte load.
 FMX_HD void wt_restore_code(uint32_t block_c, const uint8_t *hdr, int32_t tree_height, uint32_t &code,
                             int32_t &code_length) {
     code = 0;
     code_length = 1;
     uint32_t leaf_count = 0;
+    int32_t lvl = 0;  // index of the level entry under inspection
+    Quad chunk = {0, 0, 0, 0};
     while (code_length < tree_height) {
+        if ((lvl & 3) == 0) {
+            memcpy(&chunk, hdr + 4 * lvl, 16);  // entries lvl..lvl+3 (guard bytes cover the tail)
+            FMX_OPAQUE32(chunk.x);
+        }
+        const uint32_t e = (lvl & 2) ? ((lvl & 1) ? chunk.w : chunk.z) : ((lvl & 1) ? chunk.y : chunk.x);
+        const uint32_t level_leaf_count = e & 0xffffu;
         code <<= 1;
-        const uint32_t level_leaf_count = ld16(hdr);
         if (leaf_count + level_leaf_count > block_c) {
             code += block_c - leaf_count;
             break;
@@ -199,12 +256,84 @@ FMX_HD void wt_restore_code(uint32_t block_c, const uint8_t *hdr, int32_t tree_h
         code += level_leaf_count;
         ++code_length;
         leaf_count += level_leaf_count;
-        hdr += 4;
+        ++lvl;
     }
     if (code_length == tree_height) {
         code <<= 1;
         code += block_c - leaf_count;
     }
+}
+
+// header fields of a superblock that every rank needs: the first 16 bytes of SbDesc in one load
+struct SbHead {
+    int32_t sigma, bsl;
+    uint32_t off_mapping, off_bh, off_var;
+};
+FMX_HD SbHead sb_head(const SbDesc &sd) {
+    const Quad q = ld_quad(&sd);
+    SbHead h;
+    h.sigma = (int32_t)(int16_t)(q.x & 0xffffu);
+    h.bsl = (int32_t)(int16_t)(q.x >> 16);
+    h.off_mapping = q.y;
+    h.off_bh = q.z;
+    h.off_var = q.w;
+    return h;
+}
+FMX_HD BlockHdr ld_block_hdr(const BlockHdr *p) {
+    const Quad q = ld_quad(p);
+    BlockHdr b;
+    b.bv_rank = (int32_t)q.x;
+    b.bv_offset = (int32_t)q.y;
+    b.var_off = (int32_t)q.z;
+    b.sigma = (int16_t)(q.w & 0xffffu);
+    b.tree_height = (int16_t)(q.w >> 16);
+    return b;
+}
+
+// one level of the tree walk shared by rank and inverseSelect (WFBB:1187-1278 / 1388-1489):
+// the cumulative one-counts of the level (u16 each): [left-1] and [left] come from one 4-byte load
+struct TreeWalk {
+    int32_t bv_rank, bv_offset, internal_nodes, left_siblings, left_total_bv, node_bv_size, depth_total_bv, node_rank;
+    const uint8_t *second;  // cumulative one-counts of the current level
+    const uint8_t *level;   // next entry of the level table
+};
+FMX_HD void tree_level_counts(const TreeWalk &t, int32_t &left_ones, int32_t &node_ones, int32_t &level_ones) {
+    if (t.left_siblings > 0) {
+        const uint32_t pair = ld32u(t.second + 2 * (t.left_siblings - 1));
+        left_ones = (int32_t)(pair & 0xffffu);                        // WFBB:1193-1206
+        node_ones = (int32_t)(pair >> 16) - left_ones;                // WFBB:1210-1214
+    } else {
+        left_ones = 0;
+        node_ones = (int32_t)ld16(t.second);
+    }
+    level_ones = (int32_t)ld16(t.second + 2 * (t.internal_nodes - 1));  // WFBB:1220-1229
+}
+FMX_HD void tree_descend(TreeWalk &t, bool bit, int32_t rank1, int32_t node_ones) {
+    const int32_t node_zeros = t.node_bv_size - node_ones;
+    const int32_t rank0 = t.node_rank - rank1;
+    t.second += 2 * t.internal_nodes;
+    t.left_siblings <<= 1;
+    if (bit) {  // WFBB:1235-1244
+        t.node_rank = rank1;
+        t.node_bv_size = node_ones;
+        ++t.left_siblings;
+        t.left_total_bv += node_zeros;
+    } else {
+        t.node_rank = rank0;
+        t.node_bv_size = node_zeros;
+    }
+}
+// WFBB:1247-1278: next level's leaf count and total bitvector size (one 4-byte load); returns the leaf count
+FMX_HD int32_t tree_next_level(TreeWalk &t) {
+    const uint32_t e = ld32u(t.level);
+    const int32_t next_leaf_count = (int32_t)(e & 0xffffu);
+    const int32_t next_total_bv = (int32_t)(e >> 16) + 1;
+    t.level += 4;
+    t.left_total_bv -= (t.depth_total_bv - next_total_bv);
+    t.bv_offset += t.depth_total_bv;
+    t.depth_total_bv = next_total_bv;
+    t.internal_nodes = (t.internal_nodes << 1) - next_leaf_count;
+    return next_leaf_count;
 }
 
 // WFBB:1010-1285.  position <= 2^31-1, symbol is a mapped code.
@@ -219,16 +348,16 @@ FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t positio
     }
     const SbcEntry e = ix.sbc[(uint64_t)sb_id * (uint32_t)ix.wt_sigma + (uint32_t)symbol];  // WFBB:1024, 1034-1037
     const SbDesc &sd = ix.sbd[sb_id];                                                      // WFBB:1026
-    const int32_t sb_sigma = (int32_t)sd.sigma + 1;
-    if ((int32_t)e.sbc >= sb_sigma) return e.rank;  // WFBB:1040-1042
-    const int32_t bsl = sd.bsl;
+    const SbHead sh = sb_head(sd);
+    if ((int32_t)e.sbc >= sh.sigma + 1) return e.rank;  // WFBB:1040-1042
+    const int32_t bsl = sh.bsl;
     const uint32_t block_size = 1u << bsl;
     const int32_t blocks_log = 20 - bsl;
     const uint32_t block_index = position & (block_size - 1);
     uint32_t block_id = (position & 0xfffffu) >> bsl;
-    const int16_t *mapping = reinterpret_cast<const int16_t *>(ix.base + ((uint64_t)sd.off_mapping << 3));
-    const BlockHdr *bhs = reinterpret_cast<const BlockHdr *>(ix.base + ((uint64_t)sd.off_bh << 3));
-    const uint8_t *var = ix.base + ((uint64_t)sd.off_var << 3);
+    const int16_t *mapping = reinterpret_cast<const int16_t *>(ix.base + ((uint64_t)sh.off_mapping << 3));
+    const BlockHdr *bhs = reinterpret_cast<const BlockHdr *>(ix.base + ((uint64_t)sh.off_bh << 3));
+    const uint8_t *var = ix.base + ((uint64_t)sh.off_var << 3);
     const uint32_t map_row = (uint32_t)e.sbc << blocks_log;
     int32_t block_c = mapping[map_row + block_id];  // WFBB:1044-1046
 
@@ -238,23 +367,27 @@ FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t positio
         if (block_id == (1u << blocks_log))  // WFBB:1060-1069 (row n_sb of the table holds count[])
             return ix.sbc[(uint64_t)(sb_id + 1) * (uint32_t)ix.wt_sigma + (uint32_t)symbol].rank;
         block_c = mapping[map_row + block_id];
-        const BlockHdr bh = bhs[block_id];
+        const BlockHdr bh = ld_block_hdr(bhs + block_id);
         // WFBB:1080-1081: (treeHeight - 1) * 4 with no treeHeight > 0 guard, and no clamped-mapping fix-up
         const int32_t p = bh.var_off + ((int32_t)bh.tree_height - 1) * 4 + block_c * 5 + 2;
         if (p < 0 || p + 2 >= sd.var_len) {
             status = ST_JAVA_AIOOBE;
             return 0;
         }
-        return e.rank + (int32_t)ld24(var + p);  // WFBB:1096-1108
+        return e.rank + (int32_t)(ld32u(var + p) & 0xffffffu);  // WFBB:1096-1108
     }
 
-    const BlockHdr bh = bhs[block_id];  // WFBB:1113
+    const BlockHdr bh = ld_block_hdr(bhs + block_id);  // WFBB:1113
     const int32_t tree_height = bh.tree_height;
     const uint8_t *hdr = var + bh.var_off;
     const uint8_t *leaves = hdr + (tree_height > 0 ? (tree_height - 1) * 4 : 0);  // WFBB:1119-1121
-    if ((int32_t)ld16(leaves + 5 * block_c) != symbol) ++block_c;                  // WFBB:1123-1130
-    const int32_t rank_block = (int32_t)ld24(leaves + 5 * block_c + 2);            // WFBB:1132-1138
-    if (tree_height == 0) return e.rank + rank_block + (int32_t)block_index;       // WFBB:1141-1146
+    uint64_t leaf = ld64u(leaves + 5 * block_c);  // {u16 symbol, u24 rank at block start} + 3 bytes of the next entry
+    if ((int32_t)(leaf & 0xffffu) != symbol) {    // WFBB:1123-1130: clamped mapping entry
+        ++block_c;
+        leaf = ld64u(leaves + 5 * block_c);
+    }
+    const int32_t rank_block = (int32_t)((leaf >> 16) & 0xffffffu);           // WFBB:1132-1138
+    if (tree_height == 0) return e.rank + rank_block + (int32_t)block_index;  // WFBB:1141-1146
 
     uint32_t code;
     int32_t code_length;
@@ -263,49 +396,29 @@ FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t positio
     const uint32_t cur_block_size = (ix.wt_size - (position - block_index)) < block_size
                                         ? (ix.wt_size - (position - block_index))
                                         : block_size;  // WFBB:1032
-    int32_t bv_rank = bh.bv_rank;       // WFBB:1158
-    int32_t bv_offset = bh.bv_offset;   // WFBB:1161
-    int32_t internal_nodes = 1;
-    int32_t left_siblings = 0;
-    int32_t left_total_bv = 0;
-    int32_t node_bv_size = (int32_t)cur_block_size;
-    int32_t depth_total_bv = node_bv_size;
-    int32_t node_rank = (int32_t)block_index;
-    const uint8_t *second = leaves + ((int32_t)bh.sigma + 1) * 5;  // WFBB:1177-1182
-    const uint8_t *level = hdr;
+    const RrrView rv = rrr_view(sd.rrr);
+    TreeWalk t;
+    t.bv_rank = bh.bv_rank;      // WFBB:1158
+    t.bv_offset = bh.bv_offset;  // WFBB:1161
+    t.internal_nodes = 1;
+    t.left_siblings = 0;
+    t.left_total_bv = 0;
+    t.node_bv_size = (int32_t)cur_block_size;
+    t.depth_total_bv = t.node_bv_size;
+    t.node_rank = (int32_t)block_index;
+    t.second = leaves + ((int32_t)bh.sigma + 1) * 5;  // WFBB:1177-1182
+    t.level = hdr;
 
     for (int32_t depth = 0; depth < code_length; ++depth) {  // WFBB:1185-1279
-        int32_t rank1 = rrr_rank1(ix.base, sd.rrr, inv, bv_offset + left_total_bv + node_rank);
-        int32_t left_ones = 0;
-        if (left_siblings > 0) left_ones = (int32_t)ld16(second + 2 * (left_siblings - 1));
-        rank1 -= bv_rank + left_ones;
-        const int32_t node_ones = (int32_t)ld16(second + 2 * left_siblings) - left_ones;
-        const int32_t node_zeros = node_bv_size - node_ones;
-        const int32_t rank0 = node_rank - rank1;
-        bv_rank += (int32_t)ld16(second + 2 * (internal_nodes - 1));
-        second += 2 * internal_nodes;
-        left_siblings <<= 1;
-        if (code & (1u << (code_length - depth - 1))) {
-            node_rank = rank1;
-            node_bv_size = node_ones;
-            ++left_siblings;
-            left_total_bv += node_zeros;
-        } else {
-            node_rank = rank0;
-            node_bv_size = node_zeros;
-        }
-        if (depth + 1 != code_length) {
-            const int32_t next_leaf_count = (int32_t)ld16(level);
-            const int32_t next_total_bv = (int32_t)ld16(level + 2) + 1;
-            level += 4;
-            left_total_bv -= (depth_total_bv - next_total_bv);
-            bv_offset += depth_total_bv;
-            depth_total_bv = next_total_bv;
-            internal_nodes = (internal_nodes << 1) - next_leaf_count;
-            left_siblings -= next_leaf_count;
-        }
+        int32_t left_ones, node_ones, level_ones;
+        tree_level_counts(t, left_ones, node_ones, level_ones);
+        int32_t rank1 = rrr_rank1(ix.base, rv, inv, t.bv_offset + t.left_total_bv + t.node_rank);
+        rank1 -= t.bv_rank + left_ones;
+        t.bv_rank += level_ones;
+        tree_descend(t, (code & (1u << (code_length - depth - 1))) != 0, rank1, node_ones);
+        if (depth + 1 != code_length) t.left_siblings -= tree_next_level(t);
     }
-    return e.rank + rank_block + node_rank;  // WFBB:1281-1284
+    return e.rank + rank_block + t.node_rank;  // WFBB:1281-1284
 }
 
 // WFBB:1305-1537: returns the symbol at `position` (< size); *rank = occurrences before it
@@ -313,75 +426,58 @@ FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t positio
 FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t &rank_out) {
     const uint32_t sb_id = position >> 20;
     const SbDesc &sd = ix.sbd[sb_id];
-    const int32_t bsl = sd.bsl;
+    const SbHead sh = sb_head(sd);
+    const int32_t bsl = sh.bsl;
     const uint32_t block_size = 1u << bsl;
     const uint32_t block_index = position & (block_size - 1);
     const uint32_t block_id = (position & 0xfffffu) >> bsl;
-    const BlockHdr *bhs = reinterpret_cast<const BlockHdr *>(ix.base + ((uint64_t)sd.off_bh << 3));
-    const uint8_t *var = ix.base + ((uint64_t)sd.off_var << 3);
-    const BlockHdr bh = bhs[block_id];
+    const BlockHdr *bhs = reinterpret_cast<const BlockHdr *>(ix.base + ((uint64_t)sh.off_bh << 3));
+    const uint8_t *var = ix.base + ((uint64_t)sh.off_var << 3);
+    const BlockHdr bh = ld_block_hdr(bhs + block_id);
     const int32_t tree_height = bh.tree_height;
     const uint8_t *hdr = var + bh.var_off;
     const uint8_t *leaves = hdr + (tree_height > 0 ? (tree_height - 1) * 4 : 0);  // WFBB:1324-1327
     const SbcEntry *row = ix.sbc + (uint64_t)sb_id * (uint32_t)ix.wt_sigma;
 
     if (tree_height == 0) {  // WFBB:1329-1355
-        const int32_t c = (int32_t)(ld16(leaves) & 0x00ffu);  // WFBB:1332: masked to 8 bits (Q1)
-        rank_out = row[c].rank + (int32_t)ld24(leaves + 2) + (int32_t)block_index;
+        const uint64_t leaf = ld64u(leaves);
+        const int32_t c = (int32_t)(leaf & 0x00ffu);  // WFBB:1332: masked to 8 bits (Q1)
+        rank_out = row[c].rank + (int32_t)((leaf >> 16) & 0xffffffu) + (int32_t)block_index;
         return c;
     }
 
     const uint32_t cur_block_size = (ix.wt_size - (position - block_index)) < block_size
                                         ? (ix.wt_size - (position - block_index))
                                         : block_size;
+    const RrrView rv = rrr_view(sd.rrr);
     uint32_t code = 0;
     int32_t code_length = 0;
-    int32_t bv_rank = bh.bv_rank;
-    int32_t bv_offset = bh.bv_offset;
-    int32_t internal_nodes = 1;
-    int32_t left_siblings = 0;
-    int32_t left_total_bv = 0;
-    int32_t node_bv_size = (int32_t)cur_block_size;
-    int32_t depth_total_bv = node_bv_size;
-    int32_t node_rank = (int32_t)block_index;
-    const uint8_t *second = leaves + ((int32_t)bh.sigma + 1) * 5;
-    const uint8_t *level = hdr;
+    TreeWalk t;
+    t.bv_rank = bh.bv_rank;
+    t.bv_offset = bh.bv_offset;
+    t.internal_nodes = 1;
+    t.left_siblings = 0;
+    t.left_total_bv = 0;
+    t.node_bv_size = (int32_t)cur_block_size;
+    t.depth_total_bv = t.node_bv_size;
+    t.node_rank = (int32_t)block_index;
+    t.second = leaves + ((int32_t)bh.sigma + 1) * 5;
+    t.level = hdr;
 
     for (int32_t depth = 0;; ++depth) {  // WFBB:1386-1493
+        int32_t left_ones, node_ones, level_ones;
+        tree_level_counts(t, left_ones, node_ones, level_ones);
         bool next_bit;
-        int32_t rank1 =
-            rrr_rank1_access(ix.base, sd.rrr, inv, bv_offset + left_total_bv + node_rank, next_bit);
-        int32_t left_ones = 0;
-        if (left_siblings > 0) left_ones = (int32_t)ld16(second + 2 * (left_siblings - 1));
-        rank1 -= bv_rank + left_ones;
-        const int32_t node_ones = (int32_t)ld16(second + 2 * left_siblings) - left_ones;
-        const int32_t node_zeros = node_bv_size - node_ones;
-        const int32_t rank0 = node_rank - rank1;
-        bv_rank += (int32_t)ld16(second + 2 * (internal_nodes - 1));
-        second += 2 * internal_nodes;
-        left_siblings <<= 1;
-        code <<= 1;
+        int32_t rank1 = rrr_rank1_access(ix.base, rv, inv, t.bv_offset + t.left_total_bv + t.node_rank, next_bit);
+        rank1 -= t.bv_rank + left_ones;
+        t.bv_rank += level_ones;
+        code = (code << 1) | (next_bit ? 1u : 0u);
         ++code_length;
-        if (next_bit) {
-            code |= 1;
-            node_rank = rank1;
-            node_bv_size = node_ones;
-            ++left_siblings;
-            left_total_bv += node_zeros;
-        } else {
-            node_rank = rank0;
-            node_bv_size = node_zeros;
-        }
+        tree_descend(t, next_bit, rank1, node_ones);
         if (depth + 1 < tree_height) {
-            const int32_t next_leaf_count = (int32_t)ld16(level);
-            const int32_t next_total_bv = (int32_t)ld16(level + 2) + 1;
-            level += 4;
-            left_total_bv -= (depth_total_bv - next_total_bv);
-            bv_offset += depth_total_bv;
-            depth_total_bv = next_total_bv;
-            internal_nodes = (internal_nodes << 1) - next_leaf_count;
-            if (left_siblings >= next_leaf_count)
-                left_siblings -= next_leaf_count;
+            const int32_t next_leaf_count = tree_next_level(t);
+            if (t.left_siblings >= next_leaf_count)  // WFBB:1485-1489
+                t.left_siblings -= next_leaf_count;
             else
                 break;
         } else {
@@ -399,9 +495,22 @@ FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32
         temp_code <<= 1;
     }
     block_c += code - temp_code;
-    const int32_t c = (int32_t)ld16(leaves + 5 * block_c);  // WFBB:1501-1506
-    rank_out = row[c].rank + (int32_t)ld24(leaves + 5 * block_c + 2) + node_rank;  // WFBB:1521-1533
+    const uint64_t leaf = ld64u(leaves + 5 * block_c);
+    const int32_t c = (int32_t)(leaf & 0xffffu);                                        // WFBB:1501-1506
+    rank_out = row[c].rank + (int32_t)((leaf >> 16) & 0xffffffu) + t.node_rank;        // WFBB:1521-1533
     return c;
+}
+
+// true when inverseSelect's symbol at `position` is the block's real symbol (false only for a run block
+// whose symbol code is >= 256: WFBB:1332 masks it to 8 bits)
+FMX_HD bool wt_symbol_is_exact(const DevIndex &ix, uint32_t position, int32_t c) {
+    const SbDesc &sd = ix.sbd[position >> 20];
+    const SbHead sh = sb_head(sd);
+    const uint32_t block_id = (position & 0xfffffu) >> sh.bsl;
+    const BlockHdr bh = ld_block_hdr(reinterpret_cast<const BlockHdr *>(ix.base + ((uint64_t)sh.off_bh << 3)) + block_id);
+    if (bh.tree_height != 0) return true;
+    const uint8_t *leaves = ix.base + ((uint64_t)sh.off_var << 3) + bh.var_off;
+    return (int32_t)ld16(leaves) == c;
 }
 
 // ---- FmIndex helpers -----------------------------------------------------------------------
@@ -409,12 +518,23 @@ FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32
 FMX_HD int32_t fm_map(const DevIndex &ix, uint16_t ch) { return ix.char2code[ch]; }  // getOrDefault(ch, 0) FM:457
 
 // one LF-step of locate / extract: c = BWT[row-1]; row' = C[c] + rank_c(BWT, row)  (FM:532-535, 597-599).
-// The reference calls inverseSelect and then rank; both are restated as-is (no fusion), so every
-// quirk of either function is preserved.
+// The reference calls inverseSelect(row-1) and then rank(row, c).  inverseSelect already yields
+// rank_c(row-1) (WFBB:1529-1535), and rank(row, c) == rank_c(row-1) + 1 whenever rank() takes its main path
+// through the SAME block with the symbol it actually holds: i.e. row-1 and row share a block (row is not a
+// block boundary), the position is in range, and the symbol was not altered by the 8-bit mask of run blocks
+// (Q1, WFBB:1332).  Only then is the second call skipped; every other case runs rank() as the reference
+// does, so all of its quirks (next-block path, Q3) are preserved.  tests/test_fused_lf.py checks the
+// equivalence exhaustively on quirk-heavy inputs.
 FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, int32_t &c_out, int &status) {
-    int32_t unused_rank;
-    const int32_t c = (int32_t)(int16_t)wt_inverse_select(ix, inv, (uint32_t)(row - 1), unused_rank);
+    const uint32_t p = (uint32_t)(row - 1);
+    int32_t rank_before;
+    const int32_t c = (int32_t)(int16_t)wt_inverse_select(ix, inv, p, rank_before);
     c_out = c;
+    const uint32_t bsl = (uint32_t)(int32_t)ix.sbd[p >> 20].bsl;
+    const bool same_block = ((uint32_t)row & ((1u << bsl) - 1u)) != 0 && (uint32_t)row <= ix.wt_size;
+    // a run block whose symbol is >= 256 reports a masked symbol: rank(row, masked c) must really be evaluated
+    const bool exact_symbol = ix.wt_sigma <= 256 || wt_symbol_is_exact(ix, p, c);
+    if (same_block && exact_symbol) return ix.C[c] + rank_before + 1;
     return ix.C[c] + wt_rank(ix, inv, (uint32_t)row, c, status);
 }
 
@@ -438,7 +558,8 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
                              int &status) {
     int32_t j = start + 1 + k;  // FM:527-529
     distance = 0;
-    while (!rrr_access(ix.base, ix.sampled, inv, j - 1, status)) {  // FM:531
+    const RrrView sv = {ix.sampled.off_rec, ix.sampled.off_bits, ix.sampled.length, ix.sampled.total_ones};
+    while (!rrr_access(ix.base, sv, inv, j - 1, status)) {  // FM:531
         int32_t c;
         j = fm_lf_step(ix, inv, j, c, status);  // FM:532-535
         ++distance;
@@ -447,7 +568,7 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
             break;
         }
     }
-    const int32_t r = rrr_rank1(ix.base, ix.sampled, inv, j) - 1;          // FM:541
+    const int32_t r = rrr_rank1(ix.base, sv, inv, j) - 1;                  // FM:541
     return fm_packed_get(ix.suffix_words, r, ix.bw_suffixes) + distance;  // FM:538-542
 }
 

@@ -12,7 +12,7 @@
 #include <cstring>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/block/block_radix_sort.hpp>
 
 #include "fmx_device.hpp"
 
@@ -166,29 +166,158 @@ FMX_KERNEL(kBlock) void k_extract_boundary(DevIndex ix, const int32_t *__restric
     }
 }
 
-// sort key of a pattern: its last `chars` characters as alphabet codes, `bits` bits each, the LAST
-// character most significant (it is consumed first, FM:456-457)
-__global__ void k_make_keys(DevIndex ix, const uint16_t *__restrict__ pat, const int32_t *__restrict__ pat_off,
-                            int32_t n, int chars, int bits, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const int32_t beg = pat_off[p], m = pat_off[p + 1] - beg;
+// ---- processing order of a batch -------------------------------------------------------------------
+// Patterns are processed in (approximate) order of their trailing characters, the LAST character most
+// significant (it is consumed first, FM:456-457): lanes of a wave then start their backward search in the
+// same SA intervals.  Any grouping works — results are written at the original index — so instead of a
+// general device sort (rocPRIM falls back to a 21-launch merge sort at 1 M keys) the order is built by
+//   1. a coarse bucket pass on the top <=14 key bits: per-workgroup LDS histograms, ONE global atomic per
+//      (workgroup, non-empty bin) — no hot-bin serialisation — then a single-workgroup scan and a scatter
+//      whose slots come from LDS cursors;
+//   2. a tile-local LDS radix sort (4,096 patterns per workgroup) on the full key, which restores the fine
+//      order where it matters: inside a wave / a CU.
+constexpr int kTileThreads = 512;
+constexpr int kTileItems = 8;                       // patterns per thread
+constexpr int kTile = kTileThreads * kTileItems;    // 4,096 patterns per workgroup
+constexpr int kCoarseBitsMax = 14;                  // 16,384 LDS bins (64 KiB)
+
+struct SortShape {
+    int bits;         // bits per alphabet code
+    int chars;        // trailing characters in the full key
+    int total_bits;   // chars * bits (<= 32)
+    int coarse_bits;  // top bits used by the bucket pass
+};
+
+__device__ __forceinline__ uint32_t suffix_key(const DevIndex &ix, const uint16_t *pat, int32_t beg, int32_t m,
+                                               int chars, int bits) {
     uint32_t key = 0;
     for (int j = 0; j < chars; ++j) {
         const uint32_t c = (j < m) ? (uint32_t)fm_map(ix, pat[beg + m - 1 - j]) : 0u;
         key = (key << bits) | c;
     }
-    keys[p] = key;
-    vals[p] = (uint32_t)p;
+    return key;
+}
+
+// pass 1a: coarse keys + global histogram (LDS-privatised)
+__global__ __launch_bounds__(kTileThreads) void k_order_hist(DevIndex ix, const uint16_t *__restrict__ pat,
+                                                             const int32_t *__restrict__ pat_off, int32_t n,
+                                                             SortShape sh, uint32_t *__restrict__ coarse,
+                                                             uint32_t *__restrict__ ghist) {
+    extern __shared__ uint32_t s_hist[];
+    const int bins = 1 << sh.coarse_bits;
+    for (int i = threadIdx.x; i < bins; i += kTileThreads) s_hist[i] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kTile;
+    for (int k = 0; k < kTileItems; ++k) {
+        const int64_t p = base + (int64_t)k * kTileThreads + threadIdx.x;
+        if (p < n) {
+            const int32_t beg = pat_off[p];
+            const uint32_t key = suffix_key(ix, pat, beg, pat_off[p + 1] - beg, sh.chars, sh.bits);
+            const uint32_t c = key >> (sh.total_bits - sh.coarse_bits);
+            coarse[p] = c;
+            atomicAdd(&s_hist[c], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < bins; i += kTileThreads) {
+        const uint32_t v = s_hist[i];
+        if (v) atomicAdd(&ghist[i], v);
+    }
+}
+
+// pass 1b: exclusive scan of <= 16,384 bins by one workgroup (in place): coalesced load into LDS, per-thread
+// chunks, Hillis-Steele over the 1,024 partial sums, coalesced store
+constexpr int kScanThreads = 1024;
+__global__ __launch_bounds__(kScanThreads) void k_order_scan(uint32_t *__restrict__ ghist, int bins) {
+    __shared__ uint32_t s_val[(1 << kCoarseBitsMax) + 64];
+    __shared__ uint32_t s_part[kScanThreads];
+    for (int i = threadIdx.x; i < bins; i += kScanThreads) s_val[i + (i >> 8)] = ghist[i];  // +1 pad per 256: no 16-way conflicts
+    __syncthreads();
+    const int per = (bins + kScanThreads - 1) / kScanThreads;
+    const int lo = threadIdx.x * per;
+    uint32_t sum = 0;
+    for (int i = lo; i < lo + per && i < bins; ++i) sum += s_val[i + (i >> 8)];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < kScanThreads; d <<= 1) {
+        const uint32_t v = (threadIdx.x >= (unsigned)d) ? s_part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[threadIdx.x] - sum;
+    for (int i = lo; i < lo + per && i < bins; ++i) {
+        const uint32_t v = s_val[i + (i >> 8)];
+        s_val[i + (i >> 8)] = run;
+        run += v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < bins; i += kScanThreads) ghist[i] = s_val[i + (i >> 8)];
+}
+
+// pass 1c: scatter into bucket order; each workgroup reserves its share of a bin with one atomic
+__global__ __launch_bounds__(kTileThreads) void k_order_scatter(const uint32_t *__restrict__ coarse, int32_t n,
+                                                                SortShape sh, uint32_t *__restrict__ cursor,
+                                                                uint32_t *__restrict__ perm) {
+    extern __shared__ uint32_t s_hist[];
+    const int bins = 1 << sh.coarse_bits;
+    for (int i = threadIdx.x; i < bins; i += kTileThreads) s_hist[i] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kTile;
+    uint32_t mine[kTileItems];
+    for (int k = 0; k < kTileItems; ++k) {
+        const int64_t p = base + (int64_t)k * kTileThreads + threadIdx.x;
+        mine[k] = (p < n) ? coarse[p] : 0xffffffffu;
+        if (p < n) atomicAdd(&s_hist[mine[k]], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < bins; i += kTileThreads) {
+        const uint32_t v = s_hist[i];
+        if (v) s_hist[i] = atomicAdd(&cursor[i], v);  // first slot of this workgroup's share
+    }
+    __syncthreads();
+    for (int k = 0; k < kTileItems; ++k) {
+        const int64_t p = base + (int64_t)k * kTileThreads + threadIdx.x;
+        if (p < n) perm[atomicAdd(&s_hist[mine[k]], 1u)] = (uint32_t)p;
+    }
+}
+
+// pass 2: tile-local radix sort of the bucket order on the full key
+__global__ __launch_bounds__(kTileThreads) void k_order_tile_sort(DevIndex ix, const uint16_t *__restrict__ pat,
+                                                                  const int32_t *__restrict__ pat_off, int32_t n,
+                                                                  SortShape sh, const uint32_t *__restrict__ perm_in,
+                                                                  uint32_t *__restrict__ perm_out) {
+    using Sort = rocprim::block_radix_sort<uint32_t, kTileThreads, kTileItems, uint32_t>;
+    __shared__ typename Sort::storage_type storage;
+    const int64_t base = (int64_t)blockIdx.x * kTile;
+    uint32_t keys[kTileItems], vals[kTileItems];
+    for (int k = 0; k < kTileItems; ++k) {
+        const int64_t i = base + (int64_t)threadIdx.x * kTileItems + k;
+        if (i < n) {
+            const uint32_t p = perm_in[i];
+            const int32_t beg = pat_off[p];
+            keys[k] = suffix_key(ix, pat, beg, pat_off[p + 1] - beg, sh.chars, sh.bits);
+            vals[k] = p;
+        } else {
+            keys[k] = 0xffffffffu;  // padding sorts last and is dropped on write-back
+            vals[k] = 0xffffffffu;
+        }
+    }
+    Sort().sort(keys, vals, storage, 0, 32);
+    for (int k = 0; k < kTileItems; ++k) {
+        const int64_t i = base + (int64_t)threadIdx.x * kTileItems + k;
+        if (i < n) perm_out[i] = vals[k];
+    }
 }
 
 // ---- launchers (called from fmx_api.cpp) -----------------------------------------------------
 
 // tunables (fmx_set_option): workgroup size and how many workgroups per CU the grid is capped at
 static int g_block = 512;
-static int g_groups_per_cu = 8;
+static int g_groups_per_cu = 16;
+static int g_lds_pad_kb = 0;   // experiment knob: extra dynamic LDS per workgroup (lowers occupancy)
 static int g_sort_min = 16384;  // batches at least this large are processed in suffix-sorted order (0 = never)
-static int g_sort_bits = 28;    // key width: floor(sort_bits / bits-per-code) trailing characters
+static int g_sort_bits = 28;    // full key width: floor(sort_bits / bits-per-code) trailing characters
 
 int set_option(const char *name, int value) {
     if (!strcmp(name, "block")) {
@@ -199,6 +328,11 @@ int set_option(const char *name, int value) {
     if (!strcmp(name, "groups_per_cu")) {
         if (value < 1 || value > 64) return -1;
         g_groups_per_cu = value;
+        return 0;
+    }
+    if (!strcmp(name, "lds_pad_kb")) {
+        if (value < 0 || value > 96) return -1;
+        g_lds_pad_kb = value;
         return 0;
     }
     if (!strcmp(name, "sort_min")) {
@@ -227,40 +361,53 @@ static int grid_for(int64_t lanes, int block, int n_cu) {
         const int blk__ = g_block;                                                                           \
         const dim3 grid__(grid_for((LANES), blk__, n_cu));                                                   \
         if (blk__ == 1024)                                                                                   \
-            hipLaunchKernelGGL(KERNEL<1024>, grid__, dim3(1024), 0, st, __VA_ARGS__);                        \
+            hipLaunchKernelGGL(KERNEL<1024>, grid__, dim3(1024), (size_t)g_lds_pad_kb * 1024, st, __VA_ARGS__);                        \
         else                                                                                                 \
-            hipLaunchKernelGGL(KERNEL<512>, grid__, dim3(512), 0, st, __VA_ARGS__);                          \
+            hipLaunchKernelGGL(KERNEL<512>, grid__, dim3(512), (size_t)g_lds_pad_kb * 1024, st, __VA_ARGS__);                          \
     } while (0)
 
-// bytes of scratch launch_count needs to sort a batch of n patterns (0 = the batch is not sorted)
-size_t count_workspace_bytes(int32_t n) {
-    if (g_sort_min <= 0 || n < g_sort_min) return 0;
-    size_t temp = 0;
-    uint32_t *nul = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, temp, nul, nul, nul, nul, (size_t)n, 0u, 32u, (hipStream_t)0, false);
-    return (size_t)n * 16 + ((temp + 255) & ~(size_t)255) + 256;
+static SortShape sort_shape(const DevIndex &ix) {
+    SortShape sh;
+    sh.bits = 1;
+    while ((1 << sh.bits) < ix.wt_sigma && sh.bits < 15) ++sh.bits;
+    sh.chars = g_sort_bits / sh.bits;
+    if (sh.chars < 1) sh.chars = 1;
+    sh.total_bits = sh.chars * sh.bits;
+    sh.coarse_bits = sh.total_bits < kCoarseBitsMax ? sh.total_bits : kCoarseBitsMax;
+    return sh;
 }
 
-// suffix-key sort of the batch: perm_out[q] = index of the q-th pattern in processing order.
-// workspace: count_workspace_bytes(n) bytes.  Returns a hipError_t value.
+// bytes of scratch needed to order a batch of n patterns (0 = the batch is not sorted)
+size_t count_workspace_bytes(const DevIndex &ix, int32_t n) {
+    if (g_sort_min <= 0 || n < g_sort_min) return 0;
+    return (size_t)n * 12 + ((size_t)4 << kCoarseBitsMax) + 512;
+}
+
+// perm_out[q] = index of the q-th pattern in processing order.  workspace: count_workspace_bytes(ix, n).
+// Returns a hipError_t value.
 int launch_count_plan(const DevIndex &ix, const uint16_t *pat, const int32_t *off, int32_t n, void *workspace,
                       size_t workspace_bytes, const uint32_t **perm_out, hipStream_t st) {
     *perm_out = nullptr;
-    if (n <= 0 || !workspace || workspace_bytes < (size_t)n * 16 + 256) return 0;
-    int bits = 1;
-    while ((1 << bits) < ix.wt_sigma && bits < 15) ++bits;
-    int chars = g_sort_bits / bits;
-    if (chars < 1) chars = 1;
-    if (chars * bits > 32) chars = 32 / bits;
-    uint32_t *keys_in = static_cast<uint32_t *>(workspace);
-    uint32_t *keys_out = keys_in + n, *vals_in = keys_out + n, *vals_out = vals_in + n;
-    void *temp = vals_out + n;
-    size_t temp_bytes = workspace_bytes - (size_t)n * 16;
-    hipLaunchKernelGGL(k_make_keys, dim3((n + 255) / 256), dim3(256), 0, st, ix, pat, off, n, chars, bits, keys_in, vals_in);
-    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
-                                             (unsigned)(chars * bits), st, false);
+    const size_t need = count_workspace_bytes(ix, n);
+    if (n <= 0 || !workspace || need == 0 || workspace_bytes < need) return 0;
+    const SortShape sh = sort_shape(ix);
+    const int bins = 1 << sh.coarse_bits;
+    uint32_t *coarse = static_cast<uint32_t *>(workspace);
+    uint32_t *perm1 = coarse + n;
+    uint32_t *perm2 = perm1 + n;
+    uint32_t *ghist = perm2 + n;
+    const int tiles = (n + kTile - 1) / kTile;
+    hipError_t e = hipMemsetAsync(ghist, 0, (size_t)bins * 4, st);
     if (e != hipSuccess) return (int)e;
-    *perm_out = vals_out;
+    hipLaunchKernelGGL(k_order_hist, dim3(tiles), dim3(kTileThreads), (size_t)bins * 4, st, ix, pat, off, n, sh, coarse, ghist);
+    hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(kScanThreads), 0, st, ghist, bins);
+    hipLaunchKernelGGL(k_order_scatter, dim3(tiles), dim3(kTileThreads), (size_t)bins * 4, st, coarse, n, sh, ghist, perm1);
+    if (sh.total_bits > sh.coarse_bits) {
+        hipLaunchKernelGGL(k_order_tile_sort, dim3(tiles), dim3(kTileThreads), 0, st, ix, pat, off, n, sh, perm1, perm2);
+        *perm_out = perm2;
+    } else {
+        *perm_out = perm1;
+    }
     return (int)hipGetLastError();
 }
 

@@ -54,6 +54,21 @@ int32_t sim_wt_inverse_select(const uint8_t *blob, uint32_t position, int32_t *r
     return wt_inverse_select(ix, ix.inv_global, position, *rank);
 }
 
+// fused LF-step (fm_lf_step) next to the reference's literal two-call form, for tests/test_fused_lf.py
+void sim_lf_step_both(const uint8_t *blob, int32_t row, int32_t *out /* fused_row, fused_c, ref_row, ref_c, fused_st, ref_st */) {
+    DevIndex ix = make_index(blob);
+    int st = 0, c = 0;
+    out[0] = fm_lf_step(ix, ix.inv_global, row, c, st);
+    out[1] = c;
+    out[4] = st;
+    int st2 = 0;
+    int32_t unused;
+    const int32_t c2 = (int32_t)(int16_t)wt_inverse_select(ix, ix.inv_global, (uint32_t)(row - 1), unused);  // FM:532-533
+    out[2] = ix.C[c2] + wt_rank(ix, ix.inv_global, (uint32_t)row, c2, st2);                                   // FM:534-535
+    out[3] = c2;
+    out[5] = st2;
+}
+
 // mirrors k_count with both roles of a pair evaluated in turn
 void sim_count(const uint8_t *blob, const uint16_t *pat, const int32_t *off, int32_t n, int32_t *counts,
                int32_t *lf, int32_t *status_out, int32_t *range) {

@@ -43,6 +43,11 @@ class HostSim:
         c = lib().sim_wt_inverse_select(self.p, pos, r.ctypes.data)
         return c, int(r[0])
 
+    def lf_step_both(self, row):
+        out = np.zeros(6, np.int32)
+        lib().sim_lf_step_both(C.c_void_p(self.p), int(row), C.c_void_p(out.ctypes.data))
+        return out
+
     def count_batch(self, chars, offsets):
         chars = np.ascontiguousarray(chars, np.uint16)
         offsets = np.ascontiguousarray(offsets, np.int32)

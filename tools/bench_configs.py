@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[0], [2], [3] on one MI355X: timing (HIP events, operands resident in HBM), exact
+LF-step counts, and a bit-exact check of a sample against the oracle.  One JSON object per config.
+usage: python tools/bench_configs.py [--text-log2 28] [--out gpurun_out/configs.jsonl]"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def timed(fn, stream, reps):
+    import torch
+
+    fn()
+    torch.cuda.synchronize()
+    best = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        best.append(e0.elapsed_time(e1) / reps)
+    return min(best)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--text-log2", type=int, default=28)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "configs.jsonl"))
+    ap.add_argument("--check", type=int, default=2000, help="queries per config verified against the oracle")
+    args = ap.parse_args()
+    import torch
+
+    import bench
+    import index4j_amd as ia
+    import orc
+
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream()
+    sp = C.c_void_p(stream.cuda_stream)
+    out = []
+
+    def t32(a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+
+    # ---- config 0: count() of 1000 8-char patterns on 1 MiB, sampleRate 32 ----
+    text1 = ia.synth_log(1 << 20)
+    fm1 = ia.FmIndex(text1, 32, True, device=0)
+    o1 = orc.OracleFmIndex(text1, 32, True)
+    assert fm1.write() == o1.write()
+    pat, off, pos = ia.synth_patterns(text1, 8, 1000)
+    cnt, st, lf = fm1.count_batch(pat, off, want_steps=True)
+    oc, _ = o1.count_batch(pat, off)
+    assert (cnt == oc).all()
+    d_pat, d_off = torch.from_numpy(pat.view(np.int16)).to(dev), t32(off)
+    d_cnt = torch.zeros(1000, dtype=torch.int32, device=dev)
+    ms = timed(lambda: ia.lib.fmx_count_batch_dev(fm1.handle, d_pat.data_ptr(), d_off.data_ptr(), 1000, d_cnt.data_ptr(), None, None, sp), stream, 50)
+    out.append({"config": "configs[0] count 1000 x 8-char on 1 MiB, sampleRate 32", "ms": ms, "queries": 1000,
+                "lf_steps": int(lf.sum()), "queries_per_s": 1000 / ms * 1e3, "lf_steps_per_s": int(lf.sum()) / ms * 1e3,
+                "checked_vs_oracle": 1000, "note": "launch-latency bound (one small kernel)"})
+    print(json.dumps(out[-1]), flush=True)
+
+    # ---- the 256 MiB text, sampleRate 32 (config 2) and 64 (config 3) ----
+    text, fm32, path32 = bench.build_or_load_index(ia, args.text_log2, 32, "/tmp/fmx_cache")
+    fm32.to_device(0)
+    o32 = orc.OracleFmIndex.read(open(path32, "rb").read())
+    n = 100_000
+    pat, off, pos = ia.synth_patterns(text, 8, n)
+    d_pat, d_off = torch.from_numpy(pat.view(np.int16)).to(dev), t32(off)
+    M = 16
+    d_locs = torch.zeros(n * M, dtype=torch.int32, device=dev)
+    d_found = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_lf = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_ws = torch.zeros(2 * n, dtype=torch.int32, device=dev)
+
+    def locate(with_lf):
+        rc = ia.lib.fmx_locate_batch_dev(fm32.handle, d_pat.data_ptr(), d_off.data_ptr(), n, M, d_locs.data_ptr(), M,
+                                         d_found.data_ptr(), d_lf.data_ptr() if with_lf else None,
+                                         d_st.data_ptr() if with_lf else None, d_ws.data_ptr(), sp)
+        assert rc == 0, ia.lib.fmx_last_error()
+
+    locate(True)
+    torch.cuda.synchronize()
+    lf_total = int(d_lf.sum(dtype=torch.int64).item())
+    found = d_found.cpu().numpy()
+    locs = d_locs.cpu().numpy().reshape(n, M)
+    assert int(d_st.max().item()) == 0
+    orc.counters_reset()
+    for i in range(args.check):
+        k, l = o32.locate(pat[i * 8:(i + 1) * 8], max_matches=M, cap=M)
+        assert k == found[i] and (l == locs[i, :k]).all(), i
+    oc = orc.counters()
+    ms = timed(lambda: locate(False), stream, 10)
+    out.append({"config": "configs[2] locate 100k x 8-char, maxMatches 16, 256 MiB, sampleRate 32", "ms": ms, "queries": n,
+                "hits_located": int(found.sum()), "lf_steps": lf_total, "queries_per_s": n / ms * 1e3,
+                "hits_per_s": int(found.sum()) / ms * 1e3, "lf_steps_per_s": lf_total / ms * 1e3,
+                "oracle_alg_bytes_per_lf_step": oc["alg_bytes"] / max(1, oc["lf_steps"]),
+                "checked_vs_oracle": args.check})
+    print(json.dumps(out[-1]), flush=True)
+
+    # ---- config 3: extractUntilBoundary('\n') for 100k hit locations, sampleRate 64 ----
+    text, fm64, path64 = bench.build_or_load_index(ia, args.text_log2, 64, "/tmp/fmx_cache")
+    fm64.to_device(0)
+    o64 = orc.OracleFmIndex.read(open(path64, "rb").read())
+    # from_j = first located position of pattern j on the sampleRate-64 index
+    l64, f64, s64 = fm64.locate_batch(pat, off, 1, 1)
+    assert (f64 == 1).all() and (s64 == 0).all()
+    frm = l64[:, 0].astype(np.int32)
+    cap = 1024
+    d_from = t32(frm)
+    d_dst = torch.zeros(n * cap, dtype=torch.int16, device=dev)
+    d_len = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_aux = torch.zeros(n, dtype=torch.int32, device=dev)
+
+    def extract(with_lf):
+        rc = ia.lib.fmx_extract_boundary_batch_dev(fm64.handle, d_from.data_ptr(), n, 10, 0, d_dst.data_ptr(), cap, 0,
+                                                   d_len.data_ptr(), d_lf.data_ptr() if with_lf else None,
+                                                   d_st.data_ptr() if with_lf else None, d_aux.data_ptr(), sp)
+        assert rc == 0, ia.lib.fmx_last_error()
+
+    extract(True)
+    torch.cuda.synchronize()
+    lf_total = int(d_lf.sum(dtype=torch.int64).item())
+    lens = d_len.cpu().numpy()
+    dst = d_dst.cpu().numpy().view(np.uint16).reshape(n, cap)
+    assert int(d_st.max().item()) == 0
+    orc.counters_reset()
+    for i in range(args.check):
+        k, d = o64.extract_until_boundary(0, int(frm[i]), cap, 0, "\n")
+        assert k == lens[i] and (d == dst[i]).all(), i
+    oc = orc.counters()
+    nl = np.flatnonzero(text == 10)
+    j = np.searchsorted(nl, frm)
+    lo = np.where(j > 0, nl[np.maximum(j - 1, 0)] + 1, 0)
+    ok = j < len(nl)
+    exp_len = np.where(text[frm] == 10, 0, nl[np.minimum(j, len(nl) - 1)] - lo)  # a seed on the boundary returns 0 (FM:725-728)
+    assert (lens[ok] == exp_len[ok]).all()  # every full line has the scanned length
+    ms = timed(lambda: extract(False), stream, 5)
+    out.append({"config": "configs[3] extractUntilBoundary('\\n') for 100k hit locations, 256 MiB, sampleRate 64", "ms": ms,
+                "queries": n, "chars_extracted": int(lens.sum()), "lf_steps": lf_total, "queries_per_s": n / ms * 1e3,
+                "chars_per_s": int(lens.sum()) / ms * 1e3, "lf_steps_per_s": lf_total / ms * 1e3,
+                "oracle_alg_bytes_per_lf_step": oc["alg_bytes"] / max(1, oc["lf_steps"]),
+                "checked_vs_oracle": args.check})
+    print(json.dumps(out[-1]), flush=True)
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, "w") as f:
+        for o in out:
+            f.write(json.dumps(o) + "\n")
+
+
+if __name__ == "__main__":
+    main()
