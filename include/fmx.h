@@ -135,6 +135,18 @@ int fmx_extract_boundary_batch_dev(const fmx_index *idx, const int32_t *d_from, 
                                    int mode, uint16_t *d_dst, int32_t dst_len, int32_t offset, int32_t *d_out_len,
                                    int32_t *d_lf_steps, int32_t *d_status, int32_t *d_aux, void *stream);
 
+/* ---- WaveletFixedBlockBoosting as a stand-alone structure (the reference's public class, WFBB:130-154) ----
+ * `sequence` = symbols already mapped to small non-negative integers (short[] text of WFBB:130).  The handle
+ * answers only the two calls below (after fmx_to_device); free it with fmx_free. */
+int fmx_wavelet_build(const int16_t *sequence, int64_t n, int32_t sampling_rate, fmx_index **out);
+/* long rank(long position, short symbol) WFBB:1010-1285, batched */
+int fmx_wavelet_rank_batch(const fmx_index *idx, const int64_t *positions, const int32_t *symbols, int32_t n,
+                           int64_t *ranks, int32_t *status);
+/* long inverseSelect(long position) WFBB:1305-1537, batched: packed[i] = (rank << 32) | symbol, and the bare
+ * symbol for position 0, exactly as the reference returns it */
+int fmx_wavelet_inverse_select_batch(const fmx_index *idx, const int64_t *positions, int32_t n, int64_t *packed,
+                                     int32_t *status);
+
 /* ---- helpers ------------------------------------------------------------------------------ */
 
 /* FmIndex.convertBytePatternToCharPattern FM:239-298.  Returns the number of chars, or -1 with
@@ -148,7 +160,8 @@ int fmx_status_kind(int status);
 const char *fmx_last_error(void);
 int fmx_device_count(void);
 /* launch tunables: "block" = threads per workgroup (512 | 1024), "groups_per_cu" = grid cap per CU,
- * "sort_min" = smallest batch that is processed in suffix-sorted order (0 = never), "sort_bits" = sort key width */
+ * "sort_min" = smallest batch that is processed in suffix-sorted order (0 = never), "sort_bits" = sort key width,
+ * "boundary_accel" = 0 forces the literal +4-chunk right walk of extractUntilBoundary (results are identical) */
 int fmx_set_option(const char *name, int value);
 
 /* deterministic synthetic workload (bench / tests): see index4j_amd/csrc/fmx_synth.cpp */

@@ -14,6 +14,7 @@ from .fmindex import (  # noqa: F401
     synth_log,
     synth_patterns,
 )
+from .wavelet import WaveletFixedBlockBoosting  # noqa: F401
 
-__all__ = ["FmIndex", "FmIndexBuilder", "FmxError", "as_chars", "chars_to_str", "pack_patterns",
+__all__ = ["WaveletFixedBlockBoosting", "FmIndex", "FmIndexBuilder", "FmxError", "as_chars", "chars_to_str", "pack_patterns",
            "raise_for_status", "synth_log", "synth_patterns", "lib", "LIB_PATH", "SYMBOLS"]

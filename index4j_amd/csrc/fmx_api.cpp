@@ -27,6 +27,8 @@ int launch_extract(const DevIndex &, int, const int32_t *, const int32_t *, int3
                    int32_t *, int32_t *, int32_t *, hipStream_t);
 int launch_extract_boundary(const DevIndex &, int, const int32_t *, int32_t, uint16_t, int, uint16_t *, int32_t,
                             int32_t, int32_t *, int32_t *, int32_t *, int32_t *, hipStream_t);
+int launch_wt_rank(const DevIndex &, int, const int64_t *, const int32_t *, int32_t, int64_t *, int32_t *, hipStream_t);
+int launch_wt_inverse_select(const DevIndex &, int, const int64_t *, int32_t, int64_t *, int32_t *, hipStream_t);
 int set_option(const char *, int);
 }  // namespace fmx
 
@@ -40,6 +42,7 @@ struct fmx_index {
     int device = -1;
     int n_cu = 256;
     bool owns_device = false;
+    bool wavelet_only = false;  // built by fmx_wavelet_build: only the wavelet entry points apply
     fmx::DevIndex dev;
     // per-stream scratch for the in-library pattern sort (grow-only; freed with the index)
     mutable std::mutex ws_mutex;
@@ -171,6 +174,9 @@ int get_workspace(const fmx_index *idx, void *stream, size_t bytes, void **out) 
     return FMX_OK;
 }
 
+#define H2D(dst, src, bytes) HIP_TRY(hipMemcpy((dst), (src), (bytes), hipMemcpyHostToDevice))
+#define D2H(dst, src, bytes) HIP_TRY(hipMemcpy((dst), (src), (bytes), hipMemcpyDeviceToHost))
+
 // RAII device scratch for the host-buffer entry points
 struct DevBuf {
     void *p = nullptr;
@@ -229,7 +235,8 @@ int fmx_load(const uint8_t *ser, size_t len, fmx_index **out) {
 
 int fmx_save(const fmx_index *idx, int framed, uint8_t **buf, size_t *len) {
     if (!idx || !buf || !len) return fail(FMX_E_ARG, "null argument");
-    if (!idx->has_model) return fail(FMX_E_ARG, "index was attached from a device blob; nothing to serialize");
+    if (!idx->has_model || idx->wavelet_only)
+        return fail(FMX_E_ARG, "nothing to serialize (device-attached or wavelet-only handle)");
     std::vector<uint8_t> out;
     fmx::emit_model(idx->model, framed != 0, out);
     uint8_t *p = static_cast<uint8_t *>(malloc(out.size() ? out.size() : 1));
@@ -413,8 +420,6 @@ int fmx_extract_boundary_batch_dev(const fmx_index *idx, const int32_t *d_from, 
 
 // ---- host-buffer entry points --------------------------------------------------------------------
 
-#define H2D(dst, src, bytes) HIP_TRY(hipMemcpy((dst), (src), (bytes), hipMemcpyHostToDevice))
-#define D2H(dst, src, bytes) HIP_TRY(hipMemcpy((dst), (src), (bytes), hipMemcpyDeviceToHost))
 
 int fmx_count_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n, int32_t *counts,
                     int32_t *lf_steps, int32_t *status) {
@@ -535,6 +540,70 @@ int fmx_extract_boundary_batch(const fmx_index *idx, const int32_t *from, int32_
     if (status) D2H(status, d_st.p, (size_t)n * 4);
     if (aux) D2H(aux, d_aux.p, (size_t)n * 4);
     return FMX_OK;
+}
+
+// ---- WaveletFixedBlockBoosting as a stand-alone structure ------------------------------------------------
+
+int fmx_wavelet_build(const int16_t *sequence, int64_t n, int32_t sampling_rate, fmx_index **out) {
+    if (!out || !sequence || n <= 0 || n >= ((int64_t)1 << 31) || sampling_rate <= 0)
+        return fail(FMX_E_ARG, n == 0 ? "Input length must be > 0" : "bad arguments");  // WFBB:178-180
+    for (int64_t i = 0; i < n; ++i)
+        if (sequence[i] < 0) return fail(FMX_E_ARG, "negative symbol");
+    std::unique_ptr<fmx_index> idx(new fmx_index());
+    fmx::FmModel &m = idx->model;
+    m.sample_rate = sampling_rate;
+    m.enable_extract = false;
+    m.length = (int32_t)n;
+    m.bw_suffixes = 1;
+    m.C.assign(1, 0);
+    m.look_up.assign(1, 0);
+    m.suffixes.init(0, 1);
+    fmx::build_rrr(nullptr, 0, sampling_rate, m.sampled);
+    fmx::build_wavelet(sequence, n, sampling_rate, m.wt);
+    idx->has_model = true;
+    idx->wavelet_only = true;
+    *out = idx.release();
+    return FMX_OK;
+}
+
+static int wavelet_batch(const fmx_index *idx, const int64_t *positions, const int32_t *symbols, int32_t n, int64_t *out,
+                         int32_t *status) {
+    int rc = require_device(idx);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!positions || !out))) return fail(FMX_E_ARG, "bad arguments");
+    if (n == 0) return FMX_OK;
+    HIP_TRY(hipSetDevice(idx->device));
+    DevBuf d_pos, d_sym, d_out, d_st;
+    HIP_TRY(d_pos.alloc((size_t)n * 8));
+    HIP_TRY(d_sym.alloc((size_t)n * 4));
+    HIP_TRY(d_out.alloc((size_t)n * 8));
+    HIP_TRY(d_st.alloc((size_t)n * 4));
+    H2D(d_pos.p, positions, (size_t)n * 8);
+    int e;
+    if (symbols) {
+        H2D(d_sym.p, symbols, (size_t)n * 4);
+        e = fmx::launch_wt_rank(idx->dev, idx->n_cu, d_pos.as<int64_t>(), d_sym.as<int32_t>(), n, d_out.as<int64_t>(),
+                                d_st.as<int32_t>(), nullptr);
+    } else {
+        e = fmx::launch_wt_inverse_select(idx->dev, idx->n_cu, d_pos.as<int64_t>(), n, d_out.as<int64_t>(),
+                                          d_st.as<int32_t>(), nullptr);
+    }
+    if (e) return fail(FMX_E_HIP, std::string("wavelet kernel launch: ") + hipGetErrorString((hipError_t)e));
+    HIP_TRY(hipDeviceSynchronize());
+    D2H(out, d_out.p, (size_t)n * 8);
+    if (status) D2H(status, d_st.p, (size_t)n * 4);
+    return FMX_OK;
+}
+
+int fmx_wavelet_rank_batch(const fmx_index *idx, const int64_t *positions, const int32_t *symbols, int32_t n,
+                           int64_t *ranks, int32_t *status) {
+    if (n > 0 && !symbols) return fail(FMX_E_ARG, "bad arguments");
+    return wavelet_batch(idx, positions, symbols, n, ranks, status);
+}
+
+int fmx_wavelet_inverse_select_batch(const fmx_index *idx, const int64_t *positions, int32_t n, int64_t *packed,
+                                     int32_t *status) {
+    return wavelet_batch(idx, positions, nullptr, n, packed, status);
 }
 
 // ---- helpers ---------------------------------------------------------------------------------------

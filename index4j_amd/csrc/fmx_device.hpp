@@ -337,13 +337,18 @@ FMX_HD int32_t tree_next_level(TreeWalk &t) {
 }
 
 // WFBB:1010-1285.  position <= 2^31-1, symbol is a mapped code.
-FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t symbol, int &status) {
+// `suspect` is set when the value came through a path where the reference is known to misbehave (next-block
+// path onto a run block or through a clamped mapping entry, Q2/Q11; out-of-range superblock, Q3): callers
+// that replace the reference's access pattern by an equivalent one only do so on un-suspect results.
+FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t symbol, int &status,
+                       bool &suspect) {
     if (position == 0) return 0;                       // WFBB:1012-1014
     if (position > ix.wt_size) position = ix.wt_size;  // WFBB:1015-1017
     if (symbol >= ix.wt_sigma) return 0;               // WFBB:1018-1020
     const uint32_t sb_id = position >> 20;             // WFBB:1023
     if (sb_id >= (uint32_t)ix.n_sb || symbol < 0) {    // Q3: the JVM raises ArrayIndexOutOfBounds here
         status = ST_JAVA_AIOOBE;
+        suspect = true;
         return 0;
     }
     const SbcEntry e = ix.sbc[(uint64_t)sb_id * (uint32_t)ix.wt_sigma + (uint32_t)symbol];  // WFBB:1024, 1034-1037
@@ -370,6 +375,7 @@ FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t positio
         const BlockHdr bh = ld_block_hdr(bhs + block_id);
         // WFBB:1080-1081: (treeHeight - 1) * 4 with no treeHeight > 0 guard, and no clamped-mapping fix-up
         const int32_t p = bh.var_off + ((int32_t)bh.tree_height - 1) * 4 + block_c * 5 + 2;
+        if (bh.tree_height == 0 || block_c >= ix.wt_sigma - 2) suspect = true;  // Q11 / Q2
         if (p < 0 || p + 2 >= sd.var_len) {
             status = ST_JAVA_AIOOBE;
             return 0;
@@ -419,6 +425,11 @@ FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t positio
         if (depth + 1 != code_length) t.left_siblings -= tree_next_level(t);
     }
     return e.rank + rank_block + t.node_rank;  // WFBB:1281-1284
+}
+
+FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t symbol, int &status) {
+    bool suspect = false;
+    return wt_rank(ix, inv, position, symbol, status, suspect);
 }
 
 // WFBB:1305-1537: returns the symbol at `position` (< size); *rank = occurrences before it
@@ -525,7 +536,8 @@ FMX_HD int32_t fm_map(const DevIndex &ix, uint16_t ch) { return ix.char2code[ch]
 // (Q1, WFBB:1332).  Only then is the second call skipped; every other case runs rank() as the reference
 // does, so all of its quirks (next-block path, Q3) are preserved.  tests/test_fused_lf.py checks the
 // equivalence exhaustively on quirk-heavy inputs.
-FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, int32_t &c_out, int &status) {
+FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, int32_t &c_out, int &status,
+                          bool &suspect) {
     const uint32_t p = (uint32_t)(row - 1);
     int32_t rank_before;
     const int32_t c = (int32_t)(int16_t)wt_inverse_select(ix, inv, p, rank_before);
@@ -534,8 +546,13 @@ FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, 
     const bool same_block = ((uint32_t)row & ((1u << bsl) - 1u)) != 0 && (uint32_t)row <= ix.wt_size;
     // a run block whose symbol is >= 256 reports a masked symbol: rank(row, masked c) must really be evaluated
     const bool exact_symbol = ix.wt_sigma <= 256 || wt_symbol_is_exact(ix, p, c);
+    if (!exact_symbol) suspect = true;  // Q1
     if (same_block && exact_symbol) return ix.C[c] + rank_before + 1;
-    return ix.C[c] + wt_rank(ix, inv, (uint32_t)row, c, status);
+    return ix.C[c] + wt_rank(ix, inv, (uint32_t)row, c, status, suspect);
+}
+FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, int32_t &c_out, int &status) {
+    bool suspect = false;
+    return fm_lf_step(ix, inv, row, c_out, status, suspect);
 }
 
 // IntVector.getValue on the packed `suffixes` / `positions` words (IV:129-143)
@@ -618,11 +635,190 @@ FMX_HD int32_t fm_extract(const DevIndex &ix, const uint16_t *inv, int32_t start
     return range;
 }
 
+// ---- right part of extractUntilBoundary / extractUntilBoundaryRight (FM:692-758 / FM:853-921) ----------
+// The reference fetches the text right of `from` in +4-char chunks; chunk t re-seeks the ISA sample after
+// from+4t and walks back skip+4 LF-steps, i.e. ~(s/2+4)/4 steps per character.  The per-character control
+// logic (boundary detection, capacity exception, write position, return value) only depends on the
+// characters themselves, so it is kept verbatim in `boundary_chunk_char` and fed either
+//   * literally (fm_boundary_right_literal: the reference's own seek + walk per chunk), or
+//   * from a per-lane buffer holding one whole sample interval fetched with ONE walk of <= s steps
+//     (fm_boundary_right_blocks) — same characters, ~s/8 times fewer LF-steps.  If any step of such a walk
+//     reports `suspect` (a quirk path of the wavelet tree, where the reference's result depends on its own
+//     access pattern), the query is redone literally.
+struct RightState {
+    int32_t final_pos, up_pos, aux, ret;
+    bool done;  // returned 0 or threw
+};
+// body of the inner loop for one emitted character with code c (FM:721-741 / FM:882-904)
+FMX_HD void boundary_chunk_char(const DevIndex &ix, int mode, int32_t c, int32_t mapped_boundary, uint16_t *dest,
+                                int32_t dst_len, int32_t offset, int32_t down_len, RightState &r, int &status) {
+    if (c == mapped_boundary) {
+        if (r.up_pos == 0) {  // the first char was a boundary: return 0 (FM:725-728)
+            r.ret = 0;
+            r.done = true;
+            return;
+        }
+        r.final_pos = r.up_pos;
+    }
+    const int32_t w = (mode == 0) ? offset + down_len + r.up_pos : offset + r.up_pos;
+    if (w >= dst_len) {  // FM:732-737 / FM:893-898
+        status = ST_DOES_NOT_FIT;
+        r.aux = w;
+        r.done = true;
+        return;
+    }
+    if (mode == 0) {
+        if (w < 0) {
+            status = ST_JAVA_AIOOBE;
+            r.done = true;
+            return;
+        }
+        dest[w] = (uint16_t)ix.look_up[c];  // FM:738-739
+        --r.up_pos;
+    } else if (r.up_pos > 0) {  // range is (from, boundary], FM:899-902
+        if (w - 1 < 0) {
+            status = ST_JAVA_AIOOBE;
+            r.done = true;
+            return;
+        }
+        dest[w - 1] = (uint16_t)ix.look_up[c];
+        --r.up_pos;
+    }
+}
+
+FMX_HD int32_t fm_boundary_right_literal(const DevIndex &ix, const uint16_t *inv, int mode, int32_t from,
+                                         int32_t mapped_boundary, uint16_t *dest, int32_t dst_len, int32_t offset,
+                                         int32_t down_len, int32_t &steps, int &status, int32_t &aux) {
+    const int32_t step = 4;
+    RightState r = {-1, 0, 0, 0, false};
+    int32_t times_up = 1;
+    while (r.final_pos == -1) {
+        const int32_t prev_from = from;
+        from += step;
+        if (from > ix.length - 1) from = ix.length - 1;
+        int32_t remaining = from - prev_from;
+        r.up_pos = (times_up - 1) * step + remaining - 1;
+        int32_t row, skip;
+        fm_seek_after(ix, from, row, skip);
+        int32_t distance = 0;
+        while (remaining > 0) {
+            int32_t c;
+            row = fm_lf_step(ix, inv, row, c, status);
+            ++steps;
+            if (distance >= skip) {
+                boundary_chunk_char(ix, mode, c, mapped_boundary, dest, dst_len, offset, down_len, r, status);
+                if (r.done) {
+                    aux = r.aux;
+                    return r.ret;
+                }
+                --remaining;
+            }
+            ++distance;
+        }
+        if (from == ix.length - 1) {  // FM:745-752 / FM:908-915
+            r.final_pos = (mode == 0) ? ((r.up_pos < 0) ? 1 : r.up_pos + from - prev_from) : r.up_pos + from - prev_from;
+            break;
+        }
+        ++times_up;
+    }
+    return (mode == 0) ? down_len + r.final_pos : r.final_pos - 1;  // FM:758 / FM:921
+}
+
+// codes of text positions [k*s, min((k+1)*s, length)) into buf[(pos - k*s) * stride] with one walk from the
+// ISA sample k+1 (the wrap entry for the last interval, FM:367-369); returns false if any step is suspect
+FMX_HD bool fm_fetch_interval(const DevIndex &ix, const uint16_t *inv, int32_t k, uint16_t *buf, int32_t stride,
+                              int32_t &steps, int &status) {
+    const int32_t s = ix.sample_rate;
+    const int64_t top64 = (int64_t)(k + 1) * s;
+    const int32_t top = top64 < ix.length ? (int32_t)top64 : ix.length;
+    int32_t row = fm_packed_get(ix.pos_words, (int64_t)k + 1, ix.bw_positions) + 1;  // FM:705-706
+    bool suspect = false;
+    for (int32_t pos = top - 1; pos >= k * s; --pos) {
+        int32_t c;
+        row = fm_lf_step(ix, inv, row, c, status, suspect);
+        ++steps;
+        buf[(pos - k * s) * stride] = (uint16_t)c;
+    }
+    return !suspect && status == ST_OK;
+}
+
+// same result as fm_boundary_right_literal; `buf` holds sample_rate codes per lane (element i at buf[i*stride])
+FMX_HD int32_t fm_boundary_right_blocks(const DevIndex &ix, const uint16_t *inv, int mode, int32_t from,
+                                        int32_t mapped_boundary, uint16_t *dest, int32_t dst_len, int32_t offset,
+                                        int32_t down_len, int32_t &steps, int &status, int32_t &aux, uint16_t *buf,
+                                        int32_t stride, bool &clean) {
+    const int32_t s = ix.sample_rate;
+    const int32_t step = 4;
+    RightState r = {-1, 0, 0, 0, false};
+    int32_t times_up = 1;
+    int32_t cur_k = -1;
+    clean = true;
+    while (r.final_pos == -1) {
+        const int32_t prev_from = from;
+        from += step;
+        if (from > ix.length - 1) from = ix.length - 1;
+        const int32_t remaining = from - prev_from;
+        r.up_pos = (times_up - 1) * step + remaining - 1;
+        // the chunk's codes in position order: prev_from .. from-1 (<= 4; may straddle two sample intervals)
+        int32_t c4[4] = {0, 0, 0, 0};
+        for (int32_t i = 0; i < remaining; ++i) {
+            const int32_t pos = prev_from + i;
+            const int32_t k = pos / s;
+            if (k != cur_k) {
+                if (!fm_fetch_interval(ix, inv, k, buf, stride, steps, status)) {
+                    clean = false;
+                    return 0;
+                }
+                cur_k = k;
+            }
+            c4[i] = buf[(pos - k * s) * stride];
+        }
+        for (int32_t i = remaining - 1; i >= 0; --i) {  // the reference emits from-1 first, prev_from last
+            const int32_t c = (i == 3) ? c4[3] : (i == 2) ? c4[2] : (i == 1) ? c4[1] : c4[0];
+            boundary_chunk_char(ix, mode, c, mapped_boundary, dest, dst_len, offset, down_len, r, status);
+            if (r.done) {
+                aux = r.aux;
+                return r.ret;
+            }
+        }
+        if (from == ix.length - 1) {
+            r.final_pos = (mode == 0) ? ((r.up_pos < 0) ? 1 : r.up_pos + from - prev_from) : r.up_pos + from - prev_from;
+            break;
+        }
+        ++times_up;
+    }
+    return (mode == 0) ? down_len + r.final_pos : r.final_pos - 1;
+}
+
+// scratch == nullptr (or sample_rate > scratch capacity): literal form only
+FMX_HD int32_t fm_boundary_right(const DevIndex &ix, const uint16_t *inv, int mode, int32_t from,
+                                 int32_t mapped_boundary, uint16_t *dest, int32_t dst_len, int32_t offset,
+                                 int32_t down_len, int32_t &steps, int &status, int32_t &aux, uint16_t *scratch,
+                                 int32_t scratch_stride) {
+    if (scratch) {
+        bool clean;
+        int32_t steps2 = 0, aux2 = 0;
+        int status2 = ST_OK;
+        const int32_t ret = fm_boundary_right_blocks(ix, inv, mode, from, mapped_boundary, dest, dst_len, offset,
+                                                     down_len, steps2, status2, aux2, scratch, scratch_stride, clean);
+        steps += steps2;
+        if (clean) {
+            status = status2;
+            aux = aux2;
+            return ret;
+        }
+    }
+    return fm_boundary_right_literal(ix, inv, mode, from, mapped_boundary, dest, dst_len, offset, down_len, steps,
+                                     status, aux);
+}
+
 // FM:640-759 (mode 0), FM:772-831 (mode 1), FM:844-922 (mode 2).  `mapped_boundary` = code of the
 // boundary char (FM:658).  *aux = N of "Currently extracted: N".
+// scratch: per-lane buffer of sample_rate codes for the accelerated right part (nullptr = literal form).
 FMX_HD int32_t fm_extract_boundary(const DevIndex &ix, const uint16_t *inv, int mode, int32_t from,
                                    int32_t mapped_boundary, uint16_t *dest, int32_t dst_len, int32_t offset,
-                                   int32_t &steps, int &status, int32_t &aux) {
+                                   int32_t &steps, int &status, int32_t &aux, uint16_t *scratch = nullptr,
+                                   int32_t scratch_stride = 1) {
     steps = 0;
     aux = 0;
     if (mode == 1) ++from;  // FM:774
@@ -691,59 +887,8 @@ FMX_HD int32_t fm_extract_boundary(const DevIndex &ix, const uint16_t *inv, int 
         }
         if (mode == 1) return down_len;  // FM:830
     }
-    // right part in +4 chunks, FM:692-758 / FM:853-921
-    const int32_t step = 4;
-    int32_t final_pos = -1, times_up = 1;
-    while (final_pos == -1) {
-        const int32_t prev_from = from;
-        from += step;
-        if (from > ix.length - 1) from = ix.length - 1;
-        int32_t remaining = from - prev_from;
-        int32_t up_pos = (times_up - 1) * step + remaining - 1;
-        int32_t row, skip;
-        fm_seek_after(ix, from, row, skip);
-        int32_t distance = 0;
-        while (remaining > 0) {
-            int32_t c;
-            row = fm_lf_step(ix, inv, row, c, status);
-            ++steps;
-            if (distance >= skip) {
-                if (c == mapped_boundary) {
-                    if (up_pos == 0) return 0;  // the first char was a boundary (FM:725-728)
-                    final_pos = up_pos;
-                }
-                const int32_t w = (mode == 0) ? offset + down_len + up_pos : offset + up_pos;
-                if (w >= dst_len) {  // FM:732-737 / FM:893-898
-                    status = ST_DOES_NOT_FIT;
-                    aux = w;
-                    return 0;
-                }
-                if (mode == 0) {
-                    if (w < 0) {
-                        status = ST_JAVA_AIOOBE;
-                        return 0;
-                    }
-                    dest[w] = (uint16_t)ix.look_up[c];  // FM:738-739
-                    --up_pos;
-                } else if (up_pos > 0) {  // range is (from, boundary], FM:899-902
-                    if (w - 1 < 0) {
-                        status = ST_JAVA_AIOOBE;
-                        return 0;
-                    }
-                    dest[w - 1] = (uint16_t)ix.look_up[c];
-                    --up_pos;
-                }
-                --remaining;
-            }
-            ++distance;
-        }
-        if (from == ix.length - 1) {  // FM:745-752 / FM:908-915
-            final_pos = (mode == 0) ? ((up_pos < 0) ? 1 : up_pos + from - prev_from) : up_pos + from - prev_from;
-            break;
-        }
-        ++times_up;
-    }
-    return (mode == 0) ? down_len + final_pos : final_pos - 1;  // FM:758 / FM:921
+    return fm_boundary_right(ix, inv, mode, from, mapped_boundary, dest, dst_len, offset, down_len, steps, status, aux,
+                             scratch, scratch_stride);
 }
 
 }  // namespace fmx

@@ -141,28 +141,81 @@ FMX_KERNEL(kBlock) void k_extract(DevIndex ix, const int32_t *__restrict__ start
     }
 }
 
-// FM:640-759 (mode 0), FM:772-831 (mode 1), FM:844-922 (mode 2)
-template <int kBlock>
-FMX_KERNEL(kBlock) void k_extract_boundary(DevIndex ix, const int32_t *__restrict__ froms,
-                                                             int32_t n, uint16_t boundary, int mode,
-                                                             uint16_t *__restrict__ dst, int32_t dst_len,
-                                                             int32_t offset, int32_t *__restrict__ out_len,
-                                                             int32_t *__restrict__ lf_steps,
-                                                             int32_t *__restrict__ status_out,
-                                                             int32_t *__restrict__ aux_out) {
+// FM:640-759 (mode 0), FM:772-831 (mode 1), FM:844-922 (mode 2).  256-thread workgroups: 32 KiB table +
+// 32 KiB of per-lane interval buffers (sample_rate <= 64 codes per lane, element i of lane t at
+// s_buf[i * 256 + t]) for the accelerated right walk (fm_boundary_right_blocks); larger sample rates run
+// the literal form.
+constexpr int kBoundaryBlock = 256;
+constexpr int kBoundaryMaxSample = 64;
+__global__ __launch_bounds__(kBoundaryBlock) void k_extract_boundary(DevIndex ix, const int32_t *__restrict__ froms,
+                                                                     int32_t n, uint16_t boundary, int mode,
+                                                                     uint16_t *__restrict__ dst, int32_t dst_len,
+                                                                     int32_t offset, int32_t *__restrict__ out_len,
+                                                                     int32_t *__restrict__ lf_steps,
+                                                                     int32_t *__restrict__ status_out,
+                                                                     int32_t *__restrict__ aux_out, int accelerate) {
     __shared__ uint16_t s_inv[kInvEntries];
+    __shared__ uint16_t s_buf[kBoundaryMaxSample * kBoundaryBlock];
     stage_inverse_table(s_inv, ix.inv_global);
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t stride = (int64_t)gridDim.x * kBoundaryBlock;
     const int32_t mapped_boundary = fm_map(ix, boundary);  // FM:658
-    for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) {
+    uint16_t *scratch = (accelerate && ix.sample_rate <= kBoundaryMaxSample) ? s_buf + threadIdx.x : nullptr;
+    for (int64_t q = (int64_t)blockIdx.x * kBoundaryBlock + threadIdx.x; q < n; q += stride) {
         int status = ST_OK;
         int32_t steps, aux;
         const int32_t ret = fm_extract_boundary(ix, s_inv, mode, froms[q], mapped_boundary, dst + q * (int64_t)dst_len,
-                                                dst_len, offset, steps, status, aux);
+                                                dst_len, offset, steps, status, aux, scratch, kBoundaryBlock);
         out_len[q] = status ? 0 : ret;
         if (lf_steps) lf_steps[q] = steps;
         if (status_out) status_out[q] = status;
         if (aux_out) aux_out[q] = aux;
+    }
+}
+
+// WaveletFixedBlockBoosting.rank(position, symbol) WFBB:1010-1285, one lane per query
+template <int kBlock>
+FMX_KERNEL(kBlock) void k_wt_rank(DevIndex ix, const int64_t *__restrict__ positions, const int32_t *__restrict__ symbols,
+                                  int32_t n, int64_t *__restrict__ out, int32_t *__restrict__ status_out) {
+    __shared__ uint16_t s_inv[kInvEntries];
+    stage_inverse_table(s_inv, ix.inv_global);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) {
+        int status = ST_OK;
+        int64_t pos = positions[q];
+        const int32_t sym = symbols[q];
+        int64_t r = 0;
+        if (pos < 0 || sym < 0)
+            status = ST_JAVA_AIOOBE;  // negative array index in the reference
+        else {
+            if (pos > (int64_t)ix.wt_size) pos = ix.wt_size;  // WFBB:1015-1017 (also keeps the position in 32 bits)
+            r = wt_rank(ix, s_inv, (uint32_t)pos, sym, status);
+        }
+        out[q] = r;
+        if (status_out) status_out[q] = status;
+    }
+}
+
+// WaveletFixedBlockBoosting.inverseSelect(position) WFBB:1305-1537: the reference's packed long
+// (rank << 32) | symbol, the bare symbol for position 0 (WFBB:1334-1335, 1508-1509)
+template <int kBlock>
+FMX_KERNEL(kBlock) void k_wt_inverse_select(DevIndex ix, const int64_t *__restrict__ positions, int32_t n,
+                                            int64_t *__restrict__ out, int32_t *__restrict__ status_out) {
+    __shared__ uint16_t s_inv[kInvEntries];
+    stage_inverse_table(s_inv, ix.inv_global);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) {
+        const int64_t pos = positions[q];
+        int status = ST_OK;
+        int64_t v = 0;
+        if (pos < 0 || pos >= (int64_t)ix.wt_size)
+            status = ST_JAVA_AIOOBE;
+        else {
+            int32_t rank;
+            const int32_t c = wt_inverse_select(ix, s_inv, (uint32_t)pos, rank);
+            v = (pos == 0) ? (int64_t)c : (int64_t)(((uint64_t)(uint32_t)rank << 32) | (uint32_t)c);
+        }
+        out[q] = v;
+        if (status_out) status_out[q] = status;
     }
 }
 
@@ -315,6 +368,7 @@ __global__ __launch_bounds__(kTileThreads) void k_order_tile_sort(DevIndex ix, c
 // tunables (fmx_set_option): workgroup size and how many workgroups per CU the grid is capped at
 static int g_block = 512;
 static int g_groups_per_cu = 16;
+static int g_boundary_accel = 1;  // 0 = literal right walk of extractUntilBoundary (A/B and fallback)
 static int g_lds_pad_kb = 0;   // experiment knob: extra dynamic LDS per workgroup (lowers occupancy)
 static int g_sort_min = 16384;  // batches at least this large are processed in suffix-sorted order (0 = never)
 static int g_sort_bits = 28;    // full key width: floor(sort_bits / bits-per-code) trailing characters
@@ -328,6 +382,10 @@ int set_option(const char *name, int value) {
     if (!strcmp(name, "groups_per_cu")) {
         if (value < 1 || value > 64) return -1;
         g_groups_per_cu = value;
+        return 0;
+    }
+    if (!strcmp(name, "boundary_accel")) {
+        g_boundary_accel = value != 0;
         return 0;
     }
     if (!strcmp(name, "lds_pad_kb")) {
@@ -428,6 +486,20 @@ int launch_locate_walk(const DevIndex &ix, int n_cu, const int32_t *range, int32
     return (int)hipGetLastError();
 }
 
+int launch_wt_rank(const DevIndex &ix, int n_cu, const int64_t *pos, const int32_t *sym, int32_t n, int64_t *out,
+                   int32_t *status, hipStream_t st) {
+    if (n <= 0) return 0;
+    FMX_DISPATCH(k_wt_rank, (int64_t)n, ix, pos, sym, n, out, status);
+    return (int)hipGetLastError();
+}
+
+int launch_wt_inverse_select(const DevIndex &ix, int n_cu, const int64_t *pos, int32_t n, int64_t *out, int32_t *status,
+                             hipStream_t st) {
+    if (n <= 0) return 0;
+    FMX_DISPATCH(k_wt_inverse_select, (int64_t)n, ix, pos, n, out, status);
+    return (int)hipGetLastError();
+}
+
 int launch_extract(const DevIndex &ix, int n_cu, const int32_t *start, const int32_t *stop, int32_t n, uint16_t *dst,
                    int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf, int32_t *status, hipStream_t st) {
     if (n <= 0) return 0;
@@ -439,8 +511,8 @@ int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, i
                             uint16_t *dst, int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf,
                             int32_t *status, int32_t *aux, hipStream_t st) {
     if (n <= 0) return 0;
-    FMX_DISPATCH(k_extract_boundary, (int64_t)n, ix, from, n, boundary, mode, dst, dst_len, offset, out_len, lf, status,
-                 aux);
+    hipLaunchKernelGGL(k_extract_boundary, dim3(grid_for((int64_t)n, kBoundaryBlock, n_cu)), dim3(kBoundaryBlock), 0, st, ix,
+                       from, n, boundary, mode, dst, dst_len, offset, out_len, lf, status, aux, g_boundary_accel);
     return (int)hipGetLastError();
 }
 

@@ -151,18 +151,20 @@ void sim_extract(const uint8_t *blob, const int32_t *starts, const int32_t *stop
 
 void sim_extract_boundary(const uint8_t *blob, const int32_t *froms, int32_t n, uint16_t boundary, int mode,
                           uint16_t *dst, int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf,
-                          int32_t *status_out, int32_t *aux_out) {
+                          int32_t *status_out, int32_t *aux_out, int accelerate) {
     DevIndex ix = make_index(blob);
     const int32_t mapped_boundary = fm_map(ix, boundary);
+    uint16_t *scratch = accelerate ? new uint16_t[(size_t)ix.sample_rate + 1] : nullptr;
     for (int32_t q = 0; q < n; ++q) {
         int status = ST_OK;
         int32_t steps, aux;
         const int32_t ret = fm_extract_boundary(ix, ix.inv_global, mode, froms[q], mapped_boundary,
-                                                dst + (int64_t)q * dst_len, dst_len, offset, steps, status, aux);
+                                                dst + (int64_t)q * dst_len, dst_len, offset, steps, status, aux, scratch, 1);
         out_len[q] = status ? 0 : ret;
         if (lf) lf[q] = steps;
         if (status_out) status_out[q] = status;
         if (aux_out) aux_out[q] = aux;
     }
+    delete[] scratch;
 }
 }

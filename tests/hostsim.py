@@ -34,6 +34,16 @@ class HostSim:
         self.blob = fm_index.blob()
         self.p = self.blob.ctypes.data
 
+    def wt_rank_batch(self, positions, symbols):
+        st = np.zeros(1, np.int32)
+        out = np.zeros(len(positions), np.int64)
+        sts = np.zeros(len(positions), np.int32)
+        for i, (p_, s_) in enumerate(zip(positions, symbols)):
+            st[0] = 0
+            out[i] = lib().sim_wt_rank(self.p, int(p_), int(s_), st.ctypes.data)
+            sts[i] = st[0]
+        return out, sts
+
     def wt_rank(self, pos, sym):
         st = np.zeros(1, np.int32)
         return lib().sim_wt_rank(self.p, pos, sym, st.ctypes.data), int(st[0])
@@ -80,7 +90,7 @@ class HostSim:
                           C.c_void_p(lf.ctypes.data), C.c_void_p(st.ctypes.data))
         return dst, out_len, st, lf
 
-    def extract_boundary_batch(self, froms, boundary, mode, dst_len, offset=0, dst=None):
+    def extract_boundary_batch(self, froms, boundary, mode, dst_len, offset=0, dst=None, accelerate=1):
         froms = np.ascontiguousarray(froms, np.int32)
         n = len(froms)
         if dst is None:
@@ -89,5 +99,5 @@ class HostSim:
         b = boundary if isinstance(boundary, (int, np.integer)) else ord(boundary)
         lib().sim_extract_boundary(C.c_void_p(self.p), C.c_void_p(froms.ctypes.data), n, C.c_uint16(b), mode,
                                    C.c_void_p(dst.ctypes.data), dst_len, offset, C.c_void_p(out_len.ctypes.data),
-                                   C.c_void_p(lf.ctypes.data), C.c_void_p(st.ctypes.data), C.c_void_p(aux.ctypes.data))
+                                   C.c_void_p(lf.ctypes.data), C.c_void_p(st.ctypes.data), C.c_void_p(aux.ctypes.data), accelerate)
         return dst, out_len, st, aux, lf

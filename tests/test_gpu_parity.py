@@ -34,6 +34,17 @@ def test_fixture_all_queries_vs_oracle(sr):
     check_all(make_gpu, HD, sr, random.Random(sr))
 
 
+def test_literal_right_walk_gives_the_same_answers():
+    """extractUntilBoundary's accelerated right walk (one walk per sample interval) vs the literal +4-chunk
+    form of FM:692-758, both against the oracle"""
+    try:
+        assert ia.lib.fmx_set_option(b"boundary_accel", 0) == 0
+        check_all(make_gpu, HD[:120_000], 32, random.Random(77), n_q=80)
+        check_all(make_gpu, HD[:60_000], 64, random.Random(78), n_q=60)
+    finally:
+        ia.lib.fmx_set_option(b"boundary_accel", 1)
+
+
 def test_embedded_sentinels_and_small_texts():
     rnd = random.Random(11)
     mod = list(HD[:40_000])
@@ -209,3 +220,42 @@ def test_large_batch_properties_16mib():
         else:
             en, ed = o.extract_until_boundary(0, p, 1024, 0, "\n")
             assert st4[i] == 0 and ol[i] == en and (dst[i] == ed).all(), i
+
+
+def test_standalone_wavelet_kats_and_quirk_sequence():
+    """WaveletFixedBlockBoostingTest on the GPU (T-WFBB:50-131) + the sequence that drives rank() into its
+    run-block quirk (WFBB:1081): the kernels must return the reference's garbage bit for bit"""
+    from wavelet_cases import probes, quirk_sequence
+    from test_wavelet_cpu import oracle_ranks
+
+    t = "aloha what a string this is string is eh"
+    w = ia.WaveletFixedBlockBoosting(t)
+    assert w.rank(6, "a") == 2 and w.rank(len(t), "a") == 4 and w.rank(len(t), "h") == 4 and w.rank(19, "i") == 1
+    assert w.rank(22, "Z") == 0
+    w = ia.WaveletFixedBlockBoosting("a")
+    assert w.rank(1, "a") == 1 and w.rank(1, "b") == 0
+    with pytest.raises(ValueError, match="Input length must be > 0"):
+        ia.WaveletFixedBlockBoosting("")
+    w = ia.WaveletFixedBlockBoosting(np.full(100, 1, np.int16))
+    assert w.inverseSelect(0) == 1 and (w.inverseSelect(5) & 0xFFFF) == 1
+    s = np.full(30_000, 3, np.int16)
+    s[28_000] = 2
+    assert ia.WaveletFixedBlockBoosting(s).rank(90_000, 2) == 1
+    s = np.full(3_000_000, 0, np.int16)
+    s[2_800_000] = 1
+    assert ia.WaveletFixedBlockBoosting(s).rank(6_900_000, 1) == 1
+    s = np.full(3_000_000, 0, np.int16)
+    s[100] = 1
+    assert ia.WaveletFixedBlockBoosting(s).rank(1_000_000, 1) == 1
+    for seq, sampling in ((quirk_sequence(), 32), (np.random.default_rng(2).integers(0, 2000, 200_000).astype(np.int16), 16)):
+        w = ia.WaveletFixedBlockBoosting(seq, sampling)
+        o = orc.Wfbb(seq, sampling)
+        pos, sym = probes(seq, np.random.default_rng(5))
+        got, st = w.rank_batch(pos, sym)
+        orc.counters_reset()
+        exp, est = oracle_ranks(o, pos, sym)
+        assert (got == exp).all() and (st == est).all()
+        p2 = np.random.default_rng(6).integers(0, len(seq), 4000)
+        packed, st2 = w.inverse_select_batch(p2)
+        assert (st2 == 0).all() and packed.tolist() == [o.inverse_select(int(p)) for p in p2]
+    assert orc.counters()["rank_calls"] > 0
