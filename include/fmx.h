@@ -161,7 +161,8 @@ const char *fmx_last_error(void);
 int fmx_device_count(void);
 /* launch tunables: "block" = threads per workgroup (512 | 1024), "groups_per_cu" = grid cap per CU,
  * "sort_min" = smallest batch that is processed in suffix-sorted order (0 = never), "sort_bits" = sort key width,
- * "boundary_accel" = 0 forces the literal +4-chunk right walk of extractUntilBoundary (results are identical) */
+ * "boundary_accel" = 0 forces the literal +4-chunk right walk of extractUntilBoundary, "boundary_group" = lanes
+ * per extractUntilBoundary query (0 | 2 | 4 | 8 | 16); results are identical for every setting */
 int fmx_set_option(const char *name, int value);
 
 /* deterministic synthetic workload (bench / tests): see index4j_amd/csrc/fmx_synth.cpp */

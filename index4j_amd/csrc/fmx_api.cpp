@@ -26,7 +26,8 @@ int launch_locate_walk(const DevIndex &, int, const int32_t *, int32_t, int32_t,
 int launch_extract(const DevIndex &, int, const int32_t *, const int32_t *, int32_t, uint16_t *, int32_t, int32_t,
                    int32_t *, int32_t *, int32_t *, hipStream_t);
 int launch_extract_boundary(const DevIndex &, int, const int32_t *, int32_t, uint16_t, int, uint16_t *, int32_t,
-                            int32_t, int32_t *, int32_t *, int32_t *, int32_t *, hipStream_t);
+                            int32_t, int32_t *, int32_t *, int32_t *, int32_t *, void *, size_t, hipStream_t);
+size_t boundary_workspace_bytes(const DevIndex &, int32_t n, int n_cu);
 int launch_wt_rank(const DevIndex &, int, const int64_t *, const int32_t *, int32_t, int64_t *, int32_t *, hipStream_t);
 int launch_wt_inverse_select(const DevIndex &, int, const int64_t *, int32_t, int64_t *, int32_t *, hipStream_t);
 int set_option(const char *, int);
@@ -412,8 +413,13 @@ int fmx_extract_boundary_batch_dev(const fmx_index *idx, const int32_t *d_from, 
     if (rc) return rc;
     if (n < 0 || dst_len < 0 || mode < 0 || mode > 2 || (n > 0 && (!d_from || !d_out_len || (!d_dst && dst_len > 0))))
         return fail(FMX_E_ARG, "bad arguments");
+    void *ws = nullptr;
+    const size_t ws_bytes = fmx::boundary_workspace_bytes(idx->dev, n, idx->n_cu);
+    rc = get_workspace(idx, stream, ws_bytes, &ws);
+    if (rc) return rc;
     int e = fmx::launch_extract_boundary(idx->dev, idx->n_cu, d_from, n, boundary, mode, d_dst, dst_len, offset,
-                                         d_out_len, d_lf_steps, d_status, d_aux, static_cast<hipStream_t>(stream));
+                                         d_out_len, d_lf_steps, d_status, d_aux, ws, ws_bytes,
+                                         static_cast<hipStream_t>(stream));
     if (e) return fail(FMX_E_HIP, std::string("k_extract_boundary launch: ") + hipGetErrorString((hipError_t)e));
     return FMX_OK;
 }

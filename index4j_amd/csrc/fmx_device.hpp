@@ -375,7 +375,9 @@ FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t positio
         const BlockHdr bh = ld_block_hdr(bhs + block_id);
         // WFBB:1080-1081: (treeHeight - 1) * 4 with no treeHeight > 0 guard, and no clamped-mapping fix-up
         const int32_t p = bh.var_off + ((int32_t)bh.tree_height - 1) * 4 + block_c * 5 + 2;
-        if (bh.tree_height == 0 || block_c >= ix.wt_sigma - 2) suspect = true;  // Q11 / Q2
+        // the result is only trustworthy if the entry read is the symbol's own: a run block is read 4 bytes early
+        // (Q11), and a clamped mapping entry (no fix-up here, Q2) may point at a neighbour's entry
+        if (bh.tree_height == 0 || (int32_t)ld16(var + p - 2) != symbol) suspect = true;
         if (p < 0 || p + 2 >= sd.var_len) {
             status = ST_JAVA_AIOOBE;
             return 0;
@@ -651,7 +653,8 @@ struct RightState {
 };
 // body of the inner loop for one emitted character with code c (FM:721-741 / FM:882-904)
 FMX_HD void boundary_chunk_char(const DevIndex &ix, int mode, int32_t c, int32_t mapped_boundary, uint16_t *dest,
-                                int32_t dst_len, int32_t offset, int32_t down_len, RightState &r, int &status) {
+                                int32_t dst_len, int32_t offset, int32_t down_len, RightState &r, int &status,
+                                bool writer = true) {
     if (c == mapped_boundary) {
         if (r.up_pos == 0) {  // the first char was a boundary: return 0 (FM:725-728)
             r.ret = 0;
@@ -673,7 +676,7 @@ FMX_HD void boundary_chunk_char(const DevIndex &ix, int mode, int32_t c, int32_t
             r.done = true;
             return;
         }
-        dest[w] = (uint16_t)ix.look_up[c];  // FM:738-739
+        if (writer) dest[w] = (uint16_t)ix.look_up[c];  // FM:738-739
         --r.up_pos;
     } else if (r.up_pos > 0) {  // range is (from, boundary], FM:899-902
         if (w - 1 < 0) {
@@ -681,7 +684,7 @@ FMX_HD void boundary_chunk_char(const DevIndex &ix, int mode, int32_t c, int32_t
             r.done = true;
             return;
         }
-        dest[w - 1] = (uint16_t)ix.look_up[c];
+        if (writer) dest[w - 1] = (uint16_t)ix.look_up[c];
         --r.up_pos;
     }
 }
@@ -726,7 +729,7 @@ FMX_HD int32_t fm_boundary_right_literal(const DevIndex &ix, const uint16_t *inv
 
 // codes of text positions [k*s, min((k+1)*s, length)) into buf[(pos - k*s) * stride] with one walk from the
 // ISA sample k+1 (the wrap entry for the last interval, FM:367-369); returns false if any step is suspect
-FMX_HD bool fm_fetch_interval(const DevIndex &ix, const uint16_t *inv, int32_t k, uint16_t *buf, int32_t stride,
+FMX_HD bool fm_fetch_interval(const DevIndex &ix, const uint16_t *inv, int32_t k, uint16_t *buf, int64_t stride,
                               int32_t &steps, int &status) {
     const int32_t s = ix.sample_rate;
     const int64_t top64 = (int64_t)(k + 1) * s;
@@ -746,7 +749,7 @@ FMX_HD bool fm_fetch_interval(const DevIndex &ix, const uint16_t *inv, int32_t k
 FMX_HD int32_t fm_boundary_right_blocks(const DevIndex &ix, const uint16_t *inv, int mode, int32_t from,
                                         int32_t mapped_boundary, uint16_t *dest, int32_t dst_len, int32_t offset,
                                         int32_t down_len, int32_t &steps, int &status, int32_t &aux, uint16_t *buf,
-                                        int32_t stride, bool &clean) {
+                                        int64_t stride, bool &clean) {
     const int32_t s = ix.sample_rate;
     const int32_t step = 4;
     RightState r = {-1, 0, 0, 0, false};
@@ -794,7 +797,7 @@ FMX_HD int32_t fm_boundary_right_blocks(const DevIndex &ix, const uint16_t *inv,
 FMX_HD int32_t fm_boundary_right(const DevIndex &ix, const uint16_t *inv, int mode, int32_t from,
                                  int32_t mapped_boundary, uint16_t *dest, int32_t dst_len, int32_t offset,
                                  int32_t down_len, int32_t &steps, int &status, int32_t &aux, uint16_t *scratch,
-                                 int32_t scratch_stride) {
+                                 int64_t scratch_stride) {
     if (scratch) {
         bool clean;
         int32_t steps2 = 0, aux2 = 0;
@@ -818,7 +821,7 @@ FMX_HD int32_t fm_boundary_right(const DevIndex &ix, const uint16_t *inv, int mo
 FMX_HD int32_t fm_extract_boundary(const DevIndex &ix, const uint16_t *inv, int mode, int32_t from,
                                    int32_t mapped_boundary, uint16_t *dest, int32_t dst_len, int32_t offset,
                                    int32_t &steps, int &status, int32_t &aux, uint16_t *scratch = nullptr,
-                                   int32_t scratch_stride = 1) {
+                                   int64_t scratch_stride = 1) {
     steps = 0;
     aux = 0;
     if (mode == 1) ++from;  // FM:774
@@ -889,6 +892,193 @@ FMX_HD int32_t fm_extract_boundary(const DevIndex &ix, const uint16_t *inv, int 
     }
     return fm_boundary_right(ix, inv, mode, from, mapped_boundary, dest, dst_len, offset, down_len, steps, status, aux,
                              scratch, scratch_stride);
+}
+
+// ---- group-cooperative extractUntilBoundary ------------------------------------------------------------
+// G lanes serve one query.  All of them run the same replay of the reference's control flow (cheap, and it
+// keeps the group converged); the text comes from a window of G sample intervals in LDS, refilled on demand
+// with each lane walking a DIFFERENT interval (the walks are independent: every interval starts at its own
+// ISA sample).  Lane 0 of the group is the only writer of `dest`.  One serial chain of hundreds of LF-steps
+// per query becomes a few rounds of <= sample_rate steps, with G times more lanes in flight.
+// Host build: G = 1, g = 0 (no cross-lane traffic).
+template <int G>
+struct TextWindow {
+    uint16_t *buf;    // slot i (interval k_lo + i), offset j at buf[j * row_stride + i * slot_stride]
+    int64_t row_stride, slot_stride;
+    int32_t s;        // sample rate
+    int32_t k_lo;     // first interval in the window (-1: empty)
+    int32_t g;        // this lane's index in the group
+    int32_t steps;    // LF-steps this lane walked
+    bool suspect;     // some walk of the group touched a quirk path -> redo the query literally
+};
+
+template <int G>
+FMX_HD bool group_any(bool v) {
+#if defined(__HIPCC__)
+    int x = v ? 1 : 0;
+    for (int m = 1; m < G; m <<= 1) x |= __shfl_xor(x, m);
+    return x != 0;
+#else
+    return v;
+#endif
+}
+template <int G>
+FMX_HD int32_t group_sum(int32_t v) {
+#if defined(__HIPCC__)
+    for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m);
+#endif
+    return v;
+}
+
+// make interval k resident; dir > 0: window [k, k+G), dir < 0: window [k-G+1, k]
+template <int G>
+FMX_HD void window_refill(const DevIndex &ix, const uint16_t *inv, TextWindow<G> &w, int32_t k, int dir) {
+    const int32_t k_max = (ix.length - 1) / w.s;  // last interval that holds text (incl. the sentinel)
+    int32_t lo = dir > 0 ? k : k - (G - 1);
+    if (lo < 0) lo = 0;
+    w.k_lo = lo;
+    const int32_t mine = lo + w.g;
+    bool ok = true;
+    if (mine <= k_max) {
+        int status = ST_OK;
+        ok = fm_fetch_interval(ix, inv, mine, w.buf + (int64_t)w.g * w.slot_stride, w.row_stride, w.steps, status);
+    }
+    if (group_any<G>(!ok)) w.suspect = true;
+}
+
+template <int G>
+FMX_HD int32_t window_code_at(const DevIndex &ix, const uint16_t *inv, TextWindow<G> &w, int32_t pos, int dir) {
+    const int32_t k = pos / w.s;
+    if (w.k_lo < 0 || k < w.k_lo || k >= w.k_lo + G) window_refill<G>(ix, inv, w, k, dir);
+    return w.buf[(int64_t)(pos - k * w.s) * w.row_stride + (int64_t)(k - w.k_lo) * w.slot_stride];
+}
+
+// Same results as fm_extract_boundary (FM:640-922).  `clean` = false: a walk was suspect, nothing can be
+// trusted — the caller reruns the query with the literal form.  steps: LF-steps walked by the whole group.
+// buf: two windows of G intervals per group (left window, then right window `win_stride` elements further).
+// Both windows are fetched up front, at ONE program point, so that all lanes of a wave walk their intervals
+// together; later refills (lines longer than a window) happen wherever the replay needs them.
+template <int G>
+FMX_HD int32_t fm_extract_boundary_group(const DevIndex &ix, const uint16_t *inv, int mode, int32_t from,
+                                         int32_t mapped_boundary, uint16_t *dest, int32_t dst_len, int32_t offset,
+                                         int32_t &steps, int &status, int32_t &aux, uint16_t *buf, int64_t row_stride,
+                                         int64_t slot_stride, int64_t win_stride, int32_t g, bool &clean) {
+    steps = 0;
+    aux = 0;
+    clean = true;
+    const bool writer = (g == 0);
+    if (mode == 1) ++from;  // FM:774
+    if (!ix.enable_extract) {  // checkBoundsForExtraction FM:610-626
+        status = ST_NOT_ENABLED;
+        return 0;
+    }
+    if (from < 0) {
+        status = ST_POS_NEGATIVE;
+        return 0;
+    }
+    if (from >= ix.length) {
+        status = ST_POS_TOO_LONG;
+        return 0;
+    }
+    if (dst_len == 0) {
+        status = ST_DEST_SIZE_ZERO;
+        return 0;
+    }
+    if (mapped_boundary == 0) {
+        status = ST_NO_BOUNDARY;  // FM:659-661, 792-794, 849-851
+        return 0;
+    }
+    const int32_t s = ix.sample_rate;
+    const int32_t k0 = from / s;
+    TextWindow<G> wl = {buf, row_stride, slot_stride, s, -1, g, 0, false};               // intervals <= k0
+    TextWindow<G> wr = {buf + win_stride, row_stride, slot_stride, s, -1, g, 0, false};  // intervals > k0
+    window_refill<G>(ix, inv, wl, k0, -1);                          // [k0-G+1, k0]: the left part and text[from..]
+    if (mode != 1) window_refill<G>(ix, inv, wr, k0 + 1, +1);       // [k0+1, k0+G]
+    int32_t ret = 0;
+    bool finished = false;
+    int32_t down_len = 0;
+    if (mode != 2) {  // left part (FM:655-690 / FM:788-828): text[from-1], text[from-2], ... until boundary / start
+        int32_t down_pos = dst_len - 1;
+        int32_t remaining = dst_len;
+        for (int32_t pos = from - 1; mode == 1 || remaining > 0; --pos) {
+            const int32_t c = pos < 0 ? 0 : window_code_at<G>(ix, inv, wl, pos, -1);  // before text[0] the walk meets the sentinel
+            if (wl.suspect) break;
+            if (c == mapped_boundary || c == 0) break;  // FM:674-680
+            if (down_pos < 0) {                          // destination[-1]
+                status = ST_JAVA_AIOOBE;
+                finished = true;
+                break;
+            }
+            if (writer) dest[down_pos] = (uint16_t)ix.look_up[c];  // FM:682
+            --down_pos;
+            --remaining;
+            if (mode == 1 && down_pos == offset) {  // FM:816-821
+                status = ST_DOES_NOT_FIT;
+                aux = dst_len - offset;
+                finished = true;
+                break;
+            }
+        }
+        if (!finished && !wl.suspect) {
+            down_len = dst_len - (down_pos + 1);  // FM:689
+            if (offset < 0 || offset + down_len > dst_len) {  // System.arraycopy range check, FM:690
+                status = ST_JAVA_AIOOBE;
+                finished = true;
+            } else {
+                if (writer && down_len > 0 && offset != down_pos + 1) {
+                    if (offset < down_pos + 1)
+                        for (int32_t t = 0; t < down_len; ++t) dest[offset + t] = dest[down_pos + 1 + t];
+                    else
+                        for (int32_t t = down_len - 1; t >= 0; --t) dest[offset + t] = dest[down_pos + 1 + t];
+                }
+                if (mode == 1) {
+                    ret = down_len;  // FM:830
+                    finished = true;
+                }
+            }
+        }
+    }
+    if (!finished && !wl.suspect && !wr.suspect) {  // right part in +4 chunks (FM:692-758 / FM:853-921)
+        const int32_t step = 4;
+        RightState r = {-1, 0, 0, 0, false};
+        int32_t times_up = 1;
+        while (r.final_pos == -1 && !r.done && !wl.suspect && !wr.suspect) {
+            const int32_t prev_from = from;
+            from += step;
+            if (from > ix.length - 1) from = ix.length - 1;
+            const int32_t remaining = from - prev_from;
+            r.up_pos = (times_up - 1) * step + remaining - 1;
+            int32_t c4[4] = {0, 0, 0, 0};
+            for (int32_t i = 0; i < remaining; ++i) {
+                const int32_t pos = prev_from + i;
+                c4[i] = (pos / s <= k0) ? window_code_at<G>(ix, inv, wl, pos, +1) : window_code_at<G>(ix, inv, wr, pos, +1);
+            }
+            if (wl.suspect || wr.suspect) break;
+            for (int32_t i = remaining - 1; i >= 0 && !r.done; --i) {  // the reference emits from-1 first
+                const int32_t c = (i == 3) ? c4[3] : (i == 2) ? c4[2] : (i == 1) ? c4[1] : c4[0];
+                boundary_chunk_char(ix, mode, c, mapped_boundary, dest, dst_len, offset, down_len, r, status, writer);
+            }
+            if (r.done) break;
+            if (from == ix.length - 1) {  // FM:745-752 / FM:908-915
+                r.final_pos = (mode == 0) ? ((r.up_pos < 0) ? 1 : r.up_pos + from - prev_from) : r.up_pos + from - prev_from;
+                break;
+            }
+            ++times_up;
+        }
+        if (r.done) {
+            aux = r.aux;
+            ret = r.ret;
+        } else if (!wl.suspect && !wr.suspect) {
+            ret = (mode == 0) ? down_len + r.final_pos : r.final_pos - 1;  // FM:758 / FM:921
+        }
+    }
+    steps = group_sum<G>(wl.steps + wr.steps);
+    if (wl.suspect || wr.suspect) {
+        clean = false;
+        status = ST_OK;
+        return 0;
+    }
+    return ret;
 }
 
 }  // namespace fmx

@@ -141,34 +141,67 @@ FMX_KERNEL(kBlock) void k_extract(DevIndex ix, const int32_t *__restrict__ start
     }
 }
 
-// FM:640-759 (mode 0), FM:772-831 (mode 1), FM:844-922 (mode 2).  256-thread workgroups: 32 KiB table +
-// 32 KiB of per-lane interval buffers (sample_rate <= 64 codes per lane, element i of lane t at
-// s_buf[i * 256 + t]) for the accelerated right walk (fm_boundary_right_blocks); larger sample rates run
-// the literal form.
-constexpr int kBoundaryBlock = 256;
-constexpr int kBoundaryMaxSample = 64;
-__global__ __launch_bounds__(kBoundaryBlock) void k_extract_boundary(DevIndex ix, const int32_t *__restrict__ froms,
-                                                                     int32_t n, uint16_t boundary, int mode,
-                                                                     uint16_t *__restrict__ dst, int32_t dst_len,
-                                                                     int32_t offset, int32_t *__restrict__ out_len,
-                                                                     int32_t *__restrict__ lf_steps,
-                                                                     int32_t *__restrict__ status_out,
-                                                                     int32_t *__restrict__ aux_out, int accelerate) {
+// FM:640-759 (mode 0), FM:772-831 (mode 1), FM:844-922 (mode 2), one lane per query.  `scratch` (nullable) holds
+// sample_rate codes per lane of the grid (element j of lane t at scratch[j * lanes + t]) for the
+// interval-buffered right walk (fm_boundary_right_blocks); without it the literal form runs.
+template <int kBlock>
+FMX_KERNEL(kBlock) void k_extract_boundary(DevIndex ix, const int32_t *__restrict__ froms, int32_t n, uint16_t boundary,
+                                           int mode, uint16_t *__restrict__ dst, int32_t dst_len, int32_t offset,
+                                           int32_t *__restrict__ out_len, int32_t *__restrict__ lf_steps,
+                                           int32_t *__restrict__ status_out, int32_t *__restrict__ aux_out,
+                                           uint16_t *__restrict__ scratch) {
     __shared__ uint16_t s_inv[kInvEntries];
-    __shared__ uint16_t s_buf[kBoundaryMaxSample * kBoundaryBlock];
     stage_inverse_table(s_inv, ix.inv_global);
-    const int64_t stride = (int64_t)gridDim.x * kBoundaryBlock;
+    const int64_t lanes = (int64_t)gridDim.x * kBlock;
+    const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int32_t mapped_boundary = fm_map(ix, boundary);  // FM:658
-    uint16_t *scratch = (accelerate && ix.sample_rate <= kBoundaryMaxSample) ? s_buf + threadIdx.x : nullptr;
-    for (int64_t q = (int64_t)blockIdx.x * kBoundaryBlock + threadIdx.x; q < n; q += stride) {
+    for (int64_t q = lane; q < n; q += lanes) {
         int status = ST_OK;
         int32_t steps, aux;
         const int32_t ret = fm_extract_boundary(ix, s_inv, mode, froms[q], mapped_boundary, dst + q * (int64_t)dst_len,
-                                                dst_len, offset, steps, status, aux, scratch, kBoundaryBlock);
+                                                dst_len, offset, steps, status, aux, scratch ? scratch + lane : nullptr,
+                                                lanes);
         out_len[q] = status ? 0 : ret;
         if (lf_steps) lf_steps[q] = steps;
         if (status_out) status_out[q] = status;
         if (aux_out) aux_out[q] = aux;
+    }
+}
+
+// Group-cooperative extractUntilBoundary: G lanes per query (fm_extract_boundary_group); the window of a group
+// is G consecutive lane columns of `scratch` (left window in the first half, right window in the second).
+template <int kBlock, int G>
+FMX_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix, const int32_t *__restrict__ froms, int32_t n,
+                                                 uint16_t boundary, int mode, uint16_t *__restrict__ dst,
+                                                 int32_t dst_len, int32_t offset, int32_t *__restrict__ out_len,
+                                                 int32_t *__restrict__ lf_steps, int32_t *__restrict__ status_out,
+                                                 int32_t *__restrict__ aux_out, uint16_t *__restrict__ scratch) {
+    __shared__ uint16_t s_inv[kInvEntries];
+    stage_inverse_table(s_inv, ix.inv_global);
+    const int64_t lanes = (int64_t)gridDim.x * kBlock;
+    const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int g = threadIdx.x % G;
+    const int64_t groups = lanes / G;
+    const int32_t mapped_boundary = fm_map(ix, boundary);  // FM:658
+    for (int64_t q = lane / G; q < n; q += groups) {
+        int status = ST_OK;
+        int32_t steps, aux;
+        bool clean;
+        uint16_t *dest = dst + q * (int64_t)dst_len;
+        int32_t ret = fm_extract_boundary_group<G>(ix, s_inv, mode, froms[q], mapped_boundary, dest, dst_len, offset, steps,
+                                                   status, aux, scratch + (lane - g), lanes, 1, lanes * (int64_t)ix.sample_rate, g, clean);
+        if (!clean && g == 0) {  // a walk met a quirk path of the wavelet tree: literal form (rare)
+            int32_t steps2;
+            status = ST_OK;
+            ret = fm_extract_boundary(ix, s_inv, mode, froms[q], mapped_boundary, dest, dst_len, offset, steps2, status, aux);
+            steps += steps2;
+        }
+        if (g == 0) {
+            out_len[q] = status ? 0 : ret;
+            if (lf_steps) lf_steps[q] = steps;
+            if (status_out) status_out[q] = status;
+            if (aux_out) aux_out[q] = aux;
+        }
     }
 }
 
@@ -369,6 +402,7 @@ __global__ __launch_bounds__(kTileThreads) void k_order_tile_sort(DevIndex ix, c
 static int g_block = 512;
 static int g_groups_per_cu = 16;
 static int g_boundary_accel = 1;  // 0 = literal right walk of extractUntilBoundary (A/B and fallback)
+static int g_boundary_group = 4;  // lanes per query of extractUntilBoundary (0 = one lane per query)
 static int g_lds_pad_kb = 0;   // experiment knob: extra dynamic LDS per workgroup (lowers occupancy)
 static int g_sort_min = 16384;  // batches at least this large are processed in suffix-sorted order (0 = never)
 static int g_sort_bits = 28;    // full key width: floor(sort_bits / bits-per-code) trailing characters
@@ -386,6 +420,11 @@ int set_option(const char *name, int value) {
     }
     if (!strcmp(name, "boundary_accel")) {
         g_boundary_accel = value != 0;
+        return 0;
+    }
+    if (!strcmp(name, "boundary_group")) {
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return -1;
+        g_boundary_group = value;
         return 0;
     }
     if (!strcmp(name, "lds_pad_kb")) {
@@ -507,12 +546,53 @@ int launch_extract(const DevIndex &ix, int n_cu, const int32_t *start, const int
     return (int)hipGetLastError();
 }
 
+// lanes the extractUntilBoundary grid will run with, and the scratch it needs (sample_rate codes per lane)
+static int boundary_group_size() { return g_boundary_accel ? g_boundary_group : 0; }  // 0 = one lane, literal/serial forms
+static int64_t boundary_lanes(int32_t n, int n_cu) {
+    const int G = boundary_group_size();
+    return (int64_t)grid_for((int64_t)n * (G ? G : 1), g_block, n_cu) * g_block;
+}
+size_t boundary_workspace_bytes(const DevIndex &ix, int32_t n, int n_cu) {
+    if (!g_boundary_accel || n <= 0) return 0;
+    return (size_t)boundary_lanes(n, n_cu) * (size_t)ix.sample_rate * sizeof(uint16_t) * 2 + 256;  // two windows
+}
+
 int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, int32_t n, uint16_t boundary, int mode,
                             uint16_t *dst, int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf,
-                            int32_t *status, int32_t *aux, hipStream_t st) {
+                            int32_t *status, int32_t *aux, void *workspace, size_t workspace_bytes, hipStream_t st) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_extract_boundary, dim3(grid_for((int64_t)n, kBoundaryBlock, n_cu)), dim3(kBoundaryBlock), 0, st, ix,
-                       from, n, boundary, mode, dst, dst_len, offset, out_len, lf, status, aux, g_boundary_accel);
+    uint16_t *scratch = (workspace && workspace_bytes >= boundary_workspace_bytes(ix, n, n_cu) && g_boundary_accel)
+                            ? static_cast<uint16_t *>(workspace)
+                            : nullptr;
+    const int G = scratch ? boundary_group_size() : 0;
+    const int blk = g_block;
+    const dim3 grid(grid_for((int64_t)n * (G ? G : 1), blk, n_cu));
+#define FMX_LAUNCH_GROUP(GG)                                                                                            \
+    do {                                                                                                                \
+        if (blk == 1024)                                                                                                \
+            hipLaunchKernelGGL((k_extract_boundary_group<1024, GG>), grid, dim3(1024), 0, st, ix, from, n, boundary, mode, dst, \
+                               dst_len, offset, out_len, lf, status, aux, scratch);                                     \
+        else                                                                                                            \
+            hipLaunchKernelGGL((k_extract_boundary_group<512, GG>), grid, dim3(512), 0, st, ix, from, n, boundary, mode, dst,  \
+                               dst_len, offset, out_len, lf, status, aux, scratch);                                     \
+    } while (0)
+    if (G == 1)
+        FMX_LAUNCH_GROUP(1);
+    else if (G == 2)
+        FMX_LAUNCH_GROUP(2);
+    else if (G == 4)
+        FMX_LAUNCH_GROUP(4);
+    else if (G == 8)
+        FMX_LAUNCH_GROUP(8);
+    else if (G == 16)
+        FMX_LAUNCH_GROUP(16);
+    else if (blk == 1024)
+        hipLaunchKernelGGL(k_extract_boundary<1024>, grid, dim3(1024), 0, st, ix, from, n, boundary, mode, dst, dst_len, offset,
+                           out_len, lf, status, aux, scratch);
+    else
+        hipLaunchKernelGGL(k_extract_boundary<512>, grid, dim3(512), 0, st, ix, from, n, boundary, mode, dst, dst_len, offset,
+                           out_len, lf, status, aux, scratch);
+#undef FMX_LAUNCH_GROUP
     return (int)hipGetLastError();
 }
 

@@ -154,12 +154,24 @@ void sim_extract_boundary(const uint8_t *blob, const int32_t *froms, int32_t n, 
                           int32_t *status_out, int32_t *aux_out, int accelerate) {
     DevIndex ix = make_index(blob);
     const int32_t mapped_boundary = fm_map(ix, boundary);
-    uint16_t *scratch = accelerate ? new uint16_t[(size_t)ix.sample_rate + 1] : nullptr;
+    uint16_t *scratch = accelerate ? new uint16_t[2 * (size_t)ix.sample_rate + 2] : nullptr;
     for (int32_t q = 0; q < n; ++q) {
         int status = ST_OK;
         int32_t steps, aux;
-        const int32_t ret = fm_extract_boundary(ix, ix.inv_global, mode, froms[q], mapped_boundary,
-                                                dst + (int64_t)q * dst_len, dst_len, offset, steps, status, aux, scratch, 1);
+        int32_t ret;
+        if (accelerate == 2) {  // group-cooperative form with a group of one lane
+            bool clean;
+            ret = fm_extract_boundary_group<1>(ix, ix.inv_global, mode, froms[q], mapped_boundary, dst + (int64_t)q * dst_len,
+                                               dst_len, offset, steps, status, aux, scratch, 1, 1, ix.sample_rate + 1, 0, clean);
+            if (!clean) {
+                status = ST_OK;
+                ret = fm_extract_boundary(ix, ix.inv_global, mode, froms[q], mapped_boundary, dst + (int64_t)q * dst_len,
+                                          dst_len, offset, steps, status, aux);
+            }
+        } else {
+            ret = fm_extract_boundary(ix, ix.inv_global, mode, froms[q], mapped_boundary, dst + (int64_t)q * dst_len,
+                                      dst_len, offset, steps, status, aux, scratch, 1);
+        }
         out_len[q] = status ? 0 : ret;
         if (lf) lf[q] = steps;
         if (status_out) status_out[q] = status;

@@ -45,6 +45,18 @@ def test_literal_right_walk_gives_the_same_answers():
         ia.lib.fmx_set_option(b"boundary_accel", 1)
 
 
+@pytest.mark.parametrize("group", [0, 1, 2, 4, 8, 16])
+def test_group_cooperative_extract_gives_the_same_answers(group):
+    """extractUntilBoundary with G lanes per query (each lane walks a different sample interval) vs the oracle"""
+    try:
+        assert ia.lib.fmx_set_option(b"boundary_group", group) == 0
+        check_all(make_gpu, HD[:150_000], 32, random.Random(90 + group), n_q=100)
+        check_all(make_gpu, HD[:80_000], 64, random.Random(91 + group), n_q=80)
+        check_all(make_gpu, HD[:50_000], 3, random.Random(92 + group), n_q=60)
+    finally:
+        ia.lib.fmx_set_option(b"boundary_group", 4)
+
+
 def test_embedded_sentinels_and_small_texts():
     rnd = random.Random(11)
     mod = list(HD[:40_000])

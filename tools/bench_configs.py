@@ -146,8 +146,21 @@ def main():
     ok = j < len(nl)
     exp_len = np.where(text[frm] == 10, 0, nl[np.minimum(j, len(nl) - 1)] - lo)  # a seed on the boundary returns 0 (FM:725-728)
     assert (lens[ok] == exp_len[ok]).all()  # every full line has the scanned length
+    sweep = {}
+    for G in (0, 1, 2, 4, 8, 16):
+        assert ia.lib.fmx_set_option(b"boundary_group", G) == 0
+        extract(True)
+        torch.cuda.synchronize()
+        assert (d_len.cpu().numpy() == lens).all() and int(d_st.max().item()) == 0
+        assert (d_dst.cpu().numpy().view(np.uint16).reshape(n, cap) == dst).all()
+        sweep[G] = {"ms": timed(lambda: extract(False), stream, 5), "lf_steps": int(d_lf.sum(dtype=torch.int64).item())}
+    best = min(sweep, key=lambda g: sweep[g]["ms"])
+    ia.lib.fmx_set_option(b"boundary_group", 4)
+    extract(True)
+    torch.cuda.synchronize()
+    lf_total = int(d_lf.sum(dtype=torch.int64).item())
     ms = timed(lambda: extract(False), stream, 5)
-    out.append({"config": "configs[3] extractUntilBoundary('\\n') for 100k hit locations, 256 MiB, sampleRate 64", "ms": ms,
+    out.append({"lanes_per_query_sweep": sweep, "best_lanes_per_query": best, "config": "configs[3] extractUntilBoundary('\\n') for 100k hit locations, 256 MiB, sampleRate 64", "ms": ms,
                 "queries": n, "chars_extracted": int(lens.sum()), "lf_steps": lf_total, "queries_per_s": n / ms * 1e3,
                 "chars_per_s": int(lens.sum()) / ms * 1e3, "lf_steps_per_s": lf_total / ms * 1e3,
                 "oracle_alg_bytes_per_lf_step": oc["alg_bytes"] / max(1, oc["lf_steps"]),
