@@ -25,6 +25,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_latest.json")  # rocprofv3 --pmc passes of this very command
+
+
+def pmc_traffic(text_log2, patterns, sample_rate):
+    """fabric-side bytes per k_count launch from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, KiB units,
+    collected in separate passes by tools/profile.sh); None when no profile matches the workload"""
+    try:
+        p = json.load(open(PMC_FILE))
+        w = p["workload"]
+        if (w["text_log2"], w["patterns"], w["sample_rate"]) != (text_log2, patterns, sample_rate):
+            return None
+        return (p["k_count"]["FETCH_SIZE_KiB"] + p["k_count"]["WRITE_SIZE_KiB"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def log(*a):
@@ -247,7 +261,8 @@ def main():
     if bytes_per_step:
         achieved = bytes_per_step * lf_steps_per_launch / (kernel_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_count",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": pmc_traffic(args.text_log2, n, args.sample_rate), "kernel": "k_count",
                 "kernel_ms": kernel_ms, "step_ms_incl_sort": step_ms, "alg_bytes_per_lf_step": bytes_per_step,
                 "lf_steps_per_launch": lf_steps_per_launch,
                 "wt_levels_per_lf_step": holder.get("levels_per_step")}

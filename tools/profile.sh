@@ -15,6 +15,7 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_tcp" -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 3 --warmup 1 "$@" > "$OUT/bench_pmc_tcp.json" 2> "$OUT/bench_pmc_tcp.err"
 cd "$ROOT"
 python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+python3 tools/summarize_prof.py "$OUT" --pmc-json "$OUT/pmc.json" > /dev/null 2>&1
 find "$OUT" -name '*.csv' -size +8M -delete
 ls -R "$OUT" | head -60
 cat "$OUT/summary.txt"

@@ -12,8 +12,37 @@ def find(root, pattern):
     return sorted(glob.glob(os.path.join(root, "**", pattern), recursive=True))
 
 
+def pmc_json(root, path):
+    """per-launch averages of the k_count counters -> the JSON bench.py reads (profiles/pmc_latest.json)"""
+    import json
+
+    out = {}
+    for sub in ("pmc_fetch", "pmc_tcc", "pmc_sq", "pmc_tcp"):
+        for f in find(os.path.join(root, sub), "*counter_collection.csv"):
+            agg = defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                if "k_count" in r.get("Kernel_Name", ""):
+                    agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            for c, v in agg.items():
+                out[c] = sum(v) / len(v)
+    doc = {"source": "rocprofv3 --pmc passes of `bench.py --no-cpu-baseline --steps 3 --warmup 1` (tools/profile.sh), per-launch "
+                     "averages; FETCH_SIZE / WRITE_SIZE are in KiB",
+           "workload": {"text_log2": 28, "patterns": 1 << 20, "sample_rate": 32},
+           "k_count": {"FETCH_SIZE_KiB": out.get("FETCH_SIZE"), "WRITE_SIZE_KiB": out.get("WRITE_SIZE"),
+                       "TCC_HIT": out.get("TCC_HIT_sum"), "TCC_MISS": out.get("TCC_MISS_sum"),
+                       "TCP_TCC_READ_REQ": out.get("TCP_TCC_READ_REQ_sum"),
+                       "TCP_TOTAL_CACHE_ACCESSES": out.get("TCP_TOTAL_CACHE_ACCESSES_sum"),
+                       "SQ_INSTS_VALU": out.get("SQ_INSTS_VALU"), "SQ_INSTS_VMEM_RD": out.get("SQ_INSTS_VMEM_RD"),
+                       "SQ_WAVE_CYCLES": out.get("SQ_WAVE_CYCLES"), "SQ_WAIT_ANY": out.get("SQ_WAIT_ANY"),
+                       "SQ_ACTIVE_INST_ANY": out.get("SQ_ACTIVE_INST_ANY"), "GRBM_GUI_ACTIVE": out.get("GRBM_GUI_ACTIVE")}}
+    json.dump(doc, open(path, "w"), indent=1)
+
+
 def main():
     root = sys.argv[1]
+    if len(sys.argv) > 3 and sys.argv[2] == "--pmc-json":
+        pmc_json(root, sys.argv[3])
+        return
     print("# rocprofv3 summary of", root)
     for f in find(os.path.join(root, "trace"), "*kernel_stats.csv"):
         print("\n## kernel stats (%s)" % os.path.relpath(f, root))
