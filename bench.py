@@ -238,6 +238,16 @@ def main():
     else:
         lf_total = lf_steps_per_launch
 
+    # final gather of the shards' results on rank 0 (outside the timed region: the shards are independent)
+    gathered_checksum = None
+    if dist is not None:
+        from index4j_amd.shard import gather_concat
+
+        all_counts = gather_concat(dist, d_cnt, [n] * world, dev)
+        if rank == 0:
+            gathered_checksum = int(all_counts.astype(np.int64).sum())
+            if len(all_counts) != n * world:
+                raise RuntimeError("gather returned %d results for %d patterns" % (len(all_counts), n * world))
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -285,7 +295,7 @@ def main():
                                                                              (1 << args.text_log2) >> 20, args.sample_rate),
                    "text_chars": 1 << args.text_log2, "patterns_per_gpu": n, "pattern_len": args.pattern_len,
                    "sample_rate": args.sample_rate, "parallelism": "patterns sharded x%d, index replicated" % world,
-                   "count_checksum": checksum},
+                   "count_checksum": checksum, "gathered_checksum_all_ranks": gathered_checksum},
         "roofline": roof,
         "cpu_baseline": base,
     }

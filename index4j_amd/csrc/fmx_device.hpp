@@ -294,19 +294,20 @@ FMX_HD BlockHdr ld_block_hdr(const BlockHdr *p) {
 // the cumulative one-counts of the level (u16 each): [left-1] and [left] come from one 4-byte load
 struct TreeWalk {
     int32_t bv_rank, bv_offset, internal_nodes, left_siblings, left_total_bv, node_bv_size, depth_total_bv, node_rank;
-    const uint8_t *second;  // cumulative one-counts of the current level
-    const uint8_t *level;   // next entry of the level table
+    const uint8_t *hdr;     // variable-size header of the block
+    uint32_t second;        // offset of the cumulative one-counts of the current level
+    uint32_t level;         // offset of the next entry of the level table
 };
 FMX_HD void tree_level_counts(const TreeWalk &t, int32_t &left_ones, int32_t &node_ones, int32_t &level_ones) {
     if (t.left_siblings > 0) {
-        const uint32_t pair = ld32u(t.second + 2 * (t.left_siblings - 1));
+        const uint32_t pair = ld32u(t.hdr + t.second + 2 * (t.left_siblings - 1));
         left_ones = (int32_t)(pair & 0xffffu);                        // WFBB:1193-1206
         node_ones = (int32_t)(pair >> 16) - left_ones;                // WFBB:1210-1214
     } else {
         left_ones = 0;
-        node_ones = (int32_t)ld16(t.second);
+        node_ones = (int32_t)ld16(t.hdr + t.second);
     }
-    level_ones = (int32_t)ld16(t.second + 2 * (t.internal_nodes - 1));  // WFBB:1220-1229
+    level_ones = (int32_t)ld16(t.hdr + t.second + 2 * (t.internal_nodes - 1));  // WFBB:1220-1229
 }
 FMX_HD void tree_descend(TreeWalk &t, bool bit, int32_t rank1, int32_t node_ones) {
     const int32_t node_zeros = t.node_bv_size - node_ones;
@@ -325,7 +326,7 @@ FMX_HD void tree_descend(TreeWalk &t, bool bit, int32_t rank1, int32_t node_ones
 }
 // WFBB:1247-1278: next level's leaf count and total bitvector size (one 4-byte load); returns the leaf count
 FMX_HD int32_t tree_next_level(TreeWalk &t) {
-    const uint32_t e = ld32u(t.level);
+    const uint32_t e = ld32u(t.hdr + t.level);
     const int32_t next_leaf_count = (int32_t)(e & 0xffffu);
     const int32_t next_total_bv = (int32_t)(e >> 16) + 1;
     t.level += 4;
@@ -414,8 +415,9 @@ FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t positio
     t.node_bv_size = (int32_t)cur_block_size;
     t.depth_total_bv = t.node_bv_size;
     t.node_rank = (int32_t)block_index;
-    t.second = leaves + ((int32_t)bh.sigma + 1) * 5;  // WFBB:1177-1182
-    t.level = hdr;
+    t.hdr = hdr;
+    t.second = (uint32_t)((tree_height - 1) * 4 + ((int32_t)bh.sigma + 1) * 5);  // WFBB:1177-1182
+    t.level = 0;
 
     for (int32_t depth = 0; depth < code_length; ++depth) {  // WFBB:1185-1279
         int32_t left_ones, node_ones, level_ones;
@@ -474,8 +476,9 @@ FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32
     t.node_bv_size = (int32_t)cur_block_size;
     t.depth_total_bv = t.node_bv_size;
     t.node_rank = (int32_t)block_index;
-    t.second = leaves + ((int32_t)bh.sigma + 1) * 5;
-    t.level = hdr;
+    t.hdr = hdr;
+    t.second = (uint32_t)((tree_height - 1) * 4 + ((int32_t)bh.sigma + 1) * 5);
+    t.level = 0;
 
     for (int32_t depth = 0;; ++depth) {  // WFBB:1386-1493
         int32_t left_ones, node_ones, level_ones;

@@ -45,9 +45,9 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix, const uint16_t *__restrict__ pat,
     __shared__ uint16_t s_inv[kInvEntries];
     stage_inverse_table(s_inv, ix.inv_global);
     const int role = threadIdx.x & 1;
-    const int64_t pairs_per_grid = (int64_t)gridDim.x * (kBlock / 2);
-    for (int64_t q = (int64_t)blockIdx.x * (kBlock / 2) + (threadIdx.x >> 1); q < n; q += pairs_per_grid) {
-        const int64_t p = perm ? (int64_t)perm[q] : q;
+    const int32_t pairs_per_grid = (int32_t)gridDim.x * (kBlock / 2);  // 32-bit indices: n < 2^31, fewer live registers
+    for (int32_t q = (int32_t)blockIdx.x * (kBlock / 2) + (int32_t)(threadIdx.x >> 1); q < n; q += pairs_per_grid) {
+        const int32_t p = perm ? (int32_t)perm[q] : q;
         const int32_t beg = pat_off[p];
         const int32_t m = pat_off[p + 1] - beg;
         int status = ST_OK;
@@ -81,8 +81,8 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix, const uint16_t *__restrict__ pat,
             if (lf_steps) lf_steps[p] = steps;
             if (status_out) status_out[p] = status;
             if (range_out) {
-                range_out[2 * p] = start;
-                range_out[2 * p + 1] = end;
+                range_out[2 * (int64_t)p] = start;
+                range_out[2 * (int64_t)p + 1] = end;
             }
         }
     }

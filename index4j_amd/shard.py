@@ -36,7 +36,8 @@ def gather_concat(dist, local, counts_per_rank, device, dst=0):
     world, rank = dist.get_world_size(), dist.get_rank()
     mx = max(counts_per_rank)
     pad = torch.zeros(mx, dtype=torch.int32, device=device)
-    pad[: len(local)] = torch.as_tensor(local, dtype=torch.int32, device=device)
+    src = local if isinstance(local, torch.Tensor) else torch.as_tensor(np.asarray(local), dtype=torch.int32)
+    pad[: len(local)] = src.to(device=device, dtype=torch.int32)
     out = [torch.zeros(mx, dtype=torch.int32, device=device) for _ in range(world)]
     dist.all_gather(out, pad)
     if rank != dst:
