@@ -1,0 +1,20 @@
+"""Host-side product code (builder, serializer, flattener) and the oracle under AddressSanitizer +
+UndefinedBehaviorSanitizer (CPU build only; GPU ASan is not available on the pool)."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_host_code_and_oracle_are_sanitizer_clean(tmp_path):
+    exe = str(tmp_path / "san_main")
+    csrc = os.path.join(ROOT, "index4j_amd", "csrc")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-fno-omit-frame-pointer", "-I" + csrc, "-I" + os.path.join(ROOT, "oracle"), "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "san_main.cpp")]
+    cmd += [os.path.join(csrc, f) for f in ("fmx_build.cpp", "fmx_serial.cpp", "fmx_blob.cpp", "fmx_synth.cpp")]
+    cmd += ["-x", "c", os.path.join(ROOT, "oracle", "index4j_oracle.c"), "-lpthread", "-o", exe]
+    subprocess.check_call(cmd)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ERROR" not in r.stderr and "runtime error" not in r.stderr, r.stdout + r.stderr
+    assert r.stdout.count(" ok: ") == 4
