@@ -135,6 +135,38 @@ int fmx_extract_boundary_batch_dev(const fmx_index *idx, const int32_t *d_from, 
                                    int mode, uint16_t *d_dst, int32_t dst_len, int32_t offset, int32_t *d_out_len,
                                    int32_t *d_lf_steps, int32_t *d_status, int32_t *d_aux, void *stream);
 
+/* ---- locate -> extract pipelines ---------------------------------------------------------------
+ * The composite the reference times in locateAndExtractBenchmark (indices/src/jmh/java/com/dynatrace/fm/
+ * FmIndexThroughputBenchmark.java:231-249): matches = locate(pattern, 0, length, locations, maxMatches), then
+ * for each i < matches extract(locations[i], min(getInputLength(), locations[i] + maxExtractionLength),
+ * destination, 0).  Here both stages run on the device and the hit positions never leave HBM.
+ * Hit k of pattern i uses slot i*max_matches + k of locs / out_len / hit_status / hit_aux and destination
+ * row (i*max_matches + k) of `row length` chars, written from offset 0.  Only slots k < found[i] are
+ * written; all others keep the caller's values.  max_matches must be >= 1 (it is the row count per pattern,
+ * and the locate limit FM:504-552); n*max_matches must fit an int32.
+ *   status[i]     = status of locate(pattern i)              (AIOOBE cannot occur: loc_cap == max_matches)
+ *   hit_status[s] = status of the extract call of slot s (e.g. FMX_ST_STOP_TOO_LONG when the hit lies within
+ *                   extract_len of the end of the text: the benchmark's stop == getInputLength(), FM:572-574)
+ * fmx_locate_lines_* replaces extract by extractUntilBoundary (mode 0) / ...Left (1) / ...Right (2),
+ * FM:640-922 — "the lines that contain the pattern"; hit_aux as in fmx_extract_boundary_batch. */
+int fmx_locate_extract_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n,
+                             int32_t max_matches, int32_t extract_len, int32_t *locs, int32_t *found, uint16_t *dst,
+                             int32_t *out_len, int32_t *lf_steps, int32_t *status, int32_t *hit_status);
+int fmx_locate_lines_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n,
+                           int32_t max_matches, uint16_t boundary, int mode, int32_t dst_len, int32_t *locs,
+                           int32_t *found, uint16_t *dst, int32_t *out_len, int32_t *lf_steps, int32_t *status,
+                           int32_t *hit_status, int32_t *hit_aux);
+/* device-pointer forms: enqueue on `stream`; d_range_ws = 2*n ints; d_hit_status / d_hit_aux may be NULL */
+int fmx_locate_extract_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
+                                 int32_t max_matches, int32_t extract_len, int32_t *d_locs, int32_t *d_found,
+                                 uint16_t *d_dst, int32_t *d_out_len, int32_t *d_lf_steps, int32_t *d_status,
+                                 int32_t *d_hit_status, int32_t *d_range_ws, void *stream);
+int fmx_locate_lines_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
+                               int32_t max_matches, uint16_t boundary, int mode, int32_t dst_len, int32_t *d_locs,
+                               int32_t *d_found, uint16_t *d_dst, int32_t *d_out_len, int32_t *d_lf_steps,
+                               int32_t *d_status, int32_t *d_hit_status, int32_t *d_hit_aux, int32_t *d_range_ws,
+                               void *stream);
+
 /* ---- WaveletFixedBlockBoosting as a stand-alone structure (the reference's public class, WFBB:130-154) ----
  * `sequence` = symbols already mapped to small non-negative integers (short[] text of WFBB:130).  The handle
  * answers only the two calls below (after fmx_to_device); free it with fmx_free. */

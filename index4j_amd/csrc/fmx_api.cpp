@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -23,11 +24,12 @@ int launch_count(const DevIndex &, int, const uint16_t *, const int32_t *, const
 size_t count_workspace_bytes(const DevIndex &, int32_t n);
 int launch_locate_walk(const DevIndex &, int, const int32_t *, int32_t, int32_t, int32_t *, int32_t, int32_t *,
                        int32_t *, int32_t *, hipStream_t);
-int launch_extract(const DevIndex &, int, const int32_t *, const int32_t *, int32_t, uint16_t *, int32_t, int32_t,
-                   int32_t *, int32_t *, int32_t *, hipStream_t);
-int launch_extract_boundary(const DevIndex &, int, const int32_t *, int32_t, uint16_t, int, uint16_t *, int32_t,
-                            int32_t, int32_t *, int32_t *, int32_t *, int32_t *, void *, size_t, hipStream_t);
-size_t boundary_workspace_bytes(const DevIndex &, int32_t n, int n_cu);
+int launch_extract(const DevIndex &, int, const int32_t *, const int32_t *, int64_t, uint16_t *, int32_t, int32_t,
+                   int32_t *, int32_t *, int32_t *, const int32_t *, int32_t, int32_t, hipStream_t);
+int launch_extract_boundary(const DevIndex &, int, const int32_t *, int64_t, uint16_t, int, uint16_t *, int32_t,
+                            int32_t, int32_t *, int32_t *, int32_t *, int32_t *, void *, size_t, const int32_t *, int32_t,
+                            hipStream_t);
+size_t boundary_workspace_bytes(const DevIndex &, int64_t n, int n_cu);
 int launch_wt_rank(const DevIndex &, int, const int64_t *, const int32_t *, int32_t, int64_t *, int32_t *, hipStream_t);
 int launch_wt_inverse_select(const DevIndex &, int, const int64_t *, int32_t, int64_t *, int32_t *, hipStream_t);
 int set_option(const char *, int);
@@ -401,7 +403,7 @@ int fmx_extract_batch_dev(const fmx_index *idx, const int32_t *d_start, const in
     if (n < 0 || dst_len < 0 || (n > 0 && (!d_start || !d_stop || !d_out_len || (!d_dst && dst_len > 0))))
         return fail(FMX_E_ARG, "bad arguments");
     int e = fmx::launch_extract(idx->dev, idx->n_cu, d_start, d_stop, n, d_dst, dst_len, offset, d_out_len, d_lf_steps,
-                                d_status, static_cast<hipStream_t>(stream));
+                                d_status, nullptr, 0, 0, static_cast<hipStream_t>(stream));
     if (e) return fail(FMX_E_HIP, std::string("k_extract launch: ") + hipGetErrorString((hipError_t)e));
     return FMX_OK;
 }
@@ -418,7 +420,59 @@ int fmx_extract_boundary_batch_dev(const fmx_index *idx, const int32_t *d_from, 
     rc = get_workspace(idx, stream, ws_bytes, &ws);
     if (rc) return rc;
     int e = fmx::launch_extract_boundary(idx->dev, idx->n_cu, d_from, n, boundary, mode, d_dst, dst_len, offset,
-                                         d_out_len, d_lf_steps, d_status, d_aux, ws, ws_bytes,
+                                         d_out_len, d_lf_steps, d_status, d_aux, ws, ws_bytes, nullptr, 0,
+                                         static_cast<hipStream_t>(stream));
+    if (e) return fail(FMX_E_HIP, std::string("k_extract_boundary launch: ") + hipGetErrorString((hipError_t)e));
+    return FMX_OK;
+}
+
+// ---- locate -> extract pipelines: the hit positions stay in HBM between the two stages ----
+
+static int pipeline_args_ok(int32_t n, int32_t max_matches, int32_t row_len, const void *a, const void *b, const void *c,
+                            const void *d, const void *e) {
+    return n >= 0 && max_matches >= 1 && row_len >= 0 && (int64_t)n * max_matches <= INT32_MAX &&
+           (n == 0 || (a && b && c && d && e));
+}
+
+int fmx_locate_extract_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
+                                 int32_t max_matches, int32_t extract_len, int32_t *d_locs, int32_t *d_found,
+                                 uint16_t *d_dst, int32_t *d_out_len, int32_t *d_lf_steps, int32_t *d_status,
+                                 int32_t *d_hit_status, int32_t *d_range_ws, void *stream) {
+    int rc = require_device(idx);
+    if (rc) return rc;
+    if (!pipeline_args_ok(n, max_matches, extract_len, d_pat_off, d_locs, d_found, d_out_len, d_range_ws) ||
+        (n > 0 && extract_len > 0 && !d_dst))
+        return fail(FMX_E_ARG, "bad arguments");
+    rc = fmx_locate_batch_dev(idx, d_pat, d_pat_off, n, max_matches, d_locs, max_matches, d_found, d_lf_steps, d_status,
+                              d_range_ws, stream);
+    if (rc) return rc;
+    int e = fmx::launch_extract(idx->dev, idx->n_cu, d_locs, nullptr, (int64_t)n * max_matches, d_dst, extract_len, 0,
+                                d_out_len, nullptr, d_hit_status, d_found, max_matches, extract_len,
+                                static_cast<hipStream_t>(stream));
+    if (e) return fail(FMX_E_HIP, std::string("k_extract launch: ") + hipGetErrorString((hipError_t)e));
+    return FMX_OK;
+}
+
+int fmx_locate_lines_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
+                               int32_t max_matches, uint16_t boundary, int mode, int32_t dst_len, int32_t *d_locs,
+                               int32_t *d_found, uint16_t *d_dst, int32_t *d_out_len, int32_t *d_lf_steps,
+                               int32_t *d_status, int32_t *d_hit_status, int32_t *d_hit_aux, int32_t *d_range_ws,
+                               void *stream) {
+    int rc = require_device(idx);
+    if (rc) return rc;
+    if (!pipeline_args_ok(n, max_matches, dst_len, d_pat_off, d_locs, d_found, d_out_len, d_range_ws) || mode < 0 ||
+        mode > 2 || (n > 0 && dst_len > 0 && !d_dst))
+        return fail(FMX_E_ARG, "bad arguments");
+    rc = fmx_locate_batch_dev(idx, d_pat, d_pat_off, n, max_matches, d_locs, max_matches, d_found, d_lf_steps, d_status,
+                              d_range_ws, stream);
+    if (rc) return rc;
+    const int64_t slots = (int64_t)n * max_matches;
+    void *ws = nullptr;
+    const size_t ws_bytes = fmx::boundary_workspace_bytes(idx->dev, slots, idx->n_cu);
+    rc = get_workspace(idx, stream, ws_bytes, &ws);
+    if (rc) return rc;
+    int e = fmx::launch_extract_boundary(idx->dev, idx->n_cu, d_locs, slots, boundary, mode, d_dst, dst_len, 0, d_out_len,
+                                         nullptr, d_hit_status, d_hit_aux, ws, ws_bytes, d_found, max_matches,
                                          static_cast<hipStream_t>(stream));
     if (e) return fail(FMX_E_HIP, std::string("k_extract_boundary launch: ") + hipGetErrorString((hipError_t)e));
     return FMX_OK;
@@ -484,6 +538,81 @@ int fmx_locate_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *p
     if (lf_steps) D2H(lf_steps, d_lf.p, (size_t)n * 4);
     if (status) D2H(status, d_st.p, (size_t)n * 4);
     return FMX_OK;
+}
+
+// shared host-buffer driver of the two pipelines (mode < 0: fixed-length extract)
+static int locate_pipeline_host(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n,
+                                int32_t max_matches, int32_t row_len, uint16_t boundary, int mode, int32_t *locs,
+                                int32_t *found, uint16_t *dst, int32_t *out_len, int32_t *lf_steps, int32_t *status,
+                                int32_t *hit_status, int32_t *hit_aux) {
+    int rc = require_device(idx);
+    if (rc) return rc;
+    if (!pipeline_args_ok(n, max_matches, row_len, pat_off, locs, found, out_len, pat_off) || mode > 2 ||
+        (n > 0 && row_len > 0 && !dst))
+        return fail(FMX_E_ARG, "bad arguments");
+    if (n == 0) return FMX_OK;
+    HIP_TRY(hipSetDevice(idx->device));
+    const size_t chars = (size_t)(pat_off[n] > 0 ? pat_off[n] : 0);
+    const size_t slots = (size_t)n * (size_t)max_matches;
+    const size_t dst_bytes = slots * (size_t)row_len * 2;
+    DevBuf d_pat, d_off, d_locs, d_found, d_dst, d_len, d_lf, d_st, d_hst, d_aux, d_ws;
+    HIP_TRY(d_pat.alloc(chars * 2 + 8));
+    HIP_TRY(d_off.alloc((size_t)(n + 1) * 4));
+    HIP_TRY(d_locs.alloc(slots * 4));
+    HIP_TRY(d_found.alloc((size_t)n * 4));
+    HIP_TRY(d_dst.alloc(dst_bytes));
+    HIP_TRY(d_len.alloc(slots * 4));
+    HIP_TRY(d_lf.alloc((size_t)n * 4));
+    HIP_TRY(d_st.alloc((size_t)n * 4));
+    HIP_TRY(d_hst.alloc(slots * 4));
+    HIP_TRY(d_aux.alloc(slots * 4));
+    HIP_TRY(d_ws.alloc((size_t)n * 8));
+    if (chars) H2D(d_pat.p, pat, chars * 2);
+    H2D(d_off.p, pat_off, (size_t)(n + 1) * 4);
+    // rows and per-hit arrays are in/out like the reference's caller-owned arrays: slots without a hit keep
+    // the caller's values
+    H2D(d_locs.p, locs, slots * 4);
+    if (dst_bytes) H2D(d_dst.p, dst, dst_bytes);
+    H2D(d_len.p, out_len, slots * 4);
+    if (hit_status) H2D(d_hst.p, hit_status, slots * 4);
+    if (hit_aux) H2D(d_aux.p, hit_aux, slots * 4);
+    if (mode < 0)
+        rc = fmx_locate_extract_batch_dev(idx, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, max_matches, row_len,
+                                          d_locs.as<int32_t>(), d_found.as<int32_t>(), d_dst.as<uint16_t>(),
+                                          d_len.as<int32_t>(), d_lf.as<int32_t>(), d_st.as<int32_t>(),
+                                          d_hst.as<int32_t>(), d_ws.as<int32_t>(), nullptr);
+    else
+        rc = fmx_locate_lines_batch_dev(idx, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, max_matches, boundary, mode,
+                                        row_len, d_locs.as<int32_t>(), d_found.as<int32_t>(), d_dst.as<uint16_t>(),
+                                        d_len.as<int32_t>(), d_lf.as<int32_t>(), d_st.as<int32_t>(), d_hst.as<int32_t>(),
+                                        d_aux.as<int32_t>(), d_ws.as<int32_t>(), nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    D2H(locs, d_locs.p, slots * 4);
+    D2H(found, d_found.p, (size_t)n * 4);
+    if (dst_bytes) D2H(dst, d_dst.p, dst_bytes);
+    D2H(out_len, d_len.p, slots * 4);
+    if (lf_steps) D2H(lf_steps, d_lf.p, (size_t)n * 4);
+    if (status) D2H(status, d_st.p, (size_t)n * 4);
+    if (hit_status) D2H(hit_status, d_hst.p, slots * 4);
+    if (hit_aux) D2H(hit_aux, d_aux.p, slots * 4);
+    return FMX_OK;
+}
+
+int fmx_locate_extract_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n,
+                             int32_t max_matches, int32_t extract_len, int32_t *locs, int32_t *found, uint16_t *dst,
+                             int32_t *out_len, int32_t *lf_steps, int32_t *status, int32_t *hit_status) {
+    return locate_pipeline_host(idx, pat, pat_off, n, max_matches, extract_len, 0, -1, locs, found, dst, out_len,
+                                lf_steps, status, hit_status, nullptr);
+}
+
+int fmx_locate_lines_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n,
+                           int32_t max_matches, uint16_t boundary, int mode, int32_t dst_len, int32_t *locs,
+                           int32_t *found, uint16_t *dst, int32_t *out_len, int32_t *lf_steps, int32_t *status,
+                           int32_t *hit_status, int32_t *hit_aux) {
+    if (mode < 0) return fail(FMX_E_ARG, "bad arguments");
+    return locate_pipeline_host(idx, pat, pat_off, n, max_matches, dst_len, boundary, mode, locs, found, dst, out_len,
+                                lf_steps, status, hit_status, hit_aux);
 }
 
 int fmx_extract_batch(const fmx_index *idx, const int32_t *start, const int32_t *stop, int32_t n, uint16_t *dst,

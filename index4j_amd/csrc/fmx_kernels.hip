@@ -128,21 +128,31 @@ FMX_KERNEL(kBlock) void k_locate_walk(DevIndex ix, const int32_t *__restrict__ r
     }
 }
 
-// FM:564-608
+// FM:564-608.  Pipeline form (slot_found != nullptr): query q is hit (q % slots) of pattern (q / slots) and
+// runs only if that hit exists; with stops == nullptr the stop position is min(inputLength, start + fixed_len)
+// (the reference's locateAndExtractBenchmark, FmIndexThroughputBenchmark.java:231-249).
 template <int kBlock>
-FMX_KERNEL(kBlock) void k_extract(DevIndex ix, const int32_t *__restrict__ starts,
-                                                    const int32_t *__restrict__ stops, int32_t n,
-                                                    uint16_t *__restrict__ dst, int32_t dst_len, int32_t offset,
-                                                    int32_t *__restrict__ out_len, int32_t *__restrict__ lf_steps,
-                                                    int32_t *__restrict__ status_out) {
+FMX_KERNEL(kBlock) void k_extract(DevIndex ix, const int32_t *__restrict__ starts, const int32_t *__restrict__ stops,
+                                  int64_t n, uint16_t *__restrict__ dst, int32_t dst_len, int32_t offset,
+                                  int32_t *__restrict__ out_len, int32_t *__restrict__ lf_steps,
+                                  int32_t *__restrict__ status_out, const int32_t *__restrict__ slot_found,
+                                  int32_t slots, int32_t fixed_len) {
     __shared__ uint16_t s_inv[kInvEntries];
     stage_inverse_table(s_inv, ix.inv_global);
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) {
+        if (slot_found && (int32_t)(q % slots) >= slot_found[q / slots]) continue;
         int status = ST_OK;
         int32_t steps;
-        const int32_t ret =
-            fm_extract(ix, s_inv, starts[q], stops[q], dst + q * (int64_t)dst_len, dst_len, offset, steps, status);
+        const int32_t start = starts[q];
+        int32_t stop;
+        if (stops)
+            stop = stops[q];
+        else {
+            const int64_t e = (int64_t)start + fixed_len;
+            stop = e < ix.length ? (int32_t)e : ix.length;
+        }
+        const int32_t ret = fm_extract(ix, s_inv, start, stop, dst + q * (int64_t)dst_len, dst_len, offset, steps, status);
         out_len[q] = status ? 0 : ret;
         if (lf_steps) lf_steps[q] = steps;
         if (status_out) status_out[q] = status;
@@ -153,17 +163,19 @@ FMX_KERNEL(kBlock) void k_extract(DevIndex ix, const int32_t *__restrict__ start
 // sample_rate codes per lane of the grid (element j of lane t at scratch[j * lanes + t]) for the
 // interval-buffered right walk (fm_boundary_right_blocks); without it the literal form runs.
 template <int kBlock>
-FMX_KERNEL(kBlock) void k_extract_boundary(DevIndex ix, const int32_t *__restrict__ froms, int32_t n, uint16_t boundary,
+FMX_KERNEL(kBlock) void k_extract_boundary(DevIndex ix, const int32_t *__restrict__ froms, int64_t n, uint16_t boundary,
                                            int mode, uint16_t *__restrict__ dst, int32_t dst_len, int32_t offset,
                                            int32_t *__restrict__ out_len, int32_t *__restrict__ lf_steps,
                                            int32_t *__restrict__ status_out, int32_t *__restrict__ aux_out,
-                                           uint16_t *__restrict__ scratch) {
+                                           uint16_t *__restrict__ scratch, const int32_t *__restrict__ slot_found,
+                                           int32_t slots) {
     __shared__ uint16_t s_inv[kInvEntries];
     stage_inverse_table(s_inv, ix.inv_global);
     const int64_t lanes = (int64_t)gridDim.x * kBlock;
     const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int32_t mapped_boundary = fm_map(ix, boundary);  // FM:658
     for (int64_t q = lane; q < n; q += lanes) {
+        if (slot_found && (int32_t)(q % slots) >= slot_found[q / slots]) continue;
         int status = ST_OK;
         int32_t steps, aux;
         const int32_t ret = fm_extract_boundary(ix, s_inv, mode, froms[q], mapped_boundary, dst + q * (int64_t)dst_len,
@@ -179,11 +191,12 @@ FMX_KERNEL(kBlock) void k_extract_boundary(DevIndex ix, const int32_t *__restric
 // Group-cooperative extractUntilBoundary: G lanes per query (fm_extract_boundary_group); the window of a group
 // is G consecutive lane columns of `scratch` (left window in the first half, right window in the second).
 template <int kBlock, int G>
-FMX_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix, const int32_t *__restrict__ froms, int32_t n,
+FMX_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix, const int32_t *__restrict__ froms, int64_t n,
                                                  uint16_t boundary, int mode, uint16_t *__restrict__ dst,
                                                  int32_t dst_len, int32_t offset, int32_t *__restrict__ out_len,
                                                  int32_t *__restrict__ lf_steps, int32_t *__restrict__ status_out,
-                                                 int32_t *__restrict__ aux_out, uint16_t *__restrict__ scratch) {
+                                                 int32_t *__restrict__ aux_out, uint16_t *__restrict__ scratch,
+                                                 const int32_t *__restrict__ slot_found, int32_t slots) {
     __shared__ uint16_t s_inv[kInvEntries];
     stage_inverse_table(s_inv, ix.inv_global);
     const int64_t lanes = (int64_t)gridDim.x * kBlock;
@@ -192,6 +205,7 @@ FMX_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix, const int32_t *__r
     const int64_t groups = lanes / G;
     const int32_t mapped_boundary = fm_map(ix, boundary);  // FM:658
     for (int64_t q = lane / G; q < n; q += groups) {
+        if (slot_found && (int32_t)(q % slots) >= slot_found[q / slots]) continue;  // group-uniform
         int status = ST_OK;
         int32_t steps, aux;
         bool clean;
@@ -552,42 +566,44 @@ int launch_wt_inverse_select(const DevIndex &ix, int n_cu, const int64_t *pos, i
     return (int)hipGetLastError();
 }
 
-int launch_extract(const DevIndex &ix, int n_cu, const int32_t *start, const int32_t *stop, int32_t n, uint16_t *dst,
-                   int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf, int32_t *status, hipStream_t st) {
+int launch_extract(const DevIndex &ix, int n_cu, const int32_t *start, const int32_t *stop, int64_t n, uint16_t *dst,
+                   int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf, int32_t *status,
+                   const int32_t *slot_found, int32_t slots, int32_t fixed_len, hipStream_t st) {
     if (n <= 0) return 0;
-    FMX_DISPATCH(k_extract, (int64_t)n, ix, start, stop, n, dst, dst_len, offset, out_len, lf, status);
+    FMX_DISPATCH(k_extract, n, ix, start, stop, n, dst, dst_len, offset, out_len, lf, status, slot_found, slots, fixed_len);
     return (int)hipGetLastError();
 }
 
 // lanes the extractUntilBoundary grid will run with, and the scratch it needs (sample_rate codes per lane)
 static int boundary_group_size() { return g_boundary_accel ? g_boundary_group : 0; }  // 0 = one lane, literal/serial forms
-static int64_t boundary_lanes(int32_t n, int n_cu) {
+static int64_t boundary_lanes(int64_t n, int n_cu) {
     const int G = boundary_group_size();
-    return (int64_t)grid_for((int64_t)n * (G ? G : 1), g_block, n_cu) * g_block;
+    return (int64_t)grid_for(n * (G ? G : 1), g_block, n_cu) * g_block;
 }
-size_t boundary_workspace_bytes(const DevIndex &ix, int32_t n, int n_cu) {
+size_t boundary_workspace_bytes(const DevIndex &ix, int64_t n, int n_cu) {
     if (!g_boundary_accel || n <= 0) return 0;
     return (size_t)boundary_lanes(n, n_cu) * (size_t)ix.sample_rate * sizeof(uint16_t) * 2 + 256;  // two windows
 }
 
-int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, int32_t n, uint16_t boundary, int mode,
+int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, int64_t n, uint16_t boundary, int mode,
                             uint16_t *dst, int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf,
-                            int32_t *status, int32_t *aux, void *workspace, size_t workspace_bytes, hipStream_t st) {
+                            int32_t *status, int32_t *aux, void *workspace, size_t workspace_bytes,
+                            const int32_t *slot_found, int32_t slots, hipStream_t st) {
     if (n <= 0) return 0;
     uint16_t *scratch = (workspace && workspace_bytes >= boundary_workspace_bytes(ix, n, n_cu) && g_boundary_accel)
                             ? static_cast<uint16_t *>(workspace)
                             : nullptr;
     const int G = scratch ? boundary_group_size() : 0;
     const int blk = g_block;
-    const dim3 grid(grid_for((int64_t)n * (G ? G : 1), blk, n_cu));
+    const dim3 grid(grid_for(n * (G ? G : 1), blk, n_cu));
 #define FMX_LAUNCH_GROUP(GG)                                                                                            \
     do {                                                                                                                \
         if (blk == 1024)                                                                                                \
             hipLaunchKernelGGL((k_extract_boundary_group<1024, GG>), grid, dim3(1024), 0, st, ix, from, n, boundary, mode, dst, \
-                               dst_len, offset, out_len, lf, status, aux, scratch);                                     \
+                               dst_len, offset, out_len, lf, status, aux, scratch, slot_found, slots);                  \
         else                                                                                                            \
             hipLaunchKernelGGL((k_extract_boundary_group<512, GG>), grid, dim3(512), 0, st, ix, from, n, boundary, mode, dst,  \
-                               dst_len, offset, out_len, lf, status, aux, scratch);                                     \
+                               dst_len, offset, out_len, lf, status, aux, scratch, slot_found, slots);                  \
     } while (0)
     if (G == 1)
         FMX_LAUNCH_GROUP(1);
@@ -601,10 +617,10 @@ int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, i
         FMX_LAUNCH_GROUP(16);
     else if (blk == 1024)
         hipLaunchKernelGGL(k_extract_boundary<1024>, grid, dim3(1024), 0, st, ix, from, n, boundary, mode, dst, dst_len, offset,
-                           out_len, lf, status, aux, scratch);
+                           out_len, lf, status, aux, scratch, slot_found, slots);
     else
         hipLaunchKernelGGL(k_extract_boundary<512>, grid, dim3(512), 0, st, ix, from, n, boundary, mode, dst, dst_len, offset,
-                           out_len, lf, status, aux, scratch);
+                           out_len, lf, status, aux, scratch, slot_found, slots);
 #undef FMX_LAUNCH_GROUP
     return (int)hipGetLastError();
 }

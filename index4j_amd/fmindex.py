@@ -221,6 +221,43 @@ class FmIndex:
                                              status.ctypes.data, aux.ctypes.data), "fmx_extract_boundary_batch")
         return (dst, out_len, status, aux, steps) if want_steps else (dst, out_len, status, aux)
 
+    # ---- locate -> extract pipelines (hits stay in HBM between the stages) ----
+    def _pipeline(self, chars, offsets, max_matches, row_len, boundary, mode, fill):
+        chars = np.ascontiguousarray(chars, dtype=np.uint16)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        n = len(offsets) - 1
+        mm = int(max_matches)
+        out = {
+            "locs": np.full((n, mm), -1, dtype=np.int32), "found": np.zeros(n, dtype=np.int32),
+            "dst": np.full((n, mm, row_len), fill, dtype=np.uint16), "out_len": np.full((n, mm), -1, dtype=np.int32),
+            "steps": np.zeros(n, dtype=np.int32), "status": np.zeros(n, dtype=np.int32),
+            "hit_status": np.zeros((n, mm), dtype=np.int32), "hit_aux": np.zeros((n, mm), dtype=np.int32),
+        }
+        o = out
+        if mode < 0:
+            check(lib.fmx_locate_extract_batch(self._h, chars.ctypes.data, offsets.ctypes.data, n, mm, int(row_len),
+                                               o["locs"].ctypes.data, o["found"].ctypes.data, o["dst"].ctypes.data,
+                                               o["out_len"].ctypes.data, o["steps"].ctypes.data, o["status"].ctypes.data,
+                                               o["hit_status"].ctypes.data), "fmx_locate_extract_batch")
+        else:
+            b = boundary if isinstance(boundary, (int, np.integer)) else ord(boundary)
+            check(lib.fmx_locate_lines_batch(self._h, chars.ctypes.data, offsets.ctypes.data, n, mm, int(b), int(mode),
+                                             int(row_len), o["locs"].ctypes.data, o["found"].ctypes.data,
+                                             o["dst"].ctypes.data, o["out_len"].ctypes.data, o["steps"].ctypes.data,
+                                             o["status"].ctypes.data, o["hit_status"].ctypes.data,
+                                             o["hit_aux"].ctypes.data), "fmx_locate_lines_batch")
+        return out
+
+    def locate_extract_batch(self, chars, offsets, max_matches, extract_len, fill=0):
+        """locate, then extract(loc, min(getInputLength(), loc + extract_len), row, 0) per hit — the reference's
+        locateAndExtractBenchmark (FmIndexThroughputBenchmark.java:231-249).  Returns a dict of arrays; slots
+        k >= found[i] keep their initial values (locs/out_len -1, rows `fill`)."""
+        return self._pipeline(chars, offsets, max_matches, extract_len, 0, -1, fill)
+
+    def locate_lines_batch(self, chars, offsets, max_matches, boundary, dst_len, mode=0, fill=0):
+        """locate, then extractUntilBoundary{,Left,Right}(loc, row, 0, boundary) per hit (FM:640-922)"""
+        return self._pipeline(chars, offsets, max_matches, dst_len, boundary, mode, fill)
+
     # ---- scalar API, as in the reference ----
     def count(self, pattern, offset=0, length=None):  # FM:443-474
         p = as_chars(pattern)

@@ -271,3 +271,115 @@ def test_standalone_wavelet_kats_and_quirk_sequence():
         packed, st2 = w.inverse_select_batch(p2)
         assert (st2 == 0).all() and packed.tolist() == [o.inverse_select(int(p)) for p in p2]
     assert orc.counters()["rank_calls"] > 0
+
+
+_ORC_CODE = {(exc, msg.split("%")[0]): code for code, (exc, msg) in orc.MESSAGES.items()}
+
+
+def _orc_status(fn):
+    """run an oracle call; return (status code, result) in the ABI's terms"""
+    try:
+        return 0, fn()
+    except Exception as e:  # noqa: BLE001 - the oracle raises the reference's exception kinds
+        for (exc, prefix), code in _ORC_CODE.items():
+            if type(e) is exc and str(e).startswith(prefix):
+                return code, None
+        raise
+
+
+@pytest.mark.parametrize("sr,group", [(32, 4), (4, 0), (64, 8)])
+def test_locate_extract_pipeline_vs_oracle(sr, group):
+    """locate -> extract and locate -> extractUntilBoundary{,Left,Right} fused on the device, against the
+    oracle composing the same scalar calls the reference's locateAndExtractBenchmark makes (J-FM:231-249)"""
+    rnd = random.Random(1000 + sr)
+    text = HD[:100_000]
+    fm = ia.FmIndex(text, sr, True, device=0)
+    o = orc.OracleFmIndex(text, sr, True)
+    t16 = ia.as_chars(text)
+    L = len(t16)
+    pats = [t16[s:s + rnd.randrange(1, 20)] for s in (rnd.randrange(L - 20) for _ in range(60))]
+    pats += [t16[L - 5:], t16[L - 30:L - 20], ia.as_chars("zzzzqq"), ia.as_chars("\n"), ia.as_chars("INFO")]
+    ch, off = ia.pack_patterns(pats)
+    off = np.concatenate([off, [off[-1]]]).astype(np.int32)  # plus one EMPTY pattern -> AIOOBE in locate
+    inlen = o.getInputLength()
+    try:
+        assert ia.lib.fmx_set_option(b"boundary_group", group) == 0
+        for mm, xlen in ((5, 64), (1, 7), (12, 0)):
+            r = fm.locate_extract_batch(ch, off, mm, xlen, fill=0xBEEF)
+            assert r["status"][-1] == 9 and r["found"][-1] == 0
+            for i, p in enumerate(pats):
+                n, locs = o.locate(p, max_matches=mm, cap=mm)
+                assert r["status"][i] == 0 and r["found"][i] == n and (r["locs"][i, :n] == locs).all()
+                for k in range(mm):
+                    if k >= n:  # slot without a hit: untouched
+                        assert r["locs"][i, k] == -1 and r["out_len"][i, k] == -1 and (r["dst"][i, k] == 0xBEEF).all()
+                        continue
+                    exp = np.full(xlen, 0xBEEF, np.uint16)
+                    st, res = _orc_status(lambda: o.extract(int(locs[k]), min(inlen, int(locs[k]) + xlen), dest=exp))
+                    assert r["hit_status"][i, k] == st, (i, k, st)
+                    assert (r["dst"][i, k] == exp).all()
+                    if st == 0:
+                        assert r["out_len"][i, k] == res[0]
+        for mode, mm, dlen in ((0, 4, 512), (1, 3, 300), (2, 3, 300), (0, 2, 40)):
+            r = fm.locate_lines_batch(ch, off, mm, "\n", dlen, mode=mode, fill=0xBEEF)
+            for i, p in enumerate(pats):
+                n, locs = o.locate(p, max_matches=mm, cap=mm)
+                assert r["status"][i] == 0 and r["found"][i] == n and (r["locs"][i, :n] == locs).all()
+                for k in range(mm):
+                    if k >= n:
+                        assert r["out_len"][i, k] == -1 and (r["dst"][i, k] == 0xBEEF).all()
+                        continue
+                    exp = np.full(dlen, 0xBEEF, np.uint16)
+                    aux = [0]
+
+                    def call():
+                        try:
+                            return o.extract_until_boundary(mode, int(locs[k]), dlen, 0, "\n", dest=exp)
+                        except RuntimeError as e:
+                            if "Currently extracted" in str(e):
+                                aux[0] = int(str(e).rsplit(" ", 1)[1])
+                            raise
+                    st, res = _orc_status(call)
+                    assert r["hit_status"][i, k] == st, (mode, i, k, st, r["hit_status"][i, k])
+                    assert (r["dst"][i, k] == exp).all(), (mode, i, k)
+                    if st == 0:
+                        assert r["out_len"][i, k] == res[0]
+                    if st == 8:
+                        assert r["hit_aux"][i, k] == aux[0]
+    finally:
+        ia.lib.fmx_set_option(b"boundary_group", 4)
+
+
+def test_locate_lines_pipeline_properties_16mib():
+    """grep on a 16 MiB index: every returned line contains the pattern at the located column, lines of
+    different hits of one pattern differ in position, and the fused result equals the two-call result"""
+    n = 1 << 24
+    t = ia.synth_log(n)
+    fm = ia.FmIndex(t, 32, True, device=0)
+    m, N, mm = 12, 20000, 4
+    pat, off, pos = ia.synth_patterns(t, m, N)
+    r = fm.locate_lines_batch(pat, off, mm, "\n", 512)
+    locs2, found2, st2 = fm.locate_batch(pat, off, mm)
+    assert (r["found"] == found2).all() and (r["status"] == 0).all()
+    nl = np.flatnonzero(t == 10)
+    P = pat.reshape(N, m)
+    for k in range(mm):
+        sel = np.flatnonzero(r["found"] > k)
+        assert (r["locs"][sel, k] == locs2[sel, k]).all()
+        loc = r["locs"][sel, k].astype(np.int64)
+        j = np.searchsorted(nl, loc)
+        ok = (j < len(nl)) & (t[loc] != 10)  # hits inside the unterminated last line: Q12, covered elsewhere
+        lo = np.where(j > 0, nl[np.maximum(j - 1, 0)] + 1, 0)
+        hi = nl[np.minimum(j, len(nl) - 1)]
+        sel, loc, lo, hi = sel[ok], loc[ok], lo[ok], hi[ok]
+        assert (r["hit_status"][sel, k] == 0).all()
+        assert (r["out_len"][sel, k] == hi - lo).all()
+        col = loc - lo
+        rows = r["dst"][sel, k]
+        got = rows[np.arange(len(sel))[:, None], col[:, None] + np.arange(m)[None, :]]
+        fits = col + m <= hi - lo  # pattern may straddle the newline
+        assert (got[fits] == P[sel][fits]).all()
+    # separate extract call on the located positions gives the same rows
+    fr = r["locs"][:, 0][r["found"] > 0]
+    dst, ol, st4, aux = fm.extract_boundary_batch(fr, "\n", 0, 512)
+    assert (dst == r["dst"][r["found"] > 0, 0]).all() and (ol == r["out_len"][r["found"] > 0, 0]).all()
