@@ -167,6 +167,30 @@ int fmx_locate_lines_batch_dev(const fmx_index *idx, const uint16_t *d_pat, cons
                                int32_t *d_status, int32_t *d_hit_status, int32_t *d_hit_aux, int32_t *d_range_ws,
                                void *stream);
 
+/* ---- segment sets: texts beyond one FmIndex ----------------------------------------------------
+ * FmIndex addresses its text with Java ints (`length` FM:131, RrrVector positions RRR:358), so a text of
+ * >= 2^31 chars (BASELINE configs[4]: 2 GiB) is K independent FmIndex objects over consecutive pieces of the
+ * text, cut at record boundaries; a caller sums count() over them and adds each piece's start to its
+ * locate() results.  These entry points do that on the device for K handles resident on the same GPU:
+ *   counts[i] = sum over segments of count(pattern i)            (int64: the sum can pass 2^31)
+ *   locs      = n rows of max_matches int64 text positions: segment 0's hits (SA order, FM:526-548),
+ *               then segment 1's, ... each moved by seg_base[s] (host array), truncated at max_matches;
+ *               found[i] = number written (max_matches >= 1)
+ *   status[i] = first non-zero per-segment status (an empty pattern fails the same way in every segment)
+ * Occurrences that span a cut are not occurrences in any segment, exactly as with K Java objects.
+ * Device forms: d_tmp = 3*n ints (count) / 4*n + n*max_matches ints (locate); d_lf_steps / d_status may be NULL. */
+int fmx_count_segments(const fmx_index *const *segs, int32_t n_segs, const uint16_t *pat, const int32_t *pat_off,
+                       int32_t n, int64_t *counts, int64_t *lf_steps, int32_t *status);
+int fmx_locate_segments(const fmx_index *const *segs, int32_t n_segs, const int64_t *seg_base, const uint16_t *pat,
+                        const int32_t *pat_off, int32_t n, int32_t max_matches, int64_t *locs, int32_t *found,
+                        int32_t *status);
+int fmx_count_segments_dev(const fmx_index *const *segs, int32_t n_segs, const uint16_t *d_pat, const int32_t *d_pat_off,
+                           int32_t n, int64_t *d_counts, int64_t *d_lf_steps, int32_t *d_status, int32_t *d_tmp,
+                           void *stream);
+int fmx_locate_segments_dev(const fmx_index *const *segs, int32_t n_segs, const int64_t *seg_base, const uint16_t *d_pat,
+                            const int32_t *d_pat_off, int32_t n, int32_t max_matches, int64_t *d_locs, int32_t *d_found,
+                            int32_t *d_status, int32_t *d_tmp, void *stream);
+
 /* ---- WaveletFixedBlockBoosting as a stand-alone structure (the reference's public class, WFBB:130-154) ----
  * `sequence` = symbols already mapped to small non-negative integers (short[] text of WFBB:130).  The handle
  * answers only the two calls below (after fmx_to_device); free it with fmx_free. */

@@ -14,7 +14,8 @@ from .fmindex import (  # noqa: F401
     synth_log,
     synth_patterns,
 )
+from .segments import SegmentedFmIndex, cut_points  # noqa: F401
 from .wavelet import WaveletFixedBlockBoosting  # noqa: F401
 
-__all__ = ["WaveletFixedBlockBoosting", "FmIndex", "FmIndexBuilder", "FmxError", "as_chars", "chars_to_str", "pack_patterns",
+__all__ = ["WaveletFixedBlockBoosting", "SegmentedFmIndex", "cut_points", "FmIndex", "FmIndexBuilder", "FmxError", "as_chars", "chars_to_str", "pack_patterns",
            "raise_for_status", "synth_log", "synth_patterns", "lib", "LIB_PATH", "SYMBOLS"]

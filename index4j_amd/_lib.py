@@ -29,6 +29,7 @@ SYMBOLS = [
     "fmx_count_batch", "fmx_locate_batch", "fmx_extract_batch", "fmx_extract_boundary_batch",
     "fmx_count_batch_dev", "fmx_count_plan_dev", "fmx_count_ordered_dev", "fmx_locate_batch_dev", "fmx_extract_batch_dev", "fmx_extract_boundary_batch_dev",
     "fmx_locate_extract_batch", "fmx_locate_lines_batch", "fmx_locate_extract_batch_dev", "fmx_locate_lines_batch_dev",
+    "fmx_count_segments", "fmx_locate_segments", "fmx_count_segments_dev", "fmx_locate_segments_dev",
     "fmx_wavelet_build", "fmx_wavelet_rank_batch", "fmx_wavelet_inverse_select_batch",
     "fmx_convert_byte_pattern", "fmx_status_message", "fmx_status_kind", "fmx_last_error", "fmx_device_count", "fmx_set_option",
     "fmx_synth_log", "fmx_synth_patterns",
@@ -74,6 +75,10 @@ def _load():
     L.fmx_locate_lines_batch.argtypes = [vp, vp, vp, i32, i32, u16, C.c_int, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.fmx_locate_extract_batch_dev.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.fmx_locate_lines_batch_dev.argtypes = [vp, vp, vp, i32, i32, u16, C.c_int, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.fmx_count_segments.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp]
+    L.fmx_locate_segments.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp, vp, vp]
+    L.fmx_count_segments_dev.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
+    L.fmx_locate_segments_dev.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
     L.fmx_wavelet_build.argtypes = [vp, C.c_int64, i32, P(vp)]
     L.fmx_wavelet_rank_batch.argtypes = [vp, vp, vp, i32, vp, vp]
     L.fmx_wavelet_inverse_select_batch.argtypes = [vp, vp, i32, vp, vp]

@@ -23,13 +23,17 @@ int launch_count(const DevIndex &, int, const uint16_t *, const int32_t *, const
                  int32_t *, int32_t *, int32_t *, hipStream_t);
 size_t count_workspace_bytes(const DevIndex &, int32_t n);
 int launch_locate_walk(const DevIndex &, int, const int32_t *, int32_t, int32_t, int32_t *, int32_t, int32_t *,
-                       int32_t *, int32_t *, hipStream_t);
+                       int32_t *, int32_t *, const int32_t *, hipStream_t);
 int launch_extract(const DevIndex &, int, const int32_t *, const int32_t *, int64_t, uint16_t *, int32_t, int32_t,
                    int32_t *, int32_t *, int32_t *, const int32_t *, int32_t, int32_t, hipStream_t);
 int launch_extract_boundary(const DevIndex &, int, const int32_t *, int64_t, uint16_t, int, uint16_t *, int32_t,
                             int32_t, int32_t *, int32_t *, int32_t *, int32_t *, void *, size_t, const int32_t *, int32_t,
                             hipStream_t);
 size_t boundary_workspace_bytes(const DevIndex &, int64_t n, int n_cu);
+int launch_segment_add_counts(int64_t *, int64_t *, int32_t *, const int32_t *, const int32_t *, const int32_t *, int32_t,
+                              int, hipStream_t);
+int launch_segment_append_hits(int64_t *, int32_t *, int32_t *, const int32_t *, const int32_t *, const int32_t *, int32_t,
+                               int32_t, int64_t, int, hipStream_t);
 int launch_wt_rank(const DevIndex &, int, const int64_t *, const int32_t *, int32_t, int64_t *, int32_t *, hipStream_t);
 int launch_wt_inverse_select(const DevIndex &, int, const int64_t *, int32_t, int64_t *, int32_t *, hipStream_t);
 int set_option(const char *, int);
@@ -390,7 +394,7 @@ int fmx_locate_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int3
     int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, perm, n, d_found, d_lf_steps, d_status, d_range_ws, st);
     if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
     e = fmx::launch_locate_walk(idx->dev, idx->n_cu, d_range_ws, n, max_matches, d_locs, loc_cap, d_found, d_lf_steps,
-                                d_status, st);
+                                d_status, nullptr, st);
     if (e) return fail(FMX_E_HIP, std::string("k_locate_walk launch: ") + hipGetErrorString((hipError_t)e));
     return FMX_OK;
 }
@@ -475,6 +479,131 @@ int fmx_locate_lines_batch_dev(const fmx_index *idx, const uint16_t *d_pat, cons
                                          nullptr, d_hit_status, d_hit_aux, ws, ws_bytes, d_found, max_matches,
                                          static_cast<hipStream_t>(stream));
     if (e) return fail(FMX_E_HIP, std::string("k_extract_boundary launch: ") + hipGetErrorString((hipError_t)e));
+    return FMX_OK;
+}
+
+// ---- segment sets ---------------------------------------------------------------------------------
+
+static int segments_ok(const fmx_index *const *segs, int32_t n_segs) {
+    if (!segs || n_segs < 1) return fail(FMX_E_ARG, "no segments");
+    for (int32_t s = 0; s < n_segs; ++s) {
+        int rc = require_device(segs[s]);
+        if (rc) return rc;
+        if (segs[s]->device != segs[0]->device) return fail(FMX_E_ARG, "segments live on different devices");
+    }
+    return FMX_OK;
+}
+
+int fmx_count_segments_dev(const fmx_index *const *segs, int32_t n_segs, const uint16_t *d_pat, const int32_t *d_pat_off,
+                           int32_t n, int64_t *d_counts, int64_t *d_lf_steps, int32_t *d_status, int32_t *d_tmp,
+                           void *stream) {
+    int rc = segments_ok(segs, n_segs);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!d_pat_off || !d_counts || !d_tmp))) return fail(FMX_E_ARG, "bad arguments");
+    if (n == 0) return FMX_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // one processing order for all segments: any grouping is valid, and equal characters get equal codes in
+    // every segment's alphabet, so the order derived from the first segment groups the batch for all of them
+    const uint32_t *perm = nullptr;
+    rc = plan_order(segs[0], d_pat, d_pat_off, n, stream, &perm);
+    if (rc) return rc;
+    int32_t *cnt = d_tmp, *lf = d_tmp + n, *sts = d_tmp + 2 * (size_t)n;
+    for (int32_t s = 0; s < n_segs; ++s) {
+        int e = fmx::launch_count(segs[s]->dev, segs[s]->n_cu, d_pat, d_pat_off, perm, n, cnt, lf, sts, nullptr, st);
+        if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
+        e = fmx::launch_segment_add_counts(d_counts, d_lf_steps, d_status, cnt, lf, sts, n, s == 0, st);
+        if (e) return fail(FMX_E_HIP, std::string("k_segment_add_counts launch: ") + hipGetErrorString((hipError_t)e));
+    }
+    return FMX_OK;
+}
+
+int fmx_locate_segments_dev(const fmx_index *const *segs, int32_t n_segs, const int64_t *seg_base, const uint16_t *d_pat,
+                            const int32_t *d_pat_off, int32_t n, int32_t max_matches, int64_t *d_locs, int32_t *d_found,
+                            int32_t *d_status, int32_t *d_tmp, void *stream) {
+    int rc = segments_ok(segs, n_segs);
+    if (rc) return rc;
+    if (n < 0 || max_matches < 1 || !seg_base || (int64_t)n * max_matches > INT32_MAX ||
+        (n > 0 && (!d_pat_off || !d_locs || !d_found || !d_tmp)))
+        return fail(FMX_E_ARG, "bad arguments");
+    if (n == 0) return FMX_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int32_t *seg_found = d_tmp, *seg_status = d_tmp + n, *range = d_tmp + 2 * (size_t)n, *seg_locs = d_tmp + 4 * (size_t)n;
+    const uint32_t *perm = nullptr;
+    rc = plan_order(segs[0], d_pat, d_pat_off, n, stream, &perm);
+    if (rc) return rc;
+    for (int32_t s = 0; s < n_segs; ++s) {
+        int e = fmx::launch_count(segs[s]->dev, segs[s]->n_cu, d_pat, d_pat_off, perm, n, seg_found, nullptr, seg_status,
+                                  range, st);
+        if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
+        // like the caller's loop `n += seg.locate(p, 0, len, locations, maxMatches - n)`: hits already
+        // taken from earlier segments shrink this segment's limit
+        e = fmx::launch_locate_walk(segs[s]->dev, segs[s]->n_cu, range, n, max_matches, seg_locs, max_matches, seg_found,
+                                    nullptr, seg_status, s ? d_found : nullptr, st);
+        if (e) return fail(FMX_E_HIP, std::string("k_locate_walk launch: ") + hipGetErrorString((hipError_t)e));
+        e = fmx::launch_segment_append_hits(d_locs, d_found, d_status, seg_locs, seg_found, seg_status, n, max_matches,
+                                            seg_base[s], s == 0, st);
+        if (e) return fail(FMX_E_HIP, std::string("k_segment_append_hits launch: ") + hipGetErrorString((hipError_t)e));
+    }
+    return FMX_OK;
+}
+
+int fmx_count_segments(const fmx_index *const *segs, int32_t n_segs, const uint16_t *pat, const int32_t *pat_off,
+                       int32_t n, int64_t *counts, int64_t *lf_steps, int32_t *status) {
+    int rc = segments_ok(segs, n_segs);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!pat_off || !counts))) return fail(FMX_E_ARG, "bad arguments");
+    if (n == 0) return FMX_OK;
+    HIP_TRY(hipSetDevice(segs[0]->device));
+    const size_t chars = (size_t)(pat_off[n] > 0 ? pat_off[n] : 0);
+    DevBuf d_pat, d_off, d_cnt, d_lf, d_st, d_tmp;
+    HIP_TRY(d_pat.alloc(chars * 2 + 8));
+    HIP_TRY(d_off.alloc((size_t)(n + 1) * 4));
+    HIP_TRY(d_cnt.alloc((size_t)n * 8));
+    HIP_TRY(d_lf.alloc((size_t)n * 8));
+    HIP_TRY(d_st.alloc((size_t)n * 4));
+    HIP_TRY(d_tmp.alloc((size_t)n * 12));
+    if (chars) H2D(d_pat.p, pat, chars * 2);
+    H2D(d_off.p, pat_off, (size_t)(n + 1) * 4);
+    rc = fmx_count_segments_dev(segs, n_segs, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, d_cnt.as<int64_t>(),
+                                d_lf.as<int64_t>(), d_st.as<int32_t>(), d_tmp.as<int32_t>(), nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    D2H(counts, d_cnt.p, (size_t)n * 8);
+    if (lf_steps) D2H(lf_steps, d_lf.p, (size_t)n * 8);
+    if (status) D2H(status, d_st.p, (size_t)n * 4);
+    return FMX_OK;
+}
+
+int fmx_locate_segments(const fmx_index *const *segs, int32_t n_segs, const int64_t *seg_base, const uint16_t *pat,
+                        const int32_t *pat_off, int32_t n, int32_t max_matches, int64_t *locs, int32_t *found,
+                        int32_t *status) {
+    int rc = segments_ok(segs, n_segs);
+    if (rc) return rc;
+    if (n < 0 || max_matches < 1 || !seg_base || (int64_t)n * max_matches > INT32_MAX ||
+        (n > 0 && (!pat_off || !locs || !found)))
+        return fail(FMX_E_ARG, "bad arguments");
+    if (n == 0) return FMX_OK;
+    HIP_TRY(hipSetDevice(segs[0]->device));
+    const size_t chars = (size_t)(pat_off[n] > 0 ? pat_off[n] : 0);
+    const size_t slots = (size_t)n * (size_t)max_matches;
+    DevBuf d_pat, d_off, d_locs, d_found, d_st, d_tmp;
+    HIP_TRY(d_pat.alloc(chars * 2 + 8));
+    HIP_TRY(d_off.alloc((size_t)(n + 1) * 4));
+    HIP_TRY(d_locs.alloc(slots * 8));
+    HIP_TRY(d_found.alloc((size_t)n * 4));
+    HIP_TRY(d_st.alloc((size_t)n * 4));
+    HIP_TRY(d_tmp.alloc(((size_t)n * 4 + slots) * 4));
+    if (chars) H2D(d_pat.p, pat, chars * 2);
+    H2D(d_off.p, pat_off, (size_t)(n + 1) * 4);
+    H2D(d_locs.p, locs, slots * 8);  // in/out: slots without a hit keep the caller's values
+    rc = fmx_locate_segments_dev(segs, n_segs, seg_base, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, max_matches,
+                                 d_locs.as<int64_t>(), d_found.as<int32_t>(), d_st.as<int32_t>(), d_tmp.as<int32_t>(),
+                                 nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    D2H(locs, d_locs.p, slots * 8);
+    D2H(found, d_found.p, (size_t)n * 4);
+    if (status) D2H(status, d_st.p, (size_t)n * 4);
     return FMX_OK;
 }
 

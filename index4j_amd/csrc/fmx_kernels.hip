@@ -102,7 +102,8 @@ FMX_KERNEL(kBlock) void k_locate_walk(DevIndex ix, const int32_t *__restrict__ r
                                                         int32_t max_matches, int32_t *__restrict__ locs,
                                                         int32_t loc_cap, int32_t slots, int32_t *__restrict__ found,
                                                         int32_t *__restrict__ lf_steps,
-                                                        int32_t *__restrict__ status_out) {
+                                                        int32_t *__restrict__ status_out,
+                                                        const int32_t *__restrict__ taken) {
     __shared__ uint16_t s_inv[kInvEntries];
     stage_inverse_table(s_inv, ix.inv_global);
     const int64_t total = (int64_t)n * slots;
@@ -111,9 +112,15 @@ FMX_KERNEL(kBlock) void k_locate_walk(DevIndex ix, const int32_t *__restrict__ r
         const int32_t p = (int32_t)(t / slots);
         const int32_t k = (int32_t)(t - (int64_t)p * slots);
         const int32_t start = range[2 * p], end = range[2 * p + 1];
-        const int32_t hits = start < end ? end - start : 0;
+        int32_t hits = start < end ? end - start : 0;
+        // segment sets: `taken[p]` hits came from earlier segments, the caller's loop passes maxMatches - taken
+        int32_t limit = max_matches;
+        if (taken) {
+            limit = max_matches - taken[p];
+            if (limit <= 0) hits = 0;
+        }
         // the reference stops at maxMatches (FM:544-546) and overruns `locations` beyond its length (Java AIOOBE)
-        const int32_t wanted = (max_matches > 0 && hits > max_matches) ? max_matches : hits;
+        const int32_t wanted = (limit > 0 && hits > limit) ? limit : hits;
         const int32_t located = wanted < loc_cap ? wanted : loc_cap;
         if (k == 0) {
             found[p] = located;
@@ -418,6 +425,43 @@ __global__ __launch_bounds__(kTileThreads) void k_order_tile_sort(DevIndex ix, c
     }
 }
 
+// ---- segment sets: one logical text as K independent indexes (a Java int cannot address >= 2^31 chars) ----
+// counts add up; a segment's hits are appended after those of the earlier segments, moved by its base
+__global__ __launch_bounds__(256) void k_segment_add_counts(int64_t *__restrict__ total, int64_t *__restrict__ lf_total,
+                                                           int32_t *__restrict__ status_total,
+                                                           const int32_t *__restrict__ counts,
+                                                           const int32_t *__restrict__ lf,
+                                                           const int32_t *__restrict__ status, int32_t n, int first) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    total[i] = (first ? 0 : total[i]) + counts[i];
+    if (lf_total) lf_total[i] = (first ? 0 : lf_total[i]) + lf[i];
+    if (status_total) {
+        const int32_t prev = first ? 0 : status_total[i];
+        status_total[i] = prev ? prev : status[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_segment_append_hits(int64_t *__restrict__ locs, int32_t *__restrict__ found,
+                                                            int32_t *__restrict__ status_total,
+                                                            const int32_t *__restrict__ seg_locs,
+                                                            const int32_t *__restrict__ seg_found,
+                                                            const int32_t *__restrict__ seg_status, int32_t n,
+                                                            int32_t cap, int64_t base, int first) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t have = first ? 0 : found[i];
+    const int32_t st = seg_status[i];
+    const int32_t add = st ? 0 : seg_found[i];
+    int32_t k = 0;
+    for (; k < add && have + k < cap; ++k) locs[i * (int64_t)cap + have + k] = base + seg_locs[i * (int64_t)cap + k];
+    found[i] = have + k;
+    if (status_total) {
+        const int32_t prev = first ? 0 : status_total[i];
+        status_total[i] = prev ? prev : st;
+    }
+}
+
 // ---- launchers (called from fmx_api.cpp) -----------------------------------------------------
 
 // tunables (fmx_set_option): workgroup size and how many workgroups per CU the grid is capped at
@@ -544,11 +588,28 @@ int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_
 
 int launch_locate_walk(const DevIndex &ix, int n_cu, const int32_t *range, int32_t n, int32_t max_matches,
                        int32_t *locs, int32_t loc_cap, int32_t *found, int32_t *lf, int32_t *status,
-                       hipStream_t st) {
+                       const int32_t *taken, hipStream_t st) {
     if (n <= 0) return 0;
     int32_t slots = (max_matches > 0 && max_matches < loc_cap) ? max_matches : loc_cap;
     if (slots < 1) slots = 1;
-    FMX_DISPATCH(k_locate_walk, (int64_t)n * slots, ix, range, n, max_matches, locs, loc_cap, slots, found, lf, status);
+    FMX_DISPATCH(k_locate_walk, (int64_t)n * slots, ix, range, n, max_matches, locs, loc_cap, slots, found, lf, status, taken);
+    return (int)hipGetLastError();
+}
+
+int launch_segment_add_counts(int64_t *total, int64_t *lf_total, int32_t *status_total, const int32_t *counts,
+                              const int32_t *lf, const int32_t *status, int32_t n, int first, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_segment_add_counts, dim3((n + 255) / 256), dim3(256), 0, st, total, lf_total, status_total, counts,
+                       lf, status, n, first);
+    return (int)hipGetLastError();
+}
+
+int launch_segment_append_hits(int64_t *locs, int32_t *found, int32_t *status_total, const int32_t *seg_locs,
+                               const int32_t *seg_found, const int32_t *seg_status, int32_t n, int32_t cap, int64_t base,
+                               int first, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_segment_append_hits, dim3((n + 255) / 256), dim3(256), 0, st, locs, found, status_total, seg_locs,
+                       seg_found, seg_status, n, cap, base, first);
     return (int)hipGetLastError();
 }
 

@@ -383,3 +383,45 @@ def test_locate_lines_pipeline_properties_16mib():
     fr = r["locs"][:, 0][r["found"] > 0]
     dst, ol, st4, aux = fm.extract_boundary_batch(fr, "\n", 0, 512)
     assert (dst == r["dst"][r["found"] > 0, 0]).all() and (ol == r["out_len"][r["found"] > 0, 0]).all()
+
+
+def test_segment_set_count_and_locate_vs_oracle_and_brute_force():
+    """a text as K segment indexes (BASELINE configs[4]'s shape): summed counts and base-shifted
+    hits against K oracle indexes queried one by one, and against a brute-force scan of the whole text for
+    patterns that cannot span a cut (no '\\n' inside)"""
+    rnd = random.Random(4242)
+    text = HD[:200_000]
+    t16 = ia.as_chars(text)
+    sf = ia.SegmentedFmIndex(text, 16, True, device=0, segment_chars=30_000)
+    K = len(sf)
+    assert K >= 7 and sf.bases[0] == 0
+    ends = sf.bases[1:] + [len(t16)]
+    for a, b in zip(sf.bases, ends):
+        assert 0 < b - a <= 30_000 and (b == len(t16) or t16[b - 1] == 10)
+    oracles = [orc.OracleFmIndex(t16[a:b], 16, True) for a, b in zip(sf.bases, ends)]
+    for s, o in zip(sf.segments, oracles):
+        assert s.write(False) == o.write(False)
+    pats = [t16[s:s + rnd.randrange(1, 16)] for s in (rnd.randrange(len(t16) - 16) for _ in range(300))]
+    pats += [ia.as_chars("INFO"), ia.as_chars("\n"), ia.as_chars("zzqq"), ia.as_chars("e")]
+    ch, off = ia.pack_patterns(pats)
+    off = np.concatenate([off, [off[-1]]]).astype(np.int32)  # an EMPTY pattern: AIOOBE in every segment
+    cnt, st, lf = sf.count_batch(ch, off, want_steps=True)
+    assert st[-1] == 9 and (st[:-1] == 0).all()
+    for i, p in enumerate(pats):
+        per = [o.count(p) for o in oracles]
+        assert cnt[i] == sum(per), i
+        if 10 not in p:
+            assert cnt[i] == len(occurrences(text, ia.chars_to_str(p))), i
+    for mm in (1, 5, 40):
+        locs, found, st2 = sf.locate_batch(ch, off, mm)
+        assert st2[-1] == 9 and found[-1] == 0 and (locs[-1] == -1).all()
+        for i, p in enumerate(pats):
+            exp = []
+            for o, base in zip(oracles, sf.bases):
+                k, l = o.locate(p, max_matches=mm, cap=mm)
+                exp.extend(int(x) + base for x in l)
+            exp = exp[:mm]
+            assert found[i] == len(exp) and list(locs[i, :found[i]]) == exp, (mm, i)
+            assert (locs[i, found[i]:] == -1).all()
+            for x in exp:
+                assert (t16[x:x + len(p)] == p).all()
