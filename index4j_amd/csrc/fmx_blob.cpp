@@ -24,7 +24,7 @@ struct Arena {
 inline uint32_t off8(size_t byte_off) { return (uint32_t)(byte_off >> 3); }
 
 // RRR:92-103 -> 16-block records + offsets bit stream
-bool flatten_rrr(Arena &A, const RrrModel &r, RrrDesc &d, std::string &err) {
+bool flatten_rrr(Arena &A, const RrrModel &r, RrrDesc &d, bool compact, std::string &err) {
     if (r.sample_size <= 0 || r.classes.width != 4) {
         err = "unsupported RRR parameters";
         return false;
@@ -46,11 +46,24 @@ bool flatten_rrr(Arena &A, const RrrModel &r, RrrDesc &d, std::string &err) {
         rec.ones_before = (uint32_t)ones;
         rec.offset_bit = (uint32_t)obits;
         rec.classes = 0;
+        if (compact && ((ones | obits) >> kRrrCompactShift)) {
+            err = "wavelet-tree bitvector too long for compact RRR records";
+            return false;
+        }
+        uint32_t half_ones = 0, half_bits = 0;
         for (int64_t j = 0; j < 16 && k * 16 + j < n_blocks; ++j) {
             const uint64_t cls = r.classes.get(k * 16 + j);
             rec.classes |= cls << (4 * j);
             ones += cls;
             obits += bits_needed[cls];
+            if (j < 8) {
+                half_ones += (uint32_t)cls;
+                half_bits += bits_needed[cls];
+            }
+        }
+        if (compact) {
+            rec.ones_before |= half_ones << kRrrCompactShift;
+            rec.offset_bit |= half_bits << kRrrCompactShift;
         }
         A.at<RrrRecord>(rec_off)[k] = rec;
     }
@@ -119,7 +132,7 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
         if (m.map_keys[i] >= 0 && m.map_keys[i] < 65536) A.at<int16_t>(off)[m.map_keys[i]] = m.map_vals[i];
     h.off_suffixes = off8(put_packed(A, m.suffixes));
     h.off_positions = m.enable_extract ? off8(put_packed(A, m.positions)) : 0;
-    if (!flatten_rrr(A, m.sampled, h.sampled, err)) return -8;
+    if (!flatten_rrr(A, m.sampled, h.sampled, /*compact=*/false, err)) return -8;
 
     off = A.alloc(kInvEntries * 2);  // classes 0..7 only; 8..15 are complements (fmx_blob.hpp)
     h.off_inv = off8(off);
@@ -191,7 +204,7 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
         d.off_var = off8(off);
         d.var_len = (int32_t)sb.var.size();
         if (!sb.var.empty()) memcpy(A.at<uint8_t>(off), sb.var.data(), sb.var.size());
-        if (!flatten_rrr(A, sb.rank_support, d.rrr, err)) return -8;
+        if (!flatten_rrr(A, sb.rank_support, d.rrr, /*compact=*/true, err)) return -8;
         *A.at<SbDesc>(sbd_off + (size_t)s * sizeof(SbDesc)) = d;
     }
     A.alloc(64);  // tail guard

@@ -35,13 +35,20 @@
 namespace fmx {
 
 constexpr uint32_t kBlobMagic = 0x31584D46u;  // "FMX1"
-constexpr uint32_t kBlobVersion = 3;
+constexpr uint32_t kBlobVersion = 4;
 
 struct RrrRecord {         // 16 bytes: 16 blocks of 15 bits
     uint32_t ones_before;  // 1-bits in all earlier blocks
     uint32_t offset_bit;   // bit position of this record's first offset in the offsets stream
     uint64_t classes;      // block j's class in bits [4j, 4j+4)
 };
+// Two record flavours.  WIDE (the FM-index's sampled-suffix bitmap, up to 2^31 bits): the two counters use
+// all 32 bits.  COMPACT (the per-superblock vectors of the wavelet tree, < 2^24 bits: at most 2^20 symbols of
+// < 16 code bits): the counters use 24 bits and the top byte carries the sums over the record's first 8
+// blocks — ones_before[31:24] = sum of their classes (<= 120), offset_bit[31:24] = sum of their offset widths
+// (<= 104) — so a rank scans one 32-bit half of `classes` instead of the whole word.
+constexpr uint32_t kRrrCompactMask = 0x00ffffffu;
+constexpr int kRrrCompactShift = 24;
 
 struct RrrDesc {           // 32 bytes; the first 16 are what a rank needs (one dwordx4 load)
     uint32_t off_rec;      // RrrRecord[n_rec]

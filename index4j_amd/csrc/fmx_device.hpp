@@ -71,11 +71,16 @@ FMX_HD int fmx_popcll(uint64_t v) { return __builtin_popcountll(v); }
 // fetched as one dword must not become a byte + a short load: every load instruction is a trip through
 // the texture addresser, the scarce resource of these kernels)
 #if defined(__HIPCC__)
+#define FMX_NO_UNROLL _Pragma("clang loop unroll(disable)")
 #define FMX_OPAQUE32(v) asm volatile("" : "+v"(v))
 #define FMX_OPAQUE64(v) asm volatile("" : "+v"(v))
+// pins a 16-byte load: one dwordx4, complete at this point (used to request independent loads together)
+#define FMX_PIN_QUAD(q) asm volatile("" : "+v"((q).x), "+v"((q).y), "+v"((q).z), "+v"((q).w))
 #else
+#define FMX_NO_UNROLL
 #define FMX_OPAQUE32(v) (void)0
 #define FMX_OPAQUE64(v) (void)0
+#define FMX_PIN_QUAD(q) (void)0
 #endif
 
 // 16 bytes of descriptor in one load
@@ -164,13 +169,28 @@ FMX_HD void rrr_scan_word(uint64_t w, int n, uint32_t &ones, uint32_t &obits) {
     obits += acc;
 }
 
+// the same sums over the low `n` nibbles (0 <= n <= 7) of one 32-bit half of a class word — the scan of
+// a COMPACT record (fmx_blob.hpp), whose first-half sums come with the record
+FMX_HD void rrr_scan_half(uint32_t w, uint32_t n, uint32_t &ones, uint32_t &obits) {
+    const uint32_t keep = (1u << (4u * n)) - 1u;  // n <= 7
+    w &= keep;
+    const uint32_t b = (w & 0x0f0f0f0fu) + ((w >> 4) & 0x0f0f0f0fu);
+    ones += (b * 0x01010101u) >> 24;
+    const uint32_t hi = (w >> 3) & 0x11111111u;
+    const uint32_t m = (w ^ (hi * 15u)) & 0x77777777u;
+    const uint32_t top = 0x88888888u & keep;
+    const uint32_t a3 = (uint32_t)fmx_popc((m + 0x77777777u) & top) + (uint32_t)fmx_popc((m + 0x66666666u) & top);  // m>=1, m>=2
+    const uint32_t a2 = (uint32_t)fmx_popc((m + 0x55555555u) & top) + (uint32_t)fmx_popc((m + 0x44444444u) & top);  // m>=3, m>=4
+    const uint32_t a1 = (uint32_t)fmx_popc((m + 0x33333333u) & top) + (uint32_t)fmx_popc((m + 0x22222222u) & top);  // m>=5, m>=6
+    obits += n + 3u * a3 + 2u * a2 + a1;
+}
+
 // the four fields of an RRR vector a query needs (the first 16 bytes of RrrDesc)
 struct RrrView {
     uint32_t off_rec, off_bits;
     int32_t length, total_ones;
 };
-FMX_HD RrrView rrr_view(const RrrDesc &d) {  // one 16-byte load when `d` lives in HBM
-    const Quad q = ld_quad(&d);
+FMX_HD RrrView rrr_view_from(const Quad &q) {
     RrrView v;
     v.off_rec = q.x;
     v.off_bits = q.y;
@@ -178,47 +198,98 @@ FMX_HD RrrView rrr_view(const RrrDesc &d) {  // one 16-byte load when `d` lives 
     v.total_ones = (int32_t)q.w;
     return v;
 }
+FMX_HD RrrView rrr_view(const RrrDesc &d) { return rrr_view_from(ld_quad(&d)); }  // one 16-byte load
 
-// decode the 15-bit block that holds bit `position` (0 <= position < length):
-// returns the block value; prefix = ones before the block (RRR:367-390 over the 16-block records)
-FMX_HD uint32_t rrr_decode(const uint8_t *base, const RrrView &d, const uint16_t *inv, uint32_t position,
-                           uint32_t &prefix) {
+// the 16-block record that covers bit `position` (0 <= position < length)
+FMX_HD const RrrRecord *rrr_record_ptr(const uint8_t *base, const RrrView &d, uint32_t position) {
+    return reinterpret_cast<const RrrRecord *>(base + ((uint64_t)d.off_rec << 3)) + ((position / 15u) >> 4);
+}
+FMX_HD RrrRecord rrr_record_from(const Quad &q) {
+    RrrRecord r;
+    r.ones_before = q.x;
+    r.offset_bit = q.y;
+    r.classes = (uint64_t)q.z | ((uint64_t)q.w << 32);
+    return r;
+}
+FMX_HD RrrRecord rrr_load_record(const uint8_t *base, const RrrView &d, uint32_t position) {
+    return rrr_record_from(ld_quad(rrr_record_ptr(base, d, position)));
+}
+
+// decode the 15-bit block that holds bit `position` (0 <= position < length) from its record:
+// returns the block value; prefix = ones before the block (RRR:367-390 over the 16-block records).
+// kCompact: the vector is one of the wavelet tree's (COMPACT records); otherwise the sampled-suffix bitmap.
+template <bool kCompact>
+FMX_HD uint32_t rrr_decode_record(const uint8_t *base, const RrrView &d, const uint16_t *inv, const RrrRecord &rec,
+                                  uint32_t position, uint32_t &prefix) {
     const uint32_t block_id = position / 15u;  // RRR:367
     const uint32_t j = block_id & 15u;
-    const RrrRecord rec = reinterpret_cast<const RrrRecord *>(base + ((uint64_t)d.off_rec << 3))[block_id >> 4];
-    uint32_t ones = rec.ones_before;  // RRR:370
-    uint32_t obits = rec.offset_bit;  // RRR:371-372
-    rrr_scan_word(rec.classes, (int)j, ones, obits);         // RRR:376-380
-    const int cls = (int)((rec.classes >> (4 * j)) & 15);     // RRR:382
+    uint32_t ones, obits;
+    int cls;
+    if (kCompact) {
+        const bool upper = j >= 8u;
+        ones = (rec.ones_before & kRrrCompactMask) + (upper ? rec.ones_before >> kRrrCompactShift : 0u);  // RRR:370
+        obits = (rec.offset_bit & kRrrCompactMask) + (upper ? rec.offset_bit >> kRrrCompactShift : 0u);   // RRR:371-372
+        const uint32_t half = upper ? (uint32_t)(rec.classes >> 32) : (uint32_t)rec.classes;
+        rrr_scan_half(half, j & 7u, ones, obits);                 // RRR:376-380
+        cls = (int)((half >> (4u * (j & 7u))) & 15u);             // RRR:382
+    } else {
+        ones = rec.ones_before;  // RRR:370
+        obits = rec.offset_bit;  // RRR:371-372
+        rrr_scan_word(rec.classes, (int)j, ones, obits);         // RRR:376-380
+        cls = (int)((rec.classes >> (4 * j)) & 15);               // RRR:382
+    }
     const int nb = rrr_bits_needed(cls);                      // RRR:383
     const uint32_t *bits = reinterpret_cast<const uint32_t *>(base + ((uint64_t)d.off_bits << 3));
     const uint32_t off = ld_bits(bits, obits, nb);            // RRR:386
     prefix = ones;
     return rrr_inv_lookup(inv, cls, off);                     // RRR:387-390
 }
+template <bool kCompact>
+FMX_HD uint32_t rrr_decode(const uint8_t *base, const RrrView &d, const uint16_t *inv, uint32_t position,
+                           uint32_t &prefix) {
+    const RrrRecord rec = rrr_load_record(base, d, position);
+    return rrr_decode_record<kCompact>(base, d, inv, rec, position, prefix);
+}
+
+// rankOnes(position) with the record fetched ahead of time by the caller (only when 0 <= position < length;
+// otherwise `rec` is not looked at)
+FMX_HD bool rrr_in_range(const RrrView &d, int32_t position) { return position >= 0 && position < d.length; }
+template <bool kCompact>
+FMX_HD int32_t rrr_rank1_record(const uint8_t *base, const RrrView &d, const uint16_t *inv, const RrrRecord &rec,
+                                int32_t position) {
+    if (position < 0) return 0;
+    if (position >= d.length) return d.total_ones;
+    uint32_t prefix;
+    const uint32_t block = rrr_decode_record<kCompact>(base, d, inv, rec, (uint32_t)position, prefix);
+    const uint32_t t = (uint32_t)position % 15u;
+    return (int32_t)(prefix + (uint32_t)fmx_popc(block & ((1u << t) - 1u)));  // RRR:393-395
+}
 
 // RRR:358-396
+template <bool kCompact>
 FMX_HD int32_t rrr_rank1(const uint8_t *base, const RrrView &d, const uint16_t *inv, int32_t position) {
     if (position < 0) return 0;
     if (position >= d.length) return d.total_ones;
     uint32_t prefix;
-    const uint32_t block = rrr_decode(base, d, inv, (uint32_t)position, prefix);
+    const uint32_t block = rrr_decode<kCompact>(base, d, inv, (uint32_t)position, prefix);
     const uint32_t t = (uint32_t)position % 15u;
     return (int32_t)(prefix + (uint32_t)fmx_popc(block & ((1u << t) - 1u)));  // RRR:393-395
 }
 
 // RRR:314-349; out-of-range is reported through *status (IllegalArgumentException in the reference)
+template <bool kCompact>
 FMX_HD bool rrr_access(const uint8_t *base, const RrrView &d, const uint16_t *inv, int32_t position, int &status) {
     if (position < 0 || position >= d.length) {
         status = ST_JAVA_AIOOBE;
         return true;  // stops any walk that polls this bit
     }
     uint32_t prefix;
-    const uint32_t block = rrr_decode(base, d, inv, (uint32_t)position, prefix);
+    const uint32_t block = rrr_decode<kCompact>(base, d, inv, (uint32_t)position, prefix);
     return (block >> ((uint32_t)position % 15u)) & 1u;
 }
 
 // rankOnes(p) and access(p) at the same position p < length: one decode (WFBB:1389-1393)
+template <bool kCompact>
 FMX_HD int32_t rrr_rank1_access(const uint8_t *base, const RrrView &d, const uint16_t *inv, int32_t position,
                                 bool &bit) {
     if (position >= d.length || position < 0) {  // rankOnes saturates; access would throw — unreachable for a
@@ -226,7 +297,7 @@ FMX_HD int32_t rrr_rank1_access(const uint8_t *base, const RrrView &d, const uin
         return position < 0 ? 0 : d.total_ones;
     }
     uint32_t prefix;
-    const uint32_t block = rrr_decode(base, d, inv, (uint32_t)position, prefix);
+    const uint32_t block = rrr_decode<kCompact>(base, d, inv, (uint32_t)position, prefix);
     const uint32_t t = (uint32_t)position % 15u;
     bit = (block >> t) & 1u;
     return (int32_t)(prefix + (uint32_t)fmx_popc(block & ((1u << t) - 1u)));
@@ -234,19 +305,23 @@ FMX_HD int32_t rrr_rank1_access(const uint8_t *base, const RrrView &d, const uin
 
 // WFBB:250-278: block-local leaf index -> canonical (code, length).  The per-level leaf counts are the
 // u16 at stride 4 of the level table; up to four levels come from one 16-byte load.
-FMX_HD void wt_restore_code(uint32_t block_c, const uint8_t *hdr, int32_t tree_height, uint32_t &code,
+FMX_HD uint32_t quad_entry(const Quad &q, int i) {
+    const uint32_t lo = (i & 1) ? q.y : q.x, hi = (i & 1) ? q.w : q.z;
+    return (i & 2) ? hi : lo;
+}
+// `chunk` = level entries 0..3 (the first 16 bytes of the header), fetched by the caller
+FMX_HD void wt_restore_code(uint32_t block_c, const uint8_t *hdr, int32_t tree_height, Quad chunk, uint32_t &code,
                             int32_t &code_length) {
     code = 0;
     code_length = 1;
     uint32_t leaf_count = 0;
     int32_t lvl = 0;  // index of the level entry under inspection
-    Quad chunk = {0, 0, 0, 0};
     while (code_length < tree_height) {
-        if ((lvl & 3) == 0) {
-            memcpy(&chunk, hdr + 4 * lvl, 16);  // entries lvl..lvl+3 (guard bytes cover the tail)
+        if (lvl != 0 && (lvl & 3) == 0) {
+            chunk = ld_quad(hdr + 4 * lvl);  // entries lvl..lvl+3 (guard bytes cover the tail)
             FMX_OPAQUE32(chunk.x);
         }
-        const uint32_t e = (lvl & 2) ? ((lvl & 1) ? chunk.w : chunk.z) : ((lvl & 1) ? chunk.y : chunk.x);
+        const uint32_t e = quad_entry(chunk, lvl);
         const uint32_t level_leaf_count = e & 0xffffu;
         code <<= 1;
         if (leaf_count + level_leaf_count > block_c) {
@@ -264,13 +339,26 @@ FMX_HD void wt_restore_code(uint32_t block_c, const uint8_t *hdr, int32_t tree_h
     }
 }
 
+// rank + superblock code of a symbol as one 8-byte load
+FMX_HD SbcEntry sbc_from(uint64_t v) {
+    SbcEntry e;
+    e.rank = (int32_t)(uint32_t)v;
+    e.sbc = (int16_t)(uint16_t)(v >> 32);
+    e.pad = 0;
+    return e;
+}
+FMX_HD SbcEntry ld_sbc(const SbcEntry *p) {
+    uint64_t v;
+    memcpy(&v, p, 8);
+    return sbc_from(v);
+}
+
 // header fields of a superblock that every rank needs: the first 16 bytes of SbDesc in one load
 struct SbHead {
     int32_t sigma, bsl;
     uint32_t off_mapping, off_bh, off_var;
 };
-FMX_HD SbHead sb_head(const SbDesc &sd) {
-    const Quad q = ld_quad(&sd);
+FMX_HD SbHead sb_head_from(const Quad &q) {
     SbHead h;
     h.sigma = (int32_t)(int16_t)(q.x & 0xffffu);
     h.bsl = (int32_t)(int16_t)(q.x >> 16);
@@ -279,8 +367,8 @@ FMX_HD SbHead sb_head(const SbDesc &sd) {
     h.off_var = q.w;
     return h;
 }
-FMX_HD BlockHdr ld_block_hdr(const BlockHdr *p) {
-    const Quad q = ld_quad(p);
+FMX_HD SbHead sb_head(const SbDesc &sd) { return sb_head_from(ld_quad(&sd)); }
+FMX_HD BlockHdr block_hdr_from(const Quad &q) {
     BlockHdr b;
     b.bv_rank = (int32_t)q.x;
     b.bv_offset = (int32_t)q.y;
@@ -289,6 +377,7 @@ FMX_HD BlockHdr ld_block_hdr(const BlockHdr *p) {
     b.tree_height = (int16_t)(q.w >> 16);
     return b;
 }
+FMX_HD BlockHdr ld_block_hdr(const BlockHdr *p) { return block_hdr_from(ld_quad(p)); }
 
 // one level of the tree walk shared by rank and inverseSelect (WFBB:1187-1278 / 1388-1489):
 // the cumulative one-counts of the level (u16 each): [left-1] and [left] come from one 4-byte load
@@ -298,16 +387,30 @@ struct TreeWalk {
     uint32_t second;        // offset of the cumulative one-counts of the current level
     uint32_t level;         // offset of the next entry of the level table
 };
-FMX_HD void tree_level_counts(const TreeWalk &t, int32_t &left_ones, int32_t &node_ones, int32_t &level_ones) {
+// split in two so that a caller can request these together with other loads and wait once
+FMX_HD void tree_level_counts_load(const TreeWalk &t, uint32_t &raw_pair, uint32_t &raw_level) {
+    // entries [left-1, left], or [0, 1] for the leftmost node (entry 1 is then not looked at; the bytes exist:
+    // the header ends in guard bytes) — one unconditional 4-byte load
+    const int32_t first = t.left_siblings > 0 ? t.left_siblings - 1 : 0;
+    memcpy(&raw_pair, t.hdr + t.second + 2 * first, 4);
+    raw_level = ld16(t.hdr + t.second + 2 * (t.internal_nodes - 1));
+}
+FMX_HD void tree_level_counts_decode(const TreeWalk &t, uint32_t raw_pair, uint32_t raw_level, int32_t &left_ones,
+                                     int32_t &node_ones, int32_t &level_ones) {
     if (t.left_siblings > 0) {
-        const uint32_t pair = ld32u(t.hdr + t.second + 2 * (t.left_siblings - 1));
-        left_ones = (int32_t)(pair & 0xffffu);                        // WFBB:1193-1206
-        node_ones = (int32_t)(pair >> 16) - left_ones;                // WFBB:1210-1214
+        left_ones = (int32_t)(raw_pair & 0xffffu);                    // WFBB:1193-1206
+        node_ones = (int32_t)(raw_pair >> 16) - left_ones;            // WFBB:1210-1214
     } else {
         left_ones = 0;
-        node_ones = (int32_t)ld16(t.hdr + t.second);
+        node_ones = (int32_t)(raw_pair & 0xffffu);
     }
-    level_ones = (int32_t)ld16(t.hdr + t.second + 2 * (t.internal_nodes - 1));  // WFBB:1220-1229
+    level_ones = (int32_t)raw_level;  // WFBB:1220-1229
+}
+FMX_HD void tree_level_counts(const TreeWalk &t, int32_t &left_ones, int32_t &node_ones, int32_t &level_ones) {
+    uint32_t raw_pair, raw_level;
+    tree_level_counts_load(t, raw_pair, raw_level);
+    FMX_OPAQUE32(raw_pair);
+    tree_level_counts_decode(t, raw_pair, raw_level, left_ones, node_ones, level_ones);
 }
 FMX_HD void tree_descend(TreeWalk &t, bool bit, int32_t rank1, int32_t node_ones) {
     const int32_t node_zeros = t.node_bv_size - node_ones;
@@ -325,8 +428,10 @@ FMX_HD void tree_descend(TreeWalk &t, bool bit, int32_t rank1, int32_t node_ones
     }
 }
 // WFBB:1247-1278: next level's leaf count and total bitvector size (one 4-byte load); returns the leaf count
-FMX_HD int32_t tree_next_level(TreeWalk &t) {
-    const uint32_t e = ld32u(t.hdr + t.level);
+FMX_HD int32_t tree_next_level_entry(TreeWalk &t, uint32_t e);
+FMX_HD int32_t tree_next_level(TreeWalk &t) { return tree_next_level_entry(t, ld32u(t.hdr + t.level)); }
+// the same step with the level entry already at hand (entries 0..3 travel with the header's first 16 bytes)
+FMX_HD int32_t tree_next_level_entry(TreeWalk &t, uint32_t e) {
     const int32_t next_leaf_count = (int32_t)(e & 0xffffu);
     const int32_t next_total_bv = (int32_t)(e >> 16) + 1;
     t.level += 4;
@@ -352,9 +457,20 @@ FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t positio
         suspect = true;
         return 0;
     }
-    const SbcEntry e = ix.sbc[(uint64_t)sb_id * (uint32_t)ix.wt_sigma + (uint32_t)symbol];  // WFBB:1024, 1034-1037
-    const SbDesc &sd = ix.sbd[sb_id];                                                      // WFBB:1026
-    const SbHead sh = sb_head(sd);
+    // The loads of one rank form a dependent chain (superblock -> mapping -> block header -> leaf -> levels);
+    // what a stage needs is requested as soon as its address is known, so that the chain is
+    //   {superblock entry, superblock header, RRR view} -> {mapping entry, block header}
+    //   -> {leaf, level table, first level's counts, first RRR record} -> offset bits -> ...
+    uint64_t sbc_raw;
+    memcpy(&sbc_raw, ix.sbc + (uint64_t)sb_id * (uint32_t)ix.wt_sigma + (uint32_t)symbol, 8);  // WFBB:1024, 1034-1037
+    const SbDesc &sd = ix.sbd[sb_id];                                                          // WFBB:1026
+    Quad head_q = ld_quad(&sd), view_q = ld_quad(&sd.rrr);  // same 64-byte line
+    FMX_OPAQUE64(sbc_raw);
+    const SbcEntry e = sbc_from(sbc_raw);
+    FMX_PIN_QUAD(head_q);
+    FMX_PIN_QUAD(view_q);
+    const SbHead sh = sb_head_from(head_q);
+    const RrrView rv = rrr_view_from(view_q);
     if ((int32_t)e.sbc >= sh.sigma + 1) return e.rank;  // WFBB:1040-1042
     const int32_t bsl = sh.bsl;
     const uint32_t block_size = 1u << bsl;
@@ -366,6 +482,8 @@ FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t positio
     const uint8_t *var = ix.base + ((uint64_t)sh.off_var << 3);
     const uint32_t map_row = (uint32_t)e.sbc << blocks_log;
     int32_t block_c = mapping[map_row + block_id];  // WFBB:1044-1046
+    Quad bhq = ld_quad(bhs + block_id);              // WFBB:1113, requested before the mapping entry is known
+    FMX_PIN_QUAD(bhq);
 
     if (block_c < 0) {  // WFBB:1048-1110: absent; -block_c = distance to the closest block to the right that
                         // holds the symbol (what the scan of WFBB:1051-1059 finds), or to the superblock end
@@ -386,11 +504,28 @@ FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t positio
         return e.rank + (int32_t)(ld32u(var + p) & 0xffffffu);  // WFBB:1096-1108
     }
 
-    const BlockHdr bh = ld_block_hdr(bhs + block_id);  // WFBB:1113
+    const BlockHdr bh = block_hdr_from(bhq);
     const int32_t tree_height = bh.tree_height;
     const uint8_t *hdr = var + bh.var_off;
     const uint8_t *leaves = hdr + (tree_height > 0 ? (tree_height - 1) * 4 : 0);  // WFBB:1119-1121
-    uint64_t leaf = ld64u(leaves + 5 * block_c);  // {u16 symbol, u24 rank at block start} + 3 bytes of the next entry
+    // everything the first level needs hangs off the block header alone: ask for it together with the leaf
+    const uint32_t second0 = (uint32_t)((tree_height - 1) * 4 + ((int32_t)bh.sigma + 1) * 5);  // WFBB:1177-1182
+    const int32_t position0 = bh.bv_offset + (int32_t)block_index;
+    uint64_t leaf;
+    memcpy(&leaf, leaves + 5 * block_c, 8);  // {u16 symbol, u24 rank at block start} + 3 bytes of the next entry
+    Quad chunk = {0, 0, 0, 0};
+    uint32_t counts0 = 0;
+    Quad rec_q = {0, 0, 0, 0};
+    if (tree_height > 0) {
+        chunk = ld_quad(hdr);  // level entries 0..3 (guard bytes cover the tail)
+        counts0 = ld16(hdr + second0);
+        if (rrr_in_range(rv, position0)) rec_q = ld_quad(rrr_record_ptr(ix.base, rv, (uint32_t)position0));
+    }
+    FMX_OPAQUE64(leaf);
+    FMX_PIN_QUAD(chunk);
+    FMX_OPAQUE32(counts0);
+    FMX_PIN_QUAD(rec_q);
+    RrrRecord rec = rrr_record_from(rec_q);
     if ((int32_t)(leaf & 0xffffu) != symbol) {    // WFBB:1123-1130: clamped mapping entry
         ++block_c;
         leaf = ld64u(leaves + 5 * block_c);
@@ -400,12 +535,11 @@ FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t positio
 
     uint32_t code;
     int32_t code_length;
-    wt_restore_code((uint32_t)block_c, hdr, tree_height, code, code_length);  // WFBB:1148-1156
+    wt_restore_code((uint32_t)block_c, hdr, tree_height, chunk, code, code_length);  // WFBB:1148-1156
 
     const uint32_t cur_block_size = (ix.wt_size - (position - block_index)) < block_size
                                         ? (ix.wt_size - (position - block_index))
                                         : block_size;  // WFBB:1032
-    const RrrView rv = rrr_view(sd.rrr);
     TreeWalk t;
     t.bv_rank = bh.bv_rank;      // WFBB:1158
     t.bv_offset = bh.bv_offset;  // WFBB:1161
@@ -416,17 +550,32 @@ FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t positio
     t.depth_total_bv = t.node_bv_size;
     t.node_rank = (int32_t)block_index;
     t.hdr = hdr;
-    t.second = (uint32_t)((tree_height - 1) * 4 + ((int32_t)bh.sigma + 1) * 5);  // WFBB:1177-1182
+    t.second = second0;
     t.level = 0;
 
-    for (int32_t depth = 0; depth < code_length; ++depth) {  // WFBB:1185-1279
-        int32_t left_ones, node_ones, level_ones;
-        tree_level_counts(t, left_ones, node_ones, level_ones);
-        int32_t rank1 = rrr_rank1(ix.base, rv, inv, t.bv_offset + t.left_total_bv + t.node_rank);
+    // WFBB:1185-1279.  Level 0's counts are the single u16 at `second` (no left sibling, one internal node);
+    // the counts and the record of level d+1 are requested at the end of level d.
+    int32_t left_ones = 0, node_ones = (int32_t)counts0, level_ones = (int32_t)counts0;
+    int32_t rrr_position = position0;
+    FMX_NO_UNROLL  // one copy of the level code: peeled copies only add instruction-cache pressure
+    for (int32_t depth = 0; depth < code_length; ++depth) {
+        int32_t rank1 = rrr_rank1_record<true>(ix.base, rv, inv, rec, rrr_position);
         rank1 -= t.bv_rank + left_ones;
         t.bv_rank += level_ones;
         tree_descend(t, (code & (1u << (code_length - depth - 1))) != 0, rank1, node_ones);
-        if (depth + 1 != code_length) t.left_siblings -= tree_next_level(t);
+        if (depth + 1 != code_length) {
+            const uint32_t entry = depth < 4 ? quad_entry(chunk, depth) : ld32u(t.hdr + t.level);
+            t.left_siblings -= tree_next_level_entry(t, entry);
+            uint32_t raw_pair, raw_level;
+            tree_level_counts_load(t, raw_pair, raw_level);
+            rrr_position = t.bv_offset + t.left_total_bv + t.node_rank;
+            if (rrr_in_range(rv, rrr_position)) rec_q = ld_quad(rrr_record_ptr(ix.base, rv, (uint32_t)rrr_position));
+            FMX_OPAQUE32(raw_pair);
+            FMX_OPAQUE32(raw_level);
+            FMX_PIN_QUAD(rec_q);
+            rec = rrr_record_from(rec_q);
+            tree_level_counts_decode(t, raw_pair, raw_level, left_ones, node_ones, level_ones);
+        }
     }
     return e.rank + rank_block + t.node_rank;  // WFBB:1281-1284
 }
@@ -484,7 +633,7 @@ FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32
         int32_t left_ones, node_ones, level_ones;
         tree_level_counts(t, left_ones, node_ones, level_ones);
         bool next_bit;
-        int32_t rank1 = rrr_rank1_access(ix.base, rv, inv, t.bv_offset + t.left_total_bv + t.node_rank, next_bit);
+        int32_t rank1 = rrr_rank1_access<true>(ix.base, rv, inv, t.bv_offset + t.left_total_bv + t.node_rank, next_bit);
         rank1 -= t.bv_rank + left_ones;
         t.bv_rank += level_ones;
         code = (code << 1) | (next_bit ? 1u : 0u);
@@ -581,7 +730,7 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
     int32_t j = start + 1 + k;  // FM:527-529
     distance = 0;
     const RrrView sv = {ix.sampled.off_rec, ix.sampled.off_bits, ix.sampled.length, ix.sampled.total_ones};
-    while (!rrr_access(ix.base, sv, inv, j - 1, status)) {  // FM:531
+    while (!rrr_access<false>(ix.base, sv, inv, j - 1, status)) {  // FM:531
         int32_t c;
         j = fm_lf_step(ix, inv, j, c, status);  // FM:532-535
         ++distance;
@@ -590,7 +739,7 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
             break;
         }
     }
-    const int32_t r = rrr_rank1(ix.base, sv, inv, j) - 1;                  // FM:541
+    const int32_t r = rrr_rank1<false>(ix.base, sv, inv, j) - 1;                  // FM:541
     return fm_packed_get(ix.suffix_words, r, ix.bw_suffixes) + distance;  // FM:538-542
 }
 
