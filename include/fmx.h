@@ -119,7 +119,8 @@ int fmx_count_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32
 /* The two stages of fmx_count_batch_dev, callable separately (bench.py times the second one alone):
  * plan = processing order of the batch (device bucket sort on the patterns' trailing characters, so
  * that neighbouring lanes walk the same SA intervals); *d_perm points into per-stream scratch owned by
- * the index (valid until the next plan on that stream) or is NULL for small batches.
+ * the index (valid until the next plan on that stream, and only for the same d_pat / d_pat_off contents: the
+ * plan also keeps the mapped codes of each pattern's last characters for the kernel) or is NULL for small batches.
  * ordered = the k_count kernel over that order; results are written at the ORIGINAL pattern index. */
 int fmx_count_plan_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
                        const uint32_t **d_perm, void *stream);

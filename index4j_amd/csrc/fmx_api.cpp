@@ -17,9 +17,9 @@
 #include <vector>
 
 namespace fmx {
-int launch_count_plan(const DevIndex &, const uint16_t *, const int32_t *, int32_t, void *, size_t, const uint32_t **,
+int launch_count_plan(const DevIndex &, const uint16_t *, const int32_t *, int32_t, void *, size_t, const uint32_t **, const void **,
                       hipStream_t);
-int launch_count(const DevIndex &, int, const uint16_t *, const int32_t *, const uint32_t *, int32_t, int32_t *,
+int launch_count(const DevIndex &, int, const uint16_t *, const int32_t *, const uint32_t *, const void *, int32_t, int32_t *,
                  int32_t *, int32_t *, int32_t *, hipStream_t);
 size_t count_workspace_bytes(const DevIndex &, int32_t n);
 int launch_locate_walk(const DevIndex &, int, const int32_t *, int32_t, int32_t, int32_t *, int32_t, int32_t *,
@@ -54,6 +54,13 @@ struct fmx_index {
     // per-stream scratch for the in-library pattern sort (grow-only; freed with the index)
     mutable std::mutex ws_mutex;
     mutable std::map<void *, std::pair<void *, size_t>> ws;
+    struct Plan {  // the last fmx_count_plan_dev result per stream: order + per-pattern code words
+        const uint32_t *perm = nullptr;
+        const void *codes = nullptr;
+        const uint16_t *pat = nullptr;
+        int32_t n = 0;
+    };
+    mutable std::map<void *, Plan> plans;
 };
 
 namespace {
@@ -340,14 +347,16 @@ void *fmx_device_blob(const fmx_index *idx, size_t *len) {
 // stage 1 of count/locate: processing order of the batch (suffix-key radix sort) — nullptr when the
 // batch is too small to be worth sorting
 static int plan_order(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n, void *stream,
-                      const uint32_t **perm) {
+                      const uint32_t **perm, const void **codes) {
     *perm = nullptr;
+    *codes = nullptr;
     void *ws = nullptr;
     const size_t ws_bytes = fmx::count_workspace_bytes(idx->dev, n);
     int rc = get_workspace(idx, stream, ws_bytes, &ws);
     if (rc) return rc;
     if (!ws) return FMX_OK;
-    int e = fmx::launch_count_plan(idx->dev, d_pat, d_pat_off, n, ws, ws_bytes, perm, static_cast<hipStream_t>(stream));
+    int e = fmx::launch_count_plan(idx->dev, d_pat, d_pat_off, n, ws, ws_bytes, perm, codes,
+                                   static_cast<hipStream_t>(stream));
     if (e) return fail(FMX_E_HIP, std::string("pattern sort: ") + hipGetErrorString((hipError_t)e));
     return FMX_OK;
 }
@@ -357,7 +366,17 @@ int fmx_count_plan_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_
     int rc = require_device(idx);
     if (rc) return rc;
     if (n < 0 || !d_perm || (n > 0 && !d_pat_off)) return fail(FMX_E_ARG, "bad arguments");
-    return plan_order(idx, d_pat, d_pat_off, n, stream, d_perm);
+    fmx_index::Plan plan;
+    rc = plan_order(idx, d_pat, d_pat_off, n, stream, &plan.perm, &plan.codes);
+    if (rc) return rc;
+    plan.pat = d_pat;
+    plan.n = n;
+    {
+        std::lock_guard<std::mutex> lock(idx->ws_mutex);
+        idx->plans[stream] = plan;
+    }
+    *d_perm = plan.perm;
+    return FMX_OK;
 }
 
 int fmx_count_ordered_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, const uint32_t *d_perm,
@@ -365,8 +384,15 @@ int fmx_count_ordered_dev(const fmx_index *idx, const uint16_t *d_pat, const int
     int rc = require_device(idx);
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!d_pat_off || !d_counts))) return fail(FMX_E_ARG, "bad arguments");
-    int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, d_perm, n, d_counts, d_lf_steps, d_status, nullptr,
-                              static_cast<hipStream_t>(stream));
+    const void *codes = nullptr;  // only the order's own plan carries code words for these patterns
+    if (d_perm) {
+        std::lock_guard<std::mutex> lock(idx->ws_mutex);
+        auto it = idx->plans.find(stream);
+        if (it != idx->plans.end() && it->second.perm == d_perm && it->second.n == n && it->second.pat == d_pat)
+            codes = it->second.codes;
+    }
+    int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, d_perm, codes, n, d_counts, d_lf_steps, d_status,
+                              nullptr, static_cast<hipStream_t>(stream));
     if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
     return FMX_OK;
 }
@@ -389,9 +415,11 @@ int fmx_locate_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int3
     hipStream_t st = static_cast<hipStream_t>(stream);
     // found[] doubles as the scratch `counts` output of the range pass; the walk pass overwrites it
     const uint32_t *perm = nullptr;
-    rc = plan_order(idx, d_pat, d_pat_off, n, stream, &perm);
+    const void *codes = nullptr;
+    rc = plan_order(idx, d_pat, d_pat_off, n, stream, &perm, &codes);
     if (rc) return rc;
-    int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, perm, n, d_found, d_lf_steps, d_status, d_range_ws, st);
+    int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, perm, codes, n, d_found, d_lf_steps, d_status,
+                              d_range_ws, st);
     if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
     e = fmx::launch_locate_walk(idx->dev, idx->n_cu, d_range_ws, n, max_matches, d_locs, loc_cap, d_found, d_lf_steps,
                                 d_status, nullptr, st);
@@ -504,12 +532,15 @@ int fmx_count_segments_dev(const fmx_index *const *segs, int32_t n_segs, const u
     hipStream_t st = static_cast<hipStream_t>(stream);
     // one processing order for all segments: any grouping is valid, and equal characters get equal codes in
     // every segment's alphabet, so the order derived from the first segment groups the batch for all of them
+    // (the plan's code words are in the first segment's alphabet, so only that segment uses them)
     const uint32_t *perm = nullptr;
-    rc = plan_order(segs[0], d_pat, d_pat_off, n, stream, &perm);
+    const void *codes = nullptr;
+    rc = plan_order(segs[0], d_pat, d_pat_off, n, stream, &perm, &codes);
     if (rc) return rc;
     int32_t *cnt = d_tmp, *lf = d_tmp + n, *sts = d_tmp + 2 * (size_t)n;
     for (int32_t s = 0; s < n_segs; ++s) {
-        int e = fmx::launch_count(segs[s]->dev, segs[s]->n_cu, d_pat, d_pat_off, perm, n, cnt, lf, sts, nullptr, st);
+        int e = fmx::launch_count(segs[s]->dev, segs[s]->n_cu, d_pat, d_pat_off, perm, s == 0 ? codes : nullptr, n, cnt, lf,
+                                  sts, nullptr, st);
         if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
         e = fmx::launch_segment_add_counts(d_counts, d_lf_steps, d_status, cnt, lf, sts, n, s == 0, st);
         if (e) return fail(FMX_E_HIP, std::string("k_segment_add_counts launch: ") + hipGetErrorString((hipError_t)e));
@@ -529,11 +560,12 @@ int fmx_locate_segments_dev(const fmx_index *const *segs, int32_t n_segs, const 
     hipStream_t st = static_cast<hipStream_t>(stream);
     int32_t *seg_found = d_tmp, *seg_status = d_tmp + n, *range = d_tmp + 2 * (size_t)n, *seg_locs = d_tmp + 4 * (size_t)n;
     const uint32_t *perm = nullptr;
-    rc = plan_order(segs[0], d_pat, d_pat_off, n, stream, &perm);
+    const void *codes = nullptr;
+    rc = plan_order(segs[0], d_pat, d_pat_off, n, stream, &perm, &codes);
     if (rc) return rc;
     for (int32_t s = 0; s < n_segs; ++s) {
-        int e = fmx::launch_count(segs[s]->dev, segs[s]->n_cu, d_pat, d_pat_off, perm, n, seg_found, nullptr, seg_status,
-                                  range, st);
+        int e = fmx::launch_count(segs[s]->dev, segs[s]->n_cu, d_pat, d_pat_off, perm, s == 0 ? codes : nullptr, n,
+                                  seg_found, nullptr, seg_status, range, st);
         if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
         // like the caller's loop `n += seg.locate(p, 0, len, locations, maxMatches - n)`: hits already
         // taken from earlier segments shrink this segment's limit

@@ -36,16 +36,22 @@ __device__ __forceinline__ void stage_inverse_table(uint16_t *s_inv, const uint1
 // perm (nullable): processing order — slot q of the grid handles pattern perm[q].  The launcher sorts
 // the batch by the patterns' last characters so that the lanes of a wave start their backward search
 // in the same SA intervals (same sectors, broadcast loads); results land at the original index.
+// The plan stage hands k_count one 64-bit word per pattern with the codes of its trailing characters, the last
+// character in the low bits: 8 codes of 8 bits when the alphabet fits (sigma <= 256), else 4 codes of 16 bits.
+__host__ __device__ inline int plan_code_bits(int32_t sigma) { return sigma <= 256 ? 8 : 16; }
+
 template <int kBlock>
 FMX_KERNEL(kBlock) void k_count(DevIndex ix, const uint16_t *__restrict__ pat,
                                                   const int32_t *__restrict__ pat_off,
                                                   const uint32_t *__restrict__ perm, int32_t n,
                                                   int32_t *__restrict__ counts, int32_t *__restrict__ lf_steps,
                                                   int32_t *__restrict__ status_out, int32_t *__restrict__ range_out,
-                                                  int xcd_remap) {
+                                                  int xcd_remap, const uint64_t *__restrict__ codes) {
     __shared__ uint16_t s_inv[kInvEntries];
     stage_inverse_table(s_inv, ix.inv_global);
     const int role = threadIdx.x & 1;
+    const int code_bits = plan_code_bits(ix.wt_sigma), n_codes = codes ? 64 / code_bits : 0;
+    const uint32_t code_mask = (1u << code_bits) - 1u;
     const int32_t pairs_per_grid = (int32_t)gridDim.x * (kBlock / 2);  // 32-bit indices: n < 2^31, fewer live registers
     // XCD-aware block order (speed only): blocks b and b+8 share an XCD and its L2, so give the blocks of one
     // XCD a CONTIGUOUS eighth of the (suffix-sorted) batch instead of every eighth tile
@@ -64,12 +70,21 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix, const uint16_t *__restrict__ pat,
             status = ST_JAVA_AIOOBE;  // pattern[-1], FM:456-457
         } else {
             int32_t i = m - 1;
-            int32_t c = fm_map(ix, pat[beg + i]);
+            // the plan stage left the codes of the trailing characters (one 8-byte load per pattern instead of a
+            // character load and a map lookup in front of every rank)
+            const uint64_t cw = codes ? codes[p] : 0ull;
+            int32_t c = codes ? (int32_t)((uint32_t)cw & code_mask) : fm_map(ix, pat[beg + i]);
             if (c != 0) {  // FM:458-460
                 start = ix.C[c];
                 end = ix.C[c + 1];
                 while (start < end && i >= 1) {  // FM:464
-                    c = fm_map(ix, pat[beg + --i]);
+                    --i;
+                    const int32_t back = m - 1 - i;  // characters consumed before this one
+                    if (back < n_codes) {
+                        c = (int32_t)((uint32_t)(cw >> (back * code_bits)) & code_mask);
+                    } else {
+                        c = fm_map(ix, pat[beg + i]);
+                    }
                     if (c == 0) {  // FM:466-468
                         start = end = 0;
                         break;
@@ -303,13 +318,19 @@ struct SortShape {
     int coarse_bits;  // top bits used by the bucket pass
 };
 
-__device__ __forceinline__ uint32_t suffix_key(const DevIndex &ix, const uint16_t *pat, int32_t beg, int32_t m,
-                                               int chars, int bits) {
+// the plan's code word of a pattern: codes of its trailing characters, the LAST character in the low bits
+__device__ __forceinline__ uint64_t pattern_code_word(const DevIndex &ix, const uint16_t *pat, int32_t beg, int32_t m,
+                                                      int code_bits) {
+    const int n_codes = 64 / code_bits;
+    uint64_t w = 0;
+    for (int j = 0; j < n_codes && j < m; ++j) w |= (uint64_t)(uint32_t)fm_map(ix, pat[beg + m - 1 - j]) << (j * code_bits);
+    return w;
+}
+// sort key = the first `chars` codes of the word, the last character most significant
+__device__ __forceinline__ uint32_t suffix_key(uint64_t word, int code_bits, int chars, int bits) {
+    const uint32_t mask = (1u << code_bits) - 1u;
     uint32_t key = 0;
-    for (int j = 0; j < chars; ++j) {
-        const uint32_t c = (j < m) ? (uint32_t)fm_map(ix, pat[beg + m - 1 - j]) : 0u;
-        key = (key << bits) | c;
-    }
+    for (int j = 0; j < chars; ++j) key = (key << bits) | ((uint32_t)(word >> (j * code_bits)) & mask);
     return key;
 }
 
@@ -317,8 +338,10 @@ __device__ __forceinline__ uint32_t suffix_key(const DevIndex &ix, const uint16_
 __global__ __launch_bounds__(kTileThreads) void k_order_hist(DevIndex ix, const uint16_t *__restrict__ pat,
                                                              const int32_t *__restrict__ pat_off, int32_t n,
                                                              SortShape sh, uint32_t *__restrict__ coarse,
-                                                             uint32_t *__restrict__ ghist) {
+                                                             uint32_t *__restrict__ ghist,
+                                                             uint64_t *__restrict__ codes) {
     extern __shared__ uint32_t s_hist[];
+    const int code_bits = plan_code_bits(ix.wt_sigma);
     const int bins = 1 << sh.coarse_bits;
     for (int i = threadIdx.x; i < bins; i += kTileThreads) s_hist[i] = 0;
     __syncthreads();
@@ -327,7 +350,9 @@ __global__ __launch_bounds__(kTileThreads) void k_order_hist(DevIndex ix, const 
         const int64_t p = base + (int64_t)k * kTileThreads + threadIdx.x;
         if (p < n) {
             const int32_t beg = pat_off[p];
-            const uint32_t key = suffix_key(ix, pat, beg, pat_off[p + 1] - beg, sh.chars, sh.bits);
+            const uint64_t word = pattern_code_word(ix, pat, beg, pat_off[p + 1] - beg, code_bits);
+            codes[p] = word;  // kept for the tile sort and for k_count
+            const uint32_t key = suffix_key(word, code_bits, sh.chars, sh.bits);
             const uint32_t c = key >> (sh.total_bits - sh.coarse_bits);
             coarse[p] = c;
             atomicAdd(&s_hist[c], 1u);
@@ -398,10 +423,11 @@ __global__ __launch_bounds__(kTileThreads) void k_order_scatter(const uint32_t *
 }
 
 // pass 2: tile-local radix sort of the bucket order on the full key
-__global__ __launch_bounds__(kTileThreads) void k_order_tile_sort(DevIndex ix, const uint16_t *__restrict__ pat,
-                                                                  const int32_t *__restrict__ pat_off, int32_t n,
-                                                                  SortShape sh, const uint32_t *__restrict__ perm_in,
+__global__ __launch_bounds__(kTileThreads) void k_order_tile_sort(DevIndex ix, const uint64_t *__restrict__ codes,
+                                                                  int32_t n, SortShape sh,
+                                                                  const uint32_t *__restrict__ perm_in,
                                                                   uint32_t *__restrict__ perm_out) {
+    const int code_bits = plan_code_bits(ix.wt_sigma);
     using Sort = rocprim::block_radix_sort<uint32_t, kTileThreads, kTileItems, uint32_t>;
     __shared__ typename Sort::storage_type storage;
     const int64_t base = (int64_t)blockIdx.x * kTile;
@@ -410,8 +436,7 @@ __global__ __launch_bounds__(kTileThreads) void k_order_tile_sort(DevIndex ix, c
         const int64_t i = base + (int64_t)threadIdx.x * kTileItems + k;
         if (i < n) {
             const uint32_t p = perm_in[i];
-            const int32_t beg = pat_off[p];
-            keys[k] = suffix_key(ix, pat, beg, pat_off[p + 1] - beg, sh.chars, sh.bits);
+            keys[k] = suffix_key(codes[p], code_bits, sh.chars, sh.bits);
             vals[k] = p;
         } else {
             keys[k] = 0xffffffffu;  // padding sorts last and is dropped on write-back
@@ -540,22 +565,28 @@ static SortShape sort_shape(const DevIndex &ix) {
     while ((1 << sh.bits) < ix.wt_sigma && sh.bits < 15) ++sh.bits;
     sh.chars = g_sort_bits / sh.bits;
     if (sh.chars < 1) sh.chars = 1;
+    if (sh.chars > 64 / plan_code_bits(ix.wt_sigma)) sh.chars = 64 / plan_code_bits(ix.wt_sigma);
     sh.total_bits = sh.chars * sh.bits;
     sh.coarse_bits = sh.total_bits < kCoarseBitsMax ? sh.total_bits : kCoarseBitsMax;
     return sh;
 }
 
+// workspace layout: coarse[n] perm1[n] perm2[n] ghist[bins] | codes[n] (8 bytes each, 16-byte aligned)
+static size_t plan_codes_offset(int32_t n) {
+    return (((size_t)n * 12 + ((size_t)4 << kCoarseBitsMax) + 512) + 15) & ~(size_t)15;
+}
 // bytes of scratch needed to order a batch of n patterns (0 = the batch is not sorted)
 size_t count_workspace_bytes(const DevIndex &ix, int32_t n) {
     if (g_sort_min <= 0 || n < g_sort_min) return 0;
-    return (size_t)n * 12 + ((size_t)4 << kCoarseBitsMax) + 512;
+    return plan_codes_offset(n) + (size_t)n * sizeof(uint64_t);
 }
 
 // perm_out[q] = index of the q-th pattern in processing order.  workspace: count_workspace_bytes(ix, n).
 // Returns a hipError_t value.
 int launch_count_plan(const DevIndex &ix, const uint16_t *pat, const int32_t *off, int32_t n, void *workspace,
-                      size_t workspace_bytes, const uint32_t **perm_out, hipStream_t st) {
+                      size_t workspace_bytes, const uint32_t **perm_out, const void **codes_out, hipStream_t st) {
     *perm_out = nullptr;
+    *codes_out = nullptr;
     const size_t need = count_workspace_bytes(ix, n);
     if (n <= 0 || !workspace || need == 0 || workspace_bytes < need) return 0;
     const SortShape sh = sort_shape(ix);
@@ -567,22 +598,27 @@ int launch_count_plan(const DevIndex &ix, const uint16_t *pat, const int32_t *of
     const int tiles = (n + kTile - 1) / kTile;
     hipError_t e = hipMemsetAsync(ghist, 0, (size_t)bins * 4, st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_order_hist, dim3(tiles), dim3(kTileThreads), (size_t)bins * 4, st, ix, pat, off, n, sh, coarse, ghist);
+    uint64_t *codes = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(workspace) + plan_codes_offset(n));
+    hipLaunchKernelGGL(k_order_hist, dim3(tiles), dim3(kTileThreads), (size_t)bins * 4, st, ix, pat, off, n, sh, coarse, ghist, codes);
     hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(kScanThreads), 0, st, ghist, bins);
     hipLaunchKernelGGL(k_order_scatter, dim3(tiles), dim3(kTileThreads), (size_t)bins * 4, st, coarse, n, sh, ghist, perm1);
     if (sh.total_bits > sh.coarse_bits) {
-        hipLaunchKernelGGL(k_order_tile_sort, dim3(tiles), dim3(kTileThreads), 0, st, ix, pat, off, n, sh, perm1, perm2);
+        hipLaunchKernelGGL(k_order_tile_sort, dim3(tiles), dim3(kTileThreads), 0, st, ix, codes, n, sh, perm1, perm2);
         *perm_out = perm2;
     } else {
         *perm_out = perm1;
     }
+    *codes_out = codes;
     return (int)hipGetLastError();
 }
 
-int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_t *off, const uint32_t *perm, int32_t n,
-                 int32_t *counts, int32_t *lf, int32_t *status, int32_t *range, hipStream_t st) {
+// `codes` = the plan's per-pattern code words for THIS index's alphabet (nullptr: characters are mapped in the kernel)
+int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_t *off, const uint32_t *perm,
+                 const void *codes, int32_t n, int32_t *counts, int32_t *lf, int32_t *status, int32_t *range,
+                 hipStream_t st) {
     if (n <= 0) return 0;
-    FMX_DISPATCH(k_count, 2 * (int64_t)n, ix, pat, off, perm, n, counts, lf, status, range, (perm && g_xcd_remap) ? 1 : 0);
+    FMX_DISPATCH(k_count, 2 * (int64_t)n, ix, pat, off, perm, n, counts, lf, status, range, (perm && g_xcd_remap) ? 1 : 0,
+                 perm ? static_cast<const uint64_t *>(codes) : nullptr);
     return (int)hipGetLastError();
 }
 

@@ -425,3 +425,35 @@ def test_segment_set_count_and_locate_vs_oracle_and_brute_force():
             assert (locs[i, found[i]:] == -1).all()
             for x in exp:
                 assert (t16[x:x + len(p)] == p).all()
+
+
+@pytest.mark.parametrize("sigma", [40, 255, 256, 700])
+def test_planned_batches_vs_oracle_across_alphabet_sizes(sigma):
+    """batches large enough to take the planned path (suffix order + per-pattern code words, 8 codes of 8 bits
+    or 4 of 16 bits by alphabet size), with patterns shorter and longer than the planned codes, absent
+    characters and empty patterns — counts, statuses and located hits against the oracle"""
+    rnd = random.Random(sigma)
+    n = 150_000
+    arr = np.array([rnd.randrange(1, sigma) if rnd.random() < 0.9 else 10 for _ in range(n)], dtype=np.uint16) + 32
+    fm = ia.FmIndex(arr, 16, True, device=0)
+    o = orc.OracleFmIndex(arr, 16, True)
+    assert fm.getAlphabetLength() == o.getAlphabetLength()
+    N = 20_000  # > sort_min
+    pats = []
+    for i in range(N):
+        s = rnd.randrange(n - 16)
+        p = arr[s:s + rnd.randrange(1, 15)].copy()
+        if i % 11 == 0:
+            p[rnd.randrange(len(p))] = 7  # a character the text does not have
+        if i % 13 == 0:
+            p[0] = arr[rnd.randrange(n)]  # mostly zero matches
+        pats.append(p)
+    ch, off = ia.pack_patterns(pats)
+    off = np.concatenate([off, [off[-1]]]).astype(np.int32)  # + an EMPTY pattern
+    cnt, st, lf = fm.count_batch(ch, off, want_steps=True)
+    oc, ost = o.count_batch(ch, off, threads=8)
+    assert (st == ost).all() and (cnt == oc).all() and st[-1] == 9
+    locs, found, st2 = fm.locate_batch(ch, off, 4)
+    for i in range(0, N, 37):
+        k, l = o.locate(pats[i], max_matches=4, cap=4)
+        assert found[i] == k and (locs[i, :k] == l).all(), i
