@@ -62,41 +62,40 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix, const uint16_t *__restrict__ pat,
     }
     for (int32_t q = block * (kBlock / 2) + (int32_t)(threadIdx.x >> 1); q < n; q += pairs_per_grid) {
         const int32_t p = perm ? (int32_t)perm[q] : q;
-        const int32_t beg = pat_off[p];
-        const int32_t m = pat_off[p + 1] - beg;
+        const int32_t m = pat_off[p + 1] - pat_off[p];
         int status = ST_OK;
-        int32_t start = 0, end = 0, steps = 0;
+        int32_t start = 0, end = 0;
+        int32_t back = 0;  // characters consumed so far, counted from the pattern's end (FM:456: i = m - 1 - back)
         if (m <= 0) {
             status = ST_JAVA_AIOOBE;  // pattern[-1], FM:456-457
         } else {
-            int32_t i = m - 1;
             // the plan stage left the codes of the trailing characters (one 8-byte load per pattern instead of a
             // character load and a map lookup in front of every rank)
             const uint64_t cw = codes ? codes[p] : 0ull;
-            int32_t c = codes ? (int32_t)((uint32_t)cw & code_mask) : fm_map(ix, pat[beg + i]);
+            int32_t c = codes ? (int32_t)((uint32_t)cw & code_mask) : fm_map(ix, pat[pat_off[p] + m - 1]);
             if (c != 0) {  // FM:458-460
                 start = ix.C[c];
                 end = ix.C[c + 1];
-                while (start < end && i >= 1) {  // FM:464
-                    --i;
-                    const int32_t back = m - 1 - i;  // characters consumed before this one
+                while (start < end && back + 1 < m) {  // FM:464
+                    ++back;
                     if (back < n_codes) {
                         c = (int32_t)((uint32_t)(cw >> (back * code_bits)) & code_mask);
                     } else {
-                        c = fm_map(ix, pat[beg + i]);
+                        c = fm_map(ix, pat[pat_off[p] + m - 1 - back]);
                     }
-                    if (c == 0) {  // FM:466-468
+                    if (c == 0) {  // FM:466-468: ends the search before this character's two ranks
                         start = end = 0;
+                        --back;
                         break;
                     }
                     const int32_t mine = ix.C[c] + wt_rank(ix, s_inv, (uint32_t)(role ? end : start), c, status);
                     const int32_t other = __shfl_xor(mine, 1);
                     start = role ? other : mine;  // FM:469
                     end = role ? mine : other;    // FM:470
-                    steps += 2;
                 }
             }
         }
+        const int32_t steps = 2 * back;  // LF-steps executed: two ranks per character after the first
         status |= __shfl_xor(status, 1);
         if (role == 0) {
             const int32_t d = end - start;
