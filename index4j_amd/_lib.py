@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfmx.so")
+# FMX_LIBRARY: alternative build of the same library (tuning experiments only, e.g. another WALK_WAVES)
+LIB_PATH = os.environ.get("FMX_LIBRARY") or os.path.join(_HERE, "libfmx.so")
 
 OK = 0
 E_ARG, E_ALPHABET, E_FORMAT, E_VERSION, E_NO_DEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7, -8

@@ -276,6 +276,21 @@ FMX_HD int32_t rrr_rank1(const uint8_t *base, const RrrView &d, const uint16_t *
     return (int32_t)(prefix + (uint32_t)fmx_popc(block & ((1u << t) - 1u)));  // RRR:393-395
 }
 
+// rankOnes(p) and access(p) from a record fetched ahead of time (see rrr_rank1_access)
+template <bool kCompact>
+FMX_HD int32_t rrr_rank1_access_record(const uint8_t *base, const RrrView &d, const uint16_t *inv, const RrrRecord &rec,
+                                       int32_t position, bool &bit) {
+    if (position >= d.length || position < 0) {
+        bit = false;
+        return position < 0 ? 0 : d.total_ones;
+    }
+    uint32_t prefix;
+    const uint32_t block = rrr_decode_record<kCompact>(base, d, inv, rec, (uint32_t)position, prefix);
+    const uint32_t t = (uint32_t)position % 15u;
+    bit = (block >> t) & 1u;
+    return (int32_t)(prefix + (uint32_t)fmx_popc(block & ((1u << t) - 1u)));
+}
+
 // RRR:314-349; out-of-range is reported through *status (IllegalArgumentException in the reference)
 template <bool kCompact>
 FMX_HD bool rrr_access(const uint8_t *base, const RrrView &d, const uint16_t *inv, int32_t position, int &status) {
@@ -587,11 +602,19 @@ FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t positio
 
 // WFBB:1305-1537: returns the symbol at `position` (< size); *rank = occurrences before it
 // (the reference packs (rank << 32) | symbol and returns the bare symbol when position == 0).
-FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t &rank_out) {
+FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t &rank_out,
+                                 int32_t &bsl_out) {
+    // load chain (see wt_rank): {superblock header, RRR view} -> block header -> {level table, first level's
+    // counts, first RRR record} -> offset bits -> ... -> leaf -> superblock rank of the symbol
     const uint32_t sb_id = position >> 20;
     const SbDesc &sd = ix.sbd[sb_id];
-    const SbHead sh = sb_head(sd);
+    Quad head_q = ld_quad(&sd), view_q = ld_quad(&sd.rrr);
+    FMX_PIN_QUAD(head_q);
+    FMX_PIN_QUAD(view_q);
+    const SbHead sh = sb_head_from(head_q);
+    const RrrView rv = rrr_view_from(view_q);
     const int32_t bsl = sh.bsl;
+    bsl_out = bsl;
     const uint32_t block_size = 1u << bsl;
     const uint32_t block_index = position & (block_size - 1);
     const uint32_t block_id = (position & 0xfffffu) >> bsl;
@@ -610,10 +633,20 @@ FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32
         return c;
     }
 
+    const uint32_t second0 = (uint32_t)((tree_height - 1) * 4 + ((int32_t)bh.sigma + 1) * 5);
+    int32_t rrr_position = bh.bv_offset + (int32_t)block_index;
+    Quad chunk = ld_quad(hdr);  // level entries 0..3 (guard bytes cover the tail)
+    uint32_t counts0 = ld16(hdr + second0);
+    Quad rec_q = {0, 0, 0, 0};
+    if (rrr_in_range(rv, rrr_position)) rec_q = ld_quad(rrr_record_ptr(ix.base, rv, (uint32_t)rrr_position));
+    FMX_PIN_QUAD(chunk);
+    FMX_OPAQUE32(counts0);
+    FMX_PIN_QUAD(rec_q);
+    RrrRecord rec = rrr_record_from(rec_q);
+
     const uint32_t cur_block_size = (ix.wt_size - (position - block_index)) < block_size
                                         ? (ix.wt_size - (position - block_index))
                                         : block_size;
-    const RrrView rv = rrr_view(sd.rrr);
     uint32_t code = 0;
     int32_t code_length = 0;
     TreeWalk t;
@@ -626,35 +659,45 @@ FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32
     t.depth_total_bv = t.node_bv_size;
     t.node_rank = (int32_t)block_index;
     t.hdr = hdr;
-    t.second = (uint32_t)((tree_height - 1) * 4 + ((int32_t)bh.sigma + 1) * 5);
+    t.second = second0;
     t.level = 0;
 
-    for (int32_t depth = 0;; ++depth) {  // WFBB:1386-1493
-        int32_t left_ones, node_ones, level_ones;
-        tree_level_counts(t, left_ones, node_ones, level_ones);
+    // WFBB:1386-1493; level 0's counts are the single u16 at `second`, the loads of level d+1 are requested at
+    // the end of level d
+    int32_t left_ones = 0, node_ones = (int32_t)counts0, level_ones = (int32_t)counts0;
+    FMX_NO_UNROLL
+    for (int32_t depth = 0;; ++depth) {
         bool next_bit;
-        int32_t rank1 = rrr_rank1_access<true>(ix.base, rv, inv, t.bv_offset + t.left_total_bv + t.node_rank, next_bit);
+        int32_t rank1 = rrr_rank1_access_record<true>(ix.base, rv, inv, rec, rrr_position, next_bit);
         rank1 -= t.bv_rank + left_ones;
         t.bv_rank += level_ones;
         code = (code << 1) | (next_bit ? 1u : 0u);
         ++code_length;
         tree_descend(t, next_bit, rank1, node_ones);
         if (depth + 1 < tree_height) {
-            const int32_t next_leaf_count = tree_next_level(t);
+            const uint32_t entry = depth < 4 ? quad_entry(chunk, depth) : ld32u(t.hdr + t.level);
+            const int32_t next_leaf_count = tree_next_level_entry(t, entry);
             if (t.left_siblings >= next_leaf_count)  // WFBB:1485-1489
                 t.left_siblings -= next_leaf_count;
             else
                 break;
+            uint32_t raw_pair, raw_level;
+            tree_level_counts_load(t, raw_pair, raw_level);
+            rrr_position = t.bv_offset + t.left_total_bv + t.node_rank;
+            if (rrr_in_range(rv, rrr_position)) rec_q = ld_quad(rrr_record_ptr(ix.base, rv, (uint32_t)rrr_position));
+            FMX_OPAQUE32(raw_pair);
+            FMX_OPAQUE32(raw_level);
+            FMX_PIN_QUAD(rec_q);
+            rec = rrr_record_from(rec_q);
+            tree_level_counts_decode(t, raw_pair, raw_level, left_ones, node_ones, level_ones);
         } else {
             break;
         }
     }
-    // WFBB:232-248 computeSymbolFromBlockHeader
+    // WFBB:232-248 computeSymbolFromBlockHeader (level entries 0..3 are already at hand)
     uint32_t block_c = 0, temp_code = 0;
-    const uint8_t *lp = hdr;
     for (int32_t i = 1; i < code_length; ++i) {
-        const uint32_t level_leaf_count = ld16(lp);
-        lp += 4;
+        const uint32_t level_leaf_count = (i <= 4 ? quad_entry(chunk, i - 1) : ld32u(hdr + 4 * (i - 1))) & 0xffffu;
         temp_code += level_leaf_count;
         block_c += level_leaf_count;
         temp_code <<= 1;
@@ -664,6 +707,11 @@ FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32
     const int32_t c = (int32_t)(leaf & 0xffffu);                                        // WFBB:1501-1506
     rank_out = row[c].rank + (int32_t)((leaf >> 16) & 0xffffffu) + t.node_rank;        // WFBB:1521-1533
     return c;
+}
+
+FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t &rank_out) {
+    int32_t bsl;
+    return wt_inverse_select(ix, inv, position, rank_out, bsl);
 }
 
 // true when inverseSelect's symbol at `position` is the block's real symbol (false only for a run block
@@ -694,9 +742,10 @@ FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, 
                           bool &suspect) {
     const uint32_t p = (uint32_t)(row - 1);
     int32_t rank_before;
-    const int32_t c = (int32_t)(int16_t)wt_inverse_select(ix, inv, p, rank_before);
+    int32_t bsl_i;
+    const int32_t c = (int32_t)(int16_t)wt_inverse_select(ix, inv, p, rank_before, bsl_i);
     c_out = c;
-    const uint32_t bsl = (uint32_t)(int32_t)ix.sbd[p >> 20].bsl;
+    const uint32_t bsl = (uint32_t)bsl_i;
     const bool same_block = ((uint32_t)row & ((1u << bsl) - 1u)) != 0 && (uint32_t)row <= ix.wt_size;
     // a run block whose symbol is >= 256 reports a masked symbol: rank(row, masked c) must really be evaluated
     const bool exact_symbol = ix.wt_sigma <= 256 || wt_symbol_is_exact(ix, p, c);

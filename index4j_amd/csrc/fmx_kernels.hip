@@ -22,6 +22,26 @@ namespace fmx {
 // FMX_WAVES_PER_EU asks the register allocator for 8 waves per SIMD (<= 64 VGPRs, <= 80 SGPRs): the
 // kernels are latency-bound chains of dependent loads, so resident waves are what hides latency.
 #define FMX_KERNEL(BLOCK) __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
+// The LF-walk kernels (locate / extract / extractUntilBoundary) carry more state per lane; FMX_WALK_WAVES is the
+// occupancy their register budget is sized for (512 / FMX_WALK_WAVES VGPRs per lane).
+#ifndef FMX_WALK_WAVES
+#define FMX_WALK_WAVES 8
+#endif
+#define FMX_WALK_KERNEL(BLOCK) \
+    __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FMX_WALK_WAVES, 8)))
+// k_extract: 49.8 ms at a budget for 8 waves, 47.7 ms at 6 (locate -> extract pipeline, tools/bench_pipeline.py)
+#ifndef FMX_EXTRACT_WAVES
+#define FMX_EXTRACT_WAVES 6
+#endif
+#define FMX_EXTRACT_KERNEL(BLOCK) \
+    __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FMX_EXTRACT_WAVES, 8)))
+// extractUntilBoundary keeps two text windows, the replay state and a walk alive: measured 4.74 / 4.42 / 3.56 ms
+// (configs[3]) at budgets for 8 / 6 / 4 waves per SIMD — spilling costs more than the lost occupancy
+#ifndef FMX_BOUNDARY_WAVES
+#define FMX_BOUNDARY_WAVES 4
+#endif
+#define FMX_BOUNDARY_KERNEL(BLOCK) \
+    __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FMX_BOUNDARY_WAVES, 8)))
 
 __device__ __forceinline__ void stage_inverse_table(uint16_t *s_inv, const uint16_t *g_inv) {
     const uint4 *src = reinterpret_cast<const uint4 *>(g_inv);
@@ -112,7 +132,7 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix, const uint16_t *__restrict__ pat,
 
 // FM:526-548: hit k of pattern p is SA row i = start + 1 + k; walk LF until a sampled row.
 template <int kBlock>
-FMX_KERNEL(kBlock) void k_locate_walk(DevIndex ix, const int32_t *__restrict__ range, int32_t n,
+FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix, const int32_t *__restrict__ range, int32_t n,
                                                         int32_t max_matches, int32_t *__restrict__ locs,
                                                         int32_t loc_cap, int32_t slots, int32_t *__restrict__ found,
                                                         int32_t *__restrict__ lf_steps,
@@ -153,7 +173,7 @@ FMX_KERNEL(kBlock) void k_locate_walk(DevIndex ix, const int32_t *__restrict__ r
 // runs only if that hit exists; with stops == nullptr the stop position is min(inputLength, start + fixed_len)
 // (the reference's locateAndExtractBenchmark, FmIndexThroughputBenchmark.java:231-249).
 template <int kBlock>
-FMX_KERNEL(kBlock) void k_extract(DevIndex ix, const int32_t *__restrict__ starts, const int32_t *__restrict__ stops,
+FMX_EXTRACT_KERNEL(kBlock) void k_extract(DevIndex ix, const int32_t *__restrict__ starts, const int32_t *__restrict__ stops,
                                   int64_t n, uint16_t *__restrict__ dst, int32_t dst_len, int32_t offset,
                                   int32_t *__restrict__ out_len, int32_t *__restrict__ lf_steps,
                                   int32_t *__restrict__ status_out, const int32_t *__restrict__ slot_found,
@@ -184,7 +204,7 @@ FMX_KERNEL(kBlock) void k_extract(DevIndex ix, const int32_t *__restrict__ start
 // sample_rate codes per lane of the grid (element j of lane t at scratch[j * lanes + t]) for the
 // interval-buffered right walk (fm_boundary_right_blocks); without it the literal form runs.
 template <int kBlock>
-FMX_KERNEL(kBlock) void k_extract_boundary(DevIndex ix, const int32_t *__restrict__ froms, int64_t n, uint16_t boundary,
+FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary(DevIndex ix, const int32_t *__restrict__ froms, int64_t n, uint16_t boundary,
                                            int mode, uint16_t *__restrict__ dst, int32_t dst_len, int32_t offset,
                                            int32_t *__restrict__ out_len, int32_t *__restrict__ lf_steps,
                                            int32_t *__restrict__ status_out, int32_t *__restrict__ aux_out,
@@ -212,7 +232,7 @@ FMX_KERNEL(kBlock) void k_extract_boundary(DevIndex ix, const int32_t *__restric
 // Group-cooperative extractUntilBoundary: G lanes per query (fm_extract_boundary_group); the window of a group
 // is G consecutive lane columns of `scratch` (left window in the first half, right window in the second).
 template <int kBlock, int G>
-FMX_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix, const int32_t *__restrict__ froms, int64_t n,
+FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix, const int32_t *__restrict__ froms, int64_t n,
                                                  uint16_t boundary, int mode, uint16_t *__restrict__ dst,
                                                  int32_t dst_len, int32_t offset, int32_t *__restrict__ out_len,
                                                  int32_t *__restrict__ lf_steps, int32_t *__restrict__ status_out,
