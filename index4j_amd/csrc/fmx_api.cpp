@@ -3,6 +3,7 @@
 // There is no CPU query path: without a HIP device every batch call fails with FMX_E_NO_DEVICE.
 #include "../../include/fmx.h"
 #include "fmx_device.hpp"
+#include "fmx_build_stage.hpp"
 #include "fmx_model.hpp"
 
 #include <hip/hip_runtime.h>
@@ -228,6 +229,25 @@ int fmx_build(const uint16_t *text, int32_t n, int32_t sample_rate, int enable_e
     int rc = fmx::build_model(text, n, sample_rate, enable_extract != 0, idx->model, err);
     if (rc == -2) return fail(FMX_E_ALPHABET, err);
     if (rc) return fail(FMX_E_ARG, err);
+    idx->has_model = true;
+    *out = idx.release();
+    return FMX_OK;
+}
+
+int fmx_build_on_device(const uint16_t *text, int32_t n, int32_t sample_rate, int enable_extract, int device,
+                        fmx_index **out, int32_t *rounds, int64_t *rows_sorted, double *stage_seconds) {
+    if (!out || (!text && n > 0) || device < 0) return fail(FMX_E_ARG, "bad arguments");
+    std::unique_ptr<fmx_index> idx(new fmx_index());
+    std::string err;
+    fmx::SaStageStats stats;
+    int rc = fmx::build_model(text, n, sample_rate, enable_extract != 0, idx->model, err, device, &stats);
+    if (rc == -2) return fail(FMX_E_ALPHABET, err);
+    if (rc == -5) return fail(FMX_E_NO_DEVICE, err);
+    if (rc == -6) return fail(FMX_E_HIP, err);
+    if (rc) return fail(FMX_E_ARG, err);
+    if (rounds) *rounds = stats.rounds;
+    if (rows_sorted) *rows_sorted = (int64_t)stats.rows_sorted;
+    if (stage_seconds) *stage_seconds = stats.seconds;
     idx->has_model = true;
     *out = idx.release();
     return FMX_OK;

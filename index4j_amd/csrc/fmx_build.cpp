@@ -10,6 +10,7 @@
 //
 // Citations as in fmx_model.hpp.
 #include "fmx_model.hpp"
+#include "fmx_build_stage.hpp"
 #include "fmx_sais.hpp"
 
 #include <algorithm>
@@ -577,8 +578,27 @@ void build_wavelet(const int16_t *bwt, int64_t n, int sampling_rate, WfbbModel &
 // ---------------------------------------------------------------------------------------------
 // FmIndex constructor (FM:155-174)
 // ---------------------------------------------------------------------------------------------
+int host_sa_stage(const int16_t *seq, int32_t n, int alphabet, int sample_rate, bool extract, SaStage &out) {
+    std::vector<int32_t> sa((size_t)n);
+    suffix_array(seq, n, alphabet, sa.data());
+    out.which.assign((size_t)(n / 64 + 2), 0);
+    out.suffix_vals.clear();
+    out.suffix_vals.reserve((size_t)n / (size_t)sample_rate + 2);
+    out.position_vals.clear();
+    if (extract) out.position_vals.assign((size_t)n / (size_t)sample_rate + 2, 0);
+    for (int32_t i = 0; i < n; ++i)  // FM:341-366
+        if (sa[(size_t)i] % sample_rate == 0) {
+            out.suffix_vals.push_back((uint32_t)sa[(size_t)i]);
+            out.which[(size_t)(i >> 6)] |= 1ULL << (i & 63);
+            if (extract) out.position_vals[(size_t)(sa[(size_t)i] / sample_rate)] = (uint32_t)i;
+        }
+    out.bwt.resize((size_t)n);  // FM:385-392
+    for (int32_t i = 0; i < n; ++i) out.bwt[(size_t)i] = sa[(size_t)i] == 0 ? seq[(size_t)n - 1] : seq[(size_t)sa[(size_t)i] - 1];
+    return 0;
+}
+
 int build_model(const uint16_t *input, int32_t n_in, int32_t sample_rate, bool enable_extract, FmModel &m,
-                std::string &err) {
+                std::string &err, int build_device, SaStageStats *stats) {
     if (n_in < 0 || sample_rate <= 0 || n_in == INT32_MAX) {
         err = "bad arguments";
         return -1;
@@ -634,32 +654,24 @@ int build_model(const uint16_t *input, int32_t n_in, int32_t sample_rate, bool e
     m.C.assign(cc.begin(), cc.begin() + n_look);
     m.C.push_back(m.length);
 
-    // FM:329-372
-    std::vector<int32_t> sa((size_t)n);
-    suffix_array(seq.data(), n, n_look + 1, sa.data());
+    // FM:329-394: suffix array -> sampled rows, inverse samples, BWT (on the host, or in HBM)
+    SaStage st;
+    int rc = build_device >= 0 ? device_sa_stage(seq.data(), n, sample_rate, enable_extract, build_device, st, stats, err)
+                               : host_sa_stage(seq.data(), n, n_look + 1, sample_rate, enable_extract, st);
+    if (rc) return rc;
+    std::vector<int16_t>().swap(seq);
     m.bw_suffixes = min_bits((uint64_t)n);
     m.suffixes.init(n / sample_rate + 1, m.bw_suffixes);
-    std::vector<uint64_t> which((size_t)(n / 64 + 2), 0);
-    int32_t k = 0;
-    for (int32_t i = 0; i < n; ++i)
-        if (sa[(size_t)i] % sample_rate == 0) {
-            m.suffixes.set(k++, (uint64_t)sa[(size_t)i]);
-            which[(size_t)(i >> 6)] |= 1ULL << (i & 63);
-        }
-    build_rrr(which.data(), n, sample_rate, m.sampled);
-    std::vector<uint64_t>().swap(which);
+    for (size_t k = 0; k < st.suffix_vals.size(); ++k) m.suffixes.set((int64_t)k, st.suffix_vals[k]);
+    build_rrr(st.which.data(), n, sample_rate, m.sampled);
     if (enable_extract) {
         m.bw_positions = m.bw_suffixes;
         m.positions.init(n / sample_rate + 2, m.bw_positions);
-        for (int32_t i = 0; i < n; ++i)
-            if (sa[(size_t)i] % sample_rate == 0) m.positions.set(sa[(size_t)i] / sample_rate, (uint64_t)i);
+        const int64_t n_pos = (int64_t)(n - 1) / sample_rate + 1;  // slots 0 .. (n-1)/s hold samples
+        for (int64_t k = 0; k < n_pos; ++k) m.positions.set(k, st.position_vals[(size_t)k]);
         m.positions.set((n - 1) / sample_rate + 1, m.positions.get(0));  // FM:367-369
     }
-    // FM:374-394
-    std::vector<int16_t> bwt((size_t)n);
-    for (int32_t i = 0; i < n; ++i) bwt[(size_t)i] = sa[(size_t)i] == 0 ? seq[(size_t)n - 1] : seq[(size_t)sa[(size_t)i] - 1];
-    std::vector<int32_t>().swap(sa);
-    std::vector<int16_t>().swap(seq);
+    std::vector<int16_t> &bwt = st.bwt;
     build_wavelet(bwt.data(), n, sample_rate, m.wt);  // FM:173
     return 0;
 }

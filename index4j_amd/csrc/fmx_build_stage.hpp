@@ -1,0 +1,30 @@
+// The middle stage of index construction (FM:329-394): everything FmIndex derives from the suffix array of
+// the mapped text.  Two interchangeable producers: the host's SA-IS (fmx_build.cpp) and the device's prefix
+// doubling (fmx_sa_gpu.hip).  The suffix array is unique, so both give the same arrays.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace fmx {
+
+struct SaStage {
+    std::vector<int16_t> bwt;             // FM:385-392
+    std::vector<uint64_t> which;          // bit i = row i is sampled (SA[i] % sampleRate == 0), n/64 + 2 words
+    std::vector<uint32_t> suffix_vals;    // SA[i] of the sampled rows, in row order (FM:341-352)
+    std::vector<uint32_t> position_vals;  // [SA[i] / sampleRate] = i for sampled rows (FM:356-366); n/s + 2 slots
+};
+
+struct SaStageStats {
+    int rounds = 0;            // doubling rounds after the initial 4-character sort
+    uint64_t rows_sorted = 0;  // rows that went through a device sort, summed over rounds
+    double seconds = 0;        // wall time of the stage incl. the transfers to and from HBM
+};
+
+// seq: mapped text incl. the terminator (code 0 at n-1 only); returns 0 or a negative fmx error code
+int host_sa_stage(const int16_t *seq, int32_t n, int alphabet, int sample_rate, bool extract, SaStage &out);
+int device_sa_stage(const int16_t *seq, int32_t n, int sample_rate, bool extract, int device, SaStage &out,
+                    SaStageStats *stats, std::string &err);
+
+}  // namespace fmx

@@ -109,8 +109,10 @@ struct FmModel {
 };
 
 // fmx_build.cpp
+// build_device >= 0: the suffix-array stage (FM:329-394) runs on that GPU (fmx_sa_gpu.hip), else on the host
+struct SaStageStats;
 int build_model(const uint16_t *text, int32_t n, int32_t sample_rate, bool enable_extract, FmModel &out,
-                std::string &err);
+                std::string &err, int build_device = -1, SaStageStats *stats = nullptr);
 void build_wavelet(const int16_t *bwt, int64_t n, int sampling_rate, WfbbModel &w);
 void build_rrr(const uint64_t *bits, int64_t nbits, int sample_size, RrrModel &r);
 const uint16_t *rrr_offset_of_value();  // 32768 entries

@@ -1,0 +1,283 @@
+// Index construction, device stage: suffix array of the mapped text by prefix doubling, then the arrays
+// FmIndex derives from it (FM:329-394) — BWT, the sampled-row bitmap, the sampled suffix values in row order
+// and the inverse samples — all computed in HBM; only those results travel back to the host, where the
+// wavelet tree is encoded (fmx_build.cpp).
+//
+// The suffix array of a text with a unique smallest terminator is unique, so this stage and the host's SA-IS
+// (fmx_sais.hpp) produce the same arrays and the resulting index is byte-identical (tests/test_gpu_parity.py).
+//
+// Prefix doubling (Manber-Myers / Larsson-Sadakane, in the sort-based form that suits a GPU):
+//   round 0 : sort suffixes by their first 4 codes (one 64-bit key), rank = index of the group's first row
+//   round k : key = (rank[i], rank[i+h]) packed in 2*ceil(log2(L+1)) bits, h = 4, 8, 16, ...; only rows of
+//             groups that are still tied take part (the rest of SA is final and stays in place)
+//   until every group is a single row.
+// Device-wide sort / scan / select come from rocPRIM; the kernels here build keys, mark group heads and
+// scatter ranks — streaming passes over 4- and 8-byte arrays, HBM-bound.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+
+#include "fmx_build_stage.hpp"
+
+namespace fmx {
+namespace {
+
+constexpr int kThreads = 256;
+inline unsigned grid_of(int64_t n) { return (unsigned)((n + kThreads - 1) / kThreads); }
+
+#define SA_TRY(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            err = std::string(#expr) + ": " + hipGetErrorString(e_);                         \
+            return -6;                                                                       \
+        }                                                                                    \
+    } while (0)
+
+struct DevMem {
+    std::vector<void *> ptrs;
+    ~DevMem() {
+        for (void *p : ptrs) (void)hipFree(p);
+    }
+    template <class T>
+    hipError_t alloc(T **out, size_t count) {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(p);
+        *out = static_cast<T *>(p);
+        return e;
+    }
+};
+
+// round 0: the first four codes of every suffix as one key (codes are < 2^15; past the end = 0, which only the
+// terminator carries, so keys that reach the end are unique anyway)
+__global__ void k_sa_first_keys(const int16_t *__restrict__ seq, uint32_t L, uint64_t *__restrict__ keys,
+                                uint32_t *__restrict__ sa) {
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= L) return;
+    uint64_t k = 0;
+    for (uint32_t j = 0; j < 4; ++j) k = (k << 16) | (i + j < L ? (uint64_t)(uint16_t)seq[i + j] : 0ull);
+    keys[i] = k;
+    sa[i] = i;
+}
+
+// head[j] = j if row j starts a new group of equal keys, else 0 (an inclusive max-scan turns this into the
+// index of the group's first row); `row_of` maps a slot of the compacted active list to its SA row (nullptr:
+// identity).  A group boundary also lies wherever two neighbouring slots are not neighbouring rows.
+__global__ void k_sa_mark_heads(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ row_of, uint32_t n,
+                                uint32_t *__restrict__ head) {
+    const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t row = row_of ? row_of[j] : j;
+    bool first = j == 0 || keys[j] != keys[j - 1];
+    if (!first && row_of) first = row_of[j - 1] + 1 != row;
+    head[j] = first ? row : 0u;
+}
+
+// after the scan: rank of suffix sa[j] = first row of its group; rows whose group has a single member are final
+__global__ void k_sa_assign_ranks(const uint32_t *__restrict__ sa_sorted, const uint32_t *__restrict__ row_of,
+                                  const uint32_t *__restrict__ head, uint32_t n, uint32_t *__restrict__ rank,
+                                  uint32_t *__restrict__ sa_full) {
+    const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t row = row_of ? row_of[j] : j;
+    const uint32_t suffix = sa_sorted[j];
+    rank[suffix] = head[j];
+    if (row_of) sa_full[row] = suffix;  // the sorted active rows go back into their places
+}
+
+// a row is still tied if its group (rows with the same rank) has another member: look at both neighbours
+__global__ void k_sa_mark_active(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ rank, uint32_t L,
+                                 uint8_t *__restrict__ active) {
+    const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
+    if (j >= L) return;
+    const uint32_t r = rank[sa[j]];
+    const bool tied = (j > 0 && rank[sa[j - 1]] == r) || (j + 1 < L && rank[sa[j + 1]] == r);
+    active[j] = tied ? 1 : 0;
+}
+
+// key of an active row for the next round: (rank[i], rank[i + h] + 1 or 0 past the end), packed
+__global__ void k_sa_next_keys(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ row_of,
+                               const uint32_t *__restrict__ rank, uint32_t n, uint32_t L, uint32_t h, int low_bits,
+                               uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t suffix = sa[row_of[j]];
+    const uint64_t second = (uint64_t)suffix + h < L ? (uint64_t)rank[suffix + h] + 1ull : 0ull;
+    keys[j] = ((uint64_t)rank[suffix] << low_bits) | second;
+    vals[j] = suffix;
+}
+
+// FM:341-372 + FM:385-392 from the finished suffix array.  `which` gets one 64-bit word per wave through a
+// ballot (bit j&63 of word j>>6 = row j is sampled), `flag` feeds the scan that numbers the sampled rows.
+__global__ void k_sa_outputs(const uint32_t *__restrict__ sa, const int16_t *__restrict__ seq, uint32_t L,
+                             uint32_t sample_rate, int16_t *__restrict__ bwt, uint64_t *__restrict__ which,
+                             uint32_t *__restrict__ flag, uint32_t *__restrict__ position_vals) {
+    const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
+    const bool in = j < L;
+    const uint32_t s = in ? sa[j] : 1u;
+    const bool sampled = in && (s % sample_rate == 0);
+    const uint64_t word = __ballot(sampled);
+    if (in) {
+        bwt[j] = s == 0 ? seq[L - 1] : seq[s - 1];
+        flag[j] = sampled ? 1u : 0u;
+        if ((j & 63u) == 0) which[j >> 6] = word;
+        if (sampled && position_vals) position_vals[s / sample_rate] = j;
+    }
+}
+__global__ void k_sa_compact_samples(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ flag,
+                                     const uint32_t *__restrict__ slot, uint32_t L, uint32_t *__restrict__ suffix_vals) {
+    const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
+    if (j < L && flag[j]) suffix_vals[slot[j] - 1] = sa[j];
+}
+
+int ceil_log2(uint64_t v) {
+    int b = 0;
+    while ((1ull << b) < v) ++b;
+    return b;
+}
+
+}  // namespace
+
+int device_sa_stage(const int16_t *seq, int32_t n, int sample_rate, bool extract, int device, SaStage &out,
+                    SaStageStats *stats, std::string &err) {
+    if (n <= 0 || sample_rate <= 0) {
+        err = "bad arguments";
+        return -1;
+    }
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
+        err = "no HIP device visible";
+        return -5;
+    }
+    if (device < 0 || device >= n_dev) {
+        err = "device ordinal out of range";
+        return -1;
+    }
+    SA_TRY(hipSetDevice(device));
+    const auto t_begin = std::chrono::steady_clock::now();
+    const uint32_t L = (uint32_t)n;
+    DevMem mem;
+    int16_t *d_seq = nullptr;
+    uint64_t *d_keys = nullptr, *d_keys_alt = nullptr;
+    uint32_t *d_sa = nullptr, *d_vals = nullptr, *d_vals_alt = nullptr, *d_rank = nullptr, *d_head = nullptr,
+             *d_rows = nullptr, *d_count = nullptr;
+    uint8_t *d_active = nullptr;
+    SA_TRY(mem.alloc(&d_seq, (size_t)L));
+    SA_TRY(mem.alloc(&d_keys, (size_t)L));
+    SA_TRY(mem.alloc(&d_keys_alt, (size_t)L));
+    SA_TRY(mem.alloc(&d_sa, (size_t)L));
+    SA_TRY(mem.alloc(&d_vals, (size_t)L));
+    SA_TRY(mem.alloc(&d_vals_alt, (size_t)L));
+    SA_TRY(mem.alloc(&d_rank, (size_t)L));
+    SA_TRY(mem.alloc(&d_head, (size_t)L));
+    SA_TRY(mem.alloc(&d_rows, (size_t)L));
+    SA_TRY(mem.alloc(&d_active, (size_t)L));
+    SA_TRY(mem.alloc(&d_count, 1));
+    SA_TRY(hipMemcpy(d_seq, seq, (size_t)L * 2, hipMemcpyHostToDevice));
+
+    // one temporary buffer for all rocPRIM calls (sizes queried for the full length)
+    const int low_bits = ceil_log2((uint64_t)L + 1), high_bits = ceil_log2((uint64_t)L);
+    size_t tmp_sort = 0, tmp_scan = 0, tmp_select = 0;
+    SA_TRY(rocprim::radix_sort_pairs(nullptr, tmp_sort, d_keys, d_keys_alt, d_vals, d_vals_alt, (size_t)L, 0u, 64u));
+    SA_TRY(rocprim::inclusive_scan(nullptr, tmp_scan, d_head, d_head, (size_t)L, rocprim::maximum<uint32_t>()));
+    SA_TRY(rocprim::select(nullptr, tmp_select, rocprim::counting_iterator<uint32_t>(0), d_active, d_rows, d_count,
+                           (size_t)L));
+    size_t tmp_bytes = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
+    if (tmp_select > tmp_bytes) tmp_bytes = tmp_select;
+    uint8_t *d_tmp = nullptr;
+    SA_TRY(mem.alloc(&d_tmp, tmp_bytes));
+
+    // round 0
+    hipLaunchKernelGGL(k_sa_first_keys, dim3(grid_of(L)), dim3(kThreads), 0, 0, d_seq, L, d_keys, d_vals);
+    size_t bytes = tmp_bytes;
+    SA_TRY(rocprim::radix_sort_pairs(d_tmp, bytes, d_keys, d_keys_alt, d_vals, d_sa, (size_t)L, 0u, 64u));
+    hipLaunchKernelGGL(k_sa_mark_heads, dim3(grid_of(L)), dim3(kThreads), 0, 0, d_keys_alt, (const uint32_t *)nullptr, L,
+                       d_head);
+    bytes = tmp_bytes;
+    SA_TRY(rocprim::inclusive_scan(d_tmp, bytes, d_head, d_head, (size_t)L, rocprim::maximum<uint32_t>()));
+    hipLaunchKernelGGL(k_sa_assign_ranks, dim3(grid_of(L)), dim3(kThreads), 0, 0, d_sa, (const uint32_t *)nullptr, d_head,
+                       L, d_rank, d_sa);
+
+    int rounds = 0;
+    uint64_t sorted_rows = L;
+    for (uint64_t h = 4; h < (uint64_t)L * 2; h <<= 1) {
+        // rows still tied
+        hipLaunchKernelGGL(k_sa_mark_active, dim3(grid_of(L)), dim3(kThreads), 0, 0, d_sa, d_rank, L, d_active);
+        bytes = tmp_bytes;
+        SA_TRY(rocprim::select(d_tmp, bytes, rocprim::counting_iterator<uint32_t>(0), d_active, d_rows, d_count,
+                               (size_t)L));
+        uint32_t n_active = 0;
+        SA_TRY(hipMemcpy(&n_active, d_count, 4, hipMemcpyDeviceToHost));
+        if (n_active == 0) break;
+        ++rounds;
+        sorted_rows += n_active;
+        const uint32_t hh = (uint32_t)(h < L ? h : L);
+        hipLaunchKernelGGL(k_sa_next_keys, dim3(grid_of(n_active)), dim3(kThreads), 0, 0, d_sa, d_rows, d_rank, n_active, L,
+                           hh, low_bits, d_keys, d_vals);
+        bytes = tmp_bytes;
+        SA_TRY(rocprim::radix_sort_pairs(d_tmp, bytes, d_keys, d_keys_alt, d_vals, d_vals_alt, (size_t)n_active, 0u,
+                                         (unsigned)(low_bits + high_bits)));
+        hipLaunchKernelGGL(k_sa_mark_heads, dim3(grid_of(n_active)), dim3(kThreads), 0, 0, d_keys_alt, d_rows, n_active,
+                           d_head);
+        bytes = tmp_bytes;
+        SA_TRY(rocprim::inclusive_scan(d_tmp, bytes, d_head, d_head, (size_t)n_active, rocprim::maximum<uint32_t>()));
+        hipLaunchKernelGGL(k_sa_assign_ranks, dim3(grid_of(n_active)), dim3(kThreads), 0, 0, d_vals_alt, d_rows, d_head,
+                           n_active, d_rank, d_sa);
+    }
+    SA_TRY(hipGetLastError());
+
+    // FM:329-394 from the suffix array
+    const size_t n_words = (size_t)L / 64 + 2;
+    const size_t n_samples = (size_t)L / (size_t)sample_rate + 2;
+    int16_t *d_bwt = nullptr;
+    uint64_t *d_which = nullptr;
+    uint32_t *d_suffix_vals = nullptr, *d_position_vals = nullptr;
+    SA_TRY(mem.alloc(&d_bwt, (size_t)L));
+    SA_TRY(mem.alloc(&d_which, n_words));
+    SA_TRY(mem.alloc(&d_suffix_vals, n_samples));
+    SA_TRY(hipMemset(d_which, 0, n_words * 8));
+    if (extract) {
+        SA_TRY(mem.alloc(&d_position_vals, n_samples));
+        SA_TRY(hipMemset(d_position_vals, 0, n_samples * 4));
+    }
+    uint32_t *d_flag = d_head, *d_slot = d_rows;  // reuse
+    hipLaunchKernelGGL(k_sa_outputs, dim3(grid_of(((int64_t)L + 63) / 64 * 64)), dim3(kThreads), 0, 0, d_sa, d_seq, L,
+                       (uint32_t)sample_rate, d_bwt, d_which, d_flag, d_position_vals);
+    bytes = tmp_bytes;
+    SA_TRY(rocprim::inclusive_scan(d_tmp, bytes, d_flag, d_slot, (size_t)L, rocprim::plus<uint32_t>()));
+    hipLaunchKernelGGL(k_sa_compact_samples, dim3(grid_of(L)), dim3(kThreads), 0, 0, d_sa, d_flag, d_slot, L,
+                       d_suffix_vals);
+    SA_TRY(hipGetLastError());
+    uint32_t n_sampled = 0;
+    SA_TRY(hipMemcpy(&n_sampled, d_slot + (L - 1), 4, hipMemcpyDeviceToHost));
+
+    out.bwt.resize((size_t)L);
+    out.which.assign(n_words, 0);
+    out.suffix_vals.resize(n_sampled);
+    SA_TRY(hipMemcpy(out.bwt.data(), d_bwt, (size_t)L * 2, hipMemcpyDeviceToHost));
+    SA_TRY(hipMemcpy(out.which.data(), d_which, n_words * 8, hipMemcpyDeviceToHost));
+    if (n_sampled) SA_TRY(hipMemcpy(out.suffix_vals.data(), d_suffix_vals, (size_t)n_sampled * 4, hipMemcpyDeviceToHost));
+    out.position_vals.clear();
+    if (extract) {
+        out.position_vals.resize(n_samples);
+        SA_TRY(hipMemcpy(out.position_vals.data(), d_position_vals, n_samples * 4, hipMemcpyDeviceToHost));
+    }
+    if (stats) {
+        stats->rounds = rounds;
+        stats->rows_sorted = sorted_rows;
+        stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    }
+    return 0;
+}
+
+}  // namespace fmx

@@ -59,6 +59,12 @@ class FmIndexBuilder:
     def __init__(self):
         self._sample_rate = 32
         self._enable_extraction = True
+        self._build_device = None
+
+    def setBuildDevice(self, device):
+        """extension: run the suffix-array stage of the constructor on this GPU (same index, byte for byte)"""
+        self._build_device = device
+        return self
 
     def setSampleRate(self, sample_rate):  # FMB:34-37
         self._sample_rate = int(sample_rate)
@@ -69,21 +75,30 @@ class FmIndexBuilder:
         return self
 
     def build(self, text, device=0):  # FMB:59-61
-        return FmIndex(text, self._sample_rate, self._enable_extraction, device=device)
+        return FmIndex(text, self._sample_rate, self._enable_extraction, device=device, build_device=self._build_device)
 
 
 class FmIndex:
     """fm/FmIndex.java query surface.  `device=None` keeps the index on the host (build / save /
     load only); any query then fails loudly."""
 
-    def __init__(self, text=None, sampleRate=32, enableExtract=True, device=0, _handle=None):
+    def __init__(self, text=None, sampleRate=32, enableExtract=True, device=0, _handle=None, build_device=None):
         self._h = None
+        self.build_stats = None
         if _handle is not None:
             self._h = _handle
         else:
             a = as_chars(text)
             h = C.c_void_p()
-            check(lib.fmx_build(a.ctypes.data, len(a), int(sampleRate), int(bool(enableExtract)), C.byref(h)), "fmx_build")
+            if build_device is None:
+                check(lib.fmx_build(a.ctypes.data, len(a), int(sampleRate), int(bool(enableExtract)), C.byref(h)), "fmx_build")
+            else:  # suffix array, BWT and samples computed in HBM (fmx_sa_gpu.hip); same index
+                rounds, rows, secs = C.c_int32(0), C.c_int64(0), C.c_double(0)
+                check(lib.fmx_build_on_device(a.ctypes.data, len(a), int(sampleRate), int(bool(enableExtract)),
+                                              int(build_device), C.byref(h), C.byref(rounds), C.byref(rows),
+                                              C.byref(secs)), "fmx_build_on_device")
+                self.build_stats = {"doubling_rounds": rounds.value, "rows_sorted": rows.value,
+                                    "device_stage_seconds": secs.value}
             self._h = h
         if device is not None:
             self.to_device(device)

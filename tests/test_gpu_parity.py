@@ -457,3 +457,33 @@ def test_planned_batches_vs_oracle_across_alphabet_sizes(sigma):
     for i in range(0, N, 37):
         k, l = o.locate(pats[i], max_matches=4, cap=4)
         assert found[i] == k and (locs[i, :k] == l).all(), i
+
+
+def test_device_construction_is_byte_identical():
+    """fmx_build_on_device (suffix array by prefix doubling in HBM, FM:329-394 on the GPU) against the host
+    builder: the serialized indexes must be the same bytes — the suffix array of a terminated text is unique.
+    Texts: the fixture, long repeats (many doubling rounds), a single repeated character (the worst case),
+    embedded sentinels, tiny inputs, extraction on and off."""
+    rnd = random.Random(99)
+    texts = [
+        (HD[:120_000], 32), (HD[:50_000], 1), (HD[:33_333], 7),
+        ("zq" * 20_000 + "x" + "zq" * 20_000, 16),
+        ("a" * 70_000, 8),
+        ("ab\0cd\0\0ef" * 3000 + "tail", 4),
+        ("", 4), ("a", 1), ("ab", 2), ("\0", 3), ("abracadabra", 2),
+        ("".join(rnd.choice("ACGT") for _ in range(200_000)), 64),
+        ("".join(chr(rnd.randrange(40, 2000)) for _ in range(90_000)), 32),
+    ]
+    for text, sr in texts:
+        for extract in (True, False):
+            host = ia.FmIndex(text, sr, extract, device=None)
+            dev = ia.FmIndex(text, sr, extract, device=None, build_device=0)
+            assert dev.write(False) == host.write(False), (len(text), sr, extract)
+    dev = ia.FmIndex("a" * 70_000, 8, True, device=0, build_device=0)
+    assert dev.build_stats["doubling_rounds"] >= 14  # LCP ~ n: log2(70000 / 4) rounds
+    assert dev.count("aaaa") == 70_000 - 3
+    # at size: 16 MiB of synthetic log
+    t = ia.synth_log(1 << 24)
+    host = ia.FmIndex(t, 32, True, device=None)
+    dev = ia.FmIndex(t, 32, True, device=None, build_device=0)
+    assert dev.write(False) == host.write(False)
