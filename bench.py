@@ -45,8 +45,10 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_or_load_index(ia, text_log2, sample_rate, cache_dir):
-    """index of 2^text_log2 chars of synthetic log; the serialized form is cached under cache_dir"""
+def build_or_load_index(ia, text_log2, sample_rate, cache_dir, build_device=0):
+    """index of 2^text_log2 chars of synthetic log; the serialized form is cached under cache_dir.
+    Construction runs its suffix-array stage on GPU `build_device` (same index, byte for byte: fmx_build_on_device);
+    None = host builder."""
     n = 1 << text_log2
     t0 = time.time()
     text = ia.synth_log(n, seed=42)
@@ -57,8 +59,10 @@ def build_or_load_index(ia, text_log2, sample_rate, cache_dir):
         fm = ia.FmIndex.read(open(path, "rb").read(), device=None)
         log("[bench] index loaded from %s in %.1fs" % (path, time.time() - t1))
     else:
-        fm = ia.FmIndex(text, sample_rate, True, device=None)
-        log("[bench] text %.1fs, index built in %.1fs (host, %d cores)" % (t1 - t0, time.time() - t1, os.cpu_count()))
+        fm = ia.FmIndex(text, sample_rate, True, device=None, build_device=build_device)
+        log("[bench] text %.1fs, index built in %.1fs (%s, %d host cores)"
+            % (t1 - t0, time.time() - t1, "suffix array on GPU %d" % build_device if build_device is not None else "host builder",
+               os.cpu_count()))
         try:
             os.makedirs(cache_dir, exist_ok=True)
             tmp = path + ".%d.tmp" % os.getpid()
@@ -146,7 +150,7 @@ def main():
     # ---- index: rank 0 builds (or loads the cached serialized form), the HBM image is broadcast ----
     text = fm = path = None
     if rank == 0:
-        text, fm, path = build_or_load_index(ia, args.text_log2, args.sample_rate, args.cache_dir)
+        text, fm, path = build_or_load_index(ia, args.text_log2, args.sample_rate, args.cache_dir, build_device=local_rank)
     if world > 1:
         size = torch.zeros(1, dtype=torch.int64, device=dev)
         if rank == 0:
