@@ -656,8 +656,16 @@ int build_model(const uint16_t *input, int32_t n_in, int32_t sample_rate, bool e
 
     // FM:329-394: suffix array -> sampled rows, inverse samples, BWT (on the host, or in HBM)
     SaStage st;
-    int rc = build_device >= 0 ? device_sa_stage(seq.data(), n, sample_rate, enable_extract, build_device, st, stats, err)
-                               : host_sa_stage(seq.data(), n, n_look + 1, sample_rate, enable_extract, st);
+    int rc;
+    if (build_device >= 0) {
+        if (!device_sa_stage) {  // host-only link of this file (sanitizer builds of the host code)
+            err = "this build has no device construction stage";
+            return -8;
+        }
+        rc = device_sa_stage(seq.data(), n, sample_rate, enable_extract, build_device, st, stats, err);
+    } else {
+        rc = host_sa_stage(seq.data(), n, n_look + 1, sample_rate, enable_extract, st);
+    }
     if (rc) return rc;
     std::vector<int16_t>().swap(seq);
     m.bw_suffixes = min_bits((uint64_t)n);

@@ -24,7 +24,8 @@ struct SaStageStats {
 
 // seq: mapped text incl. the terminator (code 0 at n-1 only); returns 0 or a negative fmx error code
 int host_sa_stage(const int16_t *seq, int32_t n, int alphabet, int sample_rate, bool extract, SaStage &out);
+// (weak: fmx_build.cpp also links without the HIP translation unit, e.g. in the sanitizer build of the host code)
 int device_sa_stage(const int16_t *seq, int32_t n, int sample_rate, bool extract, int device, SaStage &out,
-                    SaStageStats *stats, std::string &err);
+                    SaStageStats *stats, std::string &err) __attribute__((weak));
 
 }  // namespace fmx
