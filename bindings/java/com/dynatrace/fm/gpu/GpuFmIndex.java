@@ -40,7 +40,12 @@ public final class GpuFmIndex implements AutoCloseable {
 
     /** new FmIndexBuilder().setSampleRate(s).setEnableExtraction(e).build(text) built natively (FMB:34-62). */
     public static GpuFmIndex build(char[] text, int sampleRate, boolean enableExtraction, int device) {
-        return new GpuFmIndex(nativeBuild(text, sampleRate, enableExtraction, device));
+        return new GpuFmIndex(nativeBuild(text, sampleRate, enableExtraction, device, false));
+    }
+
+    /** The same index with the constructor's suffix-array stage (FM:329-394) computed on the GPU. */
+    public static GpuFmIndex buildOnGpu(char[] text, int sampleRate, boolean enableExtraction, int device) {
+        return new GpuFmIndex(nativeBuild(text, sampleRate, enableExtraction, device, true));
     }
 
     // ---- the reference's scalar signatures (FmIndex.java:443-941) ----
@@ -123,6 +128,52 @@ public final class GpuFmIndex implements AutoCloseable {
         return found;
     }
 
+    /**
+     * locate, then extract(loc, min(getInputLength(), loc + extractLength), row, 0) for every hit, in one device
+     * call (what locateAndExtractBenchmark does hit by hit). rows: n * maxMatches rows of extractLength chars;
+     * locations / outLen / hitStatus: n * maxMatches slots; returns the number located per pattern.
+     */
+    public int[] locateExtractBatch(char[] chars, int[] offsets, int maxMatches, int extractLength, int[] locations,
+            char[] rows, int[] outLen, int[] hitStatus) {
+        return pipeline(chars, offsets, maxMatches, -1, (char) 0, extractLength, locations, rows, outLen, hitStatus);
+    }
+
+    /** locate, then extractUntilBoundary (mode 0) / Left (1) / Right (2) for every hit. */
+    public int[] locateLinesBatch(char[] chars, int[] offsets, int maxMatches, char boundary, int mode, int rowLength,
+            int[] locations, char[] rows, int[] outLen, int[] hitStatus) {
+        return pipeline(chars, offsets, maxMatches, mode, boundary, rowLength, locations, rows, outLen, hitStatus);
+    }
+
+    private int[] pipeline(char[] chars, int[] offsets, int maxMatches, int mode, char boundary, int rowLength,
+            int[] locations, char[] rows, int[] outLen, int[] hitStatus) {
+        int n = offsets.length - 1;
+        int[] found = new int[n];
+        int[] status = new int[n];
+        int[] hitAux = new int[n * maxMatches];
+        nativeLocatePipeline(handle, chars, offsets, n, maxMatches, mode, boundary, rowLength, locations, found, rows,
+                outLen, status, hitStatus, hitAux);
+        for (int s : status) {
+            rethrow(s, 0);
+        }
+        return found;
+    }
+
+    /** count() summed over K indexes of one long text (a Java int cannot address 2^31 chars, FmIndex.java:131). */
+    public static long[] countSegments(GpuFmIndex[] segments, char[] chars, int[] offsets) {
+        int n = offsets.length - 1;
+        long[] handles = new long[segments.length];
+        for (int i = 0; i < segments.length; i++) {
+            handles[i] = segments[i].handle;
+        }
+        long[] counts = new long[n];
+        int[] status = new int[n];
+        nativeCountSegments(handles, chars, offsets, n, counts, status);
+        for (int s : status) {
+            rethrow(s, 0);
+        }
+        return counts;
+    }
+
     @Override
     public void close() {
         if (handle != 0) {
@@ -179,7 +230,15 @@ public final class GpuFmIndex implements AutoCloseable {
 
     private static native long nativeLoad(byte[] serialized, int device) throws IOException;
 
-    private static native long nativeBuild(char[] text, int sampleRate, boolean enableExtraction, int device);
+    private static native long nativeBuild(char[] text, int sampleRate, boolean enableExtraction, int device,
+            boolean buildOnGpu);
+
+    private static native void nativeLocatePipeline(long handle, char[] chars, int[] offsets, int n, int maxMatches,
+            int mode, char boundary, int rowLength, int[] locations, int[] found, char[] rows, int[] outLen, int[] status,
+            int[] hitStatus, int[] hitAux);
+
+    private static native void nativeCountSegments(long[] handles, char[] chars, int[] offsets, int n, long[] counts,
+            int[] status);
 
     private static native void nativeFree(long handle);
 

@@ -38,12 +38,16 @@ JNIEXPORT jlong JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeLoad(JNIEnv *
     return (jlong)(intptr_t)idx;
 }
 
+/* buildOnGpu: the constructor's suffix-array stage (FM:329-394) runs on `device` — same index, byte for byte */
 JNIEXPORT jlong JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeBuild(JNIEnv *env, jclass c, jcharArray text,
-                                                                        jint sampleRate, jboolean extract, jint device) {
+                                                                        jint sampleRate, jboolean extract, jint device,
+                                                                        jboolean buildOnGpu) {
     jsize n = (*env)->GetArrayLength(env, text);
     jchar *p = (*env)->GetCharArrayElements(env, text, NULL);
     fmx_index *idx = NULL;
-    int rc = fmx_build((const uint16_t *)p, n, sampleRate, extract ? 1 : 0, &idx);
+    int rc = buildOnGpu ? fmx_build_on_device((const uint16_t *)p, n, sampleRate, extract ? 1 : 0, device, &idx, NULL,
+                                              NULL, NULL)
+                        : fmx_build((const uint16_t *)p, n, sampleRate, extract ? 1 : 0, &idx);
     (*env)->ReleaseCharArrayElements(env, text, p, JNI_ABORT);
     if (rc == FMX_OK) rc = fmx_to_device(idx, device);
     if (rc != FMX_OK) {
@@ -133,5 +137,62 @@ JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeExtractBoundar
     (*env)->ReleaseIntArrayElements(env, outLen, pl, 0);
     (*env)->ReleaseIntArrayElements(env, status, ps, 0);
     (*env)->ReleaseIntArrayElements(env, aux, px, 0);
+    if (rc != FMX_OK) throw_lib_error(env, rc);
+}
+
+/* locate -> extract (mode < 0, rowLength = extraction length) or locate -> extractUntilBoundary{,Left,Right}
+ * (mode 0/1/2) with the hit table kept on the device: fmx_locate_extract_batch / fmx_locate_lines_batch */
+JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeLocatePipeline(
+    JNIEnv *env, jclass c, jlong h, jcharArray chars, jintArray offsets, jint n, jint maxMatches, jint mode, jchar boundary,
+    jint rowLength, jintArray locations, jintArray found, jcharArray rows, jintArray outLen, jintArray status,
+    jintArray hitStatus, jintArray hitAux) {
+    jchar *pc = (*env)->GetCharArrayElements(env, chars, NULL);
+    jint *po = (*env)->GetIntArrayElements(env, offsets, NULL);
+    jint *pl = (*env)->GetIntArrayElements(env, locations, NULL);
+    jint *pf = (*env)->GetIntArrayElements(env, found, NULL);
+    jchar *pr = (*env)->GetCharArrayElements(env, rows, NULL);
+    jint *pn = (*env)->GetIntArrayElements(env, outLen, NULL);
+    jint *ps = (*env)->GetIntArrayElements(env, status, NULL);
+    jint *ph = (*env)->GetIntArrayElements(env, hitStatus, NULL);
+    jint *pa = (*env)->GetIntArrayElements(env, hitAux, NULL);
+    const fmx_index *idx = (const fmx_index *)(intptr_t)h;
+    int rc = mode < 0 ? fmx_locate_extract_batch(idx, (const uint16_t *)pc, (const int32_t *)po, n, maxMatches, rowLength,
+                                                 (int32_t *)pl, (int32_t *)pf, (uint16_t *)pr, (int32_t *)pn, NULL,
+                                                 (int32_t *)ps, (int32_t *)ph)
+                      : fmx_locate_lines_batch(idx, (const uint16_t *)pc, (const int32_t *)po, n, maxMatches, boundary, mode,
+                                               rowLength, (int32_t *)pl, (int32_t *)pf, (uint16_t *)pr, (int32_t *)pn, NULL,
+                                               (int32_t *)ps, (int32_t *)ph, (int32_t *)pa);
+    (*env)->ReleaseCharArrayElements(env, chars, pc, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, offsets, po, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, locations, pl, 0);
+    (*env)->ReleaseIntArrayElements(env, found, pf, 0);
+    (*env)->ReleaseCharArrayElements(env, rows, pr, 0);
+    (*env)->ReleaseIntArrayElements(env, outLen, pn, 0);
+    (*env)->ReleaseIntArrayElements(env, status, ps, 0);
+    (*env)->ReleaseIntArrayElements(env, hitStatus, ph, 0);
+    (*env)->ReleaseIntArrayElements(env, hitAux, pa, 0);
+    if (rc != FMX_OK) throw_lib_error(env, rc);
+}
+
+/* K indexes of one long text (texts of 2^31 chars or more): summed counts, fmx_count_segments */
+JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeCountSegments(JNIEnv *env, jclass c, jlongArray handles,
+                                                                               jcharArray chars, jintArray offsets, jint n,
+                                                                               jlongArray counts, jintArray status) {
+    jsize k = (*env)->GetArrayLength(env, handles);
+    jlong *ph = (*env)->GetLongArrayElements(env, handles, NULL);
+    const fmx_index *segs[64];
+    if (k > 64) k = 64;
+    for (jsize i = 0; i < k; ++i) segs[i] = (const fmx_index *)(intptr_t)ph[i];
+    jchar *pc = (*env)->GetCharArrayElements(env, chars, NULL);
+    jint *po = (*env)->GetIntArrayElements(env, offsets, NULL);
+    jlong *pn = (*env)->GetLongArrayElements(env, counts, NULL);
+    jint *ps = (*env)->GetIntArrayElements(env, status, NULL);
+    int rc = fmx_count_segments(segs, (int32_t)k, (const uint16_t *)pc, (const int32_t *)po, n, (int64_t *)pn, NULL,
+                                (int32_t *)ps);
+    (*env)->ReleaseLongArrayElements(env, handles, ph, JNI_ABORT);
+    (*env)->ReleaseCharArrayElements(env, chars, pc, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, offsets, po, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, counts, pn, 0);
+    (*env)->ReleaseIntArrayElements(env, status, ps, 0);
     if (rc != FMX_OK) throw_lib_error(env, rc);
 }

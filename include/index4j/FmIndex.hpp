@@ -50,11 +50,17 @@ inline void raise_for_status(int status, int aux = 0) {
 
 class FmIndex {
 public:
-    // new FmIndex(char[] input, int sampleRate, boolean enableExtract)  FM:155-174
-    FmIndex(const std::u16string &input, int sampleRate, bool enableExtract = true, int device = 0) {
-        detail::check(fmx_build(reinterpret_cast<const uint16_t *>(input.data()), (int32_t)input.size(), sampleRate,
-                                enableExtract ? 1 : 0, &h_),
-                      "fmx_build");
+    // new FmIndex(char[] input, int sampleRate, boolean enableExtract)  FM:155-174.
+    // buildDevice >= 0: the constructor's suffix-array stage (FM:329-394) runs on that GPU — same index, byte for byte
+    FmIndex(const std::u16string &input, int sampleRate, bool enableExtract = true, int device = 0,
+            int buildDevice = -1) {
+        const uint16_t *chars = reinterpret_cast<const uint16_t *>(input.data());
+        if (buildDevice >= 0)
+            detail::check(fmx_build_on_device(chars, (int32_t)input.size(), sampleRate, enableExtract ? 1 : 0, buildDevice,
+                                              &h_, nullptr, nullptr, nullptr),
+                          "fmx_build_on_device");
+        else
+            detail::check(fmx_build(chars, (int32_t)input.size(), sampleRate, enableExtract ? 1 : 0, &h_), "fmx_build");
         if (device >= 0) toDevice(device);
     }
     // FmIndex.read(ObjectInput) FM:983-1025 (raw DataOutput stream or ObjectOutputStream-framed, SER:89-100)
@@ -126,6 +132,24 @@ public:
         return found;
     }
 
+    // locate, then extract(loc, min(getInputLength(), loc + extractLength), row, 0) per hit, both on the device:
+    // the composite the reference times in locateAndExtractBenchmark (FmIndexThroughputBenchmark.java:231-249).
+    // Hit k of pattern i: locations[i*maxMatches+k], rows[i*maxMatches+k] (extractLength chars, only the first
+    // outLen are the text), hitStatus = status of that extract call (not thrown: one hit near the end of the text
+    // fails with "Stop position longer than index string" without hiding the others).
+    struct HitRows {
+        std::vector<int32_t> found, locations, outLen, hitStatus, hitAux;
+        std::vector<std::u16string> rows;
+    };
+    HitRows locateExtractBatch(const std::vector<std::u16string> &patterns, int maxMatches, int extractLength) const {
+        return pipeline(patterns, maxMatches, extractLength, -1, 0);
+    }
+    // locate, then extractUntilBoundary (mode 0) / ...Left (1) / ...Right (2) per hit, FM:640-922
+    HitRows locateLinesBatch(const std::vector<std::u16string> &patterns, int maxMatches, char16_t boundary,
+                             int rowLength, int mode = 0) const {
+        return pipeline(patterns, maxMatches, rowLength, mode, boundary);
+    }
+
     // ---- scalar API, as in the reference ----
     int count(const std::u16string &pattern) const { return count(pattern, 0, (int)pattern.size()); }  // FM:443-445
     int count(const std::u16string &pattern, int offset, int length) const {                            // FM:455-474
@@ -181,6 +205,11 @@ public:
         return n;
     }
 
+    static void packPatterns(const std::vector<std::u16string> &patterns, std::vector<uint16_t> &chars,
+                             std::vector<int32_t> &off) {
+        pack(patterns, chars, off);
+    }
+
 private:
     explicit FmIndex(fmx_index *h) : h_(h) {}
     static void pack(const std::vector<std::u16string> &patterns, std::vector<uint16_t> &chars,
@@ -191,6 +220,37 @@ private:
             off.push_back((int32_t)chars.size());
         }
         if (chars.empty()) chars.push_back(0);
+    }
+    HitRows pipeline(const std::vector<std::u16string> &patterns, int maxMatches, int rowLength, int mode,
+                     char16_t boundary) const {
+        std::vector<uint16_t> chars;
+        std::vector<int32_t> off;
+        pack(patterns, chars, off);
+        const int32_t n = (int32_t)patterns.size();
+        const size_t slots = (size_t)n * (size_t)maxMatches;
+        HitRows r;
+        r.found.assign(patterns.size(), 0);
+        r.locations.assign(slots, -1);
+        r.outLen.assign(slots, -1);
+        r.hitStatus.assign(slots, 0);
+        r.hitAux.assign(slots, 0);
+        std::vector<uint16_t> dst(slots * (size_t)rowLength, 0);
+        std::vector<int32_t> status(patterns.size());
+        if (mode < 0)
+            detail::check(fmx_locate_extract_batch(h_, chars.data(), off.data(), n, maxMatches, rowLength,
+                                                   r.locations.data(), r.found.data(), dst.data(), r.outLen.data(), nullptr,
+                                                   status.data(), r.hitStatus.data()),
+                          "fmx_locate_extract_batch");
+        else
+            detail::check(fmx_locate_lines_batch(h_, chars.data(), off.data(), n, maxMatches, (uint16_t)boundary, mode,
+                                                 rowLength, r.locations.data(), r.found.data(), dst.data(), r.outLen.data(),
+                                                 nullptr, status.data(), r.hitStatus.data(), r.hitAux.data()),
+                          "fmx_locate_lines_batch");
+        for (int st : status) detail::raise_for_status(st);
+        r.rows.resize(slots);
+        for (size_t q = 0; q < slots; ++q)
+            r.rows[q].assign(reinterpret_cast<const char16_t *>(dst.data()) + q * (size_t)rowLength, (size_t)rowLength);
+        return r;
     }
     int boundaryCall(int mode, int from, std::u16string &destination, int offset, char16_t boundary) const {
         int32_t len = 0, st = 0, aux = 0;
@@ -219,14 +279,64 @@ public:
         device_ = device;
         return *this;
     }
+    FmIndexBuilder &setBuildDevice(int device) {  // extension: suffix-array stage of the build on this GPU
+        buildDevice_ = device;
+        return *this;
+    }
     FmIndex build(const std::u16string &input) const {  // FMB:59-61
-        return FmIndex(input, sampleRate_, enableExtraction_, device_);
+        return FmIndex(input, sampleRate_, enableExtraction_, device_, buildDevice_);
     }
 
 private:
     int sampleRate_ = 32;
     bool enableExtraction_ = true;
     int device_ = 0;
+    int buildDevice_ = -1;
+};
+
+// One long text as K FmIndex objects over consecutive pieces (a Java int cannot address 2^31 chars, FM:131):
+// count = sum over the pieces, hits = piece start + local position, in piece order — what a caller's loop over K
+// indexes computes, as one device call (fmx_count_segments / fmx_locate_segments).  All pieces on one GPU.
+class SegmentedFmIndex {
+public:
+    void add(FmIndex &&segment, int64_t textOffset) {
+        segments_.push_back(std::move(segment));
+        bases_.push_back(textOffset);
+        handles_.push_back(segments_.back().handle());
+    }
+    size_t size() const { return segments_.size(); }
+    std::vector<int64_t> countBatch(const std::vector<std::u16string> &patterns) const {
+        std::vector<uint16_t> chars;
+        std::vector<int32_t> off;
+        FmIndex::packPatterns(patterns, chars, off);
+        std::vector<int64_t> counts(patterns.size());
+        std::vector<int32_t> status(patterns.size());
+        detail::check(fmx_count_segments(handles_.data(), (int32_t)handles_.size(), chars.data(), off.data(),
+                                         (int32_t)patterns.size(), counts.data(), nullptr, status.data()),
+                      "fmx_count_segments");
+        for (int st : status) detail::raise_for_status(st);
+        return counts;
+    }
+    // returns found[i]; locations = patterns.size() rows of maxMatches global text positions
+    std::vector<int32_t> locateBatch(const std::vector<std::u16string> &patterns, int maxMatches,
+                                     std::vector<int64_t> &locations) const {
+        std::vector<uint16_t> chars;
+        std::vector<int32_t> off;
+        FmIndex::packPatterns(patterns, chars, off);
+        locations.assign(patterns.size() * (size_t)maxMatches, -1);
+        std::vector<int32_t> found(patterns.size()), status(patterns.size());
+        detail::check(fmx_locate_segments(handles_.data(), (int32_t)handles_.size(), bases_.data(), chars.data(),
+                                          off.data(), (int32_t)patterns.size(), maxMatches, locations.data(), found.data(),
+                                          status.data()),
+                      "fmx_locate_segments");
+        for (int st : status) detail::raise_for_status(st);
+        return found;
+    }
+
+private:
+    std::vector<FmIndex> segments_;
+    std::vector<int64_t> bases_;
+    std::vector<const fmx_index *> handles_;
 };
 
 }  // namespace index4j

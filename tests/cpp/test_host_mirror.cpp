@@ -170,6 +170,54 @@ int main(int argc, char **argv) {
         CHECK(counts[0] == 1920 && counts[1] == (int)occurrences(hdfs, u"WARN") &&
               counts[2] == (int)occurrences(hdfs, u"blk_") && counts[3] == 0);
     }
+    // the index built with its suffix-array stage on the GPU is the same bytes
+    {
+        FmIndex onGpu = FmIndexBuilder().setDevice(-1).setBuildDevice(0).build(hdfs);
+        CHECK(onGpu.write(false) == fmi.write(false));
+    }
+    // locate -> extract / extractUntilBoundary pipelines (locateAndExtractBenchmark, J-FM:231-249)
+    {
+        const std::vector<std::u16string> pats = {u"INFO", u"blk_", u"zzzzzz"};
+        const int mm = 5, xl = 12;
+        const auto r = fmi.locateExtractBatch(pats, mm, xl);
+        CHECK(r.found[0] == mm && r.found[1] == mm && r.found[2] == 0);
+        for (size_t i = 0; i < pats.size(); ++i)
+            for (int k = 0; k < mm; ++k) {
+                const size_t q = i * mm + (size_t)k;
+                if (k >= r.found[i]) {
+                    CHECK(r.locations[q] == -1 && r.outLen[q] == -1);
+                    continue;
+                }
+                CHECK(r.hitStatus[q] == 0 && r.outLen[q] == xl);
+                CHECK(r.rows[q] == hdfs.substr((size_t)r.locations[q], (size_t)xl));
+                CHECK(r.rows[q].compare(0, pats[i].size(), pats[i]) == 0);
+            }
+        const auto lines = fmi.locateLinesBatch({u"WARN"}, 3, u'\n', 600);
+        CHECK(lines.found[0] == 3);
+        for (int k = 0; k < 3; ++k) {
+            const size_t loc = (size_t)lines.locations[(size_t)k];
+            const size_t lo = hdfs.rfind(u'\n', loc) + 1, hi = hdfs.find(u'\n', loc);
+            CHECK(lines.hitStatus[(size_t)k] == 0 && (size_t)lines.outLen[(size_t)k] == hi - lo);
+            CHECK(lines.rows[(size_t)k].substr(0, hi - lo) == hdfs.substr(lo, hi - lo));
+        }
+    }
+    // one text as three segment indexes cut at line ends
+    {
+        index4j::SegmentedFmIndex seg;
+        size_t a = 0;
+        for (int piece = 0; piece < 3; ++piece) {
+            size_t b = piece == 2 ? hdfs.size() : hdfs.find(u'\n', (piece + 1) * hdfs.size() / 3) + 1;
+            seg.add(FmIndexBuilder().setSampleRate(16).build(hdfs.substr(a, b - a)), (int64_t)a);
+            a = b;
+        }
+        const std::vector<std::u16string> pats = {u"INFO", u"WARN", u"zzzzzz"};
+        const auto counts = seg.countBatch(pats);
+        CHECK(counts[0] == 1920 && counts[1] == (int64_t)occurrences(hdfs, u"WARN") && counts[2] == 0);
+        std::vector<int64_t> locs;
+        const auto found = seg.locateBatch(pats, 4, locs);
+        CHECK(found[0] == 4 && found[2] == 0);
+        for (int k = 0; k < found[1]; ++k) CHECK(hdfs.compare((size_t)locs[4 + (size_t)k], 4, u"WARN") == 0);
+    }
     std::printf("host mirror (gpu mode): %d failure(s)\n", failures);
     return failures ? 1 : 0;
 }
