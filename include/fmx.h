@@ -223,6 +223,9 @@ const char *fmx_status_message(int status);
 /* 1 if the exception type is IllegalArgumentException, 0 for RuntimeException, 2 for AIOOBE */
 int fmx_status_kind(int status);
 const char *fmx_last_error(void);
+/* The host-buffer entry points recycle their device scratch between calls (up to 2 GiB per process); this
+ * returns it to the driver. */
+void fmx_release_scratch(void);
 int fmx_device_count(void);
 /* launch tunables: "block" = threads per workgroup (512 | 1024), "groups_per_cu" = grid cap per CU,
  * "sort_min" = smallest batch that is processed in suffix-sorted order (0 = never), "sort_bits" = sort key width,

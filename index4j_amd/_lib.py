@@ -32,7 +32,7 @@ SYMBOLS = [
     "fmx_locate_extract_batch", "fmx_locate_lines_batch", "fmx_locate_extract_batch_dev", "fmx_locate_lines_batch_dev",
     "fmx_count_segments", "fmx_locate_segments", "fmx_count_segments_dev", "fmx_locate_segments_dev",
     "fmx_wavelet_build", "fmx_wavelet_rank_batch", "fmx_wavelet_inverse_select_batch",
-    "fmx_convert_byte_pattern", "fmx_status_message", "fmx_status_kind", "fmx_last_error", "fmx_device_count", "fmx_set_option",
+    "fmx_convert_byte_pattern", "fmx_status_message", "fmx_status_kind", "fmx_last_error", "fmx_release_scratch", "fmx_device_count", "fmx_set_option",
     "fmx_synth_log", "fmx_synth_patterns",
 ]
 
@@ -89,6 +89,7 @@ def _load():
     L.fmx_status_message.restype = C.c_char_p
     L.fmx_status_kind.argtypes = [C.c_int]
     L.fmx_last_error.restype = C.c_char_p
+    L.fmx_release_scratch.restype = None
     L.fmx_set_option.argtypes = [C.c_char_p, C.c_int]
     L.fmx_synth_log.argtypes = [u64, i32, vp]
     L.fmx_synth_patterns.argtypes = [u64, vp, i32, i32, i32, vp, vp, vp]

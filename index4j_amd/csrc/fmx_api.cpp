@@ -192,13 +192,58 @@ int get_workspace(const fmx_index *idx, void *stream, size_t bytes, void **out) 
 #define H2D(dst, src, bytes) HIP_TRY(hipMemcpy((dst), (src), (bytes), hipMemcpyHostToDevice))
 #define D2H(dst, src, bytes) HIP_TRY(hipMemcpy((dst), (src), (bytes), hipMemcpyDeviceToHost))
 
-// RAII device scratch for the host-buffer entry points
+// Device scratch of the host-buffer entry points.  hipMalloc / hipFree cost more than a small batch's kernels, so
+// blocks are recycled: power-of-two size classes per device, at most kScratchCacheLimit bytes kept.
+constexpr size_t kScratchCacheLimit = (size_t)2 << 30;
+struct ScratchCache {
+    std::mutex mutex;
+    std::multimap<std::pair<int, size_t>, void *> free_blocks;
+    size_t cached_bytes = 0;
+    void *take(int device, size_t bytes) {
+        std::lock_guard<std::mutex> lock(mutex);
+        auto it = free_blocks.find({device, bytes});
+        if (it == free_blocks.end()) return nullptr;
+        void *p = it->second;
+        free_blocks.erase(it);
+        cached_bytes -= bytes;
+        return p;
+    }
+    bool give(int device, size_t bytes, void *p) {
+        std::lock_guard<std::mutex> lock(mutex);
+        if (cached_bytes + bytes > kScratchCacheLimit) return false;
+        free_blocks.insert({{device, bytes}, p});
+        cached_bytes += bytes;
+        return true;
+    }
+    void release_all() {
+        std::lock_guard<std::mutex> lock(mutex);
+        int current = 0;
+        (void)hipGetDevice(&current);
+        for (auto &kv : free_blocks) {
+            (void)hipSetDevice(kv.first.first);
+            (void)hipFree(kv.second);
+        }
+        (void)hipSetDevice(current);
+        free_blocks.clear();
+        cached_bytes = 0;
+    }
+};
+ScratchCache g_scratch;
+
 struct DevBuf {
     void *p = nullptr;
+    size_t bytes = 0;
+    int device = 0;
     ~DevBuf() {
-        if (p) (void)hipFree(p);
+        if (p && !g_scratch.give(device, bytes, p)) (void)hipFree(p);
     }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+    hipError_t alloc(size_t n) {
+        bytes = 256;
+        while (bytes < n) bytes <<= 1;
+        (void)hipGetDevice(&device);
+        p = g_scratch.take(device, bytes);
+        return p ? hipSuccess : hipMalloc(&p, bytes);
+    }
     template <typename T>
     T *as() {
         return static_cast<T *>(p);
@@ -210,6 +255,8 @@ struct DevBuf {
 extern "C" {
 
 const char *fmx_last_error(void) { return g_err.c_str(); }
+
+void fmx_release_scratch(void) { g_scratch.release_all(); }
 
 int fmx_set_option(const char *name, int value) {
     if (!name || fmx::set_option(name, value)) return fail(FMX_E_ARG, "unknown option or bad value");
