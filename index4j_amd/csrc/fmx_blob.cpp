@@ -24,7 +24,7 @@ struct Arena {
 inline uint32_t off8(size_t byte_off) { return (uint32_t)(byte_off >> 3); }
 
 // RRR:92-103 -> 16-block records + offsets bit stream
-bool flatten_rrr(Arena &A, const RrrModel &r, RrrDesc &d, bool compact, std::string &err) {
+bool flatten_rrr(Arena &A, const RrrModel &r, RrrDesc &d, std::string &err) {
     if (r.sample_size <= 0 || r.classes.width != 4) {
         err = "unsupported RRR parameters";
         return false;
@@ -46,24 +46,11 @@ bool flatten_rrr(Arena &A, const RrrModel &r, RrrDesc &d, bool compact, std::str
         rec.ones_before = (uint32_t)ones;
         rec.offset_bit = (uint32_t)obits;
         rec.classes = 0;
-        if (compact && ((ones | obits) >> kRrrCompactShift)) {
-            err = "wavelet-tree bitvector too long for compact RRR records";
-            return false;
-        }
-        uint32_t half_ones = 0, half_bits = 0;
         for (int64_t j = 0; j < 16 && k * 16 + j < n_blocks; ++j) {
             const uint64_t cls = r.classes.get(k * 16 + j);
             rec.classes |= cls << (4 * j);
             ones += cls;
             obits += bits_needed[cls];
-            if (j < 8) {
-                half_ones += (uint32_t)cls;
-                half_bits += bits_needed[cls];
-            }
-        }
-        if (compact) {
-            rec.ones_before |= half_ones << kRrrCompactShift;
-            rec.offset_bit |= half_bits << kRrrCompactShift;
         }
         A.at<RrrRecord>(rec_off)[k] = rec;
     }
@@ -74,6 +61,69 @@ bool flatten_rrr(Arena &A, const RrrModel &r, RrrDesc &d, bool compact, std::str
     const size_t bits_off = A.alloc((r.offsets.size() + 2) * 8);
     d.off_bits = off8(bits_off);
     if (!r.offsets.empty()) memcpy(A.at<uint8_t>(bits_off), r.offsets.data(), r.offsets.size() * 8);
+    return true;
+}
+
+// RRR:92-103 -> expanded 96-bit cells with running one-counts (the wavelet tree's vectors; see fmx_blob.hpp)
+bool flatten_expanded(Arena &A, const RrrModel &r, RrrDesc &d, std::string &err) {
+    if (r.classes.width != 4) {
+        err = "unsupported RRR parameters";
+        return false;
+    }
+    const uint8_t *bits_needed = rrr_bits_needed();
+    const uint16_t *value_of = rrr_value_of_offset(), *class_base = rrr_class_base();
+    const int64_t n_blocks = r.classes.length;
+    const int64_t n_cells = (int64_t)r.length / kBvCellBits + 2;  // + a cell for position == length and a guard
+    d.n_rec = (int32_t)n_cells;
+    d.n_blocks = (int32_t)n_blocks;
+    d.length = r.length;
+    d.total_ones = r.total_ones;
+    d.sample = r.sample_size;
+    d.pad = 0;
+    d.off_bits = 0;
+    const size_t cell_off = A.alloc((size_t)n_cells * sizeof(BvCell));
+    d.off_rec = off8(cell_off);
+    // RRR:382-390 for every block: (class, offset) -> 15 bits, into a plain LSB-first bit array ...
+    std::vector<uint64_t> plain((size_t)((int64_t)n_cells * kBvCellBits / 64 + 2), 0);
+    uint64_t obits = 0;
+    const uint64_t avail = (uint64_t)r.offsets.size() * 64;
+    for (int64_t b = 0; b < n_blocks; ++b) {
+        const int cls = (int)r.classes.get(b);
+        const int nb = bits_needed[cls];
+        if (obits + (uint64_t)nb > avail) {
+            err = "RRR offsets stream shorter than its classes imply";
+            return false;
+        }
+        const size_t w = (size_t)(obits >> 6);
+        const int sh = (int)(obits & 63);
+        uint64_t off = r.offsets[w] >> sh;
+        if (sh + nb > 64) off |= r.offsets[w + 1] << (64 - sh);
+        off &= (1ull << nb) - 1ull;
+        obits += (uint64_t)nb;
+        const uint64_t value = value_of[(size_t)class_base[cls] + (size_t)off];
+        const int64_t pos = b * 15;
+        const size_t pw = (size_t)(pos >> 6);
+        const int ps = (int)(pos & 63);
+        plain[pw] |= value << ps;
+        if (ps + 15 > 64) plain[pw + 1] |= value >> (64 - ps);
+    }
+    // ... cut into 96-bit cells with running one-counts (bits past `length` are zero: RRR pads its last block)
+    BvCell *cells = A.at<BvCell>(cell_off);
+    const uint32_t *plain32 = reinterpret_cast<const uint32_t *>(plain.data());
+    uint64_t ones = 0;
+    for (int64_t c = 0; c < n_cells; ++c) {
+        BvCell cell;
+        cell.ones_before = (uint32_t)ones;
+        for (int k = 0; k < 3; ++k) {
+            cell.bits[k] = plain32[(size_t)c * 3 + (size_t)k];
+            ones += (uint64_t)__builtin_popcount(cell.bits[k]);
+        }
+        cells[c] = cell;
+    }
+    if (ones != (uint64_t)(uint32_t)r.total_ones) {
+        err = "RRR vector decodes to a different number of ones than it declares";
+        return false;
+    }
     return true;
 }
 
@@ -132,7 +182,7 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
         if (m.map_keys[i] >= 0 && m.map_keys[i] < 65536) A.at<int16_t>(off)[m.map_keys[i]] = m.map_vals[i];
     h.off_suffixes = off8(put_packed(A, m.suffixes));
     h.off_positions = m.enable_extract ? off8(put_packed(A, m.positions)) : 0;
-    if (!flatten_rrr(A, m.sampled, h.sampled, /*compact=*/false, err)) return -8;
+    if (!flatten_rrr(A, m.sampled, h.sampled, err)) return -8;
 
     off = A.alloc(kInvEntries * 2);  // classes 0..7 only; 8..15 are complements (fmx_blob.hpp)
     h.off_inv = off8(off);
@@ -204,7 +254,7 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
         d.off_var = off8(off);
         d.var_len = (int32_t)sb.var.size();
         if (!sb.var.empty()) memcpy(A.at<uint8_t>(off), sb.var.data(), sb.var.size());
-        if (!flatten_rrr(A, sb.rank_support, d.rrr, /*compact=*/true, err)) return -8;
+        if (!flatten_expanded(A, sb.rank_support, d.rrr, err)) return -8;
         *A.at<SbDesc>(sbd_off + (size_t)s * sizeof(SbDesc)) = d;
     }
     A.alloc(64);  // tail guard

@@ -35,24 +35,31 @@
 namespace fmx {
 
 constexpr uint32_t kBlobMagic = 0x31584D46u;  // "FMX1"
-constexpr uint32_t kBlobVersion = 4;
+constexpr uint32_t kBlobVersion = 5;
 
 struct RrrRecord {         // 16 bytes: 16 blocks of 15 bits
     uint32_t ones_before;  // 1-bits in all earlier blocks
     uint32_t offset_bit;   // bit position of this record's first offset in the offsets stream
     uint64_t classes;      // block j's class in bits [4j, 4j+4)
 };
-// Two record flavours.  WIDE (the FM-index's sampled-suffix bitmap, up to 2^31 bits): the two counters use
-// all 32 bits.  COMPACT (the per-superblock vectors of the wavelet tree, < 2^24 bits: at most 2^20 symbols of
-// < 16 code bits): the counters use 24 bits and the top byte carries the sums over the record's first 8
-// blocks — ones_before[31:24] = sum of their classes (<= 120), offset_bit[31:24] = sum of their offset widths
-// (<= 104) — so a rank scans one 32-bit half of `classes` instead of the whole word.
-constexpr uint32_t kRrrCompactMask = 0x00ffffffu;
-constexpr int kRrrCompactShift = 24;
+// (RRR records serve the FM-index's sampled-suffix bitmap, FM:123: sparse — one bit in sampleRate — so the
+// compressed form is what keeps it small.)
+
+// The wavelet tree's per-superblock bit vectors (WFBB:116, an RrrVector in the reference) are EXPANDED when the
+// index is flattened for the GPU: Huffman-shaped levels are already near the entropy of the BWT, RRR saves little
+// on them, and HBM is not the scarce resource here — the rank is.  16-byte cells:
+//   {u32 ones in all earlier cells, 96 bits}
+// so rankOnes(p) is ONE aligned 16-byte load + three masked popcounts (the RRR form: a record, a dependent load
+// of the offset bits, a 32 KiB table lookup in LDS, ~85 VALU).  Costs 1/3 more space than the raw bits.
+struct BvCell {
+    uint32_t ones_before;
+    uint32_t bits[3];  // bit i of the cell = bits[i >> 5] >> (i & 31)
+};
+constexpr uint32_t kBvCellBits = 96;
 
 struct RrrDesc {           // 32 bytes; the first 16 are what a rank needs (one dwordx4 load)
-    uint32_t off_rec;      // RrrRecord[n_rec]
-    uint32_t off_bits;     // offsets bit stream, 64-bit words LSB-first (+2 guard words)
+    uint32_t off_rec;      // RrrRecord[n_rec]   (expanded vectors: BvCell[n_rec])
+    uint32_t off_bits;     // offsets bit stream, 64-bit words LSB-first (+2 guard words)   (expanded vectors: 0)
     int32_t length;        // RRR:94
     int32_t total_ones;    // RRR:95
     int32_t n_rec;
@@ -105,6 +112,7 @@ struct BlobHeader {        // 256 bytes
 };
 static_assert(sizeof(RrrDesc) == 32, "RrrDesc");
 static_assert(sizeof(RrrRecord) == 16, "RrrRecord");
+static_assert(sizeof(BvCell) == 16, "BvCell");
 static_assert(sizeof(SbDesc) == 64, "SbDesc");
 static_assert(sizeof(BlockHdr) == 16, "BlockHdr");
 static_assert(sizeof(SbcEntry) == 8, "SbcEntry");

@@ -169,22 +169,6 @@ FMX_HD void rrr_scan_word(uint64_t w, int n, uint32_t &ones, uint32_t &obits) {
     obits += acc;
 }
 
-// the same sums over the low `n` nibbles (0 <= n <= 7) of one 32-bit half of a class word — the scan of
-// a COMPACT record (fmx_blob.hpp), whose first-half sums come with the record
-FMX_HD void rrr_scan_half(uint32_t w, uint32_t n, uint32_t &ones, uint32_t &obits) {
-    const uint32_t keep = (1u << (4u * n)) - 1u;  // n <= 7
-    w &= keep;
-    const uint32_t b = (w & 0x0f0f0f0fu) + ((w >> 4) & 0x0f0f0f0fu);
-    ones += (b * 0x01010101u) >> 24;
-    const uint32_t hi = (w >> 3) & 0x11111111u;
-    const uint32_t m = (w ^ (hi * 15u)) & 0x77777777u;
-    const uint32_t top = 0x88888888u & keep;
-    const uint32_t a3 = (uint32_t)fmx_popc((m + 0x77777777u) & top) + (uint32_t)fmx_popc((m + 0x66666666u) & top);  // m>=1, m>=2
-    const uint32_t a2 = (uint32_t)fmx_popc((m + 0x55555555u) & top) + (uint32_t)fmx_popc((m + 0x44444444u) & top);  // m>=3, m>=4
-    const uint32_t a1 = (uint32_t)fmx_popc((m + 0x33333333u) & top) + (uint32_t)fmx_popc((m + 0x22222222u) & top);  // m>=5, m>=6
-    obits += n + 3u * a3 + 2u * a2 + a1;
-}
-
 // the four fields of an RRR vector a query needs (the first 16 bytes of RrrDesc)
 struct RrrView {
     uint32_t off_rec, off_bits;
@@ -217,67 +201,50 @@ FMX_HD RrrRecord rrr_load_record(const uint8_t *base, const RrrView &d, uint32_t
 
 // decode the 15-bit block that holds bit `position` (0 <= position < length) from its record:
 // returns the block value; prefix = ones before the block (RRR:367-390 over the 16-block records).
-// kCompact: the vector is one of the wavelet tree's (COMPACT records); otherwise the sampled-suffix bitmap.
-template <bool kCompact>
 FMX_HD uint32_t rrr_decode_record(const uint8_t *base, const RrrView &d, const uint16_t *inv, const RrrRecord &rec,
                                   uint32_t position, uint32_t &prefix) {
     const uint32_t block_id = position / 15u;  // RRR:367
     const uint32_t j = block_id & 15u;
-    uint32_t ones, obits;
-    int cls;
-    if (kCompact) {
-        const bool upper = j >= 8u;
-        ones = (rec.ones_before & kRrrCompactMask) + (upper ? rec.ones_before >> kRrrCompactShift : 0u);  // RRR:370
-        obits = (rec.offset_bit & kRrrCompactMask) + (upper ? rec.offset_bit >> kRrrCompactShift : 0u);   // RRR:371-372
-        const uint32_t half = upper ? (uint32_t)(rec.classes >> 32) : (uint32_t)rec.classes;
-        rrr_scan_half(half, j & 7u, ones, obits);                 // RRR:376-380
-        cls = (int)((half >> (4u * (j & 7u))) & 15u);             // RRR:382
-    } else {
-        ones = rec.ones_before;  // RRR:370
-        obits = rec.offset_bit;  // RRR:371-372
-        rrr_scan_word(rec.classes, (int)j, ones, obits);         // RRR:376-380
-        cls = (int)((rec.classes >> (4 * j)) & 15);               // RRR:382
-    }
+    uint32_t ones = rec.ones_before;                          // RRR:370
+    uint32_t obits = rec.offset_bit;                          // RRR:371-372
+    rrr_scan_word(rec.classes, (int)j, ones, obits);          // RRR:376-380
+    const int cls = (int)((rec.classes >> (4 * j)) & 15);     // RRR:382
     const int nb = rrr_bits_needed(cls);                      // RRR:383
     const uint32_t *bits = reinterpret_cast<const uint32_t *>(base + ((uint64_t)d.off_bits << 3));
     const uint32_t off = ld_bits(bits, obits, nb);            // RRR:386
     prefix = ones;
     return rrr_inv_lookup(inv, cls, off);                     // RRR:387-390
 }
-template <bool kCompact>
 FMX_HD uint32_t rrr_decode(const uint8_t *base, const RrrView &d, const uint16_t *inv, uint32_t position,
                            uint32_t &prefix) {
     const RrrRecord rec = rrr_load_record(base, d, position);
-    return rrr_decode_record<kCompact>(base, d, inv, rec, position, prefix);
+    return rrr_decode_record(base, d, inv, rec, position, prefix);
 }
 
 // rankOnes(position) with the record fetched ahead of time by the caller (only when 0 <= position < length;
 // otherwise `rec` is not looked at)
 FMX_HD bool rrr_in_range(const RrrView &d, int32_t position) { return position >= 0 && position < d.length; }
-template <bool kCompact>
 FMX_HD int32_t rrr_rank1_record(const uint8_t *base, const RrrView &d, const uint16_t *inv, const RrrRecord &rec,
                                 int32_t position) {
     if (position < 0) return 0;
     if (position >= d.length) return d.total_ones;
     uint32_t prefix;
-    const uint32_t block = rrr_decode_record<kCompact>(base, d, inv, rec, (uint32_t)position, prefix);
+    const uint32_t block = rrr_decode_record(base, d, inv, rec, (uint32_t)position, prefix);
     const uint32_t t = (uint32_t)position % 15u;
     return (int32_t)(prefix + (uint32_t)fmx_popc(block & ((1u << t) - 1u)));  // RRR:393-395
 }
 
 // RRR:358-396
-template <bool kCompact>
 FMX_HD int32_t rrr_rank1(const uint8_t *base, const RrrView &d, const uint16_t *inv, int32_t position) {
     if (position < 0) return 0;
     if (position >= d.length) return d.total_ones;
     uint32_t prefix;
-    const uint32_t block = rrr_decode<kCompact>(base, d, inv, (uint32_t)position, prefix);
+    const uint32_t block = rrr_decode(base, d, inv, (uint32_t)position, prefix);
     const uint32_t t = (uint32_t)position % 15u;
     return (int32_t)(prefix + (uint32_t)fmx_popc(block & ((1u << t) - 1u)));  // RRR:393-395
 }
 
 // rankOnes(p) and access(p) from a record fetched ahead of time (see rrr_rank1_access)
-template <bool kCompact>
 FMX_HD int32_t rrr_rank1_access_record(const uint8_t *base, const RrrView &d, const uint16_t *inv, const RrrRecord &rec,
                                        int32_t position, bool &bit) {
     if (position >= d.length || position < 0) {
@@ -285,26 +252,24 @@ FMX_HD int32_t rrr_rank1_access_record(const uint8_t *base, const RrrView &d, co
         return position < 0 ? 0 : d.total_ones;
     }
     uint32_t prefix;
-    const uint32_t block = rrr_decode_record<kCompact>(base, d, inv, rec, (uint32_t)position, prefix);
+    const uint32_t block = rrr_decode_record(base, d, inv, rec, (uint32_t)position, prefix);
     const uint32_t t = (uint32_t)position % 15u;
     bit = (block >> t) & 1u;
     return (int32_t)(prefix + (uint32_t)fmx_popc(block & ((1u << t) - 1u)));
 }
 
 // RRR:314-349; out-of-range is reported through *status (IllegalArgumentException in the reference)
-template <bool kCompact>
 FMX_HD bool rrr_access(const uint8_t *base, const RrrView &d, const uint16_t *inv, int32_t position, int &status) {
     if (position < 0 || position >= d.length) {
         status = ST_JAVA_AIOOBE;
         return true;  // stops any walk that polls this bit
     }
     uint32_t prefix;
-    const uint32_t block = rrr_decode<kCompact>(base, d, inv, (uint32_t)position, prefix);
+    const uint32_t block = rrr_decode(base, d, inv, (uint32_t)position, prefix);
     return (block >> ((uint32_t)position % 15u)) & 1u;
 }
 
 // rankOnes(p) and access(p) at the same position p < length: one decode (WFBB:1389-1393)
-template <bool kCompact>
 FMX_HD int32_t rrr_rank1_access(const uint8_t *base, const RrrView &d, const uint16_t *inv, int32_t position,
                                 bool &bit) {
     if (position >= d.length || position < 0) {  // rankOnes saturates; access would throw — unreachable for a
@@ -312,10 +277,38 @@ FMX_HD int32_t rrr_rank1_access(const uint8_t *base, const RrrView &d, const uin
         return position < 0 ? 0 : d.total_ones;
     }
     uint32_t prefix;
-    const uint32_t block = rrr_decode<kCompact>(base, d, inv, (uint32_t)position, prefix);
+    const uint32_t block = rrr_decode(base, d, inv, (uint32_t)position, prefix);
     const uint32_t t = (uint32_t)position % 15u;
     bit = (block >> t) & 1u;
     return (int32_t)(prefix + (uint32_t)fmx_popc(block & ((1u << t) - 1u)));
+}
+
+// ---- the wavelet tree's bit vectors: expanded 96-bit cells (fmx_blob.hpp BvCell) -------------------------------
+// rankOnes / access with RrrVector's semantics (RRR:358-396, 314-349): rank saturates outside [0, length)
+FMX_HD const BvCell *bv_cell_ptr(const uint8_t *base, const RrrView &d, uint32_t position) {
+    return reinterpret_cast<const BvCell *>(base + ((uint64_t)d.off_rec << 3)) + position / kBvCellBits;
+}
+// ones among the first r (0 <= r < 96) bits of a cell
+FMX_HD uint32_t bv_cell_prefix(const Quad &cell, uint32_t r) {
+    const uint64_t lo = (uint64_t)cell.y | ((uint64_t)cell.z << 32);  // bits 0..63
+    const uint32_t r_lo = r < 64u ? r : 64u, r_hi = r < 64u ? 0u : r - 64u;
+    const uint64_t m_lo = r_lo >= 64u ? ~0ull : ((1ull << r_lo) - 1ull);
+    return (uint32_t)fmx_popcll(lo & m_lo) + (uint32_t)fmx_popc(cell.w & ((1u << r_hi) - 1u));
+}
+FMX_HD int32_t bv_rank1_cell(const RrrView &d, const Quad &cell, int32_t position) {
+    if (position < 0) return 0;
+    if (position >= d.length) return d.total_ones;
+    return (int32_t)(cell.x + bv_cell_prefix(cell, (uint32_t)position % kBvCellBits));
+}
+FMX_HD int32_t bv_rank1_access_cell(const RrrView &d, const Quad &cell, int32_t position, bool &bit) {
+    if (position >= d.length || position < 0) {  // rankOnes saturates; access would throw — unreachable for a
+        bit = false;                             // well-formed tree (the node bit always exists)
+        return position < 0 ? 0 : d.total_ones;
+    }
+    const uint32_t r = (uint32_t)position % kBvCellBits;
+    const uint32_t word = r < 32u ? cell.y : (r < 64u ? cell.z : cell.w);
+    bit = (word >> (r & 31u)) & 1u;
+    return (int32_t)(cell.x + bv_cell_prefix(cell, r));
 }
 
 // WFBB:250-278: block-local leaf index -> canonical (code, length).  The per-level leaf counts are the
@@ -534,13 +527,12 @@ FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t positio
     if (tree_height > 0) {
         chunk = ld_quad(hdr);  // level entries 0..3 (guard bytes cover the tail)
         counts0 = ld16(hdr + second0);
-        if (rrr_in_range(rv, position0)) rec_q = ld_quad(rrr_record_ptr(ix.base, rv, (uint32_t)position0));
+        if (rrr_in_range(rv, position0)) rec_q = ld_quad(bv_cell_ptr(ix.base, rv, (uint32_t)position0));
     }
     FMX_OPAQUE64(leaf);
     FMX_PIN_QUAD(chunk);
     FMX_OPAQUE32(counts0);
     FMX_PIN_QUAD(rec_q);
-    RrrRecord rec = rrr_record_from(rec_q);
     if ((int32_t)(leaf & 0xffffu) != symbol) {    // WFBB:1123-1130: clamped mapping entry
         ++block_c;
         leaf = ld64u(leaves + 5 * block_c);
@@ -574,7 +566,7 @@ FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t positio
     int32_t rrr_position = position0;
     FMX_NO_UNROLL  // one copy of the level code: peeled copies only add instruction-cache pressure
     for (int32_t depth = 0; depth < code_length; ++depth) {
-        int32_t rank1 = rrr_rank1_record<true>(ix.base, rv, inv, rec, rrr_position);
+        int32_t rank1 = bv_rank1_cell(rv, rec_q, rrr_position);
         rank1 -= t.bv_rank + left_ones;
         t.bv_rank += level_ones;
         tree_descend(t, (code & (1u << (code_length - depth - 1))) != 0, rank1, node_ones);
@@ -584,11 +576,10 @@ FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t positio
             uint32_t raw_pair, raw_level;
             tree_level_counts_load(t, raw_pair, raw_level);
             rrr_position = t.bv_offset + t.left_total_bv + t.node_rank;
-            if (rrr_in_range(rv, rrr_position)) rec_q = ld_quad(rrr_record_ptr(ix.base, rv, (uint32_t)rrr_position));
+            if (rrr_in_range(rv, rrr_position)) rec_q = ld_quad(bv_cell_ptr(ix.base, rv, (uint32_t)rrr_position));
             FMX_OPAQUE32(raw_pair);
             FMX_OPAQUE32(raw_level);
             FMX_PIN_QUAD(rec_q);
-            rec = rrr_record_from(rec_q);
             tree_level_counts_decode(t, raw_pair, raw_level, left_ones, node_ones, level_ones);
         }
     }
@@ -638,11 +629,10 @@ FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32
     Quad chunk = ld_quad(hdr);  // level entries 0..3 (guard bytes cover the tail)
     uint32_t counts0 = ld16(hdr + second0);
     Quad rec_q = {0, 0, 0, 0};
-    if (rrr_in_range(rv, rrr_position)) rec_q = ld_quad(rrr_record_ptr(ix.base, rv, (uint32_t)rrr_position));
+    if (rrr_in_range(rv, rrr_position)) rec_q = ld_quad(bv_cell_ptr(ix.base, rv, (uint32_t)rrr_position));
     FMX_PIN_QUAD(chunk);
     FMX_OPAQUE32(counts0);
     FMX_PIN_QUAD(rec_q);
-    RrrRecord rec = rrr_record_from(rec_q);
 
     const uint32_t cur_block_size = (ix.wt_size - (position - block_index)) < block_size
                                         ? (ix.wt_size - (position - block_index))
@@ -668,7 +658,7 @@ FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32
     FMX_NO_UNROLL
     for (int32_t depth = 0;; ++depth) {
         bool next_bit;
-        int32_t rank1 = rrr_rank1_access_record<true>(ix.base, rv, inv, rec, rrr_position, next_bit);
+        int32_t rank1 = bv_rank1_access_cell(rv, rec_q, rrr_position, next_bit);
         rank1 -= t.bv_rank + left_ones;
         t.bv_rank += level_ones;
         code = (code << 1) | (next_bit ? 1u : 0u);
@@ -684,11 +674,10 @@ FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32
             uint32_t raw_pair, raw_level;
             tree_level_counts_load(t, raw_pair, raw_level);
             rrr_position = t.bv_offset + t.left_total_bv + t.node_rank;
-            if (rrr_in_range(rv, rrr_position)) rec_q = ld_quad(rrr_record_ptr(ix.base, rv, (uint32_t)rrr_position));
+            if (rrr_in_range(rv, rrr_position)) rec_q = ld_quad(bv_cell_ptr(ix.base, rv, (uint32_t)rrr_position));
             FMX_OPAQUE32(raw_pair);
             FMX_OPAQUE32(raw_level);
             FMX_PIN_QUAD(rec_q);
-            rec = rrr_record_from(rec_q);
             tree_level_counts_decode(t, raw_pair, raw_level, left_ones, node_ones, level_ones);
         } else {
             break;
@@ -779,7 +768,7 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
     int32_t j = start + 1 + k;  // FM:527-529
     distance = 0;
     const RrrView sv = {ix.sampled.off_rec, ix.sampled.off_bits, ix.sampled.length, ix.sampled.total_ones};
-    while (!rrr_access<false>(ix.base, sv, inv, j - 1, status)) {  // FM:531
+    while (!rrr_access(ix.base, sv, inv, j - 1, status)) {  // FM:531
         int32_t c;
         j = fm_lf_step(ix, inv, j, c, status);  // FM:532-535
         ++distance;
@@ -788,7 +777,7 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
             break;
         }
     }
-    const int32_t r = rrr_rank1<false>(ix.base, sv, inv, j) - 1;                  // FM:541
+    const int32_t r = rrr_rank1(ix.base, sv, inv, j) - 1;                  // FM:541
     return fm_packed_get(ix.suffix_words, r, ix.bw_suffixes) + distance;  // FM:538-542
 }
 

@@ -18,7 +18,8 @@
 
 namespace fmx {
 
-// Workgroup size is a template parameter (512 / 1024 threads); 32 KiB of LDS per workgroup.
+// Workgroup size is a template parameter (512 / 1024 threads).  Only k_locate_walk reads an RRR vector (the
+// sampled-suffix bitmap) and stages the 32 KiB value-of-offset table in LDS; the other kernels use no LDS.
 // FMX_WAVES_PER_EU asks the register allocator for 8 waves per SIMD (<= 64 VGPRs, <= 80 SGPRs): the
 // kernels are latency-bound chains of dependent loads, so resident waves are what hides latency.
 #define FMX_KERNEL(BLOCK) __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
@@ -67,8 +68,7 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix, const uint16_t *__restrict__ pat,
                                                   int32_t *__restrict__ counts, int32_t *__restrict__ lf_steps,
                                                   int32_t *__restrict__ status_out, int32_t *__restrict__ range_out,
                                                   int xcd_remap, const uint64_t *__restrict__ codes) {
-    __shared__ uint16_t s_inv[kInvEntries];
-    stage_inverse_table(s_inv, ix.inv_global);
+    const uint16_t *s_inv = nullptr;  // no RRR vector on this kernel's path (the wavelet tree's are expanded)
     const int role = threadIdx.x & 1;
     const int code_bits = plan_code_bits(ix.wt_sigma), n_codes = codes ? 64 / code_bits : 0;
     const uint32_t code_mask = (1u << code_bits) - 1u;
@@ -178,8 +178,7 @@ FMX_EXTRACT_KERNEL(kBlock) void k_extract(DevIndex ix, const int32_t *__restrict
                                   int32_t *__restrict__ out_len, int32_t *__restrict__ lf_steps,
                                   int32_t *__restrict__ status_out, const int32_t *__restrict__ slot_found,
                                   int32_t slots, int32_t fixed_len) {
-    __shared__ uint16_t s_inv[kInvEntries];
-    stage_inverse_table(s_inv, ix.inv_global);
+    const uint16_t *s_inv = nullptr;  // no RRR vector on this kernel's path (the wavelet tree's are expanded)
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) {
         if (slot_found && (int32_t)(q % slots) >= slot_found[q / slots]) continue;
@@ -210,8 +209,7 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary(DevIndex ix, const int32_t *
                                            int32_t *__restrict__ status_out, int32_t *__restrict__ aux_out,
                                            uint16_t *__restrict__ scratch, const int32_t *__restrict__ slot_found,
                                            int32_t slots) {
-    __shared__ uint16_t s_inv[kInvEntries];
-    stage_inverse_table(s_inv, ix.inv_global);
+    const uint16_t *s_inv = nullptr;  // no RRR vector on this kernel's path (the wavelet tree's are expanded)
     const int64_t lanes = (int64_t)gridDim.x * kBlock;
     const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int32_t mapped_boundary = fm_map(ix, boundary);  // FM:658
@@ -238,8 +236,7 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix, const int
                                                  int32_t *__restrict__ lf_steps, int32_t *__restrict__ status_out,
                                                  int32_t *__restrict__ aux_out, uint16_t *__restrict__ scratch,
                                                  const int32_t *__restrict__ slot_found, int32_t slots) {
-    __shared__ uint16_t s_inv[kInvEntries];
-    stage_inverse_table(s_inv, ix.inv_global);
+    const uint16_t *s_inv = nullptr;  // no RRR vector on this kernel's path (the wavelet tree's are expanded)
     const int64_t lanes = (int64_t)gridDim.x * kBlock;
     const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int g = threadIdx.x % G;
@@ -272,8 +269,7 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix, const int
 template <int kBlock>
 FMX_KERNEL(kBlock) void k_wt_rank(DevIndex ix, const int64_t *__restrict__ positions, const int32_t *__restrict__ symbols,
                                   int32_t n, int64_t *__restrict__ out, int32_t *__restrict__ status_out) {
-    __shared__ uint16_t s_inv[kInvEntries];
-    stage_inverse_table(s_inv, ix.inv_global);
+    const uint16_t *s_inv = nullptr;  // no RRR vector on this kernel's path (the wavelet tree's are expanded)
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) {
         int status = ST_OK;
@@ -296,8 +292,7 @@ FMX_KERNEL(kBlock) void k_wt_rank(DevIndex ix, const int64_t *__restrict__ posit
 template <int kBlock>
 FMX_KERNEL(kBlock) void k_wt_inverse_select(DevIndex ix, const int64_t *__restrict__ positions, int32_t n,
                                             int64_t *__restrict__ out, int32_t *__restrict__ status_out) {
-    __shared__ uint16_t s_inv[kInvEntries];
-    stage_inverse_table(s_inv, ix.inv_global);
+    const uint16_t *s_inv = nullptr;  // no RRR vector on this kernel's path (the wavelet tree's are expanded)
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) {
         const int64_t pos = positions[q];
