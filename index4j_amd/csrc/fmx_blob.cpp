@@ -182,7 +182,7 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
         if (m.map_keys[i] >= 0 && m.map_keys[i] < 65536) A.at<int16_t>(off)[m.map_keys[i]] = m.map_vals[i];
     h.off_suffixes = off8(put_packed(A, m.suffixes));
     h.off_positions = m.enable_extract ? off8(put_packed(A, m.positions)) : 0;
-    if (!flatten_rrr(A, m.sampled, h.sampled, err)) return -8;
+    if (!flatten_expanded(A, m.sampled, h.sampled, err)) return -8;
 
     off = A.alloc(kInvEntries * 2);  // classes 0..7 only; 8..15 are complements (fmx_blob.hpp)
     h.off_inv = off8(off);

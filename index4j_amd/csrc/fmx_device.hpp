@@ -311,6 +311,22 @@ FMX_HD int32_t bv_rank1_access_cell(const RrrView &d, const Quad &cell, int32_t 
     return (int32_t)(cell.x + bv_cell_prefix(cell, r));
 }
 
+// stand-alone forms (one load each); access reports an out-of-range position through *status like rrr_access
+FMX_HD int32_t bv_rank1(const uint8_t *base, const RrrView &d, int32_t position) {
+    if (position < 0) return 0;
+    if (position >= d.length) return d.total_ones;
+    return bv_rank1_cell(d, ld_quad(bv_cell_ptr(base, d, (uint32_t)position)), position);
+}
+FMX_HD bool bv_access(const uint8_t *base, const RrrView &d, int32_t position, int &status) {
+    if (position < 0 || position >= d.length) {
+        status = ST_JAVA_AIOOBE;
+        return true;  // stops any walk that polls this bit
+    }
+    bool bit;
+    (void)bv_rank1_access_cell(d, ld_quad(bv_cell_ptr(base, d, (uint32_t)position)), position, bit);
+    return bit;
+}
+
 // WFBB:250-278: block-local leaf index -> canonical (code, length).  The per-level leaf counts are the
 // u16 at stride 4 of the level table; up to four levels come from one 16-byte load.
 FMX_HD uint32_t quad_entry(const Quad &q, int i) {
@@ -768,7 +784,7 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
     int32_t j = start + 1 + k;  // FM:527-529
     distance = 0;
     const RrrView sv = {ix.sampled.off_rec, ix.sampled.off_bits, ix.sampled.length, ix.sampled.total_ones};
-    while (!rrr_access(ix.base, sv, inv, j - 1, status)) {  // FM:531
+    while (!bv_access(ix.base, sv, j - 1, status)) {  // FM:531 (sampledSuffixes.access)
         int32_t c;
         j = fm_lf_step(ix, inv, j, c, status);  // FM:532-535
         ++distance;
@@ -777,7 +793,7 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
             break;
         }
     }
-    const int32_t r = rrr_rank1(ix.base, sv, inv, j) - 1;                  // FM:541
+    const int32_t r = bv_rank1(ix.base, sv, j) - 1;                       // FM:541 (sampledSuffixes.rankOnes)
     return fm_packed_get(ix.suffix_words, r, ix.bw_suffixes) + distance;  // FM:538-542
 }
 

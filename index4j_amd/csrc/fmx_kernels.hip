@@ -138,8 +138,7 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix, const int32_t *__restric
                                                         int32_t *__restrict__ lf_steps,
                                                         int32_t *__restrict__ status_out,
                                                         const int32_t *__restrict__ taken) {
-    __shared__ uint16_t s_inv[kInvEntries];
-    stage_inverse_table(s_inv, ix.inv_global);
+    const uint16_t *s_inv = nullptr;  // no RRR vector on this kernel's path (the sampled-row bitmap is expanded)
     const int64_t total = (int64_t)n * slots;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
