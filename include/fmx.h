@@ -212,6 +212,16 @@ int fmx_wavelet_rank_batch(const fmx_index *idx, const int64_t *positions, const
 int fmx_wavelet_inverse_select_batch(const fmx_index *idx, const int64_t *positions, int32_t n, int64_t *packed,
                                      int32_t *status);
 
+/* ---- RrrVector as a stand-alone structure (the reference's public class, RRR:225-286) -------------------
+ * new RrrVector(BitVector, sampleSize): `bits` = one byte per bit.  The handle keeps the vector in its compressed
+ * form (15-bit blocks, class + offset) and answers only the two calls below, after fmx_to_device; free it
+ * with fmx_free.  (Inside an FM-index image the bit vectors are expanded instead, see fmx_blob.hpp.) */
+int fmx_rrr_build(const uint8_t *bits, int64_t n, int32_t sample_size, fmx_index **out);
+/* int rankOnes(int position) RRR:358-396, batched (0 below 0, totalOnes from length on) */
+int fmx_rrr_rank_ones_batch(const fmx_index *idx, const int32_t *positions, int32_t n, int32_t *ranks);
+/* boolean access(int position) RRR:314-349, batched; status = FMX_ST_JAVA_AIOOBE where the reference throws */
+int fmx_rrr_access_batch(const fmx_index *idx, const int32_t *positions, int32_t n, uint8_t *bits, int32_t *status);
+
 /* ---- helpers ------------------------------------------------------------------------------ */
 
 /* FmIndex.convertBytePatternToCharPattern FM:239-298.  Returns the number of chars, or -1 with

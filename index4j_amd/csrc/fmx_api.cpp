@@ -31,6 +31,8 @@ int launch_extract_boundary(const DevIndex &, int, const int32_t *, int64_t, uin
                             int32_t, int32_t *, int32_t *, int32_t *, int32_t *, void *, size_t, const int32_t *, int32_t,
                             hipStream_t);
 size_t boundary_workspace_bytes(const DevIndex &, int64_t n, int n_cu);
+int launch_rrr_rank_ones(const DevIndex &, int, const int32_t *, int32_t, int32_t *, hipStream_t);
+int launch_rrr_access(const DevIndex &, int, const int32_t *, int32_t, uint8_t *, int32_t *, hipStream_t);
 int launch_segment_add_counts(int64_t *, int64_t *, int32_t *, const int32_t *, const int32_t *, const int32_t *, int32_t,
                               int, hipStream_t);
 int launch_segment_append_hits(int64_t *, int32_t *, int32_t *, const int32_t *, const int32_t *, const int32_t *, int32_t,
@@ -51,6 +53,7 @@ struct fmx_index {
     int n_cu = 256;
     bool owns_device = false;
     bool wavelet_only = false;  // built by fmx_wavelet_build: only the wavelet entry points apply
+    bool rrr_only = false;      // built by fmx_rrr_build: only the RrrVector entry points apply
     fmx::DevIndex dev;
     // per-stream scratch for the in-library pattern sort (grow-only; freed with the index)
     mutable std::mutex ws_mutex;
@@ -81,7 +84,8 @@ int ensure_blob(fmx_index *idx) {
     if (!idx->blob.empty()) return FMX_OK;
     if (!idx->has_model) return fail(FMX_E_ARG, "index has neither a model nor a host blob");
     std::string err;
-    int rc = fmx::flatten_model(idx->model, idx->blob, err);
+    int rc = idx->rrr_only ? fmx::flatten_rrr_only(idx->model.sampled, idx->blob, err)
+                           : fmx::flatten_model(idx->model, idx->blob, err);
     if (rc) return fail(rc == -3 ? FMX_E_FORMAT : FMX_E_UNSUPPORTED, err);
     memcpy(&idx->hdr, idx->blob.data(), sizeof(fmx::BlobHeader));
     return FMX_OK;
@@ -163,8 +167,10 @@ void make_dev_index(fmx_index *idx) {
     d.wt_size = (uint32_t)h.wt_size;
 }
 
-int require_device(const fmx_index *idx) {
+int require_device(const fmx_index *idx, bool rrr_handle = false) {
     if (!idx) return fail(FMX_E_ARG, "null index");
+    if (idx->rrr_only != rrr_handle)
+        return fail(FMX_E_ARG, rrr_handle ? "not an RrrVector handle" : "an RrrVector handle answers only fmx_rrr_* calls");
     if (!idx->d_blob) return fail(FMX_E_NO_DEVICE, "index is not resident on a HIP device (call fmx_to_device)");
     return FMX_OK;
 }
@@ -316,7 +322,7 @@ int fmx_load(const uint8_t *ser, size_t len, fmx_index **out) {
 
 int fmx_save(const fmx_index *idx, int framed, uint8_t **buf, size_t *len) {
     if (!idx || !buf || !len) return fail(FMX_E_ARG, "null argument");
-    if (!idx->has_model || idx->wavelet_only)
+    if (!idx->has_model || idx->wavelet_only || idx->rrr_only)
         return fail(FMX_E_ARG, "nothing to serialize (device-attached or wavelet-only handle)");
     std::vector<uint8_t> out;
     fmx::emit_model(idx->model, framed != 0, out);
@@ -926,6 +932,58 @@ int fmx_wavelet_build(const int16_t *sequence, int64_t n, int32_t sampling_rate,
     idx->has_model = true;
     idx->wavelet_only = true;
     *out = idx.release();
+    return FMX_OK;
+}
+
+// ---- RrrVector as a stand-alone structure (the reference's public class sdsl/RrrVector.java) ----
+int fmx_rrr_build(const uint8_t *bits, int64_t n, int32_t sample_size, fmx_index **out) {
+    if (!out || (!bits && n > 0) || n < 0 || n >= ((int64_t)1 << 31) || sample_size <= 0) return fail(FMX_E_ARG, "bad arguments");
+    std::vector<uint64_t> words((size_t)(n / 64 + 2), 0);
+    for (int64_t i = 0; i < n; ++i)
+        if (bits[i]) words[(size_t)(i >> 6)] |= 1ull << (i & 63);
+    std::unique_ptr<fmx_index> idx(new fmx_index());
+    fmx::build_rrr(words.data(), n, sample_size, idx->model.sampled);  // RRR:225-286
+    idx->model.length = (int32_t)n;
+    idx->has_model = true;
+    idx->rrr_only = true;
+    *out = idx.release();
+    return FMX_OK;
+}
+
+int fmx_rrr_rank_ones_batch(const fmx_index *idx, const int32_t *positions, int32_t n, int32_t *ranks) {
+    int rc = require_device(idx, true);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!positions || !ranks))) return fail(FMX_E_ARG, "bad arguments");
+    if (n == 0) return FMX_OK;
+    HIP_TRY(hipSetDevice(idx->device));
+    DevBuf d_pos, d_out;
+    HIP_TRY(d_pos.alloc((size_t)n * 4));
+    HIP_TRY(d_out.alloc((size_t)n * 4));
+    H2D(d_pos.p, positions, (size_t)n * 4);
+    int e = fmx::launch_rrr_rank_ones(idx->dev, idx->n_cu, d_pos.as<int32_t>(), n, d_out.as<int32_t>(), nullptr);
+    if (e) return fail(FMX_E_HIP, std::string("k_rrr_rank_ones launch: ") + hipGetErrorString((hipError_t)e));
+    HIP_TRY(hipDeviceSynchronize());
+    D2H(ranks, d_out.p, (size_t)n * 4);
+    return FMX_OK;
+}
+
+int fmx_rrr_access_batch(const fmx_index *idx, const int32_t *positions, int32_t n, uint8_t *bits, int32_t *status) {
+    int rc = require_device(idx, true);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!positions || !bits))) return fail(FMX_E_ARG, "bad arguments");
+    if (n == 0) return FMX_OK;
+    HIP_TRY(hipSetDevice(idx->device));
+    DevBuf d_pos, d_out, d_st;
+    HIP_TRY(d_pos.alloc((size_t)n * 4));
+    HIP_TRY(d_out.alloc((size_t)n));
+    HIP_TRY(d_st.alloc((size_t)n * 4));
+    H2D(d_pos.p, positions, (size_t)n * 4);
+    int e = fmx::launch_rrr_access(idx->dev, idx->n_cu, d_pos.as<int32_t>(), n, d_out.as<uint8_t>(), d_st.as<int32_t>(),
+                                   nullptr);
+    if (e) return fail(FMX_E_HIP, std::string("k_rrr_access launch: ") + hipGetErrorString((hipError_t)e));
+    HIP_TRY(hipDeviceSynchronize());
+    D2H(bits, d_out.p, (size_t)n);
+    if (status) D2H(status, d_st.p, (size_t)n * 4);
     return FMX_OK;
 }
 

@@ -2,7 +2,10 @@
 #include "fmx_blob.hpp"
 #include "fmx_model.hpp"
 
+#include <atomic>
 #include <cstring>
+#include <mutex>
+#include <thread>
 
 namespace fmx {
 namespace {
@@ -64,27 +67,39 @@ bool flatten_rrr(Arena &A, const RrrModel &r, RrrDesc &d, std::string &err) {
     return true;
 }
 
-// RRR:92-103 -> expanded 96-bit cells with running one-counts (the wavelet tree's vectors; see fmx_blob.hpp)
-bool flatten_expanded(Arena &A, const RrrModel &r, RrrDesc &d, std::string &err) {
+// RRR:92-103 -> expanded 96-bit cells with running one-counts (see fmx_blob.hpp).  Two steps so that the
+// decoding of many vectors can run on many threads once all regions are allocated: reserve, then fill.
+struct ExpandJob {
+    const RrrModel *r;
+    size_t cell_off;
+    int64_t n_cells;
+};
+bool expanded_reserve(Arena &A, const RrrModel &r, RrrDesc &d, ExpandJob &job, std::string &err) {
     if (r.classes.width != 4) {
         err = "unsupported RRR parameters";
         return false;
     }
-    const uint8_t *bits_needed = rrr_bits_needed();
-    const uint16_t *value_of = rrr_value_of_offset(), *class_base = rrr_class_base();
-    const int64_t n_blocks = r.classes.length;
     const int64_t n_cells = (int64_t)r.length / kBvCellBits + 2;  // + a cell for position == length and a guard
     d.n_rec = (int32_t)n_cells;
-    d.n_blocks = (int32_t)n_blocks;
+    d.n_blocks = r.classes.length;
     d.length = r.length;
     d.total_ones = r.total_ones;
     d.sample = r.sample_size;
     d.pad = 0;
     d.off_bits = 0;
-    const size_t cell_off = A.alloc((size_t)n_cells * sizeof(BvCell));
-    d.off_rec = off8(cell_off);
+    job.r = &r;
+    job.n_cells = n_cells;
+    job.cell_off = A.alloc((size_t)n_cells * sizeof(BvCell));
+    d.off_rec = off8(job.cell_off);
+    return true;
+}
+bool expanded_fill(BvCell *cells, const ExpandJob &job, std::string &err) {
+    const RrrModel &r = *job.r;
+    const uint8_t *bits_needed = rrr_bits_needed();
+    const uint16_t *value_of = rrr_value_of_offset(), *class_base = rrr_class_base();
+    const int64_t n_blocks = r.classes.length;
     // RRR:382-390 for every block: (class, offset) -> 15 bits, into a plain LSB-first bit array ...
-    std::vector<uint64_t> plain((size_t)((int64_t)n_cells * kBvCellBits / 64 + 2), 0);
+    std::vector<uint64_t> plain((size_t)(job.n_cells * kBvCellBits / 64 + 2), 0);
     uint64_t obits = 0;
     const uint64_t avail = (uint64_t)r.offsets.size() * 64;
     for (int64_t b = 0; b < n_blocks; ++b) {
@@ -102,16 +117,19 @@ bool flatten_expanded(Arena &A, const RrrModel &r, RrrDesc &d, std::string &err)
         obits += (uint64_t)nb;
         const uint64_t value = value_of[(size_t)class_base[cls] + (size_t)off];
         const int64_t pos = b * 15;
+        if (pos + 15 > job.n_cells * (int64_t)kBvCellBits) {
+            err = "RRR vector has more blocks than its length";
+            return false;
+        }
         const size_t pw = (size_t)(pos >> 6);
         const int ps = (int)(pos & 63);
         plain[pw] |= value << ps;
         if (ps + 15 > 64) plain[pw + 1] |= value >> (64 - ps);
     }
     // ... cut into 96-bit cells with running one-counts (bits past `length` are zero: RRR pads its last block)
-    BvCell *cells = A.at<BvCell>(cell_off);
     const uint32_t *plain32 = reinterpret_cast<const uint32_t *>(plain.data());
     uint64_t ones = 0;
-    for (int64_t c = 0; c < n_cells; ++c) {
+    for (int64_t c = 0; c < job.n_cells; ++c) {
         BvCell cell;
         cell.ones_before = (uint32_t)ones;
         for (int k = 0; k < 3; ++k) {
@@ -134,6 +152,27 @@ size_t put_packed(Arena &A, const PackedVec &v) {
 }
 
 }  // namespace
+
+// a stand-alone RrrVector (fmx_rrr_build): header + value-of-offset table + the vector in its compressed form
+int flatten_rrr_only(const RrrModel &r, std::vector<uint8_t> &blob, std::string &err) {
+    blob.clear();
+    Arena A{blob};
+    const size_t hdr_off = A.alloc(sizeof(BlobHeader));
+    BlobHeader h;
+    memset(&h, 0, sizeof h);
+    h.magic = kBlobMagic;
+    h.version = kBlobVersion;
+    h.length = r.length;
+    h.sample_rate = r.sample_size;
+    const size_t inv_off = A.alloc((size_t)kInvEntries * 2);
+    memcpy(A.at<uint8_t>(inv_off), rrr_value_of_offset(), (size_t)kInvEntries * 2);  // classes 0..7 come first
+    h.off_inv = off8(inv_off);
+    if (!flatten_rrr(A, r, h.sampled, err)) return -8;
+    A.alloc(64);
+    h.total_bytes = blob.size();
+    memcpy(A.at<uint8_t>(hdr_off), &h, sizeof h);
+    return 0;
+}
 
 int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err) {
     const WfbbModel &w = m.wt;
@@ -182,11 +221,10 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
         if (m.map_keys[i] >= 0 && m.map_keys[i] < 65536) A.at<int16_t>(off)[m.map_keys[i]] = m.map_vals[i];
     h.off_suffixes = off8(put_packed(A, m.suffixes));
     h.off_positions = m.enable_extract ? off8(put_packed(A, m.positions)) : 0;
-    if (!flatten_expanded(A, m.sampled, h.sampled, err)) return -8;
+    std::vector<ExpandJob> jobs((size_t)n_sb + 1);
+    if (!expanded_reserve(A, m.sampled, h.sampled, jobs[(size_t)n_sb], err)) return -8;
 
-    off = A.alloc(kInvEntries * 2);  // classes 0..7 only; 8..15 are complements (fmx_blob.hpp)
-    h.off_inv = off8(off);
-    memcpy(A.at<uint8_t>(off), rrr_value_of_offset(), kInvEntries * 2);
+    h.off_inv = 0;  // no compressed RRR vector in an FM-index image (all bit vectors are expanded)
 
     // fused (rank, superblock code) table; row n_sb = total counts (WFBB:1063-1069)
     off = A.alloc((size_t)(n_sb + 1) * sigma * sizeof(SbcEntry));
@@ -254,10 +292,36 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
         d.off_var = off8(off);
         d.var_len = (int32_t)sb.var.size();
         if (!sb.var.empty()) memcpy(A.at<uint8_t>(off), sb.var.data(), sb.var.size());
-        if (!flatten_expanded(A, sb.rank_support, d.rrr, err)) return -8;
+        if (!expanded_reserve(A, sb.rank_support, d.rrr, jobs[(size_t)s], err)) return -8;
         *A.at<SbDesc>(sbd_off + (size_t)s * sizeof(SbDesc)) = d;
     }
     A.alloc(64);  // tail guard
+    {
+        // all regions exist (the arena no longer moves): decode the bit vectors on all cores
+        std::atomic<size_t> next{0};
+        std::mutex err_mutex;
+        bool failed = false;
+        auto worker = [&]() {
+            for (;;) {
+                const size_t j = next.fetch_add(1);
+                if (j >= jobs.size()) return;
+                std::string local;
+                if (!expanded_fill(A.at<BvCell>(jobs[j].cell_off), jobs[j], local)) {
+                    std::lock_guard<std::mutex> lock(err_mutex);
+                    failed = true;
+                    err = local;
+                }
+            }
+        };
+        unsigned n_threads = std::thread::hardware_concurrency();
+        if (n_threads == 0) n_threads = 1;
+        if (n_threads > jobs.size()) n_threads = (unsigned)jobs.size();
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto &t : pool) t.join();
+        if (failed) return -8;
+    }
     h.total_bytes = blob.size();
     if (blob.size() >= ((uint64_t)1 << 35)) {
         err = "blob exceeds 32 GiB";

@@ -309,6 +309,35 @@ FMX_KERNEL(kBlock) void k_wt_inverse_select(DevIndex ix, const int64_t *__restri
     }
 }
 
+// RrrVector as a stand-alone structure (fmx_rrr_*): the compressed form — 16-block records, offset bit stream,
+// and the halved value-of-offset table staged in LDS (32 KiB per workgroup).
+// rankOnes(position) RRR:358-396
+template <int kBlock>
+FMX_KERNEL(kBlock) void k_rrr_rank_ones(DevIndex ix, const int32_t *__restrict__ positions, int32_t n,
+                                        int32_t *__restrict__ out) {
+    __shared__ uint16_t s_inv[kInvEntries];
+    stage_inverse_table(s_inv, ix.inv_global);
+    const RrrView v = {ix.sampled.off_rec, ix.sampled.off_bits, ix.sampled.length, ix.sampled.total_ones};
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride)
+        out[q] = rrr_rank1(ix.base, v, s_inv, positions[q]);
+}
+// access(position) RRR:314-349; an out-of-range position is the reference's exception (status)
+template <int kBlock>
+FMX_KERNEL(kBlock) void k_rrr_access(DevIndex ix, const int32_t *__restrict__ positions, int32_t n,
+                                     uint8_t *__restrict__ out, int32_t *__restrict__ status_out) {
+    __shared__ uint16_t s_inv[kInvEntries];
+    stage_inverse_table(s_inv, ix.inv_global);
+    const RrrView v = {ix.sampled.off_rec, ix.sampled.off_bits, ix.sampled.length, ix.sampled.total_ones};
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) {
+        int status = ST_OK;
+        const bool bit = rrr_access(ix.base, v, s_inv, positions[q], status);
+        out[q] = status ? 0 : (bit ? 1 : 0);
+        if (status_out) status_out[q] = status;
+    }
+}
+
 // ---- processing order of a batch -------------------------------------------------------------------
 // Patterns are processed in (approximate) order of their trailing characters, the LAST character most
 // significant (it is consumed first, FM:456-457): lanes of a wave then start their backward search in the
@@ -673,6 +702,18 @@ int launch_wt_inverse_select(const DevIndex &ix, int n_cu, const int64_t *pos, i
                              hipStream_t st) {
     if (n <= 0) return 0;
     FMX_DISPATCH(k_wt_inverse_select, (int64_t)n, ix, pos, n, out, status);
+    return (int)hipGetLastError();
+}
+
+int launch_rrr_rank_ones(const DevIndex &ix, int n_cu, const int32_t *pos, int32_t n, int32_t *out, hipStream_t st) {
+    if (n <= 0) return 0;
+    FMX_DISPATCH(k_rrr_rank_ones, (int64_t)n, ix, pos, n, out);
+    return (int)hipGetLastError();
+}
+int launch_rrr_access(const DevIndex &ix, int n_cu, const int32_t *pos, int32_t n, uint8_t *out, int32_t *status,
+                      hipStream_t st) {
+    if (n <= 0) return 0;
+    FMX_DISPATCH(k_rrr_access, (int64_t)n, ix, pos, n, out, status);
     return (int)hipGetLastError();
 }
 

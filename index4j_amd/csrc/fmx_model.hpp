@@ -126,5 +126,6 @@ void emit_model(const FmModel &m, bool framed, std::vector<uint8_t> &out);
 
 // fmx_blob.cpp
 int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err);
+int flatten_rrr_only(const RrrModel &r, std::vector<uint8_t> &blob, std::string &err);
 
 }  // namespace fmx

@@ -487,3 +487,41 @@ def test_device_construction_is_byte_identical():
     host = ia.FmIndex(t, 32, True, device=None)
     dev = ia.FmIndex(t, 32, True, device=None, build_device=0)
     assert dev.write(False) == host.write(False)
+
+
+def test_standalone_rrr_vector_kats_and_random_vs_oracle():
+    """RrrVectorTest on the GPU (T-RRR:70-249): the compressed RrrVector (records + offset stream + value table in
+    LDS) as a stand-alone structure — known answers, corner cases, and random vectors at every sample size
+    against the oracle and a plain prefix sum"""
+    bits = np.zeros(1024, np.uint8)
+    for i in (0, 2, 11, 18, 19, 20, 199, 512):
+        bits[i] = 1
+    r = ia.RrrVector(bits, 32)  # T-RRR:70-100
+    assert [r.access(i) for i in (0, 1, 2, 15, 19, 199, 512)] == [True, False, True, False, True, True, True]
+    assert [r.rankOnes(i) for i in range(4)] == [0, 1, 1, 2]
+    assert [r.rankZeroes(i) for i in range(4)] == [0, 0, 1, 1]
+    b64 = np.array([(5 >> i) & 1 for i in range(32)] + [(1 >> i) & 1 for i in range(32)], np.uint8)
+    r = ia.RrrVector(b64, 32)  # T-RRR:102-173
+    assert (r.rankZeroes(0), r.rankOnes(0), r.rankZeroes(1), r.rankOnes(1)) == (0, 0, 0, 1)
+    assert (r.rankZeroes(64), r.rankOnes(64)) == (61, 3) and (r.rankZeroes(-1), r.rankOnes(-1)) == (0, 0)
+    for bad in (9999, -1):
+        with pytest.raises(ValueError):
+            r.access(bad)
+    with pytest.raises(ia.FmxError):  # an RrrVector handle is not an FM-index
+        ia.lib.fmx_input_length  # (attribute exists)
+        ia._lib.check(ia.lib.fmx_count_batch(r._h, None, None, 0, None, None, None), "fmx_count_batch")
+    for sample in (1, 2, 7, 32, 256):  # T-RRR:175-249
+        rng = np.random.default_rng(42 + sample)
+        for n, dens in ((1, 0.5), (15, 0.5), (16, 1.0), (1000, 0.25), (100_003, 0.05), (50_000, 0.9), (300_000, 0.5)):
+            b = (rng.random(n) < dens).astype(np.uint8)
+            g = ia.RrrVector(b, sample)
+            o = orc.Rrr(bits=b, sample=sample)
+            ps = np.concatenate([[0], np.cumsum(b)])
+            pos = np.unique(np.concatenate([rng.integers(0, n, 3000), [0, n - 1, n, n + 100, -1]])).astype(np.int32)
+            ranks = g.rank_ones_batch(pos)
+            acc, st = g.access_batch(pos)
+            inside = (pos >= 0) & (pos < n)
+            assert (ranks[inside] == ps[pos[inside]]).all() and (acc[inside] == b[pos[inside]]).all()
+            assert (st[inside] == 0).all() and (st[~inside] == 9).all()
+            for p_ in pos[:50].tolist() + pos[-5:].tolist():
+                assert ranks[list(pos).index(p_)] == o.rank_ones(int(p_))
