@@ -164,6 +164,7 @@ void make_dev_index(fmx_index *idx) {
     d.bw_suffixes = h.bw_suffixes;
     d.bw_positions = h.bw_positions;
     d.n_positions = h.n_positions;
+    d.n_c = h.n_c;
     d.wt_size = (uint32_t)h.wt_size;
 }
 

@@ -240,6 +240,8 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
                 e.sbc = (int16_t)(sigma - 1);
             }
             e.pad = 0;
+            // folded: + cumulativeCounts[c] (FM:103), so that an LF-step's C[c] + rank is one table entry
+            if ((size_t)c < m.C.size()) e.rank += m.C[(size_t)c];
             A.at<SbcEntry>(off)[s * sigma + c] = e;
         }
 

@@ -35,7 +35,7 @@
 namespace fmx {
 
 constexpr uint32_t kBlobMagic = 0x31584D46u;  // "FMX1"
-constexpr uint32_t kBlobVersion = 5;
+constexpr uint32_t kBlobVersion = 6;
 
 struct RrrRecord {         // 16 bytes: 16 blocks of 15 bits
     uint32_t ones_before;  // 1-bits in all earlier blocks
@@ -87,7 +87,7 @@ struct BlockHdr {          // 16 bytes, WFBB:1589-1595
 };
 
 struct SbcEntry {          // 8 bytes
-    int32_t rank;          // hyperBlockRank + superBlockRank of the symbol at the superblock start
+    int32_t rank;          // cumulativeCounts[symbol] (FM:103) + hyperBlockRank + superBlockRank at the superblock start
     int16_t sbc;           // globalMapping: superblock-local code, sigma-1 = absent
     int16_t pad;
 };

@@ -55,7 +55,7 @@ struct DevIndex {
     const uint16_t *inv_global;  // value-of-offset table (staged into LDS by the kernels)
     RrrDesc sampled;             // sampledSuffixes             FM:123
     int32_t length, sample_rate, enable_extract;
-    int32_t wt_sigma, n_sb, bw_suffixes, bw_positions, n_positions;
+    int32_t wt_sigma, n_sb, bw_suffixes, bw_positions, n_positions, n_c;
     uint32_t wt_size;
 };
 
@@ -470,16 +470,23 @@ FMX_HD int32_t tree_next_level_entry(TreeWalk &t, uint32_t e) {
 // `suspect` is set when the value came through a path where the reference is known to misbehave (next-block
 // path onto a run block or through a clamped mapping entry, Q2/Q11; out-of-range superblock, Q3): callers
 // that replace the reference's access pattern by an equivalent one only do so on un-suspect results.
-FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t symbol, int &status,
-                       bool &suspect) {
-    if (position == 0) return 0;                       // WFBB:1012-1014
-    if (position > ix.wt_size) position = ix.wt_size;  // WFBB:1015-1017
-    if (symbol >= ix.wt_sigma) return 0;               // WFBB:1018-1020
-    const uint32_t sb_id = position >> 20;             // WFBB:1023
-    if (sb_id >= (uint32_t)ix.n_sb || symbol < 0) {    // Q3: the JVM raises ArrayIndexOutOfBounds here
+//
+// The SbcEntry table stores rank + cumulativeCounts[symbol] ("folded"): every LF-step adds C[c] to the rank
+// (FM:469-470, 534-535), and with the sum in the table that is one load less per step.  wt_rank_folded returns
+// C[symbol] + rank; wt_rank (the reference's value) subtracts it again for callers outside the FM-index.
+FMX_HD int32_t fm_c_or_zero(const DevIndex &ix, int32_t symbol) {
+    return (symbol >= 0 && symbol < ix.n_c) ? ix.C[symbol] : 0;
+}
+FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t symbol, int &status,
+                              bool &suspect) {
+    if (position == 0) return fm_c_or_zero(ix, symbol);                 // WFBB:1012-1014
+    if (position > ix.wt_size) position = ix.wt_size;                   // WFBB:1015-1017
+    if (symbol >= ix.wt_sigma) return fm_c_or_zero(ix, symbol);         // WFBB:1018-1020
+    const uint32_t sb_id = position >> 20;                              // WFBB:1023
+    if (sb_id >= (uint32_t)ix.n_sb || symbol < 0) {  // Q3: the JVM raises ArrayIndexOutOfBounds here
         status = ST_JAVA_AIOOBE;
         suspect = true;
-        return 0;
+        return fm_c_or_zero(ix, symbol);
     }
     // The loads of one rank form a dependent chain (superblock -> mapping -> block header -> leaf -> levels);
     // what a stage needs is requested as soon as its address is known, so that the chain is
@@ -523,7 +530,7 @@ FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t positio
         if (bh.tree_height == 0 || (int32_t)ld16(var + p - 2) != symbol) suspect = true;
         if (p < 0 || p + 2 >= sd.var_len) {
             status = ST_JAVA_AIOOBE;
-            return 0;
+            return fm_c_or_zero(ix, symbol);
         }
         return e.rank + (int32_t)(ld32u(var + p) & 0xffffffu);  // WFBB:1096-1108
     }
@@ -602,6 +609,15 @@ FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t positio
     return e.rank + rank_block + t.node_rank;  // WFBB:1281-1284
 }
 
+FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t symbol, int &status) {
+    bool suspect = false;
+    return wt_rank_folded(ix, inv, position, symbol, status, suspect);
+}
+// WaveletFixedBlockBoosting.rank as the reference returns it
+FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t symbol, int &status,
+                       bool &suspect) {
+    return wt_rank_folded(ix, inv, position, symbol, status, suspect) - fm_c_or_zero(ix, symbol);
+}
 FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t symbol, int &status) {
     bool suspect = false;
     return wt_rank(ix, inv, position, symbol, status, suspect);
@@ -609,8 +625,9 @@ FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t positio
 
 // WFBB:1305-1537: returns the symbol at `position` (< size); *rank = occurrences before it
 // (the reference packs (rank << 32) | symbol and returns the bare symbol when position == 0).
-FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t &rank_out,
-                                 int32_t &bsl_out) {
+// (rank_out is FOLDED: C[symbol] + occurrences before `position`, see wt_rank_folded)
+FMX_HD int32_t wt_inverse_select_folded(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t &rank_out,
+                                        int32_t &bsl_out) {
     // load chain (see wt_rank): {superblock header, RRR view} -> block header -> {level table, first level's
     // counts, first RRR record} -> offset bits -> ... -> leaf -> superblock rank of the symbol
     const uint32_t sb_id = position >> 20;
@@ -716,7 +733,9 @@ FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32
 
 FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t &rank_out) {
     int32_t bsl;
-    return wt_inverse_select(ix, inv, position, rank_out, bsl);
+    const int32_t c = wt_inverse_select_folded(ix, inv, position, rank_out, bsl);
+    rank_out -= fm_c_or_zero(ix, c);
+    return c;
 }
 
 // true when inverseSelect's symbol at `position` is the block's real symbol (false only for a run block
@@ -748,15 +767,15 @@ FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, 
     const uint32_t p = (uint32_t)(row - 1);
     int32_t rank_before;
     int32_t bsl_i;
-    const int32_t c = (int32_t)(int16_t)wt_inverse_select(ix, inv, p, rank_before, bsl_i);
+    const int32_t c = (int32_t)(int16_t)wt_inverse_select_folded(ix, inv, p, rank_before, bsl_i);  // C[c] + rank
     c_out = c;
     const uint32_t bsl = (uint32_t)bsl_i;
     const bool same_block = ((uint32_t)row & ((1u << bsl) - 1u)) != 0 && (uint32_t)row <= ix.wt_size;
     // a run block whose symbol is >= 256 reports a masked symbol: rank(row, masked c) must really be evaluated
     const bool exact_symbol = ix.wt_sigma <= 256 || wt_symbol_is_exact(ix, p, c);
     if (!exact_symbol) suspect = true;  // Q1
-    if (same_block && exact_symbol) return ix.C[c] + rank_before + 1;
-    return ix.C[c] + wt_rank(ix, inv, (uint32_t)row, c, status, suspect);
+    if (same_block && exact_symbol) return rank_before + 1;
+    return wt_rank_folded(ix, inv, (uint32_t)row, c, status, suspect);
 }
 FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, int32_t &c_out, int &status) {
     bool suspect = false;

@@ -108,7 +108,7 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix, const uint16_t *__restrict__ pat,
                         --back;
                         break;
                     }
-                    const int32_t mine = ix.C[c] + wt_rank(ix, s_inv, (uint32_t)(role ? end : start), c, status);
+                    const int32_t mine = wt_rank_folded(ix, s_inv, (uint32_t)(role ? end : start), c, status);  // C[c] + rank
                     const int32_t other = __shfl_xor(mine, 1);
                     start = role ? other : mine;  // FM:469
                     end = role ? mine : other;    // FM:470

@@ -35,6 +35,7 @@ static DevIndex make_index(const uint8_t *b) {
     d.bw_suffixes = h.bw_suffixes;
     d.bw_positions = h.bw_positions;
     d.n_positions = h.n_positions;
+    d.n_c = h.n_c;
     d.wt_size = (uint32_t)h.wt_size;
     return d;
 }
