@@ -539,6 +539,9 @@ static int g_boundary_group = 4;  // lanes per query of extractUntilBoundary (0 
 static int g_xcd_remap = 0;    // XCD-aware block order in k_count (measured slower: profiles/r01_i_xcd_remap.txt)
 static int g_lds_pad_kb = 0;   // experiment knob: extra dynamic LDS per workgroup (lowers occupancy)
 static int g_sort_min = 16384;  // batches at least this large are processed in suffix-sorted order (0 = never)
+// bins of the bucket pass = 2^coarse_bits (<= 14: they live in LDS).  Measured on configs[1] (tools/tune_coarse.py):
+// 14 bits: plan 0.091 ms, step 0.304 ms; 12 bits: 0.075 / 0.286 ms; 10 bits: 0.071 / 0.286 ms; 8 bits: 0.069 / 0.294 ms
+static int g_coarse_bits = 12;
 static int g_sort_bits = 28;    // full key width: floor(sort_bits / bits-per-code) trailing characters
 
 int set_option(const char *name, int value) {
@@ -559,6 +562,11 @@ int set_option(const char *name, int value) {
     if (!strcmp(name, "boundary_group")) {
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return -1;
         g_boundary_group = value;
+        return 0;
+    }
+    if (!strcmp(name, "coarse_bits")) {
+        if (value < 4 || value > kCoarseBitsMax) return -1;
+        g_coarse_bits = value;
         return 0;
     }
     if (!strcmp(name, "xcd_remap")) {
@@ -609,7 +617,7 @@ static SortShape sort_shape(const DevIndex &ix) {
     if (sh.chars < 1) sh.chars = 1;
     if (sh.chars > 64 / plan_code_bits(ix.wt_sigma)) sh.chars = 64 / plan_code_bits(ix.wt_sigma);
     sh.total_bits = sh.chars * sh.bits;
-    sh.coarse_bits = sh.total_bits < kCoarseBitsMax ? sh.total_bits : kCoarseBitsMax;
+    sh.coarse_bits = sh.total_bits < g_coarse_bits ? sh.total_bits : g_coarse_bits;
     return sh;
 }
 
