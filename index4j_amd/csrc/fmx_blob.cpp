@@ -258,29 +258,78 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
             err = "superblock mapping shape mismatch";
             return -3;
         }
-        off = A.alloc(sb.mapping.size() * 2 + 8);
+        off = A.alloc(sb.mapping.size() * sizeof(MapEntry) + 16);
         d.off_mapping = off8(off);
         d.mapping_len = (int32_t)sb.mapping.size();
         {
             // absent entries (alphabetSize - 1, WFBB:383-387) become skip pointers: -(distance to the next
             // block to the right holding the symbol, or to the end of the superblock)
-            int16_t *dst = A.at<int16_t>(off);
+            MapEntry *dst = A.at<MapEntry>(off);
             const int64_t per_row = (int64_t)1 << (20 - d.bsl);
             const int16_t absent = (int16_t)(sigma - 1);
             for (int64_t row = 0; row <= sb.sigma; ++row) {
                 int64_t next_present = per_row;
                 for (int64_t blk = per_row - 1; blk >= 0; --blk) {
                     const int16_t v = sb.mapping[(size_t)(row * per_row + blk)];
+                    int16_t raw;
                     if (v != absent) {
                         if (v < 0) {
                             err = "negative mapping entry";
                             return -3;
                         }
                         next_present = blk;
-                        dst[row * per_row + blk] = v;
+                        raw = v;
                     } else {
-                        dst[row * per_row + blk] = (int16_t)(-(next_present - blk));
+                        raw = (int16_t)(-(next_present - blk));
                     }
+                    // until the block's header has been read (below) a present entry takes the reference's route
+                    dst[row * per_row + blk] = MapEntry{(uint32_t)(uint16_t)raw | (kMapSlow << 16), 0, 0, 0};
+                }
+            }
+            // what rank() needs about every (symbol, block) that occurs, from the block's own header
+            const uint8_t *var = sb.var.data();
+            const int64_t var_len = (int64_t)sb.var.size();
+            for (int64_t blk = 0; blk < (int64_t)sb.block_headers.size() && blk < per_row; ++blk) {
+                const BlockHeader &bh = sb.block_headers[(size_t)blk];
+                const int h = bh.tree_height, n_leaves = (int)bh.sigma + 1;
+                if (h < 0 || n_leaves <= 0 || bh.var_off < 0) continue;
+                const int64_t hdr = bh.var_off, leaves = hdr + (h > 0 ? (int64_t)(h - 1) * 4 : 0);
+                const int64_t second0 = (int64_t)(h - 1) * 4 + (int64_t)n_leaves * 5;
+                if (leaves + (int64_t)n_leaves * 5 > var_len || (h > 0 && hdr + second0 + 2 > var_len)) continue;
+                if (((uint32_t)bh.bv_offset | (uint32_t)bh.bv_rank) >> 24) continue;
+                const uint32_t counts0 = h > 0 ? (uint32_t)var[hdr + second0] | ((uint32_t)var[hdr + second0 + 1] << 8) : 0u;
+                for (int i = 0; i < n_leaves; ++i) {
+                    const uint8_t *lp = var + leaves + (int64_t)i * 5;
+                    const int symbol = (int)lp[0] | ((int)lp[1] << 8);
+                    const uint32_t rank_block = (uint32_t)lp[2] | ((uint32_t)lp[3] << 8) | ((uint32_t)lp[4] << 16);
+                    if (symbol >= sigma) continue;
+                    const int row = w.global_mapping[(size_t)(s * sigma + symbol)];
+                    if (row < 0 || row > sb.sigma) continue;
+                    MapEntry &e = dst[(int64_t)row * per_row + blk];
+                    if ((int16_t)(e.x & 0xffffu) < 0) continue;  // the mapping says absent: leave it to the reference's route
+                    // WFBB:250-278 restoreCodeFromBlockHeader for leaf i
+                    uint32_t code = 0, leaf_count = 0;
+                    int len = h > 0 ? 1 : 0;
+                    for (int lvl = 0; len < h && len > 0; ++lvl) {
+                        const uint32_t level_leaves = (uint32_t)var[hdr + 4 * lvl] | ((uint32_t)var[hdr + 4 * lvl + 1] << 8);
+                        code <<= 1;
+                        if (leaf_count + level_leaves > (uint32_t)i) {
+                            code += (uint32_t)i - leaf_count;
+                            break;
+                        }
+                        code += level_leaves;
+                        ++len;
+                        leaf_count += level_leaves;
+                    }
+                    if (h > 0 && len == h) {
+                        code <<= 1;
+                        code += (uint32_t)i - leaf_count;
+                    }
+                    if (len > 16 || (code >> 16)) continue;  // stays on the reference's route
+                    e.x = (e.x & 0xffffu) | ((uint32_t)len << 16) | ((counts0 >> 8) << 24);
+                    e.y = rank_block | ((counts0 & 0xffu) << 24);
+                    e.z = (uint32_t)bh.bv_offset | ((code & 0xffu) << 24);
+                    e.w = (uint32_t)bh.bv_rank | ((code >> 8) << 24);
                 }
             }
         }

@@ -35,7 +35,7 @@
 namespace fmx {
 
 constexpr uint32_t kBlobMagic = 0x31584D46u;  // "FMX1"
-constexpr uint32_t kBlobVersion = 6;
+constexpr uint32_t kBlobVersion = 7;
 
 struct RrrRecord {         // 16 bytes: 16 blocks of 15 bits
     uint32_t ones_before;  // 1-bits in all earlier blocks
@@ -68,10 +68,25 @@ struct RrrDesc {           // 32 bytes; the first 16 are what a rank needs (one 
     int32_t pad;
 };
 
+// One entry of the superblock's symbol -> block mapping (WFBB:461-471), widened from the reference's int16 to
+// everything rank() needs about (symbol, block) when the symbol occurs in the block — so that the common path
+// reads neither the leaf entry nor the level table and does not rebuild the canonical code:
+//   x = raw[15:0] | len[23:16] | counts0_hi[31:24]      raw: the reference's value (min(sigma-2, leaf index)), or
+//   y = rank_block[23:0] | counts0_lo[31:24]                  -(distance to the next block holding the symbol)
+//   z = bv_offset[23:0] | code_lo[31:24]                 len: canonical code length (0 = run block);
+//   w = bv_rank[23:0]   | code_hi[31:24]                      kMapSlow = take the reference's own route
+// rank_block = occurrences in the superblock before the block (the leaf's u24, WFBB:774-788); counts0 = ones
+// in the root node (first u16 of the cumulative counts, WFBB:793-809); bv_offset / bv_rank = the block's
+// BlockHeaderItem fields (WFBB:450-454).  The table is small (2 MB -> 17 MB on the 256 MiB log).
+struct MapEntry {
+    uint32_t x, y, z, w;
+};
+constexpr uint32_t kMapSlow = 0xffu;
+
 struct SbDesc {            // 64 bytes; bytes 0..15 = header of every rank, bytes 32..47 = its RRR vector
     int16_t sigma;         // WFBB:1623 (superblock alphabet size - 1)
     int16_t bsl;           // WFBB:1624 blockSizeLog
-    uint32_t off_mapping;  // int16[(sigma+1) << (20 - bsl)], absent entries = -(distance to next present)
+    uint32_t off_mapping;  // MapEntry[(sigma+1) << (20 - bsl)], absent entries: raw = -(distance to next present)
     uint32_t off_bh;       // BlockHdr[n_blocks]
     uint32_t off_var;      // variable-size block headers
     int32_t n_blocks;
@@ -113,6 +128,7 @@ struct BlobHeader {        // 256 bytes
 static_assert(sizeof(RrrDesc) == 32, "RrrDesc");
 static_assert(sizeof(RrrRecord) == 16, "RrrRecord");
 static_assert(sizeof(BvCell) == 16, "BvCell");
+static_assert(sizeof(MapEntry) == 16, "MapEntry");
 static_assert(sizeof(SbDesc) == 64, "SbDesc");
 static_assert(sizeof(BlockHdr) == 16, "BlockHdr");
 static_assert(sizeof(SbcEntry) == 8, "SbcEntry");

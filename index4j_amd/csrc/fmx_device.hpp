@@ -508,20 +508,22 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
     const int32_t blocks_log = 20 - bsl;
     const uint32_t block_index = position & (block_size - 1);
     uint32_t block_id = (position & 0xfffffu) >> bsl;
-    const int16_t *mapping = reinterpret_cast<const int16_t *>(ix.base + ((uint64_t)sh.off_mapping << 3));
+    const MapEntry *mapping = reinterpret_cast<const MapEntry *>(ix.base + ((uint64_t)sh.off_mapping << 3));
     const BlockHdr *bhs = reinterpret_cast<const BlockHdr *>(ix.base + ((uint64_t)sh.off_bh << 3));
     const uint8_t *var = ix.base + ((uint64_t)sh.off_var << 3);
     const uint32_t map_row = (uint32_t)e.sbc << blocks_log;
-    int32_t block_c = mapping[map_row + block_id];  // WFBB:1044-1046
-    Quad bhq = ld_quad(bhs + block_id);              // WFBB:1113, requested before the mapping entry is known
+    Quad mq = ld_quad(mapping + map_row + block_id);  // WFBB:1044-1046 (+ what the symbol's leaf would tell)
+    Quad bhq = ld_quad(bhs + block_id);               // WFBB:1113, requested before the mapping entry is known
+    FMX_PIN_QUAD(mq);
     FMX_PIN_QUAD(bhq);
+    int32_t block_c = (int32_t)(int16_t)(mq.x & 0xffffu);
 
     if (block_c < 0) {  // WFBB:1048-1110: absent; -block_c = distance to the closest block to the right that
                         // holds the symbol (what the scan of WFBB:1051-1059 finds), or to the superblock end
         block_id += (uint32_t)(-block_c);
         if (block_id == (1u << blocks_log))  // WFBB:1060-1069 (row n_sb of the table holds count[])
             return ix.sbc[(uint64_t)(sb_id + 1) * (uint32_t)ix.wt_sigma + (uint32_t)symbol].rank;
-        block_c = mapping[map_row + block_id];
+        block_c = (int32_t)(int16_t)(mapping[map_row + block_id].x & 0xffffu);
         const BlockHdr bh = ld_block_hdr(bhs + block_id);
         // WFBB:1080-1081: (treeHeight - 1) * 4 with no treeHeight > 0 guard, and no clamped-mapping fix-up
         const int32_t p = bh.var_off + ((int32_t)bh.tree_height - 1) * 4 + block_c * 5 + 2;
@@ -538,34 +540,47 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
     const BlockHdr bh = block_hdr_from(bhq);
     const int32_t tree_height = bh.tree_height;
     const uint8_t *hdr = var + bh.var_off;
-    const uint8_t *leaves = hdr + (tree_height > 0 ? (tree_height - 1) * 4 : 0);  // WFBB:1119-1121
-    // everything the first level needs hangs off the block header alone: ask for it together with the leaf
     const uint32_t second0 = (uint32_t)((tree_height - 1) * 4 + ((int32_t)bh.sigma + 1) * 5);  // WFBB:1177-1182
-    const int32_t position0 = bh.bv_offset + (int32_t)block_index;
-    uint64_t leaf;
-    memcpy(&leaf, leaves + 5 * block_c, 8);  // {u16 symbol, u24 rank at block start} + 3 bytes of the next entry
-    Quad chunk = {0, 0, 0, 0};
-    uint32_t counts0 = 0;
-    Quad rec_q = {0, 0, 0, 0};
-    if (tree_height > 0) {
-        chunk = ld_quad(hdr);  // level entries 0..3 (guard bytes cover the tail)
-        counts0 = ld16(hdr + second0);
+    const uint32_t map_len = (mq.x >> 16) & 0xffu;
+    int32_t rank_block, code_length, position0;
+    uint32_t code, counts0 = 0;
+    Quad chunk = {0, 0, 0, 0}, rec_q = {0, 0, 0, 0};
+    if (map_len != kMapSlow) {
+        // the mapping entry already holds what the leaf, the level table and restoreCode would give
+        // (WFBB:1119-1156): rank at block start, canonical code, the root's one-count, the block's bit-vector fields
+        rank_block = (int32_t)(mq.y & 0xffffffu);
+        code_length = (int32_t)map_len;
+        if (code_length == 0) return e.rank + rank_block + (int32_t)block_index;  // run block, WFBB:1141-1146
+        code = (mq.z >> 24) | ((mq.w >> 24) << 8);
+        counts0 = ((mq.x >> 24) << 8) | (mq.y >> 24);
+        position0 = (int32_t)(mq.z & 0xffffffu) + (int32_t)block_index;
+        if (code_length > 1) chunk = ld_quad(hdr);  // level entries 0..3, for the walk below the root
         if (rrr_in_range(rv, position0)) rec_q = ld_quad(bv_cell_ptr(ix.base, rv, (uint32_t)position0));
+        FMX_PIN_QUAD(chunk);
+        FMX_PIN_QUAD(rec_q);
+    } else {
+        // the reference's own route: leaf entry, clamped-mapping fix-up, code rebuilt from the level table
+        const uint8_t *leaves = hdr + (tree_height > 0 ? (tree_height - 1) * 4 : 0);  // WFBB:1119-1121
+        position0 = bh.bv_offset + (int32_t)block_index;
+        uint64_t leaf;
+        memcpy(&leaf, leaves + 5 * block_c, 8);  // {u16 symbol, u24 rank at block start} + 3 bytes of the next entry
+        if (tree_height > 0) {
+            chunk = ld_quad(hdr);  // level entries 0..3 (guard bytes cover the tail)
+            counts0 = ld16(hdr + second0);
+            if (rrr_in_range(rv, position0)) rec_q = ld_quad(bv_cell_ptr(ix.base, rv, (uint32_t)position0));
+        }
+        FMX_OPAQUE64(leaf);
+        FMX_PIN_QUAD(chunk);
+        FMX_OPAQUE32(counts0);
+        FMX_PIN_QUAD(rec_q);
+        if ((int32_t)(leaf & 0xffffu) != symbol) {  // WFBB:1123-1130: clamped mapping entry
+            ++block_c;
+            leaf = ld64u(leaves + 5 * block_c);
+        }
+        rank_block = (int32_t)((leaf >> 16) & 0xffffffu);                         // WFBB:1132-1138
+        if (tree_height == 0) return e.rank + rank_block + (int32_t)block_index;  // WFBB:1141-1146
+        wt_restore_code((uint32_t)block_c, hdr, tree_height, chunk, code, code_length);  // WFBB:1148-1156
     }
-    FMX_OPAQUE64(leaf);
-    FMX_PIN_QUAD(chunk);
-    FMX_OPAQUE32(counts0);
-    FMX_PIN_QUAD(rec_q);
-    if ((int32_t)(leaf & 0xffffu) != symbol) {    // WFBB:1123-1130: clamped mapping entry
-        ++block_c;
-        leaf = ld64u(leaves + 5 * block_c);
-    }
-    const int32_t rank_block = (int32_t)((leaf >> 16) & 0xffffffu);           // WFBB:1132-1138
-    if (tree_height == 0) return e.rank + rank_block + (int32_t)block_index;  // WFBB:1141-1146
-
-    uint32_t code;
-    int32_t code_length;
-    wt_restore_code((uint32_t)block_c, hdr, tree_height, chunk, code, code_length);  // WFBB:1148-1156
 
     const uint32_t cur_block_size = (ix.wt_size - (position - block_index)) < block_size
                                         ? (ix.wt_size - (position - block_index))

@@ -26,12 +26,33 @@ def lib():
     return _LIB
 
 
+def _without_fast_mapping(blob):
+    """copy of the image whose mapping entries all say 'take the reference's own route' (len = kMapSlow): rank()
+    then reads the leaf entry, fixes clamped entries up and rebuilds the canonical code as WFBB:1119-1156 do"""
+    import struct
+
+    b = np.array(blob, dtype=np.uint8, copy=True)
+    raw = b.tobytes()
+    ints = struct.unpack_from("<12i", raw, 16)
+    n_sb = ints[9]
+    off_sbdesc = struct.unpack_from("<8I", raw, 16 + 48 + 8)[6] * 8
+    for s_ in range(n_sb):
+        _sigma, _bsl, off_map, _obh, _ov, _nb, _vl, map_len, _pad = struct.unpack_from("<hhIIIiiii", raw, off_sbdesc + 64 * s_)
+        ent = b[off_map * 8: off_map * 8 + map_len * 16].view(np.uint32).reshape(map_len, 4)
+        present = (ent[:, 0] & 0x8000) == 0
+        ent[present, 0] = (ent[present, 0] & 0xFFFF) | (0xFF << 16)
+        ent[present, 1:] = 0
+    return b
+
+
 class HostSim:
     """runs the device code over the host blob of an index4j_amd.FmIndex"""
 
-    def __init__(self, fm_index):
+    def __init__(self, fm_index, force_reference_route=False):
         self.fm = fm_index  # keeps the blob alive
         self.blob = fm_index.blob()
+        if force_reference_route:
+            self.blob = _without_fast_mapping(self.blob)
         self.p = self.blob.ctypes.data
 
     def wt_rank_batch(self, positions, symbols):

@@ -76,3 +76,20 @@ def test_wavelet_rank_all_paths_incl_quirks():
         c, r = h.wt_inverse_select(pos)
         t = orc.lib().orc_wfbb_inverse_select(wh, pos)
         assert c == (t & 0xFFFF) and (pos == 0 or r == (t >> 32))
+
+
+def make_sim_reference_route(text, sr):
+    return hostsim.HostSim(ia.FmIndex(text, sr, True, device=None), force_reference_route=True)
+
+
+def test_rank_reference_route_still_matches():
+    """rank() normally reads leaf rank / canonical code / root count from the widened mapping entry; entries can
+    also say 'take the reference's own route' (codes longer than 16 bits).  Force that route for every entry:
+    the answers must not change."""
+    check_all(make_sim_reference_route, HD[:80_000], 16, random.Random(5), n_q=80)
+    rng = np.random.default_rng(4)
+    parts = []
+    for i in range(12):
+        parts.append("".join(chr(97 + int(x)) for x in rng.integers(0, 5 + 2 * i, 3000)))
+        parts.append("zq" * 2500)
+    check_all(make_sim_reference_route, "".join(parts), 4, random.Random(6), n_q=80)
