@@ -165,6 +165,8 @@ void make_dev_index(fmx_index *idx) {
     d.bw_positions = h.bw_positions;
     d.n_positions = h.n_positions;
     d.n_c = h.n_c;
+    d.map_by_symbol = h.map_by_symbol;
+    d.sb_cache = nullptr;
     d.wt_size = (uint32_t)h.wt_size;
 }
 
@@ -266,6 +268,11 @@ const char *fmx_last_error(void) { return g_err.c_str(); }
 void fmx_release_scratch(void) { g_scratch.release_all(); }
 
 int fmx_set_option(const char *name, int value) {
+    if (name && !strcmp(name, "map_by_symbol")) {  // layout of the mapping tables of images flattened from now on
+        if (value < -1 || value > 1) return fail(FMX_E_ARG, "bad value");
+        fmx::set_map_by_symbol(value);
+        return FMX_OK;
+    }
     if (!name || fmx::set_option(name, value)) return fail(FMX_E_ARG, "unknown option or bad value");
     return FMX_OK;
 }

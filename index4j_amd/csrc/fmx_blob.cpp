@@ -174,6 +174,10 @@ int flatten_rrr_only(const RrrModel &r, std::vector<uint8_t> &blob, std::string 
     return 0;
 }
 
+// -1 = by alphabet size; 0 / 1 force the row layout of the mapping tables (tests exercise both)
+static int g_map_by_symbol = -1;
+void set_map_by_symbol(int mode) { g_map_by_symbol = mode; }
+
 int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err) {
     const WfbbModel &w = m.wt;
     const int sigma = w.alphabet_size;
@@ -245,6 +249,10 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
             A.at<SbcEntry>(off)[s * sigma + c] = e;
         }
 
+    // mapping rows by global symbol unless the alphabet is so large that the table would explode (rows of symbols
+    // a superblock does not hold are pure skip pointers)
+    const bool by_symbol = g_map_by_symbol < 0 ? sigma <= 1024 : g_map_by_symbol != 0;
+    h.map_by_symbol = by_symbol ? 1 : 0;
     const size_t sbd_off = A.alloc((size_t)n_sb * sizeof(SbDesc));
     h.off_sbdesc = off8(sbd_off);
     for (int64_t s = 0; s < n_sb; ++s) {
@@ -258,19 +266,23 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
             err = "superblock mapping shape mismatch";
             return -3;
         }
-        off = A.alloc(sb.mapping.size() * sizeof(MapEntry) + 16);
+        const int64_t per_row = (int64_t)1 << (20 - d.bsl);
+        const int64_t n_rows = by_symbol ? sigma : (int64_t)sb.sigma + 1;
+        off = A.alloc((size_t)(n_rows * per_row) * sizeof(MapEntry) + 16);
         d.off_mapping = off8(off);
-        d.mapping_len = (int32_t)sb.mapping.size();
+        d.mapping_len = (int32_t)(n_rows * per_row);
         {
             // absent entries (alphabetSize - 1, WFBB:383-387) become skip pointers: -(distance to the next
             // block to the right holding the symbol, or to the end of the superblock)
             MapEntry *dst = A.at<MapEntry>(off);
-            const int64_t per_row = (int64_t)1 << (20 - d.bsl);
             const int16_t absent = (int16_t)(sigma - 1);
-            for (int64_t row = 0; row <= sb.sigma; ++row) {
+            for (int64_t row = 0; row < n_rows; ++row) {
+                // the reference's row of this device row: by superblock code (WFBB:461-465)
+                const int64_t src_row = by_symbol ? (int64_t)w.global_mapping[(size_t)(s * sigma + row)] : row;
+                const bool in_superblock = src_row >= 0 && src_row <= sb.sigma;
                 int64_t next_present = per_row;
                 for (int64_t blk = per_row - 1; blk >= 0; --blk) {
-                    const int16_t v = sb.mapping[(size_t)(row * per_row + blk)];
+                    const int16_t v = in_superblock ? sb.mapping[(size_t)(src_row * per_row + blk)] : absent;
                     int16_t raw;
                     if (v != absent) {
                         if (v < 0) {
@@ -303,9 +315,9 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
                     const int symbol = (int)lp[0] | ((int)lp[1] << 8);
                     const uint32_t rank_block = (uint32_t)lp[2] | ((uint32_t)lp[3] << 8) | ((uint32_t)lp[4] << 16);
                     if (symbol >= sigma) continue;
-                    const int row = w.global_mapping[(size_t)(s * sigma + symbol)];
-                    if (row < 0 || row > sb.sigma) continue;
-                    MapEntry &e = dst[(int64_t)row * per_row + blk];
+                    const int code_row = w.global_mapping[(size_t)(s * sigma + symbol)];
+                    if (code_row < 0 || code_row > sb.sigma) continue;
+                    MapEntry &e = dst[(int64_t)(by_symbol ? symbol : code_row) * per_row + blk];
                     if ((int16_t)(e.x & 0xffffu) < 0) continue;  // the mapping says absent: leave it to the reference's route
                     // WFBB:250-278 restoreCodeFromBlockHeader for leaf i
                     uint32_t code = 0, leaf_count = 0;

@@ -35,7 +35,7 @@
 namespace fmx {
 
 constexpr uint32_t kBlobMagic = 0x31584D46u;  // "FMX1"
-constexpr uint32_t kBlobVersion = 7;
+constexpr uint32_t kBlobVersion = 8;
 
 struct RrrRecord {         // 16 bytes: 16 blocks of 15 bits
     uint32_t ones_before;  // 1-bits in all earlier blocks
@@ -86,7 +86,9 @@ constexpr uint32_t kMapSlow = 0xffu;
 struct SbDesc {            // 64 bytes; bytes 0..15 = header of every rank, bytes 32..47 = its RRR vector
     int16_t sigma;         // WFBB:1623 (superblock alphabet size - 1)
     int16_t bsl;           // WFBB:1624 blockSizeLog
-    uint32_t off_mapping;  // MapEntry[(sigma+1) << (20 - bsl)], absent entries: raw = -(distance to next present)
+    uint32_t off_mapping;  // MapEntry[rows << (20 - bsl)], absent entries: raw = -(distance to next present);
+                           // rows = the index's alphabet size (BlobHeader.map_by_symbol: the row of a symbol is known
+                           // without the superblock's code table, so the entry is requested one load earlier) or sigma+1
     uint32_t off_bh;       // BlockHdr[n_blocks]
     uint32_t off_var;      // variable-size block headers
     int32_t n_blocks;
@@ -123,7 +125,8 @@ struct BlobHeader {        // 256 bytes
     uint32_t off_sbdesc;     // SbDesc[n_sb]
     uint32_t off_inv;        // uint16[16384] value-of-offset table, classes 0..7  RRR:106
     RrrDesc sampled;         // sampledSuffixes                        FM:123
-    uint8_t reserved[256 - 8 - 8 - 12 * 4 - 8 - 8 * 4 - 32];
+    int32_t map_by_symbol;   // 1: a superblock's mapping rows are indexed by the global symbol, 0: by its superblock code
+    uint8_t reserved[256 - 8 - 8 - 12 * 4 - 8 - 8 * 4 - 32 - 4];
 };
 static_assert(sizeof(RrrDesc) == 32, "RrrDesc");
 static_assert(sizeof(RrrRecord) == 16, "RrrRecord");

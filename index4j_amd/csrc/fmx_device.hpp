@@ -56,6 +56,9 @@ struct DevIndex {
     RrrDesc sampled;             // sampledSuffixes             FM:123
     int32_t length, sample_rate, enable_extract;
     int32_t wt_sigma, n_sb, bw_suffixes, bw_positions, n_positions, n_c;
+    int32_t map_by_symbol;       // mapping rows indexed by global symbol (BlobHeader.map_by_symbol)
+    // {header quad, bit-vector view quad} of every superblock, staged in LDS by the kernel (nullptr: read from HBM)
+    const struct Quad *sb_cache;
     uint32_t wt_size;
 };
 
@@ -477,8 +480,12 @@ FMX_HD int32_t tree_next_level_entry(TreeWalk &t, uint32_t e) {
 FMX_HD int32_t fm_c_or_zero(const DevIndex &ix, int32_t symbol) {
     return (symbol >= 0 && symbol < ix.n_c) ? ix.C[symbol] : 0;
 }
+// With the superblock's header at hand (ix.sb_cache, staged in LDS by the kernel) and the mapping rows indexed by
+// the global symbol, the mapping entry and the block header are requested together with the superblock entry:
+//   {superblock entry, mapping entry, block header} -> first cell -> ...
 FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t symbol, int &status,
                               bool &suspect) {
+    const Quad *sb_cache = ix.sb_cache;
     if (position == 0) return fm_c_or_zero(ix, symbol);                 // WFBB:1012-1014
     if (position > ix.wt_size) position = ix.wt_size;                   // WFBB:1015-1017
     if (symbol >= ix.wt_sigma) return fm_c_or_zero(ix, symbol);         // WFBB:1018-1020
@@ -494,15 +501,19 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
     //   -> {leaf, level table, first level's counts, first RRR record} -> offset bits -> ...
     uint64_t sbc_raw;
     memcpy(&sbc_raw, ix.sbc + (uint64_t)sb_id * (uint32_t)ix.wt_sigma + (uint32_t)symbol, 8);  // WFBB:1024, 1034-1037
-    const SbDesc &sd = ix.sbd[sb_id];                                                          // WFBB:1026
-    Quad head_q = ld_quad(&sd), view_q = ld_quad(&sd.rrr);  // same 64-byte line
-    FMX_OPAQUE64(sbc_raw);
-    const SbcEntry e = sbc_from(sbc_raw);
-    FMX_PIN_QUAD(head_q);
-    FMX_PIN_QUAD(view_q);
+    const SbDesc &sd = ix.sbd[sb_id];  // WFBB:1026
+    Quad head_q, view_q;
+    if (sb_cache) {
+        head_q = sb_cache[2 * sb_id];
+        view_q = sb_cache[2 * sb_id + 1];
+    } else {
+        head_q = ld_quad(&sd);
+        view_q = ld_quad(&sd.rrr);  // same 64-byte line
+        FMX_PIN_QUAD(head_q);
+        FMX_PIN_QUAD(view_q);
+    }
     const SbHead sh = sb_head_from(head_q);
     const RrrView rv = rrr_view_from(view_q);
-    if ((int32_t)e.sbc >= sh.sigma + 1) return e.rank;  // WFBB:1040-1042
     const int32_t bsl = sh.bsl;
     const uint32_t block_size = 1u << bsl;
     const int32_t blocks_log = 20 - bsl;
@@ -511,11 +522,26 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
     const MapEntry *mapping = reinterpret_cast<const MapEntry *>(ix.base + ((uint64_t)sh.off_mapping << 3));
     const BlockHdr *bhs = reinterpret_cast<const BlockHdr *>(ix.base + ((uint64_t)sh.off_bh << 3));
     const uint8_t *var = ix.base + ((uint64_t)sh.off_var << 3);
-    const uint32_t map_row = (uint32_t)e.sbc << blocks_log;
-    Quad mq = ld_quad(mapping + map_row + block_id);  // WFBB:1044-1046 (+ what the symbol's leaf would tell)
-    Quad bhq = ld_quad(bhs + block_id);               // WFBB:1113, requested before the mapping entry is known
-    FMX_PIN_QUAD(mq);
-    FMX_PIN_QUAD(bhq);
+    Quad mq = {0, 0, 0, 0}, bhq = {0, 0, 0, 0};
+    uint32_t map_row = (uint32_t)symbol << blocks_log;
+    if (ix.map_by_symbol) {  // the row does not depend on the superblock entry: ask for everything at once
+        mq = ld_quad(mapping + map_row + block_id);  // WFBB:1044-1046 (+ what the symbol's leaf would tell)
+        bhq = ld_quad(bhs + block_id);               // WFBB:1113
+    }
+    FMX_OPAQUE64(sbc_raw);
+    const SbcEntry e = sbc_from(sbc_raw);
+    if (ix.map_by_symbol) {
+        FMX_PIN_QUAD(mq);
+        FMX_PIN_QUAD(bhq);
+    }
+    if ((int32_t)e.sbc >= sh.sigma + 1) return e.rank;  // WFBB:1040-1042
+    if (!ix.map_by_symbol) {
+        map_row = (uint32_t)e.sbc << blocks_log;
+        mq = ld_quad(mapping + map_row + block_id);
+        bhq = ld_quad(bhs + block_id);  // requested before the mapping entry is known
+        FMX_PIN_QUAD(mq);
+        FMX_PIN_QUAD(bhq);
+    }
     int32_t block_c = (int32_t)(int16_t)(mq.x & 0xffffu);
 
     if (block_c < 0) {  // WFBB:1048-1110: absent; -block_c = distance to the closest block to the right that
@@ -647,9 +673,16 @@ FMX_HD int32_t wt_inverse_select_folded(const DevIndex &ix, const uint16_t *inv,
     // counts, first RRR record} -> offset bits -> ... -> leaf -> superblock rank of the symbol
     const uint32_t sb_id = position >> 20;
     const SbDesc &sd = ix.sbd[sb_id];
-    Quad head_q = ld_quad(&sd), view_q = ld_quad(&sd.rrr);
-    FMX_PIN_QUAD(head_q);
-    FMX_PIN_QUAD(view_q);
+    Quad head_q, view_q;
+    if (ix.sb_cache) {
+        head_q = ix.sb_cache[2 * sb_id];
+        view_q = ix.sb_cache[2 * sb_id + 1];
+    } else {
+        head_q = ld_quad(&sd);
+        view_q = ld_quad(&sd.rrr);
+        FMX_PIN_QUAD(head_q);
+        FMX_PIN_QUAD(view_q);
+    }
     const SbHead sh = sb_head_from(head_q);
     const RrrView rv = rrr_view_from(view_q);
     const int32_t bsl = sh.bsl;

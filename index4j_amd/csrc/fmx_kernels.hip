@@ -61,14 +61,31 @@ __device__ __forceinline__ void stage_inverse_table(uint16_t *s_inv, const uint1
 // character in the low bits: 8 codes of 8 bits when the alphabet fits (sigma <= 256), else 4 codes of 16 bits.
 __host__ __device__ inline int plan_code_bits(int32_t sigma) { return sigma <= 256 ? 8 : 16; }
 
+// The header quad and the bit-vector view quad of every superblock (32 bytes each) are staged in LDS when the
+// index has at most kSbCacheMax superblocks (335 M symbols): the first stage of every rank / inverseSelect then
+// reads LDS instead of HBM, and what depends only on the header is requested one round trip earlier.
+constexpr int kSbCacheMax = 320;
+__device__ __forceinline__ const Quad *stage_sb_cache(Quad *s_sb, const DevIndex &ix) {
+    if (ix.n_sb > kSbCacheMax) return nullptr;
+    const Quad *src = reinterpret_cast<const Quad *>(ix.sbd);
+    for (int i = threadIdx.x; i < 2 * ix.n_sb; i += blockDim.x) s_sb[i] = src[(i >> 1) * 4 + (i & 1) * 2];
+    __syncthreads();
+    return s_sb;
+}
+#define FMX_WITH_SB_CACHE(GLOBAL_IX, LOCAL_IX)      \
+    __shared__ Quad s_sb[2 * kSbCacheMax];          \
+    DevIndex LOCAL_IX = GLOBAL_IX;                  \
+    LOCAL_IX.sb_cache = stage_sb_cache(s_sb, GLOBAL_IX)
+
 template <int kBlock>
-FMX_KERNEL(kBlock) void k_count(DevIndex ix, const uint16_t *__restrict__ pat,
+FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__ pat,
                                                   const int32_t *__restrict__ pat_off,
                                                   const uint32_t *__restrict__ perm, int32_t n,
                                                   int32_t *__restrict__ counts, int32_t *__restrict__ lf_steps,
                                                   int32_t *__restrict__ status_out, int32_t *__restrict__ range_out,
                                                   int xcd_remap, const uint64_t *__restrict__ codes) {
     const uint16_t *s_inv = nullptr;  // no RRR vector on this kernel's path (the wavelet tree's are expanded)
+    FMX_WITH_SB_CACHE(ix_global, ix);
     const int role = threadIdx.x & 1;
     const int code_bits = plan_code_bits(ix.wt_sigma), n_codes = codes ? 64 / code_bits : 0;
     const uint32_t code_mask = (1u << code_bits) - 1u;
@@ -132,13 +149,14 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix, const uint16_t *__restrict__ pat,
 
 // FM:526-548: hit k of pattern p is SA row i = start + 1 + k; walk LF until a sampled row.
 template <int kBlock>
-FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix, const int32_t *__restrict__ range, int32_t n,
+FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix_global, const int32_t *__restrict__ range, int32_t n,
                                                         int32_t max_matches, int32_t *__restrict__ locs,
                                                         int32_t loc_cap, int32_t slots, int32_t *__restrict__ found,
                                                         int32_t *__restrict__ lf_steps,
                                                         int32_t *__restrict__ status_out,
                                                         const int32_t *__restrict__ taken) {
     const uint16_t *s_inv = nullptr;  // no RRR vector on this kernel's path (the sampled-row bitmap is expanded)
+    FMX_WITH_SB_CACHE(ix_global, ix);
     const int64_t total = (int64_t)n * slots;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
@@ -172,12 +190,13 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix, const int32_t *__restric
 // runs only if that hit exists; with stops == nullptr the stop position is min(inputLength, start + fixed_len)
 // (the reference's locateAndExtractBenchmark, FmIndexThroughputBenchmark.java:231-249).
 template <int kBlock>
-FMX_EXTRACT_KERNEL(kBlock) void k_extract(DevIndex ix, const int32_t *__restrict__ starts, const int32_t *__restrict__ stops,
+FMX_EXTRACT_KERNEL(kBlock) void k_extract(DevIndex ix_global, const int32_t *__restrict__ starts, const int32_t *__restrict__ stops,
                                   int64_t n, uint16_t *__restrict__ dst, int32_t dst_len, int32_t offset,
                                   int32_t *__restrict__ out_len, int32_t *__restrict__ lf_steps,
                                   int32_t *__restrict__ status_out, const int32_t *__restrict__ slot_found,
                                   int32_t slots, int32_t fixed_len) {
     const uint16_t *s_inv = nullptr;  // no RRR vector on this kernel's path (the wavelet tree's are expanded)
+    FMX_WITH_SB_CACHE(ix_global, ix);
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) {
         if (slot_found && (int32_t)(q % slots) >= slot_found[q / slots]) continue;
@@ -202,13 +221,14 @@ FMX_EXTRACT_KERNEL(kBlock) void k_extract(DevIndex ix, const int32_t *__restrict
 // sample_rate codes per lane of the grid (element j of lane t at scratch[j * lanes + t]) for the
 // interval-buffered right walk (fm_boundary_right_blocks); without it the literal form runs.
 template <int kBlock>
-FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary(DevIndex ix, const int32_t *__restrict__ froms, int64_t n, uint16_t boundary,
+FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary(DevIndex ix_global, const int32_t *__restrict__ froms, int64_t n, uint16_t boundary,
                                            int mode, uint16_t *__restrict__ dst, int32_t dst_len, int32_t offset,
                                            int32_t *__restrict__ out_len, int32_t *__restrict__ lf_steps,
                                            int32_t *__restrict__ status_out, int32_t *__restrict__ aux_out,
                                            uint16_t *__restrict__ scratch, const int32_t *__restrict__ slot_found,
                                            int32_t slots) {
     const uint16_t *s_inv = nullptr;  // no RRR vector on this kernel's path (the wavelet tree's are expanded)
+    FMX_WITH_SB_CACHE(ix_global, ix);
     const int64_t lanes = (int64_t)gridDim.x * kBlock;
     const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int32_t mapped_boundary = fm_map(ix, boundary);  // FM:658
@@ -229,13 +249,14 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary(DevIndex ix, const int32_t *
 // Group-cooperative extractUntilBoundary: G lanes per query (fm_extract_boundary_group); the window of a group
 // is G consecutive lane columns of `scratch` (left window in the first half, right window in the second).
 template <int kBlock, int G>
-FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix, const int32_t *__restrict__ froms, int64_t n,
+FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix_global, const int32_t *__restrict__ froms, int64_t n,
                                                  uint16_t boundary, int mode, uint16_t *__restrict__ dst,
                                                  int32_t dst_len, int32_t offset, int32_t *__restrict__ out_len,
                                                  int32_t *__restrict__ lf_steps, int32_t *__restrict__ status_out,
                                                  int32_t *__restrict__ aux_out, uint16_t *__restrict__ scratch,
                                                  const int32_t *__restrict__ slot_found, int32_t slots) {
     const uint16_t *s_inv = nullptr;  // no RRR vector on this kernel's path (the wavelet tree's are expanded)
+    FMX_WITH_SB_CACHE(ix_global, ix);
     const int64_t lanes = (int64_t)gridDim.x * kBlock;
     const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int g = threadIdx.x % G;

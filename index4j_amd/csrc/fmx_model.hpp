@@ -126,6 +126,7 @@ void emit_model(const FmModel &m, bool framed, std::vector<uint8_t> &out);
 
 // fmx_blob.cpp
 int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err);
+void set_map_by_symbol(int mode);  // -1 auto, 0 rows by superblock code, 1 rows by global symbol
 int flatten_rrr_only(const RrrModel &r, std::vector<uint8_t> &blob, std::string &err);
 
 }  // namespace fmx

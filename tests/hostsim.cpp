@@ -36,6 +36,8 @@ static DevIndex make_index(const uint8_t *b) {
     d.bw_positions = h.bw_positions;
     d.n_positions = h.n_positions;
     d.n_c = h.n_c;
+    d.map_by_symbol = h.map_by_symbol;
+    d.sb_cache = nullptr;
     d.wt_size = (uint32_t)h.wt_size;
     return d;
 }

@@ -93,3 +93,17 @@ def test_rank_reference_route_still_matches():
         parts.append("".join(chr(97 + int(x)) for x in rng.integers(0, 5 + 2 * i, 3000)))
         parts.append("zq" * 2500)
     check_all(make_sim_reference_route, "".join(parts), 4, random.Random(6), n_q=80)
+
+
+def test_mapping_rows_by_superblock_code_layout():
+    """the mapping tables are laid out by global symbol (small alphabets) or by superblock code (the reference's
+    own row order, kept for large alphabets): force the second layout and run everything again"""
+    try:
+        assert ia.lib.fmx_set_option(b"map_by_symbol", 0) == 0
+        check_all(make_sim, HD[:80_000], 16, random.Random(15), n_q=80)
+        check_all(make_sim_reference_route, HD[:40_000], 8, random.Random(16), n_q=40)
+        assert ia.lib.fmx_set_option(b"map_by_symbol", 1) == 0
+        big = "".join(chr(40 + (i * 7919) % 1500) for i in range(60_000)) + HD[:20_000]
+        check_all(make_sim, big, 8, random.Random(17), n_q=60)  # > 1024 symbols, rows by symbol all the same
+    finally:
+        ia.lib.fmx_set_option(b"map_by_symbol", -1)
