@@ -308,7 +308,6 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
                 const int64_t hdr = bh.var_off, leaves = hdr + (h > 0 ? (int64_t)(h - 1) * 4 : 0);
                 const int64_t second0 = (int64_t)(h - 1) * 4 + (int64_t)n_leaves * 5;
                 if (leaves + (int64_t)n_leaves * 5 > var_len || (h > 0 && hdr + second0 + 2 > var_len)) continue;
-                if (((uint32_t)bh.bv_offset | (uint32_t)bh.bv_rank) >> 24) continue;
                 const uint32_t counts0 = h > 0 ? (uint32_t)var[hdr + second0] | ((uint32_t)var[hdr + second0 + 1] << 8) : 0u;
                 for (int i = 0; i < n_leaves; ++i) {
                     const uint8_t *lp = var + leaves + (int64_t)i * 5;
@@ -350,6 +349,23 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
         static_assert(sizeof(BlockHeader) == sizeof(BlockHdr), "block header layout");
         if (!sb.block_headers.empty())
             memcpy(A.at<uint8_t>(off), sb.block_headers.data(), sb.block_headers.size() * sizeof(BlockHdr));
+        {
+            // the root node's one-count (first u16 of the cumulative counts, WFBB:793-809) rides in the spare top
+            // bytes of bv_rank / bv_offset (both < 2^24: at most 2^20 symbols of < 16 code bits per superblock)
+            BlockHdr *bhd = A.at<BlockHdr>(off);
+            for (size_t b = 0; b < sb.block_headers.size(); ++b) {
+                if (((uint32_t)bhd[b].bv_rank | (uint32_t)bhd[b].bv_offset) >> 24) {
+                    err = "block bit-vector fields exceed 24 bits";
+                    return -8;
+                }
+                const int h = bhd[b].tree_height;
+                const int64_t at = (int64_t)bhd[b].var_off + (int64_t)(h - 1) * 4 + ((int64_t)bhd[b].sigma + 1) * 5;
+                if (h <= 0 || bhd[b].var_off < 0 || at + 2 > (int64_t)sb.var.size()) continue;
+                const uint32_t root_ones = (uint32_t)sb.var[(size_t)at] | ((uint32_t)sb.var[(size_t)at + 1] << 8);
+                bhd[b].bv_rank |= (int32_t)((root_ones & 0xffu) << 24);
+                bhd[b].bv_offset |= (int32_t)((root_ones >> 8) << 24);
+            }
+        }
         // 16 guard bytes behind the array: 24-bit fields are fetched as one 32-bit load
         off = A.alloc(sb.var.size() + 16);
         d.off_var = off8(off);

@@ -35,7 +35,7 @@
 namespace fmx {
 
 constexpr uint32_t kBlobMagic = 0x31584D46u;  // "FMX1"
-constexpr uint32_t kBlobVersion = 8;
+constexpr uint32_t kBlobVersion = 9;
 
 struct RrrRecord {         // 16 bytes: 16 blocks of 15 bits
     uint32_t ones_before;  // 1-bits in all earlier blocks
@@ -98,7 +98,7 @@ struct SbDesc {            // 64 bytes; bytes 0..15 = header of every rank, byte
     RrrDesc rrr;
 };
 
-struct BlockHdr {          // 16 bytes, WFBB:1589-1595
+struct BlockHdr {          // 16 bytes, WFBB:1589-1595; bv_rank / bv_offset: 24 bits + a byte each of the root's one-count
     int32_t bv_rank, bv_offset, var_off;
     int16_t sigma, tree_height;
 };

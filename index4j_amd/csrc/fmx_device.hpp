@@ -395,10 +395,12 @@ FMX_HD SbHead sb_head_from(const Quad &q) {
     return h;
 }
 FMX_HD SbHead sb_head(const SbDesc &sd) { return sb_head_from(ld_quad(&sd)); }
+// (the image packs the root node's one-count into the spare top bytes of the two 24-bit bit-vector fields)
+FMX_HD uint32_t block_hdr_root_ones(const Quad &q) { return (q.x >> 24) | ((q.y >> 24) << 8); }
 FMX_HD BlockHdr block_hdr_from(const Quad &q) {
     BlockHdr b;
-    b.bv_rank = (int32_t)q.x;
-    b.bv_offset = (int32_t)q.y;
+    b.bv_rank = (int32_t)(q.x & 0xffffffu);
+    b.bv_offset = (int32_t)(q.y & 0xffffffu);
     b.var_off = (int32_t)q.z;
     b.sigma = (int16_t)(q.w & 0xffffu);
     b.tree_height = (int16_t)(q.w >> 16);
@@ -592,12 +594,11 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
         memcpy(&leaf, leaves + 5 * block_c, 8);  // {u16 symbol, u24 rank at block start} + 3 bytes of the next entry
         if (tree_height > 0) {
             chunk = ld_quad(hdr);  // level entries 0..3 (guard bytes cover the tail)
-            counts0 = ld16(hdr + second0);
+            counts0 = block_hdr_root_ones(bhq);
             if (rrr_in_range(rv, position0)) rec_q = ld_quad(bv_cell_ptr(ix.base, rv, (uint32_t)position0));
         }
         FMX_OPAQUE64(leaf);
         FMX_PIN_QUAD(chunk);
-        FMX_OPAQUE32(counts0);
         FMX_PIN_QUAD(rec_q);
         if ((int32_t)(leaf & 0xffffu) != symbol) {  // WFBB:1123-1130: clamped mapping entry
             ++block_c;
@@ -692,7 +693,8 @@ FMX_HD int32_t wt_inverse_select_folded(const DevIndex &ix, const uint16_t *inv,
     const uint32_t block_id = (position & 0xfffffu) >> bsl;
     const BlockHdr *bhs = reinterpret_cast<const BlockHdr *>(ix.base + ((uint64_t)sh.off_bh << 3));
     const uint8_t *var = ix.base + ((uint64_t)sh.off_var << 3);
-    const BlockHdr bh = ld_block_hdr(bhs + block_id);
+    const Quad bhq = ld_quad(bhs + block_id);
+    const BlockHdr bh = block_hdr_from(bhq);
     const int32_t tree_height = bh.tree_height;
     const uint8_t *hdr = var + bh.var_off;
     const uint8_t *leaves = hdr + (tree_height > 0 ? (tree_height - 1) * 4 : 0);  // WFBB:1324-1327
@@ -708,11 +710,10 @@ FMX_HD int32_t wt_inverse_select_folded(const DevIndex &ix, const uint16_t *inv,
     const uint32_t second0 = (uint32_t)((tree_height - 1) * 4 + ((int32_t)bh.sigma + 1) * 5);
     int32_t rrr_position = bh.bv_offset + (int32_t)block_index;
     Quad chunk = ld_quad(hdr);  // level entries 0..3 (guard bytes cover the tail)
-    uint32_t counts0 = ld16(hdr + second0);
+    const uint32_t counts0 = block_hdr_root_ones(bhq);  // = the u16 at hdr + second0 (WFBB:793-809)
     Quad rec_q = {0, 0, 0, 0};
     if (rrr_in_range(rv, rrr_position)) rec_q = ld_quad(bv_cell_ptr(ix.base, rv, (uint32_t)rrr_position));
     FMX_PIN_QUAD(chunk);
-    FMX_OPAQUE32(counts0);
     FMX_PIN_QUAD(rec_q);
 
     const uint32_t cur_block_size = (ix.wt_size - (position - block_index)) < block_size
