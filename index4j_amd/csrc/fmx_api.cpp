@@ -70,6 +70,7 @@ struct fmx_index {
 namespace {
 
 thread_local std::string g_err;
+int g_sb_cache_limit = 320;  // option "sb_cache_limit": applies to indexes made resident afterwards (tests: 0 = no LDS cache)
 int fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
@@ -167,6 +168,7 @@ void make_dev_index(fmx_index *idx) {
     d.n_c = h.n_c;
     d.map_by_symbol = h.map_by_symbol;
     d.sb_cache = nullptr;
+    d.sb_cache_limit = g_sb_cache_limit;
     d.wt_size = (uint32_t)h.wt_size;
 }
 
@@ -268,6 +270,11 @@ const char *fmx_last_error(void) { return g_err.c_str(); }
 void fmx_release_scratch(void) { g_scratch.release_all(); }
 
 int fmx_set_option(const char *name, int value) {
+    if (name && !strcmp(name, "sb_cache_limit")) {
+        if (value < 0 || value > 320) return fail(FMX_E_ARG, "bad value");
+        g_sb_cache_limit = value;
+        return FMX_OK;
+    }
     if (name && !strcmp(name, "map_by_symbol")) {  // layout of the mapping tables of images flattened from now on
         if (value < -1 || value > 1) return fail(FMX_E_ARG, "bad value");
         fmx::set_map_by_symbol(value);

@@ -59,6 +59,7 @@ struct DevIndex {
     int32_t map_by_symbol;       // mapping rows indexed by global symbol (BlobHeader.map_by_symbol)
     // {header quad, bit-vector view quad} of every superblock, staged in LDS by the kernel (nullptr: read from HBM)
     const struct Quad *sb_cache;
+    int32_t sb_cache_limit;      // stage the cache only for indexes with at most this many superblocks (0 = never)
     uint32_t wt_size;
 };
 

@@ -66,7 +66,7 @@ __host__ __device__ inline int plan_code_bits(int32_t sigma) { return sigma <= 2
 // reads LDS instead of HBM, and what depends only on the header is requested one round trip earlier.
 constexpr int kSbCacheMax = 320;
 __device__ __forceinline__ const Quad *stage_sb_cache(Quad *s_sb, const DevIndex &ix) {
-    if (ix.n_sb > kSbCacheMax) return nullptr;
+    if (ix.n_sb > kSbCacheMax || ix.n_sb > ix.sb_cache_limit) return nullptr;
     const Quad *src = reinterpret_cast<const Quad *>(ix.sbd);
     for (int i = threadIdx.x; i < 2 * ix.n_sb; i += blockDim.x) s_sb[i] = src[(i >> 1) * 4 + (i & 1) * 2];
     __syncthreads();

@@ -38,6 +38,7 @@ static DevIndex make_index(const uint8_t *b) {
     d.n_c = h.n_c;
     d.map_by_symbol = h.map_by_symbol;
     d.sb_cache = nullptr;
+    d.sb_cache_limit = 0;
     d.wt_size = (uint32_t)h.wt_size;
     return d;
 }

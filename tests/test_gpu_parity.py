@@ -525,3 +525,23 @@ def test_standalone_rrr_vector_kats_and_random_vs_oracle():
             assert (st[inside] == 0).all() and (st[~inside] == 9).all()
             for p_ in pos[:50].tolist() + pos[-5:].tolist():
                 assert ranks[list(pos).index(p_)] == o.rank_ones(int(p_))
+
+
+def test_layout_variants_give_the_same_answers():
+    """the image has two mapping layouts (rows by global symbol / by superblock code) and the kernels two ways
+    to reach a superblock's header (LDS cache / HBM): every combination against the oracle"""
+    try:
+        for by_symbol, cache in ((0, 320), (1, 0), (0, 0)):
+            assert ia.lib.fmx_set_option(b"map_by_symbol", by_symbol) == 0
+            assert ia.lib.fmx_set_option(b"sb_cache_limit", cache) == 0
+            check_all(make_gpu, HD[:90_000], 16, random.Random(300 + by_symbol + cache), n_q=80)
+        t = ia.synth_log(1 << 21)  # three superblocks, planned batch
+        fm = ia.FmIndex(t, 32, True, device=0)
+        o = orc.OracleFmIndex.read(fm.write(False))
+        pat, off, pos = ia.synth_patterns(t, 8, 20000)
+        cnt, st = fm.count_batch(pat, off)
+        oc, _ = o.count_batch(pat, off, threads=8)
+        assert (cnt == oc).all() and (st == 0).all()
+    finally:
+        ia.lib.fmx_set_option(b"map_by_symbol", -1)
+        ia.lib.fmx_set_option(b"sb_cache_limit", 320)
