@@ -6,28 +6,26 @@
 //   * little-endian; every section starts on a 64-byte boundary; section offsets are stored as
 //     (byte offset / 8) in a uint32 (blobs up to 32 GiB).
 //   * top-level tables that every LF-step touches are small and dense so they stay in L2:
-//       SbcEntry[(n_sb+1) * sigma]   {rank at superblock start incl. hyperblock rank, superblock code}
+//       SbcEntry[(n_sb+1) * sigma]   {C[symbol] + rank at superblock start incl. hyperblock rank, superblock code}
 //                                    = superBlockRank + hyperBlockRank + globalMapping (WFBB:108-110)
 //                                    fused into one 8-byte load; row n_sb holds count[] (WFBB:1063-1069)
 //       SbDesc[n_sb]                 one 64-byte sector per superblock header (WFBB:1621-1629)
-//   * per superblock: mapping (int16), BlockHeader[] (16 B, as WFBB:1589-1595), variable headers
-//     (bytes as written at WFBB:742-809, + 16 guard bytes), and its RRR vector.
-//   * mapping (WFBB:1628): present entries keep the block-local symbol index; an ABSENT entry
-//     (alphabetSize-1 in the reference) is stored as -d, d = distance to the closest block to the
-//     right that holds the symbol (or to the end of the superblock).  The reference finds that block
-//     with a linear scan (WFBB:1051-1059: 27 dependent reads on average on log text); the skip
-//     pointer returns the same block in one read.
-//   * an RRR vector (RRR:92-103) is stored as 16-byte records, one per 16 blocks of 15 bits,
-//     whatever the index's own sampleSize: { u32 ones before the record (the role of prefixSums,
-//     RRR:101), u32 bit pointer into the offsets stream (lengthOfSampledOffsets, RRR:99-100),
-//     u64 = the 16 4-bit classes (RRR:96) }.  One aligned 16-byte load replaces three bit-packed
-//     vector reads and bounds the class scan of RRR:376-380 to 15 nibbles of one word; a rank touches
-//     one record sector + one sector of the offsets bit stream (RRR:97-98).  Same space as the
-//     reference's sampleSize=32 layout padded to 32-byte records.
-//   * value-of-offset table (RRR:106, 64 KiB in the reference): only classes 0..7 are stored
-//     (16,384 entries, 32 KiB) — class 15-k is the bitwise complement in reverse offset order:
-//     value(15-k, off) = ~value(k, C(15,k)-1-off) & 0x7fff.  It travels in the blob and every
-//     workgroup stages it into LDS.
+//   * per superblock: mapping (MapEntry, 16 B), BlockHeader[] (16 B, as WFBB:1589-1595, the root node's one-count
+//     in the spare top bytes), variable headers (bytes as written at WFBB:742-809, + 16 guard bytes), and its bit
+//     vector as 96-bit cells (BvCell).
+//   * mapping (WFBB:1628): present entries keep the block-local symbol index and add what the block's header
+//     tells about the symbol (MapEntry below); an ABSENT entry (alphabetSize-1 in the reference) is stored as
+//     -d, d = distance to the closest block to the right that holds the symbol (or to the end of the
+//     superblock).  The reference finds that block with a linear scan (WFBB:1051-1059: 27 dependent reads on
+//     average on log text); the skip pointer returns the same block in one read.  Rows are indexed by the global
+//     symbol (BlobHeader.map_by_symbol) or, for very large alphabets, by the superblock code as in the reference.
+//   * bit vectors (RrrVector in the reference: WFBB:116, FM:123) are EXPANDED into BvCell arrays (below).
+//   * a stand-alone RrrVector (fmx_rrr_build) keeps the compressed form: 16-byte records, one per 16 blocks of 15
+//     bits, whatever the sampleSize: { u32 ones before the record (the role of prefixSums, RRR:101), u32 bit
+//     pointer into the offsets stream (lengthOfSampledOffsets, RRR:99-100), u64 = the 16 4-bit classes (RRR:96) }
+//     + the offsets bit stream (RRR:97-98) + the value-of-offset table (RRR:106, 64 KiB in the reference): only
+//     classes 0..7 are stored (16,384 entries, 32 KiB) — class 15-k is the bitwise complement in reverse offset
+//     order: value(15-k, off) = ~value(k, C(15,k)-1-off) & 0x7fff — staged into LDS by the RRR kernels.
 #pragma once
 
 #include <cstdint>

@@ -1,6 +1,7 @@
 // fmx_device.hpp — per-lane device functions of the backward-search path, written for gfx950.
 //
-//   rrr_decode / rrr_rank1 / rrr_access     RrrVector.rankOnes RRR:358-396, access RRR:314-349
+//   bv_rank1* / bv_access                   RrrVector.rankOnes RRR:358-396, access RRR:314-349 over expanded cells
+//   rrr_decode / rrr_rank1 / rrr_access     the same over the compressed form (stand-alone RrrVector handles)
 //   wt_rank                                 WaveletFixedBlockBoosting.rank WFBB:1010-1285
 //   wt_inverse_select                       WaveletFixedBlockBoosting.inverseSelect WFBB:1305-1537
 //   fm_* helpers                            FmIndex FM:455-922

@@ -5,10 +5,14 @@
 //   k_extract          FmIndex.extract          FM:564-608   one lane per query
 //   k_extract_boundary extractUntilBoundary{,Left,Right} FM:640-922  one lane per query
 //
-// Every workgroup stages the (halved, 32 KiB) RRR value-of-offset table (RRR:106) into LDS once and
-// then grid-strides over queries.  The work is bit-level integer gather (no MFMA): throughput comes from
-// tens of thousands of independent dependent-load chains in flight, the two lanes of a pattern
-// sharing their sectors (start and end of an interval usually fall in the same blocks).
+//   k_order_*          the plan stage of a batch: code words, suffix order (bucket pass + tile-local radix sort)
+//   k_wt_*, k_rrr_*    WaveletFixedBlockBoosting / RrrVector as stand-alone structures
+//   k_segment_*        merging the answers of a segment set
+//
+// Workgroups grid-stride over queries; the FM kernels stage the superblock headers (10 KiB) in LDS.  The work is
+// bit-level integer gather (no MFMA): throughput comes from tens of thousands of independent dependent-load
+// chains in flight, the two lanes of a pattern sharing their sectors (start and end of an interval usually
+// fall in the same blocks).
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -18,8 +22,8 @@
 
 namespace fmx {
 
-// Workgroup size is a template parameter (512 / 1024 threads).  Only k_locate_walk reads an RRR vector (the
-// sampled-suffix bitmap) and stages the 32 KiB value-of-offset table in LDS; the other kernels use no LDS.
+// Workgroup size is a template parameter (512 / 1024 threads).  Only the stand-alone RrrVector kernels stage the
+// 32 KiB value-of-offset table in LDS.
 // FMX_WAVES_PER_EU asks the register allocator for 8 waves per SIMD (<= 64 VGPRs, <= 80 SGPRs): the
 // kernels are latency-bound chains of dependent loads, so resident waves are what hides latency.
 #define FMX_KERNEL(BLOCK) __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
