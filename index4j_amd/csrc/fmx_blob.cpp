@@ -249,9 +249,18 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
             A.at<SbcEntry>(off)[s * sigma + c] = e;
         }
 
-    // mapping rows by global symbol unless the alphabet is so large that the table would explode (rows of symbols
-    // a superblock does not hold are pure skip pointers)
-    const bool by_symbol = g_map_by_symbol < 0 ? sigma <= 1024 : g_map_by_symbol != 0;
+    // mapping rows by global symbol (rows of symbols a superblock does not hold are pure skip pointers)
+    bool by_symbol = g_map_by_symbol > 0;
+    if (g_map_by_symbol < 0) {  // automatic: rows by symbol unless that more than doubles the tables
+        int64_t rows_by_code = 0, rows_by_symbol = 0;
+        for (int64_t s = 0; s < n_sb; ++s) {
+            const int bsl = w.sb[(size_t)s].block_size_log;
+            if (bsl < 0 || bsl > 20) continue;
+            rows_by_code += ((int64_t)w.sb[(size_t)s].sigma + 1) << (20 - bsl);
+            rows_by_symbol += (int64_t)sigma << (20 - bsl);
+        }
+        by_symbol = rows_by_symbol <= 2 * rows_by_code;
+    }
     h.map_by_symbol = by_symbol ? 1 : 0;
     const size_t sbd_off = A.alloc((size_t)n_sb * sizeof(SbDesc));
     h.off_sbdesc = off8(sbd_off);
