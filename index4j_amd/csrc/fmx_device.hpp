@@ -1132,7 +1132,9 @@ FMX_HD int32_t fm_extract_boundary(const DevIndex &ix, const uint16_t *inv, int 
             int32_t c;
             row = fm_lf_step(ix, inv, row, c, status);
             ++steps;
-            if (steps > ix.length) {  // unreachable on a well-formed index (the walk ends at the sentinel)
+            // unreachable on a well-formed index: at most `skip` <= sampleRate uncounted steps (they may wrap around
+            // a text shorter than the sample rate), then the walk ends at the boundary or the sentinel
+            if (steps > ix.length + ix.sample_rate) {
                 status = ST_JAVA_AIOOBE;
                 return 0;
             }

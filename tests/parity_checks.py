@@ -66,7 +66,10 @@ def check_all(make_engine, text, sr, rnd, n_q=120):
             assert st3[i] != 0, (i, e)
     fr = np.array([rnd.randrange(L) for _ in range(n_q)], np.int32)
     fr[:2] = (-1, L + 3)
-    bch = "\n" if "\n" in text else text[len(text) // 2]
+    if isinstance(text, str):
+        bch = "\n" if "\n" in text else text[len(text) // 2]
+    else:  # uint16 array
+        bch = 10 if (t16 == 10).any() else int(t16[L // 2])
     for mode in (0, 1, 2):
         for cap, offs in ((1 << 12, 0), (40, 0), (90, 5), (0, 0)):
             results = [h.extract_boundary_batch(fr, bch, mode, cap, offs)]

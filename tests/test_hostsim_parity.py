@@ -107,3 +107,11 @@ def test_mapping_rows_by_superblock_code_layout():
         check_all(make_sim, big, 8, random.Random(17), n_q=60)  # > 1024 symbols, rows by symbol all the same
     finally:
         ia.lib.fmx_set_option(b"map_by_symbol", -1)
+
+
+def test_texts_shorter_than_the_sample_rate():
+    """the left walk of extractUntilBoundary first skips up to sampleRate uncounted steps (FM:645-653), which on a
+    text shorter than the sample rate wraps around the whole text before the first counted character"""
+    rnd = random.Random(21)
+    for text, sr in (("A", 2), ("A", 3), ("AB", 3), ("BAA", 3), ("AB", 64), ("hello\nworld", 100)):
+        check_all(make_sim, text, sr, rnd, n_q=12)

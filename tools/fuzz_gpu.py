@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the GPU path against the oracle: random texts (alphabet 2..3000 symbols, runs, embedded
+sentinels, lengths that cross the 2^20 superblock boundary now and then), random sample rates, all query kinds
+through tests/parity_checks.check_all.  usage: python tools/fuzz_gpu.py [--seconds 240] [--seed 1]"""
+import argparse
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def random_text(rnd):
+    kind = rnd.randrange(6)
+    sigma = rnd.choice([2, 3, 5, 17, 64, 200, 257, 700, 3000])
+    n = rnd.choice([1, 7, 100, 5000, 40_000, 150_000, 300_000]) if rnd.random() < 0.9 else (1 << 20) + rnd.randrange(-3, 70_000)
+    rng = np.random.default_rng(rnd.randrange(1 << 30))
+    if kind == 0:
+        a = rng.integers(0, sigma, n)
+    elif kind == 1:  # skewed
+        a = np.minimum((rng.exponential(sigma / 8.0, n)).astype(np.int64), sigma - 1)
+    elif kind == 2:  # long runs
+        a = np.repeat(rng.integers(0, sigma, n // 50 + 1), rng.integers(1, 100, n // 50 + 1))[:n]
+    elif kind == 3:  # periodic
+        p = rng.integers(0, sigma, rnd.randrange(1, 40))
+        a = np.tile(p, n // len(p) + 1)[:n]
+    elif kind == 4:  # blocks with different alphabets
+        parts = [rng.integers(lo, lo + max(2, sigma // 8), 3000) for lo in rng.integers(0, max(1, sigma - sigma // 8), n // 3000 + 1)]
+        a = np.concatenate(parts)[:n]
+    else:  # text-like with line breaks
+        a = rng.integers(0, sigma, n)
+        a[rng.random(n) < 0.02] = 0
+    if len(a) == 0:
+        a = np.array([32], np.int64)
+    a = (a.astype(np.int64) + 33).astype(np.uint16)
+    n = len(a)
+    a[a == 43] = 10  # some newlines
+    if rnd.random() < 0.2 and n > 3:
+        a[rng.integers(0, n, max(1, n // 500))] = 0  # embedded sentinels
+    return a
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    import index4j_amd as ia
+    from parity_checks import GpuEngine, check_all
+
+    rnd = random.Random(args.seed)
+    t0 = time.time()
+    cases = 0
+    while time.time() - t0 < args.seconds:
+        text = random_text(rnd)
+        sr = rnd.choice([1, 2, 3, 8, 16, 32, 64, 100])
+        layout = rnd.choice([-1, 0, 1])
+        cache = rnd.choice([320, 0])
+        ia.lib.fmx_set_option(b"map_by_symbol", layout)
+        ia.lib.fmx_set_option(b"sb_cache_limit", cache)
+        ia.lib.fmx_set_option(b"boundary_group", rnd.choice([0, 1, 2, 4, 8]))
+        try:
+            check_all(lambda t, s: GpuEngine(t, s), text, sr, random.Random(rnd.randrange(1 << 30)), n_q=60)
+        except Exception:
+            print("FAILED: seed %d case %d len %d sr %d layout %d cache %d" % (args.seed, cases, len(text), sr, layout, cache), flush=True)
+            raise
+        cases += 1
+    print("fuzz ok: %d cases in %.0f s (seed %d)" % (cases, time.time() - t0, args.seed))
+
+
+if __name__ == "__main__":
+    main()
