@@ -66,6 +66,25 @@ def main():
         ia.lib.fmx_set_option(b"boundary_group", rnd.choice([0, 1, 2, 4, 8]))
         try:
             check_all(lambda t, s: GpuEngine(t, s), text, sr, random.Random(rnd.randrange(1 << 30)), n_q=60)
+            if cases % 6 == 0 and len(text) >= 2000:  # a batch large enough for the planned path of count / locate
+                import orc
+
+                fm = ia.FmIndex(text, sr, True, device=0)
+                o = orc.OracleFmIndex(text, sr, True)
+                t16 = ia.as_chars(text)
+                r2 = random.Random(cases)
+                pats = [t16[p_:p_ + r2.randrange(1, 22)] for p_ in (r2.randrange(len(t16) - 1) for _ in range(20000))]
+                for k in range(0, 20000, 97):
+                    pats[k] = pats[k].copy()
+                    pats[k][r2.randrange(len(pats[k]))] = 7  # absent character
+                ch, off = ia.pack_patterns(pats)
+                cnt, st, lf = fm.count_batch(ch, off, want_steps=True)
+                oc, ost = o.count_batch(ch, off, threads=8)
+                assert (cnt == oc).all() and (st == ost).all(), "planned count batch"
+                locs, found, st2 = fm.locate_batch(ch, off, 3)
+                for k in range(0, 20000, 211):
+                    kk, ll = o.locate(pats[k], max_matches=3, cap=3)
+                    assert found[k] == kk and (locs[k, :kk] == ll).all(), "planned locate batch"
         except Exception:
             print("FAILED: seed %d case %d len %d sr %d layout %d cache %d" % (args.seed, cases, len(text), sr, layout, cache), flush=True)
             raise
