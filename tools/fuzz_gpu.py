@@ -66,6 +66,11 @@ def main():
         ia.lib.fmx_set_option(b"boundary_group", rnd.choice([0, 1, 2, 4, 8]))
         try:
             check_all(lambda t, s: GpuEngine(t, s), text, sr, random.Random(rnd.randrange(1 << 30)), n_q=60)
+            if cases % 3 == 1:  # the builder with its suffix-array stage on the GPU gives the same bytes
+                extract = rnd.random() < 0.7
+                a = ia.FmIndex(text, sr, extract, device=None).write(False)
+                b = ia.FmIndex(text, sr, extract, device=None, build_device=0).write(False)
+                assert a == b, "device construction differs"
             if cases % 6 == 0 and len(text) >= 2000:  # a batch large enough for the planned path of count / locate
                 import orc
 
