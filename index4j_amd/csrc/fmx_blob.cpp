@@ -381,6 +381,33 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
         d.var_len = (int32_t)sb.var.size();
         if (!sb.var.empty()) memcpy(A.at<uint8_t>(off), sb.var.data(), sb.var.size());
         if (!expanded_reserve(A, sb.rank_support, d.rrr, jobs[(size_t)s], err)) return -8;
+        {
+            // leaf section for inverseSelect: per leaf {symbol as reported (run blocks: masked to 8 bits, WFBB:1332),
+            // folded superblock rank of that symbol + the leaf's rank at block start}
+            const size_t leaf_off = A.alloc(4 * sb.var.size() + 64);
+            d.rrr.off_bits = off8(leaf_off);
+            uint8_t *dst = A.at<uint8_t>(leaf_off);
+            const SbcEntry *sbc_row = A.at<SbcEntry>((size_t)h.off_sbc << 3) + (size_t)s * (size_t)sigma;
+            const uint8_t *var = sb.var.data();
+            const int64_t var_len = (int64_t)sb.var.size();
+            for (size_t b = 0; b < sb.block_headers.size(); ++b) {
+                const BlockHeader &bh = sb.block_headers[b];
+                const int hgt = bh.tree_height, n_leaves = (int)bh.sigma + 1;
+                if (hgt < 0 || n_leaves <= 0 || bh.var_off < 0) continue;
+                const int64_t leaves = (int64_t)bh.var_off + (hgt > 0 ? (int64_t)(hgt - 1) * 4 : 0);
+                if (leaves + (int64_t)n_leaves * 5 > var_len) continue;
+                if (4 * (int64_t)bh.var_off + 8 * (int64_t)n_leaves > 4 * var_len + 56) continue;
+                for (int i = 0; i < n_leaves; ++i) {
+                    const uint8_t *lp = var + leaves + (int64_t)i * 5;
+                    int symbol = (int)lp[0] | ((int)lp[1] << 8);
+                    if (hgt == 0) symbol &= 0xff;  // Q1
+                    const uint32_t rank_block = (uint32_t)lp[2] | ((uint32_t)lp[3] << 8) | ((uint32_t)lp[4] << 16);
+                    const uint32_t folded = (symbol < sigma ? (uint32_t)sbc_row[symbol].rank : 0u) + rank_block;
+                    const uint64_t v = ((uint64_t)folded << 32) | (uint64_t)(uint32_t)symbol;
+                    memcpy(dst + 4 * (size_t)bh.var_off + 8 * (size_t)i, &v, 8);
+                }
+            }
+        }
         *A.at<SbDesc>(sbd_off + (size_t)s * sizeof(SbDesc)) = d;
     }
     A.alloc(64);  // tail guard

@@ -33,7 +33,7 @@
 namespace fmx {
 
 constexpr uint32_t kBlobMagic = 0x31584D46u;  // "FMX1"
-constexpr uint32_t kBlobVersion = 9;
+constexpr uint32_t kBlobVersion = 10;
 
 struct RrrRecord {         // 16 bytes: 16 blocks of 15 bits
     uint32_t ones_before;  // 1-bits in all earlier blocks
@@ -57,7 +57,9 @@ constexpr uint32_t kBvCellBits = 96;
 
 struct RrrDesc {           // 32 bytes; the first 16 are what a rank needs (one dwordx4 load)
     uint32_t off_rec;      // RrrRecord[n_rec]   (expanded vectors: BvCell[n_rec])
-    uint32_t off_bits;     // offsets bit stream, 64-bit words LSB-first (+2 guard words)   (expanded vectors: 0)
+    uint32_t off_bits;     // offsets bit stream, 64-bit words LSB-first (+2 guard words)   (a superblock's expanded
+                           // vector: offset of its leaf section — u64 {symbol, folded rank} per leaf, block b's
+                           // leaves at byte 4 * var_off(b); the sampled-row bitmap: 0)
     int32_t length;        // RRR:94
     int32_t total_ones;    // RRR:95
     int32_t n_rec;

@@ -702,11 +702,17 @@ FMX_HD int32_t wt_inverse_select_folded(const DevIndex &ix, const uint16_t *inv,
     const uint8_t *leaves = hdr + (tree_height > 0 ? (tree_height - 1) * 4 : 0);  // WFBB:1324-1327
     const SbcEntry *row = ix.sbc + (uint64_t)sb_id * (uint32_t)ix.wt_sigma;
 
-    if (tree_height == 0) {  // WFBB:1329-1355
-        const uint64_t leaf = ld64u(leaves);
-        const int32_t c = (int32_t)(leaf & 0x00ffu);  // WFBB:1332: masked to 8 bits (Q1)
-        rank_out = row[c].rank + (int32_t)((leaf >> 16) & 0xffffffu) + (int32_t)block_index;
-        return c;
+    // The image keeps, per leaf of every block, {symbol as inverseSelect reports it, superblock rank of that symbol
+    // + the leaf's rank at block start}: what the reference reads from the leaf entry and then from
+    // superBlockRank[symbol] (WFBB:1501-1533) is ONE load here.  The table lives at 4 * var_off of the block inside
+    // the superblock's leaf section (view.off_bits carries its offset for the wavelet tree's vectors).
+    const uint8_t *leaf2 = ix.base + ((uint64_t)rv.off_bits << 3) + 4 * (uint64_t)(uint32_t)bh.var_off;
+    (void)leaves;
+    (void)row;
+    if (tree_height == 0) {  // WFBB:1329-1355; the stored symbol is already masked to 8 bits (WFBB:1332, Q1)
+        const uint64_t lf = ld64u(leaf2);
+        rank_out = (int32_t)(lf >> 32) + (int32_t)block_index;
+        return (int32_t)(lf & 0xffffu);
     }
 
     const uint32_t second0 = (uint32_t)((tree_height - 1) * 4 + ((int32_t)bh.sigma + 1) * 5);
@@ -776,10 +782,9 @@ FMX_HD int32_t wt_inverse_select_folded(const DevIndex &ix, const uint16_t *inv,
         temp_code <<= 1;
     }
     block_c += code - temp_code;
-    const uint64_t leaf = ld64u(leaves + 5 * block_c);
-    const int32_t c = (int32_t)(leaf & 0xffffu);                                        // WFBB:1501-1506
-    rank_out = row[c].rank + (int32_t)((leaf >> 16) & 0xffffffu) + t.node_rank;        // WFBB:1521-1533
-    return c;
+    const uint64_t lf = ld64u(leaf2 + 8 * block_c);
+    rank_out = (int32_t)(lf >> 32) + t.node_rank;  // WFBB:1501-1533
+    return (int32_t)(lf & 0xffffu);
 }
 
 FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t &rank_out) {
