@@ -3,7 +3,7 @@
 import sys, time, numpy as np
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
 import index4j_amd as ia, orc
-n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 29)
+n = (2**31 - 2) if (len(sys.argv) > 1 and sys.argv[1] == "max") else 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 29)
 t0=time.time(); t = ia.synth_log(n); print("text", time.time()-t0, flush=True)
 t0=time.time(); fm = ia.FmIndex(t, 32, True, device=0, build_device=0); print("build+to_device", time.time()-t0, fm.build_stats, flush=True)
 pat, off, pos = ia.synth_patterns(t, 8, 200000)
