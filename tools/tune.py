@@ -35,7 +35,7 @@ def main():
     stream = torch.cuda.current_stream()
     results = {}
     ref = None
-    variants = [(sb, b, g) for sb in (0, 14, 21, 28) for b in (512,) for g in (4, 8, 16)]
+    variants = [(sb, b, g) for sb in (0, 21, 24, 28, 32) for b in (512, 1024) for g in (4, 8, 16, 32)]
     for rnd in range(args.rounds):
         for (sb, b, g) in variants:
             ia.lib.fmx_set_option(b"sort_min", 0 if sb == 0 else 16384)
