@@ -15,7 +15,11 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <functional>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -597,8 +601,21 @@ int host_sa_stage(const int16_t *seq, int32_t n, int alphabet, int sample_rate, 
     return 0;
 }
 
+// FMX_BUILD_TIMING=1 prints the wall time of the constructor's phases to stderr
+struct PhaseTimer {
+    const bool on = getenv("FMX_BUILD_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[fmx build] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t).count());
+        t = now;
+    }
+};
+
 int build_model(const uint16_t *input, int32_t n_in, int32_t sample_rate, bool enable_extract, FmModel &m,
                 std::string &err, int build_device, SaStageStats *stats) {
+    PhaseTimer timer;
     if (n_in < 0 || sample_rate <= 0 || n_in == INT32_MAX) {
         err = "bad arguments";
         return -1;
@@ -610,40 +627,81 @@ int build_model(const uint16_t *input, int32_t n_in, int32_t sample_rate, bool e
     m.length = n;
 
     // FM:396-435: codes in order of first appearance; the appended sentinel is code 0; an embedded
-    // '\0' gets code 1
+    // '\0' gets code 1.  One parallel pass collects, per character, its first position and its count; the codes
+    // follow from the first positions, the mapped text and cumulativeCounts (FM:307-327) from a second pass.
+    unsigned n_threads = std::thread::hardware_concurrency();
+    if (n_threads == 0) n_threads = 1;
+    if (n_threads > 64) n_threads = 64;
+    if (n_in < (1 << 20)) n_threads = 1;
+    auto for_chunks = [&](const std::function<void(unsigned, int32_t, int32_t)> &fn) {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < n_threads; ++t) {
+            const int32_t lo = (int32_t)((int64_t)n_in * t / n_threads), hi = (int32_t)((int64_t)n_in * (t + 1) / n_threads);
+            if (t + 1 == n_threads)
+                fn(t, lo, hi);
+            else
+                pool.emplace_back(fn, t, lo, hi);
+        }
+        for (auto &th : pool) th.join();
+    };
+    std::vector<std::vector<int32_t>> first_seen(n_threads), seen_count(n_threads);
+    for_chunks([&](unsigned t, int32_t lo, int32_t hi) {
+        std::vector<int32_t> &first = first_seen[t], &count = seen_count[t];
+        first.assign(65536, -1);
+        count.assign(65536, 0);
+        for (int32_t i = lo; i < hi; ++i) {
+            const uint16_t ch = input[i];
+            if (first[ch] < 0) first[ch] = i;
+            ++count[ch];
+        }
+    });
+    std::vector<int32_t> first(65536, -1);
+    std::vector<int64_t> raw_count(65536, 0);
+    for (unsigned t = 0; t < n_threads; ++t)  // chunks are in text order: the first chunk that saw it wins
+        for (int ch = 0; ch < 65536; ++ch) {
+            if (first[(size_t)ch] < 0 && first_seen[t][(size_t)ch] >= 0) first[(size_t)ch] = first_seen[t][(size_t)ch];
+            raw_count[(size_t)ch] += seen_count[t][(size_t)ch];
+        }
+    std::vector<std::vector<int32_t>>().swap(first_seen);
+    std::vector<std::vector<int32_t>>().swap(seen_count);
     std::vector<int32_t> code_of(65536, -1);
-    int64_t zeros = 1;
-    for (int32_t i = 0; i < n_in; ++i) zeros += (input[i] == 0);
+    const int64_t zeros = 1 + raw_count[0];
     int mapped = (zeros != 1) ? 1 : 0;
     m.map_keys.push_back(0);
     m.map_vals.push_back((int16_t)mapped);
     code_of[0] = mapped;
     ++mapped;
-    for (int32_t i = 0; i < n_in; ++i) {
-        const uint16_t ch = input[i];
-        if (code_of[ch] < 0) {
-            code_of[ch] = mapped;
-            m.map_keys.push_back(ch);
-            m.map_vals.push_back((int16_t)mapped);
-            ++mapped;
-        }
-    }
-    if (m.map_keys.size() > 32767) {  // FM:423-426
+    std::vector<std::pair<int32_t, int32_t>> order;  // (first position, character)
+    for (int ch = 1; ch < 65536; ++ch)
+        if (first[(size_t)ch] >= 0) order.emplace_back(first[(size_t)ch], ch);
+    std::sort(order.begin(), order.end());
+    if (order.size() + 1 > 32767) {  // FM:423-426
         err = "Input has more than 32767 different symbols";
         return -2;
+    }
+    for (const auto &fc : order) {
+        code_of[(size_t)fc.second] = mapped;
+        m.map_keys.push_back(fc.second);
+        m.map_vals.push_back((int16_t)mapped);
+        ++mapped;
     }
     const int distinct = (int)m.map_keys.size();  // == alphabet.size() of FM:397-404
     m.look_up.assign((size_t)distinct + 1, 0);    // FM:411
     for (size_t i = 0; i < m.map_keys.size(); ++i) m.look_up[(size_t)m.map_vals[i]] = m.map_keys[i];
 
     std::vector<int16_t> seq((size_t)n);
-    for (int32_t i = 0; i < n_in; ++i) seq[(size_t)i] = (int16_t)code_of[input[i]];
+    for_chunks([&](unsigned, int32_t lo, int32_t hi) {
+        for (int32_t i = lo; i < hi; ++i) seq[(size_t)i] = (int16_t)code_of[input[i]];
+    });
     seq[(size_t)n - 1] = 0;  // FM:433
 
+    timer.mark("alphabet + mapped text");
     // FM:307-327
     const int n_look = (int)m.look_up.size();
     std::vector<int32_t> cc(65536, 0);
-    for (int32_t i = 0; i < n; ++i) ++cc[(size_t)seq[(size_t)i]];
+    for (int ch = 0; ch < 65536; ++ch)
+        if (raw_count[(size_t)ch]) cc[(size_t)code_of[(size_t)ch]] += (int32_t)raw_count[(size_t)ch];
+    ++cc[0];  // the terminator (code 0 at n-1 only)
     int32_t off = cc[0];
     cc[0] = 0;
     for (int i = 1; i < n_look; ++i) {
@@ -654,6 +712,7 @@ int build_model(const uint16_t *input, int32_t n_in, int32_t sample_rate, bool e
     m.C.assign(cc.begin(), cc.begin() + n_look);
     m.C.push_back(m.length);
 
+    timer.mark("cumulative counts");
     // FM:329-394: suffix array -> sampled rows, inverse samples, BWT (on the host, or in HBM)
     SaStage st;
     int rc;
@@ -667,11 +726,14 @@ int build_model(const uint16_t *input, int32_t n_in, int32_t sample_rate, bool e
         rc = host_sa_stage(seq.data(), n, n_look + 1, sample_rate, enable_extract, st);
     }
     if (rc) return rc;
+    timer.mark("suffix-array stage");
     std::vector<int16_t>().swap(seq);
     m.bw_suffixes = min_bits((uint64_t)n);
     m.suffixes.init(n / sample_rate + 1, m.bw_suffixes);
     for (size_t k = 0; k < st.suffix_vals.size(); ++k) m.suffixes.set((int64_t)k, st.suffix_vals[k]);
+    timer.mark("pack suffix samples");
     build_rrr(st.which.data(), n, sample_rate, m.sampled);
+    timer.mark("RRR of the sample bitmap");
     if (enable_extract) {
         m.bw_positions = m.bw_suffixes;
         m.positions.init(n / sample_rate + 2, m.bw_positions);
@@ -679,8 +741,10 @@ int build_model(const uint16_t *input, int32_t n_in, int32_t sample_rate, bool e
         for (int64_t k = 0; k < n_pos; ++k) m.positions.set(k, st.position_vals[(size_t)k]);
         m.positions.set((n - 1) / sample_rate + 1, m.positions.get(0));  // FM:367-369
     }
+    timer.mark("pack inverse samples");
     std::vector<int16_t> &bwt = st.bwt;
     build_wavelet(bwt.data(), n, sample_rate, m.wt);  // FM:173
+    timer.mark("wavelet tree");
     return 0;
 }
 

@@ -106,3 +106,17 @@ def test_convert_byte_pattern():
     dest = np.zeros(32, np.uint16)
     n = ia.FmIndex.convertBytePatternToCharPattern(s.encode("utf-8"), 0, len(s.encode("utf-8")), dest)
     assert ia.chars_to_str(dest[:n]) == s
+
+
+def test_parallel_alphabet_pass_is_byte_identical():
+    """texts of 2^20 chars and more take the constructor's multi-threaded alphabet / mapping pass (first appearance
+    order from per-chunk first positions): same bytes as the oracle, with and without embedded sentinels"""
+    import numpy as np
+
+    n = (1 << 20) + 12345
+    t = ia.synth_log(n)
+    assert ia.FmIndex(t, 32, True, device=None).write(False) == orc.OracleFmIndex(t, 32, True).write(False)
+    z = t.copy()
+    z[np.arange(1000, n, 5000)] = 0
+    z[5] = 40000  # a late-alphabet character early in the text
+    assert ia.FmIndex(z, 16, False, device=None).write(False) == orc.OracleFmIndex(z, 16, False).write(False)
