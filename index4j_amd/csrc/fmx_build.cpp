@@ -92,45 +92,96 @@ static inline unsigned bits15(const uint64_t *w, int64_t from, int64_t nbits) {
     return (unsigned)(v & low_bits((int)len));
 }
 
-void build_rrr(const uint64_t *bits, int64_t nbits, int sample_size, RrrModel &r) {
+// atomically OR `nbits` of `value` into a word array shared by several writer threads (neighbouring chunks meet
+// inside a word)
+static inline void put_bits_shared(uint64_t *words, int64_t bit, uint64_t value, int nbits) {
+    if (nbits <= 0) return;
+    value &= low_bits(nbits);
+    const size_t w = (size_t)(bit >> 6);
+    const int off = (int)(bit & 63);
+    __atomic_fetch_or(&words[w], value << off, __ATOMIC_RELAXED);
+    if (off + nbits > 64) __atomic_fetch_or(&words[w + 1], value >> (64 - off), __ATOMIC_RELAXED);
+}
+
+// RRR:225-286.  `threads` > 1: the blocks are cut into chunks (multiples of 16 * sample_size blocks); one pass
+// counts every chunk's offset bits and ones, a prefix over the chunks gives each its start, a second pass writes.
+void build_rrr(const uint64_t *bits, int64_t nbits, int sample_size, RrrModel &r, int threads) {
     const RrrTables &T = tables();
     r.sample_size = sample_size;
     r.length = (int32_t)nbits;
     const int64_t num_blocks = nbits / 15 + ((nbits % 15 > 0) ? 1 : 0);  // RRR:232
     r.classes.init((int32_t)num_blocks, 4);
-    int64_t total_offset_bits = 0, total_ones = 0;
-    for (int64_t b = 0; b < num_blocks; ++b) {
-        unsigned v = bits15(bits, b * 15, nbits);
-        int k = __builtin_popcount(v);
-        r.classes.set(b, (uint64_t)k);
-        total_offset_bits += T.bits_needed[k];
-        total_ones += k;
+    int64_t chunk = (num_blocks + threads - 1) / (threads > 0 ? threads : 1);
+    const int64_t grain = 16 * (int64_t)sample_size;  // chunk starts: whole class words and whole samples
+    chunk = (chunk + grain - 1) / grain * grain;
+    if (chunk <= 0) chunk = grain;
+    const int64_t n_chunks = num_blocks == 0 ? 0 : (num_blocks + chunk - 1) / chunk;
+    std::vector<int64_t> chunk_bits((size_t)n_chunks + 1, 0), chunk_ones((size_t)n_chunks + 1, 0);
+    auto run = [&](const std::function<void(int64_t)> &fn) {
+        if (threads <= 1 || n_chunks <= 1) {
+            for (int64_t c = 0; c < n_chunks; ++c) fn(c);
+            return;
+        }
+        std::atomic<int64_t> next{0};
+        auto worker = [&]() {
+            for (;;) {
+                const int64_t c = next.fetch_add(1);
+                if (c >= n_chunks) return;
+                fn(c);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads && t < n_chunks; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto &th : pool) th.join();
+    };
+    run([&](int64_t c) {  // classes (chunks start on class-word boundaries) and per-chunk totals
+        const int64_t lo = c * chunk, hi = std::min(num_blocks, lo + chunk);
+        int64_t ob = 0, ones = 0;
+        for (int64_t b = lo; b < hi; ++b) {
+            const unsigned v = bits15(bits, b * 15, nbits);
+            const int k = __builtin_popcount(v);
+            r.classes.set(b, (uint64_t)k);
+            ob += T.bits_needed[k];
+            ones += k;
+        }
+        chunk_bits[(size_t)c + 1] = ob;
+        chunk_ones[(size_t)c + 1] = ones;
+    });
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        chunk_bits[(size_t)c + 1] += chunk_bits[(size_t)c];
+        chunk_ones[(size_t)c + 1] += chunk_ones[(size_t)c];
     }
+    const int64_t total_offset_bits = chunk_bits[(size_t)n_chunks], total_ones = chunk_ones[(size_t)n_chunks];
     r.total_ones = (int32_t)total_ones;
     r.bits_per_offset_pos = min_bits((uint64_t)total_offset_bits);                         // RRR:262
     r.sampled_offsets.init((int32_t)(num_blocks / sample_size + 1), r.bits_per_offset_pos);  // RRR:263
     r.prefix_sums.init((int32_t)(num_blocks / sample_size + 2), min_bits((uint64_t)total_ones));  // RRR:264
-    PackedVec off;
-    off.width = 1;
-    off.words.assign((size_t)words_for_bits(total_offset_bits) + 1, 0);  // VIV:41-47 (+1 scratch word, trimmed below)
-    int64_t cur_bits = 0, prefix = 0;
-    int32_t sampled = 0;
-    for (int64_t b = 0; b < num_blocks; ++b) {
-        unsigned v = bits15(bits, b * 15, nbits);
-        int k = __builtin_popcount(v);
-        int nb = T.bits_needed[k];
-        off.put_bits(cur_bits, T.offset_of_value[v], nb);
-        if (b % sample_size == 0) {
-            r.sampled_offsets.set(sampled, (uint64_t)cur_bits);
-            r.prefix_sums.set(sampled, (uint64_t)prefix);
-            ++sampled;
+    std::vector<uint64_t> off((size_t)words_for_bits(total_offset_bits) + 1, 0);  // VIV:41-47 (+1 scratch word, trimmed below)
+    run([&](int64_t c) {
+        const int64_t lo = c * chunk, hi = std::min(num_blocks, lo + chunk);
+        int64_t cur_bits = chunk_bits[(size_t)c], prefix = chunk_ones[(size_t)c];
+        for (int64_t b = lo; b < hi; ++b) {
+            const unsigned v = bits15(bits, b * 15, nbits);
+            const int k = __builtin_popcount(v);
+            const int nb = T.bits_needed[k];
+            put_bits_shared(off.data(), cur_bits, T.offset_of_value[v], nb);
+            if (b % sample_size == 0) {
+                const int64_t sampled = b / sample_size;
+                put_bits_shared(r.sampled_offsets.words.data(), sampled * r.sampled_offsets.width, (uint64_t)cur_bits,
+                                r.sampled_offsets.width);
+                put_bits_shared(r.prefix_sums.words.data(), sampled * r.prefix_sums.width, (uint64_t)prefix,
+                                r.prefix_sums.width);
+            }
+            cur_bits += nb;
+            prefix += k;
         }
-        cur_bits += nb;
-        prefix += k;
-    }
-    r.prefix_sums.set(sampled, (uint64_t)prefix);  // RRR:285
-    off.words.resize((size_t)words_for_bits(total_offset_bits));
-    r.offsets.swap(off.words);
+    });
+    // RRR:285: one more prefix sum after the last sampled block
+    const int64_t n_sampled = num_blocks == 0 ? 0 : (num_blocks - 1) / sample_size + 1;
+    r.prefix_sums.set(n_sampled, (uint64_t)total_ones);
+    off.resize((size_t)words_for_bits(total_offset_bits));
+    r.offsets.swap(off);
 }
 
 // all-zero RRR of n bits: getEstimatedMemoryUsage() (WFBB:961-965 -> RRR:418-423), closed form
@@ -732,7 +783,7 @@ int build_model(const uint16_t *input, int32_t n_in, int32_t sample_rate, bool e
     m.suffixes.init(n / sample_rate + 1, m.bw_suffixes);
     for (size_t k = 0; k < st.suffix_vals.size(); ++k) m.suffixes.set((int64_t)k, st.suffix_vals[k]);
     timer.mark("pack suffix samples");
-    build_rrr(st.which.data(), n, sample_rate, m.sampled);
+    build_rrr(st.which.data(), n, sample_rate, m.sampled, n >= (1 << 22) ? (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency())) : 1);
     timer.mark("RRR of the sample bitmap");
     if (enable_extract) {
         m.bw_positions = m.bw_suffixes;

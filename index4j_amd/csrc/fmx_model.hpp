@@ -114,7 +114,7 @@ struct SaStageStats;
 int build_model(const uint16_t *text, int32_t n, int32_t sample_rate, bool enable_extract, FmModel &out,
                 std::string &err, int build_device = -1, SaStageStats *stats = nullptr);
 void build_wavelet(const int16_t *bwt, int64_t n, int sampling_rate, WfbbModel &w);
-void build_rrr(const uint64_t *bits, int64_t nbits, int sample_size, RrrModel &r);
+void build_rrr(const uint64_t *bits, int64_t nbits, int sample_size, RrrModel &r, int threads = 1);
 const uint16_t *rrr_offset_of_value();  // 32768 entries
 const uint16_t *rrr_value_of_offset();  // 32768 entries
 const uint16_t *rrr_class_base();       // 16 entries  (CARDINALITY_OFFSETS, RRR:105)

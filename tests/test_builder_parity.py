@@ -120,3 +120,10 @@ def test_parallel_alphabet_pass_is_byte_identical():
     z[np.arange(1000, n, 5000)] = 0
     z[5] = 40000  # a late-alphabet character early in the text
     assert ia.FmIndex(z, 16, False, device=None).write(False) == orc.OracleFmIndex(z, 16, False).write(False)
+
+
+def test_threaded_rrr_of_the_sample_bitmap_is_byte_identical():
+    """from 2^22 chars on, the RRR of the sampled-row bitmap is encoded by several threads (chunk totals, prefix,
+    second pass with shared boundary words): same bytes as the oracle"""
+    t = ia.synth_log((1 << 22) + 777)
+    assert ia.FmIndex(t, 3, True, device=None).write(False) == orc.OracleFmIndex(t, 3, True).write(False)
