@@ -273,13 +273,26 @@ def main():
     patterns_per_s = world * n * args.steps / wall
     roof = None
     if bytes_per_step:
+        # a measured streaming figure beside the vendor peak: device-to-device copy of 1 GiB, read + write
+        src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
         achieved = bytes_per_step * lf_steps_per_launch / (kernel_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(args.text_log2, n, args.sample_rate), "kernel": "k_count",
                 "kernel_ms": kernel_ms, "step_ms_incl_sort": step_ms, "alg_bytes_per_lf_step": bytes_per_step,
                 "lf_steps_per_launch": lf_steps_per_launch,
-                "wt_levels_per_lf_step": holder.get("levels_per_step")}
+                "wt_levels_per_lf_step": holder.get("levels_per_step"),
+                "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs}
     out = {
         "metric": "patterns/sec + LF-steps/sec, 1M x 8-char count() on 256 MiB log index",
         "value": patterns_per_s,
