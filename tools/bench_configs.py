@@ -109,6 +109,31 @@ def main():
                 "checked_vs_oracle": args.check})
     print(json.dumps(out[-1]), flush=True)
 
+    # ---- second series of the reference's JMH state: random lowercase patterns (J-FMS:106-111), mostly early exits ----
+    nr = 1 << 20
+    rng = np.random.default_rng(7)
+    rpat = rng.integers(97, 123, nr * 8).astype(np.uint16)
+    roff = (np.arange(nr + 1) * 8).astype(np.int32)
+    d_rpat, d_roff = torch.from_numpy(rpat.view(np.int16)).to(dev), t32(roff)
+    d_rcnt = torch.zeros(nr, dtype=torch.int32, device=dev)
+    d_rlf = torch.zeros(nr, dtype=torch.int32, device=dev)
+
+    def rcount():
+        rc = ia.lib.fmx_count_batch_dev(fm32.handle, d_rpat.data_ptr(), d_roff.data_ptr(), nr, d_rcnt.data_ptr(), d_rlf.data_ptr(), None, sp)
+        assert rc == 0, ia.lib.fmx_last_error()
+
+    rcount()
+    torch.cuda.synchronize()
+    rc_host = d_rcnt.cpu().numpy()
+    oc, _ = o32.count_batch(rpat[: args.check * 8], roff[: args.check + 1])
+    assert (oc == rc_host[: args.check]).all()
+    ms = timed(rcount, stream, 10)
+    rlf = int(d_rlf.sum(dtype=torch.int64).item())
+    out.append({"config": "count 1M x 8 random a-z chars (early exits), 256 MiB, sampleRate 32", "ms": ms, "queries": nr,
+                "matching_patterns": int((rc_host > 0).sum()), "lf_steps": rlf, "queries_per_s": nr / ms * 1e3,
+                "lf_steps_per_s": rlf / ms * 1e3, "checked_vs_oracle": args.check})
+    print(json.dumps(out[-1]), flush=True)
+
     # ---- config 3: extractUntilBoundary('\n') for 100k hit locations, sampleRate 64 ----
     text, fm64, path64 = bench.build_or_load_index(ia, args.text_log2, 64, "/tmp/fmx_cache")
     fm64.to_device(0)
