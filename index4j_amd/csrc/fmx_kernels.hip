@@ -87,21 +87,16 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
                                                   const uint32_t *__restrict__ perm, int32_t n,
                                                   int32_t *__restrict__ counts, int32_t *__restrict__ lf_steps,
                                                   int32_t *__restrict__ status_out, int32_t *__restrict__ range_out,
-                                                  int xcd_remap, const uint64_t *__restrict__ codes) {
+                                                  const uint64_t *__restrict__ codes) {
     const uint16_t *s_inv = nullptr;  // no RRR vector on this kernel's path (the wavelet tree's are expanded)
     FMX_WITH_SB_CACHE(ix_global, ix);
     const int role = threadIdx.x & 1;
     const int code_bits = plan_code_bits(ix.wt_sigma), n_codes = codes ? 64 / code_bits : 0;
     const uint32_t code_mask = (1u << code_bits) - 1u;
     const int32_t pairs_per_grid = (int32_t)gridDim.x * (kBlock / 2);  // 32-bit indices: n < 2^31, fewer live registers
-    // XCD-aware block order (speed only): blocks b and b+8 share an XCD and its L2, so give the blocks of one
-    // XCD a CONTIGUOUS eighth of the (suffix-sorted) batch instead of every eighth tile
-    int32_t block = (int32_t)blockIdx.x;
-    if (xcd_remap) {
-        const int32_t nb = (int32_t)gridDim.x, xcd = block % 8, qd = nb / 8, rm = nb % 8;
-        block = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + block / 8;
-    }
-    for (int32_t q = block * (kBlock / 2) + (int32_t)(threadIdx.x >> 1); q < n; q += pairs_per_grid) {
+    // (an XCD-aware block order — a contiguous eighth of the sorted batch per XCD — was measured slower:
+    // profiles/r01_i_xcd_remap.txt)
+    for (int32_t q = (int32_t)blockIdx.x * (kBlock / 2) + (int32_t)(threadIdx.x >> 1); q < n; q += pairs_per_grid) {
         const int32_t p = perm ? (int32_t)perm[q] : q;
         const int32_t m = pat_off[p + 1] - pat_off[p];
         int status = ST_OK;
@@ -561,7 +556,6 @@ static int g_block = 512;
 static int g_groups_per_cu = 16;
 static int g_boundary_accel = 1;  // 0 = literal right walk of extractUntilBoundary (A/B and fallback)
 static int g_boundary_group = 4;  // lanes per query of extractUntilBoundary (0 = one lane per query)
-static int g_xcd_remap = 0;    // XCD-aware block order in k_count (measured slower: profiles/r01_i_xcd_remap.txt)
 static int g_lds_pad_kb = 0;   // experiment knob: extra dynamic LDS per workgroup (lowers occupancy)
 static int g_sort_min = 16384;  // batches at least this large are processed in suffix-sorted order (0 = never)
 // bins of the bucket pass = 2^coarse_bits (<= 14: they live in LDS).  Measured on configs[1] (tools/tune_coarse.py):
@@ -592,10 +586,6 @@ int set_option(const char *name, int value) {
     if (!strcmp(name, "coarse_bits")) {
         if (value < 4 || value > kCoarseBitsMax) return -1;
         g_coarse_bits = value;
-        return 0;
-    }
-    if (!strcmp(name, "xcd_remap")) {
-        g_xcd_remap = value != 0;
         return 0;
     }
     if (!strcmp(name, "lds_pad_kb")) {
@@ -692,7 +682,7 @@ int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_
                  const void *codes, int32_t n, int32_t *counts, int32_t *lf, int32_t *status, int32_t *range,
                  hipStream_t st) {
     if (n <= 0) return 0;
-    FMX_DISPATCH(k_count, 2 * (int64_t)n, ix, pat, off, perm, n, counts, lf, status, range, (perm && g_xcd_remap) ? 1 : 0,
+    FMX_DISPATCH(k_count, 2 * (int64_t)n, ix, pat, off, perm, n, counts, lf, status, range,
                  perm ? static_cast<const uint64_t *>(codes) : nullptr);
     return (int)hipGetLastError();
 }
