@@ -492,7 +492,9 @@ __global__ __launch_bounds__(kTileThreads) void k_order_tile_sort(DevIndex ix, c
     const int code_bits = plan_code_bits(ix.wt_sigma);
     using Sort = rocprim::block_radix_sort<uint32_t, kTileThreads, kTileItems, uint32_t>;
     __shared__ typename Sort::storage_type storage;
+    __shared__ uint32_t s_first, s_last;
     const int64_t base = (int64_t)blockIdx.x * kTile;
+    const int low_bits = sh.total_bits - sh.coarse_bits;
     uint32_t keys[kTileItems], vals[kTileItems];
     for (int k = 0; k < kTileItems; ++k) {
         const int64_t i = base + (int64_t)threadIdx.x * kTileItems + k;
@@ -500,12 +502,25 @@ __global__ __launch_bounds__(kTileThreads) void k_order_tile_sort(DevIndex ix, c
             const uint32_t p = perm_in[i];
             keys[k] = suffix_key(codes[p], code_bits, sh.chars, sh.bits);
             vals[k] = p;
+            // the input is in bucket order: the tile's first item has its smallest coarse key, its last item the largest
+            if (i == base) s_first = keys[k] >> low_bits;
+            if (i == n - 1 || i == base + kTile - 1) s_last = keys[k] >> low_bits;
         } else {
-            keys[k] = 0xffffffffu;  // padding sorts last and is dropped on write-back
+            keys[k] = 0;
             vals[k] = 0xffffffffu;
         }
     }
-    Sort().sort(keys, vals, storage, 0, 32);
+    __syncthreads();
+    // keys relative to the tile's first bucket: only the bits that can differ inside the tile are sorted
+    // (a tile inside one hot bucket sorts 16 bits instead of 28)
+    const uint32_t first = s_first, span = s_last - s_first;
+    int end_bit = low_bits + 1;
+    while ((span + 1) >> (end_bit - low_bits)) ++end_bit;  // room for span + 1: the padding sorts last
+    for (int k = 0; k < kTileItems; ++k) {
+        const int64_t i = base + (int64_t)threadIdx.x * kTileItems + k;
+        keys[k] = i < n ? keys[k] - (first << low_bits) : (span + 1) << low_bits;
+    }
+    Sort().sort(keys, vals, storage, 0, end_bit);
     for (int k = 0; k < kTileItems; ++k) {
         const int64_t i = base + (int64_t)threadIdx.x * kTileItems + k;
         if (i < n) perm_out[i] = vals[k];
