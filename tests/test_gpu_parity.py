@@ -545,3 +545,32 @@ def test_layout_variants_give_the_same_answers():
     finally:
         ia.lib.fmx_set_option(b"map_by_symbol", -1)
         ia.lib.fmx_set_option(b"sb_cache_limit", 320)
+
+
+def test_api_edge_cases():
+    """empty batches, zero-capacity buffers and bad arguments through the C ABI: no kernel launch with bad shapes,
+    library-level error codes instead"""
+    import ctypes as C
+
+    fm = ia.FmIndex(HD[:5000], 8, True, device=0)
+    e = np.zeros(0, np.uint16)
+    cnt, st = fm.count_batch(e, np.zeros(1, np.int32))
+    assert len(cnt) == 0
+    ch, off = ia.pack_patterns(["INFO", "a"])
+    locs, found, st = fm.locate_batch(ch, off, 5, loc_cap=0)  # no room at all: the JVM would raise AIOOBE on the first hit
+    assert locs.shape == (2, 0) and (found == 0).all() and (st == 9).all()
+    dst, ol, st = fm.extract_batch([3], [10], 0)
+    assert st[0] == 4  # "Supplied destination is not large enough"
+    dst, ol, st, aux = fm.extract_boundary_batch([3], "\n", 0, 0)
+    assert st[0] == 6  # "Supplied destination for extraction has size zero"
+    L = ia.lib
+    z = np.zeros(4, np.int32)
+    assert L.fmx_locate_extract_batch(fm.handle, ch.ctypes.data, off.ctypes.data, 2, 0, 8, z.ctypes.data, z.ctypes.data,
+                                      None, z.ctypes.data, None, None, None) == ia._lib.E_ARG  # max_matches must be >= 1
+    assert L.fmx_count_segments(None, 0, ch.ctypes.data, off.ctypes.data, 2, z.ctypes.data, None, None) == ia._lib.E_ARG
+    assert L.fmx_count_batch(None, ch.ctypes.data, off.ctypes.data, 2, z.ctypes.data, None, None) == ia._lib.E_ARG
+    host_only = ia.FmIndex("abc", 2, True, device=None)
+    assert L.fmx_count_batch(host_only.handle, ch.ctypes.data, off.ctypes.data, 2, z.ctypes.data, None, None) == ia._lib.E_NO_DEVICE
+    bad = np.frombuffer(b"\x07garbage-not-an-index", dtype=np.uint8)
+    h = C.c_void_p()
+    assert L.fmx_load(bad.ctypes.data, len(bad), C.byref(h)) in (ia._lib.E_VERSION, ia._lib.E_FORMAT)
