@@ -15,10 +15,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def random_text(rnd):
+def random_text(rnd, big=False):
     kind = rnd.randrange(6)
     sigma = rnd.choice([2, 3, 5, 17, 64, 200, 257, 700, 3000])
     n = rnd.choice([1, 7, 100, 5000, 40_000, 150_000, 300_000]) if rnd.random() < 0.9 else (1 << 20) + rnd.randrange(-3, 70_000)
+    if big:  # two to three superblocks; alphabets that change along the text (symbols absent from whole superblocks)
+        n = rnd.choice([(1 << 20) - 1, 1 << 20, (1 << 20) + 1, (1 << 21) - 1, (1 << 21) + rnd.randrange(0, 70_000), (1 << 20) + 300_000])
+        kind = rnd.choice([0, 2, 4, 4, 5])
     rng = np.random.default_rng(rnd.randrange(1 << 30))
     if kind == 0:
         a = rng.integers(0, sigma, n)
@@ -30,7 +33,8 @@ def random_text(rnd):
         p = rng.integers(0, sigma, rnd.randrange(1, 40))
         a = np.tile(p, n // len(p) + 1)[:n]
     elif kind == 4:  # blocks with different alphabets
-        parts = [rng.integers(lo, lo + max(2, sigma // 8), 3000) for lo in rng.integers(0, max(1, sigma - sigma // 8), n // 3000 + 1)]
+        seg = 3000 if not big else rnd.choice([3000, 200_000, 700_000])
+        parts = [rng.integers(lo, lo + max(2, sigma // 8), seg) for lo in rng.integers(0, max(1, sigma - sigma // 8), n // seg + 1)]
         a = np.concatenate(parts)[:n]
     else:  # text-like with line breaks
         a = rng.integers(0, sigma, n)
@@ -49,6 +53,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--big", action="store_true", help="texts of two to three superblocks with shifting alphabets")
     args = ap.parse_args()
     import index4j_amd as ia
     from parity_checks import GpuEngine, check_all
@@ -57,7 +62,7 @@ def main():
     t0 = time.time()
     cases = 0
     while time.time() - t0 < args.seconds:
-        text = random_text(rnd)
+        text = random_text(rnd, args.big)
         sr = rnd.choice([1, 2, 3, 8, 16, 32, 64, 100])
         layout = rnd.choice([-1, 0, 1])
         cache = rnd.choice([320, 0])
