@@ -93,8 +93,11 @@ def main():
                 assert (cnt == oc).all() and (st == ost).all(), "planned count batch"
                 locs, found, st2 = fm.locate_batch(ch, off, 3)
                 for k in range(0, 20000, 211):
-                    kk, ll = o.locate(pats[k], max_matches=3, cap=3)
-                    assert found[k] == kk and (locs[k, :kk] == ll).all(), "planned locate batch"
+                    try:
+                        kk, ll = o.locate(pats[k], max_matches=3, cap=3)
+                        assert st2[k] == 0 and found[k] == kk and (locs[k, :kk] == ll).all(), "planned locate batch"
+                    except IndexError:  # rank(size) with size % 2^20 == 0: the JVM raises AIOOBE (Q3)
+                        assert st2[k] == 9, "planned locate batch: AIOOBE expected"
         except Exception:
             print("FAILED: seed %d case %d len %d sr %d layout %d cache %d" % (args.seed, cases, len(text), sr, layout, cache), flush=True)
             raise
