@@ -1821,6 +1821,78 @@ void orc_fm_count_batch(const OrcFmIndex *f, const uint16_t *pat, const int32_t 
     }
 }
 
+/* fold this thread's counters into the batch total (threads of the batch helpers below) */
+static void cnt_fold_thread(void) {
+#pragma omp critical(orc_cnt_fold)
+    {
+        g_cnt_total.lf_steps += g_cnt.lf_steps;
+        g_cnt_total.alg_bytes += g_cnt.alg_bytes;
+        g_cnt_total.wt_levels += g_cnt.wt_levels;
+        g_cnt_total.quirk_runblock_right += g_cnt.quirk_runblock_right;
+        g_cnt_total.quirk_clamped_right += g_cnt.quirk_clamped_right;
+        g_cnt_total.rank_calls += g_cnt.rank_calls;
+        g_cnt_total.absent_superblock += g_cnt.absent_superblock;
+        g_cnt_total.absent_block += g_cnt.absent_block;
+        g_cnt_total.absent_scan_steps += g_cnt.absent_scan_steps;
+        g_cnt_total.run_block += g_cnt.run_block;
+    }
+    memset(&g_cnt, 0, sizeof g_cnt);
+}
+
+/* FM:504-552 looped: row i of locs (loc_cap ints) is query i's `locations` array */
+void orc_fm_locate_batch(const OrcFmIndex *f, const uint16_t *pat, const int32_t *pat_off, int32_t n, int max_matches,
+                         int32_t *locs, int loc_cap, int32_t *found, int32_t *status, int threads) {
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+#pragma omp for schedule(dynamic, 256)
+        for (int32_t i = 0; i < n; i++) {
+            int st = 0;
+            found[i] = orc_fm_locate(f, pat + pat_off[i], 0, pat_off[i + 1] - pat_off[i], locs + (size_t)i * (size_t)loc_cap,
+                                     loc_cap, max_matches, &st);
+            if (status) status[i] = st;
+        }
+        cnt_fold_thread();
+    }
+}
+
+/* FM:640-922 looped: row i of dst (dst_len chars) is query i's `destination` array (in/out) */
+void orc_fm_extract_until_boundary_batch(const OrcFmIndex *f, int mode, const int32_t *from, int32_t n, uint16_t boundary,
+                                         uint16_t *dst, int dst_len, int offset, int32_t *out_len, int32_t *status,
+                                         int32_t *aux, int threads) {
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+#pragma omp for schedule(dynamic, 256)
+        for (int32_t i = 0; i < n; i++) {
+            int st = 0, ax = 0;
+            const int r = orc_fm_extract_until_boundary(f, mode, from[i], dst + (size_t)i * (size_t)dst_len, dst_len, offset,
+                                                        boundary, &st, &ax);
+            out_len[i] = st ? 0 : r;
+            if (status) status[i] = st;
+            if (aux) aux[i] = ax;
+        }
+        cnt_fold_thread();
+    }
+}
+
+/* FM:564-608 looped */
+void orc_fm_extract_batch(const OrcFmIndex *f, const int32_t *start, const int32_t *stop, int32_t n, uint16_t *dst,
+                          int dst_len, int offset, int32_t *out_len, int32_t *status, int threads) {
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+#pragma omp for schedule(dynamic, 256)
+        for (int32_t i = 0; i < n; i++) {
+            int st = 0;
+            const int r = orc_fm_extract(f, start[i], stop[i], dst + (size_t)i * (size_t)dst_len, dst_len, offset, &st);
+            out_len[i] = st ? 0 : r;
+            if (status) status[i] = st;
+        }
+        cnt_fold_thread();
+    }
+}
+
 /* FM:239-298 */
 int orc_convert_byte_pattern(const uint8_t *pattern, int offset, int length, uint16_t *dest, int *bad_value) {
     int pos = offset, i = 0;

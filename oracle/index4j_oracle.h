@@ -108,6 +108,14 @@ int orc_fm_extract_until_boundary(const OrcFmIndex *f, int mode, int from, uint1
 void orc_fm_count_batch(const OrcFmIndex *f, const uint16_t *pat, const int32_t *pat_off, int32_t n,
                         int32_t *counts, int32_t *status, int threads);
 
+void orc_fm_locate_batch(const OrcFmIndex *f, const uint16_t *pat, const int32_t *pat_off, int32_t n, int max_matches,
+                         int32_t *locs, int loc_cap, int32_t *found, int32_t *status, int threads);
+void orc_fm_extract_batch(const OrcFmIndex *f, const int32_t *start, const int32_t *stop, int32_t n, uint16_t *dst,
+                          int dst_len, int offset, int32_t *out_len, int32_t *status, int threads);
+void orc_fm_extract_until_boundary_batch(const OrcFmIndex *f, int mode, const int32_t *from, int32_t n,
+                                         uint16_t boundary, uint16_t *dst, int dst_len, int offset, int32_t *out_len,
+                                         int32_t *status, int32_t *aux, int threads);
+
 /* serialization (FM:948-1025, IV:196-227, VIV:175-198, RRR:430-469, WFBB:1544-1570, 1597-1667, SER:67-79) */
 int orc_fm_write(const OrcFmIndex *f, int framed, uint8_t **buf, size_t *len);
 OrcFmIndex *orc_fm_read(const uint8_t *buf, size_t len, int *status);

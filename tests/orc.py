@@ -70,6 +70,12 @@ def lib():
     L.orc_fm_extract_until_boundary.argtypes = [vp, i32, i32, vp, i32, i32, C.c_uint16, p(i32), p(i32)]
     L.orc_fm_count_batch.argtypes = [vp, vp, vp, i32, vp, vp, i32]
     L.orc_fm_count_batch.restype = None
+    L.orc_fm_locate_batch.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp, vp, i32]
+    L.orc_fm_locate_batch.restype = None
+    L.orc_fm_extract_batch.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, vp, i32]
+    L.orc_fm_extract_batch.restype = None
+    L.orc_fm_extract_until_boundary_batch.argtypes = [vp, i32, vp, i32, C.c_uint16, vp, i32, i32, vp, vp, vp, i32]
+    L.orc_fm_extract_until_boundary_batch.restype = None
     L.orc_fm_write.argtypes = [vp, i32, p(vp), p(C.c_size_t)]
     L.orc_fm_read.restype = vp
     L.orc_fm_read.argtypes = [vp, C.c_size_t, p(i32)]
@@ -252,6 +258,46 @@ class OracleFmIndex:
         status = np.zeros(n, dtype=np.int32)
         lib().orc_fm_count_batch(self.h, pat.ctypes.data, pat_off.ctypes.data, n, counts.ctypes.data, status.ctypes.data, threads)
         return counts, status
+
+    def locate_batch(self, pat, pat_off, max_matches, loc_cap=None, threads=1, fill=0):
+        """FM:504-552 looped in C (OpenMP over patterns): (locs[n, loc_cap], found, status)"""
+        pat = np.ascontiguousarray(pat, dtype=np.uint16)
+        pat_off = np.ascontiguousarray(pat_off, dtype=np.int32)
+        n = len(pat_off) - 1
+        if loc_cap is None:
+            loc_cap = max_matches
+        locs = np.full((n, max(loc_cap, 0)), fill, dtype=np.int32)
+        found = np.zeros(n, dtype=np.int32)
+        status = np.zeros(n, dtype=np.int32)
+        lib().orc_fm_locate_batch(self.h, pat.ctypes.data, pat_off.ctypes.data, n, int(max_matches), locs.ctypes.data,
+                                  int(loc_cap), found.ctypes.data, status.ctypes.data, threads)
+        return locs, found, status
+
+    def extract_batch(self, starts, stops, dst_len, offset=0, threads=1, fill=0):
+        """FM:564-608 looped in C: (dst[n, dst_len], out_len, status)"""
+        starts = np.ascontiguousarray(starts, dtype=np.int32)
+        stops = np.ascontiguousarray(stops, dtype=np.int32)
+        n = len(starts)
+        dst = np.full((n, dst_len), fill, dtype=np.uint16)
+        out_len = np.zeros(n, dtype=np.int32)
+        status = np.zeros(n, dtype=np.int32)
+        lib().orc_fm_extract_batch(self.h, starts.ctypes.data, stops.ctypes.data, n, dst.ctypes.data, int(dst_len),
+                                   int(offset), out_len.ctypes.data, status.ctypes.data, threads)
+        return dst, out_len, status
+
+    def extract_until_boundary_batch(self, mode, froms, boundary, dst_len, offset=0, threads=1, fill=0):
+        """FM:640-922 looped in C: (dst[n, dst_len], out_len, status, aux)"""
+        froms = np.ascontiguousarray(froms, dtype=np.int32)
+        n = len(froms)
+        dst = np.full((n, dst_len), fill, dtype=np.uint16)
+        out_len = np.zeros(n, dtype=np.int32)
+        status = np.zeros(n, dtype=np.int32)
+        aux = np.zeros(n, dtype=np.int32)
+        b = boundary if isinstance(boundary, (int, np.integer)) else ord(boundary)
+        lib().orc_fm_extract_until_boundary_batch(self.h, int(mode), froms.ctypes.data, n, int(b), dst.ctypes.data,
+                                                  int(dst_len), int(offset), out_len.ctypes.data, status.ctypes.data,
+                                                  aux.ctypes.data, threads)
+        return dst, out_len, status, aux
 
     def __del__(self):
         if getattr(self, "h", None):
