@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <climits>
 #include <cstdio>
 #include <cstring>
@@ -55,22 +56,25 @@ struct fmx_index {
     bool wavelet_only = false;  // built by fmx_wavelet_build: only the wavelet entry points apply
     bool rrr_only = false;      // built by fmx_rrr_build: only the RrrVector entry points apply
     fmx::DevIndex dev;
-    // per-stream scratch for the in-library pattern sort (grow-only; freed with the index)
+    // per-(stream, kind) scratch of the device-pointer entry points (grow-only; freed with the index):
+    // kind 0 = plan stage (order + code words), kind 1 = extractUntilBoundary windows
     mutable std::mutex ws_mutex;
-    mutable std::map<void *, std::pair<void *, size_t>> ws;
+    mutable std::map<std::pair<void *, int>, std::pair<void *, size_t>> ws;
     struct Plan {  // the last fmx_count_plan_dev result per stream: order + per-pattern code words
         const uint32_t *perm = nullptr;
         const void *codes = nullptr;
         const uint16_t *pat = nullptr;
         int32_t n = 0;
     };
+    // erased whenever anything else plans on the stream or its plan scratch moves: a stale perm then simply
+    // carries no code words (k_count maps the characters itself) instead of reading another batch's
     mutable std::map<void *, Plan> plans;
 };
 
 namespace {
 
 thread_local std::string g_err;
-int g_sb_cache_limit = 320;  // option "sb_cache_limit": applies to indexes made resident afterwards (tests: 0 = no LDS cache)
+std::atomic<int> g_sb_cache_limit{320};  // option "sb_cache_limit": applies to indexes made resident afterwards (tests: 0 = no LDS cache)
 int fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
@@ -118,9 +122,15 @@ int validate_model(const fmx::FmModel &m, std::string &err) {
     if (m.bw_suffixes < 1 || m.bw_suffixes > 32) return bad("bitWidthSuffixes");
     if (m.enable_extract && (m.bw_positions < 1 || m.bw_positions > 32)) return bad("bitWidthPositions");
     if (m.look_up.empty() || m.C.size() < m.look_up.size()) return bad("cumulativeCounts / monotonicLookUp sizes");
-    for (size_t i = 0; i < m.map_vals.size(); ++i)
+    if (m.map_keys.size() != m.map_vals.size()) return bad("monotonicMap keys / values");
+    for (size_t i = 0; i < m.map_vals.size(); ++i) {
         if (m.map_vals[i] < 0 || (size_t)m.map_vals[i] + 1 >= m.C.size() || (size_t)m.map_vals[i] >= m.look_up.size())
             return bad("monotonicMap value outside cumulativeCounts");
+        // every code of the map occurs in the BWT, so it is below the wavelet tree's alphabet size (WFBB:133); the
+        // plan stage sizes its sort keys and histogram bins by that alphabet
+        if (m.map_vals[i] >= m.wt.alphabet_size) return bad("monotonicMap value outside the wavelet tree's alphabet");
+        if (m.map_keys[i] < 0 || m.map_keys[i] > 65535) return bad("monotonicMap key is not a char");
+    }
     if (m.suffixes.width != m.bw_suffixes || m.suffixes.length < m.length / m.sample_rate + 1) return bad("suffixes");
     if (m.enable_extract && (m.positions.width != m.bw_positions || m.positions.length < m.length / m.sample_rate + 2))
         return bad("positions");
@@ -180,17 +190,20 @@ int require_device(const fmx_index *idx, bool rrr_handle = false) {
     return FMX_OK;
 }
 
+constexpr int kWsPlan = 0, kWsBoundary = 1;
+
 // scratch of at least `bytes` for work enqueued on `stream`; reused across calls on the same stream
-int get_workspace(const fmx_index *idx, void *stream, size_t bytes, void **out) {
+int get_workspace(const fmx_index *idx, void *stream, int kind, size_t bytes, void **out) {
     *out = nullptr;
     if (bytes == 0) return FMX_OK;
     std::lock_guard<std::mutex> lock(idx->ws_mutex);
-    auto &slot = idx->ws[stream];
+    auto &slot = idx->ws[{stream, kind}];
     if (slot.second < bytes) {
         if (slot.first) {
             HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
             (void)hipFree(slot.first);
             slot = {nullptr, 0};
+            if (kind == kWsPlan) idx->plans.erase(stream);  // its perm / code words lived in the freed block
         }
         void *p = nullptr;
         HIP_TRY(hipMalloc(&p, bytes));
@@ -261,6 +274,28 @@ struct DevBuf {
     }
 };
 
+// Where a call's device scratch comes from.  Device-pointer entry points: the index's per-(stream, kind) buffers —
+// asynchronous, the caller orders work through the stream and uses one stream per thread.  Host-buffer entry
+// points: per-call blocks from the recycling cache, so that any number of host threads may query one index at
+// once, as with the reference's immutable @ThreadSafe FmIndex (FM:82); the blocks live until the call has
+// synchronised.
+struct Scratch {
+    const fmx_index *idx;
+    void *stream;
+    bool per_call;
+    std::vector<std::unique_ptr<DevBuf>> owned;
+    Scratch(const fmx_index *i, void *st, bool call) : idx(i), stream(st), per_call(call) {}
+    int get(int kind, size_t bytes, void **out) {
+        if (!per_call) return get_workspace(idx, stream, kind, bytes, out);
+        *out = nullptr;
+        if (bytes == 0) return FMX_OK;
+        owned.emplace_back(new DevBuf());
+        HIP_TRY(owned.back()->alloc(bytes));
+        *out = owned.back()->p;
+        return FMX_OK;
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -278,6 +313,10 @@ int fmx_set_option(const char *name, int value) {
     if (name && !strcmp(name, "map_by_symbol")) {  // layout of the mapping tables of images flattened from now on
         if (value < -1 || value > 1) return fail(FMX_E_ARG, "bad value");
         fmx::set_map_by_symbol(value);
+        return FMX_OK;
+    }
+    if (name && !strcmp(name, "map_fast")) {  // 0: images flattened from now on keep every mapping entry on the reference's route
+        fmx::set_map_fast(value != 0);
         return FMX_OK;
     }
     if (!name || fmx::set_option(name, value)) return fail(FMX_E_ARG, "unknown option or bad value");
@@ -412,6 +451,15 @@ int fmx_attach_device_blob(void *device_blob, size_t len, int device, fmx_index 
     HIP_TRY(hipMemcpy(&idx->hdr, device_blob, sizeof(fmx::BlobHeader), hipMemcpyDeviceToHost));
     if (idx->hdr.magic != fmx::kBlobMagic || idx->hdr.version != fmx::kBlobVersion || idx->hdr.total_bytes != len)
         return fail(FMX_E_FORMAT, "device blob header mismatch");
+    {
+        // the image arrived from somewhere else (an RCCL broadcast): validate it on a host copy before any kernel
+        // may walk it — sections, per-superblock tables, block headers, mapping entries, and the body checksum
+        std::vector<uint8_t> copy(len);
+        HIP_TRY(hipMemcpy(copy.data(), device_blob, len, hipMemcpyDeviceToHost));
+        std::string err;
+        if (fmx::validate_blob(copy.data(), len, err)) return fail(FMX_E_FORMAT, err);
+    }
+    idx->rrr_only = idx->hdr.kind == 1;
     idx->d_blob = device_blob;
     idx->d_len = len;
     idx->device = device;
@@ -431,20 +479,26 @@ void *fmx_device_blob(const fmx_index *idx, size_t *len) {
 }
 
 // ---- device-pointer entry points ---------------------------------------------------------------
+// Every entry point is a thin wrapper over an *_impl that takes its scratch from a Scratch provider: the
+// index's per-stream buffers here, per-call blocks for the host-buffer forms further down.
 
 // stage 1 of count/locate: processing order of the batch (suffix-key radix sort) — nullptr when the
 // batch is too small to be worth sorting
-static int plan_order(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n, void *stream,
+static int plan_order(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n, Scratch &scratch,
                       const uint32_t **perm, const void **codes) {
     *perm = nullptr;
     *codes = nullptr;
+    if (!scratch.per_call) {  // whatever fmx_count_plan_dev left for this stream is about to be overwritten
+        std::lock_guard<std::mutex> lock(idx->ws_mutex);
+        idx->plans.erase(scratch.stream);
+    }
     void *ws = nullptr;
     const size_t ws_bytes = fmx::count_workspace_bytes(idx->dev, n);
-    int rc = get_workspace(idx, stream, ws_bytes, &ws);
+    int rc = scratch.get(kWsPlan, ws_bytes, &ws);
     if (rc) return rc;
     if (!ws) return FMX_OK;
     int e = fmx::launch_count_plan(idx->dev, d_pat, d_pat_off, n, ws, ws_bytes, perm, codes,
-                                   static_cast<hipStream_t>(stream));
+                                   static_cast<hipStream_t>(scratch.stream));
     if (e) return fail(FMX_E_HIP, std::string("pattern sort: ") + hipGetErrorString((hipError_t)e));
     return FMX_OK;
 }
@@ -455,7 +509,8 @@ int fmx_count_plan_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_
     if (rc) return rc;
     if (n < 0 || !d_perm || (n > 0 && !d_pat_off)) return fail(FMX_E_ARG, "bad arguments");
     fmx_index::Plan plan;
-    rc = plan_order(idx, d_pat, d_pat_off, n, stream, &plan.perm, &plan.codes);
+    Scratch scratch(idx, stream, false);
+    rc = plan_order(idx, d_pat, d_pat_off, n, scratch, &plan.perm, &plan.codes);
     if (rc) return rc;
     plan.pat = d_pat;
     plan.n = n;
@@ -485,26 +540,39 @@ int fmx_count_ordered_dev(const fmx_index *idx, const uint16_t *d_pat, const int
     return FMX_OK;
 }
 
-int fmx_count_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
-                        int32_t *d_counts, int32_t *d_lf_steps, int32_t *d_status, void *stream) {
-    const uint32_t *perm = nullptr;
-    int rc = fmx_count_plan_dev(idx, d_pat, d_pat_off, n, &perm, stream);
+static int count_impl(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n, int32_t *d_counts,
+                      int32_t *d_lf_steps, int32_t *d_status, Scratch &scratch) {
+    int rc = require_device(idx);
     if (rc) return rc;
-    return fmx_count_ordered_dev(idx, d_pat, d_pat_off, perm, n, d_counts, d_lf_steps, d_status, stream);
+    if (n < 0 || (n > 0 && (!d_pat_off || !d_counts))) return fail(FMX_E_ARG, "bad arguments");
+    const uint32_t *perm = nullptr;
+    const void *codes = nullptr;
+    rc = plan_order(idx, d_pat, d_pat_off, n, scratch, &perm, &codes);
+    if (rc) return rc;
+    int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, perm, codes, n, d_counts, d_lf_steps, d_status,
+                              nullptr, static_cast<hipStream_t>(scratch.stream));
+    if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
+    return FMX_OK;
 }
 
-int fmx_locate_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
-                         int32_t max_matches, int32_t *d_locs, int32_t loc_cap, int32_t *d_found,
-                         int32_t *d_lf_steps, int32_t *d_status, int32_t *d_range_ws, void *stream) {
+int fmx_count_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
+                        int32_t *d_counts, int32_t *d_lf_steps, int32_t *d_status, void *stream) {
+    Scratch scratch(idx, stream, false);
+    return count_impl(idx, d_pat, d_pat_off, n, d_counts, d_lf_steps, d_status, scratch);
+}
+
+static int locate_impl(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
+                       int32_t max_matches, int32_t *d_locs, int32_t loc_cap, int32_t *d_found, int32_t *d_lf_steps,
+                       int32_t *d_status, int32_t *d_range_ws, Scratch &scratch) {
     int rc = require_device(idx);
     if (rc) return rc;
     if (n < 0 || loc_cap < 0 || (n > 0 && (!d_pat_off || !d_found || !d_range_ws || (!d_locs && loc_cap > 0))))
         return fail(FMX_E_ARG, "bad arguments");
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipStream_t st = static_cast<hipStream_t>(scratch.stream);
     // found[] doubles as the scratch `counts` output of the range pass; the walk pass overwrites it
     const uint32_t *perm = nullptr;
     const void *codes = nullptr;
-    rc = plan_order(idx, d_pat, d_pat_off, n, stream, &perm, &codes);
+    rc = plan_order(idx, d_pat, d_pat_off, n, scratch, &perm, &codes);
     if (rc) return rc;
     int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, perm, codes, n, d_found, d_lf_steps, d_status,
                               d_range_ws, st);
@@ -513,6 +581,14 @@ int fmx_locate_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int3
                                 d_status, nullptr, st);
     if (e) return fail(FMX_E_HIP, std::string("k_locate_walk launch: ") + hipGetErrorString((hipError_t)e));
     return FMX_OK;
+}
+
+int fmx_locate_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
+                         int32_t max_matches, int32_t *d_locs, int32_t loc_cap, int32_t *d_found,
+                         int32_t *d_lf_steps, int32_t *d_status, int32_t *d_range_ws, void *stream) {
+    Scratch scratch(idx, stream, false);
+    return locate_impl(idx, d_pat, d_pat_off, n, max_matches, d_locs, loc_cap, d_found, d_lf_steps, d_status, d_range_ws,
+                       scratch);
 }
 
 int fmx_extract_batch_dev(const fmx_index *idx, const int32_t *d_start, const int32_t *d_stop, int32_t n,
@@ -528,6 +604,20 @@ int fmx_extract_batch_dev(const fmx_index *idx, const int32_t *d_start, const in
     return FMX_OK;
 }
 
+static int boundary_impl(const fmx_index *idx, const int32_t *d_from, int64_t n, uint16_t boundary, int mode,
+                         uint16_t *d_dst, int32_t dst_len, int32_t offset, int32_t *d_out_len, int32_t *d_lf_steps,
+                         int32_t *d_status, int32_t *d_aux, const int32_t *slot_found, int32_t slots, Scratch &scratch) {
+    void *ws = nullptr;
+    const size_t ws_bytes = fmx::boundary_workspace_bytes(idx->dev, n, idx->n_cu);
+    int rc = scratch.get(kWsBoundary, ws_bytes, &ws);
+    if (rc) return rc;
+    int e = fmx::launch_extract_boundary(idx->dev, idx->n_cu, d_from, n, boundary, mode, d_dst, dst_len, offset,
+                                         d_out_len, d_lf_steps, d_status, d_aux, ws, ws_bytes, slot_found, slots,
+                                         static_cast<hipStream_t>(scratch.stream));
+    if (e) return fail(FMX_E_HIP, std::string("k_extract_boundary launch: ") + hipGetErrorString((hipError_t)e));
+    return FMX_OK;
+}
+
 int fmx_extract_boundary_batch_dev(const fmx_index *idx, const int32_t *d_from, int32_t n, uint16_t boundary, int mode,
                                    uint16_t *d_dst, int32_t dst_len, int32_t offset, int32_t *d_out_len,
                                    int32_t *d_lf_steps, int32_t *d_status, int32_t *d_aux, void *stream) {
@@ -535,15 +625,9 @@ int fmx_extract_boundary_batch_dev(const fmx_index *idx, const int32_t *d_from, 
     if (rc) return rc;
     if (n < 0 || dst_len < 0 || mode < 0 || mode > 2 || (n > 0 && (!d_from || !d_out_len || (!d_dst && dst_len > 0))))
         return fail(FMX_E_ARG, "bad arguments");
-    void *ws = nullptr;
-    const size_t ws_bytes = fmx::boundary_workspace_bytes(idx->dev, n, idx->n_cu);
-    rc = get_workspace(idx, stream, ws_bytes, &ws);
-    if (rc) return rc;
-    int e = fmx::launch_extract_boundary(idx->dev, idx->n_cu, d_from, n, boundary, mode, d_dst, dst_len, offset,
-                                         d_out_len, d_lf_steps, d_status, d_aux, ws, ws_bytes, nullptr, 0,
-                                         static_cast<hipStream_t>(stream));
-    if (e) return fail(FMX_E_HIP, std::string("k_extract_boundary launch: ") + hipGetErrorString((hipError_t)e));
-    return FMX_OK;
+    Scratch scratch(idx, stream, false);
+    return boundary_impl(idx, d_from, n, boundary, mode, d_dst, dst_len, offset, d_out_len, d_lf_steps, d_status, d_aux,
+                         nullptr, 0, scratch);
 }
 
 // ---- locate -> extract pipelines: the hit positions stay in HBM between the two stages ----
@@ -554,23 +638,49 @@ static int pipeline_args_ok(int32_t n, int32_t max_matches, int32_t row_len, con
            (n == 0 || (a && b && c && d && e));
 }
 
-int fmx_locate_extract_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
-                                 int32_t max_matches, int32_t extract_len, int32_t *d_locs, int32_t *d_found,
-                                 uint16_t *d_dst, int32_t *d_out_len, int32_t *d_lf_steps, int32_t *d_status,
-                                 int32_t *d_hit_status, int32_t *d_range_ws, void *stream) {
+static int locate_extract_impl(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
+                               int32_t max_matches, int32_t extract_len, int32_t *d_locs, int32_t *d_found,
+                               uint16_t *d_dst, int32_t *d_out_len, int32_t *d_lf_steps, int32_t *d_status,
+                               int32_t *d_hit_status, int32_t *d_range_ws, Scratch &scratch) {
     int rc = require_device(idx);
     if (rc) return rc;
     if (!pipeline_args_ok(n, max_matches, extract_len, d_pat_off, d_locs, d_found, d_out_len, d_range_ws) ||
         (n > 0 && extract_len > 0 && !d_dst))
         return fail(FMX_E_ARG, "bad arguments");
-    rc = fmx_locate_batch_dev(idx, d_pat, d_pat_off, n, max_matches, d_locs, max_matches, d_found, d_lf_steps, d_status,
-                              d_range_ws, stream);
+    rc = locate_impl(idx, d_pat, d_pat_off, n, max_matches, d_locs, max_matches, d_found, d_lf_steps, d_status, d_range_ws,
+                     scratch);
     if (rc) return rc;
     int e = fmx::launch_extract(idx->dev, idx->n_cu, d_locs, nullptr, (int64_t)n * max_matches, d_dst, extract_len, 0,
                                 d_out_len, nullptr, d_hit_status, d_found, max_matches, extract_len,
-                                static_cast<hipStream_t>(stream));
+                                static_cast<hipStream_t>(scratch.stream));
     if (e) return fail(FMX_E_HIP, std::string("k_extract launch: ") + hipGetErrorString((hipError_t)e));
     return FMX_OK;
+}
+
+int fmx_locate_extract_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
+                                 int32_t max_matches, int32_t extract_len, int32_t *d_locs, int32_t *d_found,
+                                 uint16_t *d_dst, int32_t *d_out_len, int32_t *d_lf_steps, int32_t *d_status,
+                                 int32_t *d_hit_status, int32_t *d_range_ws, void *stream) {
+    Scratch scratch(idx, stream, false);
+    return locate_extract_impl(idx, d_pat, d_pat_off, n, max_matches, extract_len, d_locs, d_found, d_dst, d_out_len,
+                               d_lf_steps, d_status, d_hit_status, d_range_ws, scratch);
+}
+
+static int locate_lines_impl(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
+                             int32_t max_matches, uint16_t boundary, int mode, int32_t dst_len, int32_t *d_locs,
+                             int32_t *d_found, uint16_t *d_dst, int32_t *d_out_len, int32_t *d_lf_steps,
+                             int32_t *d_status, int32_t *d_hit_status, int32_t *d_hit_aux, int32_t *d_range_ws,
+                             Scratch &scratch) {
+    int rc = require_device(idx);
+    if (rc) return rc;
+    if (!pipeline_args_ok(n, max_matches, dst_len, d_pat_off, d_locs, d_found, d_out_len, d_range_ws) || mode < 0 ||
+        mode > 2 || (n > 0 && dst_len > 0 && !d_dst))
+        return fail(FMX_E_ARG, "bad arguments");
+    rc = locate_impl(idx, d_pat, d_pat_off, n, max_matches, d_locs, max_matches, d_found, d_lf_steps, d_status, d_range_ws,
+                     scratch);
+    if (rc) return rc;
+    return boundary_impl(idx, d_locs, (int64_t)n * max_matches, boundary, mode, d_dst, dst_len, 0, d_out_len, nullptr,
+                         d_hit_status, d_hit_aux, d_found, max_matches, scratch);
 }
 
 int fmx_locate_lines_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
@@ -578,24 +688,9 @@ int fmx_locate_lines_batch_dev(const fmx_index *idx, const uint16_t *d_pat, cons
                                int32_t *d_found, uint16_t *d_dst, int32_t *d_out_len, int32_t *d_lf_steps,
                                int32_t *d_status, int32_t *d_hit_status, int32_t *d_hit_aux, int32_t *d_range_ws,
                                void *stream) {
-    int rc = require_device(idx);
-    if (rc) return rc;
-    if (!pipeline_args_ok(n, max_matches, dst_len, d_pat_off, d_locs, d_found, d_out_len, d_range_ws) || mode < 0 ||
-        mode > 2 || (n > 0 && dst_len > 0 && !d_dst))
-        return fail(FMX_E_ARG, "bad arguments");
-    rc = fmx_locate_batch_dev(idx, d_pat, d_pat_off, n, max_matches, d_locs, max_matches, d_found, d_lf_steps, d_status,
-                              d_range_ws, stream);
-    if (rc) return rc;
-    const int64_t slots = (int64_t)n * max_matches;
-    void *ws = nullptr;
-    const size_t ws_bytes = fmx::boundary_workspace_bytes(idx->dev, slots, idx->n_cu);
-    rc = get_workspace(idx, stream, ws_bytes, &ws);
-    if (rc) return rc;
-    int e = fmx::launch_extract_boundary(idx->dev, idx->n_cu, d_locs, slots, boundary, mode, d_dst, dst_len, 0, d_out_len,
-                                         nullptr, d_hit_status, d_hit_aux, ws, ws_bytes, d_found, max_matches,
-                                         static_cast<hipStream_t>(stream));
-    if (e) return fail(FMX_E_HIP, std::string("k_extract_boundary launch: ") + hipGetErrorString((hipError_t)e));
-    return FMX_OK;
+    Scratch scratch(idx, stream, false);
+    return locate_lines_impl(idx, d_pat, d_pat_off, n, max_matches, boundary, mode, dst_len, d_locs, d_found, d_dst,
+                             d_out_len, d_lf_steps, d_status, d_hit_status, d_hit_aux, d_range_ws, scratch);
 }
 
 // ---- segment sets ---------------------------------------------------------------------------------
@@ -610,20 +705,18 @@ static int segments_ok(const fmx_index *const *segs, int32_t n_segs) {
     return FMX_OK;
 }
 
-int fmx_count_segments_dev(const fmx_index *const *segs, int32_t n_segs, const uint16_t *d_pat, const int32_t *d_pat_off,
-                           int32_t n, int64_t *d_counts, int64_t *d_lf_steps, int32_t *d_status, int32_t *d_tmp,
-                           void *stream) {
-    int rc = segments_ok(segs, n_segs);
-    if (rc) return rc;
+static int count_segments_impl(const fmx_index *const *segs, int32_t n_segs, const uint16_t *d_pat, const int32_t *d_pat_off,
+                               int32_t n, int64_t *d_counts, int64_t *d_lf_steps, int32_t *d_status, int32_t *d_tmp,
+                               Scratch &scratch) {
     if (n < 0 || (n > 0 && (!d_pat_off || !d_counts || !d_tmp))) return fail(FMX_E_ARG, "bad arguments");
     if (n == 0) return FMX_OK;
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipStream_t st = static_cast<hipStream_t>(scratch.stream);
     // one processing order for all segments: any grouping is valid, and equal characters get equal codes in
     // every segment's alphabet, so the order derived from the first segment groups the batch for all of them
     // (the plan's code words are in the first segment's alphabet, so only that segment uses them)
     const uint32_t *perm = nullptr;
     const void *codes = nullptr;
-    rc = plan_order(segs[0], d_pat, d_pat_off, n, stream, &perm, &codes);
+    int rc = plan_order(segs[0], d_pat, d_pat_off, n, scratch, &perm, &codes);
     if (rc) return rc;
     int32_t *cnt = d_tmp, *lf = d_tmp + n, *sts = d_tmp + 2 * (size_t)n;
     for (int32_t s = 0; s < n_segs; ++s) {
@@ -636,20 +729,27 @@ int fmx_count_segments_dev(const fmx_index *const *segs, int32_t n_segs, const u
     return FMX_OK;
 }
 
-int fmx_locate_segments_dev(const fmx_index *const *segs, int32_t n_segs, const int64_t *seg_base, const uint16_t *d_pat,
-                            const int32_t *d_pat_off, int32_t n, int32_t max_matches, int64_t *d_locs, int32_t *d_found,
-                            int32_t *d_status, int32_t *d_tmp, void *stream) {
+int fmx_count_segments_dev(const fmx_index *const *segs, int32_t n_segs, const uint16_t *d_pat, const int32_t *d_pat_off,
+                           int32_t n, int64_t *d_counts, int64_t *d_lf_steps, int32_t *d_status, int32_t *d_tmp,
+                           void *stream) {
     int rc = segments_ok(segs, n_segs);
     if (rc) return rc;
+    Scratch scratch(segs[0], stream, false);
+    return count_segments_impl(segs, n_segs, d_pat, d_pat_off, n, d_counts, d_lf_steps, d_status, d_tmp, scratch);
+}
+
+static int locate_segments_impl(const fmx_index *const *segs, int32_t n_segs, const int64_t *seg_base, const uint16_t *d_pat,
+                                const int32_t *d_pat_off, int32_t n, int32_t max_matches, int64_t *d_locs, int32_t *d_found,
+                                int32_t *d_status, int32_t *d_tmp, Scratch &scratch) {
     if (n < 0 || max_matches < 1 || !seg_base || (int64_t)n * max_matches > INT32_MAX ||
         (n > 0 && (!d_pat_off || !d_locs || !d_found || !d_tmp)))
         return fail(FMX_E_ARG, "bad arguments");
     if (n == 0) return FMX_OK;
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipStream_t st = static_cast<hipStream_t>(scratch.stream);
     int32_t *seg_found = d_tmp, *seg_status = d_tmp + n, *range = d_tmp + 2 * (size_t)n, *seg_locs = d_tmp + 4 * (size_t)n;
     const uint32_t *perm = nullptr;
     const void *codes = nullptr;
-    rc = plan_order(segs[0], d_pat, d_pat_off, n, stream, &perm, &codes);
+    int rc = plan_order(segs[0], d_pat, d_pat_off, n, scratch, &perm, &codes);
     if (rc) return rc;
     for (int32_t s = 0; s < n_segs; ++s) {
         int e = fmx::launch_count(segs[s]->dev, segs[s]->n_cu, d_pat, d_pat_off, perm, s == 0 ? codes : nullptr, n,
@@ -667,6 +767,16 @@ int fmx_locate_segments_dev(const fmx_index *const *segs, int32_t n_segs, const 
     return FMX_OK;
 }
 
+int fmx_locate_segments_dev(const fmx_index *const *segs, int32_t n_segs, const int64_t *seg_base, const uint16_t *d_pat,
+                            const int32_t *d_pat_off, int32_t n, int32_t max_matches, int64_t *d_locs, int32_t *d_found,
+                            int32_t *d_status, int32_t *d_tmp, void *stream) {
+    int rc = segments_ok(segs, n_segs);
+    if (rc) return rc;
+    Scratch scratch(segs[0], stream, false);
+    return locate_segments_impl(segs, n_segs, seg_base, d_pat, d_pat_off, n, max_matches, d_locs, d_found, d_status, d_tmp,
+                                scratch);
+}
+
 int fmx_count_segments(const fmx_index *const *segs, int32_t n_segs, const uint16_t *pat, const int32_t *pat_off,
                        int32_t n, int64_t *counts, int64_t *lf_steps, int32_t *status) {
     int rc = segments_ok(segs, n_segs);
@@ -676,6 +786,7 @@ int fmx_count_segments(const fmx_index *const *segs, int32_t n_segs, const uint1
     HIP_TRY(hipSetDevice(segs[0]->device));
     const size_t chars = (size_t)(pat_off[n] > 0 ? pat_off[n] : 0);
     DevBuf d_pat, d_off, d_cnt, d_lf, d_st, d_tmp;
+    Scratch scratch(segs[0], nullptr, true);
     HIP_TRY(d_pat.alloc(chars * 2 + 8));
     HIP_TRY(d_off.alloc((size_t)(n + 1) * 4));
     HIP_TRY(d_cnt.alloc((size_t)n * 8));
@@ -684,10 +795,10 @@ int fmx_count_segments(const fmx_index *const *segs, int32_t n_segs, const uint1
     HIP_TRY(d_tmp.alloc((size_t)n * 12));
     if (chars) H2D(d_pat.p, pat, chars * 2);
     H2D(d_off.p, pat_off, (size_t)(n + 1) * 4);
-    rc = fmx_count_segments_dev(segs, n_segs, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, d_cnt.as<int64_t>(),
-                                d_lf.as<int64_t>(), d_st.as<int32_t>(), d_tmp.as<int32_t>(), nullptr);
+    rc = count_segments_impl(segs, n_segs, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, d_cnt.as<int64_t>(),
+                             d_lf.as<int64_t>(), d_st.as<int32_t>(), d_tmp.as<int32_t>(), scratch);
+    HIP_TRY(hipDeviceSynchronize());  // also on failure: the per-call blocks go back to the cache below
     if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
     D2H(counts, d_cnt.p, (size_t)n * 8);
     if (lf_steps) D2H(lf_steps, d_lf.p, (size_t)n * 8);
     if (status) D2H(status, d_st.p, (size_t)n * 4);
@@ -707,6 +818,7 @@ int fmx_locate_segments(const fmx_index *const *segs, int32_t n_segs, const int6
     const size_t chars = (size_t)(pat_off[n] > 0 ? pat_off[n] : 0);
     const size_t slots = (size_t)n * (size_t)max_matches;
     DevBuf d_pat, d_off, d_locs, d_found, d_st, d_tmp;
+    Scratch scratch(segs[0], nullptr, true);
     HIP_TRY(d_pat.alloc(chars * 2 + 8));
     HIP_TRY(d_off.alloc((size_t)(n + 1) * 4));
     HIP_TRY(d_locs.alloc(slots * 8));
@@ -716,11 +828,11 @@ int fmx_locate_segments(const fmx_index *const *segs, int32_t n_segs, const int6
     if (chars) H2D(d_pat.p, pat, chars * 2);
     H2D(d_off.p, pat_off, (size_t)(n + 1) * 4);
     H2D(d_locs.p, locs, slots * 8);  // in/out: slots without a hit keep the caller's values
-    rc = fmx_locate_segments_dev(segs, n_segs, seg_base, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, max_matches,
-                                 d_locs.as<int64_t>(), d_found.as<int32_t>(), d_st.as<int32_t>(), d_tmp.as<int32_t>(),
-                                 nullptr);
-    if (rc) return rc;
+    rc = locate_segments_impl(segs, n_segs, seg_base, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, max_matches,
+                              d_locs.as<int64_t>(), d_found.as<int32_t>(), d_st.as<int32_t>(), d_tmp.as<int32_t>(),
+                              scratch);
     HIP_TRY(hipDeviceSynchronize());
+    if (rc) return rc;
     D2H(locs, d_locs.p, slots * 8);
     D2H(found, d_found.p, (size_t)n * 4);
     if (status) D2H(status, d_st.p, (size_t)n * 4);
@@ -746,10 +858,11 @@ int fmx_count_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pa
     HIP_TRY(d_st.alloc((size_t)n * 4));
     if (chars) H2D(d_pat.p, pat, chars * 2);
     H2D(d_off.p, pat_off, (size_t)(n + 1) * 4);
-    rc = fmx_count_batch_dev(idx, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, d_cnt.as<int32_t>(), d_lf.as<int32_t>(),
-                             d_st.as<int32_t>(), nullptr);
+    Scratch scratch(idx, nullptr, true);
+    rc = count_impl(idx, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, d_cnt.as<int32_t>(), d_lf.as<int32_t>(),
+                    d_st.as<int32_t>(), scratch);
+    HIP_TRY(hipDeviceSynchronize());  // also on failure: the per-call blocks return to the cache when this call ends
     if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
     D2H(counts, d_cnt.p, (size_t)n * 4);
     if (lf_steps) D2H(lf_steps, d_lf.p, (size_t)n * 4);
     if (status) D2H(status, d_st.p, (size_t)n * 4);
@@ -777,11 +890,11 @@ int fmx_locate_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *p
     if (chars) H2D(d_pat.p, pat, chars * 2);
     H2D(d_off.p, pat_off, (size_t)(n + 1) * 4);
     if (loc_bytes) H2D(d_locs.p, locs, loc_bytes);  // `locations` is in/out: untouched slots keep the caller's values
-    rc = fmx_locate_batch_dev(idx, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, max_matches, d_locs.as<int32_t>(),
-                              loc_cap, d_found.as<int32_t>(), d_lf.as<int32_t>(), d_st.as<int32_t>(),
-                              d_ws.as<int32_t>(), nullptr);
-    if (rc) return rc;
+    Scratch scratch(idx, nullptr, true);
+    rc = locate_impl(idx, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, max_matches, d_locs.as<int32_t>(), loc_cap,
+                     d_found.as<int32_t>(), d_lf.as<int32_t>(), d_st.as<int32_t>(), d_ws.as<int32_t>(), scratch);
     HIP_TRY(hipDeviceSynchronize());
+    if (rc) return rc;
     if (loc_bytes) D2H(locs, d_locs.p, loc_bytes);
     D2H(found, d_found.p, (size_t)n * 4);
     if (lf_steps) D2H(lf_steps, d_lf.p, (size_t)n * 4);
@@ -825,18 +938,18 @@ static int locate_pipeline_host(const fmx_index *idx, const uint16_t *pat, const
     H2D(d_len.p, out_len, slots * 4);
     if (hit_status) H2D(d_hst.p, hit_status, slots * 4);
     if (hit_aux) H2D(d_aux.p, hit_aux, slots * 4);
+    Scratch scratch(idx, nullptr, true);
     if (mode < 0)
-        rc = fmx_locate_extract_batch_dev(idx, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, max_matches, row_len,
-                                          d_locs.as<int32_t>(), d_found.as<int32_t>(), d_dst.as<uint16_t>(),
-                                          d_len.as<int32_t>(), d_lf.as<int32_t>(), d_st.as<int32_t>(),
-                                          d_hst.as<int32_t>(), d_ws.as<int32_t>(), nullptr);
+        rc = locate_extract_impl(idx, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, max_matches, row_len,
+                                 d_locs.as<int32_t>(), d_found.as<int32_t>(), d_dst.as<uint16_t>(), d_len.as<int32_t>(),
+                                 d_lf.as<int32_t>(), d_st.as<int32_t>(), d_hst.as<int32_t>(), d_ws.as<int32_t>(), scratch);
     else
-        rc = fmx_locate_lines_batch_dev(idx, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, max_matches, boundary, mode,
-                                        row_len, d_locs.as<int32_t>(), d_found.as<int32_t>(), d_dst.as<uint16_t>(),
-                                        d_len.as<int32_t>(), d_lf.as<int32_t>(), d_st.as<int32_t>(), d_hst.as<int32_t>(),
-                                        d_aux.as<int32_t>(), d_ws.as<int32_t>(), nullptr);
-    if (rc) return rc;
+        rc = locate_lines_impl(idx, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, max_matches, boundary, mode, row_len,
+                               d_locs.as<int32_t>(), d_found.as<int32_t>(), d_dst.as<uint16_t>(), d_len.as<int32_t>(),
+                               d_lf.as<int32_t>(), d_st.as<int32_t>(), d_hst.as<int32_t>(), d_aux.as<int32_t>(),
+                               d_ws.as<int32_t>(), scratch);
     HIP_TRY(hipDeviceSynchronize());
+    if (rc) return rc;
     D2H(locs, d_locs.p, slots * 4);
     D2H(found, d_found.p, (size_t)n * 4);
     if (dst_bytes) D2H(dst, d_dst.p, dst_bytes);
@@ -913,11 +1026,11 @@ int fmx_extract_boundary_batch(const fmx_index *idx, const int32_t *from, int32_
     HIP_TRY(d_aux.alloc((size_t)n * 4));
     H2D(d_a.p, from, (size_t)n * 4);
     if (dst_bytes) H2D(d_dst.p, dst, dst_bytes);
-    rc = fmx_extract_boundary_batch_dev(idx, d_a.as<int32_t>(), n, boundary, mode, d_dst.as<uint16_t>(), dst_len, offset,
-                                        d_len.as<int32_t>(), d_lf.as<int32_t>(), d_st.as<int32_t>(),
-                                        d_aux.as<int32_t>(), nullptr);
-    if (rc) return rc;
+    Scratch scratch(idx, nullptr, true);
+    rc = boundary_impl(idx, d_a.as<int32_t>(), n, boundary, mode, d_dst.as<uint16_t>(), dst_len, offset, d_len.as<int32_t>(),
+                       d_lf.as<int32_t>(), d_st.as<int32_t>(), d_aux.as<int32_t>(), nullptr, 0, scratch);
     HIP_TRY(hipDeviceSynchronize());
+    if (rc) return rc;
     if (dst_bytes) D2H(dst, d_dst.p, dst_bytes);
     D2H(out_len, d_len.p, (size_t)n * 4);
     if (lf_steps) D2H(lf_steps, d_lf.p, (size_t)n * 4);

@@ -1,5 +1,6 @@
 // fmx_blob.cpp — flatten the host model into the HBM image described in fmx_blob.hpp.
 #include "fmx_blob.hpp"
+#include "fmx_device.hpp"  // the tree-walk arithmetic of rank(), evaluated once per leaf at flatten time
 #include "fmx_model.hpp"
 
 #include <atomic>
@@ -170,13 +171,20 @@ int flatten_rrr_only(const RrrModel &r, std::vector<uint8_t> &blob, std::string 
     if (!flatten_rrr(A, r, h.sampled, err)) return -8;
     A.alloc(64);
     h.total_bytes = blob.size();
+    h.kind = 1;
+    h.checksum = 0;
     memcpy(A.at<uint8_t>(hdr_off), &h, sizeof h);
+    A.at<BlobHeader>(hdr_off)->checksum = image_checksum(blob.data(), blob.size());
     return 0;
 }
 
 // -1 = by alphabet size; 0 / 1 force the row layout of the mapping tables (tests exercise both)
-static int g_map_by_symbol = -1;
+static std::atomic<int> g_map_by_symbol{-1};
 void set_map_by_symbol(int mode) { g_map_by_symbol = mode; }
+// 0: every present mapping entry says "take the reference's own route" (tests: the slow path alone must give
+// the same answers)
+static std::atomic<int> g_map_fast{1};
+void set_map_fast(int on) { g_map_fast = on; }
 
 int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err) {
     const WfbbModel &w = m.wt;
@@ -250,8 +258,9 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
         }
 
     // mapping rows by global symbol (rows of symbols a superblock does not hold are pure skip pointers)
-    bool by_symbol = g_map_by_symbol > 0;
-    if (g_map_by_symbol < 0) {  // automatic: rows by symbol unless that more than doubles the tables
+    const int map_mode = g_map_by_symbol;
+    bool by_symbol = map_mode > 0;
+    if (map_mode < 0) {  // automatic: rows by symbol unless that more than doubles the tables
         int64_t rows_by_code = 0, rows_by_symbol = 0;
         for (int64_t s = 0; s < n_sb; ++s) {
             const int bsl = w.sb[(size_t)s].block_size_log;
@@ -264,6 +273,10 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
     h.map_by_symbol = by_symbol ? 1 : 0;
     const size_t sbd_off = A.alloc((size_t)n_sb * sizeof(SbDesc));
     h.off_sbdesc = off8(sbd_off);
+    const bool fast = g_map_fast != 0;
+    std::vector<MapEntry> map_scratch;
+    std::vector<PathRec> path_scratch;
+    std::vector<uint8_t> var_scratch;
     for (int64_t s = 0; s < n_sb; ++s) {
         const SuperBlockModel &sb = w.sb[(size_t)s];
         SbDesc d;
@@ -277,13 +290,14 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
         }
         const int64_t per_row = (int64_t)1 << (20 - d.bsl);
         const int64_t n_rows = by_symbol ? sigma : (int64_t)sb.sigma + 1;
-        off = A.alloc((size_t)(n_rows * per_row) * sizeof(MapEntry) + 16);
-        d.off_mapping = off8(off);
         d.mapping_len = (int32_t)(n_rows * per_row);
         {
-            // absent entries (alphabetSize - 1, WFBB:383-387) become skip pointers: -(distance to the next
-            // block to the right holding the symbol, or to the end of the superblock)
-            MapEntry *dst = A.at<MapEntry>(off);
+            std::vector<MapEntry> &ents = map_scratch;
+            std::vector<PathRec> &path = path_scratch;
+            ents.assign((size_t)(n_rows * per_row), MapEntry{0, 0, 0, 0});
+            path.clear();
+            // absent entries (alphabetSize - 1, WFBB:383-387) become skip pointers: the distance to the next
+            // block to the right holding the symbol, or to the end of the superblock
             const int16_t absent = (int16_t)(sigma - 1);
             for (int64_t row = 0; row < n_rows; ++row) {
                 // the reference's row of this device row: by superblock code (WFBB:461-465)
@@ -292,66 +306,113 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
                 int64_t next_present = per_row;
                 for (int64_t blk = per_row - 1; blk >= 0; --blk) {
                     const int16_t v = in_superblock ? sb.mapping[(size_t)(src_row * per_row + blk)] : absent;
-                    int16_t raw;
+                    MapEntry &e = ents[(size_t)(row * per_row + blk)];
                     if (v != absent) {
                         if (v < 0) {
                             err = "negative mapping entry";
                             return -3;
                         }
                         next_present = blk;
-                        raw = v;
+                        // until the block's header has been read (below) a present entry takes the reference's route
+                        e.x = kMapSlow | ((uint32_t)(uint16_t)v << 8);
                     } else {
-                        raw = (int16_t)(-(next_present - blk));
+                        e.x = kMapAbsent | ((uint32_t)(next_present - blk) << 8);
                     }
-                    // until the block's header has been read (below) a present entry takes the reference's route
-                    dst[row * per_row + blk] = MapEntry{(uint32_t)(uint16_t)raw | (kMapSlow << 16), 0, 0, 0};
                 }
             }
-            // what rank() needs about every (symbol, block) that occurs, from the block's own header
-            const uint8_t *var = sb.var.data();
+            // what rank() needs about every (symbol, block) that occurs, from the block's own header: the leaf's rank
+            // at the block start, its canonical code, and the nodes its walk visits (PathRec)
+            std::vector<uint8_t> &var = var_scratch;  // + guard bytes: fields are fetched as whole dwords
+            var.assign(sb.var.begin(), sb.var.end());
+            var.resize(sb.var.size() + 16, 0);
             const int64_t var_len = (int64_t)sb.var.size();
-            for (int64_t blk = 0; blk < (int64_t)sb.block_headers.size() && blk < per_row; ++blk) {
+            const int64_t sb_start = s << 20;
+            for (int64_t blk = 0; fast && blk < (int64_t)sb.block_headers.size() && blk < per_row; ++blk) {
                 const BlockHeader &bh = sb.block_headers[(size_t)blk];
                 const int h = bh.tree_height, n_leaves = (int)bh.sigma + 1;
-                if (h < 0 || n_leaves <= 0 || bh.var_off < 0) continue;
+                if (h < 0 || h > 30 || n_leaves <= 0 || bh.var_off < 0) continue;
                 const int64_t hdr = bh.var_off, leaves = hdr + (h > 0 ? (int64_t)(h - 1) * 4 : 0);
                 const int64_t second0 = (int64_t)(h - 1) * 4 + (int64_t)n_leaves * 5;
-                if (leaves + (int64_t)n_leaves * 5 > var_len || (h > 0 && hdr + second0 + 2 > var_len)) continue;
-                const uint32_t counts0 = h > 0 ? (uint32_t)var[hdr + second0] | ((uint32_t)var[hdr + second0 + 1] << 8) : 0u;
+                // the whole header the reference would touch (WFBB:479-483) must lie inside the byte array
+                if (hdr + (h > 1 ? (int64_t)(h - 1) * 4 : 0) + (int64_t)n_leaves * 5 + (int64_t)(n_leaves - 1) * 2 > var_len) continue;
+                if (((uint32_t)bh.bv_offset | (uint32_t)bh.bv_rank) >> 24) continue;
+                const uint32_t counts0 = h > 0 ? ld16(var.data() + hdr + second0) : 0u;
+                const int64_t block_start = sb_start + (blk << d.bsl);
+                const int64_t left = w.size - block_start;
+                const int32_t cur_block_size = (int32_t)(left < ((int64_t)1 << d.bsl) ? left : ((int64_t)1 << d.bsl));  // WFBB:1032
                 for (int i = 0; i < n_leaves; ++i) {
-                    const uint8_t *lp = var + leaves + (int64_t)i * 5;
-                    const int symbol = (int)lp[0] | ((int)lp[1] << 8);
-                    const uint32_t rank_block = (uint32_t)lp[2] | ((uint32_t)lp[3] << 8) | ((uint32_t)lp[4] << 16);
+                    const uint8_t *lp = var.data() + leaves + (int64_t)i * 5;
+                    const int symbol = (int)ld16(lp);
+                    const uint32_t rank_block = ld24(lp + 2);
                     if (symbol >= sigma) continue;
                     const int code_row = w.global_mapping[(size_t)(s * sigma + symbol)];
                     if (code_row < 0 || code_row > sb.sigma) continue;
-                    MapEntry &e = dst[(int64_t)(by_symbol ? symbol : code_row) * per_row + blk];
-                    if ((int16_t)(e.x & 0xffffu) < 0) continue;  // the mapping says absent: leave it to the reference's route
-                    // WFBB:250-278 restoreCodeFromBlockHeader for leaf i
-                    uint32_t code = 0, leaf_count = 0;
-                    int len = h > 0 ? 1 : 0;
-                    for (int lvl = 0; len < h && len > 0; ++lvl) {
-                        const uint32_t level_leaves = (uint32_t)var[hdr + 4 * lvl] | ((uint32_t)var[hdr + 4 * lvl + 1] << 8);
-                        code <<= 1;
-                        if (leaf_count + level_leaves > (uint32_t)i) {
-                            code += (uint32_t)i - leaf_count;
+                    MapEntry &e = ents[(size_t)((int64_t)(by_symbol ? symbol : code_row) * per_row + blk)];
+                    // only where the mapping holds the leaf's own index: an absent entry stays absent, a clamped one
+                    // (min(sigma-2, index), WFBB:466-471) keeps the reference's route with its fix-up (WFBB:1123-1130)
+                    if ((e.x & 0xffu) != kMapSlow || (e.x >> 8) != (uint32_t)i) continue;
+                    uint32_t code = 0;
+                    int32_t len = 0;
+                    if (h > 0) {
+                        Quad chunk = ld_quad(var.data() + hdr);
+                        wt_restore_code((uint32_t)i, var.data() + hdr, h, chunk, code, len);  // WFBB:250-278
+                    }
+                    if (len > (int32_t)kMapMaxLen || (code >> 16)) continue;  // stays on the reference's route
+                    // the walk of WFBB:1185-1279 along this code, position-independent part
+                    TreeWalk t;
+                    t.bv_rank = bh.bv_rank;
+                    t.bv_offset = bh.bv_offset;
+                    t.internal_nodes = 1;
+                    t.left_siblings = 0;
+                    t.left_total_bv = 0;
+                    t.node_bv_size = cur_block_size;
+                    t.depth_total_bv = t.node_bv_size;
+                    t.node_rank = 0;
+                    t.hdr = var.data() + hdr;
+                    t.second = (uint32_t)second0;
+                    t.level = 0;
+                    int32_t left_ones = 0, node_ones = (int32_t)counts0, level_ones = (int32_t)counts0;
+                    const size_t first_rec = path.size();
+                    bool ok = true;
+                    for (int32_t depth = 0; depth < len; ++depth) {
+                        const int64_t a = (int64_t)t.bv_offset + t.left_total_bv, b = (int64_t)t.bv_rank + left_ones;
+                        if (a < 0 || b < 0 || (a >> 24) || (b >> 24)) {
+                            ok = false;
                             break;
                         }
-                        code += level_leaves;
-                        ++len;
-                        leaf_count += level_leaves;
+                        if (depth > 0) path.push_back(PathRec{(uint32_t)a, (uint32_t)b});
+                        t.bv_rank += level_ones;
+                        tree_descend(t, (code & (1u << (len - depth - 1))) != 0, 0, node_ones);
+                        if (depth + 1 != len) {
+                            if ((int64_t)t.level + 4 > (int64_t)(h - 1) * 4) {  // level table exhausted: malformed header
+                                ok = false;
+                                break;
+                            }
+                            t.left_siblings -= tree_next_level_entry(t, ld32u(t.hdr + t.level));
+                            if (t.left_siblings < 0 || t.internal_nodes <= 0 || t.left_siblings >= t.internal_nodes ||
+                                hdr + t.second + 2 * (int64_t)t.internal_nodes > var_len) {
+                                ok = false;
+                                break;
+                            }
+                            tree_level_counts(t, left_ones, node_ones, level_ones);
+                        }
                     }
-                    if (h > 0 && len == h) {
-                        code <<= 1;
-                        code += (uint32_t)i - leaf_count;
+                    if (!ok || (rank_block >> 24)) {
+                        path.resize(first_rec);
+                        continue;
                     }
-                    if (len > 16 || (code >> 16)) continue;  // stays on the reference's route
-                    e.x = (e.x & 0xffffu) | ((uint32_t)len << 16) | ((counts0 >> 8) << 24);
-                    e.y = rank_block | ((counts0 & 0xffu) << 24);
-                    e.z = (uint32_t)bh.bv_offset | ((code & 0xffu) << 24);
-                    e.w = (uint32_t)bh.bv_rank | ((code >> 8) << 24);
+                    e.x = (uint32_t)len | (rank_block << 8);
+                    e.y = (uint32_t)bh.bv_offset | ((code & 0xffu) << 24);
+                    e.z = (uint32_t)bh.bv_rank | ((code >> 8) << 24);
+                    e.w = (uint32_t)(2 * (uint64_t)ents.size() + first_rec);
                 }
             }
+            d.path_len = (int32_t)path.size();
+            off = A.alloc(ents.size() * sizeof(MapEntry) + path.size() * sizeof(PathRec) + 32);
+            d.off_mapping = off8(off);
+            if (!ents.empty()) memcpy(A.at<uint8_t>(off), ents.data(), ents.size() * sizeof(MapEntry));
+            if (!path.empty())
+                memcpy(A.at<uint8_t>(off) + ents.size() * sizeof(MapEntry), path.data(), path.size() * sizeof(PathRec));
         }
         off = A.alloc(sb.block_headers.size() * sizeof(BlockHdr) + 16);
         d.off_bh = off8(off);
@@ -442,7 +503,183 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
         err = "blob exceeds 32 GiB";
         return -8;
     }
+    h.kind = 0;
+    h.checksum = 0;
     *A.at<BlobHeader>(hdr_off) = h;
+    A.at<BlobHeader>(hdr_off)->checksum = image_checksum(blob.data(), blob.size());
+    return 0;
+}
+
+// checksum of a whole image: its body and its header (with the checksum field itself taken as zero)
+uint64_t image_checksum(const uint8_t *blob, size_t len) {
+    BlobHeader h;
+    memcpy(&h, blob, sizeof h);
+    h.checksum = 0;
+    const uint64_t head = blob_checksum(reinterpret_cast<const uint8_t *>(&h), sizeof h);
+    return blob_checksum(blob + sizeof(BlobHeader), len - sizeof(BlobHeader)) + head * 0x9E3779B97F4A7C15ull;
+}
+
+// Order-sensitive 64-bit checksum of an image body: sum over its 8-byte words of mix(word + index * K)
+// (SplitMix64's finalizer), a sum so that threads can take slices.
+uint64_t blob_checksum(const uint8_t *p, size_t len) {
+    const size_t n_words = len / 8;
+    auto slice = [p](size_t lo, size_t hi) {
+        uint64_t acc = 0;
+        for (size_t i = lo; i < hi; ++i) {
+            uint64_t w;
+            memcpy(&w, p + 8 * i, 8);
+            uint64_t z = w + (uint64_t)i * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            acc += z ^ (z >> 31);
+        }
+        return acc;
+    };
+    unsigned n_threads = std::thread::hardware_concurrency();
+    if (n_threads == 0) n_threads = 1;
+    if (n_threads > 16) n_threads = 16;
+    if (n_words < ((size_t)1 << 20)) n_threads = 1;
+    std::vector<uint64_t> part(n_threads, 0);
+    std::vector<std::thread> pool;
+    const size_t per = (n_words + n_threads - 1) / n_threads;
+    for (unsigned t = 0; t < n_threads; ++t) {
+        const size_t lo = (size_t)t * per, hi = lo + per < n_words ? lo + per : n_words;
+        if (lo >= hi) break;
+        if (t + 1 == n_threads || hi == n_words) {
+            part[t] = slice(lo, hi);
+            break;
+        }
+        pool.emplace_back([&part, &slice, t, lo, hi]() { part[t] = slice(lo, hi); });
+    }
+    for (auto &t : pool) t.join();
+    uint64_t acc = 0x5851F42D4C957F2Dull ^ (uint64_t)len;
+    for (uint64_t v : part) acc += v;
+    for (size_t i = n_words * 8; i < len; ++i) acc = acc * 0x100000001B3ull + p[i];  // tail bytes (images are 8-aligned)
+    return acc;
+}
+
+// Structural validation of an image that did not come out of this process's flattener (fmx_attach_device_blob):
+// every section and per-superblock table lies inside the image, the shapes agree with each other, every block
+// header addresses bytes inside its superblock's arrays, and the body checksum matches — the same guarantee
+// validate_model gives a serialized stream before any kernel may walk it.
+int validate_blob(const uint8_t *b, size_t len, std::string &err) {
+    auto bad = [&](const char *what) {
+        err = std::string("device image fails validation: ") + what;
+        return -3;
+    };
+    if (len < sizeof(BlobHeader) + 64 || (len & 7)) return bad("size");
+    BlobHeader h;
+    memcpy(&h, b, sizeof h);
+    if (h.magic != kBlobMagic) return bad("magic");
+    if (h.version != kBlobVersion) return bad("version");
+    if (h.total_bytes != len) return bad("total_bytes");
+    auto inside = [&](uint32_t off, uint64_t bytes) {
+        const uint64_t lo = (uint64_t)off << 3;
+        return lo >= sizeof(BlobHeader) && bytes <= len && lo <= len - bytes;
+    };
+    if (h.checksum != image_checksum(b, len)) return bad("checksum");
+    if (h.kind == 1) {  // stand-alone RrrVector: records + offsets stream + value table
+        const RrrDesc &r = h.sampled;
+        if (r.length < 0 || r.n_blocks < 0 || r.n_rec != r.n_blocks / 16 + 1 ||
+            (int64_t)r.n_blocks < ((int64_t)r.length + 14) / 15)
+            return bad("RrrVector shape");
+        if (!inside(h.off_inv, (uint64_t)kInvEntries * 2) || !inside(r.off_rec, (uint64_t)r.n_rec * sizeof(RrrRecord)) ||
+            !inside(r.off_bits, 16))
+            return bad("RrrVector sections");
+        const RrrRecord *rec = reinterpret_cast<const RrrRecord *>(b + ((uint64_t)r.off_rec << 3));
+        const uint64_t stream_bits = (len - ((uint64_t)r.off_bits << 3)) * 8;
+        for (int32_t k = 0; k < r.n_rec; ++k)
+            if ((uint64_t)rec[k].offset_bit + 16 * 13 + 64 > stream_bits) return bad("RrrVector offset pointer");
+        return 0;
+    }
+    if (h.kind != 0) return bad("kind");
+    if (h.sample_rate <= 0 || h.length <= 0 || h.wt_size != h.length) return bad("sampleRate / length");
+    if (h.wt_sigma < 1 || h.wt_sigma > 32768 || h.n_c < 2 || h.n_look < 1) return bad("alphabet");
+    if (h.n_sb != (int32_t)(((int64_t)h.length + (1 << 20) - 1) >> 20)) return bad("superblock count");
+    if (h.bw_suffixes < 1 || h.bw_suffixes > 32 || (h.enable_extract && (h.bw_positions < 1 || h.bw_positions > 32)))
+        return bad("bit widths");
+    if (h.map_by_symbol != 0 && h.map_by_symbol != 1) return bad("map_by_symbol");
+    const int64_t n_samples = (int64_t)h.length / h.sample_rate;
+    if (h.n_suffixes < n_samples + 1 || (h.enable_extract && h.n_positions < n_samples + 2)) return bad("sample counts");
+    auto packed_bytes = [](int64_t n, int width) { return (uint64_t)(words_for_bits(n * width) + 2) * 8; };
+    if (!inside(h.off_c, (uint64_t)h.n_c * 4) || !inside(h.off_lookup, (uint64_t)h.n_look * 4) ||
+        !inside(h.off_char2code, 65536 * 2) || !inside(h.off_suffixes, packed_bytes(h.n_suffixes, h.bw_suffixes)) ||
+        (h.enable_extract && !inside(h.off_positions, packed_bytes(h.n_positions, h.bw_positions))) ||
+        !inside(h.off_sbc, (uint64_t)(h.n_sb + 1) * h.wt_sigma * sizeof(SbcEntry)) ||
+        !inside(h.off_sbdesc, (uint64_t)h.n_sb * sizeof(SbDesc)))
+        return bad("section outside the image");
+    const int16_t *c2c = reinterpret_cast<const int16_t *>(b + ((uint64_t)h.off_char2code << 3));
+    for (int i = 0; i < 65536; ++i)
+        if (c2c[i] < 0 || c2c[i] >= h.wt_sigma || c2c[i] + 1 >= h.n_c || c2c[i] >= h.n_look) return bad("char -> code table");
+    const int32_t *C = reinterpret_cast<const int32_t *>(b + ((uint64_t)h.off_c << 3));
+    for (int i = 0; i < h.n_c; ++i)
+        if (C[i] < 0 || C[i] > h.length) return bad("cumulativeCounts");
+    auto cells_ok = [&](const RrrDesc &r) {
+        return r.length >= 0 && r.n_rec == (int32_t)((int64_t)r.length / kBvCellBits + 2) &&
+               inside(r.off_rec, (uint64_t)r.n_rec * sizeof(BvCell));
+    };
+    if (h.sampled.length != h.length || !cells_ok(h.sampled)) return bad("sampled-row bitmap");
+    if (h.enable_extract) {  // inverse samples are SA rows: the walks start there (FM:579-587)
+        const uint32_t *pw = reinterpret_cast<const uint32_t *>(b + ((uint64_t)h.off_positions << 3));
+        for (int64_t i = 0; i < h.n_positions; ++i)
+            if ((int64_t)ld_bits(pw, (uint64_t)i * (uint32_t)h.bw_positions, h.bw_positions) >= h.length)
+                return bad("inverse sample outside the text");
+    }
+    const SbcEntry *sbc = reinterpret_cast<const SbcEntry *>(b + ((uint64_t)h.off_sbc << 3));
+    const SbDesc *sbd = reinterpret_cast<const SbDesc *>(b + ((uint64_t)h.off_sbdesc << 3));
+    for (int32_t s = 0; s < h.n_sb; ++s) {
+        const SbDesc &d = sbd[s];
+        if (d.bsl < 0 || d.bsl > 20 || d.sigma < -1 || d.sigma >= h.wt_sigma) return bad("superblock header");
+        const int64_t per_row = (int64_t)1 << (20 - d.bsl);
+        const int64_t symbols = (int64_t)h.length - ((int64_t)s << 20) < (1 << 20) ? (int64_t)h.length - ((int64_t)s << 20) : (1 << 20);
+        const int64_t n_blocks = (symbols + ((int64_t)1 << d.bsl) - 1) >> d.bsl;
+        if (d.n_blocks != n_blocks || d.n_blocks > per_row) return bad("block count");
+        const int64_t rows = h.map_by_symbol ? h.wt_sigma : (int64_t)d.sigma + 1;
+        if (d.mapping_len != rows * per_row || d.path_len < 0 || d.var_len < 0) return bad("mapping shape");
+        if (!inside(d.off_mapping, (uint64_t)d.mapping_len * sizeof(MapEntry) + (uint64_t)d.path_len * sizeof(PathRec) + 32) ||
+            !inside(d.off_bh, (uint64_t)d.n_blocks * sizeof(BlockHdr) + 16) || !inside(d.off_var, (uint64_t)d.var_len + 16) ||
+            !cells_ok(d.rrr) || d.rrr.length >= (1 << 24) || !inside(d.rrr.off_bits, 4 * (uint64_t)d.var_len + 64))
+            return bad("superblock table outside the image");
+        for (int c = 0; c < h.wt_sigma; ++c) {
+            const int16_t code = sbc[(int64_t)s * h.wt_sigma + c].sbc;
+            if (code < 0 || (code > d.sigma && code != h.wt_sigma - 1)) return bad("superblock code");
+        }
+        const BlockHdr *bh = reinterpret_cast<const BlockHdr *>(b + ((uint64_t)d.off_bh << 3));
+        for (int32_t k = 0; k < d.n_blocks; ++k) {
+            const int32_t height = bh[k].tree_height, leaves = (int32_t)bh[k].sigma + 1;
+            if (height < 0 || height > 30 || leaves < 1 || bh[k].var_off < 0) return bad("block header");
+            const int64_t need = (height > 1 ? (int64_t)(height - 1) * 4 : 0) + (int64_t)leaves * 5 + (int64_t)(leaves - 1) * 2;
+            if ((int64_t)bh[k].var_off + need > d.var_len) return bad("block header outside the byte array");
+            if ((bh[k].bv_offset & 0xffffff) > d.rrr.length) return bad("block bit-vector offset");
+        }
+        const MapEntry *me = reinterpret_cast<const MapEntry *>(b + ((uint64_t)d.off_mapping << 3));
+        for (int64_t row = 0; row < rows; ++row)
+            for (int64_t blk = 0; blk < per_row; ++blk) {
+                const MapEntry &e = me[row * per_row + blk];
+                const uint32_t tag = e.x & 0xffu, value = e.x >> 8;
+                if (tag == kMapAbsent) {
+                    if (value < 1 || blk + (int64_t)value > per_row) return bad("skip pointer");
+                    if (blk + (int64_t)value < per_row && (me[row * per_row + blk + value].x & 0xffu) == kMapAbsent)
+                        return bad("skip pointer onto an absent entry");
+                } else if (blk >= d.n_blocks) {
+                    return bad("mapping entry beyond the last block");
+                } else if (tag == kMapSlow) {
+                    if (value > 0x7fffu) return bad("leaf index");
+                } else if (tag <= kMapMaxLen) {
+                    if ((e.y & 0xffffffu) > (uint32_t)d.rrr.length) return bad("root node position");
+                    if (tag > 1) {
+                        const uint64_t first = e.w, last = first + (tag - 1);
+                        if (first < 2 * (uint64_t)d.mapping_len || last > 2 * (uint64_t)d.mapping_len + (uint64_t)d.path_len)
+                            return bad("path records outside the table");
+                    }
+                } else {
+                    return bad("mapping tag");
+                }
+            }
+        const PathRec *pr = reinterpret_cast<const PathRec *>(me + d.mapping_len);
+        for (int32_t k = 0; k < d.path_len; ++k)
+            if (pr[k].a > (uint32_t)d.rrr.length || (pr[k].b >> 24)) return bad("path record");
+    }
     return 0;
 }
 

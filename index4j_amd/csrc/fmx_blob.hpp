@@ -13,12 +13,12 @@
 //   * per superblock: mapping (MapEntry, 16 B), BlockHeader[] (16 B, as WFBB:1589-1595, the root node's one-count
 //     in the spare top bytes), variable headers (bytes as written at WFBB:742-809, + 16 guard bytes), and its bit
 //     vector as 96-bit cells (BvCell).
-//   * mapping (WFBB:1628): present entries keep the block-local symbol index and add what the block's header
-//     tells about the symbol (MapEntry below); an ABSENT entry (alphabetSize-1 in the reference) is stored as
-//     -d, d = distance to the closest block to the right that holds the symbol (or to the end of the
-//     superblock).  The reference finds that block with a linear scan (WFBB:1051-1059: 27 dependent reads on
-//     average on log text); the skip pointer returns the same block in one read.  Rows are indexed by the global
-//     symbol (BlobHeader.map_by_symbol) or, for very large alphabets, by the superblock code as in the reference.
+//   * mapping (WFBB:1628): a present entry holds what the block's header tells about the symbol and where its
+//     path records are (MapEntry below); an ABSENT entry (alphabetSize-1 in the reference) holds d = distance to
+//     the closest block to the right that holds the symbol (or to the end of the superblock).  The reference
+//     finds that block with a linear scan (WFBB:1051-1059: 27 dependent reads on average on log text); the skip
+//     pointer returns the same block in one read.  Rows are indexed by the global symbol
+//     (BlobHeader.map_by_symbol) or, for very large alphabets, by the superblock code as in the reference.
 //   * bit vectors (RrrVector in the reference: WFBB:116, FM:123) are EXPANDED into BvCell arrays (below).
 //   * a stand-alone RrrVector (fmx_rrr_build) keeps the compressed form: 16-byte records, one per 16 blocks of 15
 //     bits, whatever the sampleSize: { u32 ones before the record (the role of prefixSums, RRR:101), u32 bit
@@ -33,7 +33,7 @@
 namespace fmx {
 
 constexpr uint32_t kBlobMagic = 0x31584D46u;  // "FMX1"
-constexpr uint32_t kBlobVersion = 10;
+constexpr uint32_t kBlobVersion = 11;
 
 struct RrrRecord {         // 16 bytes: 16 blocks of 15 bits
     uint32_t ones_before;  // 1-bits in all earlier blocks
@@ -69,24 +69,39 @@ struct RrrDesc {           // 32 bytes; the first 16 are what a rank needs (one 
 };
 
 // One entry of the superblock's symbol -> block mapping (WFBB:461-471), widened from the reference's int16 to
-// everything rank() needs about (symbol, block) when the symbol occurs in the block — so that the common path
-// reads neither the leaf entry nor the level table and does not rebuild the canonical code:
-//   x = raw[15:0] | len[23:16] | counts0_hi[31:24]      raw: the reference's value (min(sigma-2, leaf index)), or
-//   y = rank_block[23:0] | counts0_lo[31:24]                  -(distance to the next block holding the symbol)
-//   z = bv_offset[23:0] | code_lo[31:24]                 len: canonical code length (0 = run block);
-//   w = bv_rank[23:0]   | code_hi[31:24]                      kMapSlow = take the reference's own route
-// rank_block = occurrences in the superblock before the block (the leaf's u24, WFBB:774-788); counts0 = ones
-// in the root node (first u16 of the cumulative counts, WFBB:793-809); bv_offset / bv_rank = the block's
-// BlockHeaderItem fields (WFBB:450-454).  The table is small (2 MB -> 17 MB on the 256 MiB log).
+// everything rank() needs about (symbol, block), so that the common path of rank() is
+//   {superblock entry, mapping entry} -> first cell [+ the leaf's path records] -> next cell -> ...
+// and reads neither the block header nor the leaf entry, the level table or the cumulative counts:
+//   x = tag[7:0] | value[31:8]
+//         tag 0..16   PRESENT, fast: tag = canonical code length (0 = run block), value = occurrences of the symbol
+//                     in the superblock before the block (the leaf's u24, WFBB:774-788)
+//         kMapAbsent  the block does not hold the symbol (alphabetSize-1 in the reference, WFBB:383-387); value =
+//                     distance to the closest block to the right that holds it, or to the end of the row
+//         kMapSlow    present, "take the reference's own route": value = the reference's int16 (min(sigma-2, leaf
+//                     index), WFBB:466-471).  Used for codes longer than 16 bits and for clamped entries.
+//   y = A0[23:0] | code[7:0]  << 24        A0 = bit position of the root node in the superblock's bit vector
+//   z = B0[23:0] | code[15:8] << 24        B0 = one-bits before it       (BlockHeaderItem, WFBB:450-454)
+//   w = offset of the leaf's path records, in 8-byte units from the start of the superblock's mapping table
+// Path records (PathRec, 8 bytes, one per level d = 1 .. length-1 of the leaf's code, contiguous): the node the
+// walk visits at depth d starts at bit A_d of the superblock's bit vector, with B_d one-bits before it.  In the
+// reference these are `blockVectorOffset + leftTotalBvSize` and `blockVectorRank + leftOnes` of WFBB:1187-1278,
+// rebuilt for every query from the level table and the cumulative counts; they depend on (block, code prefix)
+// only, never on the position, so the flattener evaluates that arithmetic once per leaf (with the reference's own
+// integer widths).  rank1 inside the node = rankOnes(A_d + rank in node) - B_d  (WFBB:1216-1218).
 struct MapEntry {
     uint32_t x, y, z, w;
 };
+struct PathRec {
+    uint32_t a, b;
+};
 constexpr uint32_t kMapSlow = 0xffu;
+constexpr uint32_t kMapAbsent = 0xfeu;
+constexpr uint32_t kMapMaxLen = 16;
 
 struct SbDesc {            // 64 bytes; bytes 0..15 = header of every rank, bytes 32..47 = its RRR vector
     int16_t sigma;         // WFBB:1623 (superblock alphabet size - 1)
     int16_t bsl;           // WFBB:1624 blockSizeLog
-    uint32_t off_mapping;  // MapEntry[rows << (20 - bsl)], absent entries: raw = -(distance to next present);
+    uint32_t off_mapping;  // MapEntry[mapping_len = rows << (20 - bsl)] followed by PathRec[path_len];
                            // rows = the index's alphabet size (BlobHeader.map_by_symbol: the row of a symbol is known
                            // without the superblock's code table, so the entry is requested one load earlier) or sigma+1
     uint32_t off_bh;       // BlockHdr[n_blocks]
@@ -94,7 +109,7 @@ struct SbDesc {            // 64 bytes; bytes 0..15 = header of every rank, byte
     int32_t n_blocks;
     int32_t var_len;
     int32_t mapping_len;
-    int32_t pad;
+    int32_t path_len;
     RrrDesc rrr;
 };
 
@@ -126,12 +141,16 @@ struct BlobHeader {        // 256 bytes
     uint32_t off_inv;        // uint16[16384] value-of-offset table, classes 0..7  RRR:106
     RrrDesc sampled;         // sampledSuffixes                        FM:123
     int32_t map_by_symbol;   // 1: a superblock's mapping rows are indexed by the global symbol, 0: by its superblock code
-    uint8_t reserved[256 - 8 - 8 - 12 * 4 - 8 - 8 * 4 - 32 - 4];
+    int32_t kind;            // 0 = FM-index image, 1 = stand-alone RrrVector (fmx_rrr_build)
+    uint64_t checksum;       // image_checksum(): body and header (this field taken as zero) — an image that travelled
+                             // (RCCL broadcast, fmx_attach_device_blob) is the one the flattener wrote
+    uint8_t reserved[256 - 8 - 8 - 12 * 4 - 8 - 8 * 4 - 32 - 4 - 4 - 8];
 };
 static_assert(sizeof(RrrDesc) == 32, "RrrDesc");
 static_assert(sizeof(RrrRecord) == 16, "RrrRecord");
 static_assert(sizeof(BvCell) == 16, "BvCell");
 static_assert(sizeof(MapEntry) == 16, "MapEntry");
+static_assert(sizeof(PathRec) == 8, "PathRec");
 static_assert(sizeof(SbDesc) == 64, "SbDesc");
 static_assert(sizeof(BlockHdr) == 16, "BlockHdr");
 static_assert(sizeof(SbcEntry) == 8, "SbcEntry");

@@ -526,40 +526,38 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
     const MapEntry *mapping = reinterpret_cast<const MapEntry *>(ix.base + ((uint64_t)sh.off_mapping << 3));
     const BlockHdr *bhs = reinterpret_cast<const BlockHdr *>(ix.base + ((uint64_t)sh.off_bh << 3));
     const uint8_t *var = ix.base + ((uint64_t)sh.off_var << 3);
-    Quad mq = {0, 0, 0, 0}, bhq = {0, 0, 0, 0};
+    Quad mq = {0, 0, 0, 0};
     uint32_t map_row = (uint32_t)symbol << blocks_log;
-    if (ix.map_by_symbol) {  // the row does not depend on the superblock entry: ask for everything at once
+    if (ix.map_by_symbol)  // the row does not depend on the superblock entry: ask for both at once
         mq = ld_quad(mapping + map_row + block_id);  // WFBB:1044-1046 (+ what the symbol's leaf would tell)
-        bhq = ld_quad(bhs + block_id);               // WFBB:1113
-    }
     FMX_OPAQUE64(sbc_raw);
     const SbcEntry e = sbc_from(sbc_raw);
-    if (ix.map_by_symbol) {
-        FMX_PIN_QUAD(mq);
-        FMX_PIN_QUAD(bhq);
-    }
+    if (ix.map_by_symbol) FMX_PIN_QUAD(mq);
     if ((int32_t)e.sbc >= sh.sigma + 1) return e.rank;  // WFBB:1040-1042
     if (!ix.map_by_symbol) {
         map_row = (uint32_t)e.sbc << blocks_log;
         mq = ld_quad(mapping + map_row + block_id);
-        bhq = ld_quad(bhs + block_id);  // requested before the mapping entry is known
         FMX_PIN_QUAD(mq);
-        FMX_PIN_QUAD(bhq);
     }
-    int32_t block_c = (int32_t)(int16_t)(mq.x & 0xffffu);
+    const uint32_t tag = mq.x & 0xffu;
 
-    if (block_c < 0) {  // WFBB:1048-1110: absent; -block_c = distance to the closest block to the right that
-                        // holds the symbol (what the scan of WFBB:1051-1059 finds), or to the superblock end
-        block_id += (uint32_t)(-block_c);
-        if (block_id == (1u << blocks_log))  // WFBB:1060-1069 (row n_sb of the table holds count[])
+    if (tag == kMapAbsent) {  // WFBB:1048-1110: the entry holds the distance to the closest block to the right that
+                              // holds the symbol (what the scan of WFBB:1051-1059 finds), or to the superblock end
+        block_id += mq.x >> 8;
+        if (block_id >= (1u << blocks_log))  // WFBB:1060-1069 (row n_sb of the table holds count[])
             return ix.sbc[(uint64_t)(sb_id + 1) * (uint32_t)ix.wt_sigma + (uint32_t)symbol].rank;
-        block_c = (int32_t)(int16_t)(mapping[map_row + block_id].x & 0xffffu);
+        const Quad nq = ld_quad(mapping + map_row + block_id);
+        const uint32_t ntag = nq.x & 0xffu;
+        // WFBB:1096-1108 reads the u24 of leaf `mapping value` of that block.  A fast entry (never clamped, see
+        // fmx_blob.hpp) of a block with a tree IS that leaf's u24, the symbol's own: not suspect.
+        if (ntag >= 1u && ntag <= kMapMaxLen) return e.rank + (int32_t)(nq.x >> 8);
+        // run block (tree height 0: the reference reads 4 bytes early, Q11) or an entry on the reference's route
+        // (clamped, no fix-up here: Q2): the literal address arithmetic of WFBB:1080-1081
+        const int32_t block_c = ntag == kMapSlow ? (int32_t)(nq.x >> 8) : 0;
         const BlockHdr bh = ld_block_hdr(bhs + block_id);
-        // WFBB:1080-1081: (treeHeight - 1) * 4 with no treeHeight > 0 guard, and no clamped-mapping fix-up
         const int32_t p = bh.var_off + ((int32_t)bh.tree_height - 1) * 4 + block_c * 5 + 2;
-        // the result is only trustworthy if the entry read is the symbol's own: a run block is read 4 bytes early
-        // (Q11), and a clamped mapping entry (no fix-up here, Q2) may point at a neighbour's entry
-        if (bh.tree_height == 0 || (int32_t)ld16(var + p - 2) != symbol) suspect = true;
+        // the result is only trustworthy if the entry read is the symbol's own
+        if (bh.tree_height == 0 || p < 2 || (int32_t)ld16(var + p - 2) != symbol) suspect = true;
         if (p < 0 || p + 2 >= sd.var_len) {
             status = ST_JAVA_AIOOBE;
             return fm_c_or_zero(ix, symbol);
@@ -567,29 +565,53 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
         return e.rank + (int32_t)(ld32u(var + p) & 0xffffffu);  // WFBB:1096-1108
     }
 
+    if (tag <= kMapMaxLen) {
+        // The common path.  The mapping entry holds the leaf's rank at the block start, its canonical code and the
+        // root node {A0 = bit position, B0 = ones before it}; the nodes below the root come from the leaf's path
+        // records, whose address is known now — so everything but the cells is requested at once, and each level
+        // is ONE dependent 16-byte load: rank1 in the node = rankOnes(A_d + rank in node) - B_d (WFBB:1216-1218).
+        const int32_t code_length = (int32_t)tag;
+        const int32_t rank_block = (int32_t)(mq.x >> 8);
+        if (code_length == 0) return e.rank + rank_block + (int32_t)block_index;  // run block, WFBB:1141-1146
+        const uint32_t code = (mq.y >> 24) | ((mq.z >> 24) << 8);
+        uint32_t node_a = mq.y & 0xffffffu, node_b = mq.z & 0xffffffu;
+        const PathRec *path = reinterpret_cast<const PathRec *>(mapping) + mq.w;
+        int32_t pos = (int32_t)node_a + (int32_t)block_index;
+        Quad pq = {0, 0, 0, 0}, cell = {0, 0, 0, 0};
+        if (code_length > 1) pq = ld_quad(path);  // records of levels 1 and 2
+        if (rrr_in_range(rv, pos)) cell = ld_quad(bv_cell_ptr(ix.base, rv, (uint32_t)pos));
+        FMX_PIN_QUAD(pq);
+        FMX_PIN_QUAD(cell);
+        int32_t node_rank = (int32_t)block_index;
+        FMX_NO_UNROLL  // one copy of the level code: peeled copies only add instruction-cache pressure
+        for (int32_t depth = 0; depth < code_length; ++depth) {
+            const int32_t rank1 = bv_rank1_cell(rv, cell, pos) - (int32_t)node_b;
+            node_rank = (code >> (code_length - depth - 1)) & 1u ? rank1 : node_rank - rank1;  // WFBB:1235-1244
+            if (depth + 1 != code_length) {
+                node_a = (depth & 1) ? pq.z : pq.x;  // record `depth` = the node at level depth + 1
+                node_b = (depth & 1) ? pq.w : pq.y;
+                pos = (int32_t)node_a + node_rank;
+                if (rrr_in_range(rv, pos)) cell = ld_quad(bv_cell_ptr(ix.base, rv, (uint32_t)pos));
+                if ((depth & 1) && depth + 2 < code_length) pq = ld_quad(path + depth + 1);  // the next two levels
+                FMX_PIN_QUAD(cell);
+                FMX_PIN_QUAD(pq);
+            }
+        }
+        return e.rank + rank_block + node_rank;  // WFBB:1281-1284
+    }
+
+    // The reference's own route (codes longer than 16 bits, clamped mapping entries): block header, leaf entry,
+    // clamped-mapping fix-up, code rebuilt from the level table, walk over the level table and cumulative counts.
+    int32_t block_c = (int32_t)(mq.x >> 8);
+    const Quad bhq = ld_quad(bhs + block_id);  // WFBB:1113
     const BlockHdr bh = block_hdr_from(bhq);
     const int32_t tree_height = bh.tree_height;
     const uint8_t *hdr = var + bh.var_off;
     const uint32_t second0 = (uint32_t)((tree_height - 1) * 4 + ((int32_t)bh.sigma + 1) * 5);  // WFBB:1177-1182
-    const uint32_t map_len = (mq.x >> 16) & 0xffu;
     int32_t rank_block, code_length, position0;
     uint32_t code, counts0 = 0;
     Quad chunk = {0, 0, 0, 0}, rec_q = {0, 0, 0, 0};
-    if (map_len != kMapSlow) {
-        // the mapping entry already holds what the leaf, the level table and restoreCode would give
-        // (WFBB:1119-1156): rank at block start, canonical code, the root's one-count, the block's bit-vector fields
-        rank_block = (int32_t)(mq.y & 0xffffffu);
-        code_length = (int32_t)map_len;
-        if (code_length == 0) return e.rank + rank_block + (int32_t)block_index;  // run block, WFBB:1141-1146
-        code = (mq.z >> 24) | ((mq.w >> 24) << 8);
-        counts0 = ((mq.x >> 24) << 8) | (mq.y >> 24);
-        position0 = (int32_t)(mq.z & 0xffffffu) + (int32_t)block_index;
-        if (code_length > 1) chunk = ld_quad(hdr);  // level entries 0..3, for the walk below the root
-        if (rrr_in_range(rv, position0)) rec_q = ld_quad(bv_cell_ptr(ix.base, rv, (uint32_t)position0));
-        FMX_PIN_QUAD(chunk);
-        FMX_PIN_QUAD(rec_q);
-    } else {
-        // the reference's own route: leaf entry, clamped-mapping fix-up, code rebuilt from the level table
+    {
         const uint8_t *leaves = hdr + (tree_height > 0 ? (tree_height - 1) * 4 : 0);  // WFBB:1119-1121
         position0 = bh.bv_offset + (int32_t)block_index;
         uint64_t leaf;

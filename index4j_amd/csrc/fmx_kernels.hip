@@ -13,6 +13,7 @@
 // bit-level integer gather (no MFMA): throughput comes from tens of thousands of independent dependent-load
 // chains in flight, the two lanes of a pattern sharing their sectors (start and end of an interval usually
 // fall in the same blocks).
+#include <atomic>
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -415,7 +416,8 @@ __global__ __launch_bounds__(kTileThreads) void k_order_hist(DevIndex ix, const 
             const uint64_t word = pattern_code_word(ix, pat, beg, pat_off[p + 1] - beg, code_bits);
             codes[p] = word;  // kept for the tile sort and for k_count
             const uint32_t key = suffix_key(word, code_bits, sh.chars, sh.bits);
-            const uint32_t c = key >> (sh.total_bits - sh.coarse_bits);
+            uint32_t c = key >> (sh.total_bits - sh.coarse_bits);
+            if (c >= (uint32_t)bins) c = (uint32_t)bins - 1u;  // cannot happen for a validated index (codes < 2^bits)
             coarse[p] = c;
             atomicAdd(&s_hist[c], 1u);
         }
@@ -566,17 +568,19 @@ __global__ __launch_bounds__(256) void k_segment_append_hits(int64_t *__restrict
 
 // ---- launchers (called from fmx_api.cpp) -----------------------------------------------------
 
-// tunables (fmx_set_option): workgroup size and how many workgroups per CU the grid is capped at
-static int g_block = 512;
-static int g_groups_per_cu = 16;
-static int g_boundary_accel = 1;  // 0 = literal right walk of extractUntilBoundary (A/B and fallback)
-static int g_boundary_group = 4;  // lanes per query of extractUntilBoundary (0 = one lane per query)
-static int g_lds_pad_kb = 0;   // experiment knob: extra dynamic LDS per workgroup (lowers occupancy)
-static int g_sort_min = 16384;  // batches at least this large are processed in suffix-sorted order (0 = never)
+// tunables (fmx_set_option): workgroup size and how many workgroups per CU the grid is capped at.  Atomics: a
+// launch on one host thread may read them while another thread sets one (results are identical for every
+// setting, so a launch that sees a mix of old and new values is still correct).
+static std::atomic<int> g_block{512};
+static std::atomic<int> g_groups_per_cu{16};
+static std::atomic<int> g_boundary_accel{1};  // 0 = literal right walk of extractUntilBoundary (A/B and fallback)
+static std::atomic<int> g_boundary_group{4};  // lanes per query of extractUntilBoundary (0 = one lane per query)
+static std::atomic<int> g_lds_pad_kb{0};   // experiment knob: extra dynamic LDS per workgroup (lowers occupancy)
+static std::atomic<int> g_sort_min{16384};  // batches at least this large are processed in suffix-sorted order (0 = never)
 // bins of the bucket pass = 2^coarse_bits (<= 14: they live in LDS).  Measured on configs[1] (tools/tune_coarse.py):
 // 14 bits: plan 0.091 ms, step 0.304 ms; 12 bits: 0.075 / 0.286 ms; 10 bits: 0.071 / 0.286 ms; 8 bits: 0.069 / 0.294 ms
-static int g_coarse_bits = 12;
-static int g_sort_bits = 28;    // full key width: floor(sort_bits / bits-per-code) trailing characters
+static std::atomic<int> g_coarse_bits{12};
+static std::atomic<int> g_sort_bits{28};    // full key width: floor(sort_bits / bits-per-code) trailing characters
 
 int set_option(const char *name, int value) {
     if (!strcmp(name, "block")) {
@@ -643,11 +647,12 @@ static SortShape sort_shape(const DevIndex &ix) {
     SortShape sh;
     sh.bits = 1;
     while ((1 << sh.bits) < ix.wt_sigma && sh.bits < 15) ++sh.bits;
-    sh.chars = g_sort_bits / sh.bits;
+    const int sort_bits = g_sort_bits, coarse_bits = g_coarse_bits;
+    sh.chars = sort_bits / sh.bits;
     if (sh.chars < 1) sh.chars = 1;
     if (sh.chars > 64 / plan_code_bits(ix.wt_sigma)) sh.chars = 64 / plan_code_bits(ix.wt_sigma);
     sh.total_bits = sh.chars * sh.bits;
-    sh.coarse_bits = sh.total_bits < g_coarse_bits ? sh.total_bits : g_coarse_bits;
+    sh.coarse_bits = sh.total_bits < coarse_bits ? sh.total_bits : coarse_bits;
     return sh;
 }
 
@@ -657,7 +662,8 @@ static size_t plan_codes_offset(int32_t n) {
 }
 // bytes of scratch needed to order a batch of n patterns (0 = the batch is not sorted)
 size_t count_workspace_bytes(const DevIndex &ix, int32_t n) {
-    if (g_sort_min <= 0 || n < g_sort_min) return 0;
+    const int sort_min = g_sort_min;
+    if (sort_min <= 0 || n < sort_min) return 0;
     return plan_codes_offset(n) + (size_t)n * sizeof(uint64_t);
 }
 
@@ -763,15 +769,36 @@ int launch_extract(const DevIndex &ix, int n_cu, const int32_t *start, const int
     return (int)hipGetLastError();
 }
 
-// lanes the extractUntilBoundary grid will run with, and the scratch it needs (sample_rate codes per lane)
-static int boundary_group_size() { return g_boundary_accel ? g_boundary_group : 0; }  // 0 = one lane, literal/serial forms
-static int64_t boundary_lanes(int64_t n, int n_cu) {
-    const int G = boundary_group_size();
-    return (int64_t)grid_for(n * (G ? G : 1), g_block, n_cu) * g_block;
+// lanes the extractUntilBoundary grid will run with, and the scratch it needs (sample_rate codes per lane).
+// The options are read ONCE per decision (BoundaryShape) so that a concurrent fmx_set_option cannot make the
+// launch disagree with the workspace it was sized for.
+struct BoundaryShape {
+    int block, group, accel;
+};
+static BoundaryShape boundary_shape() {
+    BoundaryShape b;
+    b.block = g_block;
+    b.accel = g_boundary_accel;
+    b.group = b.accel ? (int)g_boundary_group : 0;  // 0 = one lane, literal/serial forms
+    return b;
+}
+static size_t boundary_bytes_for_grid(const DevIndex &ix, int blocks, const BoundaryShape &b) {
+    return (size_t)blocks * (size_t)b.block * (size_t)ix.sample_rate * sizeof(uint16_t) * 2 + 256;  // two windows
+}
+static size_t boundary_bytes_for(const DevIndex &ix, int64_t n, int n_cu, const BoundaryShape &b) {
+    if (!b.accel || n <= 0) return 0;
+    return boundary_bytes_for_grid(ix, grid_for(n * (b.group ? b.group : 1), b.block, n_cu), b);
 }
 size_t boundary_workspace_bytes(const DevIndex &ix, int64_t n, int n_cu) {
-    if (!g_boundary_accel || n <= 0) return 0;
-    return (size_t)boundary_lanes(n, n_cu) * (size_t)ix.sample_rate * sizeof(uint16_t) * 2 + 256;  // two windows
+    // upper bound over the workgroup sizes: whatever shape the launch snapshots fits
+    BoundaryShape b = boundary_shape();
+    size_t need = 0;
+    for (int blk : {512, 1024}) {
+        b.block = blk;
+        const size_t v = boundary_bytes_for(ix, n, n_cu, b);
+        if (v > need) need = v;
+    }
+    return need;  // (a racing change of groups_per_cu / boundary_group at worst makes the launch take the literal form)
 }
 
 int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, int64_t n, uint16_t boundary, int mode,
@@ -779,12 +806,14 @@ int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, i
                             int32_t *status, int32_t *aux, void *workspace, size_t workspace_bytes,
                             const int32_t *slot_found, int32_t slots, hipStream_t st) {
     if (n <= 0) return 0;
-    uint16_t *scratch = (workspace && workspace_bytes >= boundary_workspace_bytes(ix, n, n_cu) && g_boundary_accel)
+    const BoundaryShape shape = boundary_shape();
+    const int blk = shape.block;
+    const int blocks_accel = grid_for(n * (shape.group ? shape.group : 1), blk, n_cu);  // the grid the scratch is sized for
+    uint16_t *scratch = (workspace && shape.accel && workspace_bytes >= boundary_bytes_for_grid(ix, blocks_accel, shape))
                             ? static_cast<uint16_t *>(workspace)
                             : nullptr;
-    const int G = scratch ? boundary_group_size() : 0;
-    const int blk = g_block;
-    const dim3 grid(grid_for(n * (G ? G : 1), blk, n_cu));
+    const int G = scratch ? shape.group : 0;
+    const dim3 grid(scratch ? blocks_accel : grid_for(n, blk, n_cu));
 #define FMX_LAUNCH_GROUP(GG)                                                                                            \
     do {                                                                                                                \
         if (blk == 1024)                                                                                                \

@@ -26,33 +26,27 @@ def lib():
     return _LIB
 
 
-def _without_fast_mapping(blob):
-    """copy of the image whose mapping entries all say 'take the reference's own route' (len = kMapSlow): rank()
-    then reads the leaf entry, fixes clamped entries up and rebuilds the canonical code as WFBB:1119-1156 do"""
-    import struct
+def reference_route_index(text, sample_rate, enable_extract=True):
+    """an index whose image has NO fast mapping entries: every present entry says 'take the reference's own route',
+    so rank() reads the block header and the leaf entry, fixes clamped entries up and rebuilds the canonical code
+    as WFBB:1119-1156 do.  (The image is flattened under option map_fast = 0.)"""
+    import index4j_amd as ia
 
-    b = np.array(blob, dtype=np.uint8, copy=True)
-    raw = b.tobytes()
-    ints = struct.unpack_from("<12i", raw, 16)
-    n_sb = ints[9]
-    off_sbdesc = struct.unpack_from("<8I", raw, 16 + 48 + 8)[6] * 8
-    for s_ in range(n_sb):
-        _sigma, _bsl, off_map, _obh, _ov, _nb, _vl, map_len, _pad = struct.unpack_from("<hhIIIiiii", raw, off_sbdesc + 64 * s_)
-        ent = b[off_map * 8: off_map * 8 + map_len * 16].view(np.uint32).reshape(map_len, 4)
-        present = (ent[:, 0] & 0x8000) == 0
-        ent[present, 0] = (ent[present, 0] & 0xFFFF) | (0xFF << 16)
-        ent[present, 1:] = 0
-    return b
+    assert ia.lib.fmx_set_option(b"map_fast", 0) == 0
+    try:
+        f = ia.FmIndex(text, sample_rate, enable_extract, device=None)
+        f.blob()  # flatten now, under the option
+    finally:
+        ia.lib.fmx_set_option(b"map_fast", 1)
+    return f
 
 
 class HostSim:
     """runs the device code over the host blob of an index4j_amd.FmIndex"""
 
-    def __init__(self, fm_index, force_reference_route=False):
+    def __init__(self, fm_index):
         self.fm = fm_index  # keeps the blob alive
         self.blob = fm_index.blob()
-        if force_reference_route:
-            self.blob = _without_fast_mapping(self.blob)
         self.p = self.blob.ctypes.data
 
     def wt_rank_batch(self, positions, symbols):

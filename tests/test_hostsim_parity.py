@@ -79,7 +79,7 @@ def test_wavelet_rank_all_paths_incl_quirks():
 
 
 def make_sim_reference_route(text, sr):
-    return hostsim.HostSim(ia.FmIndex(text, sr, True, device=None), force_reference_route=True)
+    return hostsim.HostSim(hostsim.reference_route_index(text, sr))
 
 
 def test_rank_reference_route_still_matches():
