@@ -121,18 +121,23 @@ int fmx_extract_boundary_batch(const fmx_index *idx, const int32_t *from, int32_
 
 /* ---- batched queries: device-resident buffers, asynchronous on `stream` (a hipStream_t) ----
  * Same semantics; every pointer is device memory on the index's device.  Nothing is synchronised:
- * the caller orders work through the stream (this is what bench.py times with HIP events). */
+ * the caller orders work through the stream (this is what bench.py times with HIP events).
+ * Threading: the index is immutable once resident (the reference's FmIndex is @ThreadSafe, FM:82).  The host-buffer
+ * entry points above may be called from any number of threads on one index at once (per-call device scratch).
+ * The device-pointer entry points keep grow-only scratch per (index, stream): use one stream per thread. */
 int fmx_count_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
                         int32_t *d_counts, int32_t *d_lf_steps, int32_t *d_status, void *stream);
 /* The two stages of fmx_count_batch_dev, callable separately (bench.py times the second one alone):
- * plan = processing order of the batch (device bucket sort on the patterns' trailing characters, so
- * that neighbouring lanes walk the same SA intervals); *d_perm points into per-stream scratch owned by
- * the index (valid until the next plan on that stream, and only for the same d_pat / d_pat_off contents: the
- * plan also keeps the mapped codes of each pattern's last characters for the kernel) or is NULL for small batches.
- * ordered = the k_count kernel over that order; results are written at the ORIGINAL pattern index. */
+ * plan = processing order of the batch (device bucket pass on the patterns' trailing characters, so that
+ * neighbouring lanes walk the same SA intervals) + the mapped codes of each pattern's last characters; *d_plan is
+ * an opaque handle into per-stream scratch owned by the index, or NULL for small batches.  It stays valid until
+ * ANYTHING else plans on that stream (every count / locate / segment / pipeline call does) and only for the same
+ * d_pat / d_pat_off contents.  ordered = the k_count kernel over that order; a handle that is no longer the
+ * stream's live plan is ignored (the batch is then processed in the caller's order: same results).  Results are
+ * written at the ORIGINAL pattern index. */
 int fmx_count_plan_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
-                       const uint32_t **d_perm, void *stream);
-int fmx_count_ordered_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, const uint32_t *d_perm,
+                       const void **d_plan, void *stream);
+int fmx_count_ordered_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, const void *d_plan,
                           int32_t n, int32_t *d_counts, int32_t *d_lf_steps, int32_t *d_status, void *stream);
 int fmx_locate_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
                          int32_t max_matches, int32_t *d_locs, int32_t loc_cap, int32_t *d_found,

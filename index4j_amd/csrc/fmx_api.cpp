@@ -5,6 +5,7 @@
 #include "fmx_device.hpp"
 #include "fmx_build_stage.hpp"
 #include "fmx_model.hpp"
+#include "fmx_plan.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -19,9 +20,9 @@
 #include <vector>
 
 namespace fmx {
-int launch_count_plan(const DevIndex &, const uint16_t *, const int32_t *, int32_t, void *, size_t, const uint32_t **, const void **,
+int launch_count_plan(const DevIndex &, const uint16_t *, const int32_t *, int32_t, void *, size_t, bool, CountPlan *,
                       hipStream_t);
-int launch_count(const DevIndex &, int, const uint16_t *, const int32_t *, const uint32_t *, const void *, int32_t, int32_t *,
+int launch_count(const DevIndex &, int, const uint16_t *, const int32_t *, const CountPlan *, bool, int32_t, int32_t *,
                  int32_t *, int32_t *, int32_t *, hipStream_t);
 size_t count_workspace_bytes(const DevIndex &, int32_t n);
 int launch_locate_walk(const DevIndex &, int, const int32_t *, int32_t, int32_t, int32_t *, int32_t, int32_t *,
@@ -60,14 +61,12 @@ struct fmx_index {
     // kind 0 = plan stage (order + code words), kind 1 = extractUntilBoundary windows
     mutable std::mutex ws_mutex;
     mutable std::map<std::pair<void *, int>, std::pair<void *, size_t>> ws;
-    struct Plan {  // the last fmx_count_plan_dev result per stream: order + per-pattern code words
-        const uint32_t *perm = nullptr;
-        const void *codes = nullptr;
+    struct Plan {  // the last fmx_count_plan_dev result per stream: the batch's records in processing order
+        fmx::CountPlan plan;
         const uint16_t *pat = nullptr;
-        int32_t n = 0;
     };
-    // erased whenever anything else plans on the stream or its plan scratch moves: a stale perm then simply
-    // carries no code words (k_count maps the characters itself) instead of reading another batch's
+    // erased whenever anything else plans on the stream or its plan scratch moves: a stale handle then simply
+    // means "the caller's order" (k_count maps the characters itself) instead of reading another batch's records
     mutable std::map<void *, Plan> plans;
 };
 
@@ -199,6 +198,7 @@ int get_workspace(const fmx_index *idx, void *stream, int kind, size_t bytes, vo
     std::lock_guard<std::mutex> lock(idx->ws_mutex);
     auto &slot = idx->ws[{stream, kind}];
     if (slot.second < bytes) {
+        if (kind == kWsPlan && bytes < fmx::kPlanHeadBytes) bytes = fmx::kPlanHeadBytes;
         if (slot.first) {
             HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
             (void)hipFree(slot.first);
@@ -207,6 +207,8 @@ int get_workspace(const fmx_index *idx, void *stream, int kind, size_t bytes, vo
         }
         void *p = nullptr;
         HIP_TRY(hipMalloc(&p, bytes));
+        // the plan kernels expect the head of their workspace zeroed and leave it zeroed (fmx_plan.hpp)
+        if (kind == kWsPlan) HIP_TRY(hipMemsetAsync(p, 0, fmx::kPlanHeadBytes, static_cast<hipStream_t>(stream)));
         slot = {p, bytes};
     }
     *out = slot.first;
@@ -485,9 +487,8 @@ void *fmx_device_blob(const fmx_index *idx, size_t *len) {
 // stage 1 of count/locate: processing order of the batch (suffix-key radix sort) — nullptr when the
 // batch is too small to be worth sorting
 static int plan_order(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n, Scratch &scratch,
-                      const uint32_t **perm, const void **codes) {
-    *perm = nullptr;
-    *codes = nullptr;
+                      fmx::CountPlan *plan) {
+    *plan = fmx::CountPlan();
     if (!scratch.per_call) {  // whatever fmx_count_plan_dev left for this stream is about to be overwritten
         std::lock_guard<std::mutex> lock(idx->ws_mutex);
         idx->plans.erase(scratch.stream);
@@ -497,44 +498,44 @@ static int plan_order(const fmx_index *idx, const uint16_t *d_pat, const int32_t
     int rc = scratch.get(kWsPlan, ws_bytes, &ws);
     if (rc) return rc;
     if (!ws) return FMX_OK;
-    int e = fmx::launch_count_plan(idx->dev, d_pat, d_pat_off, n, ws, ws_bytes, perm, codes,
+    // a per-stream workspace keeps its head zeroed between plans; a per-call block comes from the cache: clear it
+    int e = fmx::launch_count_plan(idx->dev, d_pat, d_pat_off, n, ws, ws_bytes, !scratch.per_call, plan,
                                    static_cast<hipStream_t>(scratch.stream));
-    if (e) return fail(FMX_E_HIP, std::string("pattern sort: ") + hipGetErrorString((hipError_t)e));
+    if (e) return fail(FMX_E_HIP, std::string("plan stage: ") + hipGetErrorString((hipError_t)e));
     return FMX_OK;
 }
 
 int fmx_count_plan_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
-                       const uint32_t **d_perm, void *stream) {
+                       const void **d_plan, void *stream) {
     int rc = require_device(idx);
     if (rc) return rc;
-    if (n < 0 || !d_perm || (n > 0 && !d_pat_off)) return fail(FMX_E_ARG, "bad arguments");
+    if (n < 0 || !d_plan || (n > 0 && !d_pat_off)) return fail(FMX_E_ARG, "bad arguments");
     fmx_index::Plan plan;
     Scratch scratch(idx, stream, false);
-    rc = plan_order(idx, d_pat, d_pat_off, n, scratch, &plan.perm, &plan.codes);
+    rc = plan_order(idx, d_pat, d_pat_off, n, scratch, &plan.plan);
     if (rc) return rc;
     plan.pat = d_pat;
-    plan.n = n;
     {
         std::lock_guard<std::mutex> lock(idx->ws_mutex);
         idx->plans[stream] = plan;
     }
-    *d_perm = plan.perm;
+    *d_plan = plan.plan.recs;
     return FMX_OK;
 }
 
-int fmx_count_ordered_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, const uint32_t *d_perm,
+int fmx_count_ordered_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, const void *d_plan,
                           int32_t n, int32_t *d_counts, int32_t *d_lf_steps, int32_t *d_status, void *stream) {
     int rc = require_device(idx);
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!d_pat_off || !d_counts))) return fail(FMX_E_ARG, "bad arguments");
-    const void *codes = nullptr;  // only the order's own plan carries code words for these patterns
-    if (d_perm) {
+    fmx::CountPlan plan;  // only the stream's live plan for these very patterns is honoured; anything else
+    if (d_plan) {         // (stale, foreign) means the caller's order
         std::lock_guard<std::mutex> lock(idx->ws_mutex);
         auto it = idx->plans.find(stream);
-        if (it != idx->plans.end() && it->second.perm == d_perm && it->second.n == n && it->second.pat == d_pat)
-            codes = it->second.codes;
+        if (it != idx->plans.end() && it->second.plan.recs == d_plan && it->second.plan.n == n && it->second.pat == d_pat)
+            plan = it->second.plan;
     }
-    int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, d_perm, codes, n, d_counts, d_lf_steps, d_status,
+    int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, &plan, false, n, d_counts, d_lf_steps, d_status,
                               nullptr, static_cast<hipStream_t>(stream));
     if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
     return FMX_OK;
@@ -545,11 +546,10 @@ static int count_impl(const fmx_index *idx, const uint16_t *d_pat, const int32_t
     int rc = require_device(idx);
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!d_pat_off || !d_counts))) return fail(FMX_E_ARG, "bad arguments");
-    const uint32_t *perm = nullptr;
-    const void *codes = nullptr;
-    rc = plan_order(idx, d_pat, d_pat_off, n, scratch, &perm, &codes);
+    fmx::CountPlan plan;
+    rc = plan_order(idx, d_pat, d_pat_off, n, scratch, &plan);
     if (rc) return rc;
-    int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, perm, codes, n, d_counts, d_lf_steps, d_status,
+    int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, &plan, false, n, d_counts, d_lf_steps, d_status,
                               nullptr, static_cast<hipStream_t>(scratch.stream));
     if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
     return FMX_OK;
@@ -570,11 +570,10 @@ static int locate_impl(const fmx_index *idx, const uint16_t *d_pat, const int32_
         return fail(FMX_E_ARG, "bad arguments");
     hipStream_t st = static_cast<hipStream_t>(scratch.stream);
     // found[] doubles as the scratch `counts` output of the range pass; the walk pass overwrites it
-    const uint32_t *perm = nullptr;
-    const void *codes = nullptr;
-    rc = plan_order(idx, d_pat, d_pat_off, n, scratch, &perm, &codes);
+    fmx::CountPlan plan;
+    rc = plan_order(idx, d_pat, d_pat_off, n, scratch, &plan);
     if (rc) return rc;
-    int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, perm, codes, n, d_found, d_lf_steps, d_status,
+    int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, &plan, false, n, d_found, d_lf_steps, d_status,
                               d_range_ws, st);
     if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
     e = fmx::launch_locate_walk(idx->dev, idx->n_cu, d_range_ws, n, max_matches, d_locs, loc_cap, d_found, d_lf_steps,
@@ -712,16 +711,15 @@ static int count_segments_impl(const fmx_index *const *segs, int32_t n_segs, con
     if (n == 0) return FMX_OK;
     hipStream_t st = static_cast<hipStream_t>(scratch.stream);
     // one processing order for all segments: any grouping is valid, and equal characters get equal codes in
-    // every segment's alphabet, so the order derived from the first segment groups the batch for all of them
-    // (the plan's code words are in the first segment's alphabet, so only that segment uses them)
-    const uint32_t *perm = nullptr;
-    const void *codes = nullptr;
-    int rc = plan_order(segs[0], d_pat, d_pat_off, n, scratch, &perm, &codes);
+    // every segment's alphabet, so the order derived from the first segment groups the batch for all of them.
+    // The plan's code words are in the first segment's alphabet; the other segments translate them in LDS
+    // (code -> character -> their own code), or map the characters themselves when codes are 16 bits wide.
+    fmx::CountPlan plan;
+    int rc = plan_order(segs[0], d_pat, d_pat_off, n, scratch, &plan);
     if (rc) return rc;
     int32_t *cnt = d_tmp, *lf = d_tmp + n, *sts = d_tmp + 2 * (size_t)n;
     for (int32_t s = 0; s < n_segs; ++s) {
-        int e = fmx::launch_count(segs[s]->dev, segs[s]->n_cu, d_pat, d_pat_off, perm, s == 0 ? codes : nullptr, n, cnt, lf,
-                                  sts, nullptr, st);
+        int e = fmx::launch_count(segs[s]->dev, segs[s]->n_cu, d_pat, d_pat_off, &plan, s != 0, n, cnt, lf, sts, nullptr, st);
         if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
         e = fmx::launch_segment_add_counts(d_counts, d_lf_steps, d_status, cnt, lf, sts, n, s == 0, st);
         if (e) return fail(FMX_E_HIP, std::string("k_segment_add_counts launch: ") + hipGetErrorString((hipError_t)e));
@@ -747,13 +745,12 @@ static int locate_segments_impl(const fmx_index *const *segs, int32_t n_segs, co
     if (n == 0) return FMX_OK;
     hipStream_t st = static_cast<hipStream_t>(scratch.stream);
     int32_t *seg_found = d_tmp, *seg_status = d_tmp + n, *range = d_tmp + 2 * (size_t)n, *seg_locs = d_tmp + 4 * (size_t)n;
-    const uint32_t *perm = nullptr;
-    const void *codes = nullptr;
-    int rc = plan_order(segs[0], d_pat, d_pat_off, n, scratch, &perm, &codes);
+    fmx::CountPlan plan;
+    int rc = plan_order(segs[0], d_pat, d_pat_off, n, scratch, &plan);
     if (rc) return rc;
     for (int32_t s = 0; s < n_segs; ++s) {
-        int e = fmx::launch_count(segs[s]->dev, segs[s]->n_cu, d_pat, d_pat_off, perm, s == 0 ? codes : nullptr, n,
-                                  seg_found, nullptr, seg_status, range, st);
+        int e = fmx::launch_count(segs[s]->dev, segs[s]->n_cu, d_pat, d_pat_off, &plan, s != 0, n, seg_found, nullptr,
+                                  seg_status, range, st);
         if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
         // like the caller's loop `n += seg.locate(p, 0, len, locations, maxMatches - n)`: hits already
         // taken from earlier segments shrink this segment's limit

@@ -603,7 +603,8 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
     // The reference's own route (codes longer than 16 bits, clamped mapping entries): block header, leaf entry,
     // clamped-mapping fix-up, code rebuilt from the level table, walk over the level table and cumulative counts.
     int32_t block_c = (int32_t)(mq.x >> 8);
-    const Quad bhq = ld_quad(bhs + block_id);  // WFBB:1113
+    Quad bhq = ld_quad(bhs + block_id);  // WFBB:1113
+    FMX_PIN_QUAD(bhq);
     const BlockHdr bh = block_hdr_from(bhq);
     const int32_t tree_height = bh.tree_height;
     const uint8_t *hdr = var + bh.var_off;

@@ -17,9 +17,9 @@
 #include <cstring>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/block/block_radix_sort.hpp>
 
 #include "fmx_device.hpp"
+#include "fmx_plan.hpp"
 
 namespace fmx {
 
@@ -82,34 +82,152 @@ __device__ __forceinline__ const Quad *stage_sb_cache(Quad *s_sb, const DevIndex
     DevIndex LOCAL_IX = GLOBAL_IX;                  \
     LOCAL_IX.sb_cache = stage_sb_cache(s_sb, GLOBAL_IX)
 
-template <int kBlock>
+constexpr int kTileThreads = 512;
+constexpr int kTileItems = 8;                       // patterns per thread
+constexpr int kTile = kTileThreads * kTileItems;    // 4,096 patterns per workgroup
+constexpr int kCoarseBitsMax = 14;                  // 16,384 LDS bins (64 KiB)
+
+// The (up to) 8 trailing characters of a pattern.  Patterns of >= 8 characters: the 16 bytes [beg + m - 8, beg + m) are
+// fetched as four or five ALIGNED dwords (every dword holds at least one byte of the pattern, so nothing outside
+// the caller's pages is touched) instead of eight 2-byte loads.  Split in load / decode so that a thread can have
+// the loads of several patterns in flight.
+struct TailWords {
+    uint32_t d0, d1, d2, d3, d4;
+    bool odd;
+};
+__device__ __forceinline__ TailWords pattern_tail_load(const uint16_t *pat, int32_t beg, int32_t m) {
+    TailWords t = {0, 0, 0, 0, 0, false};
+    if (m >= 8) {
+        // (pointer arithmetic on `pat`, not on an integer: the loads stay global_load instead of flat_load)
+        const int32_t first = beg + m - 8;
+        t.odd = (((uint32_t)(reinterpret_cast<uintptr_t>(pat) >> 1) + (uint32_t)first) & 1u) != 0;
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(pat + first - (t.odd ? 1 : 0));
+        t.d0 = w[0];
+        t.d1 = w[1];
+        t.d2 = w[2];
+        t.d3 = w[3];
+        if (t.odd) t.d4 = w[4];  // starts in the upper half of d0: the eighth character is the lower half of a fifth dword
+    }
+    return t;
+}
+// ch[0] = the LAST character
+__device__ __forceinline__ void pattern_tail_chars(TailWords t, const uint16_t *pat, int32_t beg, int32_t m,
+                                                   uint32_t ch[8]) {
+    if (m >= 8) {
+        FMX_OPAQUE32(t.d0);  // (keeps the compiler from turning the dwords back into eight 2-byte loads)
+        FMX_OPAQUE32(t.d1);
+        FMX_OPAQUE32(t.d2);
+        FMX_OPAQUE32(t.d3);
+        FMX_OPAQUE32(t.d4);
+        if (t.odd) {
+            t.d0 = (t.d0 >> 16) | (t.d1 << 16);
+            t.d1 = (t.d1 >> 16) | (t.d2 << 16);
+            t.d2 = (t.d2 >> 16) | (t.d3 << 16);
+            t.d3 = (t.d3 >> 16) | (t.d4 << 16);
+        }
+        ch[7] = t.d0 & 0xffffu;
+        ch[6] = t.d0 >> 16;
+        ch[5] = t.d1 & 0xffffu;
+        ch[4] = t.d1 >> 16;
+        ch[3] = t.d2 & 0xffffu;
+        ch[2] = t.d2 >> 16;
+        ch[1] = t.d3 & 0xffffu;
+        ch[0] = t.d3 >> 16;
+    } else {
+        for (int j = 0; j < 8; ++j) ch[j] = j < m ? (uint32_t)pat[beg + m - 1 - j] : 0u;
+    }
+}
+// the plan's code word of a pattern: codes of its trailing characters, the LAST character in the low bits
+// (s_map = LDS copy of the first 256 entries of the character map)
+template <int kCodeBits>
+__device__ __forceinline__ uint64_t pattern_code_word(const DevIndex &ix, const int16_t *s_map, const uint32_t ch[8],
+                                                      int32_t m) {
+    constexpr int n_codes = 64 / kCodeBits;
+    uint64_t w = 0;
+#pragma unroll
+    for (int j = 0; j < n_codes; ++j)
+        if (j < m) {
+            const int32_t c = ch[j] < 256u ? (int32_t)s_map[ch[j]] : fm_map(ix, (uint16_t)ch[j]);
+            w |= (uint64_t)(uint32_t)c << (j * kCodeBits);
+        }
+    return w;
+}
+// sort key = the first `chars` codes of the word, the last character most significant
+__device__ __forceinline__ uint32_t suffix_key(uint64_t word, int code_bits, int chars, int bits) {
+    const uint32_t mask = (1u << code_bits) - 1u;
+    uint32_t key = 0;
+    for (int j = 0; j < chars; ++j) key = (key << bits) | ((uint32_t)(word >> (j * code_bits)) & mask);
+    return key;
+}
+
+// One record per pattern.  k_plan_codes writes it at the pattern's index with {code word, sort key, length | fine
+// bin}; k_plan_fine writes the final order, where the second dword pair is {pattern index, length}.
+struct PlanRec {
+    uint64_t cw;   // codes of the trailing characters, the LAST character in the low bits
+    uint32_t a;    // k_plan_codes: suffix key (first characters of the code word, last character most significant);
+                   // final order: index of the pattern in the caller's batch
+    uint32_t m;    // the pattern's length in bits 0..21 (kPlanLongPattern: longer — read it from the offsets); from
+                   // k_plan_codes also, in bits 22..31, the bin k_plan_fine ranks a window by: the key bits around the
+                   // lower end of the coarse bits (two coarse bits, so that neighbouring buckets stay apart, + 8 below)
+};
+static_assert(sizeof(PlanRec) == 16, "PlanRec");
+constexpr uint32_t kPlanLongPattern = 0x3fffffu;
+constexpr int kFineBits = 10;  // width of the window-local order of k_plan_fine (counting sort in LDS)
+
+// recs (nullable): the plan — the batch's records in processing order; lane pair q takes record q (one coalesced
+// 16-byte load, no gather).  plan_look_up (mode 2): code of the plan's alphabet -> character, to translate code
+// words made with ANOTHER index of a segment set (0 = character absent there).
+// kMode: 0 = no plan (the caller's order, characters mapped here), 1 = plan made with this index, 2 = plan made with
+// another index of a segment set (code words translated), 3 = such a plan with 16-bit codes (order only)
+template <int kBlock, int kMode>
 FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__ pat,
                                                   const int32_t *__restrict__ pat_off,
-                                                  const uint32_t *__restrict__ perm, int32_t n,
+                                                  const PlanRec *__restrict__ recs, int32_t n,
                                                   int32_t *__restrict__ counts, int32_t *__restrict__ lf_steps,
                                                   int32_t *__restrict__ status_out, int32_t *__restrict__ range_out,
-                                                  const uint64_t *__restrict__ codes) {
+                                                  int code_bits, const int32_t *__restrict__ plan_look_up,
+                                                  int32_t plan_sigma) {
     const uint16_t *s_inv = nullptr;  // no RRR vector on this kernel's path (the wavelet tree's are expanded)
     FMX_WITH_SB_CACHE(ix_global, ix);
+    constexpr int kPairs = kBlock / 2;
+    __shared__ int16_t s_xlat[256];
+    constexpr bool planned = kMode != 0;
+    constexpr bool translate = kMode == 2;  // only offered for 8-bit code words (plan_sigma <= 256)
+    if (translate) {
+        for (int c = threadIdx.x; c < 256; c += kBlock)
+            s_xlat[c] = (c > 0 && c < plan_sigma) ? (int16_t)fm_map(ix, (uint16_t)plan_look_up[c]) : (int16_t)0;
+        __syncthreads();
+    }
     const int role = threadIdx.x & 1;
-    const int code_bits = plan_code_bits(ix.wt_sigma), n_codes = codes ? 64 / code_bits : 0;
+    const int n_codes = (kMode == 1 || kMode == 2) ? 64 / code_bits : 0;
     const uint32_t code_mask = (1u << code_bits) - 1u;
-    const int32_t pairs_per_grid = (int32_t)gridDim.x * (kBlock / 2);  // 32-bit indices: n < 2^31, fewer live registers
+    const int32_t pairs_per_grid = (int32_t)gridDim.x * kPairs;  // 32-bit indices: n < 2^31, fewer live registers
     // (an XCD-aware block order — a contiguous eighth of the sorted batch per XCD — was measured slower:
     // profiles/r01_i_xcd_remap.txt)
-    for (int32_t q = (int32_t)blockIdx.x * (kBlock / 2) + (int32_t)(threadIdx.x >> 1); q < n; q += pairs_per_grid) {
-        const int32_t p = perm ? (int32_t)perm[q] : q;
-        const int32_t m = pat_off[p + 1] - pat_off[p];
+    for (int32_t q = (int32_t)blockIdx.x * kPairs + (int32_t)(threadIdx.x >> 1); q < n; q += pairs_per_grid) {
+        int32_t p = q, m;
+        uint64_t cw = 0ull;
+        if (planned) {
+            Quad rq = ld_quad(recs + q);
+            FMX_PIN_QUAD(rq);
+            cw = (uint64_t)rq.x | ((uint64_t)rq.y << 32);
+            p = (int32_t)rq.z;
+            m = (int32_t)(rq.w & kPlanLongPattern);
+            if (m == (int32_t)kPlanLongPattern) m = pat_off[p + 1] - pat_off[p];
+        } else {
+            m = pat_off[p + 1] - pat_off[p];
+        }
         int status = ST_OK;
         int32_t start = 0, end = 0;
         int32_t back = 0;  // characters consumed so far, counted from the pattern's end (FM:456: i = m - 1 - back)
         if (m <= 0) {
             status = ST_JAVA_AIOOBE;  // pattern[-1], FM:456-457
         } else {
-            // the plan stage left the codes of the trailing characters (one 8-byte load per pattern instead of a
-            // character load and a map lookup in front of every rank)
-            const uint64_t cw = codes ? codes[p] : 0ull;
-            int32_t c = codes ? (int32_t)((uint32_t)cw & code_mask) : fm_map(ix, pat[pat_off[p] + m - 1]);
+            // the plan stage left the codes of the trailing characters (no character load and map lookup in front of
+            // every rank)
+            int32_t c = n_codes ? (int32_t)((uint32_t)cw & code_mask) : fm_map(ix, pat[pat_off[p] + m - 1]);
+            // a foreign code of 0 only says "not in the plan's alphabet": the character itself decides here
+            if (translate) c = c ? s_xlat[c] : fm_map(ix, pat[pat_off[p] + m - 1]);
             if (c != 0) {  // FM:458-460
                 start = ix.C[c];
                 end = ix.C[c + 1];
@@ -117,6 +235,7 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
                     ++back;
                     if (back < n_codes) {
                         c = (int32_t)((uint32_t)(cw >> (back * code_bits)) & code_mask);
+                        if (translate) c = c ? s_xlat[c] : fm_map(ix, pat[pat_off[p] + m - 1 - back]);
                     } else {
                         c = fm_map(ix, pat[pat_off[p] + m - 1 - back]);
                     }
@@ -359,66 +478,72 @@ FMX_KERNEL(kBlock) void k_rrr_access(DevIndex ix, const int32_t *__restrict__ po
     }
 }
 
-// ---- processing order of a batch -------------------------------------------------------------------
+// ---- processing order of a batch (the plan stage) -----------------------------------------------------
 // Patterns are processed in (approximate) order of their trailing characters, the LAST character most
 // significant (it is consumed first, FM:456-457): lanes of a wave then start their backward search in the
 // same SA intervals.  Any grouping works — results are written at the original index — so instead of a
 // general device sort (rocPRIM falls back to a 21-launch merge sort at 1 M keys) the order is built by
-//   1. a coarse bucket pass on the top <=14 key bits: per-workgroup LDS histograms, ONE global atomic per
-//      (workgroup, non-empty bin) — no hot-bin serialisation — then a single-workgroup scan and a scatter
-//      whose slots come from LDS cursors;
-//   2. a tile-local LDS radix sort (4,096 patterns per workgroup) on the full key, which restores the fine
-//      order where it matters: inside a wave / a CU.
-constexpr int kTileThreads = 512;
-constexpr int kTileItems = 8;                       // patterns per thread
-constexpr int kTile = kTileThreads * kTileItems;    // 4,096 patterns per workgroup
-constexpr int kCoarseBitsMax = 14;                  // 16,384 LDS bins (64 KiB)
+//   1. k_plan_codes: one pass over the patterns — the 16 bytes of a pattern's tail as aligned dwords, characters
+//      mapped through an LDS copy of the map's first 256 entries — leaving a record {code word, key, length, fine
+//      bin} per pattern, its coarse key (the top <= 13 key bits), and a histogram of the coarse keys: per-workgroup
+//      LDS histograms, ONE global atomic per (workgroup, non-empty bin), no hot-bin serialisation;
+//   2. k_plan_scatter: every workgroup scans the histogram itself (no scan kernel), reserves its share of each
+//      bin with one atomic and writes the pattern indices in bucket order; the last workgroup to finish zeroes
+//      the histogram and the cursors for the next plan on this stream (no memset launch);
+//   3. the fine order where it matters — which 32 patterns share a wave — is made inside k_count: a counting
+//      sort of each workgroup's 256 records on 10 key bits, in LDS.
+// Two short kernels (round 1: memset + four kernels with a tile-local radix sort, 76 us at 1 M patterns).
 
-struct SortShape {
-    int bits;         // bits per alphabet code
-    int chars;        // trailing characters in the full key
-    int total_bits;   // chars * bits (<= 32)
-    int coarse_bits;  // top bits used by the bucket pass
-};
-
-// the plan's code word of a pattern: codes of its trailing characters, the LAST character in the low bits
-__device__ __forceinline__ uint64_t pattern_code_word(const DevIndex &ix, const uint16_t *pat, int32_t beg, int32_t m,
-                                                      int code_bits) {
-    const int n_codes = 64 / code_bits;
-    uint64_t w = 0;
-    for (int j = 0; j < n_codes && j < m; ++j) w |= (uint64_t)(uint32_t)fm_map(ix, pat[beg + m - 1 - j]) << (j * code_bits);
-    return w;
-}
-// sort key = the first `chars` codes of the word, the last character most significant
-__device__ __forceinline__ uint32_t suffix_key(uint64_t word, int code_bits, int chars, int bits) {
-    const uint32_t mask = (1u << code_bits) - 1u;
-    uint32_t key = 0;
-    for (int j = 0; j < chars; ++j) key = (key << bits) | ((uint32_t)(word >> (j * code_bits)) & mask);
-    return key;
-}
-
-// pass 1a: coarse keys + global histogram (LDS-privatised)
-__global__ __launch_bounds__(kTileThreads) void k_order_hist(DevIndex ix, const uint16_t *__restrict__ pat,
+// pass 1: records, coarse keys, global histogram
+template <int kCodeBits>
+__global__ __launch_bounds__(kTileThreads) void k_plan_codes(DevIndex ix, const uint16_t *__restrict__ pat,
                                                              const int32_t *__restrict__ pat_off, int32_t n,
-                                                             SortShape sh, uint32_t *__restrict__ coarse,
-                                                             uint32_t *__restrict__ ghist,
-                                                             uint64_t *__restrict__ codes) {
+                                                             SortShape sh, PlanRec *__restrict__ recs,
+                                                             uint32_t *__restrict__ ghist) {
     extern __shared__ uint32_t s_hist[];
-    const int code_bits = plan_code_bits(ix.wt_sigma);
+    __shared__ int16_t s_map[256];
     const int bins = 1 << sh.coarse_bits;
     for (int i = threadIdx.x; i < bins; i += kTileThreads) s_hist[i] = 0;
+    for (int i = threadIdx.x; i < 256; i += kTileThreads) s_map[i] = ix.char2code[i];
     __syncthreads();
+    // the fine bin of a record: kFineBits key bits ending 8 bits below the coarse bits (or at the key's end)
+    const int below = sh.total_bits - sh.coarse_bits;
+    const int fine_shift = below > 8 ? below - 8 : 0;
     const int64_t base = (int64_t)blockIdx.x * kTile;
-    for (int k = 0; k < kTileItems; ++k) {
-        const int64_t p = base + (int64_t)k * kTileThreads + threadIdx.x;
-        if (p < n) {
-            const int32_t beg = pat_off[p];
-            const uint64_t word = pattern_code_word(ix, pat, beg, pat_off[p + 1] - beg, code_bits);
-            codes[p] = word;  // kept for the tile sort and for k_count
-            const uint32_t key = suffix_key(word, code_bits, sh.chars, sh.bits);
-            uint32_t c = key >> (sh.total_bits - sh.coarse_bits);
+    constexpr int kGroup = 4;  // patterns whose loads a thread keeps in flight together
+    for (int k0 = 0; k0 < kTileItems; k0 += kGroup) {
+        int32_t beg[kGroup], len[kGroup];
+        TailWords tail[kGroup];
+#pragma unroll
+        for (int k = 0; k < kGroup; ++k) {
+            const int64_t p = base + (int64_t)(k0 + k) * kTileThreads + threadIdx.x;
+            beg[k] = 0;
+            len[k] = -1;
+            if (p < n) {
+                beg[k] = pat_off[p];
+                len[k] = pat_off[p + 1] - beg[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kGroup; ++k) tail[k] = pattern_tail_load(pat, beg[k], len[k]);
+#pragma unroll
+        for (int k = 0; k < kGroup; ++k) {
+            const int64_t p = base + (int64_t)(k0 + k) * kTileThreads + threadIdx.x;
+            if (p >= n) continue;
+            const int32_t m = len[k];
+            uint32_t ch[8];
+            pattern_tail_chars(tail[k], pat, beg[k], m, ch);
+            const uint64_t word = pattern_code_word<kCodeBits>(ix, s_map, ch, m);
+            const uint32_t key = suffix_key(word, kCodeBits, sh.chars, sh.bits);
+            const uint32_t lenf = m < 0 ? 0u : ((uint32_t)m < kPlanLongPattern ? (uint32_t)m : kPlanLongPattern);
+            Quad q;
+            q.x = (uint32_t)word;
+            q.y = (uint32_t)(word >> 32);
+            q.z = key;
+            q.w = lenf | (((key >> fine_shift) & ((1u << kFineBits) - 1u)) << 22);  // (PlanRec.a / .m)
+            *reinterpret_cast<Quad *>(recs + p) = q;
+            uint32_t c = key >> below;
             if (c >= (uint32_t)bins) c = (uint32_t)bins - 1u;  // cannot happen for a validated index (codes < 2^bits)
-            coarse[p] = c;
             atomicAdd(&s_hist[c], 1u);
         }
     }
@@ -429,103 +554,154 @@ __global__ __launch_bounds__(kTileThreads) void k_order_hist(DevIndex ix, const 
     }
 }
 
-// pass 1b: exclusive scan of <= 16,384 bins by one workgroup (in place): coalesced load into LDS, per-thread
-// chunks, Hillis-Steele over the 1,024 partial sums, coalesced store
-constexpr int kScanThreads = 1024;
-__global__ __launch_bounds__(kScanThreads) void k_order_scan(uint32_t *__restrict__ ghist, int bins) {
-    __shared__ uint32_t s_val[(1 << kCoarseBitsMax) + 64];
-    __shared__ uint32_t s_part[kScanThreads];
-    for (int i = threadIdx.x; i < bins; i += kScanThreads) s_val[i + (i >> 8)] = ghist[i];  // +1 pad per 256: no 16-way conflicts
+// pass 2: records into bucket order (16-byte scattered writes; gathering them later instead costs a 64-byte line
+// through the fabric per record).  ghist = the batch's histogram, cursor = running fill of each bin (zero at entry),
+// ticket = workgroups done (zero at entry); all three are zero again when the kernel has finished.
+__global__ __launch_bounds__(kTileThreads) void k_plan_scatter(const PlanRec *__restrict__ recs_in, int32_t n, int bins,
+                                                               int below, uint32_t *__restrict__ ghist,
+                                                               uint32_t *__restrict__ cursor,
+                                                               uint32_t *__restrict__ ticket,
+                                                               PlanRec *__restrict__ recs_out) {
+    extern __shared__ uint32_t s_mem[];  // [bins] exclusive scan of ghist, [bins] this workgroup's counts / slots
+    __shared__ uint32_t s_wave[kTileThreads / 64];
+    __shared__ uint32_t s_last;
+    uint32_t *s_scan = s_mem, *s_cnt = s_mem + bins;
+    // this workgroup's items per bin (the loads of the scan below overlap these)
+    for (int i = threadIdx.x; i < bins; i += kTileThreads) s_cnt[i] = 0;
     __syncthreads();
-    const int per = (bins + kScanThreads - 1) / kScanThreads;
-    const int lo = threadIdx.x * per;
+    const int64_t base = (int64_t)blockIdx.x * kTile;
+    Quad mine[kTileItems];
+    uint32_t bin[kTileItems];
+#pragma unroll
+    for (int k = 0; k < kTileItems; ++k) {
+        const int64_t p = base + (int64_t)k * kTileThreads + threadIdx.x;
+        bin[k] = 0xffffffffu;
+        if (p < n) {
+            mine[k] = ld_quad(recs_in + p);
+            uint32_t c = mine[k].z >> below;  // PlanRec.a = the key
+            if (c >= (uint32_t)bins) c = (uint32_t)bins - 1u;
+            bin[k] = c;
+            mine[k].z = (uint32_t)p;  // from here on PlanRec.a = the pattern's index
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kTileItems; ++k)
+        if (bin[k] != 0xffffffffu) atomicAdd(&s_cnt[bin[k]], 1u);
+    // exclusive scan of the histogram: per-thread chunks of consecutive bins, wave scan, wave totals through LDS
+    const int per = (bins + kTileThreads - 1) / kTileThreads;
+    const int lo = (int)threadIdx.x * per;
     uint32_t sum = 0;
-    for (int i = lo; i < lo + per && i < bins; ++i) sum += s_val[i + (i >> 8)];
-    s_part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int d = 1; d < kScanThreads; d <<= 1) {
-        const uint32_t v = (threadIdx.x >= (unsigned)d) ? s_part[threadIdx.x - d] : 0u;
-        __syncthreads();
-        s_part[threadIdx.x] += v;
-        __syncthreads();
+    for (int i = lo; i < lo + per && i < bins; ++i) sum += ghist[i];
+    uint32_t incl = sum;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
     }
-    uint32_t run = s_part[threadIdx.x] - sum;
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < wave; ++w) before += s_wave[w];
+    uint32_t run = before + incl - sum;
     for (int i = lo; i < lo + per && i < bins; ++i) {
-        const uint32_t v = s_val[i + (i >> 8)];
-        s_val[i + (i >> 8)] = run;
-        run += v;
+        s_scan[i] = run;
+        run += ghist[i];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < bins; i += kScanThreads) ghist[i] = s_val[i + (i >> 8)];
-}
-
-// pass 1c: scatter into bucket order; each workgroup reserves its share of a bin with one atomic
-__global__ __launch_bounds__(kTileThreads) void k_order_scatter(const uint32_t *__restrict__ coarse, int32_t n,
-                                                                SortShape sh, uint32_t *__restrict__ cursor,
-                                                                uint32_t *__restrict__ perm) {
-    extern __shared__ uint32_t s_hist[];
-    const int bins = 1 << sh.coarse_bits;
-    for (int i = threadIdx.x; i < bins; i += kTileThreads) s_hist[i] = 0;
-    __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * kTile;
-    uint32_t mine[kTileItems];
-    for (int k = 0; k < kTileItems; ++k) {
-        const int64_t p = base + (int64_t)k * kTileThreads + threadIdx.x;
-        mine[k] = (p < n) ? coarse[p] : 0xffffffffu;
-        if (p < n) atomicAdd(&s_hist[mine[k]], 1u);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < bins; i += kTileThreads) {
-        const uint32_t v = s_hist[i];
-        if (v) s_hist[i] = atomicAdd(&cursor[i], v);  // first slot of this workgroup's share
-    }
-    __syncthreads();
-    for (int k = 0; k < kTileItems; ++k) {
-        const int64_t p = base + (int64_t)k * kTileThreads + threadIdx.x;
-        if (p < n) perm[atomicAdd(&s_hist[mine[k]], 1u)] = (uint32_t)p;
-    }
-}
-
-// pass 2: tile-local radix sort of the bucket order on the full key
-__global__ __launch_bounds__(kTileThreads) void k_order_tile_sort(DevIndex ix, const uint64_t *__restrict__ codes,
-                                                                  int32_t n, SortShape sh,
-                                                                  const uint32_t *__restrict__ perm_in,
-                                                                  uint32_t *__restrict__ perm_out) {
-    const int code_bits = plan_code_bits(ix.wt_sigma);
-    using Sort = rocprim::block_radix_sort<uint32_t, kTileThreads, kTileItems, uint32_t>;
-    __shared__ typename Sort::storage_type storage;
-    __shared__ uint32_t s_first, s_last;
-    const int64_t base = (int64_t)blockIdx.x * kTile;
-    const int low_bits = sh.total_bits - sh.coarse_bits;
-    uint32_t keys[kTileItems], vals[kTileItems];
-    for (int k = 0; k < kTileItems; ++k) {
-        const int64_t i = base + (int64_t)threadIdx.x * kTileItems + k;
-        if (i < n) {
-            const uint32_t p = perm_in[i];
-            keys[k] = suffix_key(codes[p], code_bits, sh.chars, sh.bits);
-            vals[k] = p;
-            // the input is in bucket order: the tile's first item has its smallest coarse key, its last item the largest
-            if (i == base) s_first = keys[k] >> low_bits;
-            if (i == n - 1 || i == base + kTile - 1) s_last = keys[k] >> low_bits;
-        } else {
-            keys[k] = 0;
-            vals[k] = 0xffffffffu;
+    // first slot of this workgroup's share of each bin it holds: all of a thread's atomics are issued before the
+    // first result is consumed (one round trip to the L2 instead of one per bin)
+    for (int i0 = 0; i0 < bins; i0 += kTileThreads * 8) {
+        uint32_t got[8], cnt[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * kTileThreads + (int)threadIdx.x;
+            cnt[k] = i < bins ? s_cnt[i] : 0u;
+            got[k] = cnt[k] ? atomicAdd(&cursor[i], cnt[k]) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * kTileThreads + (int)threadIdx.x;
+            if (cnt[k]) s_cnt[i] = s_scan[i] + got[k];
         }
     }
     __syncthreads();
-    // keys relative to the tile's first bucket: only the bits that can differ inside the tile are sorted
-    // (a tile inside one hot bucket sorts 16 bits instead of 28)
-    const uint32_t first = s_first, span = s_last - s_first;
-    int end_bit = low_bits + 1;
-    while ((span + 1) >> (end_bit - low_bits)) ++end_bit;  // room for span + 1: the padding sorts last
-    for (int k = 0; k < kTileItems; ++k) {
-        const int64_t i = base + (int64_t)threadIdx.x * kTileItems + k;
-        keys[k] = i < n ? keys[k] - (first << low_bits) : (span + 1) << low_bits;
+#pragma unroll
+    for (int k = 0; k < kTileItems; ++k)
+        if (bin[k] != 0xffffffffu) *reinterpret_cast<Quad *>(recs_out + atomicAdd(&s_cnt[bin[k]], 1u)) = mine[k];
+    // The last workgroup leaves histogram, cursors and ticket zeroed for the next plan in this workspace.  No fence:
+    // every workgroup's histogram loads and cursor atomics have returned before it takes its ticket, and the zeroes
+    // only have to be visible to the NEXT kernel on the stream (a __threadfence here writes the L2 back: 75 us).
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (s_last) {
+        for (int i = threadIdx.x; i < bins; i += kTileThreads) {
+            ghist[i] = 0;
+            cursor[i] = 0;
+        }
+        if (threadIdx.x == 0) *ticket = 0;
     }
-    Sort().sort(keys, vals, storage, 0, end_bit);
-    for (int k = 0; k < kTileItems; ++k) {
-        const int64_t i = base + (int64_t)threadIdx.x * kTileItems + k;
-        if (i < n) perm_out[i] = vals[k];
+}
+
+// pass 3: the fine order, in place.  A workgroup takes a window of kFineWindow consecutive records of the bucket order
+// and ranks them by their fine bins with a counting sort in LDS (histogram, scan by one wave, ranked copy), then
+// writes the window back in that order: k_count reads the records with coalesced 16-byte loads.  Which patterns
+// share a wave is what matters, not their order inside it, so 10 key bits per window are as good as a full sort.
+constexpr int kFineThreads = 512;
+constexpr int kFineItems = 2;
+constexpr int kFineWindow = kFineThreads * kFineItems;  // 1,024 patterns
+__global__ __launch_bounds__(kFineThreads) void k_plan_fine(PlanRec *__restrict__ recs, int32_t n) {
+    constexpr int n_bins = 1 << kFineBits;
+    __shared__ uint32_t s_bin[n_bins];
+    __shared__ Quad s_rec[kFineWindow];
+    for (int i = threadIdx.x; i < n_bins; i += kFineThreads) s_bin[i] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kFineWindow;
+    Quad r[kFineItems];
+    uint32_t bin[kFineItems];
+#pragma unroll
+    for (int k = 0; k < kFineItems; ++k) {
+        const int64_t q = base + (int64_t)k * kFineThreads + threadIdx.x;
+        bin[k] = 0xffffffffu;
+        if (q < n) {
+            r[k] = ld_quad(recs + q);
+            bin[k] = r[k].w >> 22;
+            r[k].w &= kPlanLongPattern;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kFineItems; ++k)
+        if (bin[k] != 0xffffffffu) atomicAdd(&s_bin[bin[k]], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) {  // exclusive scan of the bins by one wave, n_bins / 64 consecutive bins per lane
+        constexpr int kPer = n_bins / 64;
+        uint32_t v[kPer], sum = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            v[k] = s_bin[(int)threadIdx.x * kPer + k];
+            sum += v[k];
+        }
+        uint32_t incl = sum;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if ((int)threadIdx.x >= d) incl += t;
+        }
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            s_bin[(int)threadIdx.x * kPer + k] = run;
+            run += v[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kFineItems; ++k)
+        if (bin[k] != 0xffffffffu) s_rec[atomicAdd(&s_bin[bin[k]], 1u)] = r[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kFineItems; ++k) {
+        const int64_t q = base + (int64_t)k * kFineThreads + threadIdx.x;
+        if (q < n) *reinterpret_cast<Quad *>(recs + q) = s_rec[k * kFineThreads + threadIdx.x];
     }
 }
 
@@ -603,7 +779,7 @@ int set_option(const char *name, int value) {
         return 0;
     }
     if (!strcmp(name, "coarse_bits")) {
-        if (value < 4 || value > kCoarseBitsMax) return -1;
+        if (value < 4 || value > kCoarseBitsMax - 1) return -1;  // k_plan_scatter keeps two arrays of 2^bits words in LDS
         g_coarse_bits = value;
         return 0;
     }
@@ -656,55 +832,86 @@ static SortShape sort_shape(const DevIndex &ix) {
     return sh;
 }
 
-// workspace layout: coarse[n] perm1[n] perm2[n] ghist[bins] | codes[n] (8 bytes each, 16-byte aligned)
-static size_t plan_codes_offset(int32_t n) {
-    return (((size_t)n * 12 + ((size_t)4 << kCoarseBitsMax) + 512) + 15) & ~(size_t)15;
-}
+// workspace layout: head (ghist[2^14] cursor[2^14] ticket, kPlanHeadBytes, all zero between plans) | records by pattern
+// [n] (16 B) | records in processing order [n] (16 B)
 // bytes of scratch needed to order a batch of n patterns (0 = the batch is not sorted)
 size_t count_workspace_bytes(const DevIndex &ix, int32_t n) {
     const int sort_min = g_sort_min;
     if (sort_min <= 0 || n < sort_min) return 0;
-    return plan_codes_offset(n) + (size_t)n * sizeof(uint64_t);
+    return kPlanHeadBytes + (size_t)n * 2 * sizeof(PlanRec) + 64;
 }
 
-// perm_out[q] = index of the q-th pattern in processing order.  workspace: count_workspace_bytes(ix, n).
-// Returns a hipError_t value.
+// Orders a batch: plan->recs = the patterns' records in processing order (nullptr: batch too small, or no
+// workspace).  workspace: count_workspace_bytes(ix, n); head_is_zero: the workspace's head is known to be zero
+// (a per-stream workspace keeps that invariant itself), else it is cleared first.  Returns a hipError_t value.
 int launch_count_plan(const DevIndex &ix, const uint16_t *pat, const int32_t *off, int32_t n, void *workspace,
-                      size_t workspace_bytes, const uint32_t **perm_out, const void **codes_out, hipStream_t st) {
-    *perm_out = nullptr;
-    *codes_out = nullptr;
+                      size_t workspace_bytes, bool head_is_zero, CountPlan *plan, hipStream_t st) {
+    *plan = CountPlan();
     const size_t need = count_workspace_bytes(ix, n);
     if (n <= 0 || !workspace || need == 0 || workspace_bytes < need) return 0;
     const SortShape sh = sort_shape(ix);
     const int bins = 1 << sh.coarse_bits;
-    uint32_t *coarse = static_cast<uint32_t *>(workspace);
-    uint32_t *perm1 = coarse + n;
-    uint32_t *perm2 = perm1 + n;
-    uint32_t *ghist = perm2 + n;
-    const int tiles = (n + kTile - 1) / kTile;
-    hipError_t e = hipMemsetAsync(ghist, 0, (size_t)bins * 4, st);
-    if (e != hipSuccess) return (int)e;
-    uint64_t *codes = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(workspace) + plan_codes_offset(n));
-    hipLaunchKernelGGL(k_order_hist, dim3(tiles), dim3(kTileThreads), (size_t)bins * 4, st, ix, pat, off, n, sh, coarse, ghist, codes);
-    hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(kScanThreads), 0, st, ghist, bins);
-    hipLaunchKernelGGL(k_order_scatter, dim3(tiles), dim3(kTileThreads), (size_t)bins * 4, st, coarse, n, sh, ghist, perm1);
-    if (sh.total_bits > sh.coarse_bits) {
-        hipLaunchKernelGGL(k_order_tile_sort, dim3(tiles), dim3(kTileThreads), 0, st, ix, codes, n, sh, perm1, perm2);
-        *perm_out = perm2;
-    } else {
-        *perm_out = perm1;
+    uint8_t *wsb = static_cast<uint8_t *>(workspace);
+    uint32_t *ghist = reinterpret_cast<uint32_t *>(wsb);
+    uint32_t *cursor = ghist + (1 << kCoarseBitsMax);
+    uint32_t *ticket = cursor + (1 << kCoarseBitsMax);
+    PlanRec *recs = reinterpret_cast<PlanRec *>(wsb + kPlanHeadBytes);
+    PlanRec *ordered = recs + n;
+    if (!head_is_zero) {
+        hipError_t e = hipMemsetAsync(workspace, 0, kPlanHeadBytes, st);
+        if (e != hipSuccess) return (int)e;
     }
-    *codes_out = codes;
+    const int tiles = (n + kTile - 1) / kTile;
+    const int code_bits = plan_code_bits(ix.wt_sigma);
+    if (code_bits == 8)
+        hipLaunchKernelGGL(k_plan_codes<8>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 4, st, ix, pat, off, n, sh, recs,
+                           ghist);
+    else
+        hipLaunchKernelGGL(k_plan_codes<16>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 4, st, ix, pat, off, n, sh, recs,
+                           ghist);
+    hipLaunchKernelGGL(k_plan_scatter, dim3(tiles), dim3(kTileThreads), (size_t)bins * 8, st, recs, n, bins,
+                       sh.total_bits - sh.coarse_bits, ghist, cursor, ticket, ordered);
+    hipLaunchKernelGGL(k_plan_fine, dim3((n + kFineWindow - 1) / kFineWindow), dim3(kFineThreads), 0, st, ordered, n);
+    plan->recs = ordered;
+    plan->n = n;
+    plan->code_bits = code_bits;
+    plan->shape = sh;
+    plan->look_up = ix.look_up;
+    plan->sigma = ix.wt_sigma;
     return (int)hipGetLastError();
 }
 
-// `codes` = the plan's per-pattern code words for THIS index's alphabet (nullptr: characters are mapped in the kernel)
-int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_t *off, const uint32_t *perm,
-                 const void *codes, int32_t n, int32_t *counts, int32_t *lf, int32_t *status, int32_t *range,
+// plan (nullable): the batch's order and code words; plan_is_foreign: it was made with ANOTHER index of a segment
+// set, so its code words are in that index's alphabet (translated in the kernel, or ignored for 16-bit codes)
+int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_t *off, const CountPlan *plan,
+                 bool plan_is_foreign, int32_t n, int32_t *counts, int32_t *lf, int32_t *status, int32_t *range,
                  hipStream_t st) {
     if (n <= 0) return 0;
-    FMX_DISPATCH(k_count, 2 * (int64_t)n, ix, pat, off, perm, n, counts, lf, status, range,
-                 perm ? static_cast<const uint64_t *>(codes) : nullptr);
+    const PlanRec *recs = (plan && plan->recs && plan->n == n) ? static_cast<const PlanRec *>(plan->recs) : nullptr;
+    CountPlan none;
+    const CountPlan &pl = recs ? *plan : none;
+    const bool translate = recs && plan_is_foreign && pl.code_bits == 8;
+    const int mode = !recs ? 0 : (!plan_is_foreign ? 1 : (translate ? 2 : 3));
+#define FMX_COUNT_MODE(MODE)                                                                                       \
+    do {                                                                                                           \
+        const int blk__ = g_block;                                                                                 \
+        const dim3 grid__(grid_for(2 * (int64_t)n, blk__, n_cu));                                                  \
+        if (blk__ == 1024)                                                                                         \
+            hipLaunchKernelGGL((k_count<1024, MODE>), grid__, dim3(1024), (size_t)g_lds_pad_kb * 1024, st, ix, pat, off, recs, n, \
+                               counts, lf, status, range, pl.code_bits, pl.look_up, pl.sigma);                     \
+        else                                                                                                       \
+            hipLaunchKernelGGL((k_count<512, MODE>), grid__, dim3(512), (size_t)g_lds_pad_kb * 1024, st, ix, pat, off, recs, n,   \
+                               counts, lf, status, range, pl.code_bits, pl.look_up, pl.sigma);                     \
+    } while (0)
+    if (mode == 0)
+        FMX_COUNT_MODE(0);
+    else if (mode == 1)
+        FMX_COUNT_MODE(1);
+    else if (mode == 2)
+        FMX_COUNT_MODE(2);
+    else
+        FMX_COUNT_MODE(3);
+#undef FMX_COUNT_MODE
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,30 @@
+// fmx_plan.hpp — what the plan stage of a batch (fmx_kernels.hip: k_plan_codes, k_plan_scatter) hands to k_count.
+// Shared by the launchers and the C-ABI layer.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+namespace fmx {
+
+struct SortShape {
+    int bits;         // bits per alphabet code
+    int chars;        // trailing characters in the full key
+    int total_bits;   // chars * bits (<= 32)
+    int coarse_bits;  // top bits used by the bucket pass
+};
+
+struct CountPlan {
+    const void *recs = nullptr;  // PlanRec[n] in processing order (device memory); nullptr = the caller's order
+    int32_t n = 0;
+    int code_bits = 8;           // width of one code in a record's code word (8, or 16 when sigma > 256)
+    SortShape shape = {1, 1, 1, 1};
+    // the alphabet the code words are written in (the index the plan was made with): code -> char, alphabet size
+    const int32_t *look_up = nullptr;
+    int32_t sigma = 0;
+};
+
+// head of the plan workspace: histogram, cursors, ticket — all zero between plans (k_plan_scatter restores that)
+constexpr size_t kPlanHeadBytes = 2 * ((size_t)4 << 14) + 256;
+
+}  // namespace fmx
