@@ -82,9 +82,17 @@ __device__ __forceinline__ const Quad *stage_sb_cache(Quad *s_sb, const DevIndex
     DevIndex LOCAL_IX = GLOBAL_IX;                  \
     LOCAL_IX.sb_cache = stage_sb_cache(s_sb, GLOBAL_IX)
 
-constexpr int kTileThreads = 512;
-constexpr int kTileItems = 8;                       // patterns per thread
-constexpr int kTile = kTileThreads * kTileItems;    // 4,096 patterns per workgroup
+// geometry of the plan kernels' workgroups, measured on configs[1] (codes / scatter kernel, us): 512 x 8: 19.3 / 19.9,
+// 256 x 4: 27.3 / 41.2 (four times the workgroups, each zeroing, flushing and scanning all bins), 1024 x 4: 15.7 / 17.5
+#ifndef FMX_TILE_THREADS
+#define FMX_TILE_THREADS 1024
+#endif
+#ifndef FMX_TILE_ITEMS
+#define FMX_TILE_ITEMS 4
+#endif
+constexpr int kTileThreads = FMX_TILE_THREADS;
+constexpr int kTileItems = FMX_TILE_ITEMS;          // patterns per thread
+constexpr int kTile = kTileThreads * kTileItems;    // patterns per workgroup of the plan kernels
 constexpr int kCoarseBitsMax = 14;                  // 16,384 LDS bins (64 KiB)
 
 // The (up to) 8 trailing characters of a pattern.  Patterns of >= 8 characters: the 16 bytes [beg + m - 8, beg + m) are
@@ -510,7 +518,7 @@ __global__ __launch_bounds__(kTileThreads) void k_plan_codes(DevIndex ix, const 
     const int below = sh.total_bits - sh.coarse_bits;
     const int fine_shift = below > 8 ? below - 8 : 0;
     const int64_t base = (int64_t)blockIdx.x * kTile;
-    constexpr int kGroup = 4;  // patterns whose loads a thread keeps in flight together
+    constexpr int kGroup = kTileItems < 4 ? kTileItems : 4;  // patterns whose loads a thread keeps in flight together
     for (int k0 = 0; k0 < kTileItems; k0 += kGroup) {
         int32_t beg[kGroup], len[kGroup];
         TailWords tail[kGroup];
@@ -756,6 +764,7 @@ static std::atomic<int> g_sort_min{16384};  // batches at least this large are p
 // bins of the bucket pass = 2^coarse_bits (<= 14: they live in LDS).  Measured on configs[1] (tools/tune_coarse.py):
 // 14 bits: plan 0.091 ms, step 0.304 ms; 12 bits: 0.075 / 0.286 ms; 10 bits: 0.071 / 0.286 ms; 8 bits: 0.069 / 0.294 ms
 static std::atomic<int> g_coarse_bits{12};
+static std::atomic<int> g_plan_fine{1};  // 0 = skip the window-local fine order (A/B)
 static std::atomic<int> g_sort_bits{28};    // full key width: floor(sort_bits / bits-per-code) trailing characters
 
 int set_option(const char *name, int value) {
@@ -781,6 +790,10 @@ int set_option(const char *name, int value) {
     if (!strcmp(name, "coarse_bits")) {
         if (value < 4 || value > kCoarseBitsMax - 1) return -1;  // k_plan_scatter keeps two arrays of 2^bits words in LDS
         g_coarse_bits = value;
+        return 0;
+    }
+    if (!strcmp(name, "plan_fine")) {
+        g_plan_fine = value != 0;
         return 0;
     }
     if (!strcmp(name, "lds_pad_kb")) {
@@ -871,7 +884,8 @@ int launch_count_plan(const DevIndex &ix, const uint16_t *pat, const int32_t *of
                            ghist);
     hipLaunchKernelGGL(k_plan_scatter, dim3(tiles), dim3(kTileThreads), (size_t)bins * 8, st, recs, n, bins,
                        sh.total_bits - sh.coarse_bits, ghist, cursor, ticket, ordered);
-    hipLaunchKernelGGL(k_plan_fine, dim3((n + kFineWindow - 1) / kFineWindow), dim3(kFineThreads), 0, st, ordered, n);
+    if (g_plan_fine)
+        hipLaunchKernelGGL(k_plan_fine, dim3((n + kFineWindow - 1) / kFineWindow), dim3(kFineThreads), 0, st, ordered, n);
     plan->recs = ordered;
     plan->n = n;
     plan->code_bits = code_bits;
