@@ -1,21 +1,33 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the backward-search hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): count() of 1,048,576 random 8-char patterns (substrings of the
-text at SplitMix64(43) positions) on the FM-index (sampleRate 32) of 256 MiB of synthetic log text
-(SplitMix64(42)).  One "step" = one pass of the batch through fmx_count_batch_dev with the
-patterns already resident in HBM.  With --gpus N (one process per GPU, launched by
-torch.distributed.run) rank 0 builds the index, its flat HBM image is broadcast over RCCL, and every
-rank counts its own 1,048,576-pattern shard (weak scaling, no collective on the data path).
+Workload `count` (default; BASELINE.json configs[1]): count() of 1,048,576 random 8-char patterns per GPU
+(substrings of the text at SplitMix64 positions) on the FM-index (sampleRate 32) of 256 MiB of synthetic log
+text (SplitMix64(42)).  One "step" = one pass of a batch through fmx_count_batch_dev (plan stage + k_count) with
+the patterns already resident in HBM; the timed loop rotates through `--batches` distinct batches (seeds 43..).
+With --gpus N (one process per GPU over RCCL) rank 0 builds the index, its flat HBM image is broadcast, every
+batch is ONE batch of N x 1,048,576 patterns made on rank 0 and handed out in contiguous shards, every rank
+counts its shard (weak scaling, no collective on the data path) and the results are gathered on rank 0.
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` and `cpu_baseline`.
-PyTorch is only plumbing here: device memory, the stream, HIP events and torch.distributed.
+Workload `segments` (BASELINE.json configs[4]): count() + locate(maxMatches 16) of ONE batch of 8,388,608 patterns
+over a 2 GiB text held as 8 segment indexes (a Java int cannot address 2^31 chars), the images broadcast, the batch
+sharded over the ranks (strong scaling).
+
+`python bench.py --gpus N` without a launcher starts `torch.distributed.run` itself as a child process; a run
+whose rank count differs from --gpus fails instead of printing a mislabelled line.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline`, `cpu_baseline`, `secondary`
+(configs[2], [3]) and `ranks_seen`.  PyTorch is only plumbing here: device memory, the stream, HIP events and
+torch.distributed.
 """
 import argparse
 import ctypes as C
 import hashlib
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,32 +38,44 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_latest.json")  # rocprofv3 --pmc passes of this very command
-
-
-def pmc_traffic(text_log2, patterns, sample_rate):
-    """fabric-side bytes per k_count launch from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, KiB units,
-    collected in separate passes by tools/profile.sh); None when no profile matches the workload"""
-    try:
-        p = json.load(open(PMC_FILE))
-        w = p["workload"]
-        if (w["text_log2"], w["patterns"], w["sample_rate"]) != (text_log2, patterns, sample_rate):
-            return None
-        return (p["k_count"]["FETCH_SIZE_KiB"] + p["k_count"]["WRITE_SIZE_KiB"]) * 1024.0
-    except (OSError, KeyError, ValueError):
-        return None
+KERNEL_SOURCES = ["fmx_kernels.hip", "fmx_device.hpp", "fmx_blob.hpp", "fmx_blob.cpp", "fmx_plan.hpp"]
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_or_load_index(ia, text_log2, sample_rate, cache_dir, build_device=0):
+def kernel_source_sha():
+    """digest of the sources that decide what k_count reads and how (stamped into profiles/pmc_latest.json)"""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "index4j_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_counters(text_log2, patterns, sample_rate):
+    """per-launch PMC averages of k_count from the committed passes (tools/profile.sh) — only if they were taken on
+    THIS workload and THESE kernel sources; otherwise None (a stale profile must not dress up a new kernel)"""
+    try:
+        p = json.load(open(PMC_FILE))
+        w = p["workload"]
+        if (w["text_log2"], w["patterns"], w["sample_rate"]) != (text_log2, patterns, sample_rate):
+            return None, "profile is of another workload"
+        if p.get("kernel_source_sha") != kernel_source_sha():
+            return None, "profiles/pmc_latest.json was taken on other kernel sources (%s, now %s): re-run tools/profile.sh" % (
+                p.get("kernel_source_sha"), kernel_source_sha())
+        return p["k_count"], None
+    except (OSError, KeyError, ValueError) as e:
+        return None, "no usable profile (%s)" % e
+
+
+def build_or_load_index(ia, text_log2, sample_rate, cache_dir, build_device=0, seed=42):
     """index of 2^text_log2 chars of synthetic log; the serialized form is cached under cache_dir.
     Construction runs its suffix-array stage on GPU `build_device` (same index, byte for byte: fmx_build_on_device);
     None = host builder."""
     n = 1 << text_log2
     t0 = time.time()
-    text = ia.synth_log(n, seed=42)
+    text = ia.synth_log(n, seed=seed)
     key = hashlib.sha256(text[: 1 << 16].tobytes() + b"%d-%d-v1" % (n, sample_rate)).hexdigest()[:16]
     path = os.path.join(cache_dir, "fmx_%s.ser" % key)
     t1 = time.time()
@@ -60,9 +84,9 @@ def build_or_load_index(ia, text_log2, sample_rate, cache_dir, build_device=0):
         log("[bench] index loaded from %s in %.1fs" % (path, time.time() - t1))
     else:
         fm = ia.FmIndex(text, sample_rate, True, device=None, build_device=build_device)
-        log("[bench] text %.1fs, index built in %.1fs (%s, %d host cores)"
-            % (t1 - t0, time.time() - t1, "suffix array on GPU %d" % build_device if build_device is not None else "host builder",
-               os.cpu_count()))
+        log("[bench] text %.1fs, index (sampleRate %d) built in %.1fs (%s, %d host cores)"
+            % (t1 - t0, sample_rate, time.time() - t1,
+               "suffix array on GPU %d" % build_device if build_device is not None else "host builder", os.cpu_count()))
         try:
             os.makedirs(cache_dir, exist_ok=True)
             tmp = path + ".%d.tmp" % os.getpid()
@@ -74,203 +98,303 @@ def build_or_load_index(ia, text_log2, sample_rate, cache_dir, build_device=0):
     return text, fm, path
 
 
-def cpu_baseline(path, pat, off, budget_s, alg_bytes_holder):
-    """the oracle (plain-C port of the reference path) timed on host cores over a bounded sample"""
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1 only): the oracle = plain-C port of the reference path, and — if a JVM and an index4j
+# jar exist on the box — index4j itself
+# ---------------------------------------------------------------------------------------------------------------
+def oracle_module():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
 
-    ref = orc.OracleFmIndex.read(open(path, "rb").read())
+    return orc
+
+
+def jvm_leg(ser_framed_path, pat, m, cache_dir):
+    """index4j's own count() on the host cores (countBenchmark, FmIndexThroughputBenchmark.java:191-199), if `java`
+    and INDEX4J_JAR exist; else a record of what the probe found"""
+    java = shutil.which("java")
+    jar = os.environ.get("INDEX4J_JAR")
+    probe = {"java": java, "INDEX4J_JAR": jar}
+    if not java or not jar or not os.path.exists(jar):
+        return {"available": False, "probe": probe,
+                "note": "index4j JVM: not available (java: %s, INDEX4J_JAR: %s); the reference publishes ~1e6 LF-steps/s/core "
+                        "(BASELINE.md)" % (java, jar if jar else "unset")}
+    try:
+        pfile = os.path.join(cache_dir, "patterns_%d.bin" % os.getpid())
+        n = len(pat) // m
+        with open(pfile, "wb") as f:
+            f.write(np.array([n, m], np.int32).tobytes())
+            f.write(np.ascontiguousarray(pat, np.uint16).tobytes())
+        src = os.path.join(ROOT, "tools", "jvm", "CountBench.java")
+        out = {"available": True, "probe": probe, "runs": []}
+        for threads in (1, os.cpu_count() or 1):
+            r = subprocess.run([java, "-Xmx16g", "-cp", jar, src, ser_framed_path, pfile, str(threads)], capture_output=True,
+                               text=True, timeout=900)
+            if r.returncode != 0:
+                out["runs"].append({"threads": threads, "error": r.stderr[-400:]})
+                continue
+            out["runs"].append(json.loads(r.stdout.strip().splitlines()[-1]))
+        os.unlink(pfile)
+        return out
+    except Exception as e:  # noqa: BLE001 - a broken JVM leg must not take the benchmark down
+        return {"available": False, "probe": probe, "note": "JVM leg failed: %r" % e}
+
+
+def cpu_baseline(ref, pat, off, budget_s, orc):
+    """the oracle timed on host cores over a bounded sample: 1 thread for `budget_s` seconds, then all cores"""
     n = len(off) - 1
     chunk = 20000
     done = 0
     orc.counters_reset()
     t0 = time.time()
-    first = None
     while done < n and time.time() - t0 < budget_s:
         hi = min(n, done + chunk)
-        c, s = ref.count_batch(pat[off[done]: off[hi]], off[done: hi + 1] - off[done], threads=1)
-        if first is None:
-            first = (c.copy(), done, hi)
+        ref.count_batch(pat[off[done]: off[hi]], off[done: hi + 1] - off[done], threads=1)
         done = hi
     dt = time.time() - t0
     cnt = orc.counters()
-    alg_bytes_holder["bytes_per_step"] = cnt["alg_bytes"] / max(1, cnt["lf_steps"])
-    alg_bytes_holder["levels_per_step"] = cnt["wt_levels"] / max(1, cnt["lf_steps"])
     one = {"value": done / dt, "unit": "patterns/s", "cores": 1, "kind": "port",
            "lf_steps_per_s": cnt["lf_steps"] / dt,
-           "sample": "first %d of the %d patterns of the same batch, oracle/index4j_oracle.c (C port of index4j's "
-                     "count path; the Java reference cannot run here: no JDK), 1 thread, %.1f s" % (done, n, dt)}
-    # all host cores (OpenMP over patterns), reported beside it
+           "sample": "first %d of the %d patterns of batch 0, oracle/index4j_oracle.c (C port of index4j's count path), "
+                     "1 thread, %.1f s" % (done, n, dt)}
     cores = os.cpu_count() or 1
     if cores > 1:
-        m = min(n, max(chunk, done * min(cores, 16) // 2))
         t0 = time.time()
-        ref.count_batch(pat[: off[m]], off[: m + 1], threads=cores)
+        ref.count_batch(pat, off, threads=cores)
         dt = time.time() - t0
-        one["all_cores"] = {"value": m / dt, "unit": "patterns/s", "cores": cores, "sample": "first %d patterns" % m}
-    return one, first
+        one["all_cores"] = {"value": n / dt, "unit": "patterns/s", "cores": cores, "sample": "all %d patterns" % n}
+    return one
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--text-log2", type=int, default=28, help="log2 of the text length in chars (28 = 256 MiB)")
-    ap.add_argument("--patterns", type=int, default=1 << 20)
-    ap.add_argument("--pattern-len", type=int, default=8)
-    ap.add_argument("--sample-rate", type=int, default=32)
-    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of oracle time for cpu_baseline")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cache-dir", default=os.environ.get("FMX_CACHE", "/tmp/fmx_cache"))
-    args = ap.parse_args()
-
+# ---------------------------------------------------------------------------------------------------------------
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process (never exec
+    from a process that may touch the GPU) and exit with its code"""
     import torch
 
-    import index4j_amd as ia
+    if not args.dry_run and torch.cuda.device_count() < args.gpus:
+        log("[bench] --gpus %d but only %d HIP device(s) visible: refusing to print a mislabelled line"
+            % (args.gpus, torch.cuda.device_count()))
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log("[bench] no launcher in the environment: starting %s" % " ".join(cmd[1:9]))
+    return subprocess.call(cmd, env=env)
 
-    if not torch.cuda.is_available() or ia.lib.fmx_device_count() < 1:
-        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if local_rank >= torch.cuda.device_count():  # launcher that gives every rank its own visible-device mask
-        local_rank = 0
-    if world != args.gpus:
-        log("[bench] WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
+class Ctx:
+    """what every workload needs: rank info, device, torch, dist (or None), the package"""
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
-    # ---- index: rank 0 builds (or loads the cached serialized form), the HBM image is broadcast ----
-    text = fm = path = None
-    if rank == 0:
-        text, fm, path = build_or_load_index(ia, args.text_log2, args.sample_rate, args.cache_dir, build_device=local_rank)
-    if world > 1:
-        size = torch.zeros(1, dtype=torch.int64, device=dev)
-        if rank == 0:
-            host_blob = fm.blob()
-            size[0] = len(host_blob)
-        dist.broadcast(size, 0)
-        d_blob = torch.empty(int(size.item()), dtype=torch.uint8, device=dev)
-        if rank == 0:
-            d_blob.copy_(torch.from_numpy(host_blob))
-        t0 = time.time()
-        dist.broadcast(d_blob, 0)  # RCCL over xGMI: the immutable index, once
+def hip_events(torch):
+    return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+
+def check_rc(ia, rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (what, ia.lib.fmx_last_error().decode()))
+
+
+def barrier(ctx):
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+    if not ctx.dry:
+        ctx.torch.cuda.synchronize()
+
+
+def attach_everywhere(ctx, fm):
+    """rank 0's index -> every rank: broadcast of the flat image, attached in place (validated by the library)"""
+    from index4j_amd.shard import broadcast_blob
+
+    ia, torch = ctx.ia, ctx.torch
+    if ctx.dist is None:
+        if ctx.dry:
+            return None, None, len(fm.blob())
+        fm.to_device(ctx.local_rank)
+        return fm, None, fm.device_blob()[1]
+    t0 = time.time()
+    buf = broadcast_blob(ctx.dist, fm.blob() if ctx.rank == 0 else None, ctx.dev)  # RCCL over xGMI: the immutable index, once
+    if not ctx.dry:
         torch.cuda.synchronize()
-        if rank == 0:
-            log("[bench] index blob %.1f MB broadcast to %d GPUs in %.3fs" % (size.item() / 1e6, world, time.time() - t0))
-        q = ia.FmIndex.attach_device_blob(d_blob.data_ptr(), d_blob.numel(), local_rank)
-        if rank != 0:
-            text = ia.synth_log(1 << args.text_log2, seed=42)
-    else:
-        fm.to_device(local_rank)
-        q = fm
+    if ctx.rank == 0:
+        log("[bench] index image %.1f MB broadcast to %d rank(s) in %.3fs" % (buf.numel() / 1e6, ctx.world, time.time() - t0))
+    if ctx.dry:
+        return None, buf, buf.numel()
+    q = ia.FmIndex.attach_device_blob(buf.data_ptr(), buf.numel(), ctx.local_rank)
+    return q, buf, buf.numel()
 
-    # ---- this rank's shard of patterns (resident in HBM before the timed region) ----
-    n = args.patterns
-    pat, off, _pos = ia.synth_patterns(text, args.pattern_len, n, seed=43 + rank)
-    d_pat = torch.from_numpy(pat.view(np.int16)).to(dev)
-    d_off = torch.from_numpy(off).to(dev)
-    d_cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+
+def hand_out_patterns(ctx, pat_host, m, total):
+    """the batch's chars (uint16, made on rank 0) -> this rank's contiguous shard in device memory, as a flat int16
+    tensor.  Travels as bytes: neither RCCL nor gloo moves 16-bit integers."""
+    from index4j_amd.shard import scatter_rows, shard_range
+
+    torch = ctx.torch
+    rows = None if pat_host is None else np.ascontiguousarray(pat_host, dtype=np.uint16).view(np.uint8)
+    if ctx.dist is None:
+        t = torch.from_numpy(rows.reshape(total, 2 * m)).to(ctx.dev)
+    else:
+        t = scatter_rows(ctx.dist, rows, 2 * m, total, ctx.dev, torch.uint8)
+        lo, hi = shard_range(total, ctx.world, ctx.rank)
+        assert t.shape[0] == hi - lo
+    return t.contiguous().view(torch.int16).reshape(-1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# workload `count` — BASELINE.json configs[1] (+ configs[2], [3] as `secondary` at N = 1)
+# ---------------------------------------------------------------------------------------------------------------
+def run_count(ctx, args):
+    from index4j_amd import workload
+    from index4j_amd.shard import gather_concat, shard_range
+
+    ia, torch, dist, dev = ctx.ia, ctx.torch, ctx.dist, ctx.dev
+    m, n, world = args.pattern_len, args.patterns, ctx.world
+    text = fm = path = None
+    if ctx.rank == 0:
+        text, fm, path = build_or_load_index(ia, args.text_log2, args.sample_rate, args.cache_dir,
+                                             build_device=None if ctx.dry else ctx.local_rank)
+    q, blob_buf, image_bytes = attach_everywhere(ctx, fm)
+
+    # ---- batches: each ONE batch of world x n patterns made on rank 0, handed out in contiguous shards ----
+    n_batches = max(1, args.batches)
+    host_batches = []
+    d_pats = []
+    for b in range(n_batches):
+        pat = None
+        if ctx.rank == 0:
+            pat, _off, _pos = workload.count_batch_patterns(text, world * n, m, seed=workload.PATTERN_SEED + b)
+            host_batches.append(pat)
+        d_pats.append(hand_out_patterns(ctx, pat, m, world * n))
+    lo, hi = shard_range(world * n, world, ctx.rank)
+    assert hi - lo == n
+    off_host = (np.arange(n + 1, dtype=np.int64) * m).astype(np.int32)
+    d_off = torch.from_numpy(off_host).to(dev)
+    d_cnt = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(n_batches)]
     d_lf = torch.zeros(n, dtype=torch.int32, device=dev)
     d_st = torch.zeros(n, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream()
+    stream = None if ctx.dry else torch.cuda.current_stream()
+    sp = None if ctx.dry else C.c_void_p(stream.cuda_stream)
 
-    def step(with_steps):
-        rc = ia.lib.fmx_count_batch_dev(q.handle, d_pat.data_ptr(), d_off.data_ptr(), n, d_cnt.data_ptr(),
-                                        d_lf.data_ptr() if with_steps else None, d_st.data_ptr() if with_steps else None,
-                                        C.c_void_p(stream.cuda_stream))
-        if rc != 0:
-            raise RuntimeError("fmx_count_batch_dev failed: %s" % ia.lib.fmx_last_error().decode())
+    def step(b, with_steps=False):
+        if ctx.dry:
+            return
+        check_rc(ia, ia.lib.fmx_count_batch_dev(q.handle, d_pats[b].data_ptr(), d_off.data_ptr(), n, d_cnt[b].data_ptr(),
+                                                d_lf.data_ptr() if with_steps else None,
+                                                d_st.data_ptr() if with_steps else None, sp), "fmx_count_batch_dev")
 
-    step(True)  # also yields the exact LF-step count of the batch
-    torch.cuda.synchronize()
-    lf_steps_per_launch = int(d_lf.sum(dtype=torch.int64).item())
-    if int(d_st.max().item()) != 0:
-        raise RuntimeError("unexpected per-query status in the benchmark batch")
-    checksum = int(d_cnt.sum(dtype=torch.int64).item())
-    for _ in range(args.warmup):
-        step(False)
+    lf_steps = []
+    checksums = []
+    for b in range(n_batches):  # also yields the exact LF-step count of every batch
+        step(b, True)
+        if not ctx.dry:
+            torch.cuda.synchronize()
+            if int(d_st.max().item()) != 0:
+                raise RuntimeError("unexpected per-query status in the benchmark batch")
+        lf_steps.append(int(d_lf.sum(dtype=torch.int64).item()))
+        checksums.append(int(d_cnt[b].sum(dtype=torch.int64).item()))
+    for i in range(args.warmup):
+        step(i % n_batches)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
+    barrier(ctx)
     t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step(False)  # the whole hot path: suffix-key sort of the batch + k_count
-    ev1.record(stream)
-    barrier()
+    if not ctx.dry:
+        ev0, ev1 = hip_events(torch)
+        ev0.record(stream)
+    for i in range(args.steps):
+        step(i % n_batches)  # the whole hot path: plan stage of the batch + k_count
+    if not ctx.dry:
+        ev1.record(stream)
+    barrier(ctx)
     wall = time.perf_counter() - t0
-    step_ms = ev0.elapsed_time(ev1) / args.steps
+    step_ms = 0.0 if ctx.dry else ev0.elapsed_time(ev1) / args.steps
 
-    # the dominant kernel alone (k_count over the same processing order), HIP events on its stream
-    perm = C.c_void_p()
-    rc = ia.lib.fmx_count_plan_dev(q.handle, d_pat.data_ptr(), d_off.data_ptr(), n, C.byref(perm), C.c_void_p(stream.cuda_stream))
-    if rc != 0:
-        raise RuntimeError("fmx_count_plan_dev failed: %s" % ia.lib.fmx_last_error().decode())
-    torch.cuda.synchronize()
-    ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev2.record(stream)
-    for _ in range(args.steps):
-        rc = ia.lib.fmx_count_ordered_dev(q.handle, d_pat.data_ptr(), d_off.data_ptr(), perm, n, d_cnt.data_ptr(), None,
-                                          None, C.c_void_p(stream.cuda_stream))
-        if rc != 0:
-            raise RuntimeError("fmx_count_ordered_dev failed: %s" % ia.lib.fmx_last_error().decode())
-    ev3.record(stream)
-    torch.cuda.synchronize()
-    kernel_ms = ev2.elapsed_time(ev3) / args.steps
-    if int(d_cnt.sum(dtype=torch.int64).item()) != checksum:
-        raise RuntimeError("counts changed between launches")
+    # the dominant kernel alone (k_count over each batch's processing order), HIP events on its stream
+    kernel_ms_per_batch = []
+    if not ctx.dry:
+        reps = max(1, args.steps // n_batches)
+        for b in range(n_batches):
+            plan = C.c_void_p()
+            check_rc(ia, ia.lib.fmx_count_plan_dev(q.handle, d_pats[b].data_ptr(), d_off.data_ptr(), n, C.byref(plan), sp),
+                     "fmx_count_plan_dev")
+            torch.cuda.synchronize()
+            e0, e1 = hip_events(torch)
+            e0.record(stream)
+            for _ in range(reps):
+                check_rc(ia, ia.lib.fmx_count_ordered_dev(q.handle, d_pats[b].data_ptr(), d_off.data_ptr(), plan, n,
+                                                          d_cnt[b].data_ptr(), None, None, sp), "fmx_count_ordered_dev")
+            e1.record(stream)
+            torch.cuda.synchronize()
+            kernel_ms_per_batch.append(e0.elapsed_time(e1) / reps)
+            if int(d_cnt[b].sum(dtype=torch.int64).item()) != checksums[b]:
+                raise RuntimeError("counts changed between launches")
+    kernel_ms = float(np.mean(kernel_ms_per_batch)) if kernel_ms_per_batch else 0.0
+
+    lf_local = sum(lf_steps[i % n_batches] for i in range(args.steps))
+    seen = [[0, ctx.local_rank, ctx.local_rank]]
+    gathered = None
     if dist is not None:
+        from index4j_amd.shard import ranks_seen
+
         tw = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
-        tot = torch.tensor([lf_steps_per_launch], dtype=torch.int64, device=dev)
+        tot = torch.tensor([lf_local], dtype=torch.int64, device=dev)
         dist.all_reduce(tot)
         lf_total = int(tot.item())
+        seen = ranks_seen(dist, dev, ctx.local_rank, ctx.local_rank if not ctx.dry else -1)
+        # final gather of the shards' results on rank 0 (outside the timed region: the shards are independent)
+        gathered = gather_concat(dist, d_cnt[0], [n] * world, dev)
     else:
-        lf_total = lf_steps_per_launch
+        lf_total = lf_local
+    if ctx.rank != 0:
+        return None
+    if len(seen) != args.gpus or sorted(r[0] for r in seen) != list(range(args.gpus)):
+        raise RuntimeError("ranks seen %r do not match --gpus %d" % (seen, args.gpus))
 
-    # final gather of the shards' results on rank 0 (outside the timed region: the shards are independent)
-    gathered_checksum = None
-    if dist is not None:
-        from index4j_amd.shard import gather_concat
-
-        all_counts = gather_concat(dist, d_cnt, [n] * world, dev)
-        if rank == 0:
-            gathered_checksum = int(all_counts.astype(np.int64).sum())
-            if len(all_counts) != n * world:
-                raise RuntimeError("gather returned %d results for %d patterns" % (len(all_counts), n * world))
-    if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-
-    # ---- CPU baseline + algorithmic bytes per LF-step from the oracle's counting mode ----
-    holder = {}
+    # ---- parity of the run itself + algorithmic bytes per LF-step from the oracle's counting mode ----
+    bytes_per_step = levels_per_step = None
+    oracle_checked = 0
     base = None
-    if world > 1 and not args.no_cpu_baseline:
-        # cpu_baseline is reported at N=1 only; a 2,000-pattern oracle pass still yields bytes per LF-step
-        cpu_baseline(path, pat[: 2000 * args.pattern_len], off[:2001], 1e9, holder)
-    elif not args.no_cpu_baseline:
-        base, first = cpu_baseline(path, pat, off, args.cpu_budget, holder)
-        c, lo, hi = first
-        if not (d_cnt[lo:hi].cpu().numpy() == c).all():
-            raise RuntimeError("GPU counts differ from the oracle on the baseline sample")
-    bytes_per_step = holder.get("bytes_per_step")
+    ref = orc = None
+    if not ctx.dry and not args.no_cpu_baseline:
+        orc = oracle_module()
+        ref = orc.OracleFmIndex.read(open(path, "rb").read())
+        cores = os.cpu_count() or 1
+        all0 = gathered if gathered is not None else d_cnt[0].cpu().numpy()
+        off_all = (np.arange(world * n + 1, dtype=np.int64) * m).astype(np.int32)
+        orc.counters_reset()
+        oc, ost = ref.count_batch(host_batches[0], off_all, threads=cores)  # EVERY pattern of batch 0, all ranks' shards
+        cnt = orc.counters()
+        if not (all0 == oc).all() or int(ost.max()) != 0:
+            raise RuntimeError("GPU counts differ from the oracle on batch 0")
+        oracle_checked += world * n
+        bytes_per_step = cnt["alg_bytes"] / max(1, cnt["lf_steps"])
+        levels_per_step = cnt["wt_levels"] / max(1, cnt["lf_steps"])
+        oracle_checksum = int(oc.astype(np.int64).sum())
+        for b in range(1, n_batches):  # rank 0's shard of the other batches
+            oc_b, _ = ref.count_batch(host_batches[b][: n * m], off_host, threads=cores)
+            if not (d_cnt[b].cpu().numpy() == oc_b).all():
+                raise RuntimeError("GPU counts differ from the oracle on batch %d" % b)
+            oracle_checked += n
+        if world == 1:
+            base = cpu_baseline(ref, host_batches[0], off_host, args.cpu_budget, orc)
+            ser_framed = os.path.join(args.cache_dir, "fmx_framed_%d.ser" % os.getpid())
+            try:
+                with open(ser_framed, "wb") as f:
+                    f.write(fm.write(True))
+                base["index4j_jvm"] = jvm_leg(ser_framed, host_batches[0], m, args.cache_dir)
+            finally:
+                if os.path.exists(ser_framed):
+                    os.unlink(ser_framed)
+    else:
+        oracle_checksum = None
+
     ms_per_step = wall * 1e3 / args.steps
     patterns_per_s = world * n * args.steps / wall
     roof = None
@@ -279,7 +403,7 @@ def main():
         src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
         dst = torch.empty_like(src)
         dst.copy_(src)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1 = hip_events(torch)
         e0.record()
         for _ in range(5):
             dst.copy_(src)
@@ -287,20 +411,39 @@ def main():
         torch.cuda.synchronize()
         copy_gbs = 5 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
-        achieved = bytes_per_step * lf_steps_per_launch / (kernel_ms * 1e-3) / 1e9
+        lf_per_launch = float(np.mean(lf_steps))
+        alg_bytes = bytes_per_step * lf_per_launch
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        pmc, why = pmc_counters(args.text_log2, n, args.sample_rate)
+        traffic = (pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024.0 if pmc else None
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args.text_log2, n, args.sample_rate), "kernel": "k_count",
-                "kernel_ms": kernel_ms, "step_ms_incl_sort": step_ms, "alg_bytes_per_lf_step": bytes_per_step,
-                "lf_steps_per_launch": lf_steps_per_launch,
-                "wt_levels_per_lf_step": holder.get("levels_per_step"),
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_count",
+                "what_frac_means": "ALGORITHMIC bytes of the reference's layout (oracle counting mode) per k_count launch / "
+                                   "launch time / peak: distance from a perfect streaming of the reference's own reads, not "
+                                   "HBM saturation — the image is L2 / Infinity-Cache resident, see traffic_frac",
+                "kernel_ms": kernel_ms, "kernel_ms_per_batch": kernel_ms_per_batch,
+                "kernel_ms_spread": (max(kernel_ms_per_batch) - min(kernel_ms_per_batch)) / kernel_ms,
+                "step_ms_incl_plan": step_ms, "frac_whole_step": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "alg_bytes_per_lf_step": bytes_per_step, "lf_steps_per_launch": lf_per_launch,
+                "lf_steps_per_batch": lf_steps, "wt_levels_per_lf_step": levels_per_step,
+                "traffic_frac": traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
+                "traffic_note": why if traffic is None else "FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 --pmc passes "
+                                                            "(profiles/pmc_latest.json, kernel sources %s)" % kernel_source_sha(),
+                "l1_line_bytes": pmc["TCP_TOTAL_CACHE_ACCESSES"] * 64.0 if pmc and pmc.get("TCP_TOTAL_CACHE_ACCESSES") else None,
+                "l1_line_accesses_per_lf_step": pmc["TCP_TOTAL_CACHE_ACCESSES"] / lf_per_launch
+                if pmc and pmc.get("TCP_TOTAL_CACHE_ACCESSES") else None,
+                "image_bytes": image_bytes, "image_bytes_per_text_byte": image_bytes / float(1 << args.text_log2),
                 "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs}
+    secondary = None
+    if world == 1 and ref is not None and not args.no_secondary:
+        secondary = run_secondary(ctx, args, q, ref, orc, text, host_batches[0], off_host)
     out = {
         "metric": "patterns/sec + LF-steps/sec, 1M x 8-char count() on 256 MiB log index",
-        "value": patterns_per_s,
+        "value": None if ctx.dry else patterns_per_s,
         "unit": "patterns/s",
-        "lf_steps_per_sec": lf_total * args.steps / wall,
+        "lf_steps_per_sec": None if ctx.dry else lf_total / wall,
         "n_gpus": world,
+        "ranks_seen": seen,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
@@ -310,17 +453,344 @@ def main():
         "dtype": "int32",
         "data": "synthetic",
         "config": {"workload": "count() batch of %d random %d-char patterns per GPU on %d MiB synthetic log text, "
-                               "sampleRate=%d (BASELINE.json configs[1])" % (n, args.pattern_len,
-                                                                             (1 << args.text_log2) >> 20, args.sample_rate),
-                   "text_chars": 1 << args.text_log2, "patterns_per_gpu": n, "pattern_len": args.pattern_len,
-                   "sample_rate": args.sample_rate, "parallelism": "patterns sharded x%d, index replicated" % world,
-                   "count_checksum": checksum, "gathered_checksum_all_ranks": gathered_checksum},
+                               "sampleRate=%d (BASELINE.json configs[1]); %d distinct batches rotate through the timed loop"
+                               % (n, m, (1 << args.text_log2) >> 20, args.sample_rate, n_batches),
+                   "text_chars": 1 << args.text_log2, "patterns_per_gpu": n, "pattern_len": m,
+                   "sample_rate": args.sample_rate, "batches": n_batches,
+                   "parallelism": "one batch of %d patterns sharded x%d (contiguous shards from rank 0), index image "
+                                  "broadcast and replicated" % (world * n, world),
+                   "count_checksums_rank0": checksums, "count_checksum": checksums[0],
+                   "gathered_checksum_all_ranks": int(gathered.astype(np.int64).sum()) if gathered is not None else None,
+                   "oracle_checksum_batch0_all_ranks": oracle_checksum, "patterns_checked_vs_oracle": oracle_checked},
         "roofline": roof,
         "cpu_baseline": base,
+        "secondary": secondary,
     }
-    print(json.dumps(out), flush=True)
+    if ctx.dry:
+        out["dry_run"] = True
+    return out
+
+
+def run_secondary(ctx, args, q, ref, orc, text, pat, off):
+    """BASELINE.json configs[2] and [3] on the same GPU, outside the headline's timed region: HIP-event time, every
+    result checked against the oracle in this run, LF-steps and algorithmic bytes from the oracle's counting mode"""
+    ia, torch, dev = ctx.ia, ctx.torch, ctx.dev
+    m, cores = args.pattern_len, os.cpu_count() or 1
+    stream = torch.cuda.current_stream()
+    sp = C.c_void_p(stream.cuda_stream)
+    K = min(100_000, len(off) - 1)
+    M = 16
+    res = []
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = hip_events(torch)
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    d_pat = torch.from_numpy(np.ascontiguousarray(pat[: K * m]).view(np.int16)).to(dev)
+    d_off = torch.from_numpy(np.ascontiguousarray(off[: K + 1])).to(dev)
+    d_locs = torch.zeros(K * M, dtype=torch.int32, device=dev)
+    d_found = torch.zeros(K, dtype=torch.int32, device=dev)
+    d_lf = torch.zeros(K, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(K, dtype=torch.int32, device=dev)
+    d_rng = torch.zeros(2 * K, dtype=torch.int32, device=dev)
+
+    def locate(index, with_lf=True):
+        check_rc(ia, ia.lib.fmx_locate_batch_dev(index.handle, d_pat.data_ptr(), d_off.data_ptr(), K, M, d_locs.data_ptr(), M,
+                                                 d_found.data_ptr(), d_lf.data_ptr() if with_lf else None, d_st.data_ptr(),
+                                                 d_rng.data_ptr(), sp), "fmx_locate_batch_dev")
+
+    # ---- configs[2]: locate, maxMatches 16, sampleRate-32 index ----
+    d_lf.zero_()
+    d_st.zero_()
+    locate(q)
+    torch.cuda.synchronize()
+    locs = d_locs.cpu().numpy().reshape(K, M)
+    found = d_found.cpu().numpy()
+    lf_gpu = int(d_lf.sum(dtype=torch.int64).item())
+    orc.counters_reset()
+    olocs, ofound, ost = ref.locate_batch(pat[: K * m], off[: K + 1], M, threads=cores)
+    c = orc.counters()
+    live = np.arange(M)[None, :] < found[:, None]
+    if not ((found == ofound).all() and (locs[live] == olocs[live]).all() and int(d_st.max().item()) == 0 and lf_gpu == c["lf_steps"]):
+        raise RuntimeError("locate differs from the oracle")
+    ms = timed(lambda: locate(q, False), 5)
+    alg = c["alg_bytes"]
+    res.append({"config": "BASELINE.json configs[2]: locate() of %d patterns, maxMatches %d, 256 MiB text, sampleRate %d"
+                          % (K, M, args.sample_rate),
+                "ms": ms, "patterns_per_s": K / ms * 1e3, "hits": int(found.sum()), "hits_per_s": int(found.sum()) / ms * 1e3,
+                "lf_steps": c["lf_steps"], "lf_steps_per_s": c["lf_steps"] / ms * 1e3,
+                "alg_bytes_per_lf_step": alg / max(1, c["lf_steps"]),
+                "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernels": "k_plan_* + k_count + k_locate_walk"},
+                "checked_vs_oracle": "all %d patterns: found, every position (SA order), LF-step total" % K})
+
+    # ---- configs[3]: extractUntilBoundary('\n') of the first hit of each pattern, sampleRate-64 index ----
+    _t, fm64, path64 = build_or_load_index(ia, args.text_log2, 64, args.cache_dir, build_device=ctx.local_rank)
+    fm64.to_device(ctx.local_rank)
+    ref64 = orc.OracleFmIndex.read(open(path64, "rb").read())
+    d_st.zero_()
+    locate(fm64, False)
+    torch.cuda.synchronize()
+    froms = np.ascontiguousarray(d_locs.cpu().numpy().reshape(K, M)[:, 0])
+    cap = 1024
+    d_from = torch.from_numpy(froms).to(dev)
+    d_dst = torch.zeros(K * cap, dtype=torch.int16, device=dev)
+    d_len = torch.zeros(K, dtype=torch.int32, device=dev)
+    d_aux = torch.zeros(K, dtype=torch.int32, device=dev)
+
+    def boundary(with_lf=True):
+        check_rc(ia, ia.lib.fmx_extract_boundary_batch_dev(fm64.handle, d_from.data_ptr(), K, 10, 0, d_dst.data_ptr(), cap, 0,
+                                                           d_len.data_ptr(), d_lf.data_ptr() if with_lf else None,
+                                                           d_st.data_ptr(), d_aux.data_ptr(), sp), "fmx_extract_boundary_batch_dev")
+
+    boundary()
+    torch.cuda.synchronize()
+    lf_gpu = int(d_lf.sum(dtype=torch.int64).item())
+    orc.counters_reset()
+    odst, olen, ost, oaux = ref64.extract_until_boundary_batch(0, froms, "\n", cap, threads=cores)
+    c = orc.counters()
+    dst = d_dst.cpu().numpy().view(np.uint16).reshape(K, cap)
+    if not ((d_len.cpu().numpy() == olen).all() and (dst == odst).all() and (d_st.cpu().numpy() == ost).all()):
+        raise RuntimeError("extractUntilBoundary differs from the oracle")
+    ms = timed(lambda: boundary(False), 3)
+    chars = int(olen.astype(np.int64).sum())
+    alg = c["alg_bytes"]
+    res.append({"config": "BASELINE.json configs[3]: extractUntilBoundary('\\n') of %d hit locations, 256 MiB text, sampleRate 64, "
+                          "destination %d chars" % (K, cap),
+                "ms": ms, "queries_per_s": K / ms * 1e3, "chars": chars, "chars_per_s": chars / ms * 1e3,
+                "lf_steps_reference": c["lf_steps"], "lf_steps_executed_on_gpu": lf_gpu,
+                "lf_steps_per_s_reference_equivalent": c["lf_steps"] / ms * 1e3, "lf_steps_per_s_executed": lf_gpu / ms * 1e3,
+                "alg_bytes_per_lf_step": alg / max(1, c["lf_steps"]),
+                "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernels": "k_extract_boundary_group",
+                             "note": "algorithmic bytes of the REFERENCE's walk (one re-seek per 4 characters, FM:697-743); the "
+                                     "kernel fetches every sample interval once, so it executes fewer LF-steps than that"},
+                "checked_vs_oracle": "all %d queries: lengths, statuses, whole destination rows" % K})
+    fm64.close()
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# workload `segments` — BASELINE.json configs[4]
+# ---------------------------------------------------------------------------------------------------------------
+def run_segments(ctx, args):
+    from index4j_amd import workload
+    from index4j_amd.shard import broadcast_blob, gather_concat, ranks_seen, shard_range
+
+    ia, torch, dist, dev = ctx.ia, ctx.torch, ctx.dist, ctx.dev
+    K, m, M, world = args.segments, args.pattern_len, 16, ctx.world
+    total = args.patterns_total
+    texts = fms = None
+    t0 = time.time()
+    if ctx.rank == 0:
+        texts = workload.segment_texts(K, args.segment_log2)
+        fms = [ia.FmIndex(t, args.sample_rate, True, device=None, build_device=None if ctx.dry else ctx.local_rank) for t in texts]
+        log("[bench] %d segment indexes (%d chars) built in %.1fs" % (K, sum(len(t) for t in texts), time.time() - t0))
+    bases = torch.zeros(K, dtype=torch.int64, device=dev)
+    if ctx.rank == 0:
+        bases.copy_(torch.from_numpy(workload.segment_bases(texts)))
     if dist is not None:
-        dist.destroy_process_group()
+        dist.broadcast(bases, 0)
+    segs, bufs, image_bytes = [], [], 0
+    for s in range(K):
+        if dist is None:
+            if not ctx.dry:
+                fms[s].to_device(ctx.local_rank)
+            segs.append(fms[s])
+            image_bytes += len(fms[s].blob())
+        else:
+            buf = broadcast_blob(dist, fms[s].blob() if ctx.rank == 0 else None, dev)
+            bufs.append(buf)
+            image_bytes += buf.numel()
+            if not ctx.dry:
+                segs.append(ia.FmIndex.attach_device_blob(buf.data_ptr(), buf.numel(), ctx.local_rank))
+    sf = None if ctx.dry else ia.SegmentedFmIndex.from_segments(segs, bases.cpu().numpy())
+    pat = None
+    if ctx.rank == 0:
+        pat, _off = workload.segment_patterns(texts, total, m)
+    d_pat = hand_out_patterns(ctx, pat, m, total)
+    lo, hi = shard_range(total, world, ctx.rank)
+    n = hi - lo
+    d_off = torch.from_numpy((np.arange(n + 1, dtype=np.int64) * m).astype(np.int32)).to(dev)
+    d_cnt = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_lf = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_tmp = torch.zeros(n * (4 + M), dtype=torch.int32, device=dev)
+    d_locs = torch.zeros(n * M, dtype=torch.int64, device=dev)
+    d_found = torch.zeros(n, dtype=torch.int32, device=dev)
+    stream = None if ctx.dry else torch.cuda.current_stream()
+    sp = None if ctx.dry else C.c_void_p(stream.cuda_stream)
+
+    def step(with_lf=False):
+        if ctx.dry:
+            return
+        check_rc(ia, ia.lib.fmx_count_segments_dev(sf.handles, K, d_pat.data_ptr(), d_off.data_ptr(), n, d_cnt.data_ptr(),
+                                                   d_lf.data_ptr() if with_lf else None, d_st.data_ptr(), d_tmp.data_ptr(), sp),
+                 "fmx_count_segments_dev")
+        check_rc(ia, ia.lib.fmx_locate_segments_dev(sf.handles, K, sf.base_array.ctypes.data, d_pat.data_ptr(), d_off.data_ptr(), n,
+                                                    M, d_locs.data_ptr(), d_found.data_ptr(), d_st.data_ptr(), d_tmp.data_ptr(), sp),
+                 "fmx_locate_segments_dev")
+
+    step(True)
+    if not ctx.dry:
+        torch.cuda.synchronize()
+        if int(d_st.max().item()) != 0:
+            raise RuntimeError("unexpected per-query status in the benchmark batch")
+    lf_local = int(d_lf.sum().item())
+    for _ in range(args.warmup):
+        step()
+    barrier(ctx)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier(ctx)
+    wall = time.perf_counter() - t0
+    sums = torch.tensor([int(d_cnt.sum().item()), int(d_found.sum().item()), lf_local], dtype=torch.int64, device=dev)
+    seen = [[0, ctx.local_rank, ctx.local_rank]]
+    head = None
+    if dist is not None:
+        tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+        dist.all_reduce(sums)
+        seen = ranks_seen(dist, dev, ctx.local_rank, ctx.local_rank if not ctx.dry else -1)
+        sizes = [shard_range(total, world, r)[1] - shard_range(total, world, r)[0] for r in range(world)]
+        head = gather_concat(dist, d_cnt, sizes, dev, dtype=torch.int64)  # the final gather (counts; hits stay sharded)
+    if ctx.rank != 0:
+        return None
+    if len(seen) != args.gpus or sorted(r[0] for r in seen) != list(range(args.gpus)):
+        raise RuntimeError("ranks seen %r do not match --gpus %d" % (seen, args.gpus))
+    checked = 0
+    if not ctx.dry and not args.no_cpu_baseline:
+        # rank 0's oracle sample: the first patterns of the batch against 8 oracle indexes
+        orc = oracle_module()
+        cores = os.cpu_count() or 1
+        k = min(n, args.segments_check)
+        cnt = d_cnt[:k].cpu().numpy()
+        locs = d_locs[: k * M].cpu().numpy().reshape(k, M)
+        found = d_found[:k].cpu().numpy()
+        off_k = (np.arange(k + 1, dtype=np.int64) * m).astype(np.int32)
+        exp_c = np.zeros(k, np.int64)
+        exp_l = np.zeros((k, M), np.int64)
+        exp_f = np.zeros(k, np.int32)
+        bs = bases.cpu().numpy()
+        for s in range(K):
+            o = orc.OracleFmIndex.read(fms[s].write(False))
+            oc, _ = o.count_batch(pat[: k * m], off_k, threads=cores)
+            exp_c += oc
+            ol, of, _ = o.locate_batch(pat[: k * m], off_k, M, threads=cores)
+            for j in range(M):
+                sel = np.flatnonzero((of > j) & (exp_f < M))
+                exp_l[sel, exp_f[sel]] = ol[sel, j].astype(np.int64) + int(bs[s])
+                exp_f[sel] += 1
+            del o
+        live = np.arange(M)[None, :] < exp_f[:, None]
+        if not ((cnt == exp_c).all() and (found == exp_f).all() and (locs[live] == exp_l[live]).all()):
+            raise RuntimeError("segment-set results differ from the oracle sample")
+        if head is not None and not (head[:k] == exp_c).all():
+            raise RuntimeError("gathered counts differ from the oracle sample")
+        checked = k
+    out = {
+        "metric": "patterns/sec, count()+locate() of one 8M x 8-char batch over a 2 GiB log text as 8 segment indexes",
+        "value": None if ctx.dry else total * args.steps / wall,
+        "unit": "patterns/s",
+        "lf_steps_per_sec_count_stage": None if ctx.dry else int(sums[2].item()) * args.steps / wall,
+        "n_gpus": world,
+        "ranks_seen": seen,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": wall * 1e3 / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "int32",
+        "data": "synthetic",
+        "config": {"workload": "count() + locate(maxMatches %d) of ONE batch of %d random %d-char patterns over %d segment "
+                               "indexes of <= 2^%d chars (sampleRate %d), images broadcast to every GPU, batch sharded x%d "
+                               "(BASELINE.json configs[4])" % (M, total, m, K, args.segment_log2, args.sample_rate, world),
+                   "segments": K, "patterns_total": total, "pattern_len": m, "max_matches": M, "image_bytes_per_gpu": image_bytes,
+                   "count_checksum_all_ranks": int(sums[0].item()), "hits_all_ranks": int(sums[1].item()),
+                   "patterns_checked_vs_oracle": checked},
+        "roofline": None,
+        "cpu_baseline": None,
+    }
+    if ctx.dry:
+        out["dry_run"] = True
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--workload", choices=["count", "segments"], default="count")
+    ap.add_argument("--text-log2", type=int, default=28, help="log2 of the text length in chars (28 = 256 MiB)")
+    ap.add_argument("--patterns", type=int, default=1 << 20, help="patterns per GPU and batch (workload count)")
+    ap.add_argument("--batches", type=int, default=4, help="distinct batches rotating through the timed loop")
+    ap.add_argument("--pattern-len", type=int, default=8)
+    ap.add_argument("--sample-rate", type=int, default=32)
+    ap.add_argument("--segments", type=int, default=8)
+    ap.add_argument("--segment-log2", type=int, default=28)
+    ap.add_argument("--patterns-total", type=int, default=1 << 23, help="patterns of the one batch (workload segments)")
+    ap.add_argument("--segments-check", type=int, default=20000, help="patterns of rank 0's shard checked against 8 oracle indexes")
+    ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of single-thread oracle time for cpu_baseline")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every oracle leg (profiling runs)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip configs[2] / [3]")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU-only rehearsal of the launch / broadcast / shard / gather plumbing over gloo: no queries, no numbers")
+    ap.add_argument("--cache-dir", default=os.environ.get("FMX_CACHE", "/tmp/fmx_cache"))
+    args = ap.parse_args()
+
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and not launched:
+        sys.exit(self_launch(args, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log("[bench] WORLD_SIZE=%d but --gpus %d: refusing to run a mislabelled benchmark" % (world, args.gpus))
+        sys.exit(2)
+
+    import torch  # before the package: whichever HIP runtime is loaded first serves both (tests/conftest.py)
+
+    import index4j_amd as ia
+
+    ctx = Ctx()
+    ctx.ia, ctx.torch, ctx.dry = ia, torch, args.dry_run
+    ctx.world, ctx.rank = world, int(os.environ.get("RANK", "0"))
+    ctx.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not ctx.dry:
+        if not torch.cuda.is_available() or ia.lib.fmx_device_count() < 1:
+            raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+        if ctx.local_rank >= torch.cuda.device_count():  # launcher that gives every rank its own visible-device mask
+            ctx.local_rank = 0
+        torch.cuda.set_device(ctx.local_rank)
+        ctx.dev = torch.device("cuda", ctx.local_rank)
+    else:
+        ctx.dev = torch.device("cpu")
+    ctx.dist = None
+    if launched:  # also at WORLD_SIZE 1: the same RCCL code path (broadcast, scatter, attach, gather) as at 8
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if ctx.dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=ctx.dev)
+        ctx.dist = dist
+    try:
+        out = run_count(ctx, args) if args.workload == "count" else run_segments(ctx, args)
+        if ctx.rank == 0:
+            print(json.dumps(out), flush=True)
+    finally:
+        if ctx.dist is not None:
+            ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

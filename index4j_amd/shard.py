@@ -1,7 +1,7 @@
 """Multi-GPU plumbing: pattern batches shard embarrassingly (every query is an independent read of
 an immutable index, FM:82 @ThreadSafe), so the only collectives are the one-off broadcast of the
-index blob and an optional gather of results.  One process per GPU; backend "nccl" is RCCL on ROCm
-(xGMI); the CPU test-suite runs the same code over gloo."""
+index blob, the hand-out of the pattern shards and an optional gather of results.  One process per GPU;
+backend "nccl" is RCCL on ROCm (xGMI); the CPU test-suite runs the same code over gloo."""
 import numpy as np
 
 
@@ -29,17 +29,52 @@ def broadcast_blob(dist, blob_host, device, src=0):
     return buf
 
 
-def gather_concat(dist, local, counts_per_rank, device, dst=0):
-    """gather variable-length int32 shards onto `dst` in rank order (the final 'gather' of the north star)"""
+def scatter_rows(dist, rows_host, row_len, total_rows, device, dtype, src=0):
+    """hand out a (total_rows, row_len) array that lives on `src` in contiguous shards (shard_range): every rank
+    gets its rows as a torch tensor on `device`.  One collective (scatter of equal, padded shards)."""
+    import torch
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = [shard_range(total_rows, world, r)[1] - shard_range(total_rows, world, r)[0] for r in range(world)]
+    mx = max(sizes) if sizes else 0
+    out = torch.zeros((mx, row_len), dtype=dtype, device=device)
+    parts = None
+    if rank == src:
+        full = torch.from_numpy(np.ascontiguousarray(rows_host).reshape(total_rows, row_len))
+        parts = []
+        for r in range(world):
+            lo, hi = shard_range(total_rows, world, r)
+            t = torch.zeros((mx, row_len), dtype=dtype, device=device)
+            t[: hi - lo] = full[lo:hi].to(device=device, dtype=dtype)
+            parts.append(t)
+    dist.scatter(out, parts, src=src)
+    return out[: sizes[rank]].contiguous()
+
+
+def gather_concat(dist, local, counts_per_rank, device, dst=0, dtype=None):
+    """gather variable-length shards onto `dst` in rank order (the final 'gather' of the north star)"""
     import torch
 
     world, rank = dist.get_world_size(), dist.get_rank()
     mx = max(counts_per_rank)
-    pad = torch.zeros(mx, dtype=torch.int32, device=device)
-    src = local if isinstance(local, torch.Tensor) else torch.as_tensor(np.asarray(local), dtype=torch.int32)
-    pad[: len(local)] = src.to(device=device, dtype=torch.int32)
-    out = [torch.zeros(mx, dtype=torch.int32, device=device) for _ in range(world)]
+    src = local if isinstance(local, torch.Tensor) else torch.as_tensor(np.asarray(local))
+    if dtype is None:
+        dtype = src.dtype if src.dtype in (torch.int32, torch.int64) else torch.int32
+    pad = torch.zeros(mx, dtype=dtype, device=device)
+    pad[: len(local)] = src.to(device=device, dtype=dtype)
+    out = [torch.zeros(mx, dtype=dtype, device=device) for _ in range(world)]
     dist.all_gather(out, pad)
     if rank != dst:
         return None
     return np.concatenate([out[r][: counts_per_rank[r]].cpu().numpy() for r in range(world)])
+
+
+def ranks_seen(dist, device, local_rank, device_index):
+    """[(rank, local_rank, device index)] of every process that joined, gathered over the backend itself —
+    a line printed by rank 0 then proves how many GPUs really took part"""
+    import torch
+
+    me = torch.tensor([dist.get_rank(), local_rank, device_index], dtype=torch.int64, device=device)
+    out = [torch.zeros(3, dtype=torch.int64, device=device) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, me)
+    return [[int(v) for v in t.cpu().tolist()] for t in out]

@@ -18,7 +18,7 @@ def _worker(rank, world, port, q):
 
     import hostsim
     import index4j_amd as ia
-    from index4j_amd.shard import broadcast_blob, gather_concat, shard_range
+    from index4j_amd.shard import broadcast_blob, gather_concat, scatter_rows, shard_range
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -73,3 +73,41 @@ def test_shard_range_partitions():
             assert parts[0][0] == 0 and parts[-1][1] == n
             assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in parts) - min(b - a for a, b in parts) <= 1
+
+
+def _run_bench(extra, env_extra=None, timeout=600):
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    env["FMX_CACHE"] = os.path.join("/tmp", "fmx_cache_test_%d" % os.getpid())
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--text-log2", "16", "--patterns", "3001",
+                        "--patterns-total", "5003", "--segment-log2", "14", "--segments", "3", "--batches", "2", "--steps", "2",
+                        "--warmup", "1"] + extra, capture_output=True, text=True, env=env, timeout=timeout)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r.returncode, (json.loads(line[-1]) if line else None), r.stderr
+
+
+def test_bench_launches_itself_and_reports_the_ranks_that_really_ran():
+    """bench.py's own N>1 code path, rehearsed on CPU over gloo (--dry-run: launch, index build on rank 0, image
+    broadcast, one batch handed out in shards, gather, JSON line — no queries): `--gpus 2` without a launcher starts
+    torch.distributed.run as a child, and the line carries the ranks that joined"""
+    rc, out, err = _run_bench(["--gpus", "2"])
+    assert rc == 0, err[-2000:]
+    assert out["dry_run"] and out["n_gpus"] == 2 and sorted(r[0] for r in out["ranks_seen"]) == [0, 1]
+    assert out["value"] is None and out["scaling"] == "weak"
+    rc, out, err = _run_bench(["--gpus", "2", "--workload", "segments"])
+    assert rc == 0, err[-2000:]
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["patterns_total"] == 5003
+    assert sorted(r[0] for r in out["ranks_seen"]) == [0, 1]
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    rc, out, err = _run_bench(["--gpus", "2"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0",
+                                                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
+    assert rc == 2 and out is None and "mislabelled" in err
+    rc, out, err = _run_bench(["--gpus", "1"])
+    assert rc == 0 and out["n_gpus"] == 1 and out["ranks_seen"] == [[0, 0, 0]]
