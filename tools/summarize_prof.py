@@ -34,10 +34,18 @@ def pmc_json(root, path):
     per = {k: {} for k in KERNELS}
     for sub in ("pmc_fetch", "pmc_tcc", "pmc_sq", "pmc_tcp"):
         for f in find(os.path.join(root, sub), "*counter_collection.csv"):
-            agg = defaultdict(lambda: defaultdict(list))
-            for r in csv.DictReader(open(f)):
+            rows = list(csv.DictReader(open(f)))
+            # the run also launches k_count / k_plan_* on the secondary configs' smaller batches: only the dispatches of
+            # the headline batch (the largest grid of each kernel) count
+            biggest = defaultdict(int)
+            for r in rows:
                 for key, needle in KERNELS.items():
                     if needle in r.get("Kernel_Name", ""):
+                        biggest[key] = max(biggest[key], int(r.get("Grid_Size") or 0))
+            agg = defaultdict(lambda: defaultdict(list))
+            for r in rows:
+                for key, needle in KERNELS.items():
+                    if needle in r.get("Kernel_Name", "") and int(r.get("Grid_Size") or 0) == biggest[key]:
                         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
             for key, ctrs in agg.items():
                 for c, v in ctrs.items():
@@ -92,9 +100,13 @@ def main():
     for sub in ("pmc_fetch", "pmc_tcc", "pmc_sq", "pmc_tcp"):
         for f in find(os.path.join(root, sub), "*counter_collection.csv"):
             rows = list(csv.DictReader(open(f)))
-            agg = defaultdict(lambda: defaultdict(list))
+            biggest = defaultdict(int)
             for r in rows:
-                agg[r.get("Kernel_Name", "")][r.get("Counter_Name", "")].append(float(r.get("Counter_Value", 0)))
+                biggest[r.get("Kernel_Name", "")] = max(biggest[r.get("Kernel_Name", "")], int(r.get("Grid_Size") or 0))
+            agg = defaultdict(lambda: defaultdict(list))
+            for r in rows:  # per kernel: the dispatches with its largest grid (the headline batch, not the secondary legs')
+                if int(r.get("Grid_Size") or 0) == biggest[r.get("Kernel_Name", "")]:
+                    agg[r.get("Kernel_Name", "")][r.get("Counter_Name", "")].append(float(r.get("Counter_Value", 0)))
             print("\n## counters (%s)" % os.path.relpath(f, root))
             for name, ctrs in agg.items():
                 if "k_" not in name:
