@@ -7,6 +7,7 @@
  */
 #include <jni.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "fmx.h"
 
@@ -21,6 +22,27 @@ static void throw_lib_error(JNIEnv *env, int rc) {
         msg = "Input has more than 32767 different symbols";
     }
     (*env)->ThrowNew(env, (*env)->FindClass(env, cls), msg ? msg : "libfmx error");
+}
+
+/* raw pointers only cross into libfmx after the Java arrays have been measured against what the call will touch */
+static int bad_args(JNIEnv *env, const char *what) {
+    (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/IllegalArgumentException"), what);
+    return 1;
+}
+static int too_short(JNIEnv *env, jarray a, jlong need, const char *what) {
+    if (a == NULL || (jlong)(*env)->GetArrayLength(env, a) < need) return bad_args(env, what);
+    return 0;
+}
+/* offsets has n + 1 entries, starts at 0, never decreases and ends inside chars */
+static int bad_patterns(JNIEnv *env, jcharArray chars, jintArray offsets, jint n) {
+    if (n < 0) return bad_args(env, "negative batch size");
+    if (too_short(env, offsets, (jlong)n + 1, "offsets shorter than n + 1") || chars == NULL) return 1;
+    jint *po = (*env)->GetIntArrayElements(env, offsets, NULL);
+    jsize n_chars = (*env)->GetArrayLength(env, chars);
+    int bad = po[0] != 0 || po[n] > n_chars;
+    for (jint i = 0; i < n && !bad; ++i) bad = po[i + 1] < po[i];
+    (*env)->ReleaseIntArrayElements(env, offsets, po, JNI_ABORT);
+    return bad ? bad_args(env, "pattern offsets are not a partition of chars") : 0;
 }
 
 JNIEXPORT jlong JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeLoad(JNIEnv *env, jclass c, jbyteArray ser, jint device) {
@@ -71,6 +93,9 @@ JNIEXPORT jint JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeAlphabetLength
 JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeCountBatch(JNIEnv *env, jclass c, jlong h, jcharArray chars,
                                                                             jintArray offsets, jint n, jintArray counts,
                                                                             jintArray status) {
+    if (bad_patterns(env, chars, offsets, n) || too_short(env, counts, n, "counts shorter than n") ||
+        too_short(env, status, n, "status shorter than n"))
+        return;
     jchar *pc = (*env)->GetCharArrayElements(env, chars, NULL);
     jint *po = (*env)->GetIntArrayElements(env, offsets, NULL);
     jint *pn = (*env)->GetIntArrayElements(env, counts, NULL);
@@ -88,6 +113,10 @@ JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeLocateBatch(JN
                                                                              jintArray offsets, jint n, jint maxMatches,
                                                                              jintArray locations, jint locCap,
                                                                              jintArray found, jintArray status) {
+    if (bad_patterns(env, chars, offsets, n) || locCap < 0 ||
+        too_short(env, locations, (jlong)n * locCap, "locations shorter than n * locCap") ||
+        too_short(env, found, n, "found shorter than n") || too_short(env, status, n, "status shorter than n"))
+        return;
     jchar *pc = (*env)->GetCharArrayElements(env, chars, NULL);
     jint *po = (*env)->GetIntArrayElements(env, offsets, NULL);
     jint *pl = (*env)->GetIntArrayElements(env, locations, NULL);
@@ -107,6 +136,10 @@ JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeExtractBatch(J
                                                                               jintArray stop, jint n, jcharArray dst,
                                                                               jint dstLen, jint offset, jintArray outLen,
                                                                               jintArray status) {
+    if (n < 0 || dstLen < 0 || too_short(env, start, n, "start shorter than n") || too_short(env, stop, n, "stop shorter than n") ||
+        too_short(env, dst, (jlong)n * dstLen, "dst shorter than n * dstLen") ||
+        too_short(env, outLen, n, "outLen shorter than n") || too_short(env, status, n, "status shorter than n"))
+        return;
     jint *pa = (*env)->GetIntArrayElements(env, start, NULL);
     jint *pb = (*env)->GetIntArrayElements(env, stop, NULL);
     jchar *pd = (*env)->GetCharArrayElements(env, dst, NULL);
@@ -125,6 +158,10 @@ JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeExtractBatch(J
 JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeExtractBoundaryBatch(
     JNIEnv *env, jclass c, jlong h, jintArray from, jint n, jchar boundary, jint mode, jcharArray dst, jint dstLen,
     jint offset, jintArray outLen, jintArray status, jintArray aux) {
+    if (n < 0 || dstLen < 0 || too_short(env, from, n, "from shorter than n") ||
+        too_short(env, dst, (jlong)n * dstLen, "dst shorter than n * dstLen") || too_short(env, outLen, n, "outLen shorter than n") ||
+        too_short(env, status, n, "status shorter than n") || too_short(env, aux, n, "aux shorter than n"))
+        return;
     jint *pa = (*env)->GetIntArrayElements(env, from, NULL);
     jchar *pd = (*env)->GetCharArrayElements(env, dst, NULL);
     jint *pl = (*env)->GetIntArrayElements(env, outLen, NULL);
@@ -146,6 +183,14 @@ JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeLocatePipeline
     JNIEnv *env, jclass c, jlong h, jcharArray chars, jintArray offsets, jint n, jint maxMatches, jint mode, jchar boundary,
     jint rowLength, jintArray locations, jintArray found, jcharArray rows, jintArray outLen, jintArray status,
     jintArray hitStatus, jintArray hitAux) {
+    const jlong slots = (jlong)n * maxMatches;
+    if (bad_patterns(env, chars, offsets, n) || maxMatches < 1 || rowLength < 0 ||
+        too_short(env, locations, slots, "locations shorter than n * maxMatches") || too_short(env, found, n, "found shorter than n") ||
+        too_short(env, rows, slots * rowLength, "rows shorter than n * maxMatches * rowLength") ||
+        too_short(env, outLen, slots, "outLen shorter than n * maxMatches") || too_short(env, status, n, "status shorter than n") ||
+        too_short(env, hitStatus, slots, "hitStatus shorter than n * maxMatches") ||
+        too_short(env, hitAux, slots, "hitAux shorter than n * maxMatches"))
+        return;
     jchar *pc = (*env)->GetCharArrayElements(env, chars, NULL);
     jint *po = (*env)->GetIntArrayElements(env, offsets, NULL);
     jint *pl = (*env)->GetIntArrayElements(env, locations, NULL);
@@ -178,10 +223,20 @@ JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeLocatePipeline
 JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeCountSegments(JNIEnv *env, jclass c, jlongArray handles,
                                                                                jcharArray chars, jintArray offsets, jint n,
                                                                                jlongArray counts, jintArray status) {
+    if (handles == NULL || bad_patterns(env, chars, offsets, n) || too_short(env, counts, n, "counts shorter than n") ||
+        too_short(env, status, n, "status shorter than n"))
+        return;
     jsize k = (*env)->GetArrayLength(env, handles);
+    if (k < 1) {
+        bad_args(env, "no segments");
+        return;
+    }
+    const fmx_index **segs = (const fmx_index **)malloc((size_t)k * sizeof *segs);  /* any number of segments */
+    if (!segs) {
+        (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/OutOfMemoryError"), "segment table");
+        return;
+    }
     jlong *ph = (*env)->GetLongArrayElements(env, handles, NULL);
-    const fmx_index *segs[64];
-    if (k > 64) k = 64;
     for (jsize i = 0; i < k; ++i) segs[i] = (const fmx_index *)(intptr_t)ph[i];
     jchar *pc = (*env)->GetCharArrayElements(env, chars, NULL);
     jint *po = (*env)->GetIntArrayElements(env, offsets, NULL);
@@ -189,6 +244,7 @@ JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeCountSegments(
     jint *ps = (*env)->GetIntArrayElements(env, status, NULL);
     int rc = fmx_count_segments(segs, (int32_t)k, (const uint16_t *)pc, (const int32_t *)po, n, (int64_t *)pn, NULL,
                                 (int32_t *)ps);
+    free(segs);
     (*env)->ReleaseLongArrayElements(env, handles, ph, JNI_ABORT);
     (*env)->ReleaseCharArrayElements(env, chars, pc, JNI_ABORT);
     (*env)->ReleaseIntArrayElements(env, offsets, po, JNI_ABORT);
