@@ -174,6 +174,15 @@ public final class GpuFmIndex implements AutoCloseable {
         return counts;
     }
 
+    /**
+     * FmIndex.write(...) of this index as libfmx emits it (fmx_save): with {@code framed} the ObjectOutputStream form
+     * Serialization.writeToByteArray produces (SER:67-79), else the bare DataOutput stream.  Readable by
+     * Serialization.readFromByteArray(FmIndex::read, bytes).
+     */
+    public byte[] toSerialized(boolean framed) {
+        return nativeSave(handle, framed);
+    }
+
     @Override
     public void close() {
         if (handle != 0) {
@@ -229,6 +238,8 @@ public final class GpuFmIndex implements AutoCloseable {
     }
 
     private static native long nativeLoad(byte[] serialized, int device) throws IOException;
+
+    private static native byte[] nativeSave(long handle, boolean framed);
 
     private static native long nativeBuild(char[] text, int sampleRate, boolean enableExtraction, int device,
             boolean buildOnGpu);

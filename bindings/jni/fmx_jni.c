@@ -1,6 +1,7 @@
 /*
  * fmx_jni.c — JNI glue between com.dynatrace.fm.gpu.GpuFmIndex and libfmx.so (include/fmx.h).
- * SOURCE ONLY: never compiled here (no JDK / jni.h in the build image).  Build on a JDK host with
+ * SOURCE ONLY: never compiled against a JDK here (none in the build image; only a syntax pass against a throw-away
+ * stub of jni.h outside the repository).  Build on a JDK host with bindings/build.sh, or by hand:
  *   cc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude \
  *      bindings/jni/fmx_jni.c -Lindex4j_amd -lfmx -o libfmx_jni.so
  * Java `char` is an unsigned 16-bit UTF-16 code unit == the uint16_t the C ABI takes; `int` == int32_t.
@@ -58,6 +59,21 @@ JNIEXPORT jlong JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeLoad(JNIEnv *
         return 0;
     }
     return (jlong)(intptr_t)idx;
+}
+
+/* FmIndex.write bytes of the index (fmx_save), framed like Serialization.writeToByteArray or bare */
+JNIEXPORT jbyteArray JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeSave(JNIEnv *env, jclass c, jlong h, jboolean framed) {
+    uint8_t *buf = NULL;
+    size_t len = 0;
+    int rc = fmx_save((const fmx_index *)(intptr_t)h, framed ? 1 : 0, &buf, &len);
+    if (rc != FMX_OK) {
+        throw_lib_error(env, rc);
+        return NULL;
+    }
+    jbyteArray out = len <= 0x7fffffff ? (*env)->NewByteArray(env, (jsize)len) : NULL;
+    if (out) (*env)->SetByteArrayRegion(env, out, 0, (jsize)len, (const jbyte *)buf);
+    fmx_free_buffer(buf);
+    return out;
 }
 
 /* buildOnGpu: the constructor's suffix-array stage (FM:329-394) runs on `device` — same index, byte for byte */
