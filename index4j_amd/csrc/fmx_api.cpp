@@ -321,6 +321,10 @@ int fmx_set_option(const char *name, int value) {
         fmx::set_map_fast(value != 0);
         return FMX_OK;
     }
+    if (name && !strcmp(name, "inv_fast")) {  // 0: images flattened from now on walk inverseSelect the reference's way
+        fmx::set_inv_fast(value != 0);
+        return FMX_OK;
+    }
     if (!name || fmx::set_option(name, value)) return fail(FMX_E_ARG, "unknown option or bad value");
     return FMX_OK;
 }

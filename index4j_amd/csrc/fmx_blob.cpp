@@ -41,7 +41,7 @@ bool flatten_rrr(Arena &A, const RrrModel &r, RrrDesc &d, std::string &err) {
     d.length = r.length;
     d.total_ones = r.total_ones;
     d.sample = r.sample_size;
-    d.pad = 0;
+    d.node_len = 0;
     const size_t rec_off = A.alloc((size_t)n_rec * sizeof(RrrRecord) + 64);
     d.off_rec = off8(rec_off);
     uint64_t ones = 0, obits = 0;
@@ -86,7 +86,7 @@ bool expanded_reserve(Arena &A, const RrrModel &r, RrrDesc &d, ExpandJob &job, s
     d.length = r.length;
     d.total_ones = r.total_ones;
     d.sample = r.sample_size;
-    d.pad = 0;
+    d.node_len = 0;
     d.off_bits = 0;
     job.r = &r;
     job.n_cells = n_cells;
@@ -152,6 +152,116 @@ size_t put_packed(Arena &A, const PackedVec &v) {
     return off;
 }
 
+
+// ---- inverseSelect section (fmx_blob.hpp: InvHdr, NodeRec) --------------------------------------------------------
+// One block's tree: every leaf's canonical code is walked with the arithmetic of WFBB:1386-1493 (the device header's
+// TreeWalk functions, run here on the host), the bits coming from the code instead of the bit vector.  Every node on
+// the way gets its {A, B}; every (node, bit) its child.  Returns false when the header does not describe a walk this
+// table can stand for (the block then keeps the reference's own route).
+struct InvBlockTable {
+    std::vector<NodeRec> nodes;
+    std::vector<uint8_t> seen;  // bit 0 / 1: child[0] / child[1] filled
+};
+inline uint64_t inv_internal_half(uint32_t idx, uint32_t a, uint32_t b) {
+    return (uint64_t)idx | ((uint64_t)a << 16) | ((uint64_t)b << 40);
+}
+inline uint64_t inv_leaf_half(uint32_t symbol, uint32_t folded) { return ((uint64_t)symbol << 16) | ((uint64_t)folded << 32); }
+
+bool build_inverse_block(const uint8_t *var, int64_t var_len, const BlockHeader &bh, int32_t cur_block_size, int sigma,
+                         const SbcEntry *sbc_row, InvBlockTable &out, uint32_t &root_a, uint32_t &root_b) {
+    const int h = bh.tree_height, n_leaves = (int)bh.sigma + 1;
+    if (h < 1 || h > 30 || n_leaves < 2 || bh.var_off < 0) return false;
+    const int64_t hdr = bh.var_off, leaves = hdr + (int64_t)(h - 1) * 4;
+    const int64_t second0 = (int64_t)(h - 1) * 4 + (int64_t)n_leaves * 5;
+    if (hdr + second0 + (int64_t)(n_leaves - 1) * 2 > var_len) return false;
+    if (((uint32_t)bh.bv_offset | (uint32_t)bh.bv_rank) >> 24) return false;
+    const uint32_t counts0 = ld16(var + hdr + second0);
+    const int n_nodes = n_leaves - 1;
+    out.nodes.assign((size_t)n_nodes, NodeRec{{0, 0}});
+    out.seen.assign((size_t)n_nodes, 0);
+    root_a = (uint32_t)bh.bv_offset;
+    root_b = (uint32_t)bh.bv_rank;
+    for (int i = 0; i < n_leaves; ++i) {
+        const uint8_t *lp = var + leaves + (int64_t)i * 5;
+        const uint32_t symbol = ld16(lp), rank_block = ld24(lp + 2);
+        if ((int)symbol >= sigma) return false;
+        uint32_t code = 0;
+        int32_t len = 0;
+        wt_restore_code((uint32_t)i, var + hdr, h, ld_quad(var + hdr), code, len);  // WFBB:250-278
+        if (len < 1 || len > h || len > 31) return false;
+        TreeWalk t;
+        t.bv_rank = bh.bv_rank;
+        t.bv_offset = bh.bv_offset;
+        t.internal_nodes = 1;
+        t.left_siblings = 0;
+        t.left_total_bv = 0;
+        t.node_bv_size = cur_block_size;
+        t.depth_total_bv = t.node_bv_size;
+        t.node_rank = 0;
+        t.hdr = var + hdr;
+        t.second = (uint32_t)second0;
+        t.level = 0;
+        int32_t left_ones = 0, node_ones = (int32_t)counts0, level_ones = (int32_t)counts0;
+        int64_t level_base = 0;  // index of the first internal node of the current level
+        int64_t cur = 0;         // the node the walk stands on
+        uint32_t walked = 0;     // the bits read so far (inverseSelect's `code`)
+        for (int32_t depth = 0;; ++depth) {
+            if (depth >= len) return false;  // the walk goes deeper than the leaf's code
+            const bool bit = (code >> (len - depth - 1)) & 1u;
+            const int32_t internal_here = t.internal_nodes;
+            t.bv_rank += level_ones;
+            walked = (walked << 1) | (bit ? 1u : 0u);
+            tree_descend(t, bit, 0, node_ones);
+            bool leaf_child = true;
+            if (depth + 1 < h) {  // WFBB:1480-1489
+                if ((int64_t)t.level + 4 > (int64_t)(h - 1) * 4) return false;
+                const int32_t next_leaf_count = tree_next_level_entry(t, ld32u(t.hdr + t.level));
+                if (t.left_siblings >= next_leaf_count) {
+                    t.left_siblings -= next_leaf_count;
+                    leaf_child = false;
+                }
+            }
+            uint64_t half;
+            int64_t child = -1;
+            if (leaf_child) {
+                if (depth + 1 != len) return false;
+                // WFBB:232-248 computeSymbolFromBlockHeader must land on this very leaf
+                uint32_t block_c = 0, temp_code = 0;
+                for (int32_t k = 1; k < len; ++k) {
+                    const uint32_t level_leaf_count = ld32u(var + hdr + 4 * (k - 1)) & 0xffffu;
+                    temp_code += level_leaf_count;
+                    block_c += level_leaf_count;
+                    temp_code <<= 1;
+                }
+                block_c += walked - temp_code;
+                if (block_c != (uint32_t)i) return false;
+                half = inv_leaf_half(symbol, (uint32_t)sbc_row[symbol].rank + rank_block);
+            } else {
+                if (depth + 1 >= len) return false;
+                if (t.internal_nodes <= 0 || t.left_siblings < 0 || t.left_siblings >= t.internal_nodes ||
+                    hdr + (int64_t)t.second + 2 * (int64_t)t.internal_nodes > var_len)
+                    return false;
+                tree_level_counts(t, left_ones, node_ones, level_ones);
+                child = level_base + internal_here + t.left_siblings;
+                level_base += internal_here;
+                const int64_t a = (int64_t)t.bv_offset + t.left_total_bv, b = (int64_t)t.bv_rank + left_ones;
+                if (child <= cur || child >= n_nodes || a < 0 || b < 0 || (a >> 24) || (b >> 24)) return false;
+                half = inv_internal_half((uint32_t)child, (uint32_t)a, (uint32_t)b);
+            }
+            NodeRec &rec = out.nodes[(size_t)cur];
+            const uint8_t mask = bit ? 2 : 1;
+            if ((out.seen[(size_t)cur] & mask) && rec.child[bit ? 1 : 0] != half) return false;  // two leaves disagree
+            rec.child[bit ? 1 : 0] = half;
+            out.seen[(size_t)cur] |= mask;
+            if (leaf_child) break;
+            cur = child;
+        }
+    }
+    for (int k = 0; k < n_nodes; ++k)
+        if (out.seen[(size_t)k] != 3) return false;  // not a full binary tree
+    return true;
+}
+
 }  // namespace
 
 // a stand-alone RrrVector (fmx_rrr_build): header + value-of-offset table + the vector in its compressed form
@@ -185,6 +295,9 @@ void set_map_by_symbol(int mode) { g_map_by_symbol = mode; }
 // the same answers)
 static std::atomic<int> g_map_fast{1};
 void set_map_fast(int on) { g_map_fast = on; }
+// 0: every block's InvHdr says "take the reference's own route" (tests)
+static std::atomic<int> g_inv_fast{1};
+void set_inv_fast(int on) { g_inv_fast = on; }
 
 int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err) {
     const WfbbModel &w = m.wt;
@@ -277,6 +390,9 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
     std::vector<MapEntry> map_scratch;
     std::vector<PathRec> path_scratch;
     std::vector<uint8_t> var_scratch;
+    std::vector<InvHdr> inv_hdr_scratch;
+    std::vector<NodeRec> inv_node_scratch;
+    InvBlockTable inv_table;
     for (int64_t s = 0; s < n_sb; ++s) {
         const SuperBlockModel &sb = w.sb[(size_t)s];
         SbDesc d;
@@ -443,31 +559,42 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
         if (!sb.var.empty()) memcpy(A.at<uint8_t>(off), sb.var.data(), sb.var.size());
         if (!expanded_reserve(A, sb.rank_support, d.rrr, jobs[(size_t)s], err)) return -8;
         {
-            // leaf section for inverseSelect: per leaf {symbol as reported (run blocks: masked to 8 bits, WFBB:1332),
-            // folded superblock rank of that symbol + the leaf's rank at block start}
-            const size_t leaf_off = A.alloc(4 * sb.var.size() + 64);
-            d.rrr.off_bits = off8(leaf_off);
-            uint8_t *dst = A.at<uint8_t>(leaf_off);
+            // inverseSelect section: InvHdr per block, NodeRec per internal node (fmx_blob.hpp)
             const SbcEntry *sbc_row = A.at<SbcEntry>((size_t)h.off_sbc << 3) + (size_t)s * (size_t)sigma;
-            const uint8_t *var = sb.var.data();
+            const uint8_t *var = var_scratch.data();  // sb.var + 16 guard bytes (filled above)
             const int64_t var_len = (int64_t)sb.var.size();
-            for (size_t b = 0; b < sb.block_headers.size(); ++b) {
+            const size_t n_blk = sb.block_headers.size();
+            std::vector<InvHdr> &hdrs = inv_hdr_scratch;
+            std::vector<NodeRec> &nodes = inv_node_scratch;
+            hdrs.assign(n_blk, InvHdr{kInvSlow, 0, 0, 0});
+            nodes.clear();
+            const bool inv_fast = g_inv_fast != 0;
+            for (size_t b = 0; inv_fast && b < n_blk; ++b) {
                 const BlockHeader &bh = sb.block_headers[b];
                 const int hgt = bh.tree_height, n_leaves = (int)bh.sigma + 1;
                 if (hgt < 0 || n_leaves <= 0 || bh.var_off < 0) continue;
-                const int64_t leaves = (int64_t)bh.var_off + (hgt > 0 ? (int64_t)(hgt - 1) * 4 : 0);
-                if (leaves + (int64_t)n_leaves * 5 > var_len) continue;
-                if (4 * (int64_t)bh.var_off + 8 * (int64_t)n_leaves > 4 * var_len + 56) continue;
-                for (int i = 0; i < n_leaves; ++i) {
-                    const uint8_t *lp = var + leaves + (int64_t)i * 5;
-                    int symbol = (int)lp[0] | ((int)lp[1] << 8);
-                    if (hgt == 0) symbol &= 0xff;  // Q1
-                    const uint32_t rank_block = (uint32_t)lp[2] | ((uint32_t)lp[3] << 8) | ((uint32_t)lp[4] << 16);
-                    const uint32_t folded = (symbol < sigma ? (uint32_t)sbc_row[symbol].rank : 0u) + rank_block;
-                    const uint64_t v = ((uint64_t)folded << 32) | (uint64_t)(uint32_t)symbol;
-                    memcpy(dst + 4 * (size_t)bh.var_off + 8 * (size_t)i, &v, 8);
+                if (hgt == 0) {  // WFBB:1329-1355
+                    if ((int64_t)bh.var_off + 5 > var_len) continue;
+                    const uint8_t *lp = var + bh.var_off;
+                    const uint32_t symbol = ld16(lp), masked = symbol & 0xffu, rank_block = ld24(lp + 2);  // Q1
+                    if ((int)masked >= sigma) continue;
+                    hdrs[b] = InvHdr{kInvRun | (masked != symbol ? kInvMasked : 0u), masked,
+                                     (uint32_t)sbc_row[masked].rank + rank_block, 0};
+                    continue;
                 }
+                const int64_t block_start = ((int64_t)s << 20) + ((int64_t)b << d.bsl);
+                const int64_t left = w.size - block_start;
+                const int32_t cur_block_size = (int32_t)(left < ((int64_t)1 << d.bsl) ? left : ((int64_t)1 << d.bsl));
+                uint32_t root_a, root_b;
+                if (!build_inverse_block(var, var_len, bh, cur_block_size, sigma, sbc_row, inv_table, root_a, root_b)) continue;
+                hdrs[b] = InvHdr{root_a, root_b, (uint32_t)(n_blk + nodes.size()), (uint32_t)inv_table.nodes.size()};
+                nodes.insert(nodes.end(), inv_table.nodes.begin(), inv_table.nodes.end());
             }
+            d.rrr.node_len = (int32_t)(n_blk + nodes.size());
+            const size_t inv_off = A.alloc((n_blk + nodes.size()) * 16 + 64);
+            d.rrr.off_bits = off8(inv_off);
+            if (n_blk) memcpy(A.at<uint8_t>(inv_off), hdrs.data(), n_blk * sizeof(InvHdr));
+            if (!nodes.empty()) memcpy(A.at<uint8_t>(inv_off) + n_blk * sizeof(InvHdr), nodes.data(), nodes.size() * sizeof(NodeRec));
         }
         *A.at<SbDesc>(sbd_off + (size_t)s * sizeof(SbDesc)) = d;
     }
@@ -638,7 +765,8 @@ int validate_blob(const uint8_t *b, size_t len, std::string &err) {
         if (d.mapping_len != rows * per_row || d.path_len < 0 || d.var_len < 0) return bad("mapping shape");
         if (!inside(d.off_mapping, (uint64_t)d.mapping_len * sizeof(MapEntry) + (uint64_t)d.path_len * sizeof(PathRec) + 32) ||
             !inside(d.off_bh, (uint64_t)d.n_blocks * sizeof(BlockHdr) + 16) || !inside(d.off_var, (uint64_t)d.var_len + 16) ||
-            !cells_ok(d.rrr) || d.rrr.length >= (1 << 24) || !inside(d.rrr.off_bits, 4 * (uint64_t)d.var_len + 64))
+            !cells_ok(d.rrr) || d.rrr.length >= (1 << 24) || d.rrr.node_len < d.n_blocks ||
+            !inside(d.rrr.off_bits, (uint64_t)d.rrr.node_len * 16 + 64))
             return bad("superblock table outside the image");
         for (int c = 0; c < h.wt_sigma; ++c) {
             const int16_t code = sbc[(int64_t)s * h.wt_sigma + c].sbc;
@@ -676,6 +804,31 @@ int validate_blob(const uint8_t *b, size_t len, std::string &err) {
                     return bad("mapping tag");
                 }
             }
+        // inverseSelect section: every walk stays inside its block's records and ends (children lie behind parents)
+        const InvHdr *ih = reinterpret_cast<const InvHdr *>(b + ((uint64_t)d.rrr.off_bits << 3));
+        for (int32_t k = 0; k < d.n_blocks; ++k) {
+            const InvHdr &q = ih[k];
+            if (q.x & kInvSlow) continue;
+            if (q.x & kInvRun) {
+                if (bh[k].tree_height != 0 || q.y >= (uint32_t)h.wt_sigma) return bad("run block record");
+                continue;
+            }
+            if (bh[k].tree_height < 1 || (q.x >> 24) || (q.x & 0xffffffu) > (uint32_t)d.rrr.length || (q.y >> 24))
+                return bad("root record");
+            if (q.w < 1 || q.z < (uint32_t)d.n_blocks || (uint64_t)q.z + q.w > (uint64_t)d.rrr.node_len)
+                return bad("node records outside the section");
+            const NodeRec *nr = reinterpret_cast<const NodeRec *>(ih) + q.z;
+            for (uint32_t n = 0; n < q.w; ++n)
+                for (int c = 0; c < 2; ++c) {
+                    const uint64_t half = nr[n].child[c];
+                    const uint32_t idx = (uint32_t)(half & 0xffffu);
+                    if (idx == 0) {
+                        if (((half >> 16) & 0xffffu) >= (uint64_t)h.wt_sigma) return bad("leaf symbol");
+                    } else if (idx <= n || idx >= q.w || ((half >> 16) & 0xffffffu) > (uint64_t)d.rrr.length) {
+                        return bad("node record");
+                    }
+                }
+        }
         const PathRec *pr = reinterpret_cast<const PathRec *>(me + d.mapping_len);
         for (int32_t k = 0; k < d.path_len; ++k)
             if (pr[k].a > (uint32_t)d.rrr.length || (pr[k].b >> 24)) return bad("path record");

@@ -11,8 +11,8 @@
 //                                    fused into one 8-byte load; row n_sb holds count[] (WFBB:1063-1069)
 //       SbDesc[n_sb]                 one 64-byte sector per superblock header (WFBB:1621-1629)
 //   * per superblock: mapping (MapEntry, 16 B), BlockHeader[] (16 B, as WFBB:1589-1595, the root node's one-count
-//     in the spare top bytes), variable headers (bytes as written at WFBB:742-809, + 16 guard bytes), and its bit
-//     vector as 96-bit cells (BvCell).
+//     in the spare top bytes), variable headers (bytes as written at WFBB:742-809, + 16 guard bytes), its bit
+//     vector as 96-bit cells (BvCell), and the inverseSelect section (InvHdr per block, NodeRec per internal node).
 //   * mapping (WFBB:1628): a present entry holds what the block's header tells about the symbol and where its
 //     path records are (MapEntry below); an ABSENT entry (alphabetSize-1 in the reference) holds d = distance to
 //     the closest block to the right that holds the symbol (or to the end of the superblock).  The reference
@@ -33,7 +33,7 @@
 namespace fmx {
 
 constexpr uint32_t kBlobMagic = 0x31584D46u;  // "FMX1"
-constexpr uint32_t kBlobVersion = 11;
+constexpr uint32_t kBlobVersion = 12;
 
 struct RrrRecord {         // 16 bytes: 16 blocks of 15 bits
     uint32_t ones_before;  // 1-bits in all earlier blocks
@@ -58,14 +58,14 @@ constexpr uint32_t kBvCellBits = 96;
 struct RrrDesc {           // 32 bytes; the first 16 are what a rank needs (one dwordx4 load)
     uint32_t off_rec;      // RrrRecord[n_rec]   (expanded vectors: BvCell[n_rec])
     uint32_t off_bits;     // offsets bit stream, 64-bit words LSB-first (+2 guard words)   (a superblock's expanded
-                           // vector: offset of its leaf section — u64 {symbol, folded rank} per leaf, block b's
-                           // leaves at byte 4 * var_off(b); the sampled-row bitmap: 0)
+                           // vector: offset of its inverseSelect section — InvHdr[n_blocks] + NodeRec[], below; the
+                           // sampled-row bitmap: 0)
     int32_t length;        // RRR:94
     int32_t total_ones;    // RRR:95
     int32_t n_rec;
     int32_t n_blocks;
     int32_t sample;        // RRR:93 sampleSize of the source index (informational)
-    int32_t pad;
+    int32_t node_len;      // a superblock's vector: 16-byte units in its inverseSelect section (else 0)
 };
 
 // One entry of the superblock's symbol -> block mapping (WFBB:461-471), widened from the reference's int16 to
@@ -94,6 +94,36 @@ struct MapEntry {
 struct PathRec {
     uint32_t a, b;
 };
+// The inverseSelect section of a superblock (blob v12): the walk of WFBB:1386-1493 evaluated at flatten time.
+// inverseSelect does not know the symbol in advance, so it cannot use a mapping entry; in the reference (and in
+// blob <= v11) it reads the block header, the level table, and per level two cumulative-count entries before it can
+// address the next node's bits, then the leaf entry, then superBlockRank[symbol].  Everything but the bits themselves
+// depends on (block, code prefix) only.  Per block one InvHdr, per internal node of its tree one NodeRec (both 16
+// bytes, one aligned load); the walk is  InvHdr -> {root cell, root NodeRec} -> {next cell, next NodeRec} -> ...
+//   InvHdr  x = A0[23:0] | flags[31:24]   A0 = bit position of the root node in the superblock's bit vector
+//           y = B0                        one-bits before it
+//           z = index of the block's first NodeRec (root), in 16-byte units from the start of the section
+//           w = number of NodeRecs of the block (internal nodes = leaves - 1)
+//     run block (kInvRun; tree height 0, WFBB:1329-1355):  y = symbol as the reference reports it (masked to 8 bits,
+//           WFBB:1332; kInvMasked is set when that changed it), z = folded superblock rank of that symbol + the block's
+//           rank entry;  the answer is {y, z + index in block}
+//     kInvSlow: the block's header did not pass the flattener's checks (or option inv_fast = 0): the reference's own
+//           route over BlockHdr and the variable-size header bytes
+//   NodeRec = two u64 halves, [0] = child taken on a 0 bit, [1] = on a 1 bit (WFBB:1235-1244):
+//           internal child: idx[15:0] (its NodeRec, relative to the block's root; > the parent's, never 0)
+//                           | A[39:16] | B[63:40]    rank1 inside the node = rankOnes(A + rank in node) - B (WFBB:1389-1393)
+//           leaf child:     0[15:0] | symbol[31:16] | (folded superblock rank of the symbol + the leaf's u24)[63:32]
+//                           (what WFBB:1495-1533 reads from the leaf entry and superBlockRank / hyperBlockRank)
+struct InvHdr {
+    uint32_t x, y, z, w;
+};
+struct NodeRec {
+    uint64_t child[2];
+};
+constexpr uint32_t kInvRun = 0x80000000u;
+constexpr uint32_t kInvMasked = 0x40000000u;
+constexpr uint32_t kInvSlow = 0x20000000u;
+
 constexpr uint32_t kMapSlow = 0xffu;
 constexpr uint32_t kMapAbsent = 0xfeu;
 constexpr uint32_t kMapMaxLen = 16;
@@ -151,6 +181,8 @@ static_assert(sizeof(RrrRecord) == 16, "RrrRecord");
 static_assert(sizeof(BvCell) == 16, "BvCell");
 static_assert(sizeof(MapEntry) == 16, "MapEntry");
 static_assert(sizeof(PathRec) == 8, "PathRec");
+static_assert(sizeof(InvHdr) == 16, "InvHdr");
+static_assert(sizeof(NodeRec) == 16, "NodeRec");
 static_assert(sizeof(SbDesc) == 64, "SbDesc");
 static_assert(sizeof(BlockHdr) == 16, "BlockHdr");
 static_assert(sizeof(SbcEntry) == 8, "SbcEntry");

@@ -693,29 +693,45 @@ FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t positio
 // WFBB:1305-1537: returns the symbol at `position` (< size); *rank = occurrences before it
 // (the reference packs (rank << 32) | symbol and returns the bare symbol when position == 0).
 // (rank_out is FOLDED: C[symbol] + occurrences before `position`, see wt_rank_folded)
-FMX_HD int32_t wt_inverse_select_folded(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t &rank_out,
-                                        int32_t &bsl_out) {
-    // load chain (see wt_rank): {superblock header, RRR view} -> block header -> {level table, first level's
-    // counts, first RRR record} -> offset bits -> ... -> leaf -> superblock rank of the symbol
-    const uint32_t sb_id = position >> 20;
-    const SbDesc &sd = ix.sbd[sb_id];
+// exact_out = false only for a run block whose symbol code is >= 256 (WFBB:1332 masks it to 8 bits, Q1).
+//
+// The block's InvHdr (fmx_blob.hpp) can be requested by the caller ahead of time (`inv_hdr_ptr` depends on the
+// position only): the LF-walks ask for it together with the sampled-row cell they poll before every step.
+struct InvView {
+    RrrView rv;
+    int32_t bsl;
+};
+FMX_HD InvView wt_inv_view(const DevIndex &ix, uint32_t sb_id) {
     Quad head_q, view_q;
     if (ix.sb_cache) {
         head_q = ix.sb_cache[2 * sb_id];
         view_q = ix.sb_cache[2 * sb_id + 1];
     } else {
+        const SbDesc &sd = ix.sbd[sb_id];
         head_q = ld_quad(&sd);
         view_q = ld_quad(&sd.rrr);
         FMX_PIN_QUAD(head_q);
         FMX_PIN_QUAD(view_q);
     }
-    const SbHead sh = sb_head_from(head_q);
-    const RrrView rv = rrr_view_from(view_q);
-    const int32_t bsl = sh.bsl;
-    bsl_out = bsl;
-    const uint32_t block_size = 1u << bsl;
+    InvView v;
+    v.rv = rrr_view_from(view_q);
+    v.bsl = (int32_t)(int16_t)(head_q.x >> 16);
+    return v;
+}
+FMX_HD const InvHdr *wt_inv_hdr_ptr(const DevIndex &ix, const InvView &v, uint32_t position) {
+    return reinterpret_cast<const InvHdr *>(ix.base + ((uint64_t)v.rv.off_bits << 3)) + ((position & 0xfffffu) >> v.bsl);
+}
+
+// the reference's own route (blocks whose InvHdr says kInvSlow): block header, level table, cumulative counts per
+// level, leaf entry, superBlockRank[symbol]
+FMX_HD int32_t wt_inverse_select_reference_route(const DevIndex &ix, uint32_t position, const InvView &v,
+                                                 int32_t &rank_out, bool &exact_out) {
+    const uint32_t sb_id = position >> 20;
+    const SbHead sh = sb_head(ix.sbd[sb_id]);
+    const RrrView &rv = v.rv;
+    const uint32_t block_size = 1u << v.bsl;
     const uint32_t block_index = position & (block_size - 1);
-    const uint32_t block_id = (position & 0xfffffu) >> bsl;
+    const uint32_t block_id = (position & 0xfffffu) >> v.bsl;
     const BlockHdr *bhs = reinterpret_cast<const BlockHdr *>(ix.base + ((uint64_t)sh.off_bh << 3));
     const uint8_t *var = ix.base + ((uint64_t)sh.off_var << 3);
     const Quad bhq = ld_quad(bhs + block_id);
@@ -724,18 +740,13 @@ FMX_HD int32_t wt_inverse_select_folded(const DevIndex &ix, const uint16_t *inv,
     const uint8_t *hdr = var + bh.var_off;
     const uint8_t *leaves = hdr + (tree_height > 0 ? (tree_height - 1) * 4 : 0);  // WFBB:1324-1327
     const SbcEntry *row = ix.sbc + (uint64_t)sb_id * (uint32_t)ix.wt_sigma;
-
-    // The image keeps, per leaf of every block, {symbol as inverseSelect reports it, superblock rank of that symbol
-    // + the leaf's rank at block start}: what the reference reads from the leaf entry and then from
-    // superBlockRank[symbol] (WFBB:1501-1533) is ONE load here.  The table lives at 4 * var_off of the block inside
-    // the superblock's leaf section (view.off_bits carries its offset for the wavelet tree's vectors).
-    const uint8_t *leaf2 = ix.base + ((uint64_t)rv.off_bits << 3) + 4 * (uint64_t)(uint32_t)bh.var_off;
-    (void)leaves;
-    (void)row;
-    if (tree_height == 0) {  // WFBB:1329-1355; the stored symbol is already masked to 8 bits (WFBB:1332, Q1)
-        const uint64_t lf = ld64u(leaf2);
-        rank_out = (int32_t)(lf >> 32) + (int32_t)block_index;
-        return (int32_t)(lf & 0xffffu);
+    exact_out = true;
+    if (tree_height == 0) {  // WFBB:1329-1355
+        const uint64_t leaf = ld64u(leaves);
+        const int32_t c = (int32_t)(leaf & 0xffu);  // WFBB:1332 (Q1)
+        exact_out = (int32_t)(leaf & 0xffffu) == c;
+        rank_out = (c < ix.wt_sigma ? row[c].rank : 0) + (int32_t)((leaf >> 16) & 0xffffffu) + (int32_t)block_index;
+        return c;
     }
 
     const uint32_t second0 = (uint32_t)((tree_height - 1) * 4 + ((int32_t)bh.sigma + 1) * 5);
@@ -805,28 +816,67 @@ FMX_HD int32_t wt_inverse_select_folded(const DevIndex &ix, const uint16_t *inv,
         temp_code <<= 1;
     }
     block_c += code - temp_code;
-    const uint64_t lf = ld64u(leaf2 + 8 * block_c);
-    rank_out = (int32_t)(lf >> 32) + t.node_rank;  // WFBB:1501-1533
-    return (int32_t)(lf & 0xffffu);
+    const uint64_t leaf = ld64u(leaves + 5 * block_c);  // {u16 symbol, u24 rank at block start}, WFBB:1495-1520
+    const int32_t c = (int32_t)(leaf & 0xffffu);
+    rank_out = (c < ix.wt_sigma ? row[c].rank : 0) + (int32_t)((leaf >> 16) & 0xffffffu) + t.node_rank;  // WFBB:1521-1533
+    return c;
+}
+
+// the walk with the block's InvHdr at hand
+FMX_HD int32_t wt_inverse_select_from(const DevIndex &ix, uint32_t position, const InvView &v, const Quad &ihq,
+                                      int32_t &rank_out, bool &exact_out) {
+    const uint32_t block_index = position & ((1u << v.bsl) - 1u);
+    exact_out = true;
+    if (ihq.x & kInvRun) {  // WFBB:1329-1355: the stored symbol is already masked to 8 bits (WFBB:1332, Q1)
+        exact_out = (ihq.x & kInvMasked) == 0;
+        rank_out = (int32_t)ihq.z + (int32_t)block_index;
+        return (int32_t)ihq.y;
+    }
+    if (ihq.x & kInvSlow) return wt_inverse_select_reference_route(ix, position, v, rank_out, exact_out);
+    const RrrView &rv = v.rv;
+    const NodeRec *nodes = reinterpret_cast<const NodeRec *>(ix.base + ((uint64_t)rv.off_bits << 3)) + ihq.z;
+    uint32_t node_b = ihq.y;
+    int32_t pos = (int32_t)(ihq.x & 0xffffffu) + (int32_t)block_index;
+    int32_t node_rank = (int32_t)block_index;
+    Quad nq = ld_quad(nodes), cell = {0, 0, 0, 0};
+    if (rrr_in_range(rv, pos)) cell = ld_quad(bv_cell_ptr(ix.base, rv, (uint32_t)pos));
+    FMX_PIN_QUAD(nq);
+    FMX_PIN_QUAD(cell);
+    FMX_NO_UNROLL
+    for (;;) {  // ends: the flattener / validate_blob guarantee children lie behind their parents
+        bool bit;
+        const int32_t rank1 = bv_rank1_access_cell(rv, cell, pos, bit) - (int32_t)node_b;  // WFBB:1389-1393
+        node_rank = bit ? rank1 : node_rank - rank1;                                        // WFBB:1435-1470
+        const uint32_t lo = bit ? nq.z : nq.x, hi = bit ? nq.w : nq.y;
+        const uint32_t idx = lo & 0xffffu;
+        if (idx == 0) {  // leaf: {symbol, folded superblock rank + rank at block start} (WFBB:1495-1533)
+            rank_out = (int32_t)hi + node_rank;
+            return (int32_t)(lo >> 16);
+        }
+        node_b = hi >> 8;
+        pos = (int32_t)((lo >> 16) | ((hi & 0xffu) << 16)) + node_rank;
+        nq = ld_quad(nodes + idx);
+        if (rrr_in_range(rv, pos)) cell = ld_quad(bv_cell_ptr(ix.base, rv, (uint32_t)pos));
+        FMX_PIN_QUAD(nq);
+        FMX_PIN_QUAD(cell);
+    }
+}
+
+FMX_HD int32_t wt_inverse_select_folded(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t &rank_out,
+                                        int32_t &bsl_out, bool &exact_out) {
+    (void)inv;
+    const InvView v = wt_inv_view(ix, position >> 20);
+    bsl_out = v.bsl;
+    const Quad ihq = ld_quad(wt_inv_hdr_ptr(ix, v, position));
+    return wt_inverse_select_from(ix, position, v, ihq, rank_out, exact_out);
 }
 
 FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t &rank_out) {
     int32_t bsl;
-    const int32_t c = wt_inverse_select_folded(ix, inv, position, rank_out, bsl);
+    bool exact;
+    const int32_t c = wt_inverse_select_folded(ix, inv, position, rank_out, bsl, exact);
     rank_out -= fm_c_or_zero(ix, c);
     return c;
-}
-
-// true when inverseSelect's symbol at `position` is the block's real symbol (false only for a run block
-// whose symbol code is >= 256: WFBB:1332 masks it to 8 bits)
-FMX_HD bool wt_symbol_is_exact(const DevIndex &ix, uint32_t position, int32_t c) {
-    const SbDesc &sd = ix.sbd[position >> 20];
-    const SbHead sh = sb_head(sd);
-    const uint32_t block_id = (position & 0xfffffu) >> sh.bsl;
-    const BlockHdr bh = ld_block_hdr(reinterpret_cast<const BlockHdr *>(ix.base + ((uint64_t)sh.off_bh << 3)) + block_id);
-    if (bh.tree_height != 0) return true;
-    const uint8_t *leaves = ix.base + ((uint64_t)sh.off_var << 3) + bh.var_off;
-    return (int32_t)ld16(leaves) == c;
 }
 
 // ---- FmIndex helpers -----------------------------------------------------------------------
@@ -841,20 +891,23 @@ FMX_HD int32_t fm_map(const DevIndex &ix, uint16_t ch) { return ix.char2code[ch]
 // (Q1, WFBB:1332).  Only then is the second call skipped; every other case runs rank() as the reference
 // does, so all of its quirks (next-block path, Q3) are preserved.  tests/test_fused_lf.py checks the
 // equivalence exhaustively on quirk-heavy inputs.
+FMX_HD int32_t fm_lf_finish(const DevIndex &ix, const uint16_t *inv, int32_t row, int32_t c, int32_t rank_before,
+                            int32_t bsl, bool exact_symbol, int &status, bool &suspect) {
+    const bool same_block = ((uint32_t)row & ((1u << bsl) - 1u)) != 0 && (uint32_t)row <= ix.wt_size;
+    // a run block whose symbol is >= 256 reports a masked symbol: rank(row, masked c) must really be evaluated
+    if (!exact_symbol) suspect = true;  // Q1
+    if (same_block && exact_symbol) return rank_before + 1;
+    return wt_rank_folded(ix, inv, (uint32_t)row, c, status, suspect);
+}
 FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, int32_t &c_out, int &status,
                           bool &suspect) {
     const uint32_t p = (uint32_t)(row - 1);
     int32_t rank_before;
     int32_t bsl_i;
-    const int32_t c = (int32_t)(int16_t)wt_inverse_select_folded(ix, inv, p, rank_before, bsl_i);  // C[c] + rank
+    bool exact_symbol;
+    const int32_t c = (int32_t)(int16_t)wt_inverse_select_folded(ix, inv, p, rank_before, bsl_i, exact_symbol);  // C[c] + rank
     c_out = c;
-    const uint32_t bsl = (uint32_t)bsl_i;
-    const bool same_block = ((uint32_t)row & ((1u << bsl) - 1u)) != 0 && (uint32_t)row <= ix.wt_size;
-    // a run block whose symbol is >= 256 reports a masked symbol: rank(row, masked c) must really be evaluated
-    const bool exact_symbol = ix.wt_sigma <= 256 || wt_symbol_is_exact(ix, p, c);
-    if (!exact_symbol) suspect = true;  // Q1
-    if (same_block && exact_symbol) return rank_before + 1;
-    return wt_rank_folded(ix, inv, (uint32_t)row, c, status, suspect);
+    return fm_lf_finish(ix, inv, row, c, rank_before, bsl_i, exact_symbol, status, suspect);
 }
 FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, int32_t &c_out, int &status) {
     bool suspect = false;
@@ -882,16 +935,41 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
     int32_t j = start + 1 + k;  // FM:527-529
     distance = 0;
     const RrrView sv = {ix.sampled.off_rec, ix.sampled.off_bits, ix.sampled.length, ix.sampled.total_ones};
-    while (!bv_access(ix.base, sv, j - 1, status)) {  // FM:531 (sampledSuffixes.access)
-        int32_t c;
-        j = fm_lf_step(ix, inv, j, c, status);  // FM:532-535
+    // Every round polls sampledSuffixes.access(j - 1) (FM:531) and, if the row is not sampled, runs
+    // inverseSelect(j - 1) (FM:532): the bitmap cell and the block's InvHdr depend on j alone and are requested together.
+    Quad scell = {0, 0, 0, 0};
+    for (;;) {
+        const int32_t p = j - 1;
+        if (p < 0 || p >= sv.length) {  // RrrVector.access throws (RRR:316-323)
+            status = ST_JAVA_AIOOBE;
+            break;
+        }
+        // (p < length == the wavelet tree's size: validate_model / validate_blob)
+        const InvView v = wt_inv_view(ix, (uint32_t)p >> 20);
+        Quad ihq = ld_quad(wt_inv_hdr_ptr(ix, v, (uint32_t)p));
+        scell = ld_quad(bv_cell_ptr(ix.base, sv, (uint32_t)p));
+        FMX_PIN_QUAD(ihq);
+        FMX_PIN_QUAD(scell);
+        bool sampled_row;
+        (void)bv_rank1_access_cell(sv, scell, p, sampled_row);
+        if (sampled_row) break;
+        int32_t rank_before;
+        bool exact, suspect = false;
+        const int32_t c = (int32_t)(int16_t)wt_inverse_select_from(ix, (uint32_t)p, v, ihq, rank_before, exact);
+        j = fm_lf_finish(ix, inv, j, c, rank_before, v.bsl, exact, status, suspect);  // FM:532-535
         ++distance;
         if (distance > ix.length) {  // unreachable on a well-formed index; bounds the walk on a corrupt one
             status = ST_JAVA_AIOOBE;
             break;
         }
     }
-    const int32_t r = bv_rank1(ix.base, sv, j) - 1;                       // FM:541 (sampledSuffixes.rankOnes)
+    // FM:541 sampledSuffixes.rankOnes(j): row j - 1 is sampled and its cell is at hand — rankOnes(j) = rankOnes(j - 1) + 1
+    // (also at j == length, where rankOnes saturates to the total)
+    int32_t r;
+    if (status == ST_OK)
+        r = (int32_t)(scell.x + bv_cell_prefix(scell, (uint32_t)(j - 1) % kBvCellBits));
+    else
+        r = bv_rank1(ix.base, sv, j) - 1;
     return fm_packed_get(ix.suffix_words, r, ix.bw_suffixes) + distance;  // FM:538-542
 }
 

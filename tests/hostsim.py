@@ -29,16 +29,40 @@ def lib():
 def reference_route_index(text, sample_rate, enable_extract=True):
     """an index whose image has NO fast mapping entries: every present entry says 'take the reference's own route',
     so rank() reads the block header and the leaf entry, fixes clamped entries up and rebuilds the canonical code
-    as WFBB:1119-1156 do.  (The image is flattened under option map_fast = 0.)"""
+    as WFBB:1119-1156 do, and NO inverseSelect node records: every block's InvHdr says the same, so inverseSelect
+    walks block header, level table and cumulative counts as WFBB:1305-1537 do.
+    (The image is flattened under options map_fast = 0, inv_fast = 0.)"""
     import index4j_amd as ia
 
     assert ia.lib.fmx_set_option(b"map_fast", 0) == 0
+    assert ia.lib.fmx_set_option(b"inv_fast", 0) == 0
     try:
         f = ia.FmIndex(text, sample_rate, enable_extract, device=None)
-        f.blob()  # flatten now, under the option
+        f.blob()  # flatten now, under the options
     finally:
         ia.lib.fmx_set_option(b"map_fast", 1)
+        ia.lib.fmx_set_option(b"inv_fast", 1)
     return f
+
+
+def inverse_select_block_kinds(blob):
+    """(blocks with node records, run blocks, blocks on the reference's route) of an FM-index image — read from
+    the InvHdr arrays (index4j_amd/csrc/fmx_blob.hpp)"""
+    b = np.frombuffer(blob, np.uint8) if not isinstance(blob, np.ndarray) else blob
+    u32 = lambda off: int(b[off:off + 4].view(np.uint32)[0])
+    i32 = lambda off: int(b[off:off + 4].view(np.int32)[0])
+    n_sb = i32(8 + 8 + 9 * 4)            # BlobHeader.n_sb
+    off_sbdesc = u32(8 + 8 + 12 * 4 + 8 + 6 * 4) << 3
+    tree = run = slow = 0
+    for s in range(n_sb):
+        d = off_sbdesc + 64 * s
+        n_blocks = i32(d + 16)
+        inv = u32(d + 32 + 4) << 3       # SbDesc.rrr.off_bits
+        x = b[inv:inv + 16 * n_blocks].view(np.uint32)[0::4]
+        run += int(((x & 0x80000000) != 0).sum())
+        slow += int(((x & 0x20000000) != 0).sum())
+        tree += int(((x & 0xA0000000) == 0).sum())
+    return tree, run, slow
 
 
 class HostSim:

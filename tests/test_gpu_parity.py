@@ -529,11 +529,13 @@ def test_standalone_rrr_vector_kats_and_random_vs_oracle():
 
 def test_layout_variants_give_the_same_answers():
     """the image has two mapping layouts (rows by global symbol / by superblock code) and the kernels two ways
-    to reach a superblock's header (LDS cache / HBM): every combination against the oracle"""
+    to reach a superblock's header (LDS cache / HBM), inverseSelect two routes (node records / the reference's own
+    walk over the block headers): combinations against the oracle"""
     try:
-        for by_symbol, cache in ((0, 320), (1, 0), (0, 0)):
+        for by_symbol, cache, inv_fast in ((0, 320, 1), (1, 0, 0), (0, 0, 1), (1, 320, 0)):
             assert ia.lib.fmx_set_option(b"map_by_symbol", by_symbol) == 0
             assert ia.lib.fmx_set_option(b"sb_cache_limit", cache) == 0
+            assert ia.lib.fmx_set_option(b"inv_fast", inv_fast) == 0
             check_all(make_gpu, HD[:90_000], 16, random.Random(300 + by_symbol + cache), n_q=80)
         t = ia.synth_log(1 << 21)  # three superblocks, planned batch
         fm = ia.FmIndex(t, 32, True, device=0)
@@ -545,6 +547,7 @@ def test_layout_variants_give_the_same_answers():
     finally:
         ia.lib.fmx_set_option(b"map_by_symbol", -1)
         ia.lib.fmx_set_option(b"sb_cache_limit", 320)
+        ia.lib.fmx_set_option(b"inv_fast", 1)
 
 
 def test_api_edge_cases():

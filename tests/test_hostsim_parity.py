@@ -115,3 +115,23 @@ def test_texts_shorter_than_the_sample_rate():
     rnd = random.Random(21)
     for text, sr in (("A", 2), ("A", 3), ("AB", 3), ("BAA", 3), ("AB", 64), ("hello\nworld", 100)):
         check_all(make_sim, text, sr, rnd, n_q=12)
+
+
+def test_inverse_select_node_records_are_what_runs():
+    """the images the other tests walk answer inverseSelect from node records (InvHdr / NodeRec) in every block; under
+    inv_fast = 0 every block takes the reference's own route — and both give the oracle's answers"""
+    text = HD[:60_000] + "a" * 150_000 + HD[60_000:90_000]  # the run of 'a' gives the BWT run blocks
+    f = ia.FmIndex(text, 8, True, device=None)
+    tree, run, slow = hostsim.inverse_select_block_kinds(f.blob())
+    assert slow == 0 and tree > 0 and run > 0
+    g = hostsim.reference_route_index(text, 8)
+    tree2, run2, slow2 = hostsim.inverse_select_block_kinds(g.blob())
+    assert tree2 == 0 and run2 == 0 and slow2 == tree + run
+    o = orc.OracleFmIndex(text, 8, True)
+    wh = o.wavelet_handle()
+    hf, hg = hostsim.HostSim(f), hostsim.HostSim(g)
+    for pos in range(0, f.getInputLength(), 53):
+        t = orc.lib().orc_wfbb_inverse_select(wh, pos)
+        for h in (hf, hg):
+            c, r = h.wt_inverse_select(pos)
+            assert c == (t & 0xFFFF) and (pos == 0 or r == (t >> 32)), pos
