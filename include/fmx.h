@@ -55,14 +55,18 @@ typedef struct fmx_index fmx_index;
 /* new FmIndexBuilder().setSampleRate(s).setEnableExtraction(b).build(char[])  FMB:34-62 -> FM:155-174.
  * Host-side construction (suffix array, BWT, wavelet/RRR encoding); text = UTF-16 code units. */
 int fmx_build(const uint16_t *text, int32_t n, int32_t sample_rate, int enable_extract, fmx_index **out);
-/* The same index with the suffix-array stage of the constructor (FM:329-394: suffix array, sampled rows, inverse
- * samples, BWT) computed on GPU `device` by prefix doubling; the wavelet tree is still encoded on the host.
- * The suffix array of a terminated text is unique, so the result is byte-identical to fmx_build's (fmx_save
- * gives the same bytes).  Optional statistics: doubling rounds after the initial 4-character sort, and rows
+/* The same index with the middle of the constructor computed on GPU `device`: FM:329-394 (suffix array by prefix
+ * doubling, sampled rows, inverse samples, BWT) and FM:173 — the wavelet tree over the BWT (WFBB:130-154, 362-535,
+ * 570-991) and its RRR vectors (RRR:225-286), encoded in HBM where the BWT lies (alphabets of up to 1,024 codes;
+ * larger ones, and option "wavelet_on_device" = 0, encode the tree on the host).
+ * The suffix array of a terminated text is unique and the encoders make the same choices, so the result is
+ * byte-identical to fmx_build's (fmx_save gives the same bytes).  Optional statistics: doubling rounds after the initial 4-character sort, and rows
  * that went through a device sort, wall seconds of the device stage incl. transfers.  The handle still needs
  * fmx_to_device before queries. */
 int fmx_build_on_device(const uint16_t *text, int32_t n, int32_t sample_rate, int enable_extract, int device,
                         fmx_index **out, int32_t *rounds, int64_t *rows_sorted, double *stage_seconds);
+/* seconds fmx_build_on_device spent encoding the wavelet tree in HBM; 0 = it was encoded on the host */
+double fmx_build_wavelet_seconds(const fmx_index *idx);
 
 /* FmIndex.read(ObjectInput) FM:983-1025; also accepts the ObjectOutputStream-framed form produced by
  * Serialization.writeToByteArray SER:67-79 (magic AC ED 00 05 + block-data records). */

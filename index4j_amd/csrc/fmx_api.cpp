@@ -56,6 +56,7 @@ struct fmx_index {
     bool owns_device = false;
     bool wavelet_only = false;  // built by fmx_wavelet_build: only the wavelet entry points apply
     bool rrr_only = false;      // built by fmx_rrr_build: only the RrrVector entry points apply
+    double wavelet_device_seconds = 0;  // fmx_build_on_device: seconds of the wavelet encode in HBM (0: host encoder)
     fmx::DevIndex dev;
     // per-(stream, kind) scratch of the device-pointer entry points (grow-only; freed with the index):
     // kind 0 = plan stage (order + code words), kind 1 = extractUntilBoundary windows
@@ -73,6 +74,7 @@ struct fmx_index {
 namespace {
 
 thread_local std::string g_err;
+std::atomic<int> g_wavelet_on_device{1};  // option "wavelet_on_device": 0 = fmx_build_on_device encodes the wavelet tree on the host
 std::atomic<int> g_sb_cache_limit{320};  // option "sb_cache_limit": applies to indexes made resident afterwards (tests: 0 = no LDS cache)
 int fail(int code, const std::string &msg) {
     g_err = msg;
@@ -321,6 +323,10 @@ int fmx_set_option(const char *name, int value) {
         fmx::set_map_fast(value != 0);
         return FMX_OK;
     }
+    if (name && !strcmp(name, "wavelet_on_device")) {
+        g_wavelet_on_device = value != 0;
+        return FMX_OK;
+    }
     if (name && !strcmp(name, "inv_fast")) {  // 0: images flattened from now on walk inverseSelect the reference's way
         fmx::set_inv_fast(value != 0);
         return FMX_OK;
@@ -353,7 +359,8 @@ int fmx_build_on_device(const uint16_t *text, int32_t n, int32_t sample_rate, in
     std::unique_ptr<fmx_index> idx(new fmx_index());
     std::string err;
     fmx::SaStageStats stats;
-    int rc = fmx::build_model(text, n, sample_rate, enable_extract != 0, idx->model, err, device, &stats);
+    int rc = fmx::build_model(text, n, sample_rate, enable_extract != 0, idx->model, err, device, &stats,
+                              g_wavelet_on_device != 0);
     if (rc == -2) return fail(FMX_E_ALPHABET, err);
     if (rc == -5) return fail(FMX_E_NO_DEVICE, err);
     if (rc == -6) return fail(FMX_E_HIP, err);
@@ -361,10 +368,13 @@ int fmx_build_on_device(const uint16_t *text, int32_t n, int32_t sample_rate, in
     if (rounds) *rounds = stats.rounds;
     if (rows_sorted) *rows_sorted = (int64_t)stats.rows_sorted;
     if (stage_seconds) *stage_seconds = stats.seconds;
+    idx->wavelet_device_seconds = stats.wavelet_seconds;
     idx->has_model = true;
     *out = idx.release();
     return FMX_OK;
 }
+
+double fmx_build_wavelet_seconds(const fmx_index *idx) { return idx ? idx->wavelet_device_seconds : 0.0; }
 
 int fmx_load(const uint8_t *ser, size_t len, fmx_index **out) {
     if (!out || !ser) return fail(FMX_E_ARG, "null argument");

@@ -308,45 +308,20 @@ static void merge_lists(const std::vector<SymFreq> &a, const std::vector<SymFreq
     }
 }
 
-// WFBB:853-987: choose blockSizeLog in 9..16 by estimated encoding size
-static int choose_block_size_log(const int16_t *text, int64_t sb_size, int64_t sb_sigma, int alphabet,
-                                 int sampling_rate, SbScratch &S) {
+// WFBB:853-987 given, per candidate block size 2^9 .. 2^16, the sums over the superblock's blocks of the header
+// terms (WFBB:924-947) and of frequency * code length: the size estimate with its double-precision chain, and the
+// choice.  Shared by the host encoder (below) and the device encoder (fmx_wt_gpu.hip), which produce the sums.
+int pick_block_size_log(const int64_t *hdr_sum, const int64_t *unc_sum, int64_t sb_size, int64_t sb_sigma, int sampling_rate) {
     const int smallest_log = std::max(0, std::min(SBS_LOG, 16) - 7);
     const int top_log = std::min(SBS_LOG, 16);
     int best_log = 0;
     int64_t best_size = 0;
     int64_t compressed = 0, prev_uncompressed = 0;
-    std::vector<std::vector<SymFreq>> *cur = &S.lists, *nxt = &S.lists2;
     for (int bsl = smallest_log; bsl <= top_log; ++bsl) {
         const int64_t block_size = 1LL << bsl;
         const int64_t n_blocks = (sb_size + block_size - 1) / block_size;
-        int64_t enc = (int64_t)BLOCK_HEADER_ITEM_SIZE * n_blocks + sb_sigma * (SBS / block_size);
-        if (bsl == smallest_log) {
-            cur->resize((size_t)n_blocks);
-            for (int64_t b = 0; b < n_blocks; ++b) {
-                int64_t beg = b * block_size, end = std::min(beg + block_size, sb_size);
-                block_symbol_list(text + beg, end - beg, S.dense, (*cur)[(size_t)b]);
-            }
-        } else {
-            const int64_t prev_blocks = (sb_size + (block_size / 2) - 1) / (block_size / 2);
-            nxt->resize((size_t)n_blocks);
-            for (int64_t b = 0; b < prev_blocks; b += 2)
-                merge_lists((*cur)[(size_t)b], (b + 1 < prev_blocks) ? &(*cur)[(size_t)b + 1] : nullptr,
-                            (*nxt)[(size_t)(b >> 1)]);
-            std::swap(cur, nxt);
-        }
-        int64_t uncompressed = 0;
-        for (int64_t b = 0; b < n_blocks; ++b) {
-            const auto &L = (*cur)[(size_t)b];
-            const int64_t block_sigma = (int64_t)L.size();
-            enc += block_sigma * 4;          // WFBB:924
-            enc += (block_sigma - 1) * 2;    // WFBB:925
-            S.lens.resize(L.size());
-            int mcl = huffman_lengths(L.data(), (int)L.size(), S.lens.data(), S.huff);
-            if (L.empty()) mcl = -1;
-            if (mcl > 1) enc += (int64_t)(mcl - 1) * 3;  // WFBB:945-947
-            for (size_t i = 0; i < L.size(); ++i) uncompressed += (int64_t)L[i].freq * S.lens[i];
-        }
+        int64_t enc = (int64_t)BLOCK_HEADER_ITEM_SIZE * n_blocks + sb_sigma * (SBS / block_size) + hdr_sum[bsl - smallest_log];
+        const int64_t uncompressed = unc_sum[bsl - smallest_log];
         if (uncompressed > 0) {
             if (bsl == smallest_log) {
                 compressed = rrr_all_zero_estimate(uncompressed, sampling_rate);
@@ -370,8 +345,50 @@ static int choose_block_size_log(const int16_t *text, int64_t sb_size, int64_t s
             best_size = enc;
         }
     }
-    (void)alphabet;
     return best_log;
+}
+
+// WFBB:853-987: choose blockSizeLog in 9..16 by estimated encoding size
+static int choose_block_size_log(const int16_t *text, int64_t sb_size, int64_t sb_sigma, int alphabet,
+                                 int sampling_rate, SbScratch &S) {
+    const int smallest_log = std::max(0, std::min(SBS_LOG, 16) - 7);
+    const int top_log = std::min(SBS_LOG, 16);
+    int64_t hdr_sum[8] = {0}, unc_sum[8] = {0};
+    std::vector<std::vector<SymFreq>> *cur = &S.lists, *nxt = &S.lists2;
+    for (int bsl = smallest_log; bsl <= top_log; ++bsl) {
+        const int64_t block_size = 1LL << bsl;
+        const int64_t n_blocks = (sb_size + block_size - 1) / block_size;
+        if (bsl == smallest_log) {
+            cur->resize((size_t)n_blocks);
+            for (int64_t b = 0; b < n_blocks; ++b) {
+                int64_t beg = b * block_size, end = std::min(beg + block_size, sb_size);
+                block_symbol_list(text + beg, end - beg, S.dense, (*cur)[(size_t)b]);
+            }
+        } else {
+            const int64_t prev_blocks = (sb_size + (block_size / 2) - 1) / (block_size / 2);
+            nxt->resize((size_t)n_blocks);
+            for (int64_t b = 0; b < prev_blocks; b += 2)
+                merge_lists((*cur)[(size_t)b], (b + 1 < prev_blocks) ? &(*cur)[(size_t)b + 1] : nullptr,
+                            (*nxt)[(size_t)(b >> 1)]);
+            std::swap(cur, nxt);
+        }
+        int64_t uncompressed = 0, headers = 0;
+        for (int64_t b = 0; b < n_blocks; ++b) {
+            const auto &L = (*cur)[(size_t)b];
+            const int64_t block_sigma = (int64_t)L.size();
+            headers += block_sigma * 4;          // WFBB:924
+            headers += (block_sigma - 1) * 2;    // WFBB:925
+            S.lens.resize(L.size());
+            int mcl = huffman_lengths(L.data(), (int)L.size(), S.lens.data(), S.huff);
+            if (L.empty()) mcl = -1;
+            if (mcl > 1) headers += (int64_t)(mcl - 1) * 3;  // WFBB:945-947
+            for (size_t i = 0; i < L.size(); ++i) uncompressed += (int64_t)L[i].freq * S.lens[i];
+        }
+        hdr_sum[bsl - smallest_log] = headers;
+        unc_sum[bsl - smallest_log] = uncompressed;
+    }
+    (void)alphabet;
+    return pick_block_size_log(hdr_sum, unc_sum, sb_size, sb_sigma, sampling_rate);
 }
 
 static inline void wr16(uint8_t *p, unsigned v) {
@@ -665,7 +682,7 @@ struct PhaseTimer {
 };
 
 int build_model(const uint16_t *input, int32_t n_in, int32_t sample_rate, bool enable_extract, FmModel &m,
-                std::string &err, int build_device, SaStageStats *stats) {
+                std::string &err, int build_device, SaStageStats *stats, bool device_wavelet) {
     PhaseTimer timer;
     if (n_in < 0 || sample_rate <= 0 || n_in == INT32_MAX) {
         err = "bad arguments";
@@ -772,7 +789,8 @@ int build_model(const uint16_t *input, int32_t n_in, int32_t sample_rate, bool e
             err = "this build has no device construction stage";
             return -8;
         }
-        rc = device_sa_stage(seq.data(), n, sample_rate, enable_extract, build_device, st, stats, err);
+        rc = device_sa_stage(seq.data(), n, sample_rate, enable_extract, build_device, st, stats, err,
+                             device_wavelet ? &m.wt : nullptr, mapped);
     } else {
         rc = host_sa_stage(seq.data(), n, n_look + 1, sample_rate, enable_extract, st);
     }
@@ -793,9 +811,11 @@ int build_model(const uint16_t *input, int32_t n_in, int32_t sample_rate, bool e
         m.positions.set((n - 1) / sample_rate + 1, m.positions.get(0));  // FM:367-369
     }
     timer.mark("pack inverse samples");
-    std::vector<int16_t> &bwt = st.bwt;
-    build_wavelet(bwt.data(), n, sample_rate, m.wt);  // FM:173
-    timer.mark("wavelet tree");
+    if (!st.wavelet_done) {
+        std::vector<int16_t> &bwt = st.bwt;
+        build_wavelet(bwt.data(), n, sample_rate, m.wt);  // FM:173
+        timer.mark("wavelet tree (host)");
+    }
     return 0;
 }
 

@@ -14,18 +14,28 @@ struct SaStage {
     std::vector<uint64_t> which;          // bit i = row i is sampled (SA[i] % sampleRate == 0), n/64 + 2 words
     std::vector<uint32_t> suffix_vals;    // SA[i] of the sampled rows, in row order (FM:341-352)
     std::vector<uint32_t> position_vals;  // [SA[i] / sampleRate] = i for sampled rows (FM:356-366); n/s + 2 slots
+    bool wavelet_done = false;            // the device stage also encoded the wavelet tree (then `bwt` stays empty)
 };
 
 struct SaStageStats {
     int rounds = 0;            // doubling rounds after the initial 4-character sort
     uint64_t rows_sorted = 0;  // rows that went through a device sort, summed over rounds
     double seconds = 0;        // wall time of the stage incl. the transfers to and from HBM
+    double wavelet_seconds = 0;  // of which: the wavelet-tree encode in HBM (0: encoded on the host)
 };
 
 // seq: mapped text incl. the terminator (code 0 at n-1 only); returns 0 or a negative fmx error code
 int host_sa_stage(const int16_t *seq, int32_t n, int alphabet, int sample_rate, bool extract, SaStage &out);
 // (weak: fmx_build.cpp also links without the HIP translation unit, e.g. in the sanitizer build of the host code)
+// wt != nullptr: the wavelet tree (FM:173, WFBB:130-154) is encoded in HBM as well, from the BWT where it lies
+// (fmx_wt_gpu.hip; alphabets up to kWtMaxSigma codes — larger ones leave wavelet_done false and the BWT in `out`)
+struct WfbbModel;
 int device_sa_stage(const int16_t *seq, int32_t n, int sample_rate, bool extract, int device, SaStage &out,
-                    SaStageStats *stats, std::string &err) __attribute__((weak));
+                    SaStageStats *stats, std::string &err, WfbbModel *wt = nullptr, int alphabet = 0)
+    __attribute__((weak));
+constexpr int kWtMaxSigma = 1024;
+// 0 = encoded, 1 = not handled here (alphabet too large, code longer than 31 bits): encode on the host, < 0 = error
+int device_wavelet_stage(const int16_t *d_bwt, int64_t n, int sampling_rate, int alphabet, WfbbModel &w,
+                         std::string &err) __attribute__((weak));
 
 }  // namespace fmx

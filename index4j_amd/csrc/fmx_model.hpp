@@ -109,11 +109,13 @@ struct FmModel {
 };
 
 // fmx_build.cpp
-// build_device >= 0: the suffix-array stage (FM:329-394) runs on that GPU (fmx_sa_gpu.hip), else on the host
+// build_device >= 0: the suffix-array stage (FM:329-394) runs on that GPU (fmx_sa_gpu.hip) and, with device_wavelet,
+// the wavelet-tree encode as well (fmx_wt_gpu.hip); else everything on the host
 struct SaStageStats;
 int build_model(const uint16_t *text, int32_t n, int32_t sample_rate, bool enable_extract, FmModel &out,
-                std::string &err, int build_device = -1, SaStageStats *stats = nullptr);
+                std::string &err, int build_device = -1, SaStageStats *stats = nullptr, bool device_wavelet = true);
 void build_wavelet(const int16_t *bwt, int64_t n, int sampling_rate, WfbbModel &w);
+int pick_block_size_log(const int64_t *hdr_sum, const int64_t *unc_sum, int64_t sb_size, int64_t sb_sigma, int sampling_rate);
 void build_rrr(const uint64_t *bits, int64_t nbits, int sample_size, RrrModel &r, int threads = 1);
 const uint16_t *rrr_offset_of_value();  // 32768 entries
 const uint16_t *rrr_value_of_offset();  // 32768 entries

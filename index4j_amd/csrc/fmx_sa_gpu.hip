@@ -27,6 +27,7 @@
 #include <rocprim/iterator/counting_iterator.hpp>
 
 #include "fmx_build_stage.hpp"
+#include "fmx_model.hpp"
 
 namespace fmx {
 namespace {
@@ -55,6 +56,13 @@ struct DevMem {
         if (e == hipSuccess) ptrs.push_back(p);
         *out = static_cast<T *>(p);
         return e;
+    }
+    void release(void *p) {  // ahead of the destructor
+        for (void *&q : ptrs)
+            if (q == p && p) {
+                (void)hipFree(p);
+                q = nullptr;
+            }
     }
 };
 
@@ -149,7 +157,7 @@ int ceil_log2(uint64_t v) {
 }  // namespace
 
 int device_sa_stage(const int16_t *seq, int32_t n, int sample_rate, bool extract, int device, SaStage &out,
-                    SaStageStats *stats, std::string &err) {
+                    SaStageStats *stats, std::string &err, WfbbModel *wt, int alphabet) {
     if (n <= 0 || sample_rate <= 0) {
         err = "bad arguments";
         return -1;
@@ -261,10 +269,24 @@ int device_sa_stage(const int16_t *seq, int32_t n, int sample_rate, bool extract
     uint32_t n_sampled = 0;
     SA_TRY(hipMemcpy(&n_sampled, d_slot + (L - 1), 4, hipMemcpyDeviceToHost));
 
-    out.bwt.resize((size_t)L);
+    // FM:173: the wavelet tree over the BWT, encoded where the BWT lies (the suffix-array buffers are released first)
+    out.wavelet_done = false;
+    double wt_seconds = 0;
+    if (wt && device_wavelet_stage) {
+        const auto t_wt = std::chrono::steady_clock::now();
+        for (void *p : {(void *)d_keys, (void *)d_keys_alt, (void *)d_vals, (void *)d_vals_alt, (void *)d_rank}) mem.release(p);
+        const int rc = device_wavelet_stage(d_bwt, (int64_t)L, sample_rate, alphabet, *wt, err);
+        if (rc < 0) return rc;
+        out.wavelet_done = rc == 0;
+        wt_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wt).count();
+    }
+    out.bwt.clear();
     out.which.assign(n_words, 0);
     out.suffix_vals.resize(n_sampled);
-    SA_TRY(hipMemcpy(out.bwt.data(), d_bwt, (size_t)L * 2, hipMemcpyDeviceToHost));
+    if (!out.wavelet_done) {
+        out.bwt.resize((size_t)L);
+        SA_TRY(hipMemcpy(out.bwt.data(), d_bwt, (size_t)L * 2, hipMemcpyDeviceToHost));
+    }
     SA_TRY(hipMemcpy(out.which.data(), d_which, n_words * 8, hipMemcpyDeviceToHost));
     if (n_sampled) SA_TRY(hipMemcpy(out.suffix_vals.data(), d_suffix_vals, (size_t)n_sampled * 4, hipMemcpyDeviceToHost));
     out.position_vals.clear();
@@ -276,6 +298,7 @@ int device_sa_stage(const int16_t *seq, int32_t n, int sample_rate, bool extract
         stats->rounds = rounds;
         stats->rows_sorted = sorted_rows;
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        stats->wavelet_seconds = out.wavelet_done ? wt_seconds : 0;
     }
     return 0;
 }

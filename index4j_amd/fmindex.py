@@ -98,7 +98,9 @@ class FmIndex:
                                               int(build_device), C.byref(h), C.byref(rounds), C.byref(rows),
                                               C.byref(secs)), "fmx_build_on_device")
                 self.build_stats = {"doubling_rounds": rounds.value, "rows_sorted": rows.value,
-                                    "device_stage_seconds": secs.value}
+                                    "device_stage_seconds": secs.value,
+                                    # 0.0: the wavelet tree was encoded on the host (alphabet above 1,024 codes, or option)
+                                    "wavelet_device_seconds": lib.fmx_build_wavelet_seconds(h)}
             self._h = h
         if device is not None:
             self.to_device(device)

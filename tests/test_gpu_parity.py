@@ -460,10 +460,12 @@ def test_planned_batches_vs_oracle_across_alphabet_sizes(sigma):
 
 
 def test_device_construction_is_byte_identical():
-    """fmx_build_on_device (suffix array by prefix doubling in HBM, FM:329-394 on the GPU) against the host
-    builder: the serialized indexes must be the same bytes — the suffix array of a terminated text is unique.
-    Texts: the fixture, long repeats (many doubling rounds), a single repeated character (the worst case),
-    embedded sentinels, tiny inputs, extraction on and off."""
+    """fmx_build_on_device — suffix array by prefix doubling (FM:329-394) AND the wavelet tree with its RRR vectors
+    (FM:173; WFBB:130-154, 362-535, 570-991; RRR:225-286) encoded in HBM — against the ORACLE's builder and the host
+    builder: the serialized indexes must be the same bytes.
+    Texts: the fixture (763 codes), long repeats (many doubling rounds), a single repeated character (run blocks
+    only: empty bit vectors), embedded sentinels, tiny inputs, DNA, an alphabet above the device encoder's limit
+    (host fallback), extraction on and off."""
     rnd = random.Random(99)
     texts = [
         (HD[:120_000], 32), (HD[:50_000], 1), (HD[:33_333], 7),
@@ -472,21 +474,33 @@ def test_device_construction_is_byte_identical():
         ("ab\0cd\0\0ef" * 3000 + "tail", 4),
         ("", 4), ("a", 1), ("ab", 2), ("\0", 3), ("abracadabra", 2),
         ("".join(rnd.choice("ACGT") for _ in range(200_000)), 64),
-        ("".join(chr(rnd.randrange(40, 2000)) for _ in range(90_000)), 32),
+        ("".join(chr(rnd.randrange(40, 900)) for _ in range(90_000)), 32),
+        ("".join(chr(rnd.randrange(40, 2000)) for _ in range(90_000)), 32),   # 1,960 codes: the host encodes the tree
+        ("".join(chr(97 + min(25, int(rnd.expovariate(0.9)))) for _ in range(1_200_000)), 32),  # skewed, two superblocks
     ]
     for text, sr in texts:
         for extract in (True, False):
-            host = ia.FmIndex(text, sr, extract, device=None)
             dev = ia.FmIndex(text, sr, extract, device=None, build_device=0)
-            assert dev.write(False) == host.write(False), (len(text), sr, extract)
+            expect = orc.OracleFmIndex(text, sr, extract).write(False)
+            assert dev.write(False) == expect, (len(text), sr, extract)
+            on_device = dev.build_stats["wavelet_device_seconds"] > 0
+            codes = len(set(text)) + 1  # the terminator's code 0 + one per distinct character (FM:396-435)
+            assert on_device == (codes <= 1024), (len(text), codes)
+    try:  # the host encoder behind the device suffix-array stage (option): same bytes
+        assert ia.lib.fmx_set_option(b"wavelet_on_device", 0) == 0
+        dev = ia.FmIndex(HD[:120_000], 32, True, device=None, build_device=0)
+        assert dev.build_stats["wavelet_device_seconds"] == 0
+        assert dev.write(False) == ia.FmIndex(HD[:120_000], 32, True, device=None).write(False)
+    finally:
+        ia.lib.fmx_set_option(b"wavelet_on_device", 1)
     dev = ia.FmIndex("a" * 70_000, 8, True, device=0, build_device=0)
     assert dev.build_stats["doubling_rounds"] >= 14  # LCP ~ n: log2(70000 / 4) rounds
     assert dev.count("aaaa") == 70_000 - 3
     # at size: 16 MiB of synthetic log
     t = ia.synth_log(1 << 24)
-    host = ia.FmIndex(t, 32, True, device=None)
     dev = ia.FmIndex(t, 32, True, device=None, build_device=0)
-    assert dev.write(False) == host.write(False)
+    assert dev.build_stats["wavelet_device_seconds"] > 0
+    assert dev.write(False) == orc.OracleFmIndex(t, 32, True).write(False)
 
 
 def test_standalone_rrr_vector_kats_and_random_vs_oracle():
