@@ -712,26 +712,36 @@ int build_model(const uint16_t *input, int32_t n_in, int32_t sample_rate, bool e
         }
         for (auto &th : pool) th.join();
     };
-    std::vector<std::vector<int32_t>> first_seen(n_threads), seen_count(n_threads);
-    for_chunks([&](unsigned t, int32_t lo, int32_t hi) {
-        std::vector<int32_t> &first = first_seen[t], &count = seen_count[t];
-        first.assign(65536, -1);
-        count.assign(65536, 0);
-        for (int32_t i = lo; i < hi; ++i) {
-            const uint16_t ch = input[i];
-            if (first[ch] < 0) first[ch] = i;
-            ++count[ch];
-        }
-    });
     std::vector<int32_t> first(65536, -1);
     std::vector<int64_t> raw_count(65536, 0);
-    for (unsigned t = 0; t < n_threads; ++t)  // chunks are in text order: the first chunk that saw it wins
-        for (int ch = 0; ch < 65536; ++ch) {
-            if (first[(size_t)ch] < 0 && first_seen[t][(size_t)ch] >= 0) first[(size_t)ch] = first_seen[t][(size_t)ch];
-            raw_count[(size_t)ch] += seen_count[t][(size_t)ch];
+    void *d_text = nullptr;  // the text in HBM, when the device stages take it from there
+    if (build_device >= 0 && device_wavelet && device_alphabet_stage && n_in >= (1 << 16)) {
+        const int rc = device_alphabet_stage(input, n_in, build_device, first, raw_count, &d_text, err);
+        if (rc) return rc;
+    } else {
+        std::vector<std::vector<int32_t>> first_seen(n_threads), seen_count(n_threads);
+        for_chunks([&](unsigned t, int32_t lo, int32_t hi) {
+            std::vector<int32_t> &fs = first_seen[t], &count = seen_count[t];
+            fs.assign(65536, -1);
+            count.assign(65536, 0);
+            for (int32_t i = lo; i < hi; ++i) {
+                const uint16_t ch = input[i];
+                if (fs[ch] < 0) fs[ch] = i;
+                ++count[ch];
+            }
+        });
+        for (unsigned t = 0; t < n_threads; ++t)  // chunks are in text order: the first chunk that saw it wins
+            for (int ch = 0; ch < 65536; ++ch) {
+                if (first[(size_t)ch] < 0 && first_seen[t][(size_t)ch] >= 0) first[(size_t)ch] = first_seen[t][(size_t)ch];
+                raw_count[(size_t)ch] += seen_count[t][(size_t)ch];
+            }
+    }
+    struct DeviceTextGuard {  // device_sa_stage takes the buffer over; freed here only if an early return skips that stage
+        void *&p;
+        ~DeviceTextGuard() {
+            if (p && device_release) device_release(p);
         }
-    std::vector<std::vector<int32_t>>().swap(first_seen);
-    std::vector<std::vector<int32_t>>().swap(seen_count);
+    } text_guard{d_text};
     std::vector<int32_t> code_of(65536, -1);
     const int64_t zeros = 1 + raw_count[0];
     int mapped = (zeros != 1) ? 1 : 0;
@@ -757,11 +767,14 @@ int build_model(const uint16_t *input, int32_t n_in, int32_t sample_rate, bool e
     m.look_up.assign((size_t)distinct + 1, 0);    // FM:411
     for (size_t i = 0; i < m.map_keys.size(); ++i) m.look_up[(size_t)m.map_vals[i]] = m.map_keys[i];
 
-    std::vector<int16_t> seq((size_t)n);
-    for_chunks([&](unsigned, int32_t lo, int32_t hi) {
-        for (int32_t i = lo; i < hi; ++i) seq[(size_t)i] = (int16_t)code_of[input[i]];
-    });
-    seq[(size_t)n - 1] = 0;  // FM:433
+    std::vector<int16_t> seq;
+    if (!d_text) {  // (else the device maps its own copy of the text)
+        seq.resize((size_t)n);
+        for_chunks([&](unsigned, int32_t lo, int32_t hi) {
+            for (int32_t i = lo; i < hi; ++i) seq[(size_t)i] = (int16_t)code_of[input[i]];
+        });
+        seq[(size_t)n - 1] = 0;  // FM:433
+    }
 
     timer.mark("alphabet + mapped text");
     // FM:307-327
@@ -789,8 +802,13 @@ int build_model(const uint16_t *input, int32_t n_in, int32_t sample_rate, bool e
             err = "this build has no device construction stage";
             return -8;
         }
+        std::vector<int16_t> codes16(65536, 0);  // monotonicMap.getOrDefault(ch, 0) as a table (absent characters never occur)
+        for (int ch = 0; ch < 65536; ++ch)
+            if (code_of[(size_t)ch] >= 0) codes16[(size_t)ch] = (int16_t)code_of[(size_t)ch];
+        void *text_for_stage = d_text;
+        d_text = nullptr;  // the stage frees it
         rc = device_sa_stage(seq.data(), n, sample_rate, enable_extract, build_device, st, stats, err,
-                             device_wavelet ? &m.wt : nullptr, mapped);
+                             device_wavelet ? &m.wt : nullptr, mapped, text_for_stage, codes16.data());
     } else {
         rc = host_sa_stage(seq.data(), n, n_look + 1, sample_rate, enable_extract, st);
     }
@@ -798,19 +816,26 @@ int build_model(const uint16_t *input, int32_t n_in, int32_t sample_rate, bool e
     timer.mark("suffix-array stage");
     std::vector<int16_t>().swap(seq);
     m.bw_suffixes = min_bits((uint64_t)n);
-    m.suffixes.init(n / sample_rate + 1, m.bw_suffixes);
-    for (size_t k = 0; k < st.suffix_vals.size(); ++k) m.suffixes.set((int64_t)k, st.suffix_vals[k]);
-    timer.mark("pack suffix samples");
-    build_rrr(st.which.data(), n, sample_rate, m.sampled, n >= (1 << 22) ? (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency())) : 1);
-    timer.mark("RRR of the sample bitmap");
-    if (enable_extract) {
-        m.bw_positions = m.bw_suffixes;
-        m.positions.init(n / sample_rate + 2, m.bw_positions);
-        const int64_t n_pos = (int64_t)(n - 1) / sample_rate + 1;  // slots 0 .. (n-1)/s hold samples
-        for (int64_t k = 0; k < n_pos; ++k) m.positions.set(k, st.position_vals[(size_t)k]);
-        m.positions.set((n - 1) / sample_rate + 1, m.positions.get(0));  // FM:367-369
+    if (enable_extract) m.bw_positions = m.bw_suffixes;
+    if (st.vectors_done) {  // packed and RRR-encoded in HBM
+        m.suffixes = std::move(st.suffixes);
+        if (enable_extract) m.positions = std::move(st.positions);
+        m.sampled = std::move(st.sampled);
+        timer.mark("(sample vectors came packed)");
+    } else {
+        m.suffixes.init(n / sample_rate + 1, m.bw_suffixes);
+        for (size_t k = 0; k < st.suffix_vals.size(); ++k) m.suffixes.set((int64_t)k, st.suffix_vals[k]);
+        timer.mark("pack suffix samples");
+        build_rrr(st.which.data(), n, sample_rate, m.sampled, n >= (1 << 22) ? (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency())) : 1);
+        timer.mark("RRR of the sample bitmap");
+        if (enable_extract) {
+            m.positions.init(n / sample_rate + 2, m.bw_positions);
+            const int64_t n_pos = (int64_t)(n - 1) / sample_rate + 1;  // slots 0 .. (n-1)/s hold samples
+            for (int64_t k = 0; k < n_pos; ++k) m.positions.set(k, st.position_vals[(size_t)k]);
+            m.positions.set((n - 1) / sample_rate + 1, m.positions.get(0));  // FM:367-369
+        }
+        timer.mark("pack inverse samples");
     }
-    timer.mark("pack inverse samples");
     if (!st.wavelet_done) {
         std::vector<int16_t> &bwt = st.bwt;
         build_wavelet(bwt.data(), n, sample_rate, m.wt);  // FM:173

@@ -148,6 +148,43 @@ __global__ void k_sa_compact_samples(const uint32_t *__restrict__ sa, const uint
     if (j < L && flag[j]) suffix_vals[slot[j] - 1] = sa[j];
 }
 
+// FM:396-435, first half: first position and count of every character value.  Characters below kLowChars (all of a
+// typical log) go through LDS tables flushed once per workgroup; the rest straight to the global tables.
+constexpr int kLowChars = 4096;
+__global__ void k_text_stats(const uint16_t *__restrict__ text, uint32_t n, uint32_t per_group,
+                             uint32_t *__restrict__ first, uint32_t *__restrict__ count) {
+    __shared__ uint32_t s_first[kLowChars], s_count[kLowChars];
+    for (int i = threadIdx.x; i < kLowChars; i += blockDim.x) {
+        s_first[i] = 0xffffffffu;
+        s_count[i] = 0;
+    }
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * per_group;
+    const uint32_t hi = (uint32_t)(lo + per_group < n ? lo + per_group : n);
+    for (uint32_t i = (uint32_t)lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t ch = text[i];
+        if (ch < (uint32_t)kLowChars) {
+            atomicMin(&s_first[ch], i);
+            atomicAdd(&s_count[ch], 1u);
+        } else {
+            atomicMin(&first[ch], i);
+            atomicAdd(&count[ch], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kLowChars; i += blockDim.x)
+        if (s_count[i]) {
+            atomicMin(&first[i], s_first[i]);
+            atomicAdd(&count[i], s_count[i]);
+        }
+}
+// FM:427-433: characters -> codes, in place; the appended terminator gets code 0
+__global__ void k_text_map(uint16_t *__restrict__ text, uint32_t L, const int16_t *__restrict__ code_of) {
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= L) return;
+    text[i] = i + 1 == L ? (uint16_t)0 : (uint16_t)code_of[text[i]];
+}
+
 int ceil_log2(uint64_t v) {
     int b = 0;
     while ((1ull << b) < v) ++b;
@@ -156,8 +193,65 @@ int ceil_log2(uint64_t v) {
 
 }  // namespace
 
+void device_release(void *d_ptr) {
+    if (d_ptr) (void)hipFree(d_ptr);
+}
+
+int device_alphabet_stage(const uint16_t *input, int32_t n_in, int device, std::vector<int32_t> &first,
+                          std::vector<int64_t> &count, void **d_text, std::string &err) {
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
+        err = "no HIP device visible";
+        return -5;
+    }
+    if (device < 0 || device >= n_dev || n_in < 0) {
+        err = "bad arguments";
+        return -1;
+    }
+    SA_TRY(hipSetDevice(device));
+    uint16_t *d_raw = nullptr;
+    uint32_t *d_tab = nullptr;
+    SA_TRY(hipMalloc((void **)&d_raw, ((size_t)n_in + 1) * 2));
+    struct Guard {
+        void *p;
+        ~Guard() {
+            if (p) (void)hipFree(p);
+        }
+    } g_raw{d_raw}, g_tab{nullptr};
+    SA_TRY(hipMalloc((void **)&d_tab, 2 * 65536 * 4));
+    g_tab.p = d_tab;
+    if (n_in) SA_TRY(hipMemcpy(d_raw, input, (size_t)n_in * 2, hipMemcpyHostToDevice));
+    SA_TRY(hipMemset(d_tab, 0xff, 65536 * 4));
+    SA_TRY(hipMemset(d_tab + 65536, 0, 65536 * 4));
+    if (n_in) {
+        const uint32_t per_group = 1u << 16;
+        hipLaunchKernelGGL(k_text_stats, dim3((unsigned)(((int64_t)n_in + per_group - 1) / per_group)), dim3(1024), 0, 0, d_raw,
+                           (uint32_t)n_in, per_group, d_tab, d_tab + 65536);
+        SA_TRY(hipGetLastError());
+    }
+    std::vector<uint32_t> tab(2 * 65536);
+    SA_TRY(hipMemcpy(tab.data(), d_tab, tab.size() * 4, hipMemcpyDeviceToHost));
+    first.assign(65536, -1);
+    count.assign(65536, 0);
+    for (int ch = 0; ch < 65536; ++ch)
+        if (tab[65536 + (size_t)ch]) {
+            first[(size_t)ch] = (int32_t)tab[(size_t)ch];
+            count[(size_t)ch] = tab[65536 + (size_t)ch];
+        }
+    *d_text = d_raw;
+    g_raw.p = nullptr;  // handed to device_sa_stage
+    return 0;
+}
+
 int device_sa_stage(const int16_t *seq, int32_t n, int sample_rate, bool extract, int device, SaStage &out,
-                    SaStageStats *stats, std::string &err, WfbbModel *wt, int alphabet) {
+                    SaStageStats *stats, std::string &err, WfbbModel *wt, int alphabet, void *d_text,
+                    const int16_t *code_of) {
+    struct TextGuard {  // the device copy of the text is this stage's to free, whatever happens
+        void *p;
+        ~TextGuard() {
+            if (p) (void)hipFree(p);
+        }
+    } text_guard{d_text};
     if (n <= 0 || sample_rate <= 0) {
         err = "bad arguments";
         return -1;
@@ -180,7 +274,15 @@ int device_sa_stage(const int16_t *seq, int32_t n, int sample_rate, bool extract
     uint32_t *d_sa = nullptr, *d_vals = nullptr, *d_vals_alt = nullptr, *d_rank = nullptr, *d_head = nullptr,
              *d_rows = nullptr, *d_count = nullptr;
     uint8_t *d_active = nullptr;
-    SA_TRY(mem.alloc(&d_seq, (size_t)L));
+    int16_t *d_codes = nullptr;
+    if (d_text) {
+        d_seq = static_cast<int16_t *>(d_text);  // mapped in place below
+        SA_TRY(mem.alloc(&d_codes, 65536));
+        SA_TRY(hipMemcpy(d_codes, code_of, 65536 * 2, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_text_map, dim3(grid_of(L)), dim3(kThreads), 0, 0, static_cast<uint16_t *>(d_text), L, d_codes);
+    } else {
+        SA_TRY(mem.alloc(&d_seq, (size_t)L));
+    }
     SA_TRY(mem.alloc(&d_keys, (size_t)L));
     SA_TRY(mem.alloc(&d_keys_alt, (size_t)L));
     SA_TRY(mem.alloc(&d_sa, (size_t)L));
@@ -191,7 +293,7 @@ int device_sa_stage(const int16_t *seq, int32_t n, int sample_rate, bool extract
     SA_TRY(mem.alloc(&d_rows, (size_t)L));
     SA_TRY(mem.alloc(&d_active, (size_t)L));
     SA_TRY(mem.alloc(&d_count, 1));
-    SA_TRY(hipMemcpy(d_seq, seq, (size_t)L * 2, hipMemcpyHostToDevice));
+    if (!d_text) SA_TRY(hipMemcpy(d_seq, seq, (size_t)L * 2, hipMemcpyHostToDevice));
 
     // one temporary buffer for all rocPRIM calls (sizes queried for the full length)
     const int low_bits = ceil_log2((uint64_t)L + 1), high_bits = ceil_log2((uint64_t)L);
@@ -281,12 +383,38 @@ int device_sa_stage(const int16_t *seq, int32_t n, int sample_rate, bool extract
         wt_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wt).count();
     }
     out.bwt.clear();
-    out.which.assign(n_words, 0);
-    out.suffix_vals.resize(n_sampled);
     if (!out.wavelet_done) {
         out.bwt.resize((size_t)L);
         SA_TRY(hipMemcpy(out.bwt.data(), d_bwt, (size_t)L * 2, hipMemcpyDeviceToHost));
     }
+    // FM:343-370: the sample vectors packed and the bitmap RRR-encoded where they lie
+    out.vectors_done = false;
+    if (wt && device_pack_values && device_rrr_of_bits) {
+        const int width = 64 - __builtin_clzll((unsigned long long)L);  // CMN:169-175 minimumNumberOfBits(n), n >= 1
+        int rc = device_pack_values(d_suffix_vals, (int64_t)n_sampled, (int64_t)L / sample_rate + 1, width, -1, out.suffixes, err);
+        if (rc) return rc;
+        if (extract) {
+            const int64_t n_pos = (int64_t)(L - 1) / sample_rate + 1;  // slots 0 .. (n-1)/s hold samples
+            rc = device_pack_values(d_position_vals, n_pos, (int64_t)L / sample_rate + 2, width, (int64_t)(L - 1) / sample_rate + 1,
+                                    out.positions, err);
+            if (rc) return rc;
+        }
+        rc = device_rrr_of_bits(d_which, (int64_t)L, sample_rate, out.sampled, err);
+        if (rc) return rc;
+        out.vectors_done = true;
+        out.which.clear();
+        out.suffix_vals.clear();
+        out.position_vals.clear();
+        if (stats) {
+            stats->rounds = rounds;
+            stats->rows_sorted = sorted_rows;
+            stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+            stats->wavelet_seconds = out.wavelet_done ? wt_seconds : 0;
+        }
+        return 0;
+    }
+    out.which.assign(n_words, 0);
+    out.suffix_vals.resize(n_sampled);
     SA_TRY(hipMemcpy(out.which.data(), d_which, n_words * 8, hipMemcpyDeviceToHost));
     if (n_sampled) SA_TRY(hipMemcpy(out.suffix_vals.data(), d_suffix_vals, (size_t)n_sampled * 4, hipMemcpyDeviceToHost));
     out.position_vals.clear();

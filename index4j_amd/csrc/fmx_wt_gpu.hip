@@ -881,4 +881,99 @@ int device_wavelet_stage(const int16_t *d_bwt, int64_t n, int sampling_rate, int
     return 0;
 }
 
+
+// ---- the FM-index's own vectors (FM:343-370) -------------------------------------------------------------------
+namespace {
+// IntVector packing (IV:91-119): element k = vals[k] (k < n_vals; k == wrap_index: vals[0], the wrap entry of
+// FM:367-369; else 0) at bit k * width; one thread per 64-bit word
+__global__ void k_pack_values(const uint32_t *__restrict__ vals, int64_t n_vals, int64_t length, int width,
+                              int64_t wrap_index, unsigned long long *__restrict__ words, int64_t n_words) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_words) return;
+    const int64_t lo_bit = j * 64, hi_bit = lo_bit + 64;
+    unsigned long long acc = 0;
+    for (int64_t k = lo_bit / width; k < length && k * width < hi_bit; ++k) {
+        const uint64_t v = k < n_vals ? vals[k] : (k == wrap_index ? vals[0] : 0u);
+        const int64_t at = k * width;
+        const uint64_t masked = width >= 64 ? v : (v & ((1ull << width) - 1ull));
+        if (at >= lo_bit)
+            acc |= masked << (at - lo_bit);
+        else
+            acc |= masked >> (lo_bit - at);
+    }
+    words[j] = acc;
+}
+}  // namespace
+
+int device_pack_values(const uint32_t *d_vals, int64_t n_vals, int64_t length, int width, int64_t wrap_index,
+                       PackedVec &out, std::string &err) {
+    out.init((int32_t)length, width);
+    const int64_t n_words = (int64_t)out.words.size();
+    if (n_words == 0) return 0;
+    DevMem mem;
+    unsigned long long *d_words = nullptr;
+    WT_TRY(mem.alloc(&d_words, (size_t)n_words));
+    hipLaunchKernelGGL(k_pack_values, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, 0, d_vals, n_vals, length, width,
+                       wrap_index, d_words, n_words);
+    WT_TRY(hipGetLastError());
+    WT_TRY(hipMemcpy(out.words.data(), d_words, (size_t)n_words * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// RRR:225-286 of one bit vector in HBM (d_bits: LSB-first 64-bit words, two guard words behind the last bit)
+int device_rrr_of_bits(const uint64_t *d_bits, int64_t nbits, int sample, RrrModel &m, std::string &err) {
+    DevMem mem;
+    RrrPlan r;
+    memset(&r, 0, sizeof r);
+    r.nbits = (uint32_t)nbits;
+    r.n_blocks = (uint32_t)(nbits / 15 + (nbits % 15 ? 1 : 0));
+    r.n_groups = (r.n_blocks + (uint32_t)sample - 1) / (uint32_t)sample;
+    const uint32_t *d_bv = reinterpret_cast<const uint32_t *>(d_bits);
+    RrrPlan *d_rp = nullptr;
+    uint32_t *d_cls = nullptr, *d_gbits = nullptr, *d_gones = nullptr, *d_rtot = nullptr;
+    uint16_t *d_oov = nullptr;
+    const int64_t cls_words = words_for_bits((int64_t)r.n_blocks * 4) * 2;
+    WT_TRY(mem.alloc(&d_rp, 1));
+    WT_TRY(hipMemcpy(d_rp, &r, sizeof r, hipMemcpyHostToDevice));
+    WT_TRY(mem.alloc(&d_cls, (size_t)cls_words, true));
+    WT_TRY(mem.alloc(&d_gbits, (size_t)r.n_groups));
+    WT_TRY(mem.alloc(&d_gones, (size_t)r.n_groups));
+    WT_TRY(mem.alloc(&d_rtot, 2));
+    WT_TRY(mem.alloc(&d_oov, 32768));
+    WT_TRY(hipMemcpy(d_oov, rrr_offset_of_value(), 32768 * 2, hipMemcpyHostToDevice));
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(((int64_t)r.n_groups + 255) / 256, 4096));
+    hipLaunchKernelGGL(k_wt_rrr_classes, dim3(gx, 1), dim3(256), 0, 0, d_bv, d_rp, sample, d_cls, d_gbits, d_gones);
+    hipLaunchKernelGGL(k_wt_rrr_scan, dim3(1), dim3(256), 0, 0, d_rp, d_gbits, d_gones, d_rtot);
+    uint32_t rtot[2] = {0, 0};
+    WT_TRY(hipMemcpy(rtot, d_rtot, 8, hipMemcpyDeviceToHost));
+    m.sample_size = sample;
+    m.length = (int32_t)nbits;
+    m.total_ones = (int32_t)rtot[1];
+    m.bits_per_offset_pos = min_bits((uint64_t)rtot[0]);
+    m.classes.init((int32_t)r.n_blocks, 4);
+    m.sampled_offsets.init((int32_t)(r.n_blocks / (uint32_t)sample + 1), m.bits_per_offset_pos);
+    m.prefix_sums.init((int32_t)(r.n_blocks / (uint32_t)sample + 2), min_bits((uint64_t)rtot[1]));
+    m.offsets.assign((size_t)words_for_bits((int64_t)rtot[0]), 0);
+    r.w_so = m.sampled_offsets.width;
+    r.w_ps = m.prefix_sums.width;
+    WT_TRY(hipMemcpy(d_rp, &r, sizeof r, hipMemcpyHostToDevice));
+    unsigned long long *d_off = nullptr, *d_so = nullptr, *d_ps = nullptr;
+    WT_TRY(mem.alloc(&d_off, m.offsets.size() + 1, true));
+    WT_TRY(mem.alloc(&d_so, m.sampled_offsets.words.size() + 1, true));
+    WT_TRY(mem.alloc(&d_ps, m.prefix_sums.words.size() + 1, true));
+    hipLaunchKernelGGL(k_wt_rrr_offsets, dim3(gx, 1), dim3(256), 0, 0, d_bv, d_rp, sample, d_oov, d_gbits, d_gones, d_off,
+                       d_so, d_ps);
+    WT_TRY(hipGetLastError());
+    if (!m.classes.words.empty())
+        WT_TRY(hipMemcpy(m.classes.words.data(), d_cls, m.classes.words.size() * 8, hipMemcpyDeviceToHost));
+    if (!m.offsets.empty()) WT_TRY(hipMemcpy(m.offsets.data(), d_off, m.offsets.size() * 8, hipMemcpyDeviceToHost));
+    if (!m.sampled_offsets.words.empty())
+        WT_TRY(hipMemcpy(m.sampled_offsets.words.data(), d_so, m.sampled_offsets.words.size() * 8, hipMemcpyDeviceToHost));
+    if (!m.prefix_sums.words.empty())
+        WT_TRY(hipMemcpy(m.prefix_sums.words.data(), d_ps, m.prefix_sums.words.size() * 8, hipMemcpyDeviceToHost));
+    const int64_t n_sampled = r.n_blocks == 0 ? 0 : (int64_t)(r.n_blocks - 1) / sample + 1;  // RRR:285
+    m.prefix_sums.set(n_sampled, (uint64_t)(uint32_t)m.total_ones);
+    return 0;
+}
+
 }  // namespace fmx
