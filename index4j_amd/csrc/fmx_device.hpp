@@ -300,6 +300,14 @@ FMX_HD uint32_t bv_cell_prefix(const Quad &cell, uint32_t r) {
     const uint64_t m_lo = r_lo >= 64u ? ~0ull : ((1ull << r_lo) - 1ull);
     return (uint32_t)fmx_popcll(lo & m_lo) + (uint32_t)fmx_popc(cell.w & ((1u << r_hi) - 1u));
 }
+// bit r (0 <= r < 96) of a cell — with shifts, not a select over the three words: the compiler turns such a select
+// into an indexed read of a stack copy of the cell (scratch traffic in every LF-walk kernel: extractUntilBoundary
+// 2.54 -> 2.04 ms, locate 0.61 -> 0.59 ms)
+FMX_HD bool bv_cell_bit(const Quad &cell, uint32_t r) {
+    const uint64_t lo = (uint64_t)cell.y | ((uint64_t)cell.z << 32);
+    const uint32_t from_lo = (uint32_t)(lo >> (r & 63u)), from_hi = cell.w >> (r & 31u);
+    return ((r < 64u ? from_lo : from_hi) & 1u) != 0;
+}
 FMX_HD int32_t bv_rank1_cell(const RrrView &d, const Quad &cell, int32_t position) {
     if (position < 0) return 0;
     if (position >= d.length) return d.total_ones;
@@ -311,8 +319,7 @@ FMX_HD int32_t bv_rank1_access_cell(const RrrView &d, const Quad &cell, int32_t 
         return position < 0 ? 0 : d.total_ones;
     }
     const uint32_t r = (uint32_t)position % kBvCellBits;
-    const uint32_t word = r < 32u ? cell.y : (r < 64u ? cell.z : cell.w);
-    bit = (word >> (r & 31u)) & 1u;
+    bit = bv_cell_bit(cell, r);
     return (int32_t)(cell.x + bv_cell_prefix(cell, r));
 }
 
