@@ -308,18 +308,25 @@ FMX_HD bool bv_cell_bit(const Quad &cell, uint32_t r) {
     const uint32_t from_lo = (uint32_t)(lo >> (r & 63u)), from_hi = cell.w >> (r & 31u);
     return ((r < 64u ? from_lo : from_hi) & 1u) != 0;
 }
+// RrrVector.rankOnes saturates outside [0, length) (RRR:360-365).  Here that costs no branch: the position is clamped
+// into [0, length], whose cell always exists (length / 96 + 2 cells), and the rank at a clamped position IS the
+// saturated value — 0 at position 0, totalOnes at `length` (the bits past `length` are zero, and the flattener
+// verified that the cells add up to totalOnes).
+FMX_HD uint32_t bv_clamp(const RrrView &d, int32_t position) {
+    return (uint32_t)(position < 0 ? 0 : (position > d.length ? d.length : position));
+}
+FMX_HD Quad bv_load_cell(const uint8_t *base, const RrrView &d, int32_t position) {
+    return ld_quad(bv_cell_ptr(base, d, bv_clamp(d, position)));
+}
+// `cell` = bv_load_cell(position)
 FMX_HD int32_t bv_rank1_cell(const RrrView &d, const Quad &cell, int32_t position) {
-    if (position < 0) return 0;
-    if (position >= d.length) return d.total_ones;
-    return (int32_t)(cell.x + bv_cell_prefix(cell, (uint32_t)position % kBvCellBits));
+    return (int32_t)(cell.x + bv_cell_prefix(cell, bv_clamp(d, position) % kBvCellBits));
 }
 FMX_HD int32_t bv_rank1_access_cell(const RrrView &d, const Quad &cell, int32_t position, bool &bit) {
-    if (position >= d.length || position < 0) {  // rankOnes saturates; access would throw — unreachable for a
-        bit = false;                             // well-formed tree (the node bit always exists)
-        return position < 0 ? 0 : d.total_ones;
-    }
-    const uint32_t r = (uint32_t)position % kBvCellBits;
-    bit = bv_cell_bit(cell, r);
+    // access would throw outside [0, length) — unreachable for a well-formed tree (the node bit always exists);
+    // reported as a 0 bit: beyond `length` the cells hold zeros, below 0 the position is clamped onto bit 0
+    const uint32_t r = bv_clamp(d, position) % kBvCellBits;
+    bit = position >= 0 && bv_cell_bit(cell, r);
     return (int32_t)(cell.x + bv_cell_prefix(cell, r));
 }
 
@@ -586,7 +593,7 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
         int32_t pos = (int32_t)node_a + (int32_t)block_index;
         Quad pq = {0, 0, 0, 0}, cell = {0, 0, 0, 0};
         if (code_length > 1) pq = ld_quad(path);  // records of levels 1 and 2
-        if (rrr_in_range(rv, pos)) cell = ld_quad(bv_cell_ptr(ix.base, rv, (uint32_t)pos));
+        cell = bv_load_cell(ix.base, rv, pos);
         FMX_PIN_QUAD(pq);
         FMX_PIN_QUAD(cell);
         int32_t node_rank = (int32_t)block_index;
@@ -598,7 +605,7 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
                 node_a = (depth & 1) ? pq.z : pq.x;  // record `depth` = the node at level depth + 1
                 node_b = (depth & 1) ? pq.w : pq.y;
                 pos = (int32_t)node_a + node_rank;
-                if (rrr_in_range(rv, pos)) cell = ld_quad(bv_cell_ptr(ix.base, rv, (uint32_t)pos));
+                cell = bv_load_cell(ix.base, rv, pos);
                 if ((depth & 1) && depth + 2 < code_length) pq = ld_quad(path + depth + 1);  // the next two levels
                 FMX_PIN_QUAD(cell);
                 FMX_PIN_QUAD(pq);
@@ -627,7 +634,7 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
         if (tree_height > 0) {
             chunk = ld_quad(hdr);  // level entries 0..3 (guard bytes cover the tail)
             counts0 = block_hdr_root_ones(bhq);
-            if (rrr_in_range(rv, position0)) rec_q = ld_quad(bv_cell_ptr(ix.base, rv, (uint32_t)position0));
+            rec_q = bv_load_cell(ix.base, rv, position0);
         }
         FMX_OPAQUE64(leaf);
         FMX_PIN_QUAD(chunk);
@@ -673,7 +680,7 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
             uint32_t raw_pair, raw_level;
             tree_level_counts_load(t, raw_pair, raw_level);
             rrr_position = t.bv_offset + t.left_total_bv + t.node_rank;
-            if (rrr_in_range(rv, rrr_position)) rec_q = ld_quad(bv_cell_ptr(ix.base, rv, (uint32_t)rrr_position));
+            rec_q = bv_load_cell(ix.base, rv, rrr_position);
             FMX_OPAQUE32(raw_pair);
             FMX_OPAQUE32(raw_level);
             FMX_PIN_QUAD(rec_q);
@@ -761,7 +768,7 @@ FMX_HD int32_t wt_inverse_select_reference_route(const DevIndex &ix, uint32_t po
     Quad chunk = ld_quad(hdr);  // level entries 0..3 (guard bytes cover the tail)
     const uint32_t counts0 = block_hdr_root_ones(bhq);  // = the u16 at hdr + second0 (WFBB:793-809)
     Quad rec_q = {0, 0, 0, 0};
-    if (rrr_in_range(rv, rrr_position)) rec_q = ld_quad(bv_cell_ptr(ix.base, rv, (uint32_t)rrr_position));
+    rec_q = bv_load_cell(ix.base, rv, rrr_position);
     FMX_PIN_QUAD(chunk);
     FMX_PIN_QUAD(rec_q);
 
@@ -805,7 +812,7 @@ FMX_HD int32_t wt_inverse_select_reference_route(const DevIndex &ix, uint32_t po
             uint32_t raw_pair, raw_level;
             tree_level_counts_load(t, raw_pair, raw_level);
             rrr_position = t.bv_offset + t.left_total_bv + t.node_rank;
-            if (rrr_in_range(rv, rrr_position)) rec_q = ld_quad(bv_cell_ptr(ix.base, rv, (uint32_t)rrr_position));
+            rec_q = bv_load_cell(ix.base, rv, rrr_position);
             FMX_OPAQUE32(raw_pair);
             FMX_OPAQUE32(raw_level);
             FMX_PIN_QUAD(rec_q);
@@ -846,7 +853,7 @@ FMX_HD int32_t wt_inverse_select_from(const DevIndex &ix, uint32_t position, con
     int32_t pos = (int32_t)(ihq.x & 0xffffffu) + (int32_t)block_index;
     int32_t node_rank = (int32_t)block_index;
     Quad nq = ld_quad(nodes), cell = {0, 0, 0, 0};
-    if (rrr_in_range(rv, pos)) cell = ld_quad(bv_cell_ptr(ix.base, rv, (uint32_t)pos));
+    cell = bv_load_cell(ix.base, rv, pos);
     FMX_PIN_QUAD(nq);
     FMX_PIN_QUAD(cell);
     FMX_NO_UNROLL
@@ -863,7 +870,7 @@ FMX_HD int32_t wt_inverse_select_from(const DevIndex &ix, uint32_t position, con
         node_b = hi >> 8;
         pos = (int32_t)((lo >> 16) | ((hi & 0xffu) << 16)) + node_rank;
         nq = ld_quad(nodes + idx);
-        if (rrr_in_range(rv, pos)) cell = ld_quad(bv_cell_ptr(ix.base, rv, (uint32_t)pos));
+        cell = bv_load_cell(ix.base, rv, pos);
         FMX_PIN_QUAD(nq);
         FMX_PIN_QUAD(cell);
     }

@@ -29,8 +29,8 @@ def main():
     perm = C.c_void_p()
     assert ia.lib.fmx_count_plan_dev(fm.handle, d_pat.data_ptr(), d_off.data_ptr(), n, C.byref(perm), C.c_void_p(stream.cuda_stream)) == 0
     torch.cuda.synchronize()
-    for pad in (0, 8, 24, 48, 96, 0):
-        # 32 KiB static + pad: 160 KiB / (32+pad) workgroups of 8 waves per CU
+    for pad in (0, 43, 70, 96, 0):
+        # 10 KiB static (superblock header cache) + pad: 160 KiB / (10 + pad) workgroups of 8 waves per CU
         assert ia.lib.fmx_set_option(b"lds_pad_kb", pad) == 0
         ts = []
         for _ in range(3):
@@ -43,7 +43,7 @@ def main():
             ev1.record(stream)
             torch.cuda.synchronize()
             ts.append(ev0.elapsed_time(ev1) / 5)
-        wgs = min(4, 160 // (32 + pad))
+        wgs = min(4, 160 // (10 + pad))
         print("lds pad %2d KiB -> %d workgroups (%2d waves) per CU: k_count %.4f ms" % (pad, wgs, wgs * 8, min(ts)), flush=True)
 
 
