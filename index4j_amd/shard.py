@@ -12,21 +12,40 @@ def shard_range(n, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def broadcast_blob(dist, blob_host, device, src=0):
-    """broadcast the flat index image from `src`; returns a uint8 torch tensor on `device`.
-    blob_host: numpy uint8 array on src, ignored elsewhere."""
+def broadcast_blob(dist, blob_host, device, src=0, fan_out=None):
+    """the flat index image from `src` to every rank; returns a uint8 torch tensor on `device`.
+    blob_host: numpy uint8 array on src, ignored elsewhere.
+    fan_out (default: world > 2): instead of one broadcast — a single ring / tree out of `src`, bound by ONE xGMI
+    link — `src` scatters the image in `world` slices (its egress goes over all links to its peers at once), then
+    every rank all-gathers the slices from its peers.  Same bytes either way."""
     import torch
 
-    rank = dist.get_rank()
+    world, rank = dist.get_world_size(), dist.get_rank()
     size = torch.zeros(1, dtype=torch.int64, device=device)
     if rank == src:
         size[0] = len(blob_host)
     dist.broadcast(size, src)
-    buf = torch.empty(int(size.item()), dtype=torch.uint8, device=device)
+    n = int(size.item())
+    if fan_out is None:
+        fan_out = world > 2
+    if not fan_out or world == 1:
+        buf = torch.empty(n, dtype=torch.uint8, device=device)
+        if rank == src:
+            buf.copy_(torch.from_numpy(np.ascontiguousarray(blob_host)))
+        dist.broadcast(buf, src)
+        return buf
+    per = (n + world - 1) // world
+    per = (per + 255) // 256 * 256  # slices start on 256-byte boundaries
+    full = torch.empty(per * world, dtype=torch.uint8, device=device)
+    parts = None
     if rank == src:
-        buf.copy_(torch.from_numpy(np.ascontiguousarray(blob_host)))
-    dist.broadcast(buf, src)
-    return buf
+        full[:n].copy_(torch.from_numpy(np.ascontiguousarray(blob_host)))
+        full[n:].zero_()
+        parts = [full[r * per:(r + 1) * per] for r in range(world)]
+    mine = torch.empty(per, dtype=torch.uint8, device=device)
+    dist.scatter(mine, parts, src=src)
+    dist.all_gather([full[r * per:(r + 1) * per] for r in range(world)], mine)
+    return full[:n]
 
 
 def scatter_rows(dist, rows_host, row_len, total_rows, device, dtype, src=0):

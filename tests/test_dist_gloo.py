@@ -30,6 +30,9 @@ def _worker(rank, world, port, q):
         fm = ia.FmIndex(text, 32, True, device=None)
         blob = fm.blob()
     buf = broadcast_blob(dist, blob, torch.device("cpu"))
+    # the slice fan-out (scatter + all-gather of slices, the default above two ranks) delivers the same bytes
+    buf2 = broadcast_blob(dist, blob, torch.device("cpu"), fan_out=True)
+    assert buf2.shape == buf.shape and bool((buf2 == buf).all())
 
     class Holder:  # HostSim over the received image
         def blob(self_inner):
