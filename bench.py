@@ -335,6 +335,29 @@ def run_count(ctx, args):
                 raise RuntimeError("counts changed between launches")
     kernel_ms = float(np.mean(kernel_ms_per_batch)) if kernel_ms_per_batch else 0.0
 
+    # The index's suffix table (fmx.h: fmx_suffix_table_info) answers the first 2 * (chars - 1) rank evaluations of every
+    # pattern with one load.  The same steps once more with launches told to ignore it (option), for the record.
+    table_chars, table_bytes = (0, 0) if ctx.dry else q.suffix_table_info()
+    without_table = None
+    if not ctx.dry and table_chars:
+        ia.lib.fmx_set_option(b"suffix_table", 0)
+        try:
+            for i in range(max(2, args.warmup)):
+                step(i % n_batches)
+            torch.cuda.synchronize()
+            e0, e1 = hip_events(torch)
+            e0.record(stream)
+            for i in range(args.steps):
+                step(i % n_batches)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            without_table = {"ms_per_step": e0.elapsed_time(e1) / args.steps}
+            for b in range(n_batches):
+                if int(d_cnt[b].sum(dtype=torch.int64).item()) != checksums[b]:
+                    raise RuntimeError("counts differ without the suffix table")
+        finally:
+            ia.lib.fmx_set_option(b"suffix_table", 1)
+
     # Beside the contract's line (one batch after the other on one stream): the same K steps with TWO batches in
     # flight — step i on stream i mod 2, as a service with several clients would issue them — so that one batch's plan
     # stage overlaps the other's k_count.  Reported as `overlapped`, never as `value`.
@@ -388,6 +411,8 @@ def run_count(ctx, args):
 
     # ---- parity of the run itself + algorithmic bytes per LF-step from the oracle's counting mode ----
     bytes_per_step = levels_per_step = None
+    exec_steps_launch = exec_bytes_launch = None
+    table_steps = 0
     oracle_checked = 0
     base = None
     ref = orc = None
@@ -405,6 +430,22 @@ def run_count(ctx, args):
         oracle_checked += world * n
         bytes_per_step = cnt["alg_bytes"] / max(1, cnt["lf_steps"])
         levels_per_step = cnt["wt_levels"] / max(1, cnt["lf_steps"])
+        table_steps = table_alg_bytes = 0
+        if table_chars and m >= table_chars:
+            # what the table answers = ALL steps of the same patterns cut to their last `table_chars` characters (rank 0's shard)
+            tail = np.ascontiguousarray(host_batches[0][: n * m].reshape(n, m)[:, m - table_chars:]).reshape(-1)
+            off_tail = (np.arange(n + 1, dtype=np.int64) * table_chars).astype(np.int32)
+            orc.counters_reset()
+            ref.count_batch(tail, off_tail, threads=cores)
+            ct = orc.counters()
+            table_steps, table_alg_bytes = ct["lf_steps"], ct["alg_bytes"]
+            orc.counters_reset()
+            ref.count_batch(host_batches[0][: n * m], off_host, threads=cores)
+            full_shard = orc.counters()
+            exec_steps_launch = full_shard["lf_steps"] - table_steps
+            exec_bytes_launch = full_shard["alg_bytes"] - table_alg_bytes
+        else:
+            exec_steps_launch = exec_bytes_launch = None
         oracle_checksum = int(oc.astype(np.int64).sum())
         for b in range(1, n_batches):  # rank 0's shard of the other batches
             oc_b, _ = ref.count_batch(host_batches[b][: n * m], off_host, threads=cores)
@@ -442,6 +483,9 @@ def run_count(ctx, args):
         del src, dst
         lf_per_launch = float(np.mean(lf_steps))
         alg_bytes = bytes_per_step * lf_per_launch
+        alg_bytes_reference = alg_bytes
+        if exec_bytes_launch is not None:  # only the LF-steps k_count really executes count (batch 0's figures)
+            alg_bytes = float(exec_bytes_launch)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         pmc, why = pmc_counters(args.text_log2, n, args.sample_rate)
         traffic = (pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024.0 if pmc else None
@@ -454,6 +498,11 @@ def run_count(ctx, args):
                 "kernel_ms_spread": (max(kernel_ms_per_batch) - min(kernel_ms_per_batch)) / kernel_ms,
                 "step_ms_incl_plan": step_ms, "frac_whole_step": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "alg_bytes_per_lf_step": bytes_per_step, "lf_steps_per_launch": lf_per_launch,
+                "lf_steps_executed_per_launch": exec_steps_launch if exec_steps_launch is not None else lf_per_launch,
+                "alg_bytes_executed_per_launch": alg_bytes, "alg_bytes_reference_per_launch": alg_bytes_reference,
+                "suffix_table_note": None if exec_steps_launch is None else
+                "achieved / frac count ONLY the algorithmic bytes of the LF-steps k_count executes (oracle counting mode on the "
+                "batch minus the same on the patterns' last %d characters, which the suffix table answers)" % table_chars,
                 "lf_steps_per_batch": lf_steps, "wt_levels_per_lf_step": levels_per_step,
                 "traffic_frac": traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
                 "traffic_note": why if traffic is None else "FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 --pmc passes "
@@ -462,15 +511,23 @@ def run_count(ctx, args):
                 "l1_line_accesses_per_lf_step": pmc["TCP_TOTAL_CACHE_ACCESSES"] / lf_per_launch
                 if pmc and pmc.get("TCP_TOTAL_CACHE_ACCESSES") else None,
                 "image_bytes": image_bytes, "image_bytes_per_text_byte": image_bytes / float(1 << args.text_log2),
+                "suffix_table_bytes": table_bytes,
+                "resident_bytes_per_text_byte": (image_bytes + table_bytes) / float(1 << args.text_log2),
+                "frac_reference_equivalent": alg_bytes_reference / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs}
     secondary = None
     if world == 1 and ref is not None and not args.no_secondary:
         secondary = run_secondary(ctx, args, q, ref, orc, text, host_batches[0], off_host)
+    # LF-steps the suffix table answered over the timed steps (every rank's shard has the same shape: m-char substrings)
+    executed_less = 0
+    if not ctx.dry and bytes_per_step and exec_steps_launch is not None:
+        executed_less = int(table_steps) * args.steps * world
     out = {
         "metric": "patterns/sec + LF-steps/sec, 1M x 8-char count() on 256 MiB log index",
         "value": None if ctx.dry else patterns_per_s,
         "unit": "patterns/s",
-        "lf_steps_per_sec": None if ctx.dry else lf_total / wall,
+        "lf_steps_per_sec": None if ctx.dry else (lf_total - executed_less) / wall,
+        "lf_steps_per_sec_reference_equivalent": None if ctx.dry else lf_total / wall,
         "n_gpus": world,
         "ranks_seen": seen,
         "steps": args.steps,
@@ -491,6 +548,15 @@ def run_count(ctx, args):
                    "count_checksums_rank0": checksums, "count_checksum": checksums[0],
                    "gathered_checksum_all_ranks": int(gathered.astype(np.int64).sum()) if gathered is not None else None,
                    "oracle_checksum_batch0_all_ranks": oracle_checksum, "patterns_checked_vs_oracle": oracle_checked},
+        "suffix_table": None if ctx.dry else {
+            "chars": table_chars, "bytes": table_bytes,
+            "what": "SA interval of every string of `chars` codes, tabulated by the index's own rank code when it becomes "
+                    "resident (fmx_suffix_table_info); a planned batch starts from it: one load instead of %d rank evaluations per "
+                    "pattern. `lf_steps_per_sec` counts executed LF-steps only; `value` is patterns/s" % (2 * max(0, table_chars - 1)),
+            "lf_steps_answered_per_launch": int(table_steps) if bytes_per_step and exec_steps_launch is not None else None,
+            "without_it": None if not without_table else {
+                "ms_per_step": without_table["ms_per_step"],
+                "patterns_per_s": n / (without_table["ms_per_step"] * 1e-3)}},
         "overlapped": None if not overlapped else {
             "what": "the same %d steps with %d batches in flight (step i on stream i mod %d): one batch's plan stage overlaps "
                     "another's k_count; max over ranks; not the contract's `value`" % (args.steps, overlapped["streams"], overlapped["streams"]),

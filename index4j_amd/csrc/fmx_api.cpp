@@ -20,6 +20,7 @@
 #include <vector>
 
 namespace fmx {
+int launch_suffix_table(const DevIndex &, int, uint64_t, uint64_t *, hipStream_t);
 int launch_count_plan(const DevIndex &, const uint16_t *, const int32_t *, int32_t, void *, size_t, bool, CountPlan *,
                       hipStream_t);
 int launch_count(const DevIndex &, int, const uint16_t *, const int32_t *, const CountPlan *, bool, int32_t, int32_t *,
@@ -57,6 +58,8 @@ struct fmx_index {
     bool wavelet_only = false;  // built by fmx_wavelet_build: only the wavelet entry points apply
     bool rrr_only = false;      // built by fmx_rrr_build: only the RrrVector entry points apply
     double wavelet_device_seconds = 0;  // fmx_build_on_device: seconds of the wavelet encode in HBM (0: host encoder)
+    void *d_suffix_table = nullptr;     // DevIndex.suffix_table (owned, whoever owns the image)
+    size_t suffix_table_bytes = 0;
     fmx::DevIndex dev;
     // per-(stream, kind) scratch of the device-pointer entry points (grow-only; freed with the index):
     // kind 0 = plan stage (order + code words), kind 1 = extractUntilBoundary windows
@@ -75,6 +78,7 @@ namespace {
 
 thread_local std::string g_err;
 std::atomic<int> g_wavelet_on_device{1};  // option "wavelet_on_device": 0 = fmx_build_on_device encodes the wavelet tree on the host
+std::atomic<int> g_suffix_table_mb{256};  // option "suffix_table_mb": budget of the suffix table of indexes made resident afterwards (0 = none)
 std::atomic<int> g_sb_cache_limit{320};  // option "sb_cache_limit": applies to indexes made resident afterwards (tests: 0 = no LDS cache)
 int fail(int code, const std::string &msg) {
     g_err = msg;
@@ -178,6 +182,8 @@ void make_dev_index(fmx_index *idx) {
     d.n_positions = h.n_positions;
     d.n_c = h.n_c;
     d.map_by_symbol = h.map_by_symbol;
+    d.suffix_table = nullptr;
+    d.suffix_chars = 0;
     d.sb_cache = nullptr;
     d.sb_cache_limit = g_sb_cache_limit;
     d.wt_size = (uint32_t)h.wt_size;
@@ -323,6 +329,11 @@ int fmx_set_option(const char *name, int value) {
         fmx::set_map_fast(value != 0);
         return FMX_OK;
     }
+    if (name && !strcmp(name, "suffix_table_mb")) {  // budget for the suffix table of indexes made resident from now on
+        if (value < 0 || value > (1 << 16)) return fail(FMX_E_ARG, "bad value");
+        g_suffix_table_mb = value;
+        return FMX_OK;
+    }
     if (name && !strcmp(name, "wavelet_on_device")) {
         g_wavelet_on_device = value != 0;
         return FMX_OK;
@@ -412,6 +423,7 @@ void fmx_free(fmx_index *idx) {
     for (auto &kv : idx->ws)
         if (kv.second.first) (void)hipFree(kv.second.first);
     if (idx->owns_device && idx->d_blob) (void)hipFree(idx->d_blob);
+    if (idx->d_suffix_table) (void)hipFree(idx->d_suffix_table);
     delete idx;
 }
 
@@ -422,6 +434,53 @@ int32_t fmx_alphabet_length(const fmx_index *idx) {
 int32_t fmx_sample_rate(const fmx_index *idx) { return idx->has_model ? idx->model.sample_rate : idx->hdr.sample_rate; }
 int32_t fmx_extract_enabled(const fmx_index *idx) {
     return idx->has_model ? (idx->model.enable_extract ? 1 : 0) : idx->hdr.enable_extract;
+}
+
+// The suffix table of a resident FM-index (fmx_device.hpp): the longest suffix length whose table fits the budget
+// (sigma^chars entries of 8 bytes; at most what a plan code word holds).  Not having one is never an error.
+static void build_suffix_table(fmx_index *idx) {
+    if (idx->d_suffix_table) {
+        (void)hipFree(idx->d_suffix_table);
+        idx->d_suffix_table = nullptr;
+        idx->suffix_table_bytes = 0;
+    }
+    idx->dev.suffix_table = nullptr;
+    idx->dev.suffix_chars = 0;
+    if (idx->rrr_only || idx->wavelet_only || idx->hdr.kind != 0) return;
+    const uint64_t budget = (uint64_t)g_suffix_table_mb.load() << 20;
+    const uint64_t sigma = (uint64_t)idx->hdr.wt_sigma;
+    if (budget == 0 || sigma < 2) return;
+    const int max_chars = sigma <= 256 ? 6 : 4;  // the plan's code word: 8 codes of 8 bits or 4 of 16
+    int chars = 0;
+    uint64_t entries = sigma;
+    for (int k = 2; k <= max_chars; ++k) {
+        if (entries > budget / 8 / sigma) break;
+        entries *= sigma;
+        chars = k;
+    }
+    if (chars < 2) return;
+    void *d = nullptr;
+    if (hipMalloc(&d, entries * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    if (fmx::launch_suffix_table(idx->dev, chars, entries, static_cast<uint64_t *>(d), nullptr) != 0 ||
+        hipStreamSynchronize(nullptr) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(d);
+        return;
+    }
+    idx->d_suffix_table = d;
+    idx->suffix_table_bytes = entries * 8;
+    idx->dev.suffix_table = static_cast<const uint64_t *>(d);
+    idx->dev.suffix_chars = chars;
+}
+
+int fmx_suffix_table_info(const fmx_index *idx, int32_t *chars, int64_t *bytes) {
+    if (!idx) return fail(FMX_E_ARG, "null index");
+    if (chars) *chars = idx->dev.suffix_table ? idx->dev.suffix_chars : 0;
+    if (bytes) *bytes = (int64_t)idx->suffix_table_bytes;
+    return FMX_OK;
 }
 
 int fmx_blob(const fmx_index *idx_c, const uint8_t **blob, size_t *len) {
@@ -455,6 +514,7 @@ int fmx_to_device(fmx_index *idx, int device) {
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     idx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     make_dev_index(idx);
+    build_suffix_table(idx);
     return FMX_OK;
 }
 
@@ -484,6 +544,7 @@ int fmx_attach_device_blob(void *device_blob, size_t len, int device, fmx_index 
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     idx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     make_dev_index(idx.get());
+    build_suffix_table(idx.get());
     *out = idx.release();
     return FMX_OK;
 }

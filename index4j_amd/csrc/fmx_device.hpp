@@ -62,7 +62,16 @@ struct DevIndex {
     const struct Quad *sb_cache;
     int32_t sb_cache_limit;      // stage the cache only for indexes with at most this many superblocks (0 = never)
     uint32_t wt_size;
+    // Suffix table (nullptr: none): the SA interval of every string of `suffix_chars` codes, i.e. the state of
+    // FM:455-474 after the pattern's last `suffix_chars` characters, indexed by those codes (the last character most
+    // significant, radix wt_sigma).  Entry = {x, y}: x bit 31 clear: start = x, end = y (start < end, all
+    // suffix_chars - 1 steps taken); x = kSuffixEnded | b: the search ended with an empty interval after b characters
+    // beyond the first; x = kSuffixAsk: not tabulated (a zero code, an exception status) — run the loop.
+    const uint64_t *suffix_table;
+    int32_t suffix_chars;
 };
+constexpr uint32_t kSuffixEnded = 0x80000000u;
+constexpr uint32_t kSuffixAsk = 0xC0000000u;
 
 #if !defined(__HIPCC__)
 inline int fmx_popc(uint32_t v) { return __builtin_popcount(v); }

@@ -239,6 +239,29 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
             if (c != 0) {  // FM:458-460
                 start = ix.C[c];
                 end = ix.C[c + 1];
+                if (kMode == 1 && ix.suffix_table && m >= ix.suffix_chars && n_codes >= ix.suffix_chars) {
+                    // the interval after the last suffix_chars characters is tabulated (k_suffix_table ran this very
+                    // loop for every string of that many codes): one 8-byte load instead of 2 * (suffix_chars - 1) ranks
+                    uint64_t at = (uint64_t)(uint32_t)c;  // (budgets above 32 GiB give tables of more than 2^32 entries)
+                    bool known = true;
+                    for (int j = 1; j < ix.suffix_chars; ++j) {
+                        const uint32_t cj = (uint32_t)(cw >> (j * code_bits)) & code_mask;
+                        known = known && cj != 0;
+                        at = at * (uint32_t)ix.wt_sigma + cj;
+                    }
+                    if (known) {
+                        const uint64_t e = ix.suffix_table[at];
+                        const uint32_t x = (uint32_t)e;
+                        if ((x & kSuffixAsk) == kSuffixEnded) {  // the search ended inside the suffix: empty interval
+                            start = end = 0;
+                            back = (int32_t)(x & 0xffu);
+                        } else if ((x & kSuffixAsk) == 0) {
+                            start = (int32_t)x;
+                            end = (int32_t)(uint32_t)(e >> 32);
+                            back = ix.suffix_chars - 1;
+                        }
+                    }
+                }
                 while (start < end && back + 1 < m) {  // FM:464
                     ++back;
                     if (back < n_codes) {
@@ -272,6 +295,52 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
             }
         }
     }
+}
+
+// The suffix table (DevIndex.suffix_table): entry `at` = the state of the backward search of FM:455-474 after the
+// `chars` codes that `at` spells (radix wt_sigma, the LAST character of a pattern most significant), computed by the
+// very loop k_count runs — one thread per entry, both ends of the interval in turn.
+__global__ __launch_bounds__(256) void k_suffix_table(DevIndex ix, int chars, uint64_t entries, uint64_t *__restrict__ table) {
+    const uint64_t at = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (at >= entries) return;
+    const uint32_t sigma = (uint32_t)ix.wt_sigma;
+    uint32_t code[8];
+    {
+        uint64_t rest = at;
+        for (int j = chars - 1; j >= 0; --j) {
+            code[j] = (uint32_t)(rest % sigma);
+            rest /= sigma;
+        }
+    }
+    bool ask = false;
+    for (int j = 0; j < chars; ++j) ask = ask || code[j] == 0 || (int32_t)code[j] + 1 >= ix.n_c;
+    uint64_t entry = kSuffixAsk;
+    if (!ask) {
+        int status = ST_OK;
+        int32_t start = ix.C[code[0]], end = ix.C[code[0] + 1], back = 0;
+        while (start < end && back + 1 < chars) {
+            ++back;
+            const int32_t c = (int32_t)code[back];
+            const int32_t s2 = wt_rank_folded(ix, nullptr, (uint32_t)start, c, status);
+            const int32_t e2 = wt_rank_folded(ix, nullptr, (uint32_t)end, c, status);
+            start = s2;
+            end = e2;
+        }
+        if (status == ST_OK) {
+            if (start < end)
+                entry = (uint64_t)(uint32_t)start | ((uint64_t)(uint32_t)end << 32);  // (back == chars - 1)
+            else
+                entry = (uint64_t)(kSuffixEnded | (uint32_t)back);
+        }
+    }
+    table[at] = entry;
+}
+int launch_suffix_table(const DevIndex &ix, int chars, uint64_t entries, uint64_t *table, hipStream_t st) {
+    DevIndex plain = ix;
+    plain.sb_cache = nullptr;
+    plain.suffix_table = nullptr;
+    hipLaunchKernelGGL(k_suffix_table, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, st, plain, chars, entries, table);
+    return (int)hipGetLastError();
 }
 
 // FM:526-548: hit k of pattern p is SA row i = start + 1 + k; walk LF until a sampled row.
@@ -759,6 +828,7 @@ static std::atomic<int> g_block{512};
 static std::atomic<int> g_groups_per_cu{16};
 static std::atomic<int> g_boundary_accel{1};  // 0 = literal right walk of extractUntilBoundary (A/B and fallback)
 static std::atomic<int> g_boundary_group{4};  // lanes per query of extractUntilBoundary (0 = one lane per query)
+static std::atomic<int> g_suffix_table_use{1};  // 0 = k_count ignores the index's suffix table (A/B)
 static std::atomic<int> g_lds_pad_kb{0};   // experiment knob: extra dynamic LDS per workgroup (lowers occupancy)
 static std::atomic<int> g_sort_min{16384};  // batches at least this large are processed in suffix-sorted order (0 = never)
 // bins of the bucket pass = 2^coarse_bits (<= 14: they live in LDS).  Measured on configs[1] (tools/tune_coarse.py):
@@ -785,6 +855,10 @@ int set_option(const char *name, int value) {
     if (!strcmp(name, "boundary_group")) {
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return -1;
         g_boundary_group = value;
+        return 0;
+    }
+    if (!strcmp(name, "suffix_table")) {
+        g_suffix_table_use = value != 0;
         return 0;
     }
     if (!strcmp(name, "coarse_bits")) {
@@ -906,15 +980,17 @@ int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_
     const CountPlan &pl = recs ? *plan : none;
     const bool translate = recs && plan_is_foreign && pl.code_bits == 8;
     const int mode = !recs ? 0 : (!plan_is_foreign ? 1 : (translate ? 2 : 3));
+    DevIndex ix_launch = ix;
+    if (!g_suffix_table_use) ix_launch.suffix_table = nullptr;  // (A/B: the same index without its table)
 #define FMX_COUNT_MODE(MODE)                                                                                       \
     do {                                                                                                           \
         const int blk__ = g_block;                                                                                 \
         const dim3 grid__(grid_for(2 * (int64_t)n, blk__, n_cu));                                                  \
         if (blk__ == 1024)                                                                                         \
-            hipLaunchKernelGGL((k_count<1024, MODE>), grid__, dim3(1024), (size_t)g_lds_pad_kb * 1024, st, ix, pat, off, recs, n, \
+            hipLaunchKernelGGL((k_count<1024, MODE>), grid__, dim3(1024), (size_t)g_lds_pad_kb * 1024, st, ix_launch, pat, off, recs, n, \
                                counts, lf, status, range, pl.code_bits, pl.look_up, pl.sigma);                     \
         else                                                                                                       \
-            hipLaunchKernelGGL((k_count<512, MODE>), grid__, dim3(512), (size_t)g_lds_pad_kb * 1024, st, ix, pat, off, recs, n,   \
+            hipLaunchKernelGGL((k_count<512, MODE>), grid__, dim3(512), (size_t)g_lds_pad_kb * 1024, st, ix_launch, pat, off, recs, n,   \
                                counts, lf, status, range, pl.code_bits, pl.look_up, pl.sigma);                     \
     } while (0)
     if (mode == 0)

@@ -181,6 +181,12 @@ class FmIndex:
             raise RuntimeError("Found a character that exceeds (32767): it was %d" % bad.value)
         return n
 
+    def suffix_table_info(self):
+        """(characters, bytes) of the resident index's suffix table (0, 0: none) — fmx_suffix_table_info"""
+        chars, nbytes = C.c_int32(0), C.c_int64(0)
+        check(lib.fmx_suffix_table_info(self._h, C.byref(chars), C.byref(nbytes)), "fmx_suffix_table_info")
+        return chars.value, nbytes.value
+
     # ---- batched queries ----
     def count_batch(self, chars, offsets, want_steps=False):
         chars = np.ascontiguousarray(chars, dtype=np.uint16)

@@ -40,6 +40,8 @@ static DevIndex make_index(const uint8_t *b) {
     d.sb_cache = nullptr;
     d.sb_cache_limit = 0;
     d.wt_size = (uint32_t)h.wt_size;
+    d.suffix_table = nullptr;
+    d.suffix_chars = 0;
     return d;
 }
 

@@ -459,6 +459,60 @@ def test_planned_batches_vs_oracle_across_alphabet_sizes(sigma):
         assert found[i] == k and (locs[i, :k] == l).all(), i
 
 
+def test_suffix_table_changes_nothing_but_the_time():
+    """the suffix table (SA interval of every string of k codes, tabulated when the index becomes resident) lets planned
+    count / locate batches skip their first 2 * (k - 1) rank evaluations: counts, statuses, PER-PATTERN LF-step counts
+    and located hits must be what they are without it, and what the oracle says — for every table depth the budget
+    yields, on patterns that end early at every depth, hold absent characters, are shorter than the table's strings,
+    and on a text whose length is a multiple of 2^20 (rank(size) raises in the JVM: Q3 -> entries that say 'ask')"""
+    rnd = random.Random(4242)
+    texts = [ia.synth_log(1 << 18), np.array([rnd.randrange(33, 33 + 12) for _ in range((1 << 20) - 1)], dtype=np.uint16)]
+    try:
+        for text in texts:
+            o = orc.OracleFmIndex(text, 16, True)
+            N = 24_000
+            pats = []
+            for i in range(N):
+                s0 = rnd.randrange(len(text) - 16)
+                p = np.array(text[s0:s0 + rnd.randrange(1, 12)], dtype=np.uint16)
+                if i % 7 == 0:
+                    p[rnd.randrange(len(p))] = text[rnd.randrange(len(text))]  # ends early somewhere
+                if i % 17 == 0:
+                    p[rnd.randrange(len(p))] = 7  # absent character
+                pats.append(p)
+            ch, off = ia.pack_patterns(pats)
+            orc.counters_reset()
+            oc, ost = o.count_batch(ch, off, threads=1)
+            o_steps = orc.counters()["lf_steps"]
+            seen = set()
+            ref = None
+            for mb in (0, 1, 256):
+                assert ia.lib.fmx_set_option(b"suffix_table_mb", mb) == 0
+                fm = ia.FmIndex.read(o.write(False), device=0)
+                k, nbytes = fm.suffix_table_info()
+                assert (k == 0) == (mb == 0) and (k == 0 or nbytes == 8 * fm.getAlphabetLength() ** k or nbytes > 0)
+                seen.add(k)
+                for use in ((1,) if k == 0 else (1, 0)):
+                    assert ia.lib.fmx_set_option(b"suffix_table", use) == 0
+                    cnt, st, lf = fm.count_batch(ch, off, want_steps=True)
+                    assert (cnt == oc).all() and (st == ost).all(), (mb, use)
+                    assert int(lf.sum()) == o_steps, (mb, use)
+                    if ref is None:
+                        ref = lf.copy()
+                    assert (lf == ref).all(), (mb, use)  # per pattern, table or not
+                    locs, found, st2 = fm.locate_batch(ch, off, 3)
+                    for i in range(0, N, 97):
+                        try:
+                            kk, ll = o.locate(pats[i], max_matches=3, cap=3)
+                            assert st2[i] == 0 and found[i] == kk and (locs[i, :kk] == ll).all(), (mb, use, i)
+                        except IndexError:  # Q3
+                            assert st2[i] == 9
+            assert len(seen) >= 3  # no table, a shallow one, the default depth
+    finally:
+        ia.lib.fmx_set_option(b"suffix_table_mb", 256)
+        ia.lib.fmx_set_option(b"suffix_table", 1)
+
+
 def test_device_construction_is_byte_identical():
     """fmx_build_on_device — suffix array by prefix doubling (FM:329-394) AND the wavelet tree with its RRR vectors
     (FM:173; WFBB:130-154, 362-535, 570-991; RRR:225-286) encoded in HBM — against the ORACLE's builder and the host

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""configs[1] step and k_count time by suffix-table depth (option suffix_table_mb).  GPU box only."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+
+    import bench
+    import index4j_amd as ia
+
+    text, fm, path = bench.build_or_load_index(ia, 28, 32, "/tmp/fmx_cache")
+    dev = torch.device("cuda", 0)
+    n = 1 << 20
+    batches = []
+    for b in range(4):
+        pat, off, _ = ia.synth_patterns(text, 8, n, seed=43 + b)
+        batches.append((torch.from_numpy(pat.view(np.int16)).to(dev), torch.from_numpy(off).to(dev),
+                        torch.zeros(n, dtype=torch.int32, device=dev)))
+    stream = torch.cuda.current_stream()
+    sp = C.c_void_p(stream.cuda_stream)
+    budgets = [int(x) for x in sys.argv[1:]] or [0, 1, 16, 256]
+    for mb in budgets:
+        ia.lib.fmx_set_option(b"suffix_table_mb", mb)
+        t0 = time.perf_counter()
+        fm.to_device(0)
+        t_dev = time.perf_counter() - t0
+        k, nbytes = fm.suffix_table_info()
+
+        def step(i):
+            d_pat, d_off, d_cnt = batches[i % 4]
+            assert ia.lib.fmx_count_batch_dev(fm.handle, d_pat.data_ptr(), d_off.data_ptr(), n, d_cnt.data_ptr(), None, None, sp) == 0
+
+        for i in range(8):
+            step(i)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for i in range(40):
+            step(i)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        sums = [int(b[2].sum().item()) for b in batches]
+        print("budget %6d MB: table of %d chars, %10.1f MB, to_device %.3f s; step %.4f ms; checksums %s"
+              % (mb, k, nbytes / 1e6, t_dev, e0.elapsed_time(e1) / 40, sums[:2]), flush=True)
+    ia.lib.fmx_set_option(b"suffix_table_mb", 256)
+
+
+if __name__ == "__main__":
+    main()
