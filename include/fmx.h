@@ -71,7 +71,7 @@ double fmx_build_wavelet_seconds(const fmx_index *idx);
 /* The suffix table of a resident index: fmx_to_device / fmx_attach_device_blob tabulate the SA interval of every string
  * of *chars codes (the state of FM:455-474 after a pattern's last *chars characters, computed by the same rank code
  * the queries run) as long as sigma^chars entries of 8 bytes fit the budget (option "suffix_table_mb", default 256;
- * 0 = no table).  Planned count / locate batches start from it: one load instead of 2 * (chars - 1) rank evaluations;
+ * 0 = no table) and stay below 8 entries per character of the text.  Planned count / locate batches start from it: one load instead of 2 * (chars - 1) rank evaluations;
  * results, statuses and LF-step counts are unchanged (option "suffix_table" = 0 makes launches ignore it, for A/B).
  * *chars = 0: no table. */
 int fmx_suffix_table_info(const fmx_index *idx, int32_t *chars, int64_t *bytes);

@@ -453,8 +453,10 @@ static void build_suffix_table(fmx_index *idx) {
     const int max_chars = sigma <= 256 ? 6 : 4;  // the plan's code word: 8 codes of 8 bits or 4 of 16
     int chars = 0;
     uint64_t entries = sigma;
+    // (and no more entries than 8 per character of the text: a small index gets a small table)
+    const uint64_t cap = std::max<uint64_t>(4096, 8 * (uint64_t)(uint32_t)idx->hdr.length);
     for (int k = 2; k <= max_chars; ++k) {
-        if (entries > budget / 8 / sigma) break;
+        if (entries > budget / 8 / sigma || entries * sigma > cap) break;
         entries *= sigma;
         chars = k;
     }
