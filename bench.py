@@ -339,7 +339,7 @@ def run_count(ctx, args):
     # pattern with one load.  The same steps once more with launches told to ignore it (option), for the record.
     table_chars, table_bytes = (0, 0) if ctx.dry else q.suffix_table_info()
     without_table = None
-    if not ctx.dry and table_chars:
+    if not ctx.dry and table_chars and not args.profiling:
         ia.lib.fmx_set_option(b"suffix_table", 0)
         try:
             for i in range(max(2, args.warmup)):
@@ -362,7 +362,7 @@ def run_count(ctx, args):
     # flight — step i on stream i mod 2, as a service with several clients would issue them — so that one batch's plan
     # stage overlaps the other's k_count.  Reported as `overlapped`, never as `value`.
     overlapped = None
-    if not ctx.dry and args.overlap_streams > 1:
+    if not ctx.dry and args.overlap_streams > 1 and not args.profiling:
         side = [torch.cuda.Stream(device=dev) for _ in range(args.overlap_streams)]
 
         def step_on(i):
@@ -845,6 +845,9 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of single-thread oracle time for cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every oracle leg (profiling runs)")
     ap.add_argument("--no-secondary", action="store_true", help="skip configs[2] / [3]")
+    ap.add_argument("--profiling", action="store_true",
+                    help="rocprofv3 runs: skip the extra legs that launch the headline kernels in other modes (without the suffix "
+                         "table, two batches in flight), so that per-kernel averages and counters describe the timed path only")
     ap.add_argument("--overlap-streams", type=int, default=2,
                     help="streams of the extra `overlapped` measurement (batches in flight); 1 = skip it")
     ap.add_argument("--dry-run", action="store_true",
