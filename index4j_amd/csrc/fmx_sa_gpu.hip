@@ -149,33 +149,45 @@ __global__ void k_sa_compact_samples(const uint32_t *__restrict__ sa, const uint
 }
 
 // FM:396-435, first half: first position and count of every character value.  Characters below kLowChars (all of a
-// typical log) go through LDS tables flushed once per workgroup; the rest straight to the global tables.
+// typical log) go through LDS tables flushed once per workgroup; higher ones (CJK text ...) through a small hashed LDS
+// table with tags — a character whose slot is taken by another goes straight to the global tables.
 constexpr int kLowChars = 4096;
+constexpr int kHighSlots = 2048;
 __global__ void k_text_stats(const uint16_t *__restrict__ text, uint32_t n, uint32_t per_group,
                              uint32_t *__restrict__ first, uint32_t *__restrict__ count) {
-    __shared__ uint32_t s_first[kLowChars], s_count[kLowChars];
-    for (int i = threadIdx.x; i < kLowChars; i += blockDim.x) {
+    __shared__ uint32_t s_first[kLowChars + kHighSlots], s_count[kLowChars + kHighSlots], s_tag[kHighSlots];
+    for (int i = threadIdx.x; i < kLowChars + kHighSlots; i += blockDim.x) {
         s_first[i] = 0xffffffffu;
         s_count[i] = 0;
     }
+    for (int i = threadIdx.x; i < kHighSlots; i += blockDim.x) s_tag[i] = 0xffffffffu;
     __syncthreads();
     const uint64_t lo = (uint64_t)blockIdx.x * per_group;
     const uint32_t hi = (uint32_t)(lo + per_group < n ? lo + per_group : n);
     for (uint32_t i = (uint32_t)lo + threadIdx.x; i < hi; i += blockDim.x) {
         const uint32_t ch = text[i];
+        int slot = -1;
         if (ch < (uint32_t)kLowChars) {
-            atomicMin(&s_first[ch], i);
-            atomicAdd(&s_count[ch], 1u);
+            slot = (int)ch;
+        } else {
+            const uint32_t h = (ch * 2654435761u) >> 21;  // 11 bits
+            const uint32_t old = atomicCAS(&s_tag[h], 0xffffffffu, ch);
+            if (old == 0xffffffffu || old == ch) slot = kLowChars + (int)h;
+        }
+        if (slot >= 0) {
+            atomicMin(&s_first[slot], i);
+            atomicAdd(&s_count[slot], 1u);
         } else {
             atomicMin(&first[ch], i);
             atomicAdd(&count[ch], 1u);
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < kLowChars; i += blockDim.x)
+    for (int i = threadIdx.x; i < kLowChars + kHighSlots; i += blockDim.x)
         if (s_count[i]) {
-            atomicMin(&first[i], s_first[i]);
-            atomicAdd(&count[i], s_count[i]);
+            const uint32_t ch = i < kLowChars ? (uint32_t)i : s_tag[i - kLowChars];
+            atomicMin(&first[ch], s_first[i]);
+            atomicAdd(&count[ch], s_count[i]);
         }
 }
 // FM:427-433: characters -> codes, in place; the appended terminator gets code 0

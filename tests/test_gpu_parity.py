@@ -530,6 +530,8 @@ def test_device_construction_is_byte_identical():
         ("".join(rnd.choice("ACGT") for _ in range(200_000)), 64),
         ("".join(chr(rnd.randrange(40, 900)) for _ in range(90_000)), 32),
         ("".join(chr(rnd.randrange(40, 2000)) for _ in range(90_000)), 32),   # 1,960 codes: the host encodes the tree
+        # characters above the alphabet pass's direct LDS tables (hashed slots, collisions to the global tables)
+        ("".join(chr(0x4E00 + int(rnd.expovariate(0.004)) % 5000) if rnd.random() < 0.8 else " " for _ in range(120_000)), 16),
         ("".join(chr(97 + min(25, int(rnd.expovariate(0.9)))) for _ in range(1_200_000)), 32),  # skewed, two superblocks
     ]
     for text, sr in texts:
