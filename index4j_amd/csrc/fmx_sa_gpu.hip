@@ -7,8 +7,9 @@
 // (fmx_sais.hpp) produce the same arrays and the resulting index is byte-identical (tests/test_gpu_parity.py).
 //
 // Prefix doubling (Manber-Myers / Larsson-Sadakane, in the sort-based form that suits a GPU):
-//   round 0 : sort suffixes by their first 4 codes (one 64-bit key), rank = index of the group's first row
-//   round k : key = (rank[i], rank[i+h]) packed in 2*ceil(log2(L+1)) bits, h = 4, 8, 16, ...; only rows of
+//   round 0 : sort suffixes by their first c codes (one key of <= 64 bits: c = 9 for a log's ~70 codes), rank = index
+//             of the group's first row
+//   round k : key = (rank[i], rank[i+h]) packed in 2*ceil(log2(L+1)) bits, h = c, 2c, 4c, ...; only rows of
 //             groups that are still tied take part (the rest of SA is final and stays in place)
 //   until every group is a single row.
 // Device-wide sort / scan / select come from rocPRIM; the kernels here build keys, mark group heads and
@@ -66,14 +67,16 @@ struct DevMem {
     }
 };
 
-// round 0: the first four codes of every suffix as one key (codes are < 2^15; past the end = 0, which only the
-// terminator carries, so keys that reach the end are unique anyway)
-__global__ void k_sa_first_keys(const int16_t *__restrict__ seq, uint32_t L, uint64_t *__restrict__ keys,
-                                uint32_t *__restrict__ sa) {
+// round 0: the first `chars` codes of every suffix as one key, `bits` bits each (4 x 16 when the alphabet size is
+// not known, else as many codes as fit 64 bits: 9 for a log's ~70 codes — the first round then settles nine
+// characters and fewer rows stay tied).  Past the end = 0, which only the terminator carries, so keys that reach
+// the end are unique anyway.
+__global__ void k_sa_first_keys(const int16_t *__restrict__ seq, uint32_t L, int chars, int bits,
+                                uint64_t *__restrict__ keys, uint32_t *__restrict__ sa) {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= L) return;
     uint64_t k = 0;
-    for (uint32_t j = 0; j < 4; ++j) k = (k << 16) | (i + j < L ? (uint64_t)(uint16_t)seq[i + j] : 0ull);
+    for (int j = 0; j < chars; ++j) k = (k << bits) | ((uint64_t)i + j < L ? (uint64_t)(uint16_t)seq[i + j] : 0ull);
     keys[i] = k;
     sa[i] = i;
 }
@@ -320,9 +323,12 @@ int device_sa_stage(const int16_t *seq, int32_t n, int sample_rate, bool extract
     SA_TRY(mem.alloc(&d_tmp, tmp_bytes));
 
     // round 0
-    hipLaunchKernelGGL(k_sa_first_keys, dim3(grid_of(L)), dim3(kThreads), 0, 0, d_seq, L, d_keys, d_vals);
+    const int code_bits = alphabet > 0 ? (ceil_log2((uint64_t)alphabet) > 0 ? ceil_log2((uint64_t)alphabet) : 1) : 16;
+    const int first_chars = 64 / code_bits > 16 ? 16 : 64 / code_bits;
+    hipLaunchKernelGGL(k_sa_first_keys, dim3(grid_of(L)), dim3(kThreads), 0, 0, d_seq, L, first_chars, code_bits, d_keys, d_vals);
     size_t bytes = tmp_bytes;
-    SA_TRY(rocprim::radix_sort_pairs(d_tmp, bytes, d_keys, d_keys_alt, d_vals, d_sa, (size_t)L, 0u, 64u));
+    SA_TRY(rocprim::radix_sort_pairs(d_tmp, bytes, d_keys, d_keys_alt, d_vals, d_sa, (size_t)L, 0u,
+                                     (unsigned)(first_chars * code_bits)));
     hipLaunchKernelGGL(k_sa_mark_heads, dim3(grid_of(L)), dim3(kThreads), 0, 0, d_keys_alt, (const uint32_t *)nullptr, L,
                        d_head);
     bytes = tmp_bytes;
@@ -332,7 +338,7 @@ int device_sa_stage(const int16_t *seq, int32_t n, int sample_rate, bool extract
 
     int rounds = 0;
     uint64_t sorted_rows = L;
-    for (uint64_t h = 4; h < (uint64_t)L * 2; h <<= 1) {
+    for (uint64_t h = (uint64_t)first_chars; h < (uint64_t)L * 2; h <<= 1) {
         // rows still tied
         hipLaunchKernelGGL(k_sa_mark_active, dim3(grid_of(L)), dim3(kThreads), 0, 0, d_sa, d_rank, L, d_active);
         bytes = tmp_bytes;

@@ -105,6 +105,8 @@ def main():
             print("FAILED: seed %d case %d len %d sr %d layout %d cache %d" % (args.seed, cases, len(text), sr, layout, cache), flush=True)
             raise
         cases += 1
+        if cases % 25 == 0:
+            print("... %d cases, %.0f s" % (cases, time.time() - t0), flush=True)
     print("fuzz ok: %d cases in %.0f s (seed %d)" % (cases, time.time() - t0, args.seed))
 
 
