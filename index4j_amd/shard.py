@@ -15,9 +15,11 @@ def shard_range(n, world, rank):
 def broadcast_blob(dist, blob_host, device, src=0, fan_out=None):
     """the flat index image from `src` to every rank; returns a uint8 torch tensor on `device`.
     blob_host: numpy uint8 array on src, ignored elsewhere.
-    fan_out (default: world > 2): instead of one broadcast — a single ring / tree out of `src`, bound by ONE xGMI
-    link — `src` scatters the image in `world` slices (its egress goes over all links to its peers at once), then
-    every rank all-gathers the slices from its peers.  Same bytes either way."""
+    fan_out (default off; env FMX_FAN_OUT_BROADCAST=1 turns it on above two ranks): instead of one broadcast — a single
+    ring / tree out of `src`, bound by ONE xGMI link — `src` scatters the image in `world` slices (its egress goes over
+    all links to its peers at once), then every rank all-gathers the slices from its peers.  Same bytes
+    either way; a one-off start-up cost in both forms, so the plain broadcast stays the default until the slice form has
+    been timed on an 8-GPU node."""
     import torch
 
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -27,7 +29,9 @@ def broadcast_blob(dist, blob_host, device, src=0, fan_out=None):
     dist.broadcast(size, src)
     n = int(size.item())
     if fan_out is None:
-        fan_out = world > 2
+        import os
+
+        fan_out = world > 2 and os.environ.get("FMX_FAN_OUT_BROADCAST", "0") == "1"
     if not fan_out or world == 1:
         buf = torch.empty(n, dtype=torch.uint8, device=device)
         if rank == src:
