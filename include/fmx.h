@@ -257,7 +257,13 @@ int fmx_device_count(void);
 /* launch tunables: "block" = threads per workgroup (512 | 1024), "groups_per_cu" = grid cap per CU,
  * "sort_min" = smallest batch that is processed in suffix-sorted order (0 = never), "sort_bits" = sort key width,
  * "boundary_accel" = 0 forces the literal +4-chunk right walk of extractUntilBoundary, "boundary_group" = lanes
- * per extractUntilBoundary query (0 | 2 | 4 | 8 | 16); results are identical for every setting */
+ * per extractUntilBoundary query (0 | 2 | 4 | 8 | 16), "coarse_bits" / "plan_fine" = bins and fine pass of the plan
+ * stage, "suffix_table" = 0: launches ignore the index's suffix table.
+ * Applied when an index is flattened or becomes resident afterwards: "suffix_table_mb" (budget of the suffix table, 0 =
+ * none), "sb_cache_limit" (superblocks whose headers are staged in LDS), "map_by_symbol" / "map_fast" / "inv_fast"
+ * (layout of the image: tests force the reference's own routes with them).  Applied by fmx_build_on_device:
+ * "wavelet_on_device" = 0 encodes the wavelet tree on the host.
+ * Results are identical for every setting. */
 int fmx_set_option(const char *name, int value);
 
 /* deterministic synthetic workload (bench / tests): see index4j_amd/csrc/fmx_synth.cpp */
