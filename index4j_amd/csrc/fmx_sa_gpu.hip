@@ -116,6 +116,17 @@ __global__ void k_sa_mark_active(const uint32_t *__restrict__ sa, const uint32_t
     active[j] = tied ? 1 : 0;
 }
 
+// the same test over the rows that were tied in the previous round only (a row that was settled stays settled)
+__global__ void k_sa_mark_active_rows(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ rank, uint32_t L,
+                                      const uint32_t *__restrict__ rows, uint32_t n, uint8_t *__restrict__ active) {
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t j = rows[i];
+    const uint32_t r = rank[sa[j]];
+    const bool tied = (j > 0 && rank[sa[j - 1]] == r) || (j + 1 < L && rank[sa[j + 1]] == r);
+    active[i] = tied ? 1 : 0;
+}
+
 // key of an active row for the next round: (rank[i], rank[i + h] + 1 or 0 past the end), packed
 __global__ void k_sa_next_keys(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ row_of,
                                const uint32_t *__restrict__ rank, uint32_t n, uint32_t L, uint32_t h, int low_bits,
@@ -287,7 +298,7 @@ int device_sa_stage(const int16_t *seq, int32_t n, int sample_rate, bool extract
     int16_t *d_seq = nullptr;
     uint64_t *d_keys = nullptr, *d_keys_alt = nullptr;
     uint32_t *d_sa = nullptr, *d_vals = nullptr, *d_vals_alt = nullptr, *d_rank = nullptr, *d_head = nullptr,
-             *d_rows = nullptr, *d_count = nullptr;
+             *d_rows = nullptr, *d_rows_alt = nullptr, *d_count = nullptr;
     uint8_t *d_active = nullptr;
     int16_t *d_codes = nullptr;
     if (d_text) {
@@ -306,6 +317,7 @@ int device_sa_stage(const int16_t *seq, int32_t n, int sample_rate, bool extract
     SA_TRY(mem.alloc(&d_rank, (size_t)L));
     SA_TRY(mem.alloc(&d_head, (size_t)L));
     SA_TRY(mem.alloc(&d_rows, (size_t)L));
+    SA_TRY(mem.alloc(&d_rows_alt, (size_t)L));
     SA_TRY(mem.alloc(&d_active, (size_t)L));
     SA_TRY(mem.alloc(&d_count, 1));
     if (!d_text) SA_TRY(hipMemcpy(d_seq, seq, (size_t)L * 2, hipMemcpyHostToDevice));
@@ -317,8 +329,11 @@ int device_sa_stage(const int16_t *seq, int32_t n, int sample_rate, bool extract
     SA_TRY(rocprim::inclusive_scan(nullptr, tmp_scan, d_head, d_head, (size_t)L, rocprim::maximum<uint32_t>()));
     SA_TRY(rocprim::select(nullptr, tmp_select, rocprim::counting_iterator<uint32_t>(0), d_active, d_rows, d_count,
                            (size_t)L));
+    size_t tmp_select_rows = 0;
+    SA_TRY(rocprim::select(nullptr, tmp_select_rows, d_rows, d_active, d_rows_alt, d_count, (size_t)L));
     size_t tmp_bytes = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
     if (tmp_select > tmp_bytes) tmp_bytes = tmp_select;
+    if (tmp_select_rows > tmp_bytes) tmp_bytes = tmp_select_rows;
     uint8_t *d_tmp = nullptr;
     SA_TRY(mem.alloc(&d_tmp, tmp_bytes));
 
@@ -338,14 +353,26 @@ int device_sa_stage(const int16_t *seq, int32_t n, int sample_rate, bool extract
 
     int rounds = 0;
     uint64_t sorted_rows = L;
+    uint32_t n_prev = 0xffffffffu;  // tied rows of the previous round (none yet)
     for (uint64_t h = (uint64_t)first_chars; h < (uint64_t)L * 2; h <<= 1) {
-        // rows still tied
-        hipLaunchKernelGGL(k_sa_mark_active, dim3(grid_of(L)), dim3(kThreads), 0, 0, d_sa, d_rank, L, d_active);
-        bytes = tmp_bytes;
-        SA_TRY(rocprim::select(d_tmp, bytes, rocprim::counting_iterator<uint32_t>(0), d_active, d_rows, d_count,
-                               (size_t)L));
+        // rows still tied: among all rows after round 0, among the previous round's tied rows afterwards
+        if (n_prev == 0xffffffffu) {
+            hipLaunchKernelGGL(k_sa_mark_active, dim3(grid_of(L)), dim3(kThreads), 0, 0, d_sa, d_rank, L, d_active);
+            bytes = tmp_bytes;
+            SA_TRY(rocprim::select(d_tmp, bytes, rocprim::counting_iterator<uint32_t>(0), d_active, d_rows, d_count,
+                                   (size_t)L));
+        } else {
+            hipLaunchKernelGGL(k_sa_mark_active_rows, dim3(grid_of(n_prev)), dim3(kThreads), 0, 0, d_sa, d_rank, L, d_rows,
+                               n_prev, d_active);
+            bytes = tmp_bytes;
+            SA_TRY(rocprim::select(d_tmp, bytes, d_rows, d_active, d_rows_alt, d_count, (size_t)n_prev));
+            uint32_t *t = d_rows;
+            d_rows = d_rows_alt;
+            d_rows_alt = t;
+        }
         uint32_t n_active = 0;
         SA_TRY(hipMemcpy(&n_active, d_count, 4, hipMemcpyDeviceToHost));
+        n_prev = n_active;
         if (n_active == 0) break;
         ++rounds;
         sorted_rows += n_active;
