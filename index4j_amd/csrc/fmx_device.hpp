@@ -951,6 +951,62 @@ FMX_HD void fm_seek_after(const DevIndex &ix, int32_t x, int32_t &row, int32_t &
     if (q == ix.n_positions - 2) skip = ix.length - x;
 }
 
+// ---- suffix table (DevIndex.suffix_table) ---------------------------------------------------------------------
+// entry `at` = the state of the backward search of FM:455-474 after the `chars` codes that `at` spells (radix wt_sigma,
+// the LAST character of a pattern most significant), computed by the very loop k_count runs, both ends in turn
+FMX_HD uint64_t fm_suffix_entry(const DevIndex &ix, uint64_t at, int chars) {
+    const uint32_t sigma = (uint32_t)ix.wt_sigma;
+    uint32_t code[8];
+    {
+        uint64_t rest = at;
+        for (int j = chars - 1; j >= 0; --j) {
+            code[j] = (uint32_t)(rest % sigma);
+            rest /= sigma;
+        }
+    }
+    bool ask = false;
+    for (int j = 0; j < chars; ++j) ask = ask || code[j] == 0 || (int32_t)code[j] + 1 >= ix.n_c;
+    if (ask) return kSuffixAsk;
+    int status = ST_OK;
+    int32_t start = ix.C[code[0]], end = ix.C[code[0] + 1], back = 0;
+    while (start < end && back + 1 < chars) {  // FM:464
+        ++back;
+        const int32_t c = (int32_t)code[back];
+        const int32_t s2 = wt_rank_folded(ix, nullptr, (uint32_t)start, c, status);  // FM:469
+        const int32_t e2 = wt_rank_folded(ix, nullptr, (uint32_t)end, c, status);    // FM:470
+        start = s2;
+        end = e2;
+    }
+    if (status != ST_OK) return kSuffixAsk;
+    if (start < end) return (uint64_t)(uint32_t)start | ((uint64_t)(uint32_t)end << 32);  // (back == chars - 1)
+    return (uint64_t)(kSuffixEnded | (uint32_t)back);
+}
+// A pattern of m >= suffix_chars characters whose trailing codes are code[0] (the last character) ... : where the search
+// stands after them, if the table says so.  Returns false when the loop has to run from the first character.
+template <class CodeAt>
+FMX_HD bool fm_suffix_lookup(const DevIndex &ix, CodeAt code_at, int32_t &start, int32_t &end, int32_t &back) {
+    uint64_t at = (uint64_t)(uint32_t)code_at(0);  // (budgets above 32 GiB give tables of more than 2^32 entries)
+    bool known = at != 0;
+    for (int j = 1; j < ix.suffix_chars; ++j) {
+        const uint32_t cj = (uint32_t)code_at(j);
+        known = known && cj != 0;
+        at = at * (uint32_t)ix.wt_sigma + cj;
+    }
+    if (!known) return false;
+    const uint64_t e = ix.suffix_table[at];
+    const uint32_t x = (uint32_t)e;
+    if ((x & kSuffixAsk) == kSuffixEnded) {  // the search ended inside the suffix: empty interval
+        start = end = 0;
+        back = (int32_t)(x & 0xffu);
+        return true;
+    }
+    if ((x & kSuffixAsk) != 0) return false;
+    start = (int32_t)x;
+    end = (int32_t)(uint32_t)(e >> 32);
+    back = ix.suffix_chars - 1;
+    return true;
+}
+
 // FM:526-548 for one hit: SA row i = start + 1 + k; LF-walk until a sampled row.
 // Returns the text position; *distance = number of LF-steps walked.
 FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t start, int32_t k, int32_t &distance,

@@ -242,25 +242,8 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
                 if (kMode == 1 && ix.suffix_table && m >= ix.suffix_chars && n_codes >= ix.suffix_chars) {
                     // the interval after the last suffix_chars characters is tabulated (k_suffix_table ran this very
                     // loop for every string of that many codes): one 8-byte load instead of 2 * (suffix_chars - 1) ranks
-                    uint64_t at = (uint64_t)(uint32_t)c;  // (budgets above 32 GiB give tables of more than 2^32 entries)
-                    bool known = true;
-                    for (int j = 1; j < ix.suffix_chars; ++j) {
-                        const uint32_t cj = (uint32_t)(cw >> (j * code_bits)) & code_mask;
-                        known = known && cj != 0;
-                        at = at * (uint32_t)ix.wt_sigma + cj;
-                    }
-                    if (known) {
-                        const uint64_t e = ix.suffix_table[at];
-                        const uint32_t x = (uint32_t)e;
-                        if ((x & kSuffixAsk) == kSuffixEnded) {  // the search ended inside the suffix: empty interval
-                            start = end = 0;
-                            back = (int32_t)(x & 0xffu);
-                        } else if ((x & kSuffixAsk) == 0) {
-                            start = (int32_t)x;
-                            end = (int32_t)(uint32_t)(e >> 32);
-                            back = ix.suffix_chars - 1;
-                        }
-                    }
+                    (void)fm_suffix_lookup(
+                        ix, [&](int j) { return (uint32_t)(cw >> (j * code_bits)) & code_mask; }, start, end, back);
                 }
                 while (start < end && back + 1 < m) {  // FM:464
                     ++back;
@@ -297,43 +280,10 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
     }
 }
 
-// The suffix table (DevIndex.suffix_table): entry `at` = the state of the backward search of FM:455-474 after the
-// `chars` codes that `at` spells (radix wt_sigma, the LAST character of a pattern most significant), computed by the
-// very loop k_count runs — one thread per entry, both ends of the interval in turn.
+// The suffix table (DevIndex.suffix_table, fm_suffix_entry): one thread per entry.
 __global__ __launch_bounds__(256) void k_suffix_table(DevIndex ix, int chars, uint64_t entries, uint64_t *__restrict__ table) {
     const uint64_t at = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (at >= entries) return;
-    const uint32_t sigma = (uint32_t)ix.wt_sigma;
-    uint32_t code[8];
-    {
-        uint64_t rest = at;
-        for (int j = chars - 1; j >= 0; --j) {
-            code[j] = (uint32_t)(rest % sigma);
-            rest /= sigma;
-        }
-    }
-    bool ask = false;
-    for (int j = 0; j < chars; ++j) ask = ask || code[j] == 0 || (int32_t)code[j] + 1 >= ix.n_c;
-    uint64_t entry = kSuffixAsk;
-    if (!ask) {
-        int status = ST_OK;
-        int32_t start = ix.C[code[0]], end = ix.C[code[0] + 1], back = 0;
-        while (start < end && back + 1 < chars) {
-            ++back;
-            const int32_t c = (int32_t)code[back];
-            const int32_t s2 = wt_rank_folded(ix, nullptr, (uint32_t)start, c, status);
-            const int32_t e2 = wt_rank_folded(ix, nullptr, (uint32_t)end, c, status);
-            start = s2;
-            end = e2;
-        }
-        if (status == ST_OK) {
-            if (start < end)
-                entry = (uint64_t)(uint32_t)start | ((uint64_t)(uint32_t)end << 32);  // (back == chars - 1)
-            else
-                entry = (uint64_t)(kSuffixEnded | (uint32_t)back);
-        }
-    }
-    table[at] = entry;
+    if (at < entries) table[at] = fm_suffix_entry(ix, at, chars);
 }
 int launch_suffix_table(const DevIndex &ix, int chars, uint64_t entries, uint64_t *table, hipStream_t st) {
     DevIndex plain = ix;

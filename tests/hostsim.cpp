@@ -9,6 +9,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <vector>
 
 using namespace fmx;
 
@@ -114,6 +115,56 @@ void sim_count(const uint8_t *blob, const uint16_t *pat, const int32_t *off, int
             range[2 * p + 1] = end;
         }
     }
+}
+
+// mirrors k_count with a suffix table of `chars` characters: the table is filled by fm_suffix_entry (what k_suffix_table
+// runs per entry) and consulted by fm_suffix_lookup (what a planned k_count runs per pattern)
+int64_t sim_count_table(const uint8_t *blob, int32_t chars, const uint16_t *pat, const int32_t *off, int32_t n,
+                        int32_t *counts, int32_t *lf, int32_t *status_out, int64_t *answered_steps) {
+    DevIndex ix = make_index(blob);
+    uint64_t entries = 1;
+    for (int k = 0; k < chars; ++k) entries *= (uint64_t)ix.wt_sigma;
+    std::vector<uint64_t> table((size_t)entries);
+    for (uint64_t at = 0; at < entries; ++at) table[(size_t)at] = fm_suffix_entry(ix, at, chars);
+    ix.suffix_table = table.data();
+    ix.suffix_chars = chars;
+    int64_t answered = 0;
+    for (int32_t p = 0; p < n; ++p) {
+        const int32_t beg = off[p], m = off[p + 1] - beg;
+        int status = ST_OK;
+        int32_t start = 0, end = 0, back = 0;
+        if (m <= 0) {
+            status = ST_JAVA_AIOOBE;
+        } else {
+            int32_t c = fm_map(ix, pat[beg + m - 1]);
+            if (c != 0) {
+                start = ix.C[c];
+                end = ix.C[c + 1];
+                if (m >= chars &&
+                    fm_suffix_lookup(ix, [&](int j) { return (uint32_t)fm_map(ix, pat[beg + m - 1 - j]); }, start, end, back))
+                    answered += 2 * back;
+                while (start < end && back + 1 < m) {
+                    ++back;
+                    c = fm_map(ix, pat[beg + m - 1 - back]);
+                    if (c == 0) {
+                        start = end = 0;
+                        --back;
+                        break;
+                    }
+                    const int32_t s2 = wt_rank_folded(ix, ix.inv_global, (uint32_t)start, c, status);
+                    const int32_t e2 = wt_rank_folded(ix, ix.inv_global, (uint32_t)end, c, status);
+                    start = s2;
+                    end = e2;
+                }
+            }
+        }
+        const int32_t d = end - start;
+        counts[p] = d > 0 ? d : 0;
+        if (lf) lf[p] = 2 * back;
+        if (status_out) status_out[p] = status;
+    }
+    if (answered_steps) *answered_steps = answered;
+    return (int64_t)entries;
 }
 
 // mirrors k_locate_walk

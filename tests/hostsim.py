@@ -107,6 +107,20 @@ class HostSim:
                         C.c_void_p(rng.ctypes.data))
         return counts, st, lf, rng
 
+    def count_batch_with_table(self, table_chars, chars, offsets):
+        """count() started from a suffix table of `table_chars` characters (filled and consulted by the device header's
+        own functions); returns (counts, status, lf_steps per pattern, LF-steps the table answered, entries)"""
+        chars = np.ascontiguousarray(chars, np.uint16)
+        offsets = np.ascontiguousarray(offsets, np.int32)
+        n = len(offsets) - 1
+        counts, lf, st = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        answered = np.zeros(1, np.int64)
+        lib().sim_count_table.restype = C.c_int64
+        entries = lib().sim_count_table(C.c_void_p(self.p), int(table_chars), C.c_void_p(chars.ctypes.data),
+                                        C.c_void_p(offsets.ctypes.data), n, C.c_void_p(counts.ctypes.data),
+                                        C.c_void_p(lf.ctypes.data), C.c_void_p(st.ctypes.data), C.c_void_p(answered.ctypes.data))
+        return counts, st, lf, int(answered[0]), int(entries)
+
     def locate_batch(self, chars, offsets, max_matches, loc_cap):
         counts, st, lf, rng = self.count_batch(chars, offsets)
         n = len(counts)

@@ -135,3 +135,39 @@ def test_inverse_select_node_records_are_what_runs():
         for h in (hf, hg):
             c, r = h.wt_inverse_select(pos)
             assert c == (t & 0xFFFF) and (pos == 0 or r == (t >> 32)), pos
+
+
+def test_suffix_table_on_the_host_simulation():
+    """the suffix table's two device functions — fm_suffix_entry (fills an entry with the state of FM:455-474 after k
+    codes) and fm_suffix_lookup (a pattern's start from it) — on the host: counts, statuses and per-pattern LF-step
+    counts equal the oracle's and the table-free loop's, for every depth, incl. patterns that end early inside the
+    table's strings, hold absent characters or are shorter than them, and a text with the Q3 status"""
+    rnd = random.Random(77)
+    texts = ["".join(rnd.choice("abcdefghij \n") for _ in range(60_000)),
+             "".join(rnd.choice("acgt") for _ in range((1 << 20) - 1))]  # + sentinel = 2^20: rank(size) raises (Q3)
+    for text in texts:
+        f = ia.FmIndex(text, 8, True, device=None)
+        o = orc.OracleFmIndex(text, 8, True)
+        h = hostsim.HostSim(f)
+        t16 = ia.as_chars(text)
+        pats = []
+        for i in range(3000):
+            s0 = rnd.randrange(len(t16) - 12)
+            p = t16[s0:s0 + rnd.randrange(1, 10)].copy()
+            if i % 5 == 0:
+                p[rnd.randrange(len(p))] = t16[rnd.randrange(len(t16))]  # ends early somewhere
+            if i % 19 == 0:
+                p[rnd.randrange(len(p))] = ord("Z")  # absent character
+            pats.append(p)
+        ch, off = ia.pack_patterns(pats)
+        orc.counters_reset()
+        oc, ost = o.count_batch(ch, off)
+        o_steps = orc.counters()["lf_steps"]
+        plain, pst, plf, _ = h.count_batch(ch, off)
+        assert (plain == oc).all() and (pst == ost).all() and int(plf.sum()) == o_steps
+        for k in (2, 3, 4):
+            cnt, st, lf, answered, entries = h.count_batch_with_table(k, ch, off)
+            assert entries == (f.getAlphabetLength() + (1 if "\0" in text else 0)) ** k or entries > 0
+            assert (cnt == oc).all() and (st == ost).all(), k
+            assert (lf == plf).all(), k  # per pattern, table or not
+            assert 0 < answered < o_steps
