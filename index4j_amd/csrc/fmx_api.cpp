@@ -338,6 +338,10 @@ int fmx_set_option(const char *name, int value) {
         g_wavelet_on_device = value != 0;
         return FMX_OK;
     }
+    if (name && !strcmp(name, "cells_split_blocks")) {  // tests: chunked decoding of short vectors too (same image)
+        fmx::set_split_blocks(value);
+        return FMX_OK;
+    }
     if (name && !strcmp(name, "inv_fast")) {  // 0: images flattened from now on walk inverseSelect the reference's way
         fmx::set_inv_fast(value != 0);
         return FMX_OK;

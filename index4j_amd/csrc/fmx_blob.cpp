@@ -3,8 +3,13 @@
 #include "fmx_device.hpp"  // the tree-walk arithmetic of rank(), evaluated once per leaf at flatten time
 #include "fmx_model.hpp"
 
+#include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <thread>
 
@@ -13,9 +18,11 @@ namespace {
 
 struct Arena {
     std::vector<uint8_t> &b;
+    std::function<void(size_t)> before_growth;  // told the new size before every resize
     // reserve `bytes` at a 64-byte boundary, zero-filled; returns the byte offset
     size_t alloc(size_t bytes) {
         size_t off = (b.size() + 63) & ~(size_t)63;
+        if (before_growth) before_growth(off + bytes);
         b.resize(off + bytes, 0);
         return off;
     }
@@ -74,6 +81,10 @@ struct ExpandJob {
     const RrrModel *r;
     size_t cell_off;
     int64_t n_cells;
+    // A long vector (the sampled-row bitmap: one bit per text character) is decoded by several jobs.  A job takes the
+    // 15-bit blocks [b0, b1); b0 is a multiple of the sample size — where RrrVector keeps the offset pointer and the
+    // prefix sum (RRR:277-283) — and of 32, so that its first bit, 15 * b0, starts a 96-bit cell.
+    int64_t b0 = 0, b1 = -1;  // b1 < 0: the whole vector
 };
 bool expanded_reserve(Arena &A, const RrrModel &r, RrrDesc &d, ExpandJob &job, std::string &err) {
     if (r.classes.width != 4) {
@@ -94,16 +105,52 @@ bool expanded_reserve(Arena &A, const RrrModel &r, RrrDesc &d, ExpandJob &job, s
     d.off_rec = off8(job.cell_off);
     return true;
 }
+// the jobs of one vector: one, or — above kSplitBlocks blocks — chunks of whole sample groups that start on cell boundaries
+std::atomic<int64_t> g_split_blocks{1 << 20};
+void expanded_jobs(const ExpandJob &whole, std::vector<ExpandJob> &out) {
+    const RrrModel &r = *whole.r;
+    const int64_t n_blocks = r.classes.length;
+    const int64_t sample = r.sample_size;
+    const int64_t kSplitBlocks = g_split_blocks;
+    if (n_blocks <= kSplitBlocks || sample <= 0 || r.sampled_offsets.length <= 0 || r.prefix_sums.length <= 0) {
+        out.push_back(whole);
+        return;
+    }
+    int64_t unit = sample;  // lcm(sample, 32)
+    while (unit % 32) unit += sample;
+    const int64_t chunk = (kSplitBlocks / 4 + unit - 1) / unit * unit;
+    for (int64_t b0 = 0; b0 < n_blocks; b0 += chunk) {
+        ExpandJob j = whole;
+        j.b0 = b0;
+        j.b1 = b0 + chunk < n_blocks ? b0 + chunk : n_blocks;
+        // (a chunk needs the vector's own samples at its first block: a model whose sample vectors are too short is
+        // decoded in one piece, where the stream itself is the only authority)
+        if (b0 / sample >= r.sampled_offsets.length || b0 / sample >= r.prefix_sums.length) {
+            out.resize(out.size() - (size_t)(b0 / chunk));
+            out.push_back(whole);
+            return;
+        }
+        out.push_back(j);
+    }
+}
 bool expanded_fill(BvCell *cells, const ExpandJob &job, std::string &err) {
     const RrrModel &r = *job.r;
     const uint8_t *bits_needed = rrr_bits_needed();
     const uint16_t *value_of = rrr_value_of_offset(), *class_base = rrr_class_base();
     const int64_t n_blocks = r.classes.length;
+    const bool whole = job.b1 < 0;
+    const int64_t b0 = whole ? 0 : job.b0, b1 = whole ? n_blocks : job.b1;
+    const bool last = b1 >= n_blocks;
+    // the cells this job writes: from its first bit up to its last block's end — the last job also the tail cells
+    const int64_t c0 = b0 * 15 / kBvCellBits;
+    const int64_t c1 = last ? job.n_cells : b1 * 15 / kBvCellBits;
     // RRR:382-390 for every block: (class, offset) -> 15 bits, into a plain LSB-first bit array ...
-    std::vector<uint64_t> plain((size_t)(job.n_cells * kBvCellBits / 64 + 2), 0);
-    uint64_t obits = 0;
+    std::vector<uint64_t> plain((size_t)((c1 - c0) * kBvCellBits / 64 + 2), 0);
+    uint64_t obits = whole ? 0 : r.sampled_offsets.get(b0 / r.sample_size);  // RRR:371-372
+    uint64_t ones = whole ? 0 : r.prefix_sums.get(b0 / r.sample_size);        // RRR:370
     const uint64_t avail = (uint64_t)r.offsets.size() * 64;
-    for (int64_t b = 0; b < n_blocks; ++b) {
+    const int64_t bit0 = c0 * (int64_t)kBvCellBits;
+    for (int64_t b = b0; b < b1; ++b) {
         const int cls = (int)r.classes.get(b);
         const int nb = bits_needed[cls];
         if (obits + (uint64_t)nb > avail) {
@@ -122,24 +169,26 @@ bool expanded_fill(BvCell *cells, const ExpandJob &job, std::string &err) {
             err = "RRR vector has more blocks than its length";
             return false;
         }
-        const size_t pw = (size_t)(pos >> 6);
-        const int ps = (int)(pos & 63);
+        const size_t pw = (size_t)((pos - bit0) >> 6);
+        const int ps = (int)((pos - bit0) & 63);
         plain[pw] |= value << ps;
         if (ps + 15 > 64) plain[pw + 1] |= value >> (64 - ps);
     }
     // ... cut into 96-bit cells with running one-counts (bits past `length` are zero: RRR pads its last block)
     const uint32_t *plain32 = reinterpret_cast<const uint32_t *>(plain.data());
-    uint64_t ones = 0;
-    for (int64_t c = 0; c < job.n_cells; ++c) {
+    for (int64_t c = c0; c < c1; ++c) {
         BvCell cell;
         cell.ones_before = (uint32_t)ones;
         for (int k = 0; k < 3; ++k) {
-            cell.bits[k] = plain32[(size_t)c * 3 + (size_t)k];
+            cell.bits[k] = plain32[(size_t)(c - c0) * 3 + (size_t)k];
             ones += (uint64_t)__builtin_popcount(cell.bits[k]);
         }
         cells[c] = cell;
     }
-    if (ones != (uint64_t)(uint32_t)r.total_ones) {
+    // the stream and the vector's own counters must agree: with the next chunk's prefix sum, or with totalOnes at the end
+    const uint64_t expect = last ? (uint64_t)(uint32_t)r.total_ones
+                                 : (b1 / r.sample_size < r.prefix_sums.length ? r.prefix_sums.get(b1 / r.sample_size) : ones);
+    if (ones != expect) {
         err = "RRR vector decodes to a different number of ones than it declares";
         return false;
     }
@@ -267,7 +316,7 @@ bool build_inverse_block(const uint8_t *var, int64_t var_len, const BlockHeader 
 // a stand-alone RrrVector (fmx_rrr_build): header + value-of-offset table + the vector in its compressed form
 int flatten_rrr_only(const RrrModel &r, std::vector<uint8_t> &blob, std::string &err) {
     blob.clear();
-    Arena A{blob};
+    Arena A{blob, {}};
     const size_t hdr_off = A.alloc(sizeof(BlobHeader));
     BlobHeader h;
     memset(&h, 0, sizeof h);
@@ -288,6 +337,8 @@ int flatten_rrr_only(const RrrModel &r, std::vector<uint8_t> &blob, std::string 
     return 0;
 }
 
+// blocks above which a bit vector is decoded in chunks (tests lower it: the image must not depend on it)
+void set_split_blocks(int64_t blocks) { g_split_blocks = blocks < 64 ? 64 : blocks; }
 // -1 = by alphabet size; 0 / 1 force the row layout of the mapping tables (tests exercise both)
 static std::atomic<int> g_map_by_symbol{-1};
 void set_map_by_symbol(int mode) { g_map_by_symbol = mode; }
@@ -299,7 +350,21 @@ void set_map_fast(int on) { g_map_fast = on; }
 static std::atomic<int> g_inv_fast{1};
 void set_inv_fast(int on) { g_inv_fast = on; }
 
+namespace {
+struct FlattenTimer {  // FMX_BUILD_TIMING=1 prints the wall time of the flattener's phases to stderr
+    const bool on = getenv("FMX_BUILD_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[fmx flatten] %-26s %.3f s\n", what, std::chrono::duration<double>(now - t).count());
+        t = now;
+    }
+};
+}  // namespace
+
 int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err) {
+    FlattenTimer timer;
     const WfbbModel &w = m.wt;
     const int sigma = w.alphabet_size;
     const int64_t n_sb = (int64_t)w.sb.size();
@@ -314,7 +379,24 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
         return -8;
     }
     blob.clear();
-    Arena A{blob};
+    {
+        // ONE allocation for the whole image (an upper bound): the arena never moves — the cell decoders below run while
+        // this thread still appends tables — and no page is touched twice by a reallocation
+        auto cells_bytes = [](const RrrModel &r) { return ((size_t)r.length / kBvCellBits + 2) * sizeof(BvCell) + 64; };
+        size_t bound = (4u << 20) + 65536 * 2 + (m.suffixes.words.size() + m.positions.words.size() + 8) * 8 +
+                       (m.C.size() + m.look_up.size()) * 4 + cells_bytes(m.sampled) +
+                       (size_t)(n_sb + 1) * (size_t)sigma * sizeof(SbcEntry) + (size_t)n_sb * (sizeof(SbDesc) + 1024);
+        for (int64_t s = 0; s < n_sb; ++s) {
+            const SuperBlockModel &sb = w.sb[(size_t)s];
+            const int bsl = sb.block_size_log;
+            const size_t per_row = (bsl >= 0 && bsl <= 20) ? ((size_t)1 << (20 - bsl)) : 0;
+            const size_t rows = (size_t)std::max<int64_t>(sigma, (int64_t)sb.sigma + 1);  // either row layout
+            bound += rows * per_row * sizeof(MapEntry) + sb.var.size() * 32 + sb.block_headers.size() * 64 +
+                     cells_bytes(sb.rank_support) + 4096;
+        }
+        blob.reserve(bound);
+    }
+    Arena A{blob, {}};
     const size_t hdr_off = A.alloc(sizeof(BlobHeader));
     BlobHeader h;
     memset(&h, 0, sizeof h);
@@ -386,6 +468,50 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
     h.map_by_symbol = by_symbol ? 1 : 0;
     const size_t sbd_off = A.alloc((size_t)n_sb * sizeof(SbDesc));
     h.off_sbdesc = off8(sbd_off);
+    // Every bit vector's cells are reserved now and decoded on the other cores WHILE this thread builds the
+    // per-superblock tables below.  The arena must not move under the decoders: its capacity was reserved for an upper
+    // bound of the whole image (if that bound should ever fall short, the tables wait for the decoders).
+    std::vector<RrrDesc> sb_rrr((size_t)n_sb);
+    for (int64_t s = 0; s < n_sb; ++s)
+        if (!expanded_reserve(A, w.sb[(size_t)s].rank_support, sb_rrr[(size_t)s], jobs[(size_t)s], err)) return -8;
+    std::vector<ExpandJob> work;  // the longest vector first, in chunks
+    expanded_jobs(jobs[(size_t)n_sb], work);
+    for (int64_t s = 0; s < n_sb; ++s) expanded_jobs(jobs[(size_t)s], work);
+    std::atomic<size_t> next_job{0};
+    std::mutex err_mutex;
+    bool failed = false;
+    uint8_t *const arena_base = blob.data();
+    auto worker = [&]() {
+        for (;;) {
+            const size_t j = next_job.fetch_add(1);
+            if (j >= work.size()) return;
+            std::string local;
+            if (!expanded_fill(reinterpret_cast<BvCell *>(arena_base + work[j].cell_off), work[j], local)) {
+                std::lock_guard<std::mutex> lock(err_mutex);
+                failed = true;
+                err = local;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    {
+        unsigned n_threads = std::thread::hardware_concurrency();
+        if (n_threads == 0) n_threads = 1;
+        if (n_threads > work.size()) n_threads = (unsigned)work.size();
+        for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+    }
+    auto join_decoders = [&]() {
+        for (auto &t : pool) t.join();
+        pool.clear();
+    };
+    struct JoinGuard {  // (an early return below must not leave threads running into a dying arena)
+        std::function<void()> f;
+        ~JoinGuard() { f(); }
+    } join_guard{join_decoders};
+    A.before_growth = [&](size_t need) {
+        if (need > blob.capacity()) join_decoders();  // the bound fell short: no decoder may run while the arena moves
+    };
+    timer.mark("reserve + start decoders");
     const bool fast = g_map_fast != 0;
     std::vector<MapEntry> map_scratch;
     std::vector<PathRec> path_scratch;
@@ -557,7 +683,7 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
         d.off_var = off8(off);
         d.var_len = (int32_t)sb.var.size();
         if (!sb.var.empty()) memcpy(A.at<uint8_t>(off), sb.var.data(), sb.var.size());
-        if (!expanded_reserve(A, sb.rank_support, d.rrr, jobs[(size_t)s], err)) return -8;
+        d.rrr = sb_rrr[(size_t)s];
         {
             // inverseSelect section: InvHdr per block, NodeRec per internal node (fmx_blob.hpp)
             const SbcEntry *sbc_row = A.at<SbcEntry>((size_t)h.off_sbc << 3) + (size_t)s * (size_t)sigma;
@@ -599,32 +725,11 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
         *A.at<SbDesc>(sbd_off + (size_t)s * sizeof(SbDesc)) = d;
     }
     A.alloc(64);  // tail guard
-    {
-        // all regions exist (the arena no longer moves): decode the bit vectors on all cores
-        std::atomic<size_t> next{0};
-        std::mutex err_mutex;
-        bool failed = false;
-        auto worker = [&]() {
-            for (;;) {
-                const size_t j = next.fetch_add(1);
-                if (j >= jobs.size()) return;
-                std::string local;
-                if (!expanded_fill(A.at<BvCell>(jobs[j].cell_off), jobs[j], local)) {
-                    std::lock_guard<std::mutex> lock(err_mutex);
-                    failed = true;
-                    err = local;
-                }
-            }
-        };
-        unsigned n_threads = std::thread::hardware_concurrency();
-        if (n_threads == 0) n_threads = 1;
-        if (n_threads > jobs.size()) n_threads = (unsigned)jobs.size();
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(worker);
-        worker();
-        for (auto &t : pool) t.join();
-        if (failed) return -8;
-    }
+    timer.mark("tables (this thread)");
+    worker();  // help with what is left, then wait for the others
+    join_decoders();
+    if (failed) return -8;
+    timer.mark("cells (all cores)");
     h.total_bytes = blob.size();
     if (blob.size() >= ((uint64_t)1 << 35)) {
         err = "blob exceeds 32 GiB";
@@ -634,6 +739,7 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
     h.checksum = 0;
     *A.at<BlobHeader>(hdr_off) = h;
     A.at<BlobHeader>(hdr_off)->checksum = image_checksum(blob.data(), blob.size());
+    timer.mark("checksum");
     return 0;
 }
 

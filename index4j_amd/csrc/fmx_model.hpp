@@ -129,6 +129,7 @@ void emit_model(const FmModel &m, bool framed, std::vector<uint8_t> &out);
 // fmx_blob.cpp
 int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err);
 void set_map_by_symbol(int mode);  // -1 auto, 0 rows by superblock code, 1 rows by global symbol
+void set_split_blocks(int64_t blocks);  // bit vectors above this many 15-bit blocks are decoded in chunks
 void set_inv_fast(int on);         // 0: inverseSelect takes the reference's own route in every block (tests)
 void set_map_fast(int on);         // 0: every present mapping entry takes the reference's own route (tests)
 uint64_t blob_checksum(const uint8_t *p, size_t len);

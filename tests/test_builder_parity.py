@@ -127,3 +127,22 @@ def test_threaded_rrr_of_the_sample_bitmap_is_byte_identical():
     second pass with shared boundary words): same bytes as the oracle"""
     t = ia.synth_log((1 << 22) + 777)
     assert ia.FmIndex(t, 3, True, device=None).write(False) == orc.OracleFmIndex(t, 3, True).write(False)
+
+
+def test_image_does_not_depend_on_how_its_bit_vectors_are_decoded():
+    """the flattener decodes a long bit vector (the sampled-row bitmap of a big text) in chunks that start at the
+    vector's own samples (RRR:277-283) — on several threads; forced here on small vectors: the image is the same bytes"""
+    import index4j_amd as ia
+    from common import hdfs_text
+
+    text = hdfs_text()[:200_000]
+    for sr in (1, 7, 32, 64):
+        f = ia.FmIndex(text, sr, True, device=None)
+        whole = f.blob().tobytes()  # (the array is a view of the index's memory: keep `f` while it is read)
+        assert ia.lib.fmx_set_option(b"cells_split_blocks", 64) == 0
+        try:
+            g = ia.FmIndex(text, sr, True, device=None)
+            chunked = g.blob().tobytes()
+        finally:
+            ia.lib.fmx_set_option(b"cells_split_blocks", 1 << 20)
+        assert chunked == whole, sr
