@@ -218,12 +218,24 @@ def attach_everywhere(ctx, fm):
             return None, None, len(fm.blob())
         fm.to_device(ctx.local_rank)
         return fm, None, fm.device_blob()[1]
-    t0 = time.time()
-    buf = broadcast_blob(ctx.dist, fm.blob() if ctx.rank == 0 else None, ctx.dev)  # RCCL over xGMI: the immutable index, once
-    if not ctx.dry:
-        torch.cuda.synchronize()
+    host = fm.blob() if ctx.rank == 0 else None
+    times = {}
+    buf = None
+    # RCCL over xGMI: the immutable index, once.  Above two ranks both forms are timed (same bytes; the second is kept):
+    # one broadcast out of rank 0, and the slice fan-out (scatter of slices + all-gather among the ranks)
+    for form in ([False, True] if ctx.world > 2 else [False]):
+        barrier(ctx)
+        t0 = time.time()
+        got = broadcast_blob(ctx.dist, host, ctx.dev, fan_out=form)
+        barrier(ctx)
+        times["fan_out_s" if form else "broadcast_s"] = time.time() - t0
+        if buf is not None and not bool((buf == got).all()):
+            raise RuntimeError("the slice fan-out delivered other bytes than the broadcast")
+        buf = got
+    ctx.broadcast_times = dict(times, bytes=int(buf.numel()), ranks=ctx.world,
+                               note="first use of a collective includes its set-up; host staging included")
     if ctx.rank == 0:
-        log("[bench] index image %.1f MB broadcast to %d rank(s) in %.3fs" % (buf.numel() / 1e6, ctx.world, time.time() - t0))
+        log("[bench] index image %.1f MB to %d rank(s): %s" % (buf.numel() / 1e6, ctx.world, times))
     if ctx.dry:
         return None, buf, buf.numel()
     q = ia.FmIndex.attach_device_blob(buf.data_ptr(), buf.numel(), ctx.local_rank)
@@ -404,6 +416,11 @@ def run_count(ctx, args):
         gathered = gather_concat(dist, d_cnt[0], [n] * world, dev)
     else:
         lf_total = lf_local
+    # At N > 1 the same launch also measures BASELINE.json configs[4] (the 8M-pattern batch over the 2 GiB text's 8
+    # segment indexes, strong scaling): one `bench.py --gpus N` yields the weak-scaling headline and this figure
+    segments_line = None
+    if world > 1 and not args.no_secondary:
+        segments_line = run_segments(ctx, args)
     if ctx.rank != 0:
         return None
     if len(seen) != args.gpus or sorted(r[0] for r in seen) != list(range(args.gpus)):
@@ -518,6 +535,8 @@ def run_count(ctx, args):
     secondary = None
     if world == 1 and ref is not None and not args.no_secondary:
         secondary = run_secondary(ctx, args, q, ref, orc, text, host_batches[0], off_host)
+    elif segments_line is not None:
+        secondary = [segments_line]
     # LF-steps the suffix table answered over the timed steps (every rank's shard has the same shape: m-char substrings)
     executed_less = 0
     if not ctx.dry and bytes_per_step and exec_steps_launch is not None:
@@ -557,6 +576,7 @@ def run_count(ctx, args):
             "without_it": None if not without_table else {
                 "ms_per_step": without_table["ms_per_step"],
                 "patterns_per_s": n / (without_table["ms_per_step"] * 1e-3)}},
+        "index_broadcast": getattr(ctx, "broadcast_times", None),
         "overlapped": None if not overlapped else {
             "what": "the same %d steps with %d batches in flight (step i on stream i mod %d): one batch's plan stage overlaps "
                     "another's k_count; max over ranks; not the contract's `value`" % (args.steps, overlapped["streams"], overlapped["streams"]),
@@ -688,6 +708,9 @@ def run_secondary(ctx, args, q, ref, orc, text, pat, off):
 # workload `segments` — BASELINE.json configs[4]
 # ---------------------------------------------------------------------------------------------------------------
 def run_segments(ctx, args):
+    """BASELINE.json configs[4]: every rank holds all segment images, the ONE batch is sharded (strong scaling).
+    Returns the JSON line on rank 0 (None elsewhere).  Called as the workload itself (--workload segments) and, at
+    N > 1, from the default workload for its `secondary` block, so that one `bench.py --gpus N` yields both figures."""
     from index4j_amd import workload
     from index4j_amd.shard import broadcast_blob, gather_concat, ranks_seen, shard_range
 
@@ -706,6 +729,7 @@ def run_segments(ctx, args):
     if dist is not None:
         dist.broadcast(bases, 0)
     segs, bufs, image_bytes = [], [], 0
+    t0 = time.time()
     for s in range(K):
         if dist is None:
             if not ctx.dry:
@@ -718,7 +742,11 @@ def run_segments(ctx, args):
             image_bytes += buf.numel()
             if not ctx.dry:
                 segs.append(ia.FmIndex.attach_device_blob(buf.data_ptr(), buf.numel(), ctx.local_rank))
+    if ctx.rank == 0 and dist is not None:
+        log("[bench] %d segment images (%.2f GB) broadcast and attached on %d rank(s) in %.1fs" % (K, image_bytes / 1e9, world, time.time() - t0))
     sf = None if ctx.dry else ia.SegmentedFmIndex.from_segments(segs, bases.cpu().numpy())
+    table_chars = [0] * K if ctx.dry else [f.suffix_table_info()[0] for f in segs]
+    table_bytes = 0 if ctx.dry else sum(f.suffix_table_info()[1] for f in segs)
     pat = None
     if ctx.rank == 0:
         pat, _off = workload.segment_patterns(texts, total, m)
@@ -735,15 +763,21 @@ def run_segments(ctx, args):
     stream = None if ctx.dry else torch.cuda.current_stream()
     sp = None if ctx.dry else C.c_void_p(stream.cuda_stream)
 
-    def step(with_lf=False):
-        if ctx.dry:
-            return
+    def count_stage(with_lf=False):
         check_rc(ia, ia.lib.fmx_count_segments_dev(sf.handles, K, d_pat.data_ptr(), d_off.data_ptr(), n, d_cnt.data_ptr(),
                                                    d_lf.data_ptr() if with_lf else None, d_st.data_ptr(), d_tmp.data_ptr(), sp),
                  "fmx_count_segments_dev")
+
+    def locate_stage():
         check_rc(ia, ia.lib.fmx_locate_segments_dev(sf.handles, K, sf.base_array.ctypes.data, d_pat.data_ptr(), d_off.data_ptr(), n,
                                                     M, d_locs.data_ptr(), d_found.data_ptr(), d_st.data_ptr(), d_tmp.data_ptr(), sp),
                  "fmx_locate_segments_dev")
+
+    def step(with_lf=False):
+        if ctx.dry:
+            return
+        count_stage(with_lf)
+        locate_stage()
 
     step(True)
     if not ctx.dry:
@@ -759,6 +793,18 @@ def run_segments(ctx, args):
         step()
     barrier(ctx)
     wall = time.perf_counter() - t0
+    # the two stages on their own (this rank's shard), HIP events on the stream the kernels run on
+    stage_ms = None
+    if not ctx.dry:
+        stage_ms = {}
+        for name, fn in (("count", count_stage), ("locate", locate_stage)):
+            e0, e1 = hip_events(torch)
+            e0.record(stream)
+            for _ in range(max(1, args.steps // 4)):
+                fn()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            stage_ms[name] = e0.elapsed_time(e1) / max(1, args.steps // 4)
     sums = torch.tensor([int(d_cnt.sum().item()), int(d_found.sum().item()), lf_local], dtype=torch.int64, device=dev)
     seen = [[0, ctx.local_rank, ctx.local_rank]]
     head = None
@@ -775,8 +821,11 @@ def run_segments(ctx, args):
     if len(seen) != args.gpus or sorted(r[0] for r in seen) != list(range(args.gpus)):
         raise RuntimeError("ranks seen %r do not match --gpus %d" % (seen, args.gpus))
     checked = 0
+    roof = base = None
+    ms_per_step = wall * 1e3 / args.steps
     if not ctx.dry and not args.no_cpu_baseline:
-        # rank 0's oracle sample: the first patterns of the batch against 8 oracle indexes
+        # rank 0's oracle sample: the first patterns of the batch against the K oracle indexes — parity of the run, the
+        # algorithmic bytes / LF-steps of both stages (counting mode), and the CPU figure
         orc = oracle_module()
         cores = os.cpu_count() or 1
         k = min(n, args.segments_check)
@@ -788,15 +837,53 @@ def run_segments(ctx, args):
         exp_l = np.zeros((k, M), np.int64)
         exp_f = np.zeros(k, np.int32)
         bs = bases.cpu().numpy()
+        alg = {"count": 0, "locate": 0}
+        steps_ref = {"count": 0, "locate": 0}
+        table_alg = table_steps = 0
+        k1 = min(k, 2000)  # single-thread sample of the CPU figure
+        cpu_s = 0.0
         for s in range(K):
             o = orc.OracleFmIndex.read(fms[s].write(False))
+            orc.counters_reset()
             oc, _ = o.count_batch(pat[: k * m], off_k, threads=cores)
+            c = orc.counters()
+            alg["count"] += c["alg_bytes"]
+            steps_ref["count"] += c["lf_steps"]
             exp_c += oc
-            ol, of, _ = o.locate_batch(pat[: k * m], off_k, M, threads=cores)
-            for j in range(M):
-                sel = np.flatnonzero((of > j) & (exp_f < M))
-                exp_l[sel, exp_f[sel]] = ol[sel, j].astype(np.int64) + int(bs[s])
-                exp_f[sel] += 1
+            if table_chars[s] and m >= table_chars[s]:  # what this segment's suffix table answers (both stages' backward search)
+                tc = table_chars[s]
+                tail = np.ascontiguousarray(pat[: k * m].reshape(k, m)[:, m - tc:]).reshape(-1)
+                orc.counters_reset()
+                o.count_batch(tail, (np.arange(k + 1, dtype=np.int64) * tc).astype(np.int32), threads=cores)
+                ct = orc.counters()
+                table_alg += ct["alg_bytes"]
+                table_steps += ct["lf_steps"]
+            # the caller's loop `n += segment.locate(p, 0, len, locations, maxMatches - n)`: segment s is asked for the hits
+            # still missing.  Grouped by that limit so that the counters are those of exactly the work asked for; a pattern
+            # that already has all its hits still goes through this segment's backward search on the GPU (k_count runs
+            # for the whole batch), which is counted as executed work
+            remaining = M - exp_f
+            rows = pat[: k * m].reshape(k, m)
+            orc.counters_reset()
+            for r in np.unique(remaining):
+                sel = np.flatnonzero(remaining == r)
+                sub = np.ascontiguousarray(rows[sel]).reshape(-1)
+                off_sub = (np.arange(len(sel) + 1, dtype=np.int64) * m).astype(np.int32)
+                if r <= 0:
+                    o.count_batch(sub, off_sub, threads=cores)
+                    continue
+                ol, of, _ = o.locate_batch(sub, off_sub, int(r), threads=cores)
+                for j in range(int(r)):
+                    hit = np.flatnonzero(of > j)
+                    exp_l[sel[hit], exp_f[sel[hit]]] = ol[hit, j].astype(np.int64) + int(bs[s])
+                    exp_f[sel[hit]] += 1
+            c = orc.counters()
+            alg["locate"] += c["alg_bytes"]
+            steps_ref["locate"] += c["lf_steps"]
+            t1 = time.perf_counter()
+            o.count_batch(pat[: k1 * m], off_k[: k1 + 1], threads=1)
+            o.locate_batch(pat[: k1 * m], off_k[: k1 + 1], M, threads=1)
+            cpu_s += time.perf_counter() - t1
             del o
         live = np.arange(M)[None, :] < exp_f[:, None]
         if not ((cnt == exp_c).all() and (found == exp_f).all() and (locs[live] == exp_l[live]).all()):
@@ -804,6 +891,29 @@ def run_segments(ctx, args):
         if head is not None and not (head[:k] == exp_c).all():
             raise RuntimeError("gathered counts differ from the oracle sample")
         checked = k
+        scale = n / float(k)  # this rank's shard (what the stage times below cover)
+        exec_alg = {"count": (alg["count"] - table_alg) * scale, "locate": (alg["locate"] - table_alg) * scale}
+        dom = "locate" if stage_ms["locate"] >= stage_ms["count"] else "count"
+        whole = (exec_alg["count"] + exec_alg["locate"]) * world  # every rank's shard, per step
+        roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "achieved": exec_alg[dom] / (stage_ms[dom] * 1e-3) / 1e9, "frac": exec_alg[dom] / (stage_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": None, "traffic_note": "no PMC pass of this workload",
+                "kernel": "the %s stage of one shard: %d x (%s)" % (
+                    dom, K, "k_count + k_locate_walk + k_segment_append_hits" if dom == "locate" else "k_count + k_segment_add_counts"),
+                "stage_ms_this_rank": stage_ms,
+                "frac_per_stage": {st: exec_alg[st] / (stage_ms[st] * 1e-3) / 1e9 / HBM_PEAK_GBS for st in stage_ms},
+                "frac_whole_step": whole / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world,
+                "what_frac_means": "algorithmic bytes (oracle counting mode on the %d checked patterns x %d segments, scaled to the "
+                                   "shard, minus what the segments' suffix tables answer) of the stage / its HIP-event time / peak; "
+                                   "frac_whole_step: both stages over the contract's step time, per GPU" % (k, K),
+                "alg_bytes_executed_per_step_per_gpu": (exec_alg["count"] + exec_alg["locate"]),
+                "lf_steps_reference_per_pattern": {st: steps_ref[st] / float(k) for st in steps_ref},
+                "lf_steps_answered_by_tables_per_pattern": table_steps / float(k),
+                "image_bytes_per_text_byte": image_bytes / float(sum(len(t) for t in texts)),
+                "resident_bytes_per_text_byte": (image_bytes + table_bytes) / float(sum(len(t) for t in texts))}
+        base = {"value": k1 / cpu_s, "unit": "patterns/s", "cores": 1, "kind": "port",
+                "sample": "count() + locate(maxMatches %d) of the first %d patterns over the %d oracle indexes "
+                          "(oracle/index4j_oracle.c, C port of index4j's path), 1 thread, %.1f s" % (M, k1, K, cpu_s)}
     out = {
         "metric": "patterns/sec, count()+locate() of one 8M x 8-char batch over a 2 GiB log text as 8 segment indexes",
         "value": None if ctx.dry else total * args.steps / wall,
@@ -813,7 +923,7 @@ def run_segments(ctx, args):
         "ranks_seen": seen,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": wall * 1e3 / args.steps,
+        "ms_per_step": ms_per_step,
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -823,13 +933,17 @@ def run_segments(ctx, args):
                                "indexes of <= 2^%d chars (sampleRate %d), images broadcast to every GPU, batch sharded x%d "
                                "(BASELINE.json configs[4])" % (M, total, m, K, args.segment_log2, args.sample_rate, world),
                    "segments": K, "patterns_total": total, "pattern_len": m, "max_matches": M, "image_bytes_per_gpu": image_bytes,
+                   "suffix_table_chars_per_segment": table_chars, "suffix_table_bytes_per_gpu": table_bytes,
                    "count_checksum_all_ranks": int(sums[0].item()), "hits_all_ranks": int(sums[1].item()),
                    "patterns_checked_vs_oracle": checked},
-        "roofline": None,
-        "cpu_baseline": None,
+        "roofline": roof,
+        "cpu_baseline": base,
     }
     if ctx.dry:
         out["dry_run"] = True
+    for f in segs:
+        if not ctx.dry and dist is not None:
+            f.close()
     return out
 
 

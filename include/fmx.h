@@ -268,6 +268,10 @@ int fmx_set_option(const char *name, int value);
 
 /* deterministic synthetic workload (bench / tests): see index4j_amd/csrc/fmx_synth.cpp */
 int fmx_synth_log(uint64_t seed, int32_t n, uint16_t *out);
+/* the same log lines with runs of multi-byte characters dropped in at word boundaries (~6 % of the characters), `symbols`
+ * distinct characters in all: the shape of the reference's fixture HDFS_2k_multichar.log and of the data set its
+ * published numbers are quoted on (> 1,000 distinct symbols, README.md:291-292) */
+int fmx_synth_log_multichar(uint64_t seed, int32_t n, int32_t symbols, uint16_t *out);
 int fmx_synth_patterns(uint64_t seed, const uint16_t *text, int32_t n, int32_t m, int32_t count, uint16_t *pat,
                        int32_t *pat_off, int32_t *positions);
 

@@ -12,6 +12,7 @@ from .fmindex import (  # noqa: F401
     pack_patterns,
     raise_for_status,
     synth_log,
+    synth_log_multichar,
     synth_patterns,
 )
 from .rrr import RrrVector  # noqa: F401
@@ -19,4 +20,4 @@ from .segments import SegmentedFmIndex, cut_points  # noqa: F401
 from .wavelet import WaveletFixedBlockBoosting  # noqa: F401
 
 __all__ = ["WaveletFixedBlockBoosting", "RrrVector", "SegmentedFmIndex", "cut_points", "FmIndex", "FmIndexBuilder", "FmxError", "as_chars", "chars_to_str", "pack_patterns",
-           "raise_for_status", "synth_log", "synth_patterns", "lib", "LIB_PATH", "SYMBOLS"]
+           "raise_for_status", "synth_log", "synth_log_multichar", "synth_patterns", "lib", "LIB_PATH", "SYMBOLS"]

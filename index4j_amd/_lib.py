@@ -34,7 +34,7 @@ SYMBOLS = [
     "fmx_wavelet_build", "fmx_wavelet_rank_batch", "fmx_wavelet_inverse_select_batch",
     "fmx_rrr_build", "fmx_rrr_rank_ones_batch", "fmx_rrr_access_batch",
     "fmx_convert_byte_pattern", "fmx_status_message", "fmx_status_kind", "fmx_last_error", "fmx_release_scratch", "fmx_device_count", "fmx_set_option",
-    "fmx_synth_log", "fmx_synth_patterns",
+    "fmx_synth_log", "fmx_synth_log_multichar", "fmx_synth_patterns",
 ]
 
 
@@ -99,6 +99,7 @@ def _load():
     L.fmx_release_scratch.restype = None
     L.fmx_set_option.argtypes = [C.c_char_p, C.c_int]
     L.fmx_synth_log.argtypes = [u64, i32, vp]
+    L.fmx_synth_log_multichar.argtypes = [u64, i32, i32, vp]
     L.fmx_synth_patterns.argtypes = [u64, vp, i32, i32, i32, vp, vp, vp]
     return L
 

@@ -239,11 +239,18 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
             if (c != 0) {  // FM:458-460
                 start = ix.C[c];
                 end = ix.C[c + 1];
-                if (kMode == 1 && ix.suffix_table && m >= ix.suffix_chars && n_codes >= ix.suffix_chars) {
+                if ((kMode == 1 || kMode == 2) && ix.suffix_table && m >= ix.suffix_chars && n_codes >= ix.suffix_chars) {
                     // the interval after the last suffix_chars characters is tabulated (k_suffix_table ran this very
-                    // loop for every string of that many codes): one 8-byte load instead of 2 * (suffix_chars - 1) ranks
+                    // loop for every string of that many codes): one 8-byte load instead of 2 * (suffix_chars - 1) ranks.
+                    // A segment of a set looks its OWN table up with the translated codes (a code this alphabet lacks is
+                    // 0 = "not tabulated": the loop runs and lets the character itself decide).
                     (void)fm_suffix_lookup(
-                        ix, [&](int j) { return (uint32_t)(cw >> (j * code_bits)) & code_mask; }, start, end, back);
+                        ix,
+                        [&](int j) {
+                            const uint32_t cj = (uint32_t)(cw >> (j * code_bits)) & code_mask;
+                            return translate ? (uint32_t)(uint16_t)s_xlat[cj] : cj;
+                        },
+                        start, end, back);
                 }
                 while (start < end && back + 1 < m) {  // FM:464
                     ++back;

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 namespace {
 struct SplitMix64 {
@@ -137,6 +138,32 @@ void message(std::string &line, SplitMix64 &r) {
 }
 }  // namespace
 
+// One log line (ASCII, '\n'-terminated) into `line`.
+static void log_line(std::string &line, SplitMix64 &r, uint32_t &sec) {
+    line.clear();
+    sec += r.below(3);
+    uint32_t day = 9 + sec / 86400, s = sec % 86400 + 20 * 3600 + 35 * 60;
+    if (s >= 86400) {
+        s -= 86400;
+        ++day;
+    }
+    put(line, "0811");
+    put_uint(line, day % 100, 2);
+    put(line, " ");
+    put_uint(line, s / 3600, 2);
+    put_uint(line, (s / 60) % 60, 2);
+    put_uint(line, s % 60, 2);
+    put(line, " ");
+    put_uint(line, 1 + r.below(4000));
+    put(line, " ");
+    put(line, kLevels[r.below(9)]);
+    put(line, " ");
+    put(line, kComponents[r.below(10)]);
+    put(line, ": ");
+    message(line, r);
+    put(line, "\n");
+}
+
 extern "C" int fmx_synth_log(uint64_t seed, int32_t n, uint16_t *out) {
     if (n < 0 || !out) return FMX_E_ARG;
     SplitMix64 r(seed);
@@ -144,29 +171,48 @@ extern "C" int fmx_synth_log(uint64_t seed, int32_t n, uint16_t *out) {
     uint32_t sec = 0;  // seconds since 2008-11-09 20:35:00
     std::string line;
     while (pos < n) {
-        line.clear();
-        sec += r.below(3);
-        uint32_t day = 9 + sec / 86400, s = sec % 86400 + 20 * 3600 + 35 * 60;
-        if (s >= 86400) {
-            s -= 86400;
-            ++day;
-        }
-        put(line, "0811");
-        put_uint(line, day % 100, 2);
-        put(line, " ");
-        put_uint(line, s / 3600, 2);
-        put_uint(line, (s / 60) % 60, 2);
-        put_uint(line, s % 60, 2);
-        put(line, " ");
-        put_uint(line, 1 + r.below(4000));
-        put(line, " ");
-        put(line, kLevels[r.below(9)]);
-        put(line, " ");
-        put(line, kComponents[r.below(10)]);
-        put(line, ": ");
-        message(line, r);
-        put(line, "\n");
+        log_line(line, r, sec);
         for (size_t i = 0; i < line.size() && pos < n; ++i) out[pos++] = (uint16_t)(unsigned char)line[i];
+    }
+    return FMX_OK;
+}
+
+// The same log with a LARGE alphabet, shaped like the reference's own fixture (HDFS_2k_multichar.log: ASCII log lines
+// with runs of 2-9 consecutive multi-byte characters dropped in at word boundaries, ~6 % of the characters) and like
+// the data set its published numbers are quoted on (loghub Android.log, "> 1,000 distinct symbols", README.md:291-292).
+// `symbols` = distinct characters wanted (the ASCII part brings ~70; the rest comes from a pool of katakana, Thai and
+// CJK code points, all inside the BMP like the fixture's).  A run = consecutive pool entries from a start drawn with a
+// quadratic skew, so that a few symbols are frequent and most are rare, as in real logs.
+extern "C" int fmx_synth_log_multichar(uint64_t seed, int32_t n, int32_t symbols, uint16_t *out) {
+    if (n < 0 || !out || symbols < 0 || symbols > 30000) return FMX_E_ARG;
+    const int32_t extra = symbols > 70 ? symbols - 70 : 0;
+    std::vector<uint16_t> pool((size_t)extra);
+    for (int32_t i = 0; i < extra; ++i) {
+        if (i < 86)
+            pool[(size_t)i] = (uint16_t)(0x30A1 + i);  // katakana
+        else if (i < 86 + 58)
+            pool[(size_t)i] = (uint16_t)(0x0E01 + (i - 86));  // Thai
+        else
+            pool[(size_t)i] = (uint16_t)(0x4E00 + (uint32_t)(i - 144) * 20000u / (uint32_t)(extra > 144 ? extra - 144 : 1));  // CJK, spread
+    }
+    SplitMix64 r(seed);
+    SplitMix64 r2(seed ^ 0x5bd1e995u);  // the insertions draw from their own stream: the ASCII part equals fmx_synth_log's lines
+    int64_t pos = 0;
+    uint32_t sec = 0;
+    std::string line;
+    while (pos < n) {
+        log_line(line, r, sec);
+        for (size_t i = 0; i < line.size() && pos < n; ++i) {
+            out[pos++] = (uint16_t)(unsigned char)line[i];
+            if (line[i] == ' ' && extra > 0 && r2.below(8) == 0) {
+                const uint32_t len = 2 + r2.below(8);
+                const double u = (double)(r2.next() >> 11) / 9007199254740992.0;
+                uint32_t start = (uint32_t)(u * u * (double)extra);
+                if (start + len > (uint32_t)extra) start = (uint32_t)extra > len ? (uint32_t)extra - len : 0;
+                for (uint32_t k = 0; k < len && start + k < (uint32_t)extra && pos < n; ++k) out[pos++] = pool[start + k];
+                if (pos < n) out[pos++] = ' ';
+            }
+        }
     }
     return FMX_OK;
 }

@@ -117,7 +117,8 @@ class FmIndex:
         buf, n = C.c_void_p(), C.c_size_t()
         check(lib.fmx_save(self._h, int(framed), C.byref(buf), C.byref(n)), "fmx_save")
         try:
-            return C.string_at(buf.value, n.value)
+            # (ctypes.string_at takes a C int: a sampleRate-1 index of 256 MiB serializes to more than 2 GiB)
+            return bytes((C.c_ubyte * n.value).from_address(buf.value))
         finally:
             lib.fmx_free_buffer(buf)
 
@@ -336,6 +337,14 @@ def synth_log(n, seed=42):
     """deterministic synthetic ASCII log text of exactly n chars"""
     out = np.zeros(n, dtype=np.uint16)
     check(lib.fmx_synth_log(seed, n, out.ctypes.data), "fmx_synth_log")
+    return out
+
+
+def synth_log_multichar(n, symbols=1100, seed=42):
+    """the same log with runs of multi-byte characters at word boundaries, `symbols` distinct characters: the shape of the
+    reference's fixture HDFS_2k_multichar.log and of the > 1,000-symbol data set its numbers are quoted on"""
+    out = np.zeros(n, dtype=np.uint16)
+    check(lib.fmx_synth_log_multichar(seed, n, symbols, out.ctypes.data), "fmx_synth_log_multichar")
     return out
 
 

@@ -58,3 +58,30 @@ def segment_patterns(texts, n, m=8, seed=PATTERN_SEED):
         pat[sel] = t[p[:, None] + np.arange(m)[None, :]]
     off = (np.arange(n + 1, dtype=np.int64) * m).astype(np.int32)
     return np.ascontiguousarray(pat.reshape(-1)), off
+
+
+# ---- the reference's own benchmark shapes -------------------------------------------------------
+# FmIndexThroughputState.java:76-83: start uniform in [0, len - maxQueryLength), size uniform in [minQueryLength,
+# maxQueryLength) = 8..31 chars, queries are substrings of the indexed text; extractBenchmark extracts
+# [start, start + maxQueryLength) (FmIndexThroughputBenchmark.java:222-229).  The data set behind the published numbers
+# (loghub Android.log, > 1,000 distinct symbols, README.md:291-292) is not in the repository: the text here is the
+# synthetic log with runs of multi-byte characters (fmx_synth_log_multichar), ~1,100 symbols.
+REFERENCE_SYMBOLS = 1100
+MIN_QUERY, MAX_QUERY = 8, 32
+
+
+def reference_text(text_log2, symbols=REFERENCE_SYMBOLS, seed=TEXT_SEED):
+    from .fmindex import synth_log_multichar
+
+    return synth_log_multichar(1 << text_log2, symbols, seed=seed)
+
+
+def reference_queries(text, n, seed=42, min_len=MIN_QUERY, max_len=MAX_QUERY):
+    """(chars, offsets, starts): n substrings of min_len..max_len-1 chars, the JMH state's query shape"""
+    rng = np.random.default_rng(seed)
+    starts = rng.integers(0, len(text) - max_len, n).astype(np.int64)
+    lens = rng.integers(min_len, max_len, n).astype(np.int64)
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    idx = np.repeat(starts - off[:-1], lens) + np.arange(off[-1])
+    return np.ascontiguousarray(text[idx], dtype=np.uint16), off.astype(np.int32), starts.astype(np.int32)

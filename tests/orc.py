@@ -194,7 +194,7 @@ class OracleFmIndex:
         buf = C.c_void_p()
         n = C.c_size_t()
         lib().orc_fm_write(self.h, int(framed), C.byref(buf), C.byref(n))
-        out = C.string_at(buf.value, n.value)
+        out = bytes((C.c_ubyte * n.value).from_address(buf.value))  # (string_at takes a C int; streams may pass 2 GiB)
         lib().orc_free_buffer(buf)
         return out
 

@@ -6,6 +6,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -49,7 +50,9 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_shard_broadcast_gather():
+@pytest.mark.parametrize("world", [2, 8])
+def test_shard_broadcast_gather(world):
+    """two ranks, and the eight of one node: image broadcast (plain and slice fan-out), contiguous shards, gather"""
     import torch.multiprocessing as mp
 
     s = socket.socket()
@@ -58,7 +61,7 @@ def test_two_rank_shard_broadcast_gather():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     ok = q.get(timeout=240)
@@ -106,6 +109,21 @@ def test_bench_launches_itself_and_reports_the_ranks_that_really_ran():
     assert rc == 0, err[-2000:]
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["patterns_total"] == 5003
     assert sorted(r[0] for r in out["ranks_seen"]) == [0, 1]
+
+
+def test_bench_eight_rank_rehearsal_of_both_workloads_with_the_slice_fan_out():
+    """the driver's N = 8 launch, rehearsed over gloo: `bench.py --gpus 8` carries the weak-scaling headline AND the
+    configs[4] line (segment images broadcast, ONE batch sharded over 8 ranks) in `secondary`; the images travel by the
+    slice fan-out (scatter of slices from rank 0 + all-gather among the ranks)"""
+    rc, out, err = _run_bench(["--gpus", "8"], {"FMX_FAN_OUT_BROADCAST": "1"}, timeout=900)
+    assert rc == 0, err[-2000:]
+    assert out["dry_run"] and out["n_gpus"] == 8 and sorted(r[0] for r in out["ranks_seen"]) == list(range(8))
+    seg = out["secondary"][0]
+    assert seg["n_gpus"] == 8 and seg["scaling"] == "strong" and seg["config"]["patterns_total"] == 5003
+    assert sorted(r[0] for r in seg["ranks_seen"]) == list(range(8))
+    rc, out, err = _run_bench(["--gpus", "8", "--workload", "segments"], {"FMX_FAN_OUT_BROADCAST": "1"}, timeout=900)
+    assert rc == 0, err[-2000:]
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and sorted(r[0] for r in out["ranks_seen"]) == list(range(8))
 
 
 def test_bench_refuses_a_rank_count_that_differs_from_gpus():
