@@ -145,8 +145,9 @@ int fmx_count_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32
  * an opaque handle into per-stream scratch owned by the index, or NULL for small batches.  It stays valid until
  * ANYTHING else plans on that stream (every count / locate / segment / pipeline call does) and only for the same
  * d_pat / d_pat_off contents.  ordered = the k_count kernel over that order; a handle that is no longer the
- * stream's live plan is ignored (the batch is then processed in the caller's order: same results).  Results are
- * written at the ORIGINAL pattern index. */
+ * stream's live plan — or that was made for other d_pat / d_pat_off BUFFERS or another n — is ignored (the batch is
+ * then processed in the caller's order: same results).  The library compares buffer addresses, not contents: a
+ * caller that refills d_pat or d_pat_off in place must plan again.  Results are written at the ORIGINAL pattern index. */
 int fmx_count_plan_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
                        const void **d_plan, void *stream);
 int fmx_count_ordered_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, const void *d_plan,

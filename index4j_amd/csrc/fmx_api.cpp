@@ -16,6 +16,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -68,6 +69,7 @@ struct fmx_index {
     struct Plan {  // the last fmx_count_plan_dev result per stream: the batch's records in processing order
         fmx::CountPlan plan;
         const uint16_t *pat = nullptr;
+        const int32_t *pat_off = nullptr;  // the records carry lengths and code words cut with THESE offsets
     };
     // erased whenever anything else plans on the stream or its plan scratch moves: a stale handle then simply
     // means "the caller's order" (k_count maps the characters itself) instead of reading another batch's records
@@ -220,6 +222,16 @@ int get_workspace(const fmx_index *idx, void *stream, int kind, size_t bytes, vo
         slot = {p, bytes};
     }
     *out = slot.first;
+    return FMX_OK;
+}
+
+// Host-buffer entry points size their device copy of the characters from pat_off[n] alone: offsets that start below 0 or
+// run backwards would make the kernels read outside it (k_plan_codes fetches 16-byte pattern tails).  One O(n) pass.
+int check_offsets(const int32_t *pat_off, int32_t n) {
+    if (!pat_off || n < 0) return fail(FMX_E_ARG, "bad arguments");
+    if (pat_off[0] < 0) return fail(FMX_E_ARG, "pattern offsets start below 0");
+    for (int32_t i = 0; i < n; ++i)
+        if (pat_off[i + 1] < pat_off[i]) return fail(FMX_E_ARG, "pattern offsets decrease");
     return FMX_OK;
 }
 
@@ -536,10 +548,12 @@ int fmx_attach_device_blob(void *device_blob, size_t len, int device, fmx_index 
     {
         // the image arrived from somewhere else (an RCCL broadcast): validate it on a host copy before any kernel
         // may walk it — sections, per-superblock tables, block headers, mapping entries, and the body checksum
-        std::vector<uint8_t> copy(len);
-        HIP_TRY(hipMemcpy(copy.data(), device_blob, len, hipMemcpyDeviceToHost));
+        // (an uninitialised buffer: a zero-filled vector would touch every page of a GB-sized image once more per rank)
+        std::unique_ptr<uint8_t[]> copy(new (std::nothrow) uint8_t[len]);
+        if (!copy) return fail(FMX_E_NOMEM, "out of memory");
+        HIP_TRY(hipMemcpy(copy.get(), device_blob, len, hipMemcpyDeviceToHost));
         std::string err;
-        if (fmx::validate_blob(copy.data(), len, err)) return fail(FMX_E_FORMAT, err);
+        if (fmx::validate_blob(copy.get(), len, err)) return fail(FMX_E_FORMAT, err);
     }
     idx->rrr_only = idx->hdr.kind == 1;
     idx->d_blob = device_blob;
@@ -596,6 +610,7 @@ int fmx_count_plan_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_
     rc = plan_order(idx, d_pat, d_pat_off, n, scratch, &plan.plan);
     if (rc) return rc;
     plan.pat = d_pat;
+    plan.pat_off = d_pat_off;
     {
         std::lock_guard<std::mutex> lock(idx->ws_mutex);
         idx->plans[stream] = plan;
@@ -613,7 +628,8 @@ int fmx_count_ordered_dev(const fmx_index *idx, const uint16_t *d_pat, const int
     if (d_plan) {         // (stale, foreign) means the caller's order
         std::lock_guard<std::mutex> lock(idx->ws_mutex);
         auto it = idx->plans.find(stream);
-        if (it != idx->plans.end() && it->second.plan.recs == d_plan && it->second.plan.n == n && it->second.pat == d_pat)
+        if (it != idx->plans.end() && it->second.plan.recs == d_plan && it->second.plan.n == n && it->second.pat == d_pat &&
+            it->second.pat_off == d_pat_off)
             plan = it->second.plan;
     }
     int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, &plan, false, n, d_counts, d_lf_steps, d_status,
@@ -862,6 +878,8 @@ int fmx_count_segments(const fmx_index *const *segs, int32_t n_segs, const uint1
     if (n < 0 || (n > 0 && (!pat_off || !counts))) return fail(FMX_E_ARG, "bad arguments");
     if (n == 0) return FMX_OK;
     HIP_TRY(hipSetDevice(segs[0]->device));
+    rc = check_offsets(pat_off, n);
+    if (rc) return rc;
     const size_t chars = (size_t)(pat_off[n] > 0 ? pat_off[n] : 0);
     DevBuf d_pat, d_off, d_cnt, d_lf, d_st, d_tmp;
     Scratch scratch(segs[0], nullptr, true);
@@ -893,6 +911,8 @@ int fmx_locate_segments(const fmx_index *const *segs, int32_t n_segs, const int6
         return fail(FMX_E_ARG, "bad arguments");
     if (n == 0) return FMX_OK;
     HIP_TRY(hipSetDevice(segs[0]->device));
+    rc = check_offsets(pat_off, n);
+    if (rc) return rc;
     const size_t chars = (size_t)(pat_off[n] > 0 ? pat_off[n] : 0);
     const size_t slots = (size_t)n * (size_t)max_matches;
     DevBuf d_pat, d_off, d_locs, d_found, d_st, d_tmp;
@@ -927,6 +947,8 @@ int fmx_count_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pa
     if (n < 0 || (n > 0 && (!pat_off || !counts))) return fail(FMX_E_ARG, "bad arguments");
     if (n == 0) return FMX_OK;
     HIP_TRY(hipSetDevice(idx->device));
+    rc = check_offsets(pat_off, n);
+    if (rc) return rc;
     const size_t chars = (size_t)(pat_off[n] > 0 ? pat_off[n] : 0);
     DevBuf d_pat, d_off, d_cnt, d_lf, d_st;
     HIP_TRY(d_pat.alloc(chars * 2 + 8));
@@ -955,6 +977,8 @@ int fmx_locate_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *p
         return fail(FMX_E_ARG, "bad arguments");
     if (n == 0) return FMX_OK;
     HIP_TRY(hipSetDevice(idx->device));
+    rc = check_offsets(pat_off, n);
+    if (rc) return rc;
     const size_t chars = (size_t)(pat_off[n] > 0 ? pat_off[n] : 0);
     const size_t loc_bytes = (size_t)n * (size_t)loc_cap * 4;
     DevBuf d_pat, d_off, d_locs, d_found, d_lf, d_st, d_ws;
@@ -992,6 +1016,8 @@ static int locate_pipeline_host(const fmx_index *idx, const uint16_t *pat, const
         return fail(FMX_E_ARG, "bad arguments");
     if (n == 0) return FMX_OK;
     HIP_TRY(hipSetDevice(idx->device));
+    rc = check_offsets(pat_off, n);
+    if (rc) return rc;
     const size_t chars = (size_t)(pat_off[n] > 0 ? pat_off[n] : 0);
     const size_t slots = (size_t)n * (size_t)max_matches;
     const size_t dst_bytes = slots * (size_t)row_len * 2;

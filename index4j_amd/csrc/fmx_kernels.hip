@@ -187,91 +187,185 @@ constexpr int kFineBits = 10;  // width of the window-local order of k_plan_fine
 // words made with ANOTHER index of a segment set (0 = character absent there).
 // kMode: 0 = no plan (the caller's order, characters mapped here), 1 = plan made with this index, 2 = plan made with
 // another index of a segment set (code words translated), 3 = such a plan with 16-bit codes (order only)
-template <int kBlock, int kMode>
+// The codes of a pattern's characters reach the loop in CHUNKS of up to 8 consecutive characters (counted from the
+// pattern's end), code j of the chunk at bits [j * code_bits, (j + 1) * code_bits) of a 128-bit pair.  The first chunk
+// of a planned batch is the record's code word; every further chunk is ONE fetch of the pattern's next 16 bytes (aligned
+// dwords, pattern_tail_load) mapped through an LDS copy of the character map's first 256 entries — instead of a
+// character load and a map lookup (two dependent loads) in front of every pair of ranks.  Patterns of the
+// reference's benchmark shape are 8..31 characters long (FmIndexThroughputState.java:76-83).
+struct CodeChunk {
+    uint64_t lo, hi;
+    int32_t base;  // `back` index of the chunk's first code
+    int32_t n;     // codes in the chunk
+};
+template <int kCodeBits>
+__device__ __forceinline__ int32_t chunk_code(const CodeChunk &ck, int32_t j) {
+    constexpr uint32_t code_mask = (1u << kCodeBits) - 1u;
+    const uint32_t pos = (uint32_t)j * (uint32_t)kCodeBits;
+    if (kCodeBits == 8) return (int32_t)((uint32_t)(ck.lo >> pos) & code_mask);  // 8 codes of 8 bits: one word
+    const uint64_t w = pos < 64u ? ck.lo : ck.hi;
+    return (int32_t)((uint32_t)(w >> (pos & 63u)) & code_mask);
+}
+// the chunk that starts `back` characters before the pattern's last one (`beg` = the pattern's first character).
+// NOT inlined: a refill happens once per 8 characters, and with its forty-odd instructions and five loads folded into
+// k_count the register allocation of the whole kernel got worse (the headline batch, whose patterns never refill, ran
+// 1.2 % slower with the code merely present: profiles/r03_experiments.txt).
+template <int kCodeBits>
+__device__ __attribute__((noinline)) CodeChunk chunk_refill(const int16_t *__restrict__ char2code, const int16_t *s_map,
+                                                            const uint16_t *__restrict__ pat, int32_t beg, int32_t m,
+                                                            int32_t back) {
+    const int32_t left = m - back;  // characters not yet consumed (>= 1)
+    const TailWords t = pattern_tail_load(pat, beg, left);
+    uint32_t ch[8];
+    pattern_tail_chars(t, pat, beg, left, ch);
+    uint64_t lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        uint32_t c = 0;
+        if (j < left) c = (uint32_t)(uint16_t)(ch[j] < 256u ? s_map[ch[j]] : char2code[ch[j]]);
+        const uint32_t pos = (uint32_t)(j * kCodeBits);
+        if (pos < 64u)
+            lo |= (uint64_t)c << pos;
+        else
+            hi |= (uint64_t)c << (pos - 64u);
+    }
+    CodeChunk ck;
+    ck.lo = lo;
+    ck.hi = hi;
+    ck.base = back;
+    ck.n = left < 8 ? left : 8;
+    return ck;
+}
+
+// The backward search of ONE pattern by a lane pair (FM:455-474): lane `role` 0 computes `start`, lane 1 `end`.
+// kChunks = false: every character the loop will consume has its code in the record's word `ck.lo` (m <= ck.n; the
+// common case of a planned batch of short patterns: nothing but shifts in front of a rank).  kChunks = true: further
+// chunks are fetched and mapped on the way (chunk_refill), or — kMode 0 / 3 — all of them.
+template <int kMode, int kCodeBits, bool kChunks>
+__device__ __forceinline__ void count_one(const DevIndex &ix, const int16_t *s_map, const int16_t *s_xlat,
+                                          const uint16_t *__restrict__ pat, const int32_t *__restrict__ pat_off, int32_t p,
+                                          int32_t m, CodeChunk ck, int role, int32_t &start, int32_t &end, int32_t &back,
+                                          int &status) {
+    constexpr uint32_t code_mask = (1u << kCodeBits) - 1u;
+    const uint16_t *s_inv = nullptr;
+    constexpr bool translate = kMode == 2;
+    // where the pattern starts: only patterns longer than the record's code word need it (one load, requested here,
+    // used by the first refill)
+    int32_t beg = 0;
+    if (kChunks) {
+        if (m > ck.n) beg = pat_off[p];
+        if (kMode == 0 || kMode == 3) ck = chunk_refill<kCodeBits>(ix.char2code, s_map, pat, beg, m, 0);  // no code word: the first chunk
+    }
+    // the plan stage left the codes of the trailing characters (no character load and map lookup in front of every rank)
+    int32_t c = chunk_code<kCodeBits>(ck, 0);
+    // a foreign code of 0 only says "not in the plan's alphabet": the character itself decides here
+    if (translate) c = c ? s_xlat[c] : fm_map(ix, pat[pat_off[p] + m - 1]);
+    if (c == 0) return;  // FM:458-460
+    start = ix.C[c];
+    end = ix.C[c + 1];
+    if (ix.suffix_table && m >= ix.suffix_chars && ck.n >= ix.suffix_chars) {
+        // the interval after the last suffix_chars characters is tabulated (k_suffix_table ran this very loop for every
+        // string of that many codes): one 8-byte load instead of 2 * (suffix_chars - 1) ranks.  A segment of a set looks
+        // its OWN table up with the translated codes (a code this alphabet lacks is 0 = "not tabulated": the loop runs and
+        // lets the character itself decide).
+        (void)fm_suffix_lookup(
+            ix,
+            [&](int j) {
+                const uint32_t cj = (uint32_t)chunk_code<kCodeBits>(ck, j);
+                return translate ? (uint32_t)(uint16_t)s_xlat[cj] : cj;
+            },
+            start, end, back);
+    }
+    bool first_chunk = true;  // the record's word (its codes are the PLAN's: translated in mode 2)
+    while (start < end && back + 1 < m) {  // FM:464
+        ++back;
+        if (kChunks) {
+            if (back - ck.base >= ck.n) {
+                ck = chunk_refill<kCodeBits>(ix.char2code, s_map, pat, beg, m, back);
+                first_chunk = false;
+            }
+            c = chunk_code<kCodeBits>(ck, back - ck.base);
+        } else {
+            c = (int32_t)((uint32_t)(ck.lo >> (back * kCodeBits)) & code_mask);
+        }
+        if (translate && first_chunk) c = c ? s_xlat[c] : fm_map(ix, pat[pat_off[p] + m - 1 - back]);
+        if (c == 0) {  // FM:466-468: ends the search before this character's two ranks
+            start = end = 0;
+            --back;
+            break;
+        }
+        const int32_t mine = wt_rank_folded(ix, s_inv, (uint32_t)(role ? end : start), c, status);  // C[c] + rank
+        const int32_t other = __shfl_xor(mine, 1);
+        start = role ? other : mine;  // FM:469
+        end = role ? mine : other;    // FM:470
+    }
+}
+
+template <int kBlock, int kMode, int kCodeBits>
 FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__ pat,
                                                   const int32_t *__restrict__ pat_off,
                                                   const PlanRec *__restrict__ recs, int32_t n,
                                                   int32_t *__restrict__ counts, int32_t *__restrict__ lf_steps,
                                                   int32_t *__restrict__ status_out, int32_t *__restrict__ range_out,
-                                                  int code_bits, const int32_t *__restrict__ plan_look_up,
-                                                  int32_t plan_sigma) {
-    const uint16_t *s_inv = nullptr;  // no RRR vector on this kernel's path (the wavelet tree's are expanded)
-    FMX_WITH_SB_CACHE(ix_global, ix);
+                                                  const int32_t *__restrict__ plan_look_up, int32_t plan_sigma) {
+    // kCodeBits: width of a code in the record's word and in the chunks — 8 when the alphabet fits (8 codes per word),
+    // else 16 (the plan's alphabet in modes 1 / 2, this index's own in modes 0 / 3)
     constexpr int kPairs = kBlock / 2;
     __shared__ int16_t s_xlat[256];
+    __shared__ int16_t s_map[256];  // this index's character map, characters below 256
     constexpr bool planned = kMode != 0;
     constexpr bool translate = kMode == 2;  // only offered for 8-bit code words (plan_sigma <= 256)
-    if (translate) {
-        for (int c = threadIdx.x; c < 256; c += kBlock)
-            s_xlat[c] = (c > 0 && c < plan_sigma) ? (int16_t)fm_map(ix, (uint16_t)plan_look_up[c]) : (int16_t)0;
-        __syncthreads();
+    // (staged in front of the superblock cache so that both share ONE barrier: a workgroup lives for a few hundred
+    // patterns, its start-up is not free)
+    for (int c = threadIdx.x; c < 256; c += kBlock) {
+        s_map[c] = ix_global.char2code[c];
+        if (translate)
+            s_xlat[c] = (c > 0 && c < plan_sigma) ? (int16_t)fm_map(ix_global, (uint16_t)plan_look_up[c]) : (int16_t)0;
     }
+    FMX_WITH_SB_CACHE(ix_global, ix);
+    if (!ix.sb_cache) __syncthreads();
     const int role = threadIdx.x & 1;
-    const int n_codes = (kMode == 1 || kMode == 2) ? 64 / code_bits : 0;
-    const uint32_t code_mask = (1u << code_bits) - 1u;
+    // codes the record's word carries (mode 3: a foreign plan with 16-bit codes gives the order only)
+    constexpr int n_codes = (kMode == 1 || kMode == 2) ? 64 / kCodeBits : 0;
     const int32_t pairs_per_grid = (int32_t)gridDim.x * kPairs;  // 32-bit indices: n < 2^31, fewer live registers
     // (an XCD-aware block order — a contiguous eighth of the sorted batch per XCD — was measured slower:
     // profiles/r01_i_xcd_remap.txt)
-    for (int32_t q = (int32_t)blockIdx.x * kPairs + (int32_t)(threadIdx.x >> 1); q < n; q += pairs_per_grid) {
-        int32_t p = q, m;
-        uint64_t cw = 0ull;
-        if (planned) {
-            Quad rq = ld_quad(recs + q);
-            FMX_PIN_QUAD(rq);
-            cw = (uint64_t)rq.x | ((uint64_t)rq.y << 32);
-            p = (int32_t)rq.z;
-            m = (int32_t)(rq.w & kPlanLongPattern);
-            if (m == (int32_t)kPlanLongPattern) m = pat_off[p + 1] - pat_off[p];
-        } else {
-            m = pat_off[p + 1] - pat_off[p];
+    for (int32_t q0 = (int32_t)blockIdx.x * kPairs; q0 < n; q0 += pairs_per_grid) {
+        const int32_t q = q0 + (int32_t)(threadIdx.x >> 1);
+        const bool live = q < n;
+        int32_t p = q, m = 0;
+        CodeChunk ck = {0ull, 0ull, 0, 0};
+        if (live) {
+            if (planned) {
+                Quad rq = ld_quad(recs + q);
+                FMX_PIN_QUAD(rq);
+                ck.lo = (uint64_t)rq.x | ((uint64_t)rq.y << 32);
+                p = (int32_t)rq.z;
+                m = (int32_t)(rq.w & kPlanLongPattern);
+                if (m == (int32_t)kPlanLongPattern) m = pat_off[p + 1] - pat_off[p];
+            } else {
+                m = pat_off[p + 1] - pat_off[p];
+            }
         }
+        ck.n = m < n_codes ? m : n_codes;
         int status = ST_OK;
         int32_t start = 0, end = 0;
         int32_t back = 0;  // characters consumed so far, counted from the pattern's end (FM:456: i = m - 1 - back)
-        if (m <= 0) {
+        // one decision per wave: does any of its patterns run past the record's code word?
+#if defined(FMX_EXPERIMENT_NO_CHUNKS)
+        const bool chunks = kMode == 0 || kMode == 3;
+#else
+        const bool chunks = n_codes == 0 || __any(m > n_codes);
+#endif
+        if (live && m <= 0) {
             status = ST_JAVA_AIOOBE;  // pattern[-1], FM:456-457
-        } else {
-            // the plan stage left the codes of the trailing characters (no character load and map lookup in front of
-            // every rank)
-            int32_t c = n_codes ? (int32_t)((uint32_t)cw & code_mask) : fm_map(ix, pat[pat_off[p] + m - 1]);
-            // a foreign code of 0 only says "not in the plan's alphabet": the character itself decides here
-            if (translate) c = c ? s_xlat[c] : fm_map(ix, pat[pat_off[p] + m - 1]);
-            if (c != 0) {  // FM:458-460
-                start = ix.C[c];
-                end = ix.C[c + 1];
-                if ((kMode == 1 || kMode == 2) && ix.suffix_table && m >= ix.suffix_chars && n_codes >= ix.suffix_chars) {
-                    // the interval after the last suffix_chars characters is tabulated (k_suffix_table ran this very
-                    // loop for every string of that many codes): one 8-byte load instead of 2 * (suffix_chars - 1) ranks.
-                    // A segment of a set looks its OWN table up with the translated codes (a code this alphabet lacks is
-                    // 0 = "not tabulated": the loop runs and lets the character itself decide).
-                    (void)fm_suffix_lookup(
-                        ix,
-                        [&](int j) {
-                            const uint32_t cj = (uint32_t)(cw >> (j * code_bits)) & code_mask;
-                            return translate ? (uint32_t)(uint16_t)s_xlat[cj] : cj;
-                        },
-                        start, end, back);
-                }
-                while (start < end && back + 1 < m) {  // FM:464
-                    ++back;
-                    if (back < n_codes) {
-                        c = (int32_t)((uint32_t)(cw >> (back * code_bits)) & code_mask);
-                        if (translate) c = c ? s_xlat[c] : fm_map(ix, pat[pat_off[p] + m - 1 - back]);
-                    } else {
-                        c = fm_map(ix, pat[pat_off[p] + m - 1 - back]);
-                    }
-                    if (c == 0) {  // FM:466-468: ends the search before this character's two ranks
-                        start = end = 0;
-                        --back;
-                        break;
-                    }
-                    const int32_t mine = wt_rank_folded(ix, s_inv, (uint32_t)(role ? end : start), c, status);  // C[c] + rank
-                    const int32_t other = __shfl_xor(mine, 1);
-                    start = role ? other : mine;  // FM:469
-                    end = role ? mine : other;    // FM:470
-                }
-            }
+        } else if (live) {
+            if (chunks)
+                count_one<kMode, kCodeBits, true>(ix, s_map, s_xlat, pat, pat_off, p, m, ck, role, start, end, back, status);
+            else
+                count_one<kMode, kCodeBits, false>(ix, s_map, s_xlat, pat, pat_off, p, m, ck, role, start, end, back, status);
         }
+        if (!live) continue;  // (whole lane pairs: q is the same for both lanes of a pair)
         const int32_t steps = 2 * back;  // LF-steps executed: two ranks per character after the first
         status |= __shfl_xor(status, 1);
         if (role == 0) {
@@ -939,16 +1033,23 @@ int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_
     const int mode = !recs ? 0 : (!plan_is_foreign ? 1 : (translate ? 2 : 3));
     DevIndex ix_launch = ix;
     if (!g_suffix_table_use) ix_launch.suffix_table = nullptr;  // (A/B: the same index without its table)
+    // code width: the plan's in modes 1 / 2 (its record words), this index's own where the kernel makes the chunks itself
+    const int bits = (mode == 1 || mode == 2) ? pl.code_bits : plan_code_bits(ix.wt_sigma);
+#define FMX_COUNT_LAUNCH(BLOCK, MODE, BITS)                                                                           \
+    hipLaunchKernelGGL((k_count<BLOCK, MODE, BITS>), grid__, dim3(BLOCK), (size_t)g_lds_pad_kb * 1024, st, ix_launch, pat, \
+                       off, recs, n, counts, lf, status, range, pl.look_up, pl.sigma)
 #define FMX_COUNT_MODE(MODE)                                                                                       \
     do {                                                                                                           \
         const int blk__ = g_block;                                                                                 \
         const dim3 grid__(grid_for(2 * (int64_t)n, blk__, n_cu));                                                  \
-        if (blk__ == 1024)                                                                                         \
-            hipLaunchKernelGGL((k_count<1024, MODE>), grid__, dim3(1024), (size_t)g_lds_pad_kb * 1024, st, ix_launch, pat, off, recs, n, \
-                               counts, lf, status, range, pl.code_bits, pl.look_up, pl.sigma);                     \
+        if (blk__ == 1024 && bits == 8)                                                                            \
+            FMX_COUNT_LAUNCH(1024, MODE, 8);                                                                       \
+        else if (blk__ == 1024)                                                                                    \
+            FMX_COUNT_LAUNCH(1024, MODE, 16);                                                                      \
+        else if (bits == 8)                                                                                        \
+            FMX_COUNT_LAUNCH(512, MODE, 8);                                                                        \
         else                                                                                                       \
-            hipLaunchKernelGGL((k_count<512, MODE>), grid__, dim3(512), (size_t)g_lds_pad_kb * 1024, st, ix_launch, pat, off, recs, n,   \
-                               counts, lf, status, range, pl.code_bits, pl.look_up, pl.sigma);                     \
+            FMX_COUNT_LAUNCH(512, MODE, 16);                                                                       \
     } while (0)
     if (mode == 0)
         FMX_COUNT_MODE(0);
@@ -958,6 +1059,7 @@ int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_
         FMX_COUNT_MODE(2);
     else
         FMX_COUNT_MODE(3);
+#undef FMX_COUNT_LAUNCH
 #undef FMX_COUNT_MODE
     return (int)hipGetLastError();
 }

@@ -59,3 +59,33 @@ def test_blob_header_is_self_describing():
     b = f.blob()
     assert bytes(b[:4]) == b"FMX1" and int(np.frombuffer(bytes(b[8:16]), np.uint64)[0]) == len(b)
     assert len(b) % 64 == 0
+
+
+def test_jni_glue_type_checks_against_fmx_h():
+    """bindings/jni/fmx_jni.c cannot be built here (no JDK).  Type-checked with gcc -fsyntax-only against include/fmx.h and a
+    test-local declaration of the JNI entries it uses (tests/jni_stub/jni.h): a change of the C ABI that the glue does not
+    follow — an argument added, a pointer type changed — fails here instead of in a maintainer's build."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    r = subprocess.run([gcc, "-fsyntax-only", "-std=c11", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter",
+                        "-I", os.path.join(ROOT, "tests", "jni_stub"), "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "bindings", "jni", "fmx_jni.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # every native method the Java class declares has its JNI entry point in the glue, and the other way round
+    java = open(os.path.join(ROOT, "bindings", "java", "com", "dynatrace", "fm", "gpu", "GpuFmIndex.java")).read()
+    glue = open(os.path.join(ROOT, "bindings", "jni", "fmx_jni.c")).read()
+    declared = set(re.findall(r"\bnative\s+[\w\[\]]+\s+(native\w+)\s*\(", java))
+    defined = set(re.findall(r"Java_com_dynatrace_fm_gpu_GpuFmIndex_(native\w+)\s*\(", glue))
+    assert declared and declared == defined, (sorted(declared - defined), sorted(defined - declared))
+
+
+def test_fmx_h_is_plain_c():
+    """the header a cgo / JNI / Panama binding includes compiles as C11 on its own (no C++, no torch, no HIP types)"""
+    import subprocess
+
+    r = subprocess.run(["gcc", "-fsyntax-only", "-std=c11", "-Wall", "-Wextra", "-Werror", "-x", "c",
+                        os.path.join(ROOT, "include", "fmx.h")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]

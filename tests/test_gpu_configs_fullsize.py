@@ -152,14 +152,16 @@ def test_config3_extract_until_boundary_100k_on_sample_rate_64(text256, batch):
 
 def test_config4_share_over_8_segments_vs_8_oracle_indexes():
     """2 GiB as 8 segment indexes, all resident on this GPU (SURVEY §8e scheme (i)): counts summed over the
-    segments and base-shifted hits of a 32,768-pattern share of the batch against 8 oracle indexes"""
+    segments and base-shifted hits of the whole per-GPU share of the 8M batch (1,048,576 patterns) against 8 oracle
+    indexes; segments 1..7 look their own suffix tables up with translated code words"""
     K = 8
     texts = workload.segment_texts(K, 28)
     sf = workload.build_segment_set(texts, 32, device=0, build_device=0)
     try:
         assert sum(len(t) for t in texts) > (1 << 31) - (1 << 20)  # a text one FmIndex cannot hold
-        n = 1 << 15
+        n = 1 << 20
         pat, off = workload.segment_patterns(texts, n, M)
+        assert all(f.suffix_table_info()[0] >= 2 for f in sf.segments)
         cnt, st, lf = sf.count_batch(pat, off, want_steps=True)
         locs, found, st2 = sf.locate_batch(pat, off, 16)
         exp_c = np.zeros(n, np.int64)
