@@ -1370,6 +1370,7 @@ struct TextWindow {
     int64_t row_stride, slot_stride;
     int32_t s;        // sample rate
     int32_t k_lo;     // first interval in the window (-1: empty)
+    int32_t n;        // intervals in the window: G after a refill, G / 2 after the first fill of both windows
     int32_t g;        // this lane's index in the group
     int32_t steps;    // LF-steps this lane walked
     bool suspect;     // some walk of the group touched a quirk path -> redo the query literally
@@ -1393,27 +1394,84 @@ FMX_HD int32_t group_sum(int32_t v) {
     return v;
 }
 
-// make interval k resident; dir > 0: window [k, k+G), dir < 0: window [k-G+1, k]
+// Interval k lives in slot k mod G of the window's buffer (a ring), so that a window can GROW by the slots it does not
+// use yet without moving what it holds.
+template <int G>
+FMX_HD uint16_t *window_slot(const TextWindow<G> &w, int32_t k) {
+    return w.buf + (int64_t)(k & (G - 1)) * w.slot_stride;
+}
+// make interval k resident.  Adjacent to a window that still has free slots: the window grows towards k by as many
+// intervals as it has free slots (what it holds — the interval of `from` above all — stays).  Otherwise the window is
+// replaced; dir > 0: [k, k+G), dir < 0: [k-G+1, k].  Every lane that fetches walks ONE interval.
 template <int G>
 FMX_HD void window_refill(const DevIndex &ix, const uint16_t *inv, TextWindow<G> &w, int32_t k, int dir) {
     const int32_t k_max = (ix.length - 1) / w.s;  // last interval that holds text (incl. the sentinel)
-    int32_t lo = dir > 0 ? k : k - (G - 1);
-    if (lo < 0) lo = 0;
-    w.k_lo = lo;
-    const int32_t mine = lo + w.g;
+    int32_t mine = -1;
+    if (w.k_lo >= 0 && w.n < G && dir < 0 && k == w.k_lo - 1) {  // grow to the left
+        int32_t e = G - w.n;
+        if (e > k + 1) e = k + 1;  // (not below interval 0)
+        if (w.g < e) mine = k - w.g;
+        w.k_lo -= e;
+        w.n += e;
+    } else if (w.k_lo >= 0 && w.n < G && dir > 0 && k == w.k_lo + w.n) {  // grow to the right
+        const int32_t e = G - w.n;
+        if (w.g < e) mine = k + w.g;
+        w.n += e;
+    } else {
+        int32_t lo = dir > 0 ? k : k - (G - 1);
+        if (lo < 0) lo = 0;
+        w.k_lo = lo;
+        w.n = G;
+        mine = lo + w.g;
+    }
     bool ok = true;
-    if (mine <= k_max) {
+    if (mine >= 0 && mine <= k_max) {
         int status = ST_OK;
-        ok = fm_fetch_interval(ix, inv, mine, w.buf + (int64_t)w.g * w.slot_stride, w.row_stride, w.steps, status);
+        ok = fm_fetch_interval(ix, inv, mine, window_slot<G>(w, mine), w.row_stride, w.steps, status);
     }
     if (group_any<G>(!ok)) w.suspect = true;
+}
+
+// A narrower first fill (option boundary_first_fill = 1; measured, not the default — profiles/r03_experiments.txt), at
+// ONE program point for the whole group: half of the lanes fetch the intervals up to k0 (the left part and
+// text[from ..]), the other half those behind it — one walk per lane.  A line of log text is two or three sample
+// intervals long; text beyond these G intervals is fetched when the replay asks for it, the windows growing into their
+// free slots.  The default fetches G intervals on each side up front: 8 walks per query where 3 are needed, but no lane
+// ever waits for another query's refill.
+template <int G>
+FMX_HD void window_fill_both(const DevIndex &ix, const uint16_t *inv, TextWindow<G> &wl, TextWindow<G> &wr, int32_t k0,
+                             bool want_right) {
+    constexpr int H = G / 2;
+    const int32_t k_max = (ix.length - 1) / wl.s;
+    int32_t lo = k0 - (H - 1);
+    if (lo < 0) lo = 0;
+    wl.k_lo = lo;
+    wl.n = k0 - lo + 1;
+    wr.k_lo = k0 + 1;
+    wr.n = H;
+    // ONE call site for all lanes (an if / else around two walks would run them one after the other)
+    int32_t mine = -1;
+    uint16_t *slot = wl.buf;
+    if (wl.g < H) {
+        if (lo + wl.g <= k0) mine = lo + wl.g;
+        slot = window_slot<G>(wl, lo + wl.g);
+    } else if (want_right) {
+        if (k0 + 1 + (wl.g - H) <= k_max) mine = k0 + 1 + (wl.g - H);
+        slot = window_slot<G>(wr, k0 + 1 + (wl.g - H));
+    }
+    bool ok = true;
+    if (mine >= 0) {
+        int status = ST_OK;
+        ok = fm_fetch_interval(ix, inv, mine, slot, wl.row_stride, wl.steps, status);
+    }
+    if (group_any<G>(!ok)) wl.suspect = true;
 }
 
 template <int G>
 FMX_HD int32_t window_code_at(const DevIndex &ix, const uint16_t *inv, TextWindow<G> &w, int32_t pos, int dir) {
     const int32_t k = pos / w.s;
-    if (w.k_lo < 0 || k < w.k_lo || k >= w.k_lo + G) window_refill<G>(ix, inv, w, k, dir);
-    return w.buf[(int64_t)(pos - k * w.s) * w.row_stride + (int64_t)(k - w.k_lo) * w.slot_stride];
+    if (w.k_lo < 0 || k < w.k_lo || k >= w.k_lo + w.n) window_refill<G>(ix, inv, w, k, dir);
+    return window_slot<G>(w, k)[(int64_t)(pos - k * w.s) * w.row_stride];
 }
 
 // Same results as fm_extract_boundary (FM:640-922).  `clean` = false: a walk was suspect, nothing can be
@@ -1425,7 +1483,8 @@ template <int G>
 FMX_HD int32_t fm_extract_boundary_group(const DevIndex &ix, const uint16_t *inv, int mode, int32_t from,
                                          int32_t mapped_boundary, uint16_t *dest, int32_t dst_len, int32_t offset,
                                          int32_t &steps, int &status, int32_t &aux, uint16_t *buf, int64_t row_stride,
-                                         int64_t slot_stride, int64_t win_stride, int32_t g, bool &clean) {
+                                         int64_t slot_stride, int64_t win_stride, int32_t g, bool &clean,
+                                         bool first_fill_halves = false) {
     steps = 0;
     aux = 0;
     clean = true;
@@ -1453,10 +1512,14 @@ FMX_HD int32_t fm_extract_boundary_group(const DevIndex &ix, const uint16_t *inv
     }
     const int32_t s = ix.sample_rate;
     const int32_t k0 = from / s;
-    TextWindow<G> wl = {buf, row_stride, slot_stride, s, -1, g, 0, false};               // intervals <= k0
-    TextWindow<G> wr = {buf + win_stride, row_stride, slot_stride, s, -1, g, 0, false};  // intervals > k0
-    window_refill<G>(ix, inv, wl, k0, -1);                          // [k0-G+1, k0]: the left part and text[from..]
-    if (mode != 1) window_refill<G>(ix, inv, wr, k0 + 1, +1);       // [k0+1, k0+G]
+    TextWindow<G> wl = {buf, row_stride, slot_stride, s, -1, 0, g, 0, false};               // intervals <= k0
+    TextWindow<G> wr = {buf + win_stride, row_stride, slot_stride, s, -1, 0, g, 0, false};  // intervals > k0
+    if (G >= 2 && first_fill_halves) {
+        window_fill_both<G>(ix, inv, wl, wr, k0, mode != 1);        // [k0-G/2+1, k0] and [k0+1, k0+G/2], one walk per lane
+    } else {
+        window_refill<G>(ix, inv, wl, k0, -1);                      // [k0-G+1, k0]: the left part and text[from..]
+        if (mode != 1) window_refill<G>(ix, inv, wr, k0 + 1, +1);   // [k0+1, k0+G]
+    }
     int32_t ret = 0;
     bool finished = false;
     int32_t down_len = 0;

@@ -501,7 +501,7 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix_global, co
                                                  int32_t dst_len, int32_t offset, int32_t *__restrict__ out_len,
                                                  int32_t *__restrict__ lf_steps, int32_t *__restrict__ status_out,
                                                  int32_t *__restrict__ aux_out, uint16_t *__restrict__ scratch,
-                                                 const int32_t *__restrict__ slot_found, int32_t slots) {
+                                                 const int32_t *__restrict__ slot_found, int32_t slots, int first_fill) {
     const uint16_t *s_inv = nullptr;  // no RRR vector on this kernel's path (the wavelet tree's are expanded)
     FMX_WITH_SB_CACHE(ix_global, ix);
     const int64_t lanes = (int64_t)gridDim.x * kBlock;
@@ -516,7 +516,8 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix_global, co
         bool clean;
         uint16_t *dest = dst + q * (int64_t)dst_len;
         int32_t ret = fm_extract_boundary_group<G>(ix, s_inv, mode, froms[q], mapped_boundary, dest, dst_len, offset, steps,
-                                                   status, aux, scratch + (lane - g), lanes, 1, lanes * (int64_t)ix.sample_rate, g, clean);
+                                                   status, aux, scratch + (lane - g), lanes, 1, lanes * (int64_t)ix.sample_rate, g, clean,
+                                                   first_fill != 0);
         if (!clean && g == 0) {  // a walk met a quirk path of the wavelet tree: literal form (rare)
             int32_t steps2;
             status = ST_OK;
@@ -879,6 +880,7 @@ static std::atomic<int> g_block{512};
 static std::atomic<int> g_groups_per_cu{16};
 static std::atomic<int> g_boundary_accel{1};  // 0 = literal right walk of extractUntilBoundary (A/B and fallback)
 static std::atomic<int> g_boundary_group{4};  // lanes per query of extractUntilBoundary (0 = one lane per query)
+static std::atomic<int> g_boundary_first_fill{0};  // 1 = narrow first fill of the text windows (experiment)
 static std::atomic<int> g_suffix_table_use{1};  // 0 = k_count ignores the index's suffix table (A/B)
 static std::atomic<int> g_lds_pad_kb{0};   // experiment knob: extra dynamic LDS per workgroup (lowers occupancy)
 static std::atomic<int> g_sort_min{16384};  // batches at least this large are processed in suffix-sorted order (0 = never)
@@ -906,6 +908,10 @@ int set_option(const char *name, int value) {
     if (!strcmp(name, "boundary_group")) {
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return -1;
         g_boundary_group = value;
+        return 0;
+    }
+    if (!strcmp(name, "boundary_first_fill")) {
+        g_boundary_first_fill = value != 0;
         return 0;
     }
     if (!strcmp(name, "suffix_table")) {
@@ -1169,15 +1175,16 @@ int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, i
                             ? static_cast<uint16_t *>(workspace)
                             : nullptr;
     const int G = scratch ? shape.group : 0;
+    const int first_fill = g_boundary_first_fill;
     const dim3 grid(scratch ? blocks_accel : grid_for(n, blk, n_cu));
 #define FMX_LAUNCH_GROUP(GG)                                                                                            \
     do {                                                                                                                \
         if (blk == 1024)                                                                                                \
             hipLaunchKernelGGL((k_extract_boundary_group<1024, GG>), grid, dim3(1024), 0, st, ix, from, n, boundary, mode, dst, \
-                               dst_len, offset, out_len, lf, status, aux, scratch, slot_found, slots);                  \
+                               dst_len, offset, out_len, lf, status, aux, scratch, slot_found, slots, first_fill);      \
         else                                                                                                            \
             hipLaunchKernelGGL((k_extract_boundary_group<512, GG>), grid, dim3(512), 0, st, ix, from, n, boundary, mode, dst,  \
-                               dst_len, offset, out_len, lf, status, aux, scratch, slot_found, slots);                  \
+                               dst_len, offset, out_len, lf, status, aux, scratch, slot_found, slots, first_fill);      \
     } while (0)
     if (G == 1)
         FMX_LAUNCH_GROUP(1);
