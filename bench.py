@@ -64,7 +64,9 @@ def pmc_counters(text_log2, patterns, sample_rate):
         if p.get("kernel_source_sha") != kernel_source_sha():
             return None, "profiles/pmc_latest.json was taken on other kernel sources (%s, now %s): re-run tools/profile.sh" % (
                 p.get("kernel_source_sha"), kernel_source_sha())
-        return p["k_count"], None
+        k = dict(p["k_count"])
+        k["calibration"] = p.get("calibration")
+        return k, None
     except (OSError, KeyError, ValueError) as e:
         return None, "no usable profile (%s)" % e
 
@@ -310,6 +312,17 @@ def run_count(ctx, args):
                 raise RuntimeError("unexpected per-query status in the benchmark batch")
         lf_steps.append(int(d_lf.sum(dtype=torch.int64).item()))
         checksums.append(int(d_cnt[b].sum(dtype=torch.int64).item()))
+    # the LF-steps k_count really evaluates (without those the suffix table answers), exact for every batch and rank
+    lf_executed = list(lf_steps)
+    if not ctx.dry:
+        ia.lib.fmx_set_option(b"lf_steps_executed_only", 1)
+        try:
+            for b in range(n_batches):
+                step(b, True)
+                torch.cuda.synchronize()
+                lf_executed[b] = int(d_lf.sum(dtype=torch.int64).item())
+        finally:
+            ia.lib.fmx_set_option(b"lf_steps_executed_only", 0)
     for i in range(args.warmup):
         step(i % n_batches)
 
@@ -396,6 +409,7 @@ def run_count(ctx, args):
         overlapped = {"streams": len(side), "wall_s_this_rank": wall2}
 
     lf_local = sum(lf_steps[i % n_batches] for i in range(args.steps))
+    lf_exec_local = sum(lf_executed[i % n_batches] for i in range(args.steps))
     seen = [[0, ctx.local_rank, ctx.local_rank]]
     gathered = None
     if dist is not None:
@@ -408,14 +422,14 @@ def run_count(ctx, args):
             tw2 = torch.tensor([overlapped["wall_s_this_rank"]], dtype=torch.float64, device=dev)
             dist.all_reduce(tw2, op=dist.ReduceOp.MAX)
             overlapped["wall_s_this_rank"] = float(tw2.item())
-        tot = torch.tensor([lf_local], dtype=torch.int64, device=dev)
+        tot = torch.tensor([lf_local, lf_exec_local], dtype=torch.int64, device=dev)
         dist.all_reduce(tot)
-        lf_total = int(tot.item())
+        lf_total, lf_exec_total = int(tot[0].item()), int(tot[1].item())
         seen = ranks_seen(dist, dev, ctx.local_rank, ctx.local_rank if not ctx.dry else -1)
         # final gather of the shards' results on rank 0 (outside the timed region: the shards are independent)
         gathered = gather_concat(dist, d_cnt[0], [n] * world, dev)
     else:
-        lf_total = lf_local
+        lf_total, lf_exec_total = lf_local, lf_exec_local
     # At N > 1 the same launch also measures BASELINE.json configs[4] (the 8M-pattern batch over the 2 GiB text's 8
     # segment indexes, strong scaling): one `bench.py --gpus N` yields the weak-scaling headline and this figure
     segments_line = None
@@ -505,7 +519,12 @@ def run_count(ctx, args):
             alg_bytes = float(exec_bytes_launch)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         pmc, why = pmc_counters(args.text_log2, n, args.sample_rate)
-        traffic = (pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024.0 if pmc else None
+        # FETCH_SIZE tallies a fabric read request at 64 bytes; tools/calibrate_fetch.py measures what a request carries on
+        # this GPU (a 128-byte line, for streamed and for scattered 16-byte loads alike) and stores the factor beside the counters
+        cal = (pmc or {}).get("calibration") or {}
+        fetch_factor = cal.get("fabric_bytes_per_FETCH_SIZE_byte") or 1.0
+        traffic_raw = (pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024.0 if pmc else None
+        traffic = (pmc["FETCH_SIZE_KiB"] * fetch_factor + pmc["WRITE_SIZE_KiB"]) * 1024.0 if pmc else None
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_count",
                 "what_frac_means": "ALGORITHMIC bytes of the reference's layout (oracle counting mode) per k_count launch / "
@@ -515,18 +534,22 @@ def run_count(ctx, args):
                 "kernel_ms_spread": (max(kernel_ms_per_batch) - min(kernel_ms_per_batch)) / kernel_ms,
                 "step_ms_incl_plan": step_ms, "frac_whole_step": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "alg_bytes_per_lf_step": bytes_per_step, "lf_steps_per_launch": lf_per_launch,
-                "lf_steps_executed_per_launch": exec_steps_launch if exec_steps_launch is not None else lf_per_launch,
+                "lf_steps_executed_per_launch": float(np.mean(lf_executed)), "lf_steps_executed_per_batch": lf_executed,
                 "alg_bytes_executed_per_launch": alg_bytes, "alg_bytes_reference_per_launch": alg_bytes_reference,
                 "suffix_table_note": None if exec_steps_launch is None else
                 "achieved / frac count ONLY the algorithmic bytes of the LF-steps k_count executes (oracle counting mode on the "
                 "batch minus the same on the patterns' last %d characters, which the suffix table answers)" % table_chars,
                 "lf_steps_per_batch": lf_steps, "wt_levels_per_lf_step": levels_per_step,
                 "traffic_frac": traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
-                "traffic_note": why if traffic is None else "FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 --pmc passes "
-                                                            "(profiles/pmc_latest.json, kernel sources %s)" % kernel_source_sha(),
+                "traffic_note": why if traffic is None else
+                "FETCH_SIZE x %.2f + WRITE_SIZE of the committed rocprofv3 --pmc passes (profiles/pmc_latest.json, kernel sources %s); "
+                "the factor is tools/calibrate_fetch.py's: %s" % (fetch_factor, kernel_source_sha(),
+                                                                 cal.get("reading", "no calibration stored: raw counter values")),
+                "traffic_raw_counters": traffic_raw,
                 "l1_line_bytes": pmc["TCP_TOTAL_CACHE_ACCESSES"] * 64.0 if pmc and pmc.get("TCP_TOTAL_CACHE_ACCESSES") else None,
-                "l1_line_accesses_per_lf_step": pmc["TCP_TOTAL_CACHE_ACCESSES"] / lf_per_launch
+                "l1_line_accesses_per_lf_step": pmc["TCP_TOTAL_CACHE_ACCESSES"] / float(exec_steps_launch or lf_per_launch)
                 if pmc and pmc.get("TCP_TOTAL_CACHE_ACCESSES") else None,
+                "l1_line_accesses_per_lf_step_note": "per EXECUTED LF-step of a launch",
                 "image_bytes": image_bytes, "image_bytes_per_text_byte": image_bytes / float(1 << args.text_log2),
                 "suffix_table_bytes": table_bytes,
                 "resident_bytes_per_text_byte": (image_bytes + table_bytes) / float(1 << args.text_log2),
@@ -537,10 +560,10 @@ def run_count(ctx, args):
         secondary = run_secondary(ctx, args, q, ref, orc, text, host_batches[0], off_host)
     elif segments_line is not None:
         secondary = [segments_line]
-    # LF-steps the suffix table answered over the timed steps (every rank's shard has the same shape: m-char substrings)
-    executed_less = 0
-    if not ctx.dry and bytes_per_step and exec_steps_launch is not None:
-        executed_less = int(table_steps) * args.steps * world
+    # LF-steps the suffix table answered over the timed steps
+    executed_less = lf_total - lf_exec_total  # counted by the kernel itself, every batch of every rank
+    if not ctx.dry and exec_steps_launch is not None and exec_steps_launch != lf_executed[0]:
+        raise RuntimeError("executed LF-steps: the kernel says %d, the oracle's accounting %d" % (lf_executed[0], exec_steps_launch))
     out = {
         "metric": "patterns/sec + LF-steps/sec, 1M x 8-char count() on 256 MiB log index",
         "value": None if ctx.dry else patterns_per_s,
@@ -582,7 +605,8 @@ def run_count(ctx, args):
                     "another's k_count; max over ranks; not the contract's `value`" % (args.steps, overlapped["streams"], overlapped["streams"]),
             "streams": overlapped["streams"], "ms_per_step": overlapped["wall_s_this_rank"] * 1e3 / args.steps,
             "patterns_per_s": world * n * args.steps / overlapped["wall_s_this_rank"],
-            "lf_steps_per_s": lf_total / overlapped["wall_s_this_rank"]},
+            "lf_steps_per_s": (lf_total - executed_less) / overlapped["wall_s_this_rank"],
+            "lf_steps_per_s_reference_equivalent": lf_total / overlapped["wall_s_this_rank"]},
         "roofline": roof,
         "cpu_baseline": base,
         "secondary": secondary,
@@ -689,18 +713,33 @@ def run_secondary(ctx, args, q, ref, orc, text, pat, off):
     ms = timed(lambda: boundary(False), 3)
     chars = int(olen.astype(np.int64).sum())
     alg = c["alg_bytes"]
+    alg_exec = alg * (lf_gpu / float(max(1, c["lf_steps"])))  # the same bytes per step over the steps really walked
     res.append({"config": "BASELINE.json configs[3]: extractUntilBoundary('\\n') of %d hit locations, 256 MiB text, sampleRate 64, "
                           "destination %d chars" % (K, cap),
                 "ms": ms, "queries_per_s": K / ms * 1e3, "chars": chars, "chars_per_s": chars / ms * 1e3,
                 "lf_steps_reference": c["lf_steps"], "lf_steps_executed_on_gpu": lf_gpu,
                 "lf_steps_per_s_reference_equivalent": c["lf_steps"] / ms * 1e3, "lf_steps_per_s_executed": lf_gpu / ms * 1e3,
                 "alg_bytes_per_lf_step": alg / max(1, c["lf_steps"]),
-                "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernels": "k_extract_boundary_group",
-                             "note": "algorithmic bytes of the REFERENCE's walk (one re-seek per 4 characters, FM:697-743); the "
-                                     "kernel fetches every sample interval once, so it executes fewer LF-steps than that"},
+                "roofline": {"bound": "hbm", "achieved": alg_exec / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": alg_exec / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "frac_reference_equivalent": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "kernels": "k_extract_boundary_group",
+                             "note": "frac counts the LF-steps the kernel EXECUTES (it fetches every sample interval once) at the "
+                                     "oracle's algorithmic bytes per step; frac_reference_equivalent the steps of the REFERENCE's walk "
+                                     "(one re-seek per 4 characters, FM:697-743) over the same time"},
                 "checked_vs_oracle": "all %d queries: lengths, statuses, whole destination rows" % K})
     fm64.close()
+    # ---- the reference's own benchmark shapes on a text with the published data set's alphabet size ----
+    if not args.no_ref_series:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import ref_series
+
+        res.append({"config": "reference_series: FmIndexThroughputBenchmark's count / locate (maxMatches 1, 10, 100, 1000) / "
+                              "extract (32 chars) at sampleRate 1, 32, 64, queries of 8..31 chars sampled from a ~1,100-symbol text",
+                    "series": ref_series.run_series(
+                        ia, torch, orc, dev, text_log2=args.text_log2, queries=args.series_queries,
+                        sample_rates=(32,) if args.profiling else (1, 32, 64), max_matches=(1,) if args.profiling else (1, 10, 100, 1000),
+                        build_device=ctx.local_rank, log=log)})
     return res
 
 
@@ -967,7 +1006,9 @@ def main():
     ap.add_argument("--segments-check", type=int, default=20000, help="patterns of rank 0's shard checked against 8 oracle indexes")
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of single-thread oracle time for cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every oracle leg (profiling runs)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip configs[2] / [3]")
+    ap.add_argument("--no-secondary", action="store_true", help="skip configs[2] / [3] and the reference-shaped series")
+    ap.add_argument("--no-ref-series", action="store_true", help="skip the reference-shaped series of `secondary`")
+    ap.add_argument("--series-queries", type=int, default=1 << 18, help="queries per batch of the reference-shaped series")
     ap.add_argument("--profiling", action="store_true",
                     help="rocprofv3 runs: skip the extra legs that launch the headline kernels in other modes (without the suffix "
                          "table, two batches in flight), so that per-kernel averages and counters describe the timed path only")

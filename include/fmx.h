@@ -259,7 +259,10 @@ int fmx_device_count(void);
  * "sort_min" = smallest batch that is processed in suffix-sorted order (0 = never), "sort_bits" = sort key width,
  * "boundary_accel" = 0 forces the literal +4-chunk right walk of extractUntilBoundary, "boundary_group" = lanes
  * per extractUntilBoundary query (0 | 2 | 4 | 8 | 16), "coarse_bits" / "plan_fine" = bins and fine pass of the plan
- * stage, "suffix_table" = 0: launches ignore the index's suffix table.
+ * stage, "suffix_table" = 0: launches ignore the index's suffix table, "lf_steps_executed_only" = 1: the LF-step
+ * output of count() leaves out the rank evaluations the suffix table answered (bench.py's executed-work figure; the
+ * default reports the reference's count), "boundary_first_fill" = 1: narrower first fill of extractUntilBoundary's
+ * text windows (experiment).
  * Applied when an index is flattened or becomes resident afterwards: "suffix_table_mb" (budget of the suffix table, 0 =
  * none), "sb_cache_limit" (superblocks whose headers are staged in LDS), "map_by_symbol" / "map_fast" / "inv_fast"
  * (layout of the image: tests force the reference's own routes with them).  Applied by fmx_build_on_device:

@@ -245,7 +245,7 @@ template <int kMode, int kCodeBits, bool kChunks>
 __device__ __forceinline__ void count_one(const DevIndex &ix, const int16_t *s_map, const int16_t *s_xlat,
                                           const uint16_t *__restrict__ pat, const int32_t *__restrict__ pat_off, int32_t p,
                                           int32_t m, CodeChunk ck, int role, int32_t &start, int32_t &end, int32_t &back,
-                                          int &status) {
+                                          int32_t &tabled, int &status) {
     constexpr uint32_t code_mask = (1u << kCodeBits) - 1u;
     const uint16_t *s_inv = nullptr;
     constexpr bool translate = kMode == 2;
@@ -275,6 +275,7 @@ __device__ __forceinline__ void count_one(const DevIndex &ix, const int16_t *s_m
                 return translate ? (uint32_t)(uint16_t)s_xlat[cj] : cj;
             },
             start, end, back);
+        tabled = back;  // characters whose rank evaluations the table answered
     }
     bool first_chunk = true;  // the record's word (its codes are the PLAN's: translated in mode 2)
     while (start < end && back + 1 < m) {  // FM:464
@@ -307,7 +308,8 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
                                                   const PlanRec *__restrict__ recs, int32_t n,
                                                   int32_t *__restrict__ counts, int32_t *__restrict__ lf_steps,
                                                   int32_t *__restrict__ status_out, int32_t *__restrict__ range_out,
-                                                  const int32_t *__restrict__ plan_look_up, int32_t plan_sigma) {
+                                                  const int32_t *__restrict__ plan_look_up, int32_t plan_sigma,
+                                                  int steps_mode) {
     // kCodeBits: width of a code in the record's word and in the chunks — 8 when the alphabet fits (8 codes per word),
     // else 16 (the plan's alphabet in modes 1 / 2, this index's own in modes 0 / 3)
     constexpr int kPairs = kBlock / 2;
@@ -351,6 +353,7 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
         int status = ST_OK;
         int32_t start = 0, end = 0;
         int32_t back = 0;  // characters consumed so far, counted from the pattern's end (FM:456: i = m - 1 - back)
+        int32_t tabled = 0;
         // one decision per wave: does any of its patterns run past the record's code word?
 #if defined(FMX_EXPERIMENT_NO_CHUNKS)
         const bool chunks = kMode == 0 || kMode == 3;
@@ -361,12 +364,14 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
             status = ST_JAVA_AIOOBE;  // pattern[-1], FM:456-457
         } else if (live) {
             if (chunks)
-                count_one<kMode, kCodeBits, true>(ix, s_map, s_xlat, pat, pat_off, p, m, ck, role, start, end, back, status);
+                count_one<kMode, kCodeBits, true>(ix, s_map, s_xlat, pat, pat_off, p, m, ck, role, start, end, back, tabled, status);
             else
-                count_one<kMode, kCodeBits, false>(ix, s_map, s_xlat, pat, pat_off, p, m, ck, role, start, end, back, status);
+                count_one<kMode, kCodeBits, false>(ix, s_map, s_xlat, pat, pat_off, p, m, ck, role, start, end, back, tabled, status);
         }
         if (!live) continue;  // (whole lane pairs: q is the same for both lanes of a pair)
-        const int32_t steps = 2 * back;  // LF-steps executed: two ranks per character after the first
+        // LF-steps of the pattern: two ranks per character after the first (steps_mode 1: only those evaluated here, without
+        // the ones the suffix table answered — what bench.py counts as executed work)
+        const int32_t steps = 2 * (steps_mode ? back - tabled : back);
         status |= __shfl_xor(status, 1);
         if (role == 0) {
             const int32_t d = end - start;
@@ -881,6 +886,7 @@ static std::atomic<int> g_groups_per_cu{16};
 static std::atomic<int> g_boundary_accel{1};  // 0 = literal right walk of extractUntilBoundary (A/B and fallback)
 static std::atomic<int> g_boundary_group{4};  // lanes per query of extractUntilBoundary (0 = one lane per query)
 static std::atomic<int> g_boundary_first_fill{0};  // 1 = narrow first fill of the text windows (experiment)
+static std::atomic<int> g_steps_executed_only{0};  // 1 = d_lf_steps of count() leave out what the suffix table answered
 static std::atomic<int> g_suffix_table_use{1};  // 0 = k_count ignores the index's suffix table (A/B)
 static std::atomic<int> g_lds_pad_kb{0};   // experiment knob: extra dynamic LDS per workgroup (lowers occupancy)
 static std::atomic<int> g_sort_min{16384};  // batches at least this large are processed in suffix-sorted order (0 = never)
@@ -908,6 +914,10 @@ int set_option(const char *name, int value) {
     if (!strcmp(name, "boundary_group")) {
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return -1;
         g_boundary_group = value;
+        return 0;
+    }
+    if (!strcmp(name, "lf_steps_executed_only")) {
+        g_steps_executed_only = value != 0;
         return 0;
     }
     if (!strcmp(name, "boundary_first_fill")) {
@@ -1043,7 +1053,7 @@ int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_
     const int bits = (mode == 1 || mode == 2) ? pl.code_bits : plan_code_bits(ix.wt_sigma);
 #define FMX_COUNT_LAUNCH(BLOCK, MODE, BITS)                                                                           \
     hipLaunchKernelGGL((k_count<BLOCK, MODE, BITS>), grid__, dim3(BLOCK), (size_t)g_lds_pad_kb * 1024, st, ix_launch, pat, \
-                       off, recs, n, counts, lf, status, range, pl.look_up, pl.sigma)
+                       off, recs, n, counts, lf, status, range, pl.look_up, pl.sigma, (int)g_steps_executed_only)
 #define FMX_COUNT_MODE(MODE)                                                                                       \
     do {                                                                                                           \
         const int blk__ = g_block;                                                                                 \

@@ -1,0 +1,49 @@
+"""The reference's own benchmark shapes on a LARGE alphabet: a 16 MiB text of ~1,100 distinct
+symbols shaped like the reference's fixture (HDFS_2k_multichar.log: log lines with runs of multi-byte characters),
+queries of 8..31 characters sampled from it (FmIndexThroughputState.java:76-83), countBenchmark / locateBenchmark with
+maxMatches 1, 10, 100, 1000 / extractBenchmark (32 characters) at sampleRate 1, 32 and 64 — every count, located
+position (SA order), extracted row, status and LF-step total against the oracle.  16-bit code words, mapping rows by
+superblock code, chunked pattern fetches and alphabets beyond the device encoder's limit are only exercised here.
+tools/ref_series.py is the same code bench.py runs at 256 MiB."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import index4j_amd as ia
+import orc
+from index4j_amd import workload
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.mark.gpu
+def test_reference_series_on_a_1100_symbol_text_matches_the_oracle_row_by_row():
+    import torch
+
+    import ref_series
+
+    out = ref_series.run_series(ia, torch, orc, torch.device("cuda", 0), text_log2=24, queries=20000, bounded=False)
+    rows = out["rows"]
+    assert len(rows) == 3 * 6  # raises inside on any mismatch with the oracle
+    assert {(r["benchmark"], r.get("max_matches")) for r in rows} >= {("count", None), ("locate", 1), ("locate", 1000)}
+    for i in out["indexes"]:
+        assert i["suffix_table_chars"] >= 2
+    # (at 256 MiB the reference's run-block mask, WFBB:1332 / DESIGN Q1, shows on this alphabet — 1.7 % of the extracted rows
+    # are not the text's; whether a 16 MiB text has such a block under one of 20,000 windows is chance, so nothing is asserted)
+    assert all("rows_where_the_reference_differs_from_the_text" in r for r in rows if r["benchmark"] == "extract")
+
+
+def test_multichar_text_has_the_fixture_shape():
+    t = workload.reference_text(20)
+    assert 1000 <= len(np.unique(t)) <= 1100
+    assert 0.03 < float((t > 127).mean()) < 0.09  # the fixture: 6 % of its characters are multi-byte
+    # the ASCII part is the plain log's line structure
+    assert (t == 10).sum() > (1 << 20) // 200
+    pat, off, starts = workload.reference_queries(t, 500)
+    lens = np.diff(off)
+    assert lens.min() >= 8 and lens.max() <= 31
+    for i in (0, 17, 499):
+        assert (pat[off[i]:off[i + 1]] == t[starts[i]:starts[i] + lens[i]]).all()

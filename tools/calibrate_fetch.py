@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Calibrates rocprofv3's FETCH_SIZE for SCATTERED 16-byte loads (k_count's access pattern) on this GPU and stores the
+factor in profiles/pmc_latest.json ("calibration"), so that bench.py's `traffic` / `traffic_frac` are absolute bytes
+rather than raw counter values (the guide calibrates the counter for wide streaming reads only: 1/2 of the bytes).
+
+Runs tools/microbench/fetch_calibration.hip (loads from DISTINCT 128-byte lines of a 2 GiB table, each touched once) under
+`rocprofv3 --pmc FETCH_SIZE` and `--pmc TCC_MISS_sum TCC_EA0_RDREQ_sum`, plus the streaming case as the control.
+Run on the GPU box:  python tools/calibrate_fetch.py [--update profiles/pmc_latest.json]"""
+import argparse
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_counter(exe, args, counters, outdir):
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = ["rocprofv3", "--pmc"] + counters + ["--output-format", "csv", "-d", outdir, "--", exe] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp", env=env, timeout=600)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    vals = {}
+    for f in glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if "k_calib" in row.get("Kernel_Name", ""):
+                vals[row["Counter_Name"]] = vals.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+    return (json.loads(line[-1]) if line else None), vals, r.stderr[-500:]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--table-mib", type=int, default=2048)
+    ap.add_argument("--loads", type=int, default=1 << 24)
+    ap.add_argument("--update", default=None, help="pmc json to store the calibration in")
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fetch_calibration.json"))
+    args = ap.parse_args()
+    work = os.path.join(ROOT, "gpurun_out", "calib")
+    os.makedirs(work, exist_ok=True)
+    exe = os.path.join(work, "fetch_calibration")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950",
+                           os.path.join(ROOT, "tools", "microbench", "fetch_calibration.hip"), "-o", exe])
+    doc = {"what": "rocprofv3 FETCH_SIZE (KiB) against known bytes, gfx950: scattered = 16-byte loads from DISTINCT 128-byte "
+                   "lines of a %d MiB table (each line once), stream = the same number of 16-byte loads, consecutive" % args.table_mib,
+           "cases": {}}
+    for name, extra in (("scatter", []), ("stream", ["1"])):
+        a = [str(args.table_mib), str(args.loads)] + extra
+        info, v1, err1 = run_counter(exe, a, ["FETCH_SIZE"], os.path.join(work, name + "_fetch"))
+        _, v2, err2 = run_counter(exe, a, ["TCC_MISS_sum", "TCC_EA0_RDREQ_sum"], os.path.join(work, name + "_tcc"))
+        if not info or "FETCH_SIZE" not in v1:
+            print("calibration pass failed:", err1, err2, file=sys.stderr)
+            return 1
+        fetch_bytes = v1["FETCH_SIZE"] * 1024.0
+        case = dict(info, FETCH_SIZE_bytes=fetch_bytes, TCC_MISS=v2.get("TCC_MISS_sum"), TCC_EA0_RDREQ=v2.get("TCC_EA0_RDREQ_sum"),
+                    FETCH_bytes_per_load=fetch_bytes / info["loads"])
+        doc["cases"][name] = case
+    sc, stc = doc["cases"]["scatter"], doc["cases"]["stream"]
+    doc["scattered_16B_load"] = {"FETCH_SIZE_bytes_per_load": sc["FETCH_bytes_per_load"]}
+    doc["streaming_16B_load"] = {"FETCH_SIZE_bytes_per_load": stc["FETCH_bytes_per_load"],
+                                 "fraction_of_bytes_loaded": stc["FETCH_SIZE_bytes"] / stc["bytes_loaded"]}
+    # What one fabric read request carries: the streaming case loads every byte of the lines it touches, so
+    # bytes_loaded / TCC_EA0_RDREQ is the request size (128 on gfx950: one request per 128-byte L2 line, tallied by
+    # FETCH_SIZE at 64).  A scattered load costs one such request as well, so the bytes that really cross the fabric are
+    # requests x that size for BOTH patterns: FETCH_SIZE x (size / 64).
+    req_bytes = stc["bytes_loaded"] / stc["TCC_EA0_RDREQ"] if stc.get("TCC_EA0_RDREQ") else None
+    doc["fabric_read_request_bytes"] = req_bytes
+    doc["requests_per_scattered_load"] = sc["TCC_EA0_RDREQ"] / sc["loads"] if sc.get("TCC_EA0_RDREQ") else None
+    doc["fabric_bytes_per_FETCH_SIZE_byte"] = req_bytes / 64.0 if req_bytes else None
+    doc["reading"] = ("FETCH_SIZE = TCC_EA0_RDREQ x 64 B, but a request fills a whole %.0f-byte L2 line (the streaming case moves "
+                      "%.0f bytes per request); a scattered 16-byte load that misses costs one request too.  Absolute fabric read "
+                      "bytes = FETCH_SIZE x %.2f for both patterns" % (req_bytes or 0, req_bytes or 0, (req_bytes or 0) / 64.0))
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    json.dump(doc, open(args.out, "w"), indent=1)
+    print(json.dumps(doc, indent=1))
+    if args.update and os.path.exists(args.update):
+        p = json.load(open(args.update))
+        p["calibration"] = doc
+        json.dump(p, open(args.update, "w"), indent=1)
+    os.remove(exe)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -47,10 +47,19 @@ def _timed(torch, stream, fn, reps):
 
 
 def run_series(ia, torch, orc, dev, text_log2=28, queries=1 << 18, sample_rates=(1, 32, 64), max_matches=(1, 10, 100, 1000),
-               symbols=None, build_device=0, log=lambda *a: None):
+               symbols=None, build_device=0, log=lambda *a: None, bounded=True):
+    """bounded: the locate rows with maxMatches 100 / 1000 (sampleRate > 1) take the first queries / 4 and queries / 16 of the batch — the
+    oracle's check of every located position is what takes the time (256 host cores: 150 s for 262,144 queries x 1000 at
+    sampleRate 64), and bench.py's default run has to finish within minutes"""
     from index4j_amd import workload
 
     symbols = workload.REFERENCE_SYMBOLS if symbols is None else symbols
+    t_start = time.time()
+    user_log = log
+
+    def log(msg):  # every line with the seconds since the series began
+        user_log("%s  [+%.1fs]" % (msg, time.time() - t_start))
+
     cores = os.cpu_count() or 1
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
@@ -102,20 +111,26 @@ def run_series(ia, torch, orc, dev, text_log2=28, queries=1 << 18, sample_rates=
         log("[series] sampleRate %d: built %.1fs, resident %.1fs, image %.3f B/char, table %d chars"
             % (s, t_build, t_dev, image_bytes / n_text, table_chars))
         # what the suffix table answers of every pattern's backward search: all steps of the last `table_chars` characters
-        table_steps = table_alg = 0
-        if table_chars:
-            ends = off[1:].astype(np.int64)
+        def table_part(n_q):
+            """(algorithmic bytes, LF-steps) the table answers for the first n_q queries"""
+            if not table_chars:
+                return 0, 0
+            ends = off[1: n_q + 1].astype(np.int64)
             idx = (ends[:, None] - table_chars + np.arange(table_chars)[None, :]).reshape(-1)
             tail = np.ascontiguousarray(pat[idx])
             orc.counters_reset()
-            ref.count_batch(tail, (np.arange(Q + 1, dtype=np.int64) * table_chars).astype(np.int32), threads=cores)
+            ref.count_batch(tail, (np.arange(n_q + 1, dtype=np.int64) * table_chars).astype(np.int32), threads=cores)
             c = orc.counters()
-            table_steps, table_alg = c["lf_steps"], c["alg_bytes"]
+            return c["alg_bytes"], c["lf_steps"]
 
-        def row(bench, mm, ms, units, c, extra):
-            executed_alg = c["alg_bytes"] - (table_alg if bench != "extract" else 0)
-            executed_steps = c["lf_steps"] - (table_steps if bench != "extract" else 0)
-            r = {"benchmark": bench, "sample_rate": s, "ms_per_batch": ms, "ops_per_s": Q / ms * 1e3,
+        table_alg, table_steps = table_part(Q)
+
+        def row(bench, mm, ms, units, c, extra, n_q=None):
+            n_q = Q if n_q is None else n_q
+            t_alg, t_steps = (table_alg, table_steps) if n_q == Q else table_part(n_q)
+            executed_alg = c["alg_bytes"] - (t_alg if bench != "extract" else 0)
+            executed_steps = c["lf_steps"] - (t_steps if bench != "extract" else 0)
+            r = {"benchmark": bench, "sample_rate": s, "queries": n_q, "ms_per_batch": ms, "ops_per_s": n_q / ms * 1e3,
                  "lf_steps_reference": c["lf_steps"], "lf_steps_executed": executed_steps,
                  "lf_steps_per_s_executed": executed_steps / ms * 1e3,
                  "alg_bytes_per_lf_step": c["alg_bytes"] / max(1, c["lf_steps"]),
@@ -150,10 +165,12 @@ def run_series(ia, torch, orc, dev, text_log2=28, queries=1 << 18, sample_rates=
 
         # ---- locateBenchmark ----
         for mm in max_matches:
-            d_locs = torch.zeros(Q * mm, dtype=torch.int32, device=dev)
+            # (sampleRate 1 has no walks to check: its rows keep every query)
+            Qm = Q if not bounded or mm < 100 or s == 1 else max(1, Q // (4 if mm < 1000 else 16))
+            d_locs = torch.zeros(Qm * mm, dtype=torch.int32, device=dev)
 
             def locate(with_lf):
-                check_rc(ia.lib.fmx_locate_batch_dev(fm.handle, d_pat.data_ptr(), d_off.data_ptr(), Q, mm, d_locs.data_ptr(), mm,
+                check_rc(ia.lib.fmx_locate_batch_dev(fm.handle, d_pat.data_ptr(), d_off.data_ptr(), Qm, mm, d_locs.data_ptr(), mm,
                                                      d_found.data_ptr(), d_lf.data_ptr() if with_lf else None, d_st.data_ptr(),
                                                      d_rng.data_ptr(), sp), "fmx_locate_batch_dev")
 
@@ -161,19 +178,20 @@ def run_series(ia, torch, orc, dev, text_log2=28, queries=1 << 18, sample_rates=
             d_st.zero_()
             locate(True)
             torch.cuda.synchronize()
-            found = d_found.cpu().numpy()
-            locs = d_locs.cpu().numpy().reshape(Q, mm)
+            found = d_found.cpu().numpy()[:Qm]
+            locs = d_locs.cpu().numpy().reshape(Qm, mm)
             orc.counters_reset()
-            olocs, ofound, ost = ref.locate_batch(pat, off, mm, threads=cores)
+            olocs, ofound, ost = ref.locate_batch(pat[: off[Qm]], off[: Qm + 1], mm, threads=cores)
             c = orc.counters()
             live = np.arange(mm)[None, :] < found[:, None]
-            if not ((found == ofound).all() and (locs[live] == olocs[live]).all() and int(d_st.max().item()) == 0
-                    and int(d_lf.sum(dtype=torch.int64).item()) == c["lf_steps"]):
+            if not ((found == ofound).all() and (locs[live] == olocs[live]).all() and int(d_st[:Qm].max().item()) == 0
+                    and int(d_lf[:Qm].sum(dtype=torch.int64).item()) == c["lf_steps"]):
                 raise RuntimeError("locate differs from the oracle (sampleRate %d, maxMatches %d)" % (s, mm))
             hits = int(found.astype(np.int64).sum())
             del olocs, locs, live
             row("locate", mm, _timed(torch, stream, lambda: locate(False), 3 if mm >= 100 else 5), {"hits": hits}, c,
-                {"checked_vs_oracle": "all %d queries: found, every position in SA order (%d hits), LF-step total" % (Q, hits)})
+                {"checked_vs_oracle": "all %d queries: found, every position in SA order (%d hits), LF-step total" % (Qm, hits)},
+                n_q=Qm)
             row_ms = rows[-1]["ms_per_batch"]
             rows[-1]["hits_per_s"] = hits / row_ms * 1e3
             del d_locs
@@ -220,6 +238,7 @@ def main():
     ap.add_argument("--symbols", type=int, default=None)
     ap.add_argument("--sample-rates", default="1,32,64")
     ap.add_argument("--max-matches", default="1,10,100,1000")
+    ap.add_argument("--full", action="store_true", help="every row over all the queries (maxMatches 1000 at sampleRate 64: minutes of oracle time)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "ref_series.json"))
     args = ap.parse_args()
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
@@ -232,7 +251,7 @@ def main():
 
     out = run_series(ia, torch, orc, torch.device("cuda", 0), args.text_log2, args.queries,
                      tuple(int(x) for x in args.sample_rates.split(",")), tuple(int(x) for x in args.max_matches.split(",")),
-                     args.symbols, log=lambda *a: print(*a, file=sys.stderr, flush=True))
+                     args.symbols, log=lambda *a: print(*a, file=sys.stderr, flush=True), bounded=not args.full)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:
         json.dump(out, f, indent=1)
@@ -241,8 +260,8 @@ def main():
             i["sample_rate"], i["image_bytes_per_char"], i["suffix_table_bytes_per_char"], i["suffix_table_chars"],
             i["serialized_bytes_per_char"], i["build_s"], i["flatten_upload_table_s"]))
     for r in out["rows"]:
-        print("s=%-3d %-8s %-5s %9.3f ms  %10.4g ops/s  (published %s)  executed %.3g LF-steps/s  frac %.3f" % (
-            r["sample_rate"], r["benchmark"], r.get("max_matches", r.get("chars", "")), r["ms_per_batch"], r["ops_per_s"],
+        print("s=%-3d %-8s %-5s %7d q %9.3f ms  %10.4g ops/s  (published %s)  executed %.3g LF-steps/s  frac %.3f" % (
+            r["sample_rate"], r["benchmark"], r.get("max_matches", r.get("chars", "")), r["queries"], r["ms_per_batch"], r["ops_per_s"],
             r["published_reference_ops_per_s_1core_xeon"], r["lf_steps_per_s_executed"], r["roofline"]["frac"]))
 
 
