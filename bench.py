@@ -560,6 +560,9 @@ def run_count(ctx, args):
         secondary = run_secondary(ctx, args, q, ref, orc, text, host_batches[0], off_host)
     elif segments_line is not None:
         secondary = [segments_line]
+    host_buffers = None
+    if world == 1 and not ctx.dry and not args.profiling and oracle_checksum is not None:
+        host_buffers = measure_host_buffers(ctx, args, q, host_batches[0][: n * m], off_host, d_cnt[0].cpu().numpy(), ms_per_step)
     # LF-steps the suffix table answered over the timed steps
     executed_less = lf_total - lf_exec_total  # counted by the kernel itself, every batch of every rank
     if not ctx.dry and exec_steps_launch is not None and exec_steps_launch != lf_executed[0]:
@@ -609,11 +612,85 @@ def run_count(ctx, args):
             "lf_steps_per_s_reference_equivalent": lf_total / overlapped["wall_s_this_rank"]},
         "roofline": roof,
         "cpu_baseline": base,
+        "host_buffers": host_buffers,
         "secondary": secondary,
     }
     if ctx.dry:
         out["dry_run"] = True
     return out
+
+
+def measure_host_buffers(ctx, args, q, pat, off, expect, step_ms):
+    """The drop-in's real call path: fmx_count_batch with the caller's plain (pageable) arrays, what the JNI binding of
+    FmIndex.count calls (bindings/jni/fmx_jni.c).  Wall time per call incl. both PCIe directions, beside the PCIe floor
+    of the same bytes measured with pinned copies in this run.  Never `value`."""
+    ia, torch, dev = ctx.ia, ctx.torch, ctx.dev
+    n = len(off) - 1
+    pat = np.ascontiguousarray(pat, dtype=np.uint16)
+    off = np.ascontiguousarray(off, dtype=np.int32)
+    counts = np.zeros(n, np.int32)
+    status = np.zeros(n, np.int32)
+
+    def call(pipe_min=None):
+        if pipe_min is not None:
+            ia.lib.fmx_set_option(b"host_pipeline_min", pipe_min)
+        t0 = time.perf_counter()
+        check_rc(ia, ia.lib.fmx_count_batch(q.handle, pat.ctypes.data, off.ctypes.data, n, counts.ctypes.data, None,
+                                            status.ctypes.data), "fmx_count_batch")
+        return (time.perf_counter() - t0) * 1e3
+
+    try:
+        call()
+        if not (counts == expect).all() or int(status.max()) != 0:
+            raise RuntimeError("host-buffer counts differ from the device-pointer path")
+        piped = min(call() for _ in range(7))
+        call(0)
+        if not (counts == expect).all():
+            raise RuntimeError("host-buffer counts (unpipelined) differ from the device-pointer path")
+        plain = min(call() for _ in range(5))
+    finally:
+        ia.lib.fmx_set_option(b"host_pipeline_min", 131072)
+    # the same call with the caller's arrays pinned once (fmx_host_register: what a binding does with its direct buffers)
+    registered = None
+    regs = []
+    try:
+        for a in (pat, off, counts, status):
+            check_rc(ia, ia.lib.fmx_host_register(a.ctypes.data, a.nbytes), "fmx_host_register")
+            regs.append(a)
+        call()
+        if not (counts == expect).all():
+            raise RuntimeError("host-buffer counts (registered buffers) differ from the device-pointer path")
+        registered = min(call() for _ in range(7))
+    finally:
+        for a in regs:
+            ia.lib.fmx_host_unregister(a.ctypes.data)
+    # PCIe rates of this box: pinned copies of 64 MiB, each direction
+    hp = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
+    dd = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    rates = {}
+    for name, (dst, src) in (("h2d", (dd, hp)), ("d2h", (hp, dd))):
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        rates[name] = 3 * (64 << 20) / (time.perf_counter() - t0) / 1e9
+    lens = np.diff(off)
+    uniform = bool((lens == lens[0]).all())
+    bytes_in = pat.nbytes + (0 if uniform else off.nbytes)
+    bytes_out = counts.nbytes + status.nbytes
+    floor_in = bytes_in / rates["h2d"] / 1e6
+    floor = max(floor_in, step_ms)
+    return {"what": "fmx_count_batch (host buffers, pageable numpy arrays; counts + statuses back) of batch 0: the JNI binding's call "
+                    "path.  Chunks of 262,144 patterns travel while the previous chunk is counted (2 streams), results return through "
+                    "pinned staging, offsets of equal-length runs are made on the device",
+            "patterns": n, "ms_per_call": piped, "patterns_per_s": n / piped * 1e3,
+            "ms_per_call_unpipelined": plain, "ms_per_call_registered_buffers": registered,
+            "ratio_registered_to_max_of_floor_and_device_step": registered / floor,
+            "bytes_in": bytes_in, "bytes_out": bytes_out, "offsets_made_on_device": uniform,
+            "pinned_copy_GBps": rates, "pcie_floor_ms_in": floor_in, "pcie_floor_ms_in_plus_out": floor_in + bytes_out / rates["d2h"] / 1e6,
+            "device_step_ms": step_ms, "ratio_to_max_of_floor_and_device_step": piped / floor}
 
 
 def run_secondary(ctx, args, q, ref, orc, text, pat, off):

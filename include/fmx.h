@@ -106,9 +106,17 @@ void *fmx_device_blob(const fmx_index *idx, size_t *len);
 
 /* ---- batched queries: host buffers (H2D copy, kernels, D2H copy, synchronous) ------------- */
 
+/* Optional: pin a long-lived host buffer of the caller (a direct ByteBuffer of the Java shim, a reused array) so that the
+ * host-buffer entry points move it by DMA without staging copies; buffers that are not registered work all the same.
+ * (hipHostRegister / hipHostUnregister; pages stay locked until unregistered.) */
+int fmx_host_register(void *p, size_t bytes);
+int fmx_host_unregister(void *p);
+
 /* int count(char[] pattern, int offset, int length) FM:455-474, batched: pattern i is
  * pat[pat_off[i] .. pat_off[i+1]).  lf_steps[i] (nullable) = number of C[c]+rank evaluations spent
- * (FM:469-470). status[i] (nullable) is FMX_ST_JAVA_AIOOBE for an empty pattern. */
+ * (FM:469-470). status[i] (nullable) is FMX_ST_JAVA_AIOOBE for an empty pattern.
+ * Batches of >= 131,072 patterns (option "host_pipeline_min") travel in chunks of 262,144 patterns, a chunk's transfer
+ * overlapping the kernels of the one before; pat_off must start at >= 0 and never decrease (FMX_E_ARG otherwise). */
 int fmx_count_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n,
                     int32_t *counts, int32_t *lf_steps, int32_t *status);
 

@@ -26,7 +26,7 @@ ST_JAVA_AIOOBE = 9
 SYMBOLS = [
     "fmx_build", "fmx_build_on_device", "fmx_build_wavelet_seconds", "fmx_suffix_table_info", "fmx_load", "fmx_save", "fmx_free_buffer", "fmx_free",
     "fmx_input_length", "fmx_alphabet_length", "fmx_sample_rate", "fmx_extract_enabled",
-    "fmx_blob", "fmx_to_device", "fmx_attach_device_blob", "fmx_device_blob",
+    "fmx_blob", "fmx_to_device", "fmx_attach_device_blob", "fmx_device_blob", "fmx_host_register", "fmx_host_unregister",
     "fmx_count_batch", "fmx_locate_batch", "fmx_extract_batch", "fmx_extract_boundary_batch",
     "fmx_count_batch_dev", "fmx_count_plan_dev", "fmx_count_ordered_dev", "fmx_locate_batch_dev", "fmx_extract_batch_dev", "fmx_extract_boundary_batch_dev",
     "fmx_locate_extract_batch", "fmx_locate_lines_batch", "fmx_locate_extract_batch_dev", "fmx_locate_lines_batch_dev",
@@ -67,6 +67,8 @@ def _load():
     L.fmx_attach_device_blob.argtypes = [vp, sz, C.c_int, P(vp)]
     L.fmx_device_blob.argtypes = [vp, P(sz)]
     L.fmx_device_blob.restype = vp
+    L.fmx_host_register.argtypes = [vp, sz]
+    L.fmx_host_unregister.argtypes = [vp]
     L.fmx_count_batch.argtypes = [vp, vp, vp, i32, vp, vp, vp]
     L.fmx_locate_batch.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp, vp, vp]
     L.fmx_extract_batch.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp]

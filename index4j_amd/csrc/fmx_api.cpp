@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <climits>
 #include <cstdio>
 #include <cstring>
@@ -18,6 +19,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace fmx {
@@ -41,6 +43,7 @@ int launch_segment_add_counts(int64_t *, int64_t *, int32_t *, const int32_t *, 
                               int, hipStream_t);
 int launch_segment_append_hits(int64_t *, int32_t *, int32_t *, const int32_t *, const int32_t *, const int32_t *, int32_t,
                                int32_t, int64_t, int, hipStream_t);
+int launch_fill_offsets(int32_t *, int32_t, int32_t, int32_t, hipStream_t);
 int launch_wt_rank(const DevIndex &, int, const int64_t *, const int32_t *, int32_t, int64_t *, int32_t *, hipStream_t);
 int launch_wt_inverse_select(const DevIndex &, int, const int64_t *, int32_t, int64_t *, int32_t *, hipStream_t);
 int set_option(const char *, int);
@@ -81,6 +84,9 @@ namespace {
 thread_local std::string g_err;
 std::atomic<int> g_wavelet_on_device{1};  // option "wavelet_on_device": 0 = fmx_build_on_device encodes the wavelet tree on the host
 std::atomic<int> g_suffix_table_mb{256};  // option "suffix_table_mb": budget of the suffix table of indexes made resident afterwards (0 = none)
+// host-buffer count(): batches of at least this many patterns go through the pipeline (smaller ones: one copy in, kernels, one copy out)
+std::atomic<int> g_host_pipeline_min{131072};
+std::atomic<int> g_host_pipeline_chunk{262144};  // patterns per stage of that pipeline
 std::atomic<int> g_sb_cache_limit{320};  // option "sb_cache_limit": applies to indexes made resident afterwards (tests: 0 = no LDS cache)
 int fail(int code, const std::string &msg) {
     g_err = msg;
@@ -296,6 +302,89 @@ struct DevBuf {
     }
 };
 
+// Pinned host staging of the pipelined host-buffer entry points, recycled like the device blocks (hipHostMalloc costs
+// more than a batch).
+struct PinCache {
+    std::mutex mutex;
+    std::multimap<size_t, void *> free_blocks;
+    size_t cached_bytes = 0;
+    void *take(size_t bytes) {
+        std::lock_guard<std::mutex> lock(mutex);
+        auto it = free_blocks.find(bytes);
+        if (it == free_blocks.end()) return nullptr;
+        void *p = it->second;
+        free_blocks.erase(it);
+        cached_bytes -= bytes;
+        return p;
+    }
+    bool give(size_t bytes, void *p) {
+        std::lock_guard<std::mutex> lock(mutex);
+        if (cached_bytes + bytes > ((size_t)512 << 20)) return false;
+        free_blocks.insert({bytes, p});
+        cached_bytes += bytes;
+        return true;
+    }
+    void release_all() {
+        std::lock_guard<std::mutex> lock(mutex);
+        for (auto &kv : free_blocks) (void)hipHostFree(kv.second);
+        free_blocks.clear();
+        cached_bytes = 0;
+    }
+};
+PinCache g_pinned;
+struct PinBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~PinBuf() {
+        if (p && !g_pinned.give(bytes, p)) (void)hipHostFree(p);
+    }
+    hipError_t alloc(size_t n) {
+        bytes = 4096;
+        while (bytes < n) bytes <<= 1;
+        p = g_pinned.take(bytes);
+        return p ? hipSuccess : hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    }
+    template <typename T>
+    T *as() {
+        return static_cast<T *>(p);
+    }
+};
+
+// Three streams per (host thread, device) for the pipelined host-buffer entry points.  Created on first use and never
+// destroyed (a thread_local destructor would run while the HIP runtime may already be shutting down).
+constexpr int kPipeStreams = 3;  // copies in, kernels, copies out
+constexpr int kPipeEvents = 16;
+struct PipeStreams {
+    int device = -1;
+    hipStream_t s[kPipeStreams] = {nullptr, nullptr, nullptr};
+    hipEvent_t in[kPipeEvents] = {}, counted[kPipeEvents] = {}, done[kPipeEvents] = {};
+};
+int pipe_streams(int device, PipeStreams **out) {
+    thread_local PipeStreams ps;
+    if (ps.device != device) {
+        for (int i = 0; i < kPipeStreams; ++i) HIP_TRY(hipStreamCreateWithFlags(&ps.s[i], hipStreamNonBlocking));
+        for (auto *set : {ps.in, ps.counted, ps.done})
+            for (int i = 0; i < kPipeEvents; ++i) HIP_TRY(hipEventCreateWithFlags(&set[i], hipEventDisableTiming));
+        ps.device = device;
+    }
+    *out = &ps;
+    return FMX_OK;
+}
+
+// One pass over pat_off[lo .. hi]: offsets never decrease and end at or below `limit`; *uniform = every pattern of the
+// run has the same length (then the offsets need not travel: k_fill_offsets).  Branch-free so that it vectorises.
+bool scan_offsets(const int32_t *pat_off, int32_t lo, int32_t hi, int64_t limit, bool *uniform) {
+    const int32_t m0 = pat_off[lo + 1] - pat_off[lo];
+    int32_t neg = 0, diff = 0;
+    for (int32_t i = lo; i < hi; ++i) {
+        const int32_t d = pat_off[i + 1] - pat_off[i];
+        neg |= d;
+        diff |= d ^ m0;
+    }
+    *uniform = diff == 0;
+    return neg >= 0 && pat_off[lo] >= 0 && (int64_t)pat_off[hi] <= limit;
+}
+
 // Where a call's device scratch comes from.  Device-pointer entry points: the index's per-(stream, kind) buffers —
 // asynchronous, the caller orders work through the stream and uses one stream per thread.  Host-buffer entry
 // points: per-call blocks from the recycling cache, so that any number of host threads may query one index at
@@ -324,7 +413,10 @@ extern "C" {
 
 const char *fmx_last_error(void) { return g_err.c_str(); }
 
-void fmx_release_scratch(void) { g_scratch.release_all(); }
+void fmx_release_scratch(void) {
+    g_scratch.release_all();
+    g_pinned.release_all();
+}
 
 int fmx_set_option(const char *name, int value) {
     if (name && !strcmp(name, "sb_cache_limit")) {
@@ -344,6 +436,16 @@ int fmx_set_option(const char *name, int value) {
     if (name && !strcmp(name, "suffix_table_mb")) {  // budget for the suffix table of indexes made resident from now on
         if (value < 0 || value > (1 << 16)) return fail(FMX_E_ARG, "bad value");
         g_suffix_table_mb = value;
+        return FMX_OK;
+    }
+    if (name && !strcmp(name, "host_pipeline_min")) {  // host-buffer count(): batches at least this large are pipelined (0 = never)
+        if (value < 0) return fail(FMX_E_ARG, "bad value");
+        g_host_pipeline_min = value;
+        return FMX_OK;
+    }
+    if (name && !strcmp(name, "host_pipeline_chunk")) {
+        if (value < 65536) return fail(FMX_E_ARG, "bad value");
+        g_host_pipeline_chunk = value;
         return FMX_OK;
     }
     if (name && !strcmp(name, "wavelet_on_device")) {
@@ -566,6 +668,19 @@ int fmx_attach_device_blob(void *device_blob, size_t len, int device, fmx_index 
     make_dev_index(idx.get());
     build_suffix_table(idx.get());
     *out = idx.release();
+    return FMX_OK;
+}
+
+// Pins a long-lived host buffer of the caller (a direct ByteBuffer of the Java shim, a numpy array) so that the
+// host-buffer entry points move it by DMA without staging copies.
+int fmx_host_register(void *p, size_t bytes) {
+    if (!p || bytes == 0) return fail(FMX_E_ARG, "bad arguments");
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return FMX_OK;
+}
+int fmx_host_unregister(void *p) {
+    if (!p) return fail(FMX_E_ARG, "bad arguments");
+    HIP_TRY(hipHostUnregister(p));
     return FMX_OK;
 }
 
@@ -940,6 +1055,220 @@ int fmx_locate_segments(const fmx_index *const *segs, int32_t n_segs, const int6
 // ---- host-buffer entry points --------------------------------------------------------------------
 
 
+constexpr int32_t kPipeChunkMin = 65536;  // smallest stage of the pipeline (patterns)
+
+// is `p` host memory the GPU can DMA from / to directly (hipHostMalloc, hipHostRegister / fmx_host_register)?
+static bool is_pinned(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // plain malloc'ed memory: "invalid value", not an error of ours
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+// fmx_count_batch for large batches — what a JNI binding's count(char[][]) costs is PCIe, not the kernels: the batch goes
+// to the GPU in chunks, chunk c's transfer overlapping the kernels of chunk c - 1 and the return of chunk c - 2 (three streams); offsets of equal-length
+// runs are made on the device instead of being shipped; the offsets are validated chunk by chunk on the way (the same
+// pass finds the equal-length runs).  Results of a chunk return as soon as its stage is done: straight into the
+// caller's arrays when those are pinned (fmx_host_register), else through pinned staging, copied out by a helper thread
+// while this one keeps feeding the pipeline (a pageable source makes hipMemcpyAsync stage on the calling thread).
+static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n, int32_t *counts,
+                                 int32_t *lf_steps, int32_t *status) {
+    if (pat_off[0] < 0 || pat_off[n] < pat_off[0]) return fail(FMX_E_ARG, "pattern offsets start below 0 or decrease");
+    const int64_t total_chars = pat_off[n];
+    PipeStreams *ps = nullptr;
+    int rc = pipe_streams(idx->device, &ps);
+    if (rc) return rc;
+    // equal chunks (a schedule of halving sizes — a small last chunk, so that little is left that overlaps nothing — was
+    // slower: the first chunk's kernels then start after half of the transfer; profiles/r03_experiments.txt)
+    const int32_t chunk = std::max<int32_t>(kPipeChunkMin, g_host_pipeline_chunk.load());
+    std::vector<int32_t> bounds(1, 0);
+    while (bounds.back() < n) bounds.push_back((int32_t)std::min<int64_t>(n, (int64_t)bounds.back() + chunk));
+    const int32_t n_chunks = (int32_t)bounds.size() - 1;
+    const bool direct_out = is_pinned(counts) && (!lf_steps || is_pinned(lf_steps)) && (!status || is_pinned(status));
+    DevBuf d_pat, d_off, d_cnt, d_lf, d_st;
+    PinBuf h_cnt, h_lf, h_st;
+    HIP_TRY(d_pat.alloc((size_t)total_chars * 2 + 8));
+    HIP_TRY(d_off.alloc(((size_t)n + 1 + (size_t)n_chunks) * 4));  // every chunk its own run of offsets (n_c + 1 entries)
+    HIP_TRY(d_cnt.alloc((size_t)n * 4));
+    if (lf_steps) HIP_TRY(d_lf.alloc((size_t)n * 4));
+    if (status) HIP_TRY(d_st.alloc((size_t)n * 4));
+    int32_t *o_cnt = counts, *o_lf = lf_steps, *o_st = status;  // where the D2H copies land
+    if (!direct_out) {
+        HIP_TRY(h_cnt.alloc((size_t)n * 4));
+        o_cnt = h_cnt.as<int32_t>();
+        if (lf_steps) {
+            HIP_TRY(h_lf.alloc((size_t)n * 4));
+            o_lf = h_lf.as<int32_t>();
+        }
+        if (status) {
+            HIP_TRY(h_st.alloc((size_t)n * 4));
+            o_st = h_st.as<int32_t>();
+        }
+    }
+    std::vector<std::unique_ptr<Scratch>> scratches;
+    int failed = FMX_OK;
+    std::atomic<int32_t> issued{0};
+    std::atomic<bool> stop{false};
+    std::atomic<int> out_error{0};
+    auto drain = [&]() {
+        for (int i = 0; i < kPipeStreams; ++i) (void)hipStreamSynchronize(ps->s[i]);
+    };
+    // chunk b's results: pinned staging -> the caller's arrays, once its stage is done
+    auto copy_out = [&](int32_t b) {
+        const int32_t blo = bounds[(size_t)b], bhi = bounds[(size_t)b + 1];
+        if (hipEventSynchronize(ps->done[b % kPipeEvents]) != hipSuccess) {
+            out_error = 1;
+            return;
+        }
+        if (direct_out) return;
+        memcpy(counts + blo, o_cnt + blo, (size_t)(bhi - blo) * 4);
+        if (lf_steps) memcpy(lf_steps + blo, o_lf + blo, (size_t)(bhi - blo) * 4);
+        if (status) memcpy(status + blo, o_st + blo, (size_t)(bhi - blo) * 4);
+    };
+    std::atomic<int32_t> copied{0};
+    std::thread helper;
+    if (!direct_out) {
+        const int device = idx->device;
+        helper = std::thread([&, device]() {
+            (void)hipSetDevice(device);
+            for (;;) {
+                const int32_t have = issued.load(std::memory_order_acquire);
+                if (copied.load() < have) {
+                    copy_out(copied.load());
+                    copied.fetch_add(1, std::memory_order_release);
+                } else if (stop.load()) {
+                    if (copied.load() >= issued.load(std::memory_order_acquire)) return;
+                } else {
+                    std::this_thread::yield();
+                }
+            }
+        });
+    }
+    static const bool timing = getenv("FMX_PIPE_TIMING") != nullptr;  // stderr: where a call's host time goes
+    auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_scan = 0, t_in = 0, t_launch = 0, t_out = 0;
+    const double t_begin = now();
+    hipStream_t s_in = ps->s[0], s_k = ps->s[1], s_out = ps->s[2];
+    const bool in_pinned = is_pinned(pat) && is_pinned(pat_off);
+    // A pageable source is staged by whichever thread calls the copy: a FEEDER thread pushes the chunks' characters one
+    // after the other with the plain copy (twice the rate of the asynchronous one from pageable memory; it returns when
+    // the bytes are in HBM, so the kernels need no event), so that the link stays busy while this thread checks the
+    // offsets and launches kernels.  (The two ends of every chunk are checked before anything moves.)
+    for (int32_t c = 0; c < n_chunks; ++c) {
+        const int64_t c0 = pat_off[bounds[(size_t)c]], c1 = pat_off[bounds[(size_t)c + 1]];
+        if (c0 < 0 || c1 < c0 || c1 > total_chars) {
+            stop = true;
+            if (helper.joinable()) helper.join();
+            return fail(FMX_E_ARG, "pattern offsets decrease or leave the batch");
+        }
+    }
+    std::atomic<int32_t> fed{0};
+    std::atomic<int> feed_error{0};
+    std::atomic<bool> feed_stop{false};
+    std::thread feeder;
+    if (!in_pinned) {
+        const int device = idx->device;
+        feeder = std::thread([&, device]() {
+            (void)hipSetDevice(device);
+            for (int32_t c = 0; c < n_chunks && !feed_stop.load(); ++c) {
+                const int64_t c0 = pat_off[bounds[(size_t)c]], c1 = pat_off[bounds[(size_t)c + 1]];
+                if (c1 > c0 && hipMemcpy(d_pat.as<uint16_t>() + c0, pat + c0, (size_t)(c1 - c0) * 2, hipMemcpyHostToDevice) != hipSuccess)
+                    feed_error = 1;
+                fed.store(c + 1, std::memory_order_release);
+            }
+        });
+    }
+    for (int32_t c = 0; c < n_chunks && !failed; ++c) {
+        const int32_t lo = bounds[(size_t)c], hi = bounds[(size_t)c + 1], n_c = hi - lo;
+        const int slot = c % kPipeEvents;
+        double t0 = now();
+        // an event slot is reused every kPipeEvents chunks: its earlier chunk must have been copied out
+        while (c >= kPipeEvents && copied.load(std::memory_order_acquire) <= c - kPipeEvents && !out_error) {
+            if (direct_out) {
+                copy_out(copied.load());
+                copied.fetch_add(1);
+            } else {
+                std::this_thread::yield();
+            }
+        }
+        // the chunk's characters start travelling before its offsets are looked at
+        const int64_t c0 = pat_off[lo], c1 = pat_off[hi];
+        hipError_t e = hipSuccess;
+        if (c1 > c0 && in_pinned)
+            e = hipMemcpyAsync(d_pat.as<uint16_t>() + c0, pat + c0, (size_t)(c1 - c0) * 2, hipMemcpyHostToDevice, s_in);
+        t_in += now() - t0;
+        t0 = now();
+        bool uniform = false;
+        if (!scan_offsets(pat_off, lo, hi, total_chars, &uniform)) {
+            failed = fail(FMX_E_ARG, "pattern offsets decrease or leave the batch");
+            break;
+        }
+        t_scan += now() - t0;
+        t0 = now();
+        int32_t *d_off_c = d_off.as<int32_t>() + lo + c;
+        if (e == hipSuccess) {
+            if (uniform)
+                e = (hipError_t)fmx::launch_fill_offsets(d_off_c, (int32_t)c0, pat_off[lo + 1] - pat_off[lo], n_c + 1, s_k);
+            else if (in_pinned)
+                e = hipMemcpyAsync(d_off_c, pat_off + lo, (size_t)(n_c + 1) * 4, hipMemcpyHostToDevice, s_in);
+            else
+                e = hipMemcpyAsync(d_off_c, pat_off + lo, (size_t)(n_c + 1) * 4, hipMemcpyHostToDevice, s_k);
+        }
+        if (!in_pinned) {  // the feeder has this chunk's characters in HBM?
+            while (fed.load(std::memory_order_acquire) <= c) std::this_thread::yield();
+            if (feed_error) e = hipErrorUnknown;
+        }
+        if (e == hipSuccess && in_pinned) {
+            e = hipEventRecord(ps->in[slot], s_in);
+            if (e == hipSuccess) e = hipStreamWaitEvent(s_k, ps->in[slot], 0);
+        }
+        if (e != hipSuccess) {
+            failed = fail(FMX_E_HIP, std::string("host-buffer pipeline, copy in: ") + hipGetErrorString(e));
+            break;
+        }
+        t_in += now() - t0;
+        t0 = now();
+        scratches.emplace_back(new Scratch(idx, s_k, true));
+        rc = count_impl(idx, d_pat.as<uint16_t>(), d_off_c, n_c, d_cnt.as<int32_t>() + lo, lf_steps ? d_lf.as<int32_t>() + lo : nullptr,
+                        status ? d_st.as<int32_t>() + lo : nullptr, *scratches.back());
+        if (rc) {
+            failed = rc;
+            break;
+        }
+        t_launch += now() - t0;
+        t0 = now();
+        e = hipEventRecord(ps->counted[slot], s_k);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s_out, ps->counted[slot], 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(o_cnt + lo, d_cnt.as<int32_t>() + lo, (size_t)n_c * 4, hipMemcpyDeviceToHost, s_out);
+        if (e == hipSuccess && lf_steps) e = hipMemcpyAsync(o_lf + lo, d_lf.as<int32_t>() + lo, (size_t)n_c * 4, hipMemcpyDeviceToHost, s_out);
+        if (e == hipSuccess && status) e = hipMemcpyAsync(o_st + lo, d_st.as<int32_t>() + lo, (size_t)n_c * 4, hipMemcpyDeviceToHost, s_out);
+        if (e == hipSuccess) e = hipEventRecord(ps->done[slot], s_out);
+        if (e != hipSuccess) {
+            failed = fail(FMX_E_HIP, std::string("host-buffer pipeline, copy out: ") + hipGetErrorString(e));
+            break;
+        }
+        issued.store(c + 1, std::memory_order_release);
+        t_out += now() - t0;
+    }
+    const double t_issued = now();
+    feed_stop = true;
+    if (feeder.joinable()) feeder.join();
+    stop = true;
+    if (helper.joinable()) helper.join();
+    const double t_joined = now();
+    drain();  // (also on failure: the per-call blocks go back to the cache when this call ends, nothing may still use them)
+    if (timing)
+        fprintf(stderr, "[fmx pipe] %d chunks: alloc %.0f us | scan %.0f | copy-in calls %.0f | kernel launches %.0f | copy-out calls %.0f | "
+                        "issue loop %.0f | helper join +%.0f | drain +%.0f (direct_out %d)\n",
+                n_chunks, 0.0, t_scan, t_in, t_launch, t_out, t_issued - t_begin, t_joined - t_issued, now() - t_joined, (int)direct_out);
+    if (failed) return failed;
+    if (out_error) return fail(FMX_E_HIP, "host-buffer pipeline: a stage failed");
+    return FMX_OK;
+}
+
 int fmx_count_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n, int32_t *counts,
                     int32_t *lf_steps, int32_t *status) {
     int rc = require_device(idx);
@@ -947,6 +1276,10 @@ int fmx_count_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pa
     if (n < 0 || (n > 0 && (!pat_off || !counts))) return fail(FMX_E_ARG, "bad arguments");
     if (n == 0) return FMX_OK;
     HIP_TRY(hipSetDevice(idx->device));
+    {
+        const int pipe_min = g_host_pipeline_min;
+        if (pipe_min > 0 && n >= pipe_min) return count_batch_pipelined(idx, pat, pat_off, n, counts, lf_steps, status);
+    }
     rc = check_offsets(pat_off, n);
     if (rc) return rc;
     const size_t chars = (size_t)(pat_off[n] > 0 ? pat_off[n] : 0);

@@ -1090,6 +1090,17 @@ int launch_locate_walk(const DevIndex &ix, int n_cu, const int32_t *range, int32
     return (int)hipGetLastError();
 }
 
+// pat_off of a run of equal-length patterns, made on the device (the host-buffer pipeline then does not ship it)
+__global__ __launch_bounds__(256) void k_fill_offsets(int32_t *__restrict__ off, int32_t first, int32_t m, int32_t count) {
+    const int32_t i = (int32_t)blockIdx.x * 256 + (int32_t)threadIdx.x;
+    if (i < count) off[i] = first + i * m;
+}
+int launch_fill_offsets(int32_t *off, int32_t first, int32_t m, int32_t count, hipStream_t st) {
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(k_fill_offsets, dim3((count + 255) / 256), dim3(256), 0, st, off, first, m, count);
+    return (int)hipGetLastError();
+}
+
 int launch_segment_add_counts(int64_t *total, int64_t *lf_total, int32_t *status_total, const int32_t *counts,
                               const int32_t *lf, const int32_t *status, int32_t n, int first, hipStream_t st) {
     if (n <= 0) return 0;

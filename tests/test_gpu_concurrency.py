@@ -176,3 +176,71 @@ def test_attach_rejects_damaged_images():
         bad = good.copy()
         bad[off:off + 4] = np.frombuffer(np.uint32(0x7fffff00).tobytes(), np.uint8)
         assert attach(bad) != 0
+
+
+def test_pipelined_host_buffer_count_from_threads_with_plain_and_registered_arrays():
+    """fmx_count_batch above host_pipeline_min patterns travels in chunks (feeder thread, three streams, results through
+    pinned staging or straight into registered arrays): same counts, statuses and LF-steps as the oracle — from several
+    host threads at once, patterns of 8..31 characters (offsets shipped) and of one length (offsets made on the device),
+    pageable and registered (fmx_host_register) arrays; offsets that run backwards are refused before anything is launched"""
+    from index4j_amd import workload
+
+    t = workload.reference_text(22)
+    fm = ia.FmIndex(t, 32, True, device=0)
+    o = orc.OracleFmIndex.read(fm.write(False))
+    n = 300_000  # two chunks of the pipeline
+    work = []
+    pat, off, _ = workload.reference_queries(t, n, seed=5)
+    work.append((pat, off))
+    pat8, off8, _ = ia.synth_patterns(t, 8, n, seed=6)
+    work.append((pat8, off8))
+    expect = []
+    for p, f in work:
+        orc.counters_reset()
+        oc, ost = o.count_batch(p, f, threads=8)
+        expect.append((oc, ost, orc.counters()["lf_steps"]))
+    errors = []
+
+    def run(k, registered):
+        try:
+            p, f = work[k % 2]
+            cnt = np.full(n, -1, np.int32)
+            st = np.full(n, -1, np.int32)
+            lf = np.full(n, -1, np.int32)
+            arrays = (p, f, cnt, st, lf) if registered else ()
+            for a in arrays:
+                assert ia.lib.fmx_host_register(a.ctypes.data, a.nbytes) == 0
+            try:
+                for _ in range(3):
+                    rc = ia.lib.fmx_count_batch(fm.handle, p.ctypes.data, f.ctypes.data, n, cnt.ctypes.data, lf.ctypes.data, st.ctypes.data)
+                    assert rc == 0, ia.lib.fmx_last_error()
+                    oc, ost, steps = expect[k % 2]
+                    assert (cnt == oc).all() and (st == ost).all() and int(lf.astype(np.int64).sum()) == steps
+            finally:
+                for a in arrays:
+                    ia.lib.fmx_host_unregister(a.ctypes.data)
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, registered, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(k, k >= 2)) for k in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    # the unpipelined path (option) gives the same
+    ia.lib.fmx_set_option(b"host_pipeline_min", 0)
+    try:
+        c2, s2 = fm.count_batch(work[0][0], work[0][1])
+        assert (c2 == expect[0][0]).all() and (s2 == expect[0][1]).all()
+    finally:
+        ia.lib.fmx_set_option(b"host_pipeline_min", 131072)
+    # offsets that decrease: FMX_E_ARG from both paths, nothing launched
+    bad = work[1][1].copy()
+    bad[200_000] = bad[199_999] - 3
+    cnt = np.zeros(n, np.int32)
+    for nn in (n, 1000):
+        b = bad if nn == n else np.array([0, 8, 4] + [8] * (nn - 2), np.int32)
+        rc = ia.lib.fmx_count_batch(fm.handle, work[1][0].ctypes.data, b.ctypes.data, nn, cnt.ctypes.data, None, None)
+        assert rc == -1 and b"offsets" in ia.lib.fmx_last_error()
+    fm.close()
