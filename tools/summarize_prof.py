@@ -13,7 +13,8 @@ def find(root, pattern):
 
 
 KERNELS = {"k_count": "k_count", "k_locate_walk": "k_locate_walk", "k_extract_boundary_group": "k_extract_boundary_group",
-           "k_plan_codes": "k_plan_codes", "k_plan_scatter": "k_plan_scatter", "k_plan_fine": "k_plan_fine"}
+           "k_plan_codes": "k_plan_codes", "k_plan_scatter": "k_plan_scatter", "k_plan_fine": "k_plan_fine",
+           "k_extract": "k_extract<"}  # ("k_extract<": not k_extract_boundary*)
 
 
 def kernel_source_sha():
