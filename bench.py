@@ -546,6 +546,14 @@ def run_count(ctx, args):
                 "the factor is tools/calibrate_fetch.py's: %s" % (fetch_factor, kernel_source_sha(),
                                                                  cal.get("reading", "no calibration stored: raw counter values")),
                 "traffic_raw_counters": traffic_raw,
+                # the kernel's line fills per second against what the chip delivers to this access pattern (random 16-byte loads)
+                "fabric_line_fills_per_launch": pmc["FETCH_SIZE_KiB"] * 1024.0 / 64.0 if pmc else None,
+                "fabric_line_fills_per_lf_step_executed": pmc["FETCH_SIZE_KiB"] * 1024.0 / 64.0 / float(np.mean(lf_executed)) if pmc else None,
+                "fabric_line_fills_Gper_s": pmc["FETCH_SIZE_KiB"] * 1024.0 / 64.0 / (kernel_ms * 1e-3) / 1e9 if pmc else None,
+                "random_line_rate_Glines_per_s": (cal.get("random_line_rate_Glines_per_s") or {}).get("192_MiB"),
+                "frac_of_random_line_rate": (pmc["FETCH_SIZE_KiB"] * 1024.0 / 64.0 / (kernel_ms * 1e-3) / 1e9 /
+                                             cal["random_line_rate_Glines_per_s"]["192_MiB"])
+                if pmc and (cal.get("random_line_rate_Glines_per_s") or {}).get("192_MiB") else None,
                 "l1_line_bytes": pmc["TCP_TOTAL_CACHE_ACCESSES"] * 64.0 if pmc and pmc.get("TCP_TOTAL_CACHE_ACCESSES") else None,
                 "l1_line_accesses_per_lf_step": pmc["TCP_TOTAL_CACHE_ACCESSES"] / float(exec_steps_launch or lf_per_launch)
                 if pmc and pmc.get("TCP_TOTAL_CACHE_ACCESSES") else None,

@@ -71,6 +71,20 @@ def main():
     doc["reading"] = ("FETCH_SIZE = TCC_EA0_RDREQ x 64 B, but a request fills a whole %.0f-byte L2 line (the streaming case moves "
                       "%.0f bytes per request); a scattered 16-byte load that misses costs one request too.  Absolute fabric read "
                       "bytes = FETCH_SIZE x %.2f for both patterns" % (req_bytes or 0, req_bytes or 0, (req_bytes or 0) / 64.0))
+    # the ceiling of the LF kernels' access pattern: random 16-byte loads = random 128-byte lines per second
+    rl = os.path.join(work, "random_lines")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950",
+                           os.path.join(ROOT, "tools", "microbench", "random_lines.hip"), "-o", rl])
+    r = subprocess.run([rl], capture_output=True, text=True, timeout=300)
+    os.remove(rl)
+    rates = {}
+    for ln in r.stdout.splitlines():
+        parts = ln.split()
+        if ln.startswith("table") and "chained" in ln:
+            rates["%s_MiB" % parts[1]] = float(ln.split(":")[1].split()[0])
+    doc["random_line_rate_Glines_per_s"] = dict(rates, what="random 16-byte loads per second, chained (one in flight per lane), 8 waves "
+                                                            "per SIMD, by table size (tools/microbench/random_lines.hip): what the "
+                                                            "memory system delivers to the LF kernels' access pattern")
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump(doc, open(args.out, "w"), indent=1)
     print(json.dumps(doc, indent=1))
