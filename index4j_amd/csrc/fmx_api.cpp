@@ -711,7 +711,17 @@ static int plan_order(const fmx_index *idx, const uint16_t *d_pat, const int32_t
     // a per-stream workspace keeps its head zeroed between plans; a per-call block comes from the cache: clear it
     int e = fmx::launch_count_plan(idx->dev, d_pat, d_pat_off, n, ws, ws_bytes, !scratch.per_call, plan,
                                    static_cast<hipStream_t>(scratch.stream));
-    if (e) return fail(FMX_E_HIP, std::string("plan stage: ") + hipGetErrorString((hipError_t)e));
+    if (e) {
+        // A plan that stopped half way (k_plan_codes ran, k_plan_scatter did not) leaves its histogram in the workspace's
+        // head, which a per-stream workspace is trusted to hold zeroed between plans: clear it, and forget the stream's plan
+        if (!scratch.per_call) {
+            (void)hipMemsetAsync(ws, 0, fmx::kPlanHeadBytes, static_cast<hipStream_t>(scratch.stream));
+            std::lock_guard<std::mutex> lock(idx->ws_mutex);
+            idx->plans.erase(scratch.stream);
+        }
+        *plan = fmx::CountPlan();
+        return fail(FMX_E_HIP, std::string("plan stage: ") + hipGetErrorString((hipError_t)e));
+    }
     return FMX_OK;
 }
 

@@ -1023,6 +1023,8 @@ int launch_count_plan(const DevIndex &ix, const uint16_t *pat, const int32_t *of
     else
         hipLaunchKernelGGL(k_plan_codes<16>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 4, st, ix, pat, off, n, sh, recs,
                            ghist);
+    // (a failed launch here would leave the histogram filled: the caller then clears the workspace's head)
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_plan_scatter, dim3(tiles), dim3(kTileThreads), (size_t)bins * 8, st, recs, n, bins,
                        sh.total_bits - sh.coarse_bits, ghist, cursor, ticket, ordered);
     if (g_plan_fine)
