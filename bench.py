@@ -603,9 +603,10 @@ def run_count(ctx, args):
                    "oracle_checksum_batch0_all_ranks": oracle_checksum, "patterns_checked_vs_oracle": oracle_checked},
         "suffix_table": None if ctx.dry else {
             "chars": table_chars, "bytes": table_bytes,
-            "what": "SA interval of every string of `chars` codes, tabulated by the index's own rank code when it becomes "
-                    "resident (fmx_suffix_table_info); a planned batch starts from it: one load instead of %d rank evaluations per "
-                    "pattern. `lf_steps_per_sec` counts executed LF-steps only; `value` is patterns/s" % (2 * max(0, table_chars - 1)),
+            "what": "SA interval of every string of `chars` codes that occurs in the text, grown level by level by the index's own "
+                    "rank code and hashed when the index becomes resident (fmx_suffix_table_info); a batch starts from it: one 16-byte "
+                    "slot instead of %d rank evaluations per pattern. `lf_steps_per_sec` counts executed LF-steps only; `value` is "
+                    "patterns/s" % (2 * max(0, table_chars - 1)),
             "lf_steps_answered_per_launch": int(table_steps) if bytes_per_step and exec_steps_launch is not None else None,
             "without_it": None if not without_table else {
                 "ms_per_step": without_table["ms_per_step"],

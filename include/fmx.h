@@ -68,12 +68,15 @@ int fmx_build_on_device(const uint16_t *text, int32_t n, int32_t sample_rate, in
 /* seconds fmx_build_on_device spent encoding the wavelet tree in HBM; 0 = it was encoded on the host */
 double fmx_build_wavelet_seconds(const fmx_index *idx);
 
-/* The suffix table of a resident index: fmx_to_device / fmx_attach_device_blob tabulate the SA interval of every string
- * of *chars codes (the state of FM:455-474 after a pattern's last *chars characters, computed by the same rank code
- * the queries run) as long as sigma^chars entries of 8 bytes fit the budget (option "suffix_table_mb", default 256;
- * 0 = no table) and stay below 8 entries per character of the text.  Planned count / locate batches start from it: one load instead of 2 * (chars - 1) rank evaluations;
- * results, statuses and LF-step counts are unchanged (option "suffix_table" = 0 makes launches ignore it, for A/B).
- * *chars = 0: no table. */
+/* The suffix table of a resident index: fmx_to_device / fmx_attach_device_blob grow, level by level, the set of strings of
+ * *chars codes that OCCUR in the text, each with its SA interval (the state of FM:455-474 after a pattern's last *chars
+ * characters, computed by the same rank code the queries run), and hash it: 16-byte slots, twice as many as strings.
+ * Depth: option "suffix_table_chars" (default 4; at most what a 64-bit key holds: 8 codes of 8 bits, 4 of 16), cut where a
+ * level would pass the budget (option "suffix_table_mb", default 256, 32 bytes per string; 0 = no table).  count / locate
+ * batches start from it: one slot instead of 2 * (chars - 1) rank evaluations; a string that is not in it (it does not
+ * occur, holds an unknown character, or its search raised a status) is searched by the loop.  Results, statuses and
+ * LF-step counts are unchanged (option "suffix_table" = 0 makes launches ignore it, for A/B).  *chars = 0: no table;
+ * *bytes = the table's size (0.8 MB for the 26,064 four-character strings of the 256 MiB synthetic log). */
 int fmx_suffix_table_info(const fmx_index *idx, int32_t *chars, int64_t *bytes);
 
 /* FmIndex.read(ObjectInput) FM:983-1025; also accepts the ObjectOutputStream-framed form produced by
@@ -271,8 +274,8 @@ int fmx_device_count(void);
  * output of count() leaves out the rank evaluations the suffix table answered (bench.py's executed-work figure; the
  * default reports the reference's count), "boundary_first_fill" = 1: narrower first fill of extractUntilBoundary's
  * text windows (experiment).
- * Applied when an index is flattened or becomes resident afterwards: "suffix_table_mb" (budget of the suffix table, 0 =
- * none), "sb_cache_limit" (superblocks whose headers are staged in LDS), "map_by_symbol" / "map_fast" / "inv_fast"
+ * Applied when an index is flattened or becomes resident afterwards: "suffix_table_mb" / "suffix_table_chars" (budget
+ * and depth of the suffix table, 0 = none), "sb_cache_limit" (superblocks whose headers are staged in LDS), "map_by_symbol" / "map_fast" / "inv_fast"
  * (layout of the image: tests force the reference's own routes with them).  Applied by fmx_build_on_device:
  * "wavelet_on_device" = 0 encodes the wavelet tree on the host.
  * Results are identical for every setting. */

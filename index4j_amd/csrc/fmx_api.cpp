@@ -23,7 +23,10 @@
 #include <vector>
 
 namespace fmx {
-int launch_suffix_table(const DevIndex &, int, uint64_t, uint64_t *, hipStream_t);
+int launch_suffix_level1(const DevIndex &, SuffixSlot *, uint32_t *, uint32_t, hipStream_t);
+int launch_suffix_expand(const DevIndex &, int, const SuffixSlot *, uint32_t, int, int, SuffixSlot *, uint32_t *, uint32_t, hipStream_t);
+int launch_suffix_insert(const DevIndex &, const SuffixSlot *, uint32_t, SuffixSlot *, hipStream_t);
+int launch_suffix_columns(const SuffixSlot *, uint32_t, int, uint32_t *, hipStream_t);
 int launch_count_plan(const DevIndex &, const uint16_t *, const int32_t *, int32_t, void *, size_t, bool, CountPlan *,
                       hipStream_t);
 int launch_count(const DevIndex &, int, const uint16_t *, const int32_t *, const CountPlan *, bool, int32_t, int32_t *,
@@ -64,6 +67,7 @@ struct fmx_index {
     double wavelet_device_seconds = 0;  // fmx_build_on_device: seconds of the wavelet encode in HBM (0: host encoder)
     void *d_suffix_table = nullptr;     // DevIndex.suffix_table (owned, whoever owns the image)
     size_t suffix_table_bytes = 0;
+    uint32_t suffix_table_strings = 0;  // strings of suffix_chars codes the table holds
     fmx::DevIndex dev;
     // per-(stream, kind) scratch of the device-pointer entry points (grow-only; freed with the index):
     // kind 0 = plan stage (order + code words), kind 1 = extractUntilBoundary windows
@@ -84,6 +88,7 @@ namespace {
 thread_local std::string g_err;
 std::atomic<int> g_wavelet_on_device{1};  // option "wavelet_on_device": 0 = fmx_build_on_device encodes the wavelet tree on the host
 std::atomic<int> g_suffix_table_mb{256};  // option "suffix_table_mb": budget of the suffix table of indexes made resident afterwards (0 = none)
+std::atomic<int> g_suffix_table_chars{4};  // option "suffix_table_chars": its depth (characters; the budget and the key width may cut it)
 // host-buffer count(): batches of at least this many patterns go through the pipeline (smaller ones: one copy in, kernels, one copy out)
 std::atomic<int> g_host_pipeline_min{131072};
 std::atomic<int> g_host_pipeline_chunk{262144};  // patterns per stage of that pipeline
@@ -192,6 +197,9 @@ void make_dev_index(fmx_index *idx) {
     d.map_by_symbol = h.map_by_symbol;
     d.suffix_table = nullptr;
     d.suffix_chars = 0;
+    d.suffix_key_bits = h.wt_sigma <= 256 ? 8 : 16;
+    d.suffix_shift = 0;
+    d.suffix_mask = 0;
     d.sb_cache = nullptr;
     d.sb_cache_limit = g_sb_cache_limit;
     d.wt_size = (uint32_t)h.wt_size;
@@ -448,6 +456,11 @@ int fmx_set_option(const char *name, int value) {
         g_host_pipeline_chunk = value;
         return FMX_OK;
     }
+    if (name && !strcmp(name, "suffix_table_chars")) {  // depth of the suffix table of indexes made resident from now on
+        if (value < 0 || value > 8) return fail(FMX_E_ARG, "bad value");
+        g_suffix_table_chars = value;
+        return FMX_OK;
+    }
     if (name && !strcmp(name, "wavelet_on_device")) {
         g_wavelet_on_device = value != 0;
         return FMX_OK;
@@ -554,8 +567,10 @@ int32_t fmx_extract_enabled(const fmx_index *idx) {
     return idx->has_model ? (idx->model.enable_extract ? 1 : 0) : idx->hdr.enable_extract;
 }
 
-// The suffix table of a resident FM-index (fmx_device.hpp): the longest suffix length whose table fits the budget
-// (sigma^chars entries of 8 bytes; at most what a plan code word holds).  Not having one is never an error.
+// The suffix table of a resident FM-index (fmx_device.hpp): grown level by level on the device — the strings of k codes
+// that occur in the text, each with its SA interval — up to `suffix_table_chars` characters (what a key of 64 bits holds at
+// most: 8 codes of 8 bits, 4 of 16), or as deep as the budget `suffix_table_mb` carries (32 bytes per string: a slot of 16
+// in a table of twice as many slots).  Then hashed.  Not having one is never an error.
 static void build_suffix_table(fmx_index *idx) {
     if (idx->d_suffix_table) {
         (void)hipFree(idx->d_suffix_table);
@@ -564,36 +579,102 @@ static void build_suffix_table(fmx_index *idx) {
     }
     idx->dev.suffix_table = nullptr;
     idx->dev.suffix_chars = 0;
+    idx->dev.suffix_key_bits = idx->hdr.wt_sigma <= 256 ? 8 : 16;
+    idx->dev.suffix_shift = 0;
+    idx->dev.suffix_mask = 0;
     if (idx->rrr_only || idx->wavelet_only || idx->hdr.kind != 0) return;
     const uint64_t budget = (uint64_t)g_suffix_table_mb.load() << 20;
-    const uint64_t sigma = (uint64_t)idx->hdr.wt_sigma;
-    if (budget == 0 || sigma < 2) return;
-    const int max_chars = sigma <= 256 ? 6 : 4;  // the plan's code word: 8 codes of 8 bits or 4 of 16
-    int chars = 0;
-    uint64_t entries = sigma;
-    // (and no more entries than 8 per character of the text: a small index gets a small table)
-    const uint64_t cap = std::max<uint64_t>(4096, 8 * (uint64_t)(uint32_t)idx->hdr.length);
-    for (int k = 2; k <= max_chars; ++k) {
-        if (entries > budget / 8 / sigma || entries * sigma > cap) break;
-        entries *= sigma;
-        chars = k;
-    }
-    if (chars < 2) return;
-    void *d = nullptr;
-    if (hipMalloc(&d, entries * 8) != hipSuccess) {
+    const int key_bits = idx->dev.suffix_key_bits;
+    int max_chars = g_suffix_table_chars.load();
+    if (max_chars > 64 / key_bits) max_chars = 64 / key_bits;
+    if (budget == 0 || max_chars < 2 || idx->hdr.wt_sigma < 2) return;
+    // strings of a level: never more than the text has characters, nor than the budget carries
+    uint64_t cap64 = std::min<uint64_t>(budget / 32, (uint64_t)(uint32_t)idx->hdr.length);
+    if (cap64 < 1024) cap64 = 1024;
+    if (cap64 > 0x7fffffffu) cap64 = 0x7fffffffu;
+    const uint32_t cap = (uint32_t)cap64;
+    fmx::SuffixSlot *level[2] = {nullptr, nullptr};
+    uint32_t *d_count = nullptr;
+    void *d_slots = nullptr;
+    auto cleanup = [&]() {
         (void)hipGetLastError();
+        for (auto *p : level)
+            if (p) (void)hipFree(p);
+        if (d_count) (void)hipFree(d_count);
+    };
+    if (hipMalloc(reinterpret_cast<void **>(&level[0]), (size_t)cap * sizeof(fmx::SuffixSlot)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&level[1]), (size_t)cap * sizeof(fmx::SuffixSlot)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&d_count), 64) != hipSuccess) {
+        cleanup();
         return;
     }
-    if (fmx::launch_suffix_table(idx->dev, chars, entries, static_cast<uint64_t *>(d), nullptr) != 0 ||
+    auto counted = [&](uint32_t *out) {  // the level's size, once its kernel has finished
+        return hipMemcpy(out, d_count, 4, hipMemcpyDeviceToHost) == hipSuccess;
+    };
+    uint32_t n_cur = 0;
+    int chars = 0, cur = 0;
+    if (hipMemset(d_count, 0, 64) != hipSuccess || fmx::launch_suffix_level1(idx->dev, level[0], d_count, cap, nullptr) != 0 ||
+        !counted(&n_cur) || n_cur == 0 || n_cur > cap) {
+        cleanup();
+        return;
+    }
+    chars = 1;
+    while (chars < max_chars) {
+        uint32_t n_next = 0;
+        if (hipMemset(d_count, 0, 64) != hipSuccess ||
+            fmx::launch_suffix_expand(idx->dev, idx->n_cu, level[cur], n_cur, chars, key_bits, level[cur ^ 1], d_count, cap, nullptr) != 0 ||
+            !counted(&n_next)) {
+            cleanup();
+            return;
+        }
+        if (n_next == 0 || n_next > cap) break;  // (the next level does not fit: this one is the table)
+        cur ^= 1;
+        n_cur = n_next;
+        ++chars;
+    }
+    if (chars < 2) {
+        cleanup();
+        return;
+    }
+    // the table: 16 columns of slots (fm_suffix_home), the fullest at most half full
+    uint32_t columns[16] = {0};
+    if (hipMemset(d_count, 0, 64) != hipSuccess ||
+        fmx::launch_suffix_columns(level[cur], n_cur, (chars - 1) * key_bits, d_count, nullptr) != 0 ||
+        hipMemcpy(columns, d_count, sizeof columns, hipMemcpyDeviceToHost) != hipSuccess) {
+        cleanup();
+        return;
+    }
+    uint64_t fullest = 0;
+    for (uint32_t v : columns) fullest = std::max<uint64_t>(fullest, v);
+    uint64_t slots64 = 1024;
+    while (slots64 < 2 * (uint64_t)n_cur || slots64 < 32 * fullest) slots64 <<= 1;
+    if (slots64 * sizeof(fmx::SuffixSlot) > std::max<uint64_t>(budget, 1 << 20) * 4 || slots64 > 0x40000000u) {  // (a lopsided alphabet)
+        cleanup();
+        return;
+    }
+    const uint32_t slots = (uint32_t)slots64;
+    int log2_slots = 0;
+    while ((1u << log2_slots) < slots) ++log2_slots;
+    fmx::DevIndex geometry = idx->dev;  // what fm_suffix_home needs
+    geometry.suffix_chars = chars;
+    geometry.suffix_shift = (uint32_t)(64 - (log2_slots - 4));  // groups of 16 slots
+    geometry.suffix_mask = slots - 1;
+    if (hipMalloc(&d_slots, (size_t)slots * sizeof(fmx::SuffixSlot)) != hipSuccess ||
+        hipMemset(d_slots, 0xff, (size_t)slots * sizeof(fmx::SuffixSlot)) != hipSuccess ||
+        fmx::launch_suffix_insert(geometry, level[cur], n_cur, static_cast<fmx::SuffixSlot *>(d_slots), nullptr) != 0 ||
         hipStreamSynchronize(nullptr) != hipSuccess) {
-        (void)hipGetLastError();
-        (void)hipFree(d);
+        if (d_slots) (void)hipFree(d_slots);
+        cleanup();
         return;
     }
-    idx->d_suffix_table = d;
-    idx->suffix_table_bytes = entries * 8;
-    idx->dev.suffix_table = static_cast<const uint64_t *>(d);
+    cleanup();
+    idx->d_suffix_table = d_slots;
+    idx->suffix_table_bytes = (size_t)slots * sizeof(fmx::SuffixSlot);
+    idx->suffix_table_strings = n_cur;
+    idx->dev.suffix_table = static_cast<const fmx::SuffixSlot *>(d_slots);
     idx->dev.suffix_chars = chars;
+    idx->dev.suffix_shift = geometry.suffix_shift;
+    idx->dev.suffix_mask = slots - 1;
 }
 
 int fmx_suffix_table_info(const fmx_index *idx, int32_t *chars, int64_t *bytes) {

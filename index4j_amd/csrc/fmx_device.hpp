@@ -62,16 +62,27 @@ struct DevIndex {
     const struct Quad *sb_cache;
     int32_t sb_cache_limit;      // stage the cache only for indexes with at most this many superblocks (0 = never)
     uint32_t wt_size;
-    // Suffix table (nullptr: none): the SA interval of every string of `suffix_chars` codes, i.e. the state of
-    // FM:455-474 after the pattern's last `suffix_chars` characters, indexed by those codes (the last character most
-    // significant, radix wt_sigma).  Entry = {x, y}: x bit 31 clear: start = x, end = y (start < end, all
-    // suffix_chars - 1 steps taken); x = kSuffixEnded | b: the search ended with an empty interval after b characters
-    // beyond the first; x = kSuffixAsk: not tabulated (a zero code, an exception status) — run the loop.
-    const uint64_t *suffix_table;
+    // Suffix table (nullptr: none): the SA interval of every string of `suffix_chars` codes THAT OCCURS IN THE TEXT, i.e.
+    // the state of FM:455-474 after a pattern's last `suffix_chars` characters — an open-addressing hash table of 16-byte
+    // slots {key, start, end}; key = the codes, the LAST character in the low bits, `suffix_key_bits` (8 or 16, by this
+    // index's alphabet) each: the low bits of a plan record's code word as they stand.  A string that is not in the table
+    // (it does not occur, holds a code of 0, or its search raised a status) is simply looked for with the loop.
+    const struct SuffixSlot *suffix_table;
     int32_t suffix_chars;
+    int32_t suffix_key_bits;
+    uint32_t suffix_shift;  // group of a key = (its hashed bits * kSuffixHashMul) >> suffix_shift (fm_suffix_home)
+    uint32_t suffix_mask;   // slots - 1 (slots: a power of two, >= 1024)
 };
-constexpr uint32_t kSuffixEnded = 0x80000000u;
-constexpr uint32_t kSuffixAsk = 0xC0000000u;
+struct SuffixSlot {
+    uint64_t key;  // kSuffixEmpty: free
+    uint32_t start, end;
+};
+constexpr uint64_t kSuffixEmpty = ~0ull;
+constexpr uint64_t kSuffixHashMul = 0x9E3779B97F4A7C15ull;
+// Strings that differ only in the low 4 bits of their FIRST character's code (the one a pattern consumes last of the
+// table's characters) share a group of 16 consecutive slots — 256 bytes — and probing moves by whole groups: the lanes
+// of a wave, neighbours in suffix order, then read the same lines, as they did in a dense table's row.
+constexpr uint32_t kSuffixGroup = 16;
 
 #if !defined(__HIPCC__)
 inline int fmx_popc(uint32_t v) { return __builtin_popcount(v); }
@@ -952,59 +963,56 @@ FMX_HD void fm_seek_after(const DevIndex &ix, int32_t x, int32_t &row, int32_t &
 }
 
 // ---- suffix table (DevIndex.suffix_table) ---------------------------------------------------------------------
-// entry `at` = the state of the backward search of FM:455-474 after the `chars` codes that `at` spells (radix wt_sigma,
-// the LAST character of a pattern most significant), computed by the very loop k_count runs, both ends in turn
-FMX_HD uint64_t fm_suffix_entry(const DevIndex &ix, uint64_t at, int chars) {
-    const uint32_t sigma = (uint32_t)ix.wt_sigma;
-    uint32_t code[8];
-    {
-        uint64_t rest = at;
-        for (int j = chars - 1; j >= 0; --j) {
-            code[j] = (uint32_t)(rest % sigma);
-            rest /= sigma;
-        }
-    }
-    bool ask = false;
-    for (int j = 0; j < chars; ++j) ask = ask || code[j] == 0 || (int32_t)code[j] + 1 >= ix.n_c;
-    if (ask) return kSuffixAsk;
+// The table is grown level by level when an index becomes resident: level 1 = the characters (cumulativeCounts), level
+// j + 1 = every string of level j with every character put in front of it — by the very step k_count runs (FM:469-470 over
+// the index's own rank(), quirks included) — keeping what has a non-empty interval and raised no status.  A slot IS the
+// state of the backward search after a pattern's last k characters.
+// one string of level j (`parent`: its key holds j codes) with code c in front: false = not kept
+FMX_HD bool fm_suffix_extend(const DevIndex &ix, const SuffixSlot &parent, int depth, int32_t c, int key_bits, SuffixSlot &child) {
     int status = ST_OK;
-    int32_t start = ix.C[code[0]], end = ix.C[code[0] + 1], back = 0;
-    while (start < end && back + 1 < chars) {  // FM:464
-        ++back;
-        const int32_t c = (int32_t)code[back];
-        const int32_t s2 = wt_rank_folded(ix, nullptr, (uint32_t)start, c, status);  // FM:469
-        const int32_t e2 = wt_rank_folded(ix, nullptr, (uint32_t)end, c, status);    // FM:470
-        start = s2;
-        end = e2;
-    }
-    if (status != ST_OK) return kSuffixAsk;
-    if (start < end) return (uint64_t)(uint32_t)start | ((uint64_t)(uint32_t)end << 32);  // (back == chars - 1)
-    return (uint64_t)(kSuffixEnded | (uint32_t)back);
+    const int32_t s2 = wt_rank_folded(ix, nullptr, parent.start, c, status);  // FM:469
+    const int32_t e2 = wt_rank_folded(ix, nullptr, parent.end, c, status);    // FM:470
+    if (status != ST_OK || s2 >= e2) return false;
+    child.key = parent.key | ((uint64_t)(uint32_t)c << (depth * key_bits));
+    child.start = (uint32_t)s2;
+    child.end = (uint32_t)e2;
+    return true;
 }
-// A pattern of m >= suffix_chars characters whose trailing codes are code[0] (the last character) ... : where the search
-// stands after them, if the table says so.  Returns false when the loop has to run from the first character.
+FMX_HD uint32_t fm_suffix_home(const DevIndex &ix, uint64_t key) {
+    const int top = (ix.suffix_chars - 1) * ix.suffix_key_bits;  // where the first character's code sits
+    const uint64_t low4 = (key >> top) & (kSuffixGroup - 1);
+    const uint64_t rest = key & ~((uint64_t)(kSuffixGroup - 1) << top);
+    return ((uint32_t)((rest * kSuffixHashMul) >> ix.suffix_shift) * kSuffixGroup + (uint32_t)low4) & ix.suffix_mask;
+}
+// A pattern of m >= suffix_chars characters whose trailing codes spell `key`: where the search stands after them, if
+// the table says so.  Returns false when the loop has to run from the first character.
+FMX_HD bool fm_suffix_lookup(const DevIndex &ix, uint64_t key, int32_t &start, int32_t &end, int32_t &back) {
+    uint32_t h = fm_suffix_home(ix, key);
+    // (ends at a free slot: the table has at least twice as many slots as strings; the bound is for a damaged table)
+    for (uint32_t probe = 0; probe <= ix.suffix_mask / kSuffixGroup; ++probe, h = (h + kSuffixGroup) & ix.suffix_mask) {
+        const Quad q = ld_quad(ix.suffix_table + h);
+        const uint64_t k = (uint64_t)q.x | ((uint64_t)q.y << 32);
+        if (k == key) {
+            start = (int32_t)q.z;
+            end = (int32_t)q.w;
+            back = ix.suffix_chars - 1;
+            return true;
+        }
+        if (k == kSuffixEmpty) return false;
+    }
+    return false;
+}
+// the key of a pattern's last suffix_chars characters from its codes (code_at(0) = the last character); false: a code of 0
 template <class CodeAt>
-FMX_HD bool fm_suffix_lookup(const DevIndex &ix, CodeAt code_at, int32_t &start, int32_t &end, int32_t &back) {
-    uint64_t at = (uint64_t)(uint32_t)code_at(0);  // (budgets above 32 GiB give tables of more than 2^32 entries)
-    bool known = at != 0;
-    for (int j = 1; j < ix.suffix_chars; ++j) {
+FMX_HD bool fm_suffix_key(const DevIndex &ix, CodeAt code_at, uint64_t &key) {
+    key = 0;
+    bool known = true;
+    for (int j = 0; j < ix.suffix_chars; ++j) {
         const uint32_t cj = (uint32_t)code_at(j);
         known = known && cj != 0;
-        at = at * (uint32_t)ix.wt_sigma + cj;
+        key |= (uint64_t)cj << (j * ix.suffix_key_bits);
     }
-    if (!known) return false;
-    const uint64_t e = ix.suffix_table[at];
-    const uint32_t x = (uint32_t)e;
-    if ((x & kSuffixAsk) == kSuffixEnded) {  // the search ended inside the suffix: empty interval
-        start = end = 0;
-        back = (int32_t)(x & 0xffu);
-        return true;
-    }
-    if ((x & kSuffixAsk) != 0) return false;
-    start = (int32_t)x;
-    end = (int32_t)(uint32_t)(e >> 32);
-    back = ix.suffix_chars - 1;
-    return true;
+    return known;
 }
 
 // FM:526-548 for one hit: SA row i = start + 1 + k; LF-walk until a sampled row.

@@ -264,17 +264,25 @@ __device__ __forceinline__ void count_one(const DevIndex &ix, const int16_t *s_m
     start = ix.C[c];
     end = ix.C[c + 1];
     if (ix.suffix_table && m >= ix.suffix_chars && ck.n >= ix.suffix_chars) {
-        // the interval after the last suffix_chars characters is tabulated (k_suffix_table ran this very loop for every
-        // string of that many codes): one 8-byte load instead of 2 * (suffix_chars - 1) ranks.  A segment of a set looks
-        // its OWN table up with the translated codes (a code this alphabet lacks is 0 = "not tabulated": the loop runs and
-        // lets the character itself decide).
-        (void)fm_suffix_lookup(
-            ix,
-            [&](int j) {
-                const uint32_t cj = (uint32_t)chunk_code<kCodeBits>(ck, j);
-                return translate ? (uint32_t)(uint16_t)s_xlat[cj] : cj;
-            },
-            start, end, back);
+        // the interval after the last suffix_chars characters is tabulated (the table was grown by this very loop over every
+        // string of that many codes that occurs): one 16-byte slot instead of 2 * (suffix_chars - 1) ranks.  The key is the
+        // low bits of the code word where that is written in this index's alphabet; a segment of a set makes it from the
+        // translated codes (a code its alphabet lacks is 0: not tabulated, the loop runs and lets the character decide).
+        uint64_t key;
+        bool known = true;
+        if (translate || kCodeBits != ix.suffix_key_bits) {
+            known = fm_suffix_key(
+                ix,
+                [&](int j) {
+                    const uint32_t cj = (uint32_t)chunk_code<kCodeBits>(ck, j);
+                    return translate ? (uint32_t)(uint16_t)s_xlat[cj] : cj;
+                },
+                key);
+        } else {
+            const int bits = ix.suffix_chars * kCodeBits;
+            key = bits >= 64 ? ck.lo : (ck.lo & ((1ull << bits) - 1ull));
+        }
+        if (known) (void)fm_suffix_lookup(ix, key, start, end, back);
         tabled = back;  // characters whose rank evaluations the table answered
     }
     bool first_chunk = true;  // the record's word (its codes are the PLAN's: translated in mode 2)
@@ -386,16 +394,92 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
     }
 }
 
-// The suffix table (DevIndex.suffix_table, fm_suffix_entry): one thread per entry.
-__global__ __launch_bounds__(256) void k_suffix_table(DevIndex ix, int chars, uint64_t entries, uint64_t *__restrict__ table) {
-    const uint64_t at = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (at < entries) table[at] = fm_suffix_entry(ix, at, chars);
+// ---- growing the suffix table (fmx_device.hpp: fm_suffix_extend) when an index becomes resident ----
+// level 1: every character of the alphabet that occurs (its interval is cumulativeCounts' own)
+__global__ __launch_bounds__(256) void k_suffix_level1(DevIndex ix, SuffixSlot *__restrict__ out, uint32_t *__restrict__ count,
+                                                       uint32_t cap) {
+    const int32_t c = (int32_t)(blockIdx.x * 256 + threadIdx.x) + 1;  // code 0 is never tabulated
+    if (c + 1 >= ix.n_c || c >= ix.wt_sigma) return;
+    const int32_t lo = ix.C[c], hi = ix.C[c + 1];
+    if (lo >= hi) return;
+    const uint32_t at = atomicAdd(count, 1u);
+    if (at < cap) out[at] = SuffixSlot{(uint64_t)(uint32_t)c, (uint32_t)lo, (uint32_t)hi};
 }
-int launch_suffix_table(const DevIndex &ix, int chars, uint64_t entries, uint64_t *table, hipStream_t st) {
+// level depth + 1: every string of level `depth` with every character in front of it
+__global__ __launch_bounds__(256) void k_suffix_expand(DevIndex ix, const SuffixSlot *__restrict__ in, uint32_t n_in, int depth,
+                                                       int key_bits, SuffixSlot *__restrict__ out, uint32_t *__restrict__ count,
+                                                       uint32_t cap) {
+    const uint32_t sigma1 = (uint32_t)ix.wt_sigma - 1u;  // codes 1 .. sigma - 1
+    const uint64_t work = (uint64_t)n_in * sigma1;
+    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < work; t += (uint64_t)gridDim.x * 256) {
+        const uint32_t i = (uint32_t)(t / sigma1);
+        const int32_t c = (int32_t)(t - (uint64_t)i * sigma1) + 1;
+        if (c + 1 >= ix.n_c) continue;
+        SuffixSlot child;
+        if (!fm_suffix_extend(ix, in[i], depth, c, key_bits, child)) continue;
+        const uint32_t at = atomicAdd(count, 1u);
+        if (at < cap) out[at] = child;
+    }
+}
+// the last level into the hash table (slots preset to kSuffixEmpty); ix carries the table's geometry (fm_suffix_home)
+__global__ __launch_bounds__(256) void k_suffix_insert(DevIndex ix, const SuffixSlot *__restrict__ in, uint32_t n_in,
+                                                       SuffixSlot *__restrict__ slots) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_in) return;
+    const SuffixSlot me = in[i];
+    uint32_t h = fm_suffix_home(ix, me.key);
+    for (uint32_t probe = 0; probe <= ix.suffix_mask / kSuffixGroup; ++probe, h = (h + kSuffixGroup) & ix.suffix_mask) {
+        unsigned long long *key = reinterpret_cast<unsigned long long *>(&slots[h].key);
+        if (atomicCAS(key, (unsigned long long)kSuffixEmpty, (unsigned long long)me.key) == (unsigned long long)kSuffixEmpty) {
+            slots[h].start = me.start;
+            slots[h].end = me.end;
+            return;
+        }
+    }
+    // (a column of the table is full: cannot happen at half load spread by the hash; the string is then simply not found)
+}
+// how many strings of the last level fall into each of the table's 16 slot columns (the low 4 bits of the first
+// character's code): the table is sized so that the fullest column stays at most half full
+__global__ __launch_bounds__(256) void k_suffix_columns(const SuffixSlot *__restrict__ in, uint32_t n_in, int top_shift,
+                                                        uint32_t *__restrict__ counts) {
+    __shared__ uint32_t s_c[kSuffixGroup];
+    if (threadIdx.x < kSuffixGroup) s_c[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_in; i += gridDim.x * 256)
+        atomicAdd(&s_c[(uint32_t)(in[i].key >> top_shift) & (kSuffixGroup - 1)], 1u);
+    __syncthreads();
+    if (threadIdx.x < kSuffixGroup && s_c[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_c[threadIdx.x]);
+}
+int launch_suffix_columns(const SuffixSlot *in, uint32_t n_in, int top_shift, uint32_t *counts, hipStream_t st) {
+    if (n_in == 0) return 0;
+    uint32_t blocks = (n_in + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_suffix_columns, dim3(blocks), dim3(256), 0, st, in, n_in, top_shift, counts);
+    return (int)hipGetLastError();
+}
+int launch_suffix_level1(const DevIndex &ix, SuffixSlot *out, uint32_t *count, uint32_t cap, hipStream_t st) {
     DevIndex plain = ix;
     plain.sb_cache = nullptr;
     plain.suffix_table = nullptr;
-    hipLaunchKernelGGL(k_suffix_table, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, st, plain, chars, entries, table);
+    hipLaunchKernelGGL(k_suffix_level1, dim3((unsigned)((ix.wt_sigma + 255) / 256)), dim3(256), 0, st, plain, out, count, cap);
+    return (int)hipGetLastError();
+}
+int launch_suffix_expand(const DevIndex &ix, int n_cu, const SuffixSlot *in, uint32_t n_in, int depth, int key_bits, SuffixSlot *out,
+                         uint32_t *count, uint32_t cap, hipStream_t st) {
+    DevIndex plain = ix;
+    plain.sb_cache = nullptr;
+    plain.suffix_table = nullptr;
+    const uint64_t work = (uint64_t)n_in * (uint64_t)(ix.wt_sigma > 1 ? ix.wt_sigma - 1 : 1);
+    uint64_t blocks = (work + 255) / 256;
+    const uint64_t cap_blocks = (uint64_t)n_cu * 64;
+    if (blocks > cap_blocks) blocks = cap_blocks;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_suffix_expand, dim3((unsigned)blocks), dim3(256), 0, st, plain, in, n_in, depth, key_bits, out, count, cap);
+    return (int)hipGetLastError();
+}
+int launch_suffix_insert(const DevIndex &geometry, const SuffixSlot *in, uint32_t n_in, SuffixSlot *slots, hipStream_t st) {
+    if (n_in == 0) return 0;
+    hipLaunchKernelGGL(k_suffix_insert, dim3((n_in + 255) / 256), dim3(256), 0, st, geometry, in, n_in, slots);
     return (int)hipGetLastError();
 }
 

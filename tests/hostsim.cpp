@@ -43,6 +43,9 @@ static DevIndex make_index(const uint8_t *b) {
     d.wt_size = (uint32_t)h.wt_size;
     d.suffix_table = nullptr;
     d.suffix_chars = 0;
+    d.suffix_key_bits = h.wt_sigma <= 256 ? 8 : 16;
+    d.suffix_shift = 0;
+    d.suffix_mask = 0;
     return d;
 }
 
@@ -117,17 +120,42 @@ void sim_count(const uint8_t *blob, const uint16_t *pat, const int32_t *off, int
     }
 }
 
-// mirrors k_count with a suffix table of `chars` characters: the table is filled by fm_suffix_entry (what k_suffix_table
-// runs per entry) and consulted by fm_suffix_lookup (what a planned k_count runs per pattern)
+// mirrors k_count with a suffix table of `chars` characters: the table is grown level by level with fm_suffix_extend (what
+// k_suffix_level1 / k_suffix_expand run), hashed as k_suffix_insert does, and consulted by fm_suffix_key + fm_suffix_lookup
+// (what k_count runs per pattern).  Returns the number of strings in the table.
 int64_t sim_count_table(const uint8_t *blob, int32_t chars, const uint16_t *pat, const int32_t *off, int32_t n,
                         int32_t *counts, int32_t *lf, int32_t *status_out, int64_t *answered_steps) {
     DevIndex ix = make_index(blob);
-    uint64_t entries = 1;
-    for (int k = 0; k < chars; ++k) entries *= (uint64_t)ix.wt_sigma;
-    std::vector<uint64_t> table((size_t)entries);
-    for (uint64_t at = 0; at < entries; ++at) table[(size_t)at] = fm_suffix_entry(ix, at, chars);
-    ix.suffix_table = table.data();
+    const int key_bits = ix.wt_sigma <= 256 ? 8 : 16;
+    std::vector<SuffixSlot> level;
+    for (int32_t c = 1; c + 1 < ix.n_c && c < ix.wt_sigma; ++c)
+        if (ix.C[c] < ix.C[c + 1]) level.push_back(SuffixSlot{(uint64_t)(uint32_t)c, (uint32_t)ix.C[c], (uint32_t)ix.C[c + 1]});
+    for (int depth = 1; depth < chars; ++depth) {
+        std::vector<SuffixSlot> next;
+        for (const SuffixSlot &parent : level)
+            for (int32_t c = 1; c < ix.wt_sigma; ++c) {
+                if (c + 1 >= ix.n_c) continue;
+                SuffixSlot child;
+                if (fm_suffix_extend(ix, parent, depth, c, key_bits, child)) next.push_back(child);
+            }
+        level.swap(next);
+    }
+    uint32_t slots = 1024;
+    while (slots < 2 * (uint64_t)level.size()) slots <<= 1;
+    int log2_slots = 0;
+    while ((1u << log2_slots) < slots) ++log2_slots;
+    std::vector<SuffixSlot> table(slots, SuffixSlot{kSuffixEmpty, 0, 0});
+    ix.suffix_key_bits = key_bits;
     ix.suffix_chars = chars;
+    ix.suffix_shift = (uint32_t)(64 - (log2_slots - 4));
+    ix.suffix_mask = slots - 1;
+    for (const SuffixSlot &e : level) {
+        uint32_t h = fm_suffix_home(ix, e.key);
+        while (table[h].key != kSuffixEmpty) h = (h + kSuffixGroup) & ix.suffix_mask;
+        table[h] = e;
+    }
+    ix.suffix_table = table.data();
+    const int64_t entries = (int64_t)level.size();
     int64_t answered = 0;
     for (int32_t p = 0; p < n; ++p) {
         const int32_t beg = off[p], m = off[p + 1] - beg;
@@ -140,8 +168,9 @@ int64_t sim_count_table(const uint8_t *blob, int32_t chars, const uint16_t *pat,
             if (c != 0) {
                 start = ix.C[c];
                 end = ix.C[c + 1];
-                if (m >= chars &&
-                    fm_suffix_lookup(ix, [&](int j) { return (uint32_t)fm_map(ix, pat[beg + m - 1 - j]); }, start, end, back))
+                uint64_t key;
+                if (m >= chars && fm_suffix_key(ix, [&](int j) { return (uint32_t)fm_map(ix, pat[beg + m - 1 - j]); }, key) &&
+                    fm_suffix_lookup(ix, key, start, end, back))
                     answered += 2 * back;
                 while (start < end && back + 1 < m) {
                     ++back;

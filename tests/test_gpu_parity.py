@@ -460,8 +460,8 @@ def test_planned_batches_vs_oracle_across_alphabet_sizes(sigma):
 
 
 def test_suffix_table_changes_nothing_but_the_time():
-    """the suffix table (SA interval of every string of k codes, tabulated when the index becomes resident) lets planned
-    count / locate batches skip their first 2 * (k - 1) rank evaluations: counts, statuses, PER-PATTERN LF-step counts
+    """the suffix table (SA interval of every string of k codes that occurs, grown and hashed when the index becomes resident)
+    lets count / locate batches skip their first 2 * (k - 1) rank evaluations: counts, statuses, PER-PATTERN LF-step counts
     and located hits must be what they are without it, and what the oracle says — for every table depth the budget
     yields, on patterns that end early at every depth, hold absent characters, are shorter than the table's strings,
     and on a text whose length is a multiple of 2^20 (rank(size) raises in the JVM: Q3 -> entries that say 'ask')"""
@@ -486,11 +486,14 @@ def test_suffix_table_changes_nothing_but_the_time():
             o_steps = orc.counters()["lf_steps"]
             seen = set()
             ref = None
-            for mb in (0, 1, 256):
+            for mb, depth in ((0, 4), (256, 2), (256, 3), (256, 4), (256, 6), (1, 8)):
                 assert ia.lib.fmx_set_option(b"suffix_table_mb", mb) == 0
+                assert ia.lib.fmx_set_option(b"suffix_table_chars", depth) == 0
                 fm = ia.FmIndex.read(o.write(False), device=0)
                 k, nbytes = fm.suffix_table_info()
-                assert (k == 0) == (mb == 0) and (k == 0 or nbytes == 8 * fm.getAlphabetLength() ** k or nbytes > 0)
+                # the depth asked for, unless the budget stops the growth earlier (1 MB: 32,768 strings)
+                assert (k == 0) == (mb == 0) and k <= depth and (k == 0 or nbytes >= 16 * 1024)
+                assert mb != 256 or k == depth
                 seen.add(k)
                 for use in ((1,) if k == 0 else (1, 0)):
                     assert ia.lib.fmx_set_option(b"suffix_table", use) == 0
@@ -507,9 +510,10 @@ def test_suffix_table_changes_nothing_but_the_time():
                             assert st2[i] == 0 and found[i] == kk and (locs[i, :kk] == ll).all(), (mb, use, i)
                         except IndexError:  # Q3
                             assert st2[i] == 9
-            assert len(seen) >= 3  # no table, a shallow one, the default depth
+            assert len(seen) >= 5  # no table, depths 2, 3, 4, 6 (and what a 1 MB budget allows)
     finally:
         ia.lib.fmx_set_option(b"suffix_table_mb", 256)
+        ia.lib.fmx_set_option(b"suffix_table_chars", 4)
         ia.lib.fmx_set_option(b"suffix_table", 1)
 
 

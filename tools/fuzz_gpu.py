@@ -70,7 +70,8 @@ def main():
         ia.lib.fmx_set_option(b"sb_cache_limit", cache)
         ia.lib.fmx_set_option(b"map_fast", rnd.choice([1, 1, 1, 0]))  # 0: every mapping entry on the reference's route
         ia.lib.fmx_set_option(b"inv_fast", rnd.choice([1, 1, 1, 0]))  # 0: inverseSelect on the reference's route
-        ia.lib.fmx_set_option(b"suffix_table_mb", rnd.choice([256, 256, 1, 0]))  # depth of the suffix table (0: none)
+        ia.lib.fmx_set_option(b"suffix_table_mb", rnd.choice([256, 256, 1, 0]))  # budget of the suffix table (0: none)
+        ia.lib.fmx_set_option(b"suffix_table_chars", rnd.choice([4, 4, 2, 3, 6, 8]))  # its depth
         ia.lib.fmx_set_option(b"cells_split_blocks", rnd.choice([1 << 20, 64, 256]))  # chunked decoding of the bit vectors
         ia.lib.fmx_set_option(b"boundary_group", rnd.choice([0, 1, 2, 4, 8]))
         try:

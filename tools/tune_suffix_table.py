@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""configs[1] step and k_count time by suffix-table depth (option suffix_table_mb).  GPU box only."""
+"""configs[1] step by suffix-table depth (option suffix_table_chars; arguments: depths, default 0 2 3 4 5 6 8).  GPU box only."""
 import ctypes as C
 import os
 import sys
@@ -27,9 +27,10 @@ def main():
                         torch.zeros(n, dtype=torch.int32, device=dev)))
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
-    budgets = [int(x) for x in sys.argv[1:]] or [0, 1, 16, 256]
-    for mb in budgets:
-        ia.lib.fmx_set_option(b"suffix_table_mb", mb)
+    depths = [int(x) for x in sys.argv[1:]] or [0, 2, 3, 4, 5, 6, 8]
+    for depth in depths:
+        ia.lib.fmx_set_option(b"suffix_table_mb", 0 if depth == 0 else 4096)
+        ia.lib.fmx_set_option(b"suffix_table_chars", max(depth, 2))
         t0 = time.perf_counter()
         fm.to_device(0)
         t_dev = time.perf_counter() - t0
@@ -49,9 +50,10 @@ def main():
         e1.record(stream)
         torch.cuda.synchronize()
         sums = [int(b[2].sum().item()) for b in batches]
-        print("budget %6d MB: table of %d chars, %10.1f MB, to_device %.3f s; step %.4f ms; checksums %s"
-              % (mb, k, nbytes / 1e6, t_dev, e0.elapsed_time(e1) / 40, sums[:2]), flush=True)
+        print("depth asked %d: table of %d chars, %10.2f MB, to_device %.3f s; step %.4f ms; checksums %s"
+              % (depth, k, nbytes / 1e6, t_dev, e0.elapsed_time(e1) / 40, sums[:2]), flush=True)
     ia.lib.fmx_set_option(b"suffix_table_mb", 256)
+    ia.lib.fmx_set_option(b"suffix_table_chars", 4)
 
 
 if __name__ == "__main__":
