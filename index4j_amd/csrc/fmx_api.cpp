@@ -604,7 +604,7 @@ static void build_suffix_table(fmx_index *idx) {
     };
     if (hipMalloc(reinterpret_cast<void **>(&level[0]), (size_t)cap * sizeof(fmx::SuffixSlot)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&level[1]), (size_t)cap * sizeof(fmx::SuffixSlot)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&d_count), 64) != hipSuccess) {
+        hipMalloc(reinterpret_cast<void **>(&d_count), 4 * fmx::kSuffixGroup + 64) != hipSuccess) {
         cleanup();
         return;
     }
@@ -636,9 +636,9 @@ static void build_suffix_table(fmx_index *idx) {
         cleanup();
         return;
     }
-    // the table: 16 columns of slots (fm_suffix_home), the fullest at most half full
-    uint32_t columns[16] = {0};
-    if (hipMemset(d_count, 0, 64) != hipSuccess ||
+    // the table: kSuffixGroup columns of slots (fm_suffix_home), the fullest at most half full
+    uint32_t columns[fmx::kSuffixGroup] = {0};
+    if (hipMemset(d_count, 0, 4 * fmx::kSuffixGroup) != hipSuccess ||
         fmx::launch_suffix_columns(level[cur], n_cur, (chars - 1) * key_bits, d_count, nullptr) != 0 ||
         hipMemcpy(columns, d_count, sizeof columns, hipMemcpyDeviceToHost) != hipSuccess) {
         cleanup();
@@ -647,7 +647,7 @@ static void build_suffix_table(fmx_index *idx) {
     uint64_t fullest = 0;
     for (uint32_t v : columns) fullest = std::max<uint64_t>(fullest, v);
     uint64_t slots64 = 1024;
-    while (slots64 < 2 * (uint64_t)n_cur || slots64 < 32 * fullest) slots64 <<= 1;
+    while (slots64 < 2 * (uint64_t)n_cur || slots64 < 2 * fmx::kSuffixGroup * fullest) slots64 <<= 1;
     if (slots64 * sizeof(fmx::SuffixSlot) > std::max<uint64_t>(budget, 1 << 20) * 4 || slots64 > 0x40000000u) {  // (a lopsided alphabet)
         cleanup();
         return;
@@ -657,7 +657,7 @@ static void build_suffix_table(fmx_index *idx) {
     while ((1u << log2_slots) < slots) ++log2_slots;
     fmx::DevIndex geometry = idx->dev;  // what fm_suffix_home needs
     geometry.suffix_chars = chars;
-    geometry.suffix_shift = (uint32_t)(64 - (log2_slots - 4));  // groups of 16 slots
+    geometry.suffix_shift = (uint32_t)(64 - (log2_slots - fmx::kSuffixGroupLog2));  // whole groups
     geometry.suffix_mask = slots - 1;
     if (hipMalloc(&d_slots, (size_t)slots * sizeof(fmx::SuffixSlot)) != hipSuccess ||
         hipMemset(d_slots, 0xff, (size_t)slots * sizeof(fmx::SuffixSlot)) != hipSuccess ||

@@ -79,10 +79,11 @@ struct SuffixSlot {
 };
 constexpr uint64_t kSuffixEmpty = ~0ull;
 constexpr uint64_t kSuffixHashMul = 0x9E3779B97F4A7C15ull;
-// Strings that differ only in the low 4 bits of their FIRST character's code (the one a pattern consumes last of the
-// table's characters) share a group of 16 consecutive slots — 256 bytes — and probing moves by whole groups: the lanes
-// of a wave, neighbours in suffix order, then read the same lines, as they did in a dense table's row.
-constexpr uint32_t kSuffixGroup = 16;
+// Strings that differ only in the low 6 bits of their FIRST character's code (the one a pattern consumes last of the
+// table's characters) share a group of 64 consecutive slots — 1 KiB — and probing moves by whole groups: the lanes of a
+// wave, neighbours in suffix order, then read the same few lines, as they did in a dense table's row.
+constexpr int kSuffixGroupLog2 = 6;
+constexpr uint32_t kSuffixGroup = 1u << kSuffixGroupLog2;
 
 #if !defined(__HIPCC__)
 inline int fmx_popc(uint32_t v) { return __builtin_popcount(v); }
@@ -988,19 +989,20 @@ FMX_HD uint32_t fm_suffix_home(const DevIndex &ix, uint64_t key) {
 // the table says so.  Returns false when the loop has to run from the first character.
 FMX_HD bool fm_suffix_lookup(const DevIndex &ix, uint64_t key, int32_t &start, int32_t &end, int32_t &back) {
     uint32_t h = fm_suffix_home(ix, key);
+    Quad q = ld_quad(ix.suffix_table + h);  // the home slot answers nearly every lookup (the fullest column is half full at most)
+    FMX_PIN_QUAD(q);
+    uint64_t k = (uint64_t)q.x | ((uint64_t)q.y << 32);
     // (ends at a free slot: the table has at least twice as many slots as strings; the bound is for a damaged table)
-    for (uint32_t probe = 0; probe <= ix.suffix_mask / kSuffixGroup; ++probe, h = (h + kSuffixGroup) & ix.suffix_mask) {
-        const Quad q = ld_quad(ix.suffix_table + h);
-        const uint64_t k = (uint64_t)q.x | ((uint64_t)q.y << 32);
-        if (k == key) {
-            start = (int32_t)q.z;
-            end = (int32_t)q.w;
-            back = ix.suffix_chars - 1;
-            return true;
-        }
-        if (k == kSuffixEmpty) return false;
+    for (uint32_t probe = 0; k != key && k != kSuffixEmpty && probe < ix.suffix_mask / kSuffixGroup; ++probe) {
+        h = (h + kSuffixGroup) & ix.suffix_mask;
+        q = ld_quad(ix.suffix_table + h);
+        k = (uint64_t)q.x | ((uint64_t)q.y << 32);
     }
-    return false;
+    if (k != key) return false;
+    start = (int32_t)q.z;
+    end = (int32_t)q.w;
+    back = ix.suffix_chars - 1;
+    return true;
 }
 // the key of a pattern's last suffix_chars characters from its codes (code_at(0) = the last character); false: a code of 0
 template <class CodeAt>

@@ -140,14 +140,19 @@ int64_t sim_count_table(const uint8_t *blob, int32_t chars, const uint16_t *pat,
             }
         level.swap(next);
     }
+    // sized as the library does: twice the strings, and the fullest of the kSuffixGroup slot columns at most half full
+    std::vector<uint64_t> column(kSuffixGroup, 0);
+    for (const SuffixSlot &e : level) ++column[(e.key >> ((chars - 1) * key_bits)) & (kSuffixGroup - 1)];
+    uint64_t fullest = 0;
+    for (uint64_t v : column) fullest = v > fullest ? v : fullest;
     uint32_t slots = 1024;
-    while (slots < 2 * (uint64_t)level.size()) slots <<= 1;
+    while (slots < 2 * (uint64_t)level.size() || slots < 2 * (uint64_t)kSuffixGroup * fullest) slots <<= 1;
     int log2_slots = 0;
     while ((1u << log2_slots) < slots) ++log2_slots;
     std::vector<SuffixSlot> table(slots, SuffixSlot{kSuffixEmpty, 0, 0});
     ix.suffix_key_bits = key_bits;
     ix.suffix_chars = chars;
-    ix.suffix_shift = (uint32_t)(64 - (log2_slots - 4));
+    ix.suffix_shift = (uint32_t)(64 - (log2_slots - kSuffixGroupLog2));
     ix.suffix_mask = slots - 1;
     for (const SuffixSlot &e : level) {
         uint32_t h = fm_suffix_home(ix, e.key);
