@@ -636,7 +636,7 @@ static void build_suffix_table(fmx_index *idx) {
         cleanup();
         return;
     }
-    // the table: kSuffixGroup columns of slots (fm_suffix_home), the fullest at most half full
+    // the table: kSuffixGroup columns of slots (fm_suffix_home)
     uint32_t columns[fmx::kSuffixGroup] = {0};
     if (hipMemset(d_count, 0, 4 * fmx::kSuffixGroup) != hipSuccess ||
         fmx::launch_suffix_columns(level[cur], n_cur, (chars - 1) * key_bits, d_count, nullptr) != 0 ||
@@ -647,7 +647,14 @@ static void build_suffix_table(fmx_index *idx) {
     uint64_t fullest = 0;
     for (uint32_t v : columns) fullest = std::max<uint64_t>(fullest, v);
     uint64_t slots64 = 1024;
-    while (slots64 < 2 * (uint64_t)n_cur || slots64 < 2 * fmx::kSuffixGroup * fullest) slots64 <<= 1;
+    // twice as many slots as strings, and the fullest column half full (probing stays inside a column: 0.8 % of the headline
+    // batch's step) — or, where that would pass an eighth of the image, room for the fullest column with a quarter to spare
+    while (slots64 < 2 * (uint64_t)n_cur || 4 * slots64 < 5 * fmx::kSuffixGroup * fullest) slots64 <<= 1;
+    {
+        uint64_t roomy = slots64;
+        while (roomy < 2 * fmx::kSuffixGroup * fullest) roomy <<= 1;
+        if (roomy * sizeof(fmx::SuffixSlot) <= idx->d_len / 8) slots64 = roomy;
+    }
     if (slots64 * sizeof(fmx::SuffixSlot) > std::max<uint64_t>(budget, 1 << 20) * 4 || slots64 > 0x40000000u) {  // (a lopsided alphabet)
         cleanup();
         return;

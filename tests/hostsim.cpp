@@ -140,13 +140,13 @@ int64_t sim_count_table(const uint8_t *blob, int32_t chars, const uint16_t *pat,
             }
         level.swap(next);
     }
-    // sized as the library does: twice the strings, and the fullest of the kSuffixGroup slot columns at most half full
+    // sized as the library does: twice the strings, and room for the fullest of the kSuffixGroup slot columns with a quarter to spare
     std::vector<uint64_t> column(kSuffixGroup, 0);
     for (const SuffixSlot &e : level) ++column[(e.key >> ((chars - 1) * key_bits)) & (kSuffixGroup - 1)];
     uint64_t fullest = 0;
     for (uint64_t v : column) fullest = v > fullest ? v : fullest;
     uint32_t slots = 1024;
-    while (slots < 2 * (uint64_t)level.size() || slots < 2 * (uint64_t)kSuffixGroup * fullest) slots <<= 1;
+    while (slots < 2 * (uint64_t)level.size() || 4 * (uint64_t)slots < 5 * (uint64_t)kSuffixGroup * fullest) slots <<= 1;
     int log2_slots = 0;
     while ((1u << log2_slots) < slots) ++log2_slots;
     std::vector<SuffixSlot> table(slots, SuffixSlot{kSuffixEmpty, 0, 0});
