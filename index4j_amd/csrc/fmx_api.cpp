@@ -55,6 +55,7 @@ int set_option(const char *, int);
 struct fmx_index {
     fmx::FmModel model;
     bool has_model = false;
+    bool from_stream = false;    // the model was parsed from a caller's bytes (fmx_load), not built here: its image is validated
     std::vector<uint8_t> blob;   // host image (empty for attached device blobs)
     fmx::BlobHeader hdr;         // host copy of the header
     void *d_blob = nullptr;
@@ -110,63 +111,14 @@ int ensure_blob(fmx_index *idx) {
     int rc = idx->rrr_only ? fmx::flatten_rrr_only(idx->model.sampled, idx->blob, err)
                            : fmx::flatten_model(idx->model, idx->blob, err);
     if (rc) return fail(rc == -3 ? FMX_E_FORMAT : FMX_E_UNSUPPORTED, err);
+    // validate_model is about the stream's shapes; the image's own invariants (every mapping entry, skip pointer, path and
+    // node record, sample and count inside its table) are what the kernels rely on: an image made from a caller's bytes has
+    // to pass them too before any kernel may walk it (tests/cpp/fuzz_load.cpp)
+    if (idx->from_stream && !idx->rrr_only && fmx::validate_blob(idx->blob.data(), idx->blob.size(), err)) {
+        idx->blob.clear();
+        return fail(FMX_E_FORMAT, err);
+    }
     memcpy(&idx->hdr, idx->blob.data(), sizeof(fmx::BlobHeader));
-    return FMX_OK;
-}
-
-// structural checks before any kernel may walk the image (a kernel fault can take the GPU down)
-int validate_model(const fmx::FmModel &m, std::string &err) {
-    using namespace fmx;
-    auto bad = [&](const char *what) {
-        err = std::string("index fails validation: ") + what;
-        return FMX_E_FORMAT;
-    };
-    auto check_rrr = [&](const RrrModel &r) {
-        if (r.sample_size <= 0 || r.length < 0 || r.classes.width != 4) return false;
-        const int64_t nb = r.length / 15 + (r.length % 15 > 0);
-        if (r.classes.length < nb) return false;
-        if ((int64_t)r.classes.words.size() < words_for_bits((int64_t)r.classes.length * 4)) return false;
-        const int64_t n_rec = r.classes.length / r.sample_size + 1;
-        if (r.sampled_offsets.length < n_rec || r.prefix_sums.length < n_rec) return false;
-        if (r.bits_per_offset_pos < 1 || r.bits_per_offset_pos > 32 || r.prefix_sums.width < 1 || r.prefix_sums.width > 32)
-            return false;
-        if (r.sampled_offsets.width < r.bits_per_offset_pos) return false;
-        const uint64_t total_bits = (uint64_t)r.offsets.size() * 64;
-        for (int64_t k = 0; k < n_rec; ++k)
-            if (r.sampled_offsets.get_bits(k * r.sampled_offsets.width, r.bits_per_offset_pos) > total_bits) return false;
-        return true;
-    };
-    if (m.sample_rate <= 0 || m.length <= 0) return bad("sampleRate / length");
-    if (m.bw_suffixes < 1 || m.bw_suffixes > 32) return bad("bitWidthSuffixes");
-    if (m.enable_extract && (m.bw_positions < 1 || m.bw_positions > 32)) return bad("bitWidthPositions");
-    if (m.look_up.empty() || m.C.size() < m.look_up.size()) return bad("cumulativeCounts / monotonicLookUp sizes");
-    if (m.map_keys.size() != m.map_vals.size()) return bad("monotonicMap keys / values");
-    for (size_t i = 0; i < m.map_vals.size(); ++i) {
-        if (m.map_vals[i] < 0 || (size_t)m.map_vals[i] + 1 >= m.C.size() || (size_t)m.map_vals[i] >= m.look_up.size())
-            return bad("monotonicMap value outside cumulativeCounts");
-        // every code of the map occurs in the BWT, so it is below the wavelet tree's alphabet size (WFBB:133); the
-        // plan stage sizes its sort keys and histogram bins by that alphabet
-        if (m.map_vals[i] >= m.wt.alphabet_size) return bad("monotonicMap value outside the wavelet tree's alphabet");
-        if (m.map_keys[i] < 0 || m.map_keys[i] > 65535) return bad("monotonicMap key is not a char");
-    }
-    if (m.suffixes.width != m.bw_suffixes || m.suffixes.length < m.length / m.sample_rate + 1) return bad("suffixes");
-    if (m.enable_extract && (m.positions.width != m.bw_positions || m.positions.length < m.length / m.sample_rate + 2))
-        return bad("positions");
-    if (m.sampled.length != m.length || !check_rrr(m.sampled)) return bad("sampledSuffixes");
-    const WfbbModel &w = m.wt;
-    if (w.size != m.length || w.alphabet_size <= 0 || w.alphabet_size > 32768) return bad("wavelet size / alphabet");
-    if ((size_t)w.alphabet_size > m.look_up.size() + 1) return bad("wavelet alphabet larger than monotonicLookUp");
-    for (const auto &sb : w.sb) {
-        if (sb.block_size_log < 0 || sb.block_size_log > 20 || sb.sigma < -1) return bad("superblock header");
-        if (!check_rrr(sb.rank_support)) return bad("superblock RRR");
-        for (const auto &bh : sb.block_headers) {
-            if (bh.tree_height < 0 || bh.tree_height > 30 || bh.sigma < 0) return bad("block tree height / sigma");
-            const int64_t sigma = (int64_t)bh.sigma + 1;
-            const int64_t need = (bh.tree_height > 1 ? (bh.tree_height - 1) * 4 : 0) + sigma * 5 + (sigma - 1) * 2;
-            if (bh.var_off < 0 || bh.var_off + need > (int64_t)sb.var.size()) return bad("block header offset");
-            if (bh.bv_offset < 0 || bh.bv_offset > sb.rank_support.length || bh.bv_rank < 0) return bad("block bitvector offset");
-        }
-    }
     return FMX_OK;
 }
 
@@ -525,9 +477,10 @@ int fmx_load(const uint8_t *ser, size_t len, fmx_index **out) {
     int rc = fmx::parse_model(ser, len, idx->model, err);
     if (rc == 2) return fail(FMX_E_VERSION, err);
     if (rc) return fail(FMX_E_FORMAT, err);
-    rc = validate_model(idx->model, err);
+    rc = fmx::validate_model(idx->model, err);
     if (rc) return fail(rc, err);
     idx->has_model = true;
+    idx->from_stream = true;
     *out = idx.release();
     return FMX_OK;
 }
@@ -917,7 +870,10 @@ static int boundary_impl(const fmx_index *idx, const int32_t *d_from, int64_t n,
                          uint16_t *d_dst, int32_t dst_len, int32_t offset, int32_t *d_out_len, int32_t *d_lf_steps,
                          int32_t *d_status, int32_t *d_aux, const int32_t *slot_found, int32_t slots, Scratch &scratch) {
     void *ws = nullptr;
-    const size_t ws_bytes = fmx::boundary_workspace_bytes(idx->dev, n, idx->n_cu);
+    // two windows of sampleRate characters per lane; an index sampled so sparsely that they would take more than 8 GiB is
+    // served by the literal form (no windows) instead of failing on the allocation
+    size_t ws_bytes = fmx::boundary_workspace_bytes(idx->dev, n, idx->n_cu);
+    if (ws_bytes > ((size_t)8 << 30)) ws_bytes = 0;
     int rc = scratch.get(kWsBoundary, ws_bytes, &ws);
     if (rc) return rc;
     int e = fmx::launch_extract_boundary(idx->dev, idx->n_cu, d_from, n, boundary, mode, d_dst, dst_len, offset,

@@ -163,6 +163,13 @@ bool expanded_fill(BvCell *cells, const ExpandJob &job, std::string &err) {
         if (sh + nb > 64) off |= r.offsets[w + 1] << (64 - sh);
         off &= (1ull << nb) - 1ull;
         obits += (uint64_t)nb;
+        // (an offset beyond its class's C(15, class) values: the reference would read a neighbouring class's entry, or
+        // past VALUE_OF_OFFSET — no encoder writes it)
+        const size_t class_end = cls < 15 ? (size_t)class_base[cls + 1] : (size_t)32768;
+        if ((size_t)class_base[cls] + (size_t)off >= class_end) {
+            err = "RRR offset outside its class";
+            return false;
+        }
         const uint64_t value = value_of[(size_t)class_base[cls] + (size_t)off];
         const int64_t pos = b * 15;
         if (pos + 15 > job.n_cells * (int64_t)kBvCellBits) {
@@ -250,6 +257,7 @@ bool build_inverse_block(const uint8_t *var, int64_t var_len, const BlockHeader 
         t.hdr = var + hdr;
         t.second = (uint32_t)second0;
         t.level = 0;
+        t.limit = (uint32_t)(var_len - hdr);
         int32_t left_ones = 0, node_ones = (int32_t)counts0, level_ones = (int32_t)counts0;
         int64_t level_base = 0;  // index of the first internal node of the current level
         int64_t cur = 0;         // the node the walk stands on
@@ -419,7 +427,9 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
     size_t off = A.alloc(m.C.size() * 4 + 8);
     h.off_c = off8(off);
     memcpy(A.at<uint8_t>(off), m.C.data(), m.C.size() * 4);
-    off = A.alloc(m.look_up.size() * 4 + 8);
+    // (zero-padded to the wavelet tree's alphabet + 1: the kernels clamp a symbol to that before they look its character
+    // up, so that a symbol no well-formed tree holds still reads inside the table — fm_char_of)
+    off = A.alloc(std::max(m.look_up.size(), (size_t)w.alphabet_size + 1) * 4 + 8);
     h.off_lookup = off8(off);
     memcpy(A.at<uint8_t>(off), m.look_up.data(), m.look_up.size() * 4);
     off = A.alloc(65536 * 2);
@@ -613,6 +623,7 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
                     t.hdr = var.data() + hdr;
                     t.second = (uint32_t)second0;
                     t.level = 0;
+                    t.limit = (uint32_t)(var_len - hdr);
                     int32_t left_ones = 0, node_ones = (int32_t)counts0, level_ones = (int32_t)counts0;
                     const size_t first_rec = path.size();
                     bool ok = true;
@@ -835,7 +846,7 @@ int validate_blob(const uint8_t *b, size_t len, std::string &err) {
     const int64_t n_samples = (int64_t)h.length / h.sample_rate;
     if (h.n_suffixes < n_samples + 1 || (h.enable_extract && h.n_positions < n_samples + 2)) return bad("sample counts");
     auto packed_bytes = [](int64_t n, int width) { return (uint64_t)(words_for_bits(n * width) + 2) * 8; };
-    if (!inside(h.off_c, (uint64_t)h.n_c * 4) || !inside(h.off_lookup, (uint64_t)h.n_look * 4) ||
+    if (!inside(h.off_c, (uint64_t)h.n_c * 4) || !inside(h.off_lookup, (uint64_t)std::max(h.n_look, h.wt_sigma + 1) * 4) ||
         !inside(h.off_char2code, 65536 * 2) || !inside(h.off_suffixes, packed_bytes(h.n_suffixes, h.bw_suffixes)) ||
         (h.enable_extract && !inside(h.off_positions, packed_bytes(h.n_positions, h.bw_positions))) ||
         !inside(h.off_sbc, (uint64_t)(h.n_sb + 1) * h.wt_sigma * sizeof(SbcEntry)) ||
@@ -852,6 +863,16 @@ int validate_blob(const uint8_t *b, size_t len, std::string &err) {
                inside(r.off_rec, (uint64_t)r.n_rec * sizeof(BvCell));
     };
     if (h.sampled.length != h.length || !cells_ok(h.sampled)) return bad("sampled-row bitmap");
+    {  // rankOnes over this bitmap indexes `suffixes` (FM:541): its running counts must be what its bits say
+        const BvCell *cells = reinterpret_cast<const BvCell *>(b + ((uint64_t)h.sampled.off_rec << 3));
+        uint64_t ones = 0;
+        for (int32_t c = 0; c < h.sampled.n_rec; ++c) {
+            if (cells[c].ones_before != ones) return bad("sampled-row bitmap counts");
+            for (int k = 0; k < 3; ++k) ones += (uint64_t)__builtin_popcount(cells[c].bits[k]);
+        }
+        if (ones != (uint64_t)(uint32_t)h.sampled.total_ones || h.sampled.total_ones < 1 || h.sampled.total_ones > h.n_suffixes)
+            return bad("sampled rows vs suffix samples");
+    }
     if (h.enable_extract) {  // inverse samples are SA rows: the walks start there (FM:579-587)
         const uint32_t *pw = reinterpret_cast<const uint32_t *>(b + ((uint64_t)h.off_positions << 3));
         for (int64_t i = 0; i < h.n_positions; ++i)

@@ -33,7 +33,7 @@
 namespace fmx {
 
 constexpr uint32_t kBlobMagic = 0x31584D46u;  // "FMX1"
-constexpr uint32_t kBlobVersion = 12;
+constexpr uint32_t kBlobVersion = 13;  // 13: monotonicLookUp zero-padded to the alphabet + 1 (fm_char_of)
 
 struct RrrRecord {         // 16 bytes: 16 blocks of 15 bits
     uint32_t ones_before;  // 1-bits in all earlier blocks

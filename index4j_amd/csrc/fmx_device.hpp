@@ -113,7 +113,22 @@ FMX_HD int fmx_popcll(uint64_t v) { return __builtin_popcountll(v); }
 struct Quad {
     uint32_t x, y, z, w;
 };
+#if defined(FMX_DIAG_LINES) && defined(__HIPCC__)
+// Diagnostic build only (tools/k_count_lines.py): which 128-byte lines of the index image each XCD's loads touch.
+__device__ unsigned long long g_diag_base;    // first byte of the image (set by launch_count)
+__device__ unsigned g_diag_lines[8][1 << 19];  // per XCD: one bit per line of the first 2 GiB
+#endif
 FMX_HD Quad ld_quad(const void *p) {
+#if defined(FMX_DIAG_LINES) && defined(__HIP_DEVICE_COMPILE__)
+    {
+        const unsigned long long d = (unsigned long long)p - g_diag_base;
+        if (d < (1ull << 31)) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            atomicOr(&g_diag_lines[xcc & 7][d >> 12], 1u << ((d >> 7) & 31));
+        }
+    }
+#endif
     Quad q;
     memcpy(&q, p, 16);
     return q;
@@ -452,14 +467,19 @@ struct TreeWalk {
     const uint8_t *hdr;     // variable-size header of the block
     uint32_t second;        // offset of the cumulative one-counts of the current level
     uint32_t level;         // offset of the next entry of the level table
+    uint32_t limit;         // bytes of the superblock's header array from `hdr` on (16 guard bytes follow them)
 };
+// Offsets inside a header come out of the header's own entries: on a damaged index they can be anything.  Every read at
+// a computed offset is clamped into the array (a well-formed header never reaches the clamp).
+FMX_HD const uint8_t *hdr_bytes(const uint8_t *hdr, uint32_t limit, uint32_t off) { return hdr + (off < limit ? off : limit); }
+FMX_HD const uint8_t *tree_bytes(const TreeWalk &t, uint32_t off) { return hdr_bytes(t.hdr, t.limit, off); }
 // split in two so that a caller can request these together with other loads and wait once
 FMX_HD void tree_level_counts_load(const TreeWalk &t, uint32_t &raw_pair, uint32_t &raw_level) {
     // entries [left-1, left], or [0, 1] for the leftmost node (entry 1 is then not looked at; the bytes exist:
     // the header ends in guard bytes) — one unconditional 4-byte load
     const int32_t first = t.left_siblings > 0 ? t.left_siblings - 1 : 0;
-    memcpy(&raw_pair, t.hdr + t.second + 2 * first, 4);
-    raw_level = ld16(t.hdr + t.second + 2 * (t.internal_nodes - 1));
+    memcpy(&raw_pair, tree_bytes(t, t.second + 2u * (uint32_t)first), 4);
+    raw_level = ld16(tree_bytes(t, t.second + 2u * (uint32_t)(t.internal_nodes - 1)));
 }
 FMX_HD void tree_level_counts_decode(const TreeWalk &t, uint32_t raw_pair, uint32_t raw_level, int32_t &left_ones,
                                      int32_t &node_ones, int32_t &level_ones) {
@@ -495,7 +515,7 @@ FMX_HD void tree_descend(TreeWalk &t, bool bit, int32_t rank1, int32_t node_ones
 }
 // WFBB:1247-1278: next level's leaf count and total bitvector size (one 4-byte load); returns the leaf count
 FMX_HD int32_t tree_next_level_entry(TreeWalk &t, uint32_t e);
-FMX_HD int32_t tree_next_level(TreeWalk &t) { return tree_next_level_entry(t, ld32u(t.hdr + t.level)); }
+FMX_HD int32_t tree_next_level(TreeWalk &t) { return tree_next_level_entry(t, ld32u(tree_bytes(t, t.level))); }
 // the same step with the level entry already at hand (entries 0..3 travel with the header's first 16 bytes)
 FMX_HD int32_t tree_next_level_entry(TreeWalk &t, uint32_t e) {
     const int32_t next_leaf_count = (int32_t)(e & 0xffffu);
@@ -516,6 +536,12 @@ FMX_HD int32_t tree_next_level_entry(TreeWalk &t, uint32_t e) {
 // The SbcEntry table stores rank + cumulativeCounts[symbol] ("folded"): every LF-step adds C[c] to the rank
 // (FM:469-470, 534-535), and with the sum in the table that is one load less per step.  wt_rank_folded returns
 // C[symbol] + rank; wt_rank (the reference's value) subtracts it again for callers outside the FM-index.
+// monotonicLookUp[c] (FM:105) for a symbol inverseSelect reported: the table is zero-padded to wt_sigma + 1 entries in the
+// image and the symbol clamped to that (no well-formed tree reports such a symbol; the reference would throw)
+FMX_HD uint16_t fm_char_of(const DevIndex &ix, int32_t c) {
+    const uint32_t u = (uint32_t)c < (uint32_t)ix.wt_sigma ? (uint32_t)c : (uint32_t)ix.wt_sigma;
+    return (uint16_t)ix.look_up[u];
+}
 FMX_HD int32_t fm_c_or_zero(const DevIndex &ix, int32_t symbol) {
     return (symbol >= 0 && symbol < ix.n_c) ? ix.C[symbol] : 0;
 }
@@ -591,12 +617,13 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
         const int32_t block_c = ntag == kMapSlow ? (int32_t)(nq.x >> 8) : 0;
         const BlockHdr bh = ld_block_hdr(bhs + block_id);
         const int32_t p = bh.var_off + ((int32_t)bh.tree_height - 1) * 4 + block_c * 5 + 2;
-        // the result is only trustworthy if the entry read is the symbol's own
-        if (bh.tree_height == 0 || p < 2 || (int32_t)ld16(var + p - 2) != symbol) suspect = true;
         if (p < 0 || p + 2 >= sd.var_len) {
             status = ST_JAVA_AIOOBE;
+            suspect = true;
             return fm_c_or_zero(ix, symbol);
         }
+        // the result is only trustworthy if the entry read is the symbol's own
+        if (bh.tree_height == 0 || p < 2 || (int32_t)ld16(var + p - 2) != symbol) suspect = true;
         return e.rank + (int32_t)(ld32u(var + p) & 0xffffffu);  // WFBB:1096-1108
     }
 
@@ -643,15 +670,17 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
     const BlockHdr bh = block_hdr_from(bhq);
     const int32_t tree_height = bh.tree_height;
     const uint8_t *hdr = var + bh.var_off;
+    const uint32_t hdr_limit = (uint32_t)(sd.var_len - bh.var_off);  // (>= the header's own size: validate_model / validate_blob)
     const uint32_t second0 = (uint32_t)((tree_height - 1) * 4 + ((int32_t)bh.sigma + 1) * 5);  // WFBB:1177-1182
     int32_t rank_block, code_length, position0;
     uint32_t code, counts0 = 0;
     Quad chunk = {0, 0, 0, 0}, rec_q = {0, 0, 0, 0};
     {
-        const uint8_t *leaves = hdr + (tree_height > 0 ? (tree_height - 1) * 4 : 0);  // WFBB:1119-1121
+        const uint32_t leaves = (uint32_t)(tree_height > 0 ? (tree_height - 1) * 4 : 0);  // WFBB:1119-1121
         position0 = bh.bv_offset + (int32_t)block_index;
         uint64_t leaf;
-        memcpy(&leaf, leaves + 5 * block_c, 8);  // {u16 symbol, u24 rank at block start} + 3 bytes of the next entry
+        // {u16 symbol, u24 rank at block start} + 3 bytes of the next entry
+        memcpy(&leaf, hdr_bytes(hdr, hdr_limit, leaves + 5u * (uint32_t)block_c), 8);
         if (tree_height > 0) {
             chunk = ld_quad(hdr);  // level entries 0..3 (guard bytes cover the tail)
             counts0 = block_hdr_root_ones(bhq);
@@ -662,7 +691,7 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
         FMX_PIN_QUAD(rec_q);
         if ((int32_t)(leaf & 0xffffu) != symbol) {  // WFBB:1123-1130: clamped mapping entry
             ++block_c;
-            leaf = ld64u(leaves + 5 * block_c);
+            leaf = ld64u(hdr_bytes(hdr, hdr_limit, leaves + 5u * (uint32_t)block_c));
         }
         rank_block = (int32_t)((leaf >> 16) & 0xffffffu);                         // WFBB:1132-1138
         if (tree_height == 0) return e.rank + rank_block + (int32_t)block_index;  // WFBB:1141-1146
@@ -684,6 +713,7 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
     t.hdr = hdr;
     t.second = second0;
     t.level = 0;
+    t.limit = hdr_limit;
 
     // WFBB:1185-1279.  Level 0's counts are the single u16 at `second` (no left sibling, one internal node);
     // the counts and the record of level d+1 are requested at the end of level d.
@@ -696,7 +726,7 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
         t.bv_rank += level_ones;
         tree_descend(t, (code & (1u << (code_length - depth - 1))) != 0, rank1, node_ones);
         if (depth + 1 != code_length) {
-            const uint32_t entry = depth < 4 ? quad_entry(chunk, depth) : ld32u(t.hdr + t.level);
+            const uint32_t entry = depth < 4 ? quad_entry(chunk, depth) : ld32u(tree_bytes(t, t.level));
             t.left_siblings -= tree_next_level_entry(t, entry);
             uint32_t raw_pair, raw_level;
             tree_level_counts_load(t, raw_pair, raw_level);
@@ -773,6 +803,7 @@ FMX_HD int32_t wt_inverse_select_reference_route(const DevIndex &ix, uint32_t po
     const BlockHdr bh = block_hdr_from(bhq);
     const int32_t tree_height = bh.tree_height;
     const uint8_t *hdr = var + bh.var_off;
+    const uint32_t hdr_limit = (uint32_t)(ix.sbd[sb_id].var_len - bh.var_off);
     const uint8_t *leaves = hdr + (tree_height > 0 ? (tree_height - 1) * 4 : 0);  // WFBB:1324-1327
     const SbcEntry *row = ix.sbc + (uint64_t)sb_id * (uint32_t)ix.wt_sigma;
     exact_out = true;
@@ -810,6 +841,7 @@ FMX_HD int32_t wt_inverse_select_reference_route(const DevIndex &ix, uint32_t po
     t.hdr = hdr;
     t.second = second0;
     t.level = 0;
+    t.limit = hdr_limit;
 
     // WFBB:1386-1493; level 0's counts are the single u16 at `second`, the loads of level d+1 are requested at
     // the end of level d
@@ -824,7 +856,7 @@ FMX_HD int32_t wt_inverse_select_reference_route(const DevIndex &ix, uint32_t po
         ++code_length;
         tree_descend(t, next_bit, rank1, node_ones);
         if (depth + 1 < tree_height) {
-            const uint32_t entry = depth < 4 ? quad_entry(chunk, depth) : ld32u(t.hdr + t.level);
+            const uint32_t entry = depth < 4 ? quad_entry(chunk, depth) : ld32u(tree_bytes(t, t.level));
             const int32_t next_leaf_count = tree_next_level_entry(t, entry);
             if (t.left_siblings >= next_leaf_count)  // WFBB:1485-1489
                 t.left_siblings -= next_leaf_count;
@@ -851,7 +883,8 @@ FMX_HD int32_t wt_inverse_select_reference_route(const DevIndex &ix, uint32_t po
         temp_code <<= 1;
     }
     block_c += code - temp_code;
-    const uint64_t leaf = ld64u(leaves + 5 * block_c);  // {u16 symbol, u24 rank at block start}, WFBB:1495-1520
+    // {u16 symbol, u24 rank at block start}, WFBB:1495-1520
+    const uint64_t leaf = ld64u(hdr_bytes(hdr, hdr_limit, (uint32_t)(tree_height - 1) * 4u + 5u * block_c));
     const int32_t c = (int32_t)(leaf & 0xffffu);
     rank_out = (c < ix.wt_sigma ? row[c].rank : 0) + (int32_t)((leaf >> 16) & 0xffffffu) + t.node_rank;  // WFBB:1521-1533
     return c;
@@ -937,6 +970,11 @@ FMX_HD int32_t fm_lf_finish(const DevIndex &ix, const uint16_t *inv, int32_t row
 FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, int32_t &c_out, int &status,
                           bool &suspect) {
     const uint32_t p = (uint32_t)(row - 1);
+    if (p >= ix.wt_size) {  // never on a well-formed index (its rows are 1..length); superBlockHeaderItems[superBlockId] would throw (WFBB:1310)
+        status = ST_JAVA_AIOOBE;
+        c_out = 0;
+        return 0;
+    }
     int32_t rank_before;
     int32_t bsl_i;
     bool exact_symbol;
@@ -961,6 +999,9 @@ FMX_HD void fm_seek_after(const DevIndex &ix, int32_t x, int32_t &row, int32_t &
     row = fm_packed_get(ix.pos_words, (int64_t)q + 1, ix.bw_positions) + 1;
     skip = s - x % s;
     if (q == ix.n_positions - 2) skip = ix.length - x;
+    // (the sample after x lies inside the text: on a well-formed index skip <= length - x already; a damaged sample count
+    // must not turn the walk back to x into one of 2^31 steps)
+    if (skip > ix.length - x) skip = ix.length - x;
 }
 
 // ---- suffix table (DevIndex.suffix_table) ---------------------------------------------------------------------
@@ -1027,6 +1068,12 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
     // Every round polls sampledSuffixes.access(j - 1) (FM:531) and, if the row is not sampled, runs
     // inverseSelect(j - 1) (FM:532): the bitmap cell and the block's InvHdr depend on j alone and are requested together.
     Quad scell = {0, 0, 0, 0};
+    // Every sample_rate-th text position is sampled, so a walk takes < sampleRate steps — unless a quirk of the reference
+    // derails it (Q1: a run block's symbol masked to 8 bits sends the walk to another row, from where it goes on to THAT
+    // row's next sample; the reference has no bound at all).  256 such stretches are out of reach for a well-formed index
+    // and still end a walk over a damaged one in milliseconds instead of `length` steps.
+    const int64_t stretches = (int64_t)ix.sample_rate * 256;
+    const int32_t walk_limit = (int32_t)(stretches < 4096 ? 4096 : (stretches < (int64_t)ix.length ? stretches : (int64_t)ix.length));
     for (;;) {
         const int32_t p = j - 1;
         if (p < 0 || p >= sv.length) {  // RrrVector.access throws (RRR:316-323)
@@ -1047,7 +1094,7 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
         const int32_t c = (int32_t)(int16_t)wt_inverse_select_from(ix, (uint32_t)p, v, ihq, rank_before, exact);
         j = fm_lf_finish(ix, inv, j, c, rank_before, v.bsl, exact, status, suspect);  // FM:532-535
         ++distance;
-        if (distance > ix.length) {  // unreachable on a well-formed index; bounds the walk on a corrupt one
+        if (distance > walk_limit) {  // bounds the walk on a damaged index (see walk_limit above)
             status = ST_JAVA_AIOOBE;
             break;
         }
@@ -1057,8 +1104,12 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
     int32_t r;
     if (status == ST_OK)
         r = (int32_t)(scell.x + bv_cell_prefix(scell, (uint32_t)(j - 1) % kBvCellBits));
-    else
+    else {
+        // (a walk that ended in a status — the reference throws — reports no position: the read only has to stay inside
+        // `suffixes`, whose total_ones entries validate_model / validate_blob guarantee; rankOnes saturates at that total)
         r = bv_rank1(ix.base, sv, j) - 1;
+        if (r < 0) r = 0;
+    }
     return fm_packed_get(ix.suffix_words, r, ix.bw_suffixes) + distance;  // FM:538-542
 }
 
@@ -1100,7 +1151,7 @@ FMX_HD int32_t fm_extract(const DevIndex &ix, const uint16_t *inv, int32_t start
                 status = ST_JAVA_AIOOBE;
                 return 0;
             }
-            dest[idx] = (uint16_t)ix.look_up[c];
+            dest[idx] = fm_char_of(ix, c);
             --remaining;
         }
         ++distance;
@@ -1147,7 +1198,7 @@ FMX_HD void boundary_chunk_char(const DevIndex &ix, int mode, int32_t c, int32_t
             r.done = true;
             return;
         }
-        if (writer) dest[w] = (uint16_t)ix.look_up[c];  // FM:738-739
+        if (writer) dest[w] = fm_char_of(ix, c);  // FM:738-739
         --r.up_pos;
     } else if (r.up_pos > 0) {  // range is (from, boundary], FM:899-902
         if (w - 1 < 0) {
@@ -1155,7 +1206,7 @@ FMX_HD void boundary_chunk_char(const DevIndex &ix, int mode, int32_t c, int32_t
             r.done = true;
             return;
         }
-        if (writer) dest[w - 1] = (uint16_t)ix.look_up[c];
+        if (writer) dest[w - 1] = fm_char_of(ix, c);
         --r.up_pos;
     }
 }
@@ -1339,7 +1390,7 @@ FMX_HD int32_t fm_extract_boundary(const DevIndex &ix, const uint16_t *inv, int 
                     status = ST_JAVA_AIOOBE;
                     return 0;
                 }
-                dest[down_pos--] = (uint16_t)ix.look_up[c];  // FM:682
+                dest[down_pos--] = fm_char_of(ix, c);  // FM:682
                 --remaining;
                 if (mode == 1 && down_pos == offset) {  // FM:816-821
                     status = ST_DOES_NOT_FIT;
@@ -1545,7 +1596,7 @@ FMX_HD int32_t fm_extract_boundary_group(const DevIndex &ix, const uint16_t *inv
                 finished = true;
                 break;
             }
-            if (writer) dest[down_pos] = (uint16_t)ix.look_up[c];  // FM:682
+            if (writer) dest[down_pos] = fm_char_of(ix, c);  // FM:682
             --down_pos;
             --remaining;
             if (mode == 1 && down_pos == offset) {  // FM:816-821

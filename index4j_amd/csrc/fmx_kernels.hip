@@ -310,6 +310,29 @@ __device__ __forceinline__ void count_one(const DevIndex &ix, const int16_t *s_m
     }
 }
 
+#if defined(FMX_DIAG_TIMELINE)
+// Diagnostic build only (make EXTRA_DEFS=-DFMX_DIAG_TIMELINE; tools/k_count_timeline.py): when every workgroup of the
+// last k_count launch started and ended (100 MHz wall clock), and where it ran (XCC id, CU id).
+constexpr int kDiagGroups = 8192;
+__device__ unsigned long long g_diag_timeline[3 * kDiagGroups];
+__device__ __forceinline__ void diag_begin() {
+    if (threadIdx.x == 0 && blockIdx.x < kDiagGroups) {
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        g_diag_timeline[3 * blockIdx.x] = wall_clock64();
+        g_diag_timeline[3 * blockIdx.x + 1] = 0;
+        g_diag_timeline[3 * blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hw;
+    }
+}
+__device__ __forceinline__ void diag_end() {
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < kDiagGroups) atomicMax(&g_diag_timeline[3 * blockIdx.x + 1], wall_clock64());
+}
+#else
+__device__ __forceinline__ void diag_begin() {}
+__device__ __forceinline__ void diag_end() {}
+#endif
+
 template <int kBlock, int kMode, int kCodeBits>
 FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__ pat,
                                                   const int32_t *__restrict__ pat_off,
@@ -321,6 +344,7 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
     // kCodeBits: width of a code in the record's word and in the chunks — 8 when the alphabet fits (8 codes per word),
     // else 16 (the plan's alphabet in modes 1 / 2, this index's own in modes 0 / 3)
     constexpr int kPairs = kBlock / 2;
+    diag_begin();
     __shared__ int16_t s_xlat[256];
     __shared__ int16_t s_map[256];  // this index's character map, characters below 256
     constexpr bool planned = kMode != 0;
@@ -340,7 +364,11 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
     const int32_t pairs_per_grid = (int32_t)gridDim.x * kPairs;  // 32-bit indices: n < 2^31, fewer live registers
     // (an XCD-aware block order — a contiguous eighth of the sorted batch per XCD — was measured slower:
     // profiles/r01_i_xcd_remap.txt)
+#if defined(FMX_DIAG_REVERSE)
+    for (int32_t q0 = (int32_t)(gridDim.x - 1 - blockIdx.x) * kPairs; q0 < n; q0 += pairs_per_grid) {
+#else
     for (int32_t q0 = (int32_t)blockIdx.x * kPairs; q0 < n; q0 += pairs_per_grid) {
+#endif
         const int32_t q = q0 + (int32_t)(threadIdx.x >> 1);
         const bool live = q < n;
         int32_t p = q, m = 0;
@@ -392,6 +420,7 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
             }
         }
     }
+    diag_end();
 }
 
 // ---- growing the suffix table (fmx_device.hpp: fm_suffix_extend) when an index becomes resident ----
@@ -1153,6 +1182,12 @@ int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_
         else                                                                                                       \
             FMX_COUNT_LAUNCH(512, MODE, 16);                                                                       \
     } while (0)
+#if defined(FMX_DIAG_LINES)
+    {
+        const unsigned long long base = (unsigned long long)ix.base;
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_diag_base), &base, 8, 0, hipMemcpyHostToDevice, st);
+    }
+#endif
     if (mode == 0)
         FMX_COUNT_MODE(0);
     else if (mode == 1)
@@ -1314,3 +1349,26 @@ int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, i
 }
 
 }  // namespace fmx
+
+#if defined(FMX_DIAG_TIMELINE)
+// (diagnostic builds only; not declared in include/fmx.h) copies {start, end, xcc << 32 | hw id} of the first `groups`
+// workgroups of the last k_count launch
+extern "C" __attribute__((visibility("default"))) int fmx_diag_timeline(unsigned long long *out, int groups) {
+    if (groups > fmx::kDiagGroups) groups = fmx::kDiagGroups;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fmx::g_diag_timeline), (size_t)groups * 24, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
+#if defined(FMX_DIAG_LINES)
+// (diagnostic builds only) out == NULL: clear the bitmaps; else copy them out (8 x 2 MiB)
+extern "C" __attribute__((visibility("default"))) int fmx_diag_lines(unsigned *out) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (!out) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(fmx::g_diag_lines)) != hipSuccess) return -1;
+        return (int)hipMemset(p, 0, sizeof(unsigned) * 8 * (1 << 19));
+    }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fmx::g_diag_lines), sizeof(unsigned) * 8 * (1 << 19), 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -125,6 +125,7 @@ const uint8_t *rrr_bits_needed();       // 16 entries  (BITS_NEEDED_BINOMIAL_COE
 // fmx_serial.cpp
 int parse_model(const uint8_t *buf, size_t len, FmModel &out, std::string &err);
 void emit_model(const FmModel &m, bool framed, std::vector<uint8_t> &out);
+int validate_model(const FmModel &m, std::string &err);  // 0 ok, -3 malformed: run on every parsed stream (fmx_load)
 
 // fmx_blob.cpp
 int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err);

@@ -349,4 +349,60 @@ void emit_model(const FmModel &m, bool framed, std::vector<uint8_t> &out) {
     }
 }
 
+// structural checks on a parsed stream before it is flattened and any kernel may walk the image (a kernel fault can take
+// the GPU down); 0 ok, -3 (FMX_E_FORMAT) malformed.  What the image itself must satisfy: validate_blob.
+int validate_model(const FmModel &m, std::string &err) {
+    auto bad = [&](const char *what) {
+        err = std::string("index fails validation: ") + what;
+        return -3;
+    };
+    auto check_rrr = [&](const RrrModel &r) {
+        if (r.sample_size <= 0 || r.length < 0 || r.classes.width != 4) return false;
+        const int64_t nb = r.length / 15 + (r.length % 15 > 0);
+        if (r.classes.length < nb) return false;
+        if ((int64_t)r.classes.words.size() < words_for_bits((int64_t)r.classes.length * 4)) return false;
+        const int64_t n_rec = r.classes.length / r.sample_size + 1;
+        if (r.sampled_offsets.length < n_rec || r.prefix_sums.length < n_rec) return false;
+        if (r.bits_per_offset_pos < 1 || r.bits_per_offset_pos > 32 || r.prefix_sums.width < 1 || r.prefix_sums.width > 32)
+            return false;
+        if (r.sampled_offsets.width < r.bits_per_offset_pos) return false;
+        const uint64_t total_bits = (uint64_t)r.offsets.size() * 64;
+        for (int64_t k = 0; k < n_rec; ++k)
+            if (r.sampled_offsets.get_bits(k * r.sampled_offsets.width, r.bits_per_offset_pos) > total_bits) return false;
+        return true;
+    };
+    if (m.sample_rate <= 0 || m.length <= 0) return bad("sampleRate / length");
+    if (m.bw_suffixes < 1 || m.bw_suffixes > 32) return bad("bitWidthSuffixes");
+    if (m.enable_extract && (m.bw_positions < 1 || m.bw_positions > 32)) return bad("bitWidthPositions");
+    if (m.look_up.empty() || m.C.size() < m.look_up.size()) return bad("cumulativeCounts / monotonicLookUp sizes");
+    if (m.map_keys.size() != m.map_vals.size()) return bad("monotonicMap keys / values");
+    for (size_t i = 0; i < m.map_vals.size(); ++i) {
+        if (m.map_vals[i] < 0 || (size_t)m.map_vals[i] + 1 >= m.C.size() || (size_t)m.map_vals[i] >= m.look_up.size())
+            return bad("monotonicMap value outside cumulativeCounts");
+        // every code of the map occurs in the BWT, so it is below the wavelet tree's alphabet size (WFBB:133); the
+        // plan stage sizes its sort keys and histogram bins by that alphabet
+        if (m.map_vals[i] >= m.wt.alphabet_size) return bad("monotonicMap value outside the wavelet tree's alphabet");
+        if (m.map_keys[i] < 0 || m.map_keys[i] > 65535) return bad("monotonicMap key is not a char");
+    }
+    if (m.suffixes.width != m.bw_suffixes || m.suffixes.length < m.length / m.sample_rate + 1) return bad("suffixes");
+    if (m.enable_extract && (m.positions.width != m.bw_positions || m.positions.length < m.length / m.sample_rate + 2))
+        return bad("positions");
+    if (m.sampled.length != m.length || !check_rrr(m.sampled)) return bad("sampledSuffixes");
+    const WfbbModel &w = m.wt;
+    if (w.size != m.length || w.alphabet_size <= 0 || w.alphabet_size > 32768) return bad("wavelet size / alphabet");
+    if ((size_t)w.alphabet_size > m.look_up.size() + 1) return bad("wavelet alphabet larger than monotonicLookUp");
+    for (const auto &sb : w.sb) {
+        if (sb.block_size_log < 0 || sb.block_size_log > 20 || sb.sigma < -1) return bad("superblock header");
+        if (!check_rrr(sb.rank_support)) return bad("superblock RRR");
+        for (const auto &bh : sb.block_headers) {
+            if (bh.tree_height < 0 || bh.tree_height > 30 || bh.sigma < 0) return bad("block tree height / sigma");
+            const int64_t sigma = (int64_t)bh.sigma + 1;
+            const int64_t need = (bh.tree_height > 1 ? (bh.tree_height - 1) * 4 : 0) + sigma * 5 + (sigma - 1) * 2;
+            if (bh.var_off < 0 || bh.var_off + need > (int64_t)sb.var.size()) return bad("block header offset");
+            if (bh.bv_offset < 0 || bh.bv_offset > sb.rank_support.length || bh.bv_rank < 0) return bad("block bitvector offset");
+        }
+    }
+    return 0;
+}
+
 }  // namespace fmx

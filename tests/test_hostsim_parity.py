@@ -171,3 +171,22 @@ def test_suffix_table_on_the_host_simulation():
             assert (cnt == oc).all() and (st == ost).all(), k
             assert (lf == plf).all(), k  # per pattern, table or not
             assert 0 < answered < o_steps
+
+
+def test_derailed_locate_walks_run_past_the_sample_rate():
+    """Q1 on an alphabet above 256 codes: a run block reports its symbol masked to 8 bits, the LF-walk of locate() lands on
+    another row and goes on to THAT row's next sample — such a walk takes more than sampleRate steps, and the reference
+    has no bound on it.  The engine's bound against damaged indexes (fm_locate_hit: walk_limit) must not cut it."""
+    n, sr = 1 << 19, 8
+    text = ia.synth_log_multichar(n, 600)
+    h = make_sim(text, sr)
+    o = orc.OracleFmIndex(text, sr, True)
+    rnd = random.Random(5)
+    pats = [text[s:s + rnd.randrange(2, 6)] for s in (rnd.randrange(n - 8) for _ in range(1500))]
+    ch, off = ia.pack_patterns(pats)
+    locs, found, st, lf = h.locate_batch(ch, off, 16, 16)
+    assert (st == 0).all()
+    assert (lf > found * (sr - 1)).sum() > 20  # walks that left their own sample interval
+    for i, p in enumerate(pats):
+        k, l = o.locate(p, max_matches=16, cap=16)
+        assert k == found[i] and (l == locs[i, :k]).all(), i
