@@ -1378,7 +1378,10 @@ int fmx_locate_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *p
     HIP_TRY(d_ws.alloc((size_t)n * 8));
     if (chars) H2D(d_pat.p, pat, chars * 2);
     H2D(d_off.p, pat_off, (size_t)(n + 1) * 4);
-    if (loc_bytes) H2D(d_locs.p, locs, loc_bytes);  // `locations` is in/out: untouched slots keep the caller's values
+    // `locations` is in/out (FM:504: the caller's array; slots beyond the hits keep the caller's values): it travels up and
+    // down whole.  (Bringing the rows back through pinned staging and copying found[i] slots per row instead was measured
+    // slower — 1.23 vs 1.05 ms on configs[2]: profiles/r03_experiments.txt §12.)
+    if (loc_bytes) H2D(d_locs.p, locs, loc_bytes);
     Scratch scratch(idx, nullptr, true);
     rc = locate_impl(idx, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, max_matches, d_locs.as<int32_t>(), loc_cap,
                      d_found.as<int32_t>(), d_lf.as<int32_t>(), d_st.as<int32_t>(), d_ws.as<int32_t>(), scratch);

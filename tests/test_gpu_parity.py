@@ -651,3 +651,32 @@ def test_api_edge_cases():
     bad = np.frombuffer(b"\x07garbage-not-an-index", dtype=np.uint8)
     h = C.c_void_p()
     assert L.fmx_load(bad.ctypes.data, len(bad), C.byref(h)) in (ia._lib.E_VERSION, ia._lib.E_FORMAT)
+
+
+@pytest.mark.gpu
+def test_host_locate_keeps_the_callers_slots_beyond_the_hits():
+    """`locations` of FmIndex.locate is the caller's array (FM:504): slots beyond a pattern's hits keep what they held — also
+    for capped and failing patterns"""
+    rnd = random.Random(4242)
+    text = HD[:120_000]
+    fm = ia.FmIndex(text, 16, True, device=0)
+    o = orc.OracleFmIndex(text, 16, True)
+    t16 = ia.as_chars(text)
+    L = len(t16)
+    pats = [t16[s:s + rnd.randrange(1, 14)] for s in (rnd.randrange(L - 16) for _ in range(400))]
+    pats += [ia.as_chars("zzzzqq"), ia.as_chars(" "), ia.as_chars("INFO"), t16[:1]]
+    ch, off = ia.pack_patterns(pats)
+    off = np.concatenate([off, [off[-1]]]).astype(np.int32)  # plus one EMPTY pattern -> AIOOBE
+    for mm, cap in ((8, 8), (-1, 5), (3, 8), (8, 3)):
+        mine = np.arange(len(pats) + 1, dtype=np.int32)[:, None] * 1000 + np.arange(cap, dtype=np.int32)[None, :] - 5_000_000
+        mine = np.ascontiguousarray(mine)
+        locs, found, st = fm.locate_batch(ch, off, mm, cap, locs=mine)
+        assert locs is mine
+        for i, p in enumerate(pats):
+            keep = i * 1000 + np.arange(cap) - 5_000_000
+            try:
+                n, l = o.locate(p, max_matches=mm, cap=cap)
+                assert st[i] == 0 and found[i] == n and (locs[i, :n] == l).all() and (locs[i, n:] == keep[n:]).all(), (i, mm, cap)
+            except IndexError:
+                assert st[i] == 9 and (locs[i, found[i]:] == keep[found[i]:]).all()
+        assert st[-1] == 9 and found[-1] == 0
