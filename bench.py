@@ -174,7 +174,7 @@ def self_launch(args, argv):
     from a process that may touch the GPU) and exit with its code"""
     import torch
 
-    if not args.dry_run and torch.cuda.device_count() < args.gpus:
+    if not args.dry_run and not args.share_one_gpu and torch.cuda.device_count() < args.gpus:
         log("[bench] --gpus %d but only %d HIP device(s) visible: refusing to print a mislabelled line"
             % (args.gpus, torch.cuda.device_count()))
         return 2
@@ -228,7 +228,7 @@ def attach_everywhere(ctx, fm):
     for form in ([False, True] if ctx.world > 2 else [False]):
         barrier(ctx)
         t0 = time.time()
-        got = broadcast_blob(ctx.dist, host, ctx.dev, fan_out=form)
+        got = broadcast_blob(ctx.dist, host, ctx.cdev, fan_out=form)
         barrier(ctx)
         times["fan_out_s" if form else "broadcast_s"] = time.time() - t0
         if buf is not None and not bool((buf == got).all()):
@@ -240,6 +240,7 @@ def attach_everywhere(ctx, fm):
         log("[bench] index image %.1f MB to %d rank(s): %s" % (buf.numel() / 1e6, ctx.world, times))
     if ctx.dry:
         return None, buf, buf.numel()
+    buf = buf.to(ctx.dev)
     q = ia.FmIndex.attach_device_blob(buf.data_ptr(), buf.numel(), ctx.local_rank)
     return q, buf, buf.numel()
 
@@ -254,7 +255,7 @@ def hand_out_patterns(ctx, pat_host, m, total):
     if ctx.dist is None:
         t = torch.from_numpy(rows.reshape(total, 2 * m)).to(ctx.dev)
     else:
-        t = scatter_rows(ctx.dist, rows, 2 * m, total, ctx.dev, torch.uint8)
+        t = scatter_rows(ctx.dist, rows, 2 * m, total, ctx.cdev, torch.uint8).to(ctx.dev)
         lo, hi = shard_range(total, ctx.world, ctx.rank)
         assert t.shape[0] == hi - lo
     return t.contiguous().view(torch.int16).reshape(-1)
@@ -415,19 +416,20 @@ def run_count(ctx, args):
     if dist is not None:
         from index4j_amd.shard import ranks_seen
 
-        tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+        cdev = ctx.cdev
+        tw = torch.tensor([wall], dtype=torch.float64, device=cdev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
         if overlapped:
-            tw2 = torch.tensor([overlapped["wall_s_this_rank"]], dtype=torch.float64, device=dev)
+            tw2 = torch.tensor([overlapped["wall_s_this_rank"]], dtype=torch.float64, device=cdev)
             dist.all_reduce(tw2, op=dist.ReduceOp.MAX)
             overlapped["wall_s_this_rank"] = float(tw2.item())
-        tot = torch.tensor([lf_local, lf_exec_local], dtype=torch.int64, device=dev)
+        tot = torch.tensor([lf_local, lf_exec_local], dtype=torch.int64, device=cdev)
         dist.all_reduce(tot)
         lf_total, lf_exec_total = int(tot[0].item()), int(tot[1].item())
-        seen = ranks_seen(dist, dev, ctx.local_rank, ctx.local_rank if not ctx.dry else -1)
+        seen = ranks_seen(dist, cdev, ctx.local_rank, ctx.local_rank if not ctx.dry else -1)
         # final gather of the shards' results on rank 0 (outside the timed region: the shards are independent)
-        gathered = gather_concat(dist, d_cnt[0], [n] * world, dev)
+        gathered = gather_concat(dist, d_cnt[0], [n] * world, cdev)
     else:
         lf_total, lf_exec_total = lf_local, lf_exec_local
     # At N > 1 the same launch also measures BASELINE.json configs[4] (the 8M-pattern batch over the 2 GiB text's 8
@@ -626,6 +628,8 @@ def run_count(ctx, args):
     }
     if ctx.dry:
         out["dry_run"] = True
+    if getattr(ctx, "shared", False):
+        out["rehearsal"] = "N ranks sharing ONE GPU, collectives over gloo on host tensors: checks the N > 1 code path end to end, measures nothing"
     return out
 
 
@@ -848,7 +852,7 @@ def run_segments(ctx, args):
         texts = workload.segment_texts(K, args.segment_log2)
         fms = [ia.FmIndex(t, args.sample_rate, True, device=None, build_device=None if ctx.dry else ctx.local_rank) for t in texts]
         log("[bench] %d segment indexes (%d chars) built in %.1fs" % (K, sum(len(t) for t in texts), time.time() - t0))
-    bases = torch.zeros(K, dtype=torch.int64, device=dev)
+    bases = torch.zeros(K, dtype=torch.int64, device=ctx.cdev)
     if ctx.rank == 0:
         bases.copy_(torch.from_numpy(workload.segment_bases(texts)))
     if dist is not None:
@@ -862,7 +866,9 @@ def run_segments(ctx, args):
             segs.append(fms[s])
             image_bytes += len(fms[s].blob())
         else:
-            buf = broadcast_blob(dist, fms[s].blob() if ctx.rank == 0 else None, dev)
+            buf = broadcast_blob(dist, fms[s].blob() if ctx.rank == 0 else None, ctx.cdev)
+            if not ctx.dry:
+                buf = buf.to(dev)
             bufs.append(buf)
             image_bytes += buf.numel()
             if not ctx.dry:
@@ -930,17 +936,17 @@ def run_segments(ctx, args):
             e1.record(stream)
             torch.cuda.synchronize()
             stage_ms[name] = e0.elapsed_time(e1) / max(1, args.steps // 4)
-    sums = torch.tensor([int(d_cnt.sum().item()), int(d_found.sum().item()), lf_local], dtype=torch.int64, device=dev)
+    sums = torch.tensor([int(d_cnt.sum().item()), int(d_found.sum().item()), lf_local], dtype=torch.int64, device=ctx.cdev)
     seen = [[0, ctx.local_rank, ctx.local_rank]]
     head = None
     if dist is not None:
-        tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+        tw = torch.tensor([wall], dtype=torch.float64, device=ctx.cdev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
         dist.all_reduce(sums)
-        seen = ranks_seen(dist, dev, ctx.local_rank, ctx.local_rank if not ctx.dry else -1)
+        seen = ranks_seen(dist, ctx.cdev, ctx.local_rank, ctx.local_rank if not ctx.dry else -1)
         sizes = [shard_range(total, world, r)[1] - shard_range(total, world, r)[0] for r in range(world)]
-        head = gather_concat(dist, d_cnt, sizes, dev, dtype=torch.int64)  # the final gather (counts; hits stay sharded)
+        head = gather_concat(dist, d_cnt, sizes, ctx.cdev, dtype=torch.int64)  # the final gather (counts; hits stay sharded)
     if ctx.rank != 0:
         return None
     if len(seen) != args.gpus or sorted(r[0] for r in seen) != list(range(args.gpus)):
@@ -1066,6 +1072,8 @@ def run_segments(ctx, args):
     }
     if ctx.dry:
         out["dry_run"] = True
+    if getattr(ctx, "shared", False):
+        out["rehearsal"] = "N ranks sharing ONE GPU, collectives over gloo on host tensors: checks the N > 1 code path end to end, measures nothing"
     for f in segs:
         if not ctx.dry and dist is not None:
             f.close()
@@ -1100,6 +1108,9 @@ def main():
                          "table, two batches in flight), so that per-kernel averages and counters describe the timed path only")
     ap.add_argument("--overlap-streams", type=int, default=2,
                     help="streams of the extra `overlapped` measurement (batches in flight); 1 = skip it")
+    ap.add_argument("--share-one-gpu", action="store_true",
+                    help="REHEARSAL of the N > 1 code path on a one-GPU box: every rank queries on cuda:0, collectives run "
+                         "over gloo on host tensors.  The line says so (`rehearsal`); it is not a measurement.")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU-only rehearsal of the launch / broadcast / shard / gather plumbing over gloo: no queries, no numbers")
     ap.add_argument("--cache-dir", default=os.environ.get("FMX_CACHE", "/tmp/fmx_cache"))
@@ -1126,16 +1137,21 @@ def main():
             raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
         if ctx.local_rank >= torch.cuda.device_count():  # launcher that gives every rank its own visible-device mask
             ctx.local_rank = 0
+        if args.share_one_gpu:
+            ctx.local_rank = 0
         torch.cuda.set_device(ctx.local_rank)
         ctx.dev = torch.device("cuda", ctx.local_rank)
     else:
         ctx.dev = torch.device("cpu")
+    # where collectives' tensors live: the device (RCCL), or the host in the rehearsal forms (gloo)
+    ctx.cdev = torch.device("cpu") if (ctx.dry or args.share_one_gpu) else ctx.dev
+    ctx.shared = bool(args.share_one_gpu)
     ctx.dist = None
     if launched:  # also at WORLD_SIZE 1: the same RCCL code path (broadcast, scatter, attach, gather) as at 8
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if ctx.dry:
+        if ctx.dry or args.share_one_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=ctx.dev)
