@@ -1,0 +1,29 @@
+"""The N > 1 form of bench.py with real kernels on ONE GPU: two ranks share cuda:0, collectives run over gloo on host
+tensors (`--share-one-gpu`).  Checks what the CPU rehearsal (tests/test_dist_gloo.py, --dry-run) cannot: image broadcast ->
+fmx_attach_device_blob, pattern shards, every rank's kernels, max-over-ranks timing, the gathered counts, and the
+configs[4] line a multi-GPU launch carries in `secondary`.  The numbers of such a run mean nothing and are not looked at."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_run_the_whole_multi_gpu_path():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-one-gpu", "--steps", "4", "--warmup", "1",
+           "--cpu-budget", "0.5", "--text-log2", "24", "--segment-log2", "22", "--patterns-total", "1048576",
+           "--segments-check", "2000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-4000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and sorted(x[0] for x in line["ranks_seen"]) == [0, 1] and "rehearsal" in line
+    assert line["scaling"] == "weak" and line["value"] > 0
+    seg = [s for s in line["secondary"] if s.get("scaling") == "strong"]
+    assert len(seg) == 1 and seg[0]["n_gpus"] == 2 and seg[0]["roofline"] and seg[0]["cpu_baseline"]
+    assert seg[0]["config"]["patterns_checked_vs_oracle"] > 0
