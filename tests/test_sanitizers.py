@@ -33,6 +33,6 @@ def test_damaged_streams_and_images_never_leave_their_tables(tmp_path):
     cmd += ["-lpthread", "-o", exe]
     subprocess.check_call(cmd)
     for seed in (1, 2):
-        r = subprocess.run([exe, "450", str(seed)], capture_output=True, text=True, timeout=900)
+        r = subprocess.run([exe, "1200", str(seed)], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "ERROR" not in r.stderr and "HANG" not in r.stderr, r.stdout[-2000:] + r.stderr[-6000:]
         assert r.stdout.startswith("fuzz ok:"), r.stdout
