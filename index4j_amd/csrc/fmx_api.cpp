@@ -108,8 +108,14 @@ int ensure_blob(fmx_index *idx) {
     if (!idx->blob.empty()) return FMX_OK;
     if (!idx->has_model) return fail(FMX_E_ARG, "index has neither a model nor a host blob");
     std::string err;
-    int rc = idx->rrr_only ? fmx::flatten_rrr_only(idx->model.sampled, idx->blob, err)
+    int rc;
+    try {
+        rc = idx->rrr_only ? fmx::flatten_rrr_only(idx->model.sampled, idx->blob, err)
                            : fmx::flatten_model(idx->model, idx->blob, err);
+    } catch (const std::exception &e) {  // (an image this host cannot hold: the ABI does not throw)
+        idx->blob.clear();
+        return fail(FMX_E_UNSUPPORTED, std::string("flattening the index: ") + e.what());
+    }
     if (rc) return fail(rc == -3 ? FMX_E_FORMAT : FMX_E_UNSUPPORTED, err);
     // validate_model is about the stream's shapes; the image's own invariants (every mapping entry, skip pointer, path and
     // node record, sample and count inside its table) are what the kernels rely on: an image made from a caller's bytes has
@@ -474,7 +480,12 @@ int fmx_load(const uint8_t *ser, size_t len, fmx_index **out) {
     if (!out || !ser) return fail(FMX_E_ARG, "null argument");
     std::unique_ptr<fmx_index> idx(new fmx_index());
     std::string err;
-    int rc = fmx::parse_model(ser, len, idx->model, err);
+    int rc;
+    try {
+        rc = fmx::parse_model(ser, len, idx->model, err);
+    } catch (const std::exception &e) {
+        return fail(FMX_E_FORMAT, std::string("reading the stream: ") + e.what());
+    }
     if (rc == 2) return fail(FMX_E_VERSION, err);
     if (rc) return fail(FMX_E_FORMAT, err);
     rc = fmx::validate_model(idx->model, err);

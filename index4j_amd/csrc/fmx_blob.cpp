@@ -387,6 +387,36 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
         return -8;
     }
     blob.clear();
+    // every superblock's own table shape first (WFBB:461-471: superBlockSigma x blocks per superblock entries): what is laid
+    // out and reserved below is then bounded by what the model itself holds, whatever a damaged header field says
+    for (int64_t s = 0; s < n_sb; ++s) {
+        const SuperBlockModel &sb = w.sb[(size_t)s];
+        const int bsl = sb.block_size_log;
+        if (bsl < 0 || bsl > 20 || sb.sigma < -1 || (int64_t)sb.mapping.size() != ((int64_t)sb.sigma + 1) << (20 - bsl)) {
+            err = "superblock mapping shape mismatch";
+            return -3;
+        }
+        if (sb.rank_support.length < 0 || sb.rank_support.length > (int64_t)15 * sb.rank_support.classes.length + 15) {
+            err = "superblock bit vector longer than its RRR blocks";
+            return -3;
+        }
+    }
+    if (m.sampled.length < 0 || m.sampled.length > (int64_t)15 * m.sampled.classes.length + 15) {
+        err = "sampled-row bitmap longer than its RRR blocks";
+        return -3;
+    }
+    // mapping rows by global symbol (rows of symbols a superblock does not hold are pure skip pointers)
+    const int map_mode = g_map_by_symbol;
+    bool by_symbol = map_mode > 0;
+    if (map_mode < 0) {  // automatic: rows by symbol unless that more than doubles the tables
+        int64_t rows_by_code = 0, rows_by_symbol = 0;
+        for (int64_t s = 0; s < n_sb; ++s) {
+            const int bsl = w.sb[(size_t)s].block_size_log;
+            rows_by_code += ((int64_t)w.sb[(size_t)s].sigma + 1) << (20 - bsl);
+            rows_by_symbol += (int64_t)sigma << (20 - bsl);
+        }
+        by_symbol = rows_by_symbol <= 2 * rows_by_code;
+    }
     {
         // ONE allocation for the whole image (an upper bound): the arena never moves — the cell decoders below run while
         // this thread still appends tables — and no page is touched twice by a reallocation
@@ -397,8 +427,8 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
         for (int64_t s = 0; s < n_sb; ++s) {
             const SuperBlockModel &sb = w.sb[(size_t)s];
             const int bsl = sb.block_size_log;
-            const size_t per_row = (bsl >= 0 && bsl <= 20) ? ((size_t)1 << (20 - bsl)) : 0;
-            const size_t rows = (size_t)std::max<int64_t>(sigma, (int64_t)sb.sigma + 1);  // either row layout
+            const size_t per_row = (size_t)1 << (20 - bsl);
+            const size_t rows = by_symbol ? (size_t)sigma : (size_t)((int64_t)sb.sigma + 1);
             bound += rows * per_row * sizeof(MapEntry) + sb.var.size() * 32 + sb.block_headers.size() * 64 +
                      cells_bytes(sb.rank_support) + 4096;
         }
@@ -462,19 +492,6 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
             A.at<SbcEntry>(off)[s * sigma + c] = e;
         }
 
-    // mapping rows by global symbol (rows of symbols a superblock does not hold are pure skip pointers)
-    const int map_mode = g_map_by_symbol;
-    bool by_symbol = map_mode > 0;
-    if (map_mode < 0) {  // automatic: rows by symbol unless that more than doubles the tables
-        int64_t rows_by_code = 0, rows_by_symbol = 0;
-        for (int64_t s = 0; s < n_sb; ++s) {
-            const int bsl = w.sb[(size_t)s].block_size_log;
-            if (bsl < 0 || bsl > 20) continue;
-            rows_by_code += ((int64_t)w.sb[(size_t)s].sigma + 1) << (20 - bsl);
-            rows_by_symbol += (int64_t)sigma << (20 - bsl);
-        }
-        by_symbol = rows_by_symbol <= 2 * rows_by_code;
-    }
     h.map_by_symbol = by_symbol ? 1 : 0;
     const size_t sbd_off = A.alloc((size_t)n_sb * sizeof(SbDesc));
     h.off_sbdesc = off8(sbd_off);
