@@ -375,6 +375,19 @@ struct Scratch {
 
 }  // namespace
 
+// The ABI never throws (an exception crossing into a JVM through JNI aborts it): every entry point that returns a status runs
+// inside this guard.  What can throw in here: allocations sized by the caller's data, thread creation.
+template <class F>
+static int guarded(F &&body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(FMX_E_UNSUPPORTED, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(FMX_E_UNSUPPORTED, std::string("internal error: ") + e.what());
+    }
+}
+
 extern "C" {
 
 const char *fmx_last_error(void) { return g_err.c_str(); }
@@ -385,6 +398,7 @@ void fmx_release_scratch(void) {
 }
 
 int fmx_set_option(const char *name, int value) {
+    return guarded([&]() -> int {
     if (name && !strcmp(name, "sb_cache_limit")) {
         if (value < 0 || value > 320) return fail(FMX_E_ARG, "bad value");
         g_sb_cache_limit = value;
@@ -433,15 +447,19 @@ int fmx_set_option(const char *name, int value) {
     }
     if (!name || fmx::set_option(name, value)) return fail(FMX_E_ARG, "unknown option or bad value");
     return FMX_OK;
+    });
 }
 
 int fmx_device_count(void) {
+    return guarded([&]() -> int {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+    });
 }
 
 int fmx_build(const uint16_t *text, int32_t n, int32_t sample_rate, int enable_extract, fmx_index **out) {
+    return guarded([&]() -> int {
     if (!out || (!text && n > 0)) return fail(FMX_E_ARG, "null argument");
     std::unique_ptr<fmx_index> idx(new fmx_index());
     std::string err;
@@ -451,10 +469,12 @@ int fmx_build(const uint16_t *text, int32_t n, int32_t sample_rate, int enable_e
     idx->has_model = true;
     *out = idx.release();
     return FMX_OK;
+    });
 }
 
 int fmx_build_on_device(const uint16_t *text, int32_t n, int32_t sample_rate, int enable_extract, int device,
                         fmx_index **out, int32_t *rounds, int64_t *rows_sorted, double *stage_seconds) {
+    return guarded([&]() -> int {
     if (!out || (!text && n > 0) || device < 0) return fail(FMX_E_ARG, "bad arguments");
     std::unique_ptr<fmx_index> idx(new fmx_index());
     std::string err;
@@ -472,11 +492,13 @@ int fmx_build_on_device(const uint16_t *text, int32_t n, int32_t sample_rate, in
     idx->has_model = true;
     *out = idx.release();
     return FMX_OK;
+    });
 }
 
 double fmx_build_wavelet_seconds(const fmx_index *idx) { return idx ? idx->wavelet_device_seconds : 0.0; }
 
 int fmx_load(const uint8_t *ser, size_t len, fmx_index **out) {
+    return guarded([&]() -> int {
     if (!out || !ser) return fail(FMX_E_ARG, "null argument");
     std::unique_ptr<fmx_index> idx(new fmx_index());
     std::string err;
@@ -494,9 +516,11 @@ int fmx_load(const uint8_t *ser, size_t len, fmx_index **out) {
     idx->from_stream = true;
     *out = idx.release();
     return FMX_OK;
+    });
 }
 
 int fmx_save(const fmx_index *idx, int framed, uint8_t **buf, size_t *len) {
+    return guarded([&]() -> int {
     if (!idx || !buf || !len) return fail(FMX_E_ARG, "null argument");
     if (!idx->has_model || idx->wavelet_only || idx->rrr_only)
         return fail(FMX_E_ARG, "nothing to serialize (device-attached or wavelet-only handle)");
@@ -508,6 +532,7 @@ int fmx_save(const fmx_index *idx, int framed, uint8_t **buf, size_t *len) {
     *buf = p;
     *len = out.size();
     return FMX_OK;
+    });
 }
 
 void fmx_free_buffer(uint8_t *buf) { free(buf); }
@@ -649,13 +674,16 @@ static void build_suffix_table(fmx_index *idx) {
 }
 
 int fmx_suffix_table_info(const fmx_index *idx, int32_t *chars, int64_t *bytes) {
+    return guarded([&]() -> int {
     if (!idx) return fail(FMX_E_ARG, "null index");
     if (chars) *chars = idx->dev.suffix_table ? idx->dev.suffix_chars : 0;
     if (bytes) *bytes = (int64_t)idx->suffix_table_bytes;
     return FMX_OK;
+    });
 }
 
 int fmx_blob(const fmx_index *idx_c, const uint8_t **blob, size_t *len) {
+    return guarded([&]() -> int {
     fmx_index *idx = const_cast<fmx_index *>(idx_c);
     if (!idx || !blob || !len) return fail(FMX_E_ARG, "null argument");
     int rc = ensure_blob(idx);
@@ -663,9 +691,11 @@ int fmx_blob(const fmx_index *idx_c, const uint8_t **blob, size_t *len) {
     *blob = idx->blob.data();
     *len = idx->blob.size();
     return FMX_OK;
+    });
 }
 
 int fmx_to_device(fmx_index *idx, int device) {
+    return guarded([&]() -> int {
     if (!idx) return fail(FMX_E_ARG, "null index");
     int rc = ensure_blob(idx);
     if (rc) return rc;
@@ -688,9 +718,11 @@ int fmx_to_device(fmx_index *idx, int device) {
     make_dev_index(idx);
     build_suffix_table(idx);
     return FMX_OK;
+    });
 }
 
 int fmx_attach_device_blob(void *device_blob, size_t len, int device, fmx_index **out) {
+    return guarded([&]() -> int {
     if (!device_blob || !out || len < sizeof(fmx::BlobHeader)) return fail(FMX_E_ARG, "bad blob");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(FMX_E_NO_DEVICE, "no HIP device visible");
@@ -721,19 +753,24 @@ int fmx_attach_device_blob(void *device_blob, size_t len, int device, fmx_index 
     build_suffix_table(idx.get());
     *out = idx.release();
     return FMX_OK;
+    });
 }
 
 // Pins a long-lived host buffer of the caller (a direct ByteBuffer of the Java shim, a numpy array) so that the
 // host-buffer entry points move it by DMA without staging copies.
 int fmx_host_register(void *p, size_t bytes) {
+    return guarded([&]() -> int {
     if (!p || bytes == 0) return fail(FMX_E_ARG, "bad arguments");
     HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
     return FMX_OK;
+    });
 }
 int fmx_host_unregister(void *p) {
+    return guarded([&]() -> int {
     if (!p) return fail(FMX_E_ARG, "bad arguments");
     HIP_TRY(hipHostUnregister(p));
     return FMX_OK;
+    });
 }
 
 void *fmx_device_blob(const fmx_index *idx, size_t *len) {
@@ -779,6 +816,7 @@ static int plan_order(const fmx_index *idx, const uint16_t *d_pat, const int32_t
 
 int fmx_count_plan_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
                        const void **d_plan, void *stream) {
+    return guarded([&]() -> int {
     int rc = require_device(idx);
     if (rc) return rc;
     if (n < 0 || !d_plan || (n > 0 && !d_pat_off)) return fail(FMX_E_ARG, "bad arguments");
@@ -794,10 +832,12 @@ int fmx_count_plan_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_
     }
     *d_plan = plan.plan.recs;
     return FMX_OK;
+    });
 }
 
 int fmx_count_ordered_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, const void *d_plan,
                           int32_t n, int32_t *d_counts, int32_t *d_lf_steps, int32_t *d_status, void *stream) {
+    return guarded([&]() -> int {
     int rc = require_device(idx);
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!d_pat_off || !d_counts))) return fail(FMX_E_ARG, "bad arguments");
@@ -813,6 +853,7 @@ int fmx_count_ordered_dev(const fmx_index *idx, const uint16_t *d_pat, const int
                               nullptr, static_cast<hipStream_t>(stream));
     if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
     return FMX_OK;
+    });
 }
 
 static int count_impl(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n, int32_t *d_counts,
@@ -831,8 +872,10 @@ static int count_impl(const fmx_index *idx, const uint16_t *d_pat, const int32_t
 
 int fmx_count_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
                         int32_t *d_counts, int32_t *d_lf_steps, int32_t *d_status, void *stream) {
+    return guarded([&]() -> int {
     Scratch scratch(idx, stream, false);
     return count_impl(idx, d_pat, d_pat_off, n, d_counts, d_lf_steps, d_status, scratch);
+    });
 }
 
 static int locate_impl(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
@@ -859,14 +902,17 @@ static int locate_impl(const fmx_index *idx, const uint16_t *d_pat, const int32_
 int fmx_locate_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
                          int32_t max_matches, int32_t *d_locs, int32_t loc_cap, int32_t *d_found,
                          int32_t *d_lf_steps, int32_t *d_status, int32_t *d_range_ws, void *stream) {
+    return guarded([&]() -> int {
     Scratch scratch(idx, stream, false);
     return locate_impl(idx, d_pat, d_pat_off, n, max_matches, d_locs, loc_cap, d_found, d_lf_steps, d_status, d_range_ws,
                        scratch);
+    });
 }
 
 int fmx_extract_batch_dev(const fmx_index *idx, const int32_t *d_start, const int32_t *d_stop, int32_t n,
                           uint16_t *d_dst, int32_t dst_len, int32_t offset, int32_t *d_out_len, int32_t *d_lf_steps,
                           int32_t *d_status, void *stream) {
+    return guarded([&]() -> int {
     int rc = require_device(idx);
     if (rc) return rc;
     if (n < 0 || dst_len < 0 || (n > 0 && (!d_start || !d_stop || !d_out_len || (!d_dst && dst_len > 0))))
@@ -875,6 +921,7 @@ int fmx_extract_batch_dev(const fmx_index *idx, const int32_t *d_start, const in
                                 d_status, nullptr, 0, 0, static_cast<hipStream_t>(stream));
     if (e) return fail(FMX_E_HIP, std::string("k_extract launch: ") + hipGetErrorString((hipError_t)e));
     return FMX_OK;
+    });
 }
 
 static int boundary_impl(const fmx_index *idx, const int32_t *d_from, int64_t n, uint16_t boundary, int mode,
@@ -897,6 +944,7 @@ static int boundary_impl(const fmx_index *idx, const int32_t *d_from, int64_t n,
 int fmx_extract_boundary_batch_dev(const fmx_index *idx, const int32_t *d_from, int32_t n, uint16_t boundary, int mode,
                                    uint16_t *d_dst, int32_t dst_len, int32_t offset, int32_t *d_out_len,
                                    int32_t *d_lf_steps, int32_t *d_status, int32_t *d_aux, void *stream) {
+    return guarded([&]() -> int {
     int rc = require_device(idx);
     if (rc) return rc;
     if (n < 0 || dst_len < 0 || mode < 0 || mode > 2 || (n > 0 && (!d_from || !d_out_len || (!d_dst && dst_len > 0))))
@@ -904,6 +952,7 @@ int fmx_extract_boundary_batch_dev(const fmx_index *idx, const int32_t *d_from, 
     Scratch scratch(idx, stream, false);
     return boundary_impl(idx, d_from, n, boundary, mode, d_dst, dst_len, offset, d_out_len, d_lf_steps, d_status, d_aux,
                          nullptr, 0, scratch);
+    });
 }
 
 // ---- locate -> extract pipelines: the hit positions stay in HBM between the two stages ----
@@ -937,9 +986,11 @@ int fmx_locate_extract_batch_dev(const fmx_index *idx, const uint16_t *d_pat, co
                                  int32_t max_matches, int32_t extract_len, int32_t *d_locs, int32_t *d_found,
                                  uint16_t *d_dst, int32_t *d_out_len, int32_t *d_lf_steps, int32_t *d_status,
                                  int32_t *d_hit_status, int32_t *d_range_ws, void *stream) {
+    return guarded([&]() -> int {
     Scratch scratch(idx, stream, false);
     return locate_extract_impl(idx, d_pat, d_pat_off, n, max_matches, extract_len, d_locs, d_found, d_dst, d_out_len,
                                d_lf_steps, d_status, d_hit_status, d_range_ws, scratch);
+    });
 }
 
 static int locate_lines_impl(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
@@ -964,9 +1015,11 @@ int fmx_locate_lines_batch_dev(const fmx_index *idx, const uint16_t *d_pat, cons
                                int32_t *d_found, uint16_t *d_dst, int32_t *d_out_len, int32_t *d_lf_steps,
                                int32_t *d_status, int32_t *d_hit_status, int32_t *d_hit_aux, int32_t *d_range_ws,
                                void *stream) {
+    return guarded([&]() -> int {
     Scratch scratch(idx, stream, false);
     return locate_lines_impl(idx, d_pat, d_pat_off, n, max_matches, boundary, mode, dst_len, d_locs, d_found, d_dst,
                              d_out_len, d_lf_steps, d_status, d_hit_status, d_hit_aux, d_range_ws, scratch);
+    });
 }
 
 // ---- segment sets ---------------------------------------------------------------------------------
@@ -1007,10 +1060,12 @@ static int count_segments_impl(const fmx_index *const *segs, int32_t n_segs, con
 int fmx_count_segments_dev(const fmx_index *const *segs, int32_t n_segs, const uint16_t *d_pat, const int32_t *d_pat_off,
                            int32_t n, int64_t *d_counts, int64_t *d_lf_steps, int32_t *d_status, int32_t *d_tmp,
                            void *stream) {
+    return guarded([&]() -> int {
     int rc = segments_ok(segs, n_segs);
     if (rc) return rc;
     Scratch scratch(segs[0], stream, false);
     return count_segments_impl(segs, n_segs, d_pat, d_pat_off, n, d_counts, d_lf_steps, d_status, d_tmp, scratch);
+    });
 }
 
 static int locate_segments_impl(const fmx_index *const *segs, int32_t n_segs, const int64_t *seg_base, const uint16_t *d_pat,
@@ -1044,15 +1099,18 @@ static int locate_segments_impl(const fmx_index *const *segs, int32_t n_segs, co
 int fmx_locate_segments_dev(const fmx_index *const *segs, int32_t n_segs, const int64_t *seg_base, const uint16_t *d_pat,
                             const int32_t *d_pat_off, int32_t n, int32_t max_matches, int64_t *d_locs, int32_t *d_found,
                             int32_t *d_status, int32_t *d_tmp, void *stream) {
+    return guarded([&]() -> int {
     int rc = segments_ok(segs, n_segs);
     if (rc) return rc;
     Scratch scratch(segs[0], stream, false);
     return locate_segments_impl(segs, n_segs, seg_base, d_pat, d_pat_off, n, max_matches, d_locs, d_found, d_status, d_tmp,
                                 scratch);
+    });
 }
 
 int fmx_count_segments(const fmx_index *const *segs, int32_t n_segs, const uint16_t *pat, const int32_t *pat_off,
                        int32_t n, int64_t *counts, int64_t *lf_steps, int32_t *status) {
+    return guarded([&]() -> int {
     int rc = segments_ok(segs, n_segs);
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!pat_off || !counts))) return fail(FMX_E_ARG, "bad arguments");
@@ -1079,11 +1137,13 @@ int fmx_count_segments(const fmx_index *const *segs, int32_t n_segs, const uint1
     if (lf_steps) D2H(lf_steps, d_lf.p, (size_t)n * 8);
     if (status) D2H(status, d_st.p, (size_t)n * 4);
     return FMX_OK;
+    });
 }
 
 int fmx_locate_segments(const fmx_index *const *segs, int32_t n_segs, const int64_t *seg_base, const uint16_t *pat,
                         const int32_t *pat_off, int32_t n, int32_t max_matches, int64_t *locs, int32_t *found,
                         int32_t *status) {
+    return guarded([&]() -> int {
     int rc = segments_ok(segs, n_segs);
     if (rc) return rc;
     if (n < 0 || max_matches < 1 || !seg_base || (int64_t)n * max_matches > INT32_MAX ||
@@ -1115,6 +1175,7 @@ int fmx_locate_segments(const fmx_index *const *segs, int32_t n_segs, const int6
     D2H(found, d_found.p, (size_t)n * 4);
     if (status) D2H(status, d_st.p, (size_t)n * 4);
     return FMX_OK;
+    });
 }
 
 // ---- host-buffer entry points --------------------------------------------------------------------
@@ -1181,6 +1242,12 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
     auto drain = [&]() {
         for (int i = 0; i < kPipeStreams; ++i) (void)hipStreamSynchronize(ps->s[i]);
     };
+    struct DrainOnExit {  // declared after the buffers, before the threads: threads are joined, then the streams drained, then
+        PipeStreams *ps;  // the blocks go back to their caches
+        ~DrainOnExit() {
+            for (int i = 0; i < kPipeStreams; ++i) (void)hipStreamSynchronize(ps->s[i]);
+        }
+    } drain_on_exit{ps};
     // chunk b's results: pinned staging -> the caller's arrays, once its stage is done
     auto copy_out = [&](int32_t b) {
         const int32_t blo = bounds[(size_t)b], bhi = bounds[(size_t)b + 1];
@@ -1194,7 +1261,17 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
         if (status) memcpy(status + blo, o_st + blo, (size_t)(bhi - blo) * 4);
     };
     std::atomic<int32_t> copied{0};
+    // (whatever leaves this function — an exception included — first stops and joins its threads: they work on this frame)
+    struct JoinOnExit {
+        std::thread &t;
+        std::atomic<bool> &flag;
+        ~JoinOnExit() {
+            flag = true;
+            if (t.joinable()) t.join();
+        }
+    };
     std::thread helper;
+    JoinOnExit join_helper{helper, stop};
     if (!direct_out) {
         const int device = idx->device;
         helper = std::thread([&, device]() {
@@ -1234,6 +1311,7 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
     std::atomic<int> feed_error{0};
     std::atomic<bool> feed_stop{false};
     std::thread feeder;
+    JoinOnExit join_feeder{feeder, feed_stop};
     if (!in_pinned) {
         const int device = idx->device;
         feeder = std::thread([&, device]() {
@@ -1336,6 +1414,7 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
 
 int fmx_count_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n, int32_t *counts,
                     int32_t *lf_steps, int32_t *status) {
+    return guarded([&]() -> int {
     int rc = require_device(idx);
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!pat_off || !counts))) return fail(FMX_E_ARG, "bad arguments");
@@ -1365,10 +1444,12 @@ int fmx_count_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pa
     if (lf_steps) D2H(lf_steps, d_lf.p, (size_t)n * 4);
     if (status) D2H(status, d_st.p, (size_t)n * 4);
     return FMX_OK;
+    });
 }
 
 int fmx_locate_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n, int32_t max_matches,
                      int32_t *locs, int32_t loc_cap, int32_t *found, int32_t *lf_steps, int32_t *status) {
+    return guarded([&]() -> int {
     int rc = require_device(idx);
     if (rc) return rc;
     if (n < 0 || loc_cap < 0 || (n > 0 && (!pat_off || !found || (!locs && loc_cap > 0))))
@@ -1403,6 +1484,7 @@ int fmx_locate_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *p
     if (lf_steps) D2H(lf_steps, d_lf.p, (size_t)n * 4);
     if (status) D2H(status, d_st.p, (size_t)n * 4);
     return FMX_OK;
+    });
 }
 
 // shared host-buffer driver of the two pipelines (mode < 0: fixed-length extract)
@@ -1469,21 +1551,26 @@ static int locate_pipeline_host(const fmx_index *idx, const uint16_t *pat, const
 int fmx_locate_extract_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n,
                              int32_t max_matches, int32_t extract_len, int32_t *locs, int32_t *found, uint16_t *dst,
                              int32_t *out_len, int32_t *lf_steps, int32_t *status, int32_t *hit_status) {
+    return guarded([&]() -> int {
     return locate_pipeline_host(idx, pat, pat_off, n, max_matches, extract_len, 0, -1, locs, found, dst, out_len,
                                 lf_steps, status, hit_status, nullptr);
+    });
 }
 
 int fmx_locate_lines_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n,
                            int32_t max_matches, uint16_t boundary, int mode, int32_t dst_len, int32_t *locs,
                            int32_t *found, uint16_t *dst, int32_t *out_len, int32_t *lf_steps, int32_t *status,
                            int32_t *hit_status, int32_t *hit_aux) {
+    return guarded([&]() -> int {
     if (mode < 0) return fail(FMX_E_ARG, "bad arguments");
     return locate_pipeline_host(idx, pat, pat_off, n, max_matches, dst_len, boundary, mode, locs, found, dst, out_len,
                                 lf_steps, status, hit_status, hit_aux);
+    });
 }
 
 int fmx_extract_batch(const fmx_index *idx, const int32_t *start, const int32_t *stop, int32_t n, uint16_t *dst,
                       int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf_steps, int32_t *status) {
+    return guarded([&]() -> int {
     int rc = require_device(idx);
     if (rc) return rc;
     if (n < 0 || dst_len < 0 || (n > 0 && (!start || !stop || !out_len || (!dst && dst_len > 0))))
@@ -1510,11 +1597,13 @@ int fmx_extract_batch(const fmx_index *idx, const int32_t *start, const int32_t 
     if (lf_steps) D2H(lf_steps, d_lf.p, (size_t)n * 4);
     if (status) D2H(status, d_st.p, (size_t)n * 4);
     return FMX_OK;
+    });
 }
 
 int fmx_extract_boundary_batch(const fmx_index *idx, const int32_t *from, int32_t n, uint16_t boundary, int mode,
                                uint16_t *dst, int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf_steps,
                                int32_t *status, int32_t *aux) {
+    return guarded([&]() -> int {
     int rc = require_device(idx);
     if (rc) return rc;
     if (n < 0 || dst_len < 0 || mode < 0 || mode > 2 || (n > 0 && (!from || !out_len || (!dst && dst_len > 0))))
@@ -1542,11 +1631,13 @@ int fmx_extract_boundary_batch(const fmx_index *idx, const int32_t *from, int32_
     if (status) D2H(status, d_st.p, (size_t)n * 4);
     if (aux) D2H(aux, d_aux.p, (size_t)n * 4);
     return FMX_OK;
+    });
 }
 
 // ---- WaveletFixedBlockBoosting as a stand-alone structure ------------------------------------------------
 
 int fmx_wavelet_build(const int16_t *sequence, int64_t n, int32_t sampling_rate, fmx_index **out) {
+    return guarded([&]() -> int {
     if (!out || !sequence || n <= 0 || n >= ((int64_t)1 << 31) || sampling_rate <= 0)
         return fail(FMX_E_ARG, n == 0 ? "Input length must be > 0" : "bad arguments");  // WFBB:178-180
     for (int64_t i = 0; i < n; ++i)
@@ -1566,10 +1657,12 @@ int fmx_wavelet_build(const int16_t *sequence, int64_t n, int32_t sampling_rate,
     idx->wavelet_only = true;
     *out = idx.release();
     return FMX_OK;
+    });
 }
 
 // ---- RrrVector as a stand-alone structure (the reference's public class sdsl/RrrVector.java) ----
 int fmx_rrr_build(const uint8_t *bits, int64_t n, int32_t sample_size, fmx_index **out) {
+    return guarded([&]() -> int {
     if (!out || (!bits && n > 0) || n < 0 || n >= ((int64_t)1 << 31) || sample_size <= 0) return fail(FMX_E_ARG, "bad arguments");
     std::vector<uint64_t> words((size_t)(n / 64 + 2), 0);
     for (int64_t i = 0; i < n; ++i)
@@ -1581,9 +1674,11 @@ int fmx_rrr_build(const uint8_t *bits, int64_t n, int32_t sample_size, fmx_index
     idx->rrr_only = true;
     *out = idx.release();
     return FMX_OK;
+    });
 }
 
 int fmx_rrr_rank_ones_batch(const fmx_index *idx, const int32_t *positions, int32_t n, int32_t *ranks) {
+    return guarded([&]() -> int {
     int rc = require_device(idx, true);
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!positions || !ranks))) return fail(FMX_E_ARG, "bad arguments");
@@ -1598,9 +1693,11 @@ int fmx_rrr_rank_ones_batch(const fmx_index *idx, const int32_t *positions, int3
     HIP_TRY(hipDeviceSynchronize());
     D2H(ranks, d_out.p, (size_t)n * 4);
     return FMX_OK;
+    });
 }
 
 int fmx_rrr_access_batch(const fmx_index *idx, const int32_t *positions, int32_t n, uint8_t *bits, int32_t *status) {
+    return guarded([&]() -> int {
     int rc = require_device(idx, true);
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!positions || !bits))) return fail(FMX_E_ARG, "bad arguments");
@@ -1618,6 +1715,7 @@ int fmx_rrr_access_batch(const fmx_index *idx, const int32_t *positions, int32_t
     D2H(bits, d_out.p, (size_t)n);
     if (status) D2H(status, d_st.p, (size_t)n * 4);
     return FMX_OK;
+    });
 }
 
 static int wavelet_batch(const fmx_index *idx, const int64_t *positions, const int32_t *symbols, int32_t n, int64_t *out,
@@ -1651,13 +1749,17 @@ static int wavelet_batch(const fmx_index *idx, const int64_t *positions, const i
 
 int fmx_wavelet_rank_batch(const fmx_index *idx, const int64_t *positions, const int32_t *symbols, int32_t n,
                            int64_t *ranks, int32_t *status) {
+    return guarded([&]() -> int {
     if (n > 0 && !symbols) return fail(FMX_E_ARG, "bad arguments");
     return wavelet_batch(idx, positions, symbols, n, ranks, status);
+    });
 }
 
 int fmx_wavelet_inverse_select_batch(const fmx_index *idx, const int64_t *positions, int32_t n, int64_t *packed,
                                      int32_t *status) {
+    return guarded([&]() -> int {
     return wavelet_batch(idx, positions, nullptr, n, packed, status);
+    });
 }
 
 // ---- helpers ---------------------------------------------------------------------------------------
@@ -1665,6 +1767,7 @@ int fmx_wavelet_inverse_select_batch(const fmx_index *idx, const int64_t *positi
 // FM:239-298 (Java `byte` is signed: the masks below restate the reference's expressions)
 int fmx_convert_byte_pattern(const uint8_t *pattern, int32_t offset, int32_t length, uint16_t *dest,
                              int32_t *bad_value) {
+    return guarded([&]() -> int {
     int pos = offset, i = 0;
     while (pos < length + offset) {
         const int first = (int8_t)pattern[pos];
@@ -1695,6 +1798,7 @@ int fmx_convert_byte_pattern(const uint8_t *pattern, int32_t offset, int32_t len
         dest[i++] = next;
     }
     return i;
+    });
 }
 
 const char *fmx_status_message(int status) {
@@ -1714,9 +1818,11 @@ const char *fmx_status_message(int status) {
 }
 
 int fmx_status_kind(int status) {
+    return guarded([&]() -> int {
     if (status == FMX_ST_DEST_SIZE_ZERO || status == FMX_ST_NO_BOUNDARY) return 1;
     if (status == FMX_ST_JAVA_AIOOBE) return 2;
     return 0;
+    });
 }
 
 }  // extern "C"
