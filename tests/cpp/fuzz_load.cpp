@@ -170,6 +170,12 @@ void query_everything(const std::vector<uint8_t> &blob, const std::vector<uint16
     std::vector<int32_t> counts(n), lf(n), st(n), range(2 * n);
     g_where = "count";
     sim_count(img, pat.data(), off.data(), n, counts.data(), lf.data(), st.data(), range.data());
+    {  // the same batch from a suffix table grown over this image (fm_suffix_extend, fm_suffix_key, fm_suffix_lookup)
+        std::vector<int32_t> c2(n), lf2(n), st2(n);
+        int64_t answered = 0;
+        g_where = "count with a suffix table";
+        (void)sim_count_table(img, h.wt_sigma < 100 ? 3 : 2, pat.data(), off.data(), n, c2.data(), lf2.data(), st2.data(), &answered);
+    }
     // ranges as the kernels may see them: what count left, plus a few arbitrary rows inside [0, length]
     const int32_t rows = h.length + 1;
     for (int q = 0; q < n; q += 3) {
