@@ -987,6 +987,134 @@ FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, 
     return fm_lf_step(ix, inv, row, c_out, status, suspect);
 }
 
+// TWO independent LF-steps of one lane, their loads in flight together (round 3: extractUntilBoundary fetches the sample
+// intervals left and right of a position — two walks that know nothing of each other).  A chain whose flag is off is left
+// alone.  Both chains take the common path jointly — InvHdr, then per level {NodeRec, cell} — so that a level costs ONE round
+// trip for the two of them; whatever leaves that path (a block on the reference's route, a step that crosses a block
+// boundary or meets a quirk) finishes with the very functions fm_lf_step calls.  Same rows, symbols, statuses as two calls.
+struct LfChain {
+    int32_t row;   // in: SA row; out: the row before it in text order
+    int32_t c;     // out: the symbol
+    bool on;
+};
+FMX_HD void fm_lf_step2(const DevIndex &ix, const uint16_t *inv, LfChain &a, LfChain &b, int &status, bool &suspect) {
+    // per chain: p = row - 1, the block's view and InvHdr
+    const uint32_t pa = (uint32_t)(a.row - 1), pb = (uint32_t)(b.row - 1);
+    bool la = a.on, lb = b.on;
+    if (la && pa >= ix.wt_size) {  // as fm_lf_step: a row no well-formed index produces
+        status = ST_JAVA_AIOOBE;
+        a.row = 0;
+        a.c = 0;
+        la = false;
+    }
+    if (lb && pb >= ix.wt_size) {
+        status = ST_JAVA_AIOOBE;
+        b.row = 0;
+        b.c = 0;
+        lb = false;
+    }
+    if (!la && !lb) return;
+    const InvView va = wt_inv_view(ix, la ? pa >> 20 : 0u), vb = wt_inv_view(ix, lb ? pb >> 20 : 0u);
+    Quad iha = {0, 0, 0, 0}, ihb = {0, 0, 0, 0};
+    if (la) iha = ld_quad(wt_inv_hdr_ptr(ix, va, pa));
+    if (lb) ihb = ld_quad(wt_inv_hdr_ptr(ix, vb, pb));
+    FMX_PIN_QUAD(iha);
+    FMX_PIN_QUAD(ihb);
+    int32_t rank_a = 0, rank_b = 0, ca = 0, cb = 0;
+    bool exact_a = true, exact_b = true;
+    // which chains walk node records (the others are answered by their InvHdr, or take the reference's route below)
+    bool wa = la && !(iha.x & (kInvRun | kInvSlow)), wb = lb && !(ihb.x & (kInvRun | kInvSlow));
+    const uint32_t bia = pa & ((1u << va.bsl) - 1u), bib = pb & ((1u << vb.bsl) - 1u);
+    // (a chain that does not walk — its InvHdr holds other things in these fields — reads the section's first record and
+    // the vector's first cell: loads that are issued, never used)
+    const NodeRec *na = reinterpret_cast<const NodeRec *>(ix.base + ((uint64_t)va.rv.off_bits << 3)) + (wa ? iha.z : 0u);
+    const NodeRec *nb = reinterpret_cast<const NodeRec *>(ix.base + ((uint64_t)vb.rv.off_bits << 3)) + (wb ? ihb.z : 0u);
+    uint32_t node_b_a = iha.y, node_b_b = ihb.y;
+    int32_t pos_a = wa ? (int32_t)(iha.x & 0xffffffu) + (int32_t)bia : 0, pos_b = wb ? (int32_t)(ihb.x & 0xffffffu) + (int32_t)bib : 0;
+    int32_t nr_a = (int32_t)bia, nr_b = (int32_t)bib;
+    // Lockstep: the loads of a level — {NodeRec, cell} of both chains — are issued back to back and waited for ONCE; all the
+    // arithmetic of a level sits between that wait and the next four loads.  (Interleaving "use A, load A, use B, load B"
+    // made every use wait for the other chain's fresh loads as well: the two walks ran one after the other.)
+    Quad nqa = {0, 0, 0, 0}, cella = {0, 0, 0, 0}, nqb = {0, 0, 0, 0}, cellb = {0, 0, 0, 0};
+    if (wa) {
+        nqa = ld_quad(na);
+        cella = bv_load_cell(ix.base, va.rv, pos_a);
+    }
+    if (wb) {
+        nqb = ld_quad(nb);
+        cellb = bv_load_cell(ix.base, vb.rv, pos_b);
+    }
+    FMX_NO_UNROLL
+    while (wa || wb) {  // ends: children lie behind their parents (flattener / validate_blob), as in wt_inverse_select_from
+        FMX_PIN_QUAD(nqa);
+        FMX_PIN_QUAD(cella);
+        FMX_PIN_QUAD(nqb);
+        FMX_PIN_QUAD(cellb);
+        uint32_t idx_a = 0, idx_b = 0;
+        if (wa) {
+            bool bit;
+            const int32_t rank1 = bv_rank1_access_cell(va.rv, cella, pos_a, bit) - (int32_t)node_b_a;  // WFBB:1389-1393
+            nr_a = bit ? rank1 : nr_a - rank1;                                                      // WFBB:1435-1470
+            const uint32_t lo = bit ? nqa.z : nqa.x, hi = bit ? nqa.w : nqa.y;
+            idx_a = lo & 0xffffu;
+            if (idx_a == 0) {  // leaf (WFBB:1495-1533)
+                rank_a = (int32_t)hi + nr_a;
+                ca = (int32_t)(lo >> 16);
+                wa = false;
+            } else {
+                node_b_a = hi >> 8;
+                pos_a = (int32_t)((lo >> 16) | ((hi & 0xffu) << 16)) + nr_a;
+            }
+        }
+        if (wb) {
+            bool bit;
+            const int32_t rank1 = bv_rank1_access_cell(vb.rv, cellb, pos_b, bit) - (int32_t)node_b_b;
+            nr_b = bit ? rank1 : nr_b - rank1;
+            const uint32_t lo = bit ? nqb.z : nqb.x, hi = bit ? nqb.w : nqb.y;
+            idx_b = lo & 0xffffu;
+            if (idx_b == 0) {
+                rank_b = (int32_t)hi + nr_b;
+                cb = (int32_t)(lo >> 16);
+                wb = false;
+            } else {
+                node_b_b = hi >> 8;
+                pos_b = (int32_t)((lo >> 16) | ((hi & 0xffu) << 16)) + nr_b;
+            }
+        }
+        if (wa) {
+            nqa = ld_quad(na + idx_a);
+            cella = bv_load_cell(ix.base, va.rv, pos_a);
+        }
+        if (wb) {
+            nqb = ld_quad(nb + idx_b);
+            cellb = bv_load_cell(ix.base, vb.rv, pos_b);
+        }
+    }
+    // run blocks (the InvHdr holds the answer; WFBB:1329-1355, the symbol masked to 8 bits: Q1) and blocks on the reference's route
+    if (la && (iha.x & kInvRun)) {
+        exact_a = (iha.x & kInvMasked) == 0;
+        rank_a = (int32_t)iha.z + (int32_t)bia;
+        ca = (int32_t)iha.y;
+    } else if (la && (iha.x & kInvSlow)) {
+        ca = wt_inverse_select_reference_route(ix, pa, va, rank_a, exact_a);
+    }
+    if (lb && (ihb.x & kInvRun)) {
+        exact_b = (ihb.x & kInvMasked) == 0;
+        rank_b = (int32_t)ihb.z + (int32_t)bib;
+        cb = (int32_t)ihb.y;
+    } else if (lb && (ihb.x & kInvSlow)) {
+        cb = wt_inverse_select_reference_route(ix, pb, vb, rank_b, exact_b);
+    }
+    if (la) {
+        a.c = (int32_t)(int16_t)ca;
+        a.row = fm_lf_finish(ix, inv, a.row, a.c, rank_a, va.bsl, exact_a, status, suspect);  // FM:532-535
+    }
+    if (lb) {
+        b.c = (int32_t)(int16_t)cb;
+        b.row = fm_lf_finish(ix, inv, b.row, b.c, rank_b, vb.bsl, exact_b, status, suspect);
+    }
+}
+
 // IntVector.getValue on the packed `suffixes` / `positions` words (IV:129-143)
 FMX_HD int32_t fm_packed_get(const uint32_t *words, int64_t index, int width) {
     return (int32_t)ld_bits(words, (uint64_t)index * (uint32_t)width, width);
@@ -1267,6 +1395,36 @@ FMX_HD bool fm_fetch_interval(const DevIndex &ix, const uint16_t *inv, int32_t k
     return !suspect && status == ST_OK;
 }
 
+// two intervals with the two walks interleaved (fm_lf_step2): ka / kb < 0 = nothing to fetch on that side
+FMX_HD bool fm_fetch_interval2(const DevIndex &ix, const uint16_t *inv, int32_t ka, uint16_t *bufa, int32_t kb, uint16_t *bufb,
+                               int64_t stride, int32_t &steps_a, int32_t &steps_b, int &status) {
+    const int32_t s = ix.sample_rate;
+    int32_t na = 0, nb = 0;
+    LfChain a = {0, 0, false}, b = {0, 0, false};
+    if (ka >= 0) {
+        const int64_t top64 = (int64_t)(ka + 1) * s;
+        na = (top64 < ix.length ? (int32_t)top64 : ix.length) - ka * s;
+        a.row = fm_packed_get(ix.pos_words, (int64_t)ka + 1, ix.bw_positions) + 1;  // FM:705-706
+    }
+    if (kb >= 0) {
+        const int64_t top64 = (int64_t)(kb + 1) * s;
+        nb = (top64 < ix.length ? (int32_t)top64 : ix.length) - kb * s;
+        b.row = fm_packed_get(ix.pos_words, (int64_t)kb + 1, ix.bw_positions) + 1;
+    }
+    bool suspect = false;
+    const int32_t n = na > nb ? na : nb;
+    for (int32_t i = 0; i < n; ++i) {  // step i writes offset n_x - 1 - i of its interval
+        a.on = i < na;
+        b.on = i < nb;
+        fm_lf_step2(ix, inv, a, b, status, suspect);
+        if (a.on) bufa[(int64_t)(na - 1 - i) * stride] = (uint16_t)a.c;
+        if (b.on) bufb[(int64_t)(nb - 1 - i) * stride] = (uint16_t)b.c;
+    }
+    steps_a += na;
+    steps_b += nb;
+    return !suspect && status == ST_OK;
+}
+
 // same result as fm_boundary_right_literal; `buf` holds sample_rate codes per lane (element i at buf[i*stride])
 FMX_HD int32_t fm_boundary_right_blocks(const DevIndex &ix, const uint16_t *inv, int mode, int32_t from,
                                         int32_t mapped_boundary, uint16_t *dest, int32_t dst_len, int32_t offset,
@@ -1528,6 +1686,33 @@ FMX_HD void window_fill_both(const DevIndex &ix, const uint16_t *inv, TextWindow
     if (group_any<G>(!ok)) wl.suspect = true;
 }
 
+// The default first fill — G intervals on each side — with every lane's two walks interleaved (fm_fetch_interval2): what
+// window_refill(wl, k0, -1) followed by window_refill(wr, k0 + 1, +1) would fetch, in half the round trips.
+template <int G>
+FMX_HD void window_fill_pairs(const DevIndex &ix, const uint16_t *inv, TextWindow<G> &wl, TextWindow<G> &wr, int32_t k0,
+                              bool want_right) {
+    const int32_t k_max = (ix.length - 1) / wl.s;
+    int32_t lo = k0 - (G - 1);
+    if (lo < 0) lo = 0;
+    wl.k_lo = lo;
+    wl.n = G;
+    int32_t mine_l = lo + wl.g, mine_r = -1;
+    if (mine_l > k_max) mine_l = -1;
+    if (want_right) {
+        wr.k_lo = k0 + 1;
+        wr.n = G;
+        mine_r = k0 + 1 + wr.g;
+        if (mine_r > k_max) mine_r = -1;
+    }
+    int status = ST_OK;
+    const bool ok = fm_fetch_interval2(ix, inv, mine_l, window_slot<G>(wl, mine_l < 0 ? 0 : mine_l), mine_r,
+                                       window_slot<G>(wr, mine_r < 0 ? 0 : mine_r), wl.row_stride, wl.steps, wr.steps, status);
+    if (group_any<G>(!ok)) {
+        wl.suspect = true;
+        if (want_right) wr.suspect = true;
+    }
+}
+
 template <int G>
 FMX_HD int32_t window_code_at(const DevIndex &ix, const uint16_t *inv, TextWindow<G> &w, int32_t pos, int dir) {
     const int32_t k = pos / w.s;
@@ -1545,7 +1730,7 @@ FMX_HD int32_t fm_extract_boundary_group(const DevIndex &ix, const uint16_t *inv
                                          int32_t mapped_boundary, uint16_t *dest, int32_t dst_len, int32_t offset,
                                          int32_t &steps, int &status, int32_t &aux, uint16_t *buf, int64_t row_stride,
                                          int64_t slot_stride, int64_t win_stride, int32_t g, bool &clean,
-                                         bool first_fill_halves = false) {
+                                         bool first_fill_halves = false, bool pair_walks = false) {
     steps = 0;
     aux = 0;
     clean = true;
@@ -1577,6 +1762,8 @@ FMX_HD int32_t fm_extract_boundary_group(const DevIndex &ix, const uint16_t *inv
     TextWindow<G> wr = {buf + win_stride, row_stride, slot_stride, s, -1, 0, g, 0, false};  // intervals > k0
     if (G >= 2 && first_fill_halves) {
         window_fill_both<G>(ix, inv, wl, wr, k0, mode != 1);        // [k0-G/2+1, k0] and [k0+1, k0+G/2], one walk per lane
+    } else if (pair_walks) {
+        window_fill_pairs<G>(ix, inv, wl, wr, k0, mode != 1);       // the same two windows, a lane's two walks interleaved
     } else {
         window_refill<G>(ix, inv, wl, k0, -1);                      // [k0-G+1, k0]: the left part and text[from..]
         if (mode != 1) window_refill<G>(ix, inv, wr, k0 + 1, +1);   // [k0+1, k0+G]

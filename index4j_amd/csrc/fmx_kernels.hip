@@ -635,7 +635,7 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix_global, co
         uint16_t *dest = dst + q * (int64_t)dst_len;
         int32_t ret = fm_extract_boundary_group<G>(ix, s_inv, mode, froms[q], mapped_boundary, dest, dst_len, offset, steps,
                                                    status, aux, scratch + (lane - g), lanes, 1, lanes * (int64_t)ix.sample_rate, g, clean,
-                                                   first_fill != 0);
+                                                   first_fill == 1, first_fill == 2);
         if (!clean && g == 0) {  // a walk met a quirk path of the wavelet tree: literal form (rare)
             int32_t steps2;
             status = ST_OK;
@@ -998,7 +998,9 @@ static std::atomic<int> g_block{512};
 static std::atomic<int> g_groups_per_cu{16};
 static std::atomic<int> g_boundary_accel{1};  // 0 = literal right walk of extractUntilBoundary (A/B and fallback)
 static std::atomic<int> g_boundary_group{4};  // lanes per query of extractUntilBoundary (0 = one lane per query)
-static std::atomic<int> g_boundary_first_fill{0};  // 1 = narrow first fill of the text windows (experiment)
+// first fill of extractUntilBoundary's two text windows: 0 = G intervals on each side, a lane walks one after the other;
+// 1 = G / 2 on each side, one walk per lane (measured, slower); 2 = as 0 with a lane's two walks interleaved (fm_lf_step2)
+static std::atomic<int> g_boundary_first_fill{2};
 static std::atomic<int> g_steps_executed_only{0};  // 1 = d_lf_steps of count() leave out what the suffix table answered
 static std::atomic<int> g_suffix_table_use{1};  // 0 = k_count ignores the index's suffix table (A/B)
 static std::atomic<int> g_lds_pad_kb{0};   // experiment knob: extra dynamic LDS per workgroup (lowers occupancy)
@@ -1034,7 +1036,8 @@ int set_option(const char *name, int value) {
         return 0;
     }
     if (!strcmp(name, "boundary_first_fill")) {
-        g_boundary_first_fill = value != 0;
+        if (value < 0 || value > 2) return -1;
+        g_boundary_first_fill = value;
         return 0;
     }
     if (!strcmp(name, "suffix_table")) {

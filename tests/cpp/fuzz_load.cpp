@@ -204,7 +204,7 @@ void query_everything(const std::vector<uint8_t> &blob, const std::vector<uint16
         g_where = "extract";
         sim_extract(img, a.data(), b.data(), n, dst.data(), dst_len, (int32_t)r.below(4), out_len.data(), lf.data(), st.data());
         for (int mode = 0; mode < 3; ++mode)
-            for (int acc = 0; acc < 3; ++acc) {
+            for (int acc = 0; acc < 4; ++acc) {
                 // (the windowed forms hold 2 x sampleRate characters per lane; the library takes the literal form when
                 // that would not fit — fmx_api.cpp: boundary_impl)
                 if (acc && h.sample_rate > (1 << 20)) continue;

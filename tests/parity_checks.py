@@ -76,6 +76,7 @@ def check_all(make_engine, text, sr, rnd, n_q=120):
             if hasattr(h, "blob"):  # host simulation: also the literal +4-chunk form (accelerate=0)
                 results.append(h.extract_boundary_batch(fr, bch, mode, cap, offs, accelerate=0))
                 results.append(h.extract_boundary_batch(fr, bch, mode, cap, offs, accelerate=2))  # group form, G = 1
+                results.append(h.extract_boundary_batch(fr, bch, mode, cap, offs, accelerate=3))  # + interleaved first walks (fm_lf_step2)
             for dst, ol, st4, aux, lf4 in results:
                 for i in range(n_q):
                     try:

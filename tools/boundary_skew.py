@@ -11,6 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+MODE = int(os.environ.get("FMX_MODE", "0"))
+
+
 def main():
     import torch
 
@@ -34,28 +37,33 @@ def main():
                                                                                           w.max(axis=1).mean() / steps.mean()))
     dev = torch.device("cuda", 0)
     sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for K in (25_000, 50_000, 100_000, 200_000, 400_000, 800_000):
-        d_from = torch.from_numpy(froms_all[:K]).to(dev)
-        d_dst = torch.zeros(K * 1024, dtype=torch.int16, device=dev)
-        d_len = torch.zeros(K, dtype=torch.int32, device=dev)
-        d_st = torch.zeros(K, dtype=torch.int32, device=dev)
-        d_aux = torch.zeros(K, dtype=torch.int32, device=dev)
+    fills = [int(x) for x in os.environ.get("FMX_FIRST_FILLS", "").split(",") if x] or [None]
+    for fill in fills:
+      if fill is not None:
+        assert ia.lib.fmx_set_option(b"boundary_first_fill", fill) == 0
+        print("boundary_first_fill = %d" % fill)
+      for K in (25_000, 100_000, 800_000) if fill is not None else (25_000, 50_000, 100_000, 200_000, 400_000, 800_000):
+          d_from = torch.from_numpy(froms_all[:K]).to(dev)
+          d_dst = torch.zeros(K * 1024, dtype=torch.int16, device=dev)
+          d_len = torch.zeros(K, dtype=torch.int32, device=dev)
+          d_st = torch.zeros(K, dtype=torch.int32, device=dev)
+          d_aux = torch.zeros(K, dtype=torch.int32, device=dev)
 
-        def call():
-            assert ia.lib.fmx_extract_boundary_batch_dev(fm.handle, d_from.data_ptr(), K, 10, 0, d_dst.data_ptr(), 1024, 0, d_len.data_ptr(),
-                                                         None, d_st.data_ptr(), d_aux.data_ptr(), sp) == 0
+          def call():
+              assert ia.lib.fmx_extract_boundary_batch_dev(fm.handle, d_from.data_ptr(), K, 10, MODE, d_dst.data_ptr(), 1024, 0, d_len.data_ptr(),
+                                                           None, d_st.data_ptr(), d_aux.data_ptr(), sp) == 0
 
-        for _ in range(2):
-            call()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(4):
-            call()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 4
-        print("K = %7d queries: %.3f ms  (%.1f ns per query)" % (K, ms, ms * 1e6 / K), flush=True)
-        del d_dst
+          for _ in range(2):
+              call()
+          e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+          e0.record()
+          for _ in range(4):
+              call()
+          e1.record()
+          torch.cuda.synchronize()
+          ms = e0.elapsed_time(e1) / 4
+          print("K = %7d queries: %.3f ms  (%.1f ns per query)" % (K, ms, ms * 1e6 / K), flush=True)
+          del d_dst
 
 
 if __name__ == "__main__":
