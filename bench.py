@@ -1102,7 +1102,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every oracle leg (profiling runs)")
     ap.add_argument("--no-secondary", action="store_true", help="skip configs[2] / [3] and the reference-shaped series")
     ap.add_argument("--no-ref-series", action="store_true", help="skip the reference-shaped series of `secondary`")
-    ap.add_argument("--series-queries", type=int, default=1 << 18, help="queries per batch of the reference-shaped series")
+    ap.add_argument("--series-queries", type=int, default=1 << 20, help="queries per batch of the reference-shaped series")
     ap.add_argument("--profiling", action="store_true",
                     help="rocprofv3 runs: skip the extra legs that launch the headline kernels in other modes (without the suffix "
                          "table, two batches in flight), so that per-kernel averages and counters describe the timed path only")

@@ -46,7 +46,7 @@ def _timed(torch, stream, fn, reps):
     return best
 
 
-def run_series(ia, torch, orc, dev, text_log2=28, queries=1 << 18, sample_rates=(1, 32, 64), max_matches=(1, 10, 100, 1000),
+def run_series(ia, torch, orc, dev, text_log2=28, queries=1 << 20, sample_rates=(1, 32, 64), max_matches=(1, 10, 100, 1000),
                symbols=None, build_device=0, log=lambda *a: None, bounded=True):
     """bounded: the locate rows with maxMatches 100 / 1000 (sampleRate > 1) take the first queries / 4 and queries / 16 of the batch — the
     oracle's check of every located position is what takes the time (256 host cores: 150 s for 262,144 queries x 1000 at
@@ -234,7 +234,7 @@ def run_series(ia, torch, orc, dev, text_log2=28, queries=1 << 18, sample_rates=
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--text-log2", type=int, default=28)
-    ap.add_argument("--queries", type=int, default=1 << 18)
+    ap.add_argument("--queries", type=int, default=1 << 20)
     ap.add_argument("--symbols", type=int, default=None)
     ap.add_argument("--sample-rates", default="1,32,64")
     ap.add_argument("--max-matches", default="1,10,100,1000")
