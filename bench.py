@@ -16,9 +16,12 @@ sharded over the ranks (strong scaling).
 `python bench.py --gpus N` without a launcher starts `torch.distributed.run` itself as a child process; a run
 whose rank count differs from --gpus fails instead of printing a mislabelled line.
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline`, `cpu_baseline`, `secondary`
-(configs[2], [3]) and `ranks_seen`.  PyTorch is only plumbing here: device memory, the stream, HIP events and
-torch.distributed.
+Output (rank 0): the DETAIL record — everything measured, with prose — as the stdout line `BENCH_DETAIL {...}` and as
+gpurun_out/bench_detail.json; then, LAST, one compact JSON line (< 4 KB for every workload and N) with the driver's
+contract fields, `roofline`, `cpu_baseline`, `ranks_seen` and one {config, ms, frac} triple per secondary config
+(configs[2], [3]; the reference-shaped series only with --series).  tools/bench_detail.py extracts the detail from a
+captured stdout.  All times are MEANS over the timed calls.  PyTorch is only plumbing here: device memory, the stream,
+HIP events and torch.distributed.
 """
 import argparse
 import ctypes as C
@@ -194,6 +197,129 @@ class Ctx:
     """what every workload needs: rank info, device, torch, dist (or None), the package"""
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# what goes to stdout: the DETAIL (everything measured, with prose) as an earlier line and as a file, and — LAST — one
+# compact line of the contract's fields.  The driver keeps the last 8,000 characters of stdout: the contract line must
+# fit there whole (round 3's 21.7 KB line did not, and went unparsed).
+# ---------------------------------------------------------------------------------------------------------------
+COMPACT_LIMIT = 4096
+DETAIL_FILE = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+
+
+def _pick(d, keys):
+    return None if not d else {k: d[k] for k in keys if k in d and d[k] is not None}
+
+
+def _short(s, n=140):
+    s = str(s)
+    return s if len(s) <= n else s[: n - 3] + "..."
+
+
+def _sig(x, digits=5):
+    """floats of the optional blocks to `digits` significant digits (the contract's own fields stay exact)"""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x))
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def compact_line(out):
+    """the contract's fields of a detail record, bounded below COMPACT_LIMIT characters for every workload and N"""
+    c = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                 "scaling", "vs_baseline", "dtype", "data")}
+    for k in ("lf_steps_per_sec", "lf_steps_per_sec_reference_equivalent", "lf_steps_per_sec_count_stage", "ms_per_step_ranks",
+              "dry_run", "parity"):
+        if out.get(k) is not None:
+            c[k] = out[k]
+    if out.get("rehearsal"):
+        c["rehearsal"] = _short(out["rehearsal"], 60)
+    c["ranks_seen"] = out.get("ranks_seen")
+    cfg = out.get("config") or {}
+    c["config"] = {"workload": _short(cfg.get("workload"), 260)}
+    for k in ("text_chars", "patterns_per_gpu", "pattern_len", "sample_rate", "batches", "segments", "patterns_total", "max_matches",
+              "count_checksum", "patterns_checked_vs_oracle"):
+        if cfg.get(k) is not None:
+            c["config"][k] = cfg[k]
+    c["config"]["parallelism"] = "dp%d" % (out.get("n_gpus") or 1)
+    r = out.get("roofline")
+    c["roofline"] = _pick(r, ("bound", "achieved", "peak", "unit", "frac")) if r else None
+    if r:
+        c["roofline"]["traffic"] = r.get("traffic")
+        c["roofline"].update(_pick(r, ("kernel_ms", "alg_bytes_executed_per_launch", "alg_bytes_per_lf_step",
+                                       "lf_steps_executed_per_launch", "frac_whole_step", "traffic_frac", "step_ms_incl_plan",
+                                       "fabric_line_fills_per_lf_step_executed", "resident_bytes_per_text_byte",
+                                       "stage_ms_this_rank")) or {})
+        c["roofline"]["kernel"] = _short(r.get("kernel"), 100)
+    b = out.get("cpu_baseline")
+    c["cpu_baseline"] = _pick(b, ("value", "unit", "cores", "kind", "lf_steps_per_s")) if b else None
+    if b:
+        c["cpu_baseline"]["sample"] = _short(b.get("sample"), 150)
+        if b.get("all_cores"):
+            c["cpu_baseline"]["all_cores"] = _pick(b["all_cores"], ("value", "cores"))
+        jv = b.get("index4j_jvm")
+        if jv is not None:
+            c["cpu_baseline"]["index4j_jvm"] = "timed: see detail" if jv.get("available") else "not available (no JVM on this box)"
+    if out.get("overlapped"):
+        c["overlapped_ms_per_step"] = out["overlapped"].get("ms_per_step")
+    if out.get("suffix_table"):
+        st = out["suffix_table"]
+        c["suffix_table"] = {"chars": st.get("chars"), "bytes": st.get("bytes"),
+                             "ms_per_step_without": (st.get("without_it") or {}).get("ms_per_step")}
+    hb = out.get("host_buffers")
+    if hb:
+        c["host_buffers"] = _pick(hb, ("ms_per_call", "ms_per_call_registered_buffers", "ratio_to_max_of_floor_and_device_step",
+                                       "ratio_registered_to_max_of_floor_and_device_step", "pcie_floor_ms_in", "stat"))
+    if out.get("index_broadcast"):
+        c["index_broadcast"] = _pick(out["index_broadcast"], ("broadcast_s", "fan_out_s", "kept", "bytes"))
+    sec = []
+    for row in out.get("secondary") or []:
+        if row is None:
+            continue
+        if "series" in row:
+            for sr in (row["series"] or {}).get("rows", []):
+                sec.append({"config": _short("series %s s=%s%s" % (sr.get("benchmark"), sr.get("sample_rate"),
+                                                                    "" if sr.get("max_matches") is None else " max=%s" % sr["max_matches"]), 40),
+                            "ms": sr.get("ms_per_batch"), "frac": (sr.get("roofline") or {}).get("frac")})
+            continue
+        sec.append({"config": _short(str(row.get("config") or row.get("metric")).replace("BASELINE.json ", ""), 48),
+                    "ms": row.get("ms", row.get("ms_per_step")), "frac": (row.get("roofline") or {}).get("frac")})
+    if sec:
+        c["secondary"] = sec
+    exact = ("bound", "achieved", "peak", "unit", "frac", "traffic", "value", "cores", "kind")
+    for blk in ("roofline", "cpu_baseline"):
+        if c.get(blk):
+            c[blk] = {k: (v if k in exact else _sig(v)) for k, v in c[blk].items()}
+    for blk in ("secondary", "host_buffers", "index_broadcast", "suffix_table", "overlapped_ms_per_step", "ms_per_step_ranks"):
+        if blk in c:
+            c[blk] = _sig(c[blk])
+    c["detail"] = "gpurun_out/bench_detail.json (+ the stdout line before this one)"
+    line = json.dumps(c, separators=(",", ":"))
+    if len(line) >= COMPACT_LIMIT:  # never let an over-long line out again: shed the optional blocks, largest first
+        for k in ("secondary", "host_buffers", "index_broadcast", "suffix_table", "ranks_seen"):
+            if k in c and len(line) >= COMPACT_LIMIT:
+                c[k] = "see detail"
+                line = json.dumps(c, separators=(",", ":"))
+    if len(line) >= COMPACT_LIMIT:
+        raise RuntimeError("bench.py's contract line is %d characters (limit %d)" % (len(line), COMPACT_LIMIT))
+    return line
+
+
+def emit(out):
+    """detail first (stdout line + file), the compact contract line LAST"""
+    detail = json.dumps(out)
+    try:
+        os.makedirs(os.path.dirname(DETAIL_FILE), exist_ok=True)
+        with open(DETAIL_FILE, "w") as f:
+            f.write(detail + "\n")
+    except OSError as e:
+        log("[bench] could not write %s: %s" % (DETAIL_FILE, e))
+    print("BENCH_DETAIL " + detail, flush=True)
+    print(compact_line(out), flush=True)
+
+
 def hip_events(torch):
     return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
@@ -234,7 +360,11 @@ def attach_everywhere(ctx, fm):
         if buf is not None and not bool((buf == got).all()):
             raise RuntimeError("the slice fan-out delivered other bytes than the broadcast")
         buf = got
-    ctx.broadcast_times = dict(times, bytes=int(buf.numel()), ranks=ctx.world,
+    # the faster form serves every later image of this run (the segment images of configs[4]); all ranks must agree: rank 0 decides
+    pick = torch.tensor([1 if min(times, key=times.get) == "fan_out_s" else 0], dtype=torch.int32, device=ctx.cdev)
+    ctx.dist.broadcast(pick, 0)
+    ctx.fan_out = bool(int(pick.item()))
+    ctx.broadcast_times = dict(times, bytes=int(buf.numel()), ranks=ctx.world, kept="fan_out_s" if ctx.fan_out else "broadcast_s",
                                note="first use of a collective includes its set-up; host staging included")
     if ctx.rank == 0:
         log("[bench] index image %.1f MB to %d rank(s): %s" % (buf.numel() / 1e6, ctx.world, times))
@@ -418,7 +548,10 @@ def run_count(ctx, args):
 
         cdev = ctx.cdev
         tw = torch.tensor([wall], dtype=torch.float64, device=cdev)
+        tmin = tw.clone()
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        wall_ranks = {"min": float(tmin.item()) * 1e3 / args.steps, "max": float(tw.item()) * 1e3 / args.steps}
         wall = float(tw.item())
         if overlapped:
             tw2 = torch.tensor([overlapped["wall_s_this_rank"]], dtype=torch.float64, device=cdev)
@@ -432,6 +565,7 @@ def run_count(ctx, args):
         gathered = gather_concat(dist, d_cnt[0], [n] * world, cdev)
     else:
         lf_total, lf_exec_total = lf_local, lf_exec_local
+        wall_ranks = {"min": wall * 1e3 / args.steps, "max": wall * 1e3 / args.steps}
     # At N > 1 the same launch also measures BASELINE.json configs[4] (the 8M-pattern batch over the 2 GiB text's 8
     # segment indexes, strong scaling): one `bench.py --gpus N` yields the weak-scaling headline and this figure
     segments_line = None
@@ -588,6 +722,7 @@ def run_count(ctx, args):
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "ms_per_step_ranks": wall_ranks,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -656,11 +791,12 @@ def measure_host_buffers(ctx, args, q, pat, off, expect, step_ms):
         call()
         if not (counts == expect).all() or int(status.max()) != 0:
             raise RuntimeError("host-buffer counts differ from the device-pointer path")
-        piped = min(call() for _ in range(7))
+        piped_all = [call() for _ in range(7)]
+        piped = float(np.mean(piped_all))
         call(0)
         if not (counts == expect).all():
             raise RuntimeError("host-buffer counts (unpipelined) differ from the device-pointer path")
-        plain = min(call() for _ in range(5))
+        plain = float(np.mean([call() for _ in range(5)]))
     finally:
         ia.lib.fmx_set_option(b"host_pipeline_min", 131072)
     # the same call with the caller's arrays pinned once (fmx_host_register: what a binding does with its direct buffers)
@@ -673,7 +809,8 @@ def measure_host_buffers(ctx, args, q, pat, off, expect, step_ms):
         call()
         if not (counts == expect).all():
             raise RuntimeError("host-buffer counts (registered buffers) differ from the device-pointer path")
-        registered = min(call() for _ in range(7))
+        registered_all = [call() for _ in range(7)]
+        registered = float(np.mean(registered_all))
     finally:
         for a in regs:
             ia.lib.fmx_host_unregister(a.ctypes.data)
@@ -698,6 +835,7 @@ def measure_host_buffers(ctx, args, q, pat, off, expect, step_ms):
     return {"what": "fmx_count_batch (host buffers, pageable numpy arrays; counts + statuses back) of batch 0: the JNI binding's call "
                     "path.  Chunks of 262,144 patterns travel while the previous chunk is counted (2 streams), results return through "
                     "pinned staging, offsets of equal-length runs are made on the device",
+            "stat": "means of 7 calls (minima: pageable %.3f, registered %.3f ms)" % (min(piped_all), min(registered_all)),
             "patterns": n, "ms_per_call": piped, "patterns_per_s": n / piped * 1e3,
             "ms_per_call_unpipelined": plain, "ms_per_call_registered_buffers": registered,
             "ratio_registered_to_max_of_floor_and_device_step": registered / floor,
@@ -718,21 +856,16 @@ def run_secondary(ctx, args, q, ref, orc, text, pat, off):
     res = []
 
     def timed(fn, reps):
-        # HIP events bracket `reps` back-to-back calls; the smallest of three rounds: an event pair also spans the gaps a
-        # descheduled host thread leaves between launches (the oracle's OpenMP team has just been busy on every core)
+        # MEAN over 3 x reps back-to-back calls between one HIP-event pair: the headline's standard (minima until round 3)
         fn()
         torch.cuda.synchronize()
-        best = None
-        for _ in range(3):
-            e0, e1 = hip_events(torch)
-            e0.record(stream)
-            for _ in range(reps):
-                fn()
-            e1.record(stream)
-            torch.cuda.synchronize()
-            t = e0.elapsed_time(e1) / reps
-            best = t if best is None or t < best else best
-        return best
+        e0, e1 = hip_events(torch)
+        e0.record(stream)
+        for _ in range(3 * reps):
+            fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / (3 * reps)
 
     d_pat = torch.from_numpy(np.ascontiguousarray(pat[: K * m]).view(np.int16)).to(dev)
     d_off = torch.from_numpy(np.ascontiguousarray(off[: K + 1])).to(dev)
@@ -820,7 +953,7 @@ def run_secondary(ctx, args, q, ref, orc, text, pat, off):
                 "checked_vs_oracle": "all %d queries: lengths, statuses, whole destination rows" % K})
     fm64.close()
     # ---- the reference's own benchmark shapes on a text with the published data set's alphabet size ----
-    if not args.no_ref_series:
+    if args.series and not args.no_ref_series:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import ref_series
 
@@ -866,7 +999,7 @@ def run_segments(ctx, args):
             segs.append(fms[s])
             image_bytes += len(fms[s].blob())
         else:
-            buf = broadcast_blob(dist, fms[s].blob() if ctx.rank == 0 else None, ctx.cdev)
+            buf = broadcast_blob(dist, fms[s].blob() if ctx.rank == 0 else None, ctx.cdev, fan_out=getattr(ctx, "fan_out", None))
             if not ctx.dry:
                 buf = buf.to(dev)
             bufs.append(buf)
@@ -1101,7 +1234,10 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of single-thread oracle time for cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every oracle leg (profiling runs)")
     ap.add_argument("--no-secondary", action="store_true", help="skip configs[2] / [3] and the reference-shaped series")
-    ap.add_argument("--no-ref-series", action="store_true", help="skip the reference-shaped series of `secondary`")
+    ap.add_argument("--series", action="store_true",
+                    help="also run the reference-shaped series (count / locate 1..1000 / extract-32 at sampleRate 1, 32, 64 on the "
+                         "1,100-symbol text; ~100 s, most of it the oracle's check); off by default so that the default run stays short")
+    ap.add_argument("--no-ref-series", action="store_true", help="(default since round 4; kept for old command lines)")
     ap.add_argument("--series-queries", type=int, default=1 << 20, help="queries per batch of the reference-shaped series")
     ap.add_argument("--profiling", action="store_true",
                     help="rocprofv3 runs: skip the extra legs that launch the headline kernels in other modes (without the suffix "
@@ -1159,7 +1295,7 @@ def main():
     try:
         out = run_count(ctx, args) if args.workload == "count" else run_segments(ctx, args)
         if ctx.rank == 0:
-            print(json.dumps(out), flush=True)
+            emit(out)
     finally:
         if ctx.dist is not None:
             ctx.dist.destroy_process_group()

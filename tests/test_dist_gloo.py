@@ -1,6 +1,7 @@
 """N>1 path on CPU: world_size-2 gloo run of the sharding plumbing bench.py uses (broadcast of the index
 blob, contiguous pattern shards, rank-ordered gather).  Queries run through the test-only host
 simulation here; on the GPU box the same plumbing runs over RCCL with the HIP kernels."""
+import json
 import os
 import socket
 import sys
@@ -93,8 +94,26 @@ def _run_bench(extra, env_extra=None, timeout=600):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--text-log2", "16", "--patterns", "3001",
                         "--patterns-total", "5003", "--segment-log2", "14", "--segments", "3", "--batches", "2", "--steps", "2",
                         "--warmup", "1"] + extra, capture_output=True, text=True, env=env, timeout=timeout)
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    return r.returncode, (json.loads(line[-1]) if line else None), r.stderr
+    detail = [ln[len("BENCH_DETAIL "):] for ln in r.stdout.splitlines() if ln.startswith("BENCH_DETAIL ")]
+    if r.returncode == 0:
+        _check_contract_line(r.stdout, json.loads(detail[-1]))
+    return r.returncode, (json.loads(detail[-1]) if detail else None), r.stderr
+
+
+def _check_contract_line(stdout, detail):
+    """what the driver's parser sees: the LAST line of the last 8,000 characters of stdout is the whole contract line,
+    below 4 KB, and agrees with the detail record (round 3's one 21.7 KB line went unparsed)"""
+    tail = stdout[-8000:]
+    last = tail.rstrip("\n").splitlines()[-1]
+    assert stdout.rstrip("\n").splitlines()[-1] == last, "the contract line does not fit the driver's 8,000-character tail"
+    assert len(last) < 4096, len(last)
+    c = json.loads(last)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "ranks_seen"):
+        assert k in c, k
+        if k not in ("config", "roofline", "cpu_baseline"):
+            assert c[k] == detail[k], k
+    assert isinstance(c["config"]["workload"], str) and "model" not in c["config"]
 
 
 def test_bench_launches_itself_and_reports_the_ranks_that_really_ran():
