@@ -76,7 +76,8 @@ double fmx_build_wavelet_seconds(const fmx_index *idx);
  * batches start from it: one slot instead of 2 * (chars - 1) rank evaluations; a string that is not in it (it does not
  * occur, holds an unknown character, or its search raised a status) is searched by the loop.  Results, statuses and
  * LF-step counts are unchanged (option "suffix_table" = 0 makes launches ignore it, for A/B).  *chars = 0: no table;
- * *bytes = the table's size (0.8 MB for the 26,064 four-character strings of the 256 MiB synthetic log). */
+ * *bytes = the table's size (8 MB for the 26,064 four-character strings of the 256 MiB synthetic log: sized so that the
+ * fullest of its 16 slot columns stays half full; never above the budget). */
 int fmx_suffix_table_info(const fmx_index *idx, int32_t *chars, int64_t *bytes);
 
 /* FmIndex.read(ObjectInput) FM:983-1025; also accepts the ObjectOutputStream-framed form produced by

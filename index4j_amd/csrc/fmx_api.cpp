@@ -326,24 +326,47 @@ struct PipeStreams {
     hipEvent_t in[kPipeEvents] = {}, counted[kPipeEvents] = {}, done[kPipeEvents] = {};
 };
 int pipe_streams(int device, PipeStreams **out) {
-    thread_local PipeStreams ps;
-    if (ps.device != device) {
-        for (int i = 0; i < kPipeStreams; ++i) HIP_TRY(hipStreamCreateWithFlags(&ps.s[i], hipStreamNonBlocking));
-        for (auto *set : {ps.in, ps.counted, ps.done})
-            for (int i = 0; i < kPipeEvents; ++i) HIP_TRY(hipEventCreateWithFlags(&set[i], hipEventDisableTiming));
-        ps.device = device;
-    }
-    *out = &ps;
+    // one set per device this thread has used (a thread that alternates between devices keeps both; nothing is re-created)
+    thread_local std::vector<PipeStreams *> sets;
+    for (PipeStreams *p : sets)
+        if (p->device == device) {
+            *out = p;
+            return FMX_OK;
+        }
+    std::unique_ptr<PipeStreams> ps(new PipeStreams());
+    auto undo = [&]() {  // a set that could not be completed is taken apart again
+        for (int i = 0; i < kPipeStreams; ++i)
+            if (ps->s[i]) (void)hipStreamDestroy(ps->s[i]);
+        for (auto *set : {ps->in, ps->counted, ps->done})
+            for (int i = 0; i < kPipeEvents; ++i)
+                if (set[i]) (void)hipEventDestroy(set[i]);
+    };
+    for (int i = 0; i < kPipeStreams; ++i)
+        if (hipError_t e = hipStreamCreateWithFlags(&ps->s[i], hipStreamNonBlocking); e != hipSuccess) {
+            undo();
+            HIP_TRY(e);
+        }
+    for (auto *set : {ps->in, ps->counted, ps->done})
+        for (int i = 0; i < kPipeEvents; ++i)
+            if (hipError_t e = hipEventCreateWithFlags(&set[i], hipEventDisableTiming); e != hipSuccess) {
+                undo();
+                HIP_TRY(e);
+            }
+    ps->device = device;
+    sets.push_back(ps.release());
+    *out = sets.back();
     return FMX_OK;
 }
 
 // One pass over pat_off[lo .. hi]: offsets never decrease and end at or below `limit`; *uniform = every pattern of the
 // run has the same length (then the offsets need not travel: k_fill_offsets).  Branch-free so that it vectorises.
 bool scan_offsets(const int32_t *pat_off, int32_t lo, int32_t hi, int64_t limit, bool *uniform) {
-    const int32_t m0 = pat_off[lo + 1] - pat_off[lo];
-    int32_t neg = 0, diff = 0;
+    // differences in 64 bits: {8, 2000000000, -2000000000, 16} has no negative int32 difference (the second wraps to
+    // +294,967,296) and both ends in range — monotonic offsets with checked ends is what keeps every offset inside
+    const int64_t m0 = (int64_t)pat_off[lo + 1] - pat_off[lo];
+    int64_t neg = 0, diff = 0;
     for (int32_t i = lo; i < hi; ++i) {
-        const int32_t d = pat_off[i + 1] - pat_off[i];
+        const int64_t d = (int64_t)pat_off[i + 1] - pat_off[i];
         neg |= d;
         diff |= d ^ m0;
     }
@@ -602,51 +625,63 @@ static void build_suffix_table(fmx_index *idx) {
     };
     uint32_t n_cur = 0;
     int chars = 0, cur = 0;
-    if (hipMemset(d_count, 0, 64) != hipSuccess || fmx::launch_suffix_level1(idx->dev, level[0], d_count, cap, nullptr) != 0 ||
-        !counted(&n_cur) || n_cur == 0 || n_cur > cap) {
-        cleanup();
-        return;
-    }
-    chars = 1;
-    while (chars < max_chars) {
-        uint32_t n_next = 0;
-        if (hipMemset(d_count, 0, 64) != hipSuccess ||
-            fmx::launch_suffix_expand(idx->dev, idx->n_cu, level[cur], n_cur, chars, key_bits, level[cur ^ 1], d_count, cap, nullptr) != 0 ||
-            !counted(&n_next)) {
+    uint64_t slots64 = 0;
+    // work of one level = strings x (sigma - 1) rank pairs, most of them of absent characters: bounded, so that a large
+    // alphabet (sigma up to 32,767) does not spend tens of seconds on a level that is thrown away in the end
+    constexpr uint64_t kLevelWorkMax = 1ull << 35;
+    // grown to `limit` characters, then sized; a table that would pass the budget (a lopsided alphabet asks for many more
+    // slots than strings) is grown again one character shallower
+    for (int limit = max_chars;; limit = chars - 1) {
+        if (limit < 2) {
             cleanup();
             return;
         }
-        if (n_next == 0 || n_next > cap) break;  // (the next level does not fit: this one is the table)
-        cur ^= 1;
-        n_cur = n_next;
-        ++chars;
-    }
-    if (chars < 2) {
-        cleanup();
-        return;
-    }
-    // the table: kSuffixGroup columns of slots (fm_suffix_home)
-    uint32_t columns[fmx::kSuffixGroup] = {0};
-    if (hipMemset(d_count, 0, 4 * fmx::kSuffixGroup) != hipSuccess ||
-        fmx::launch_suffix_columns(level[cur], n_cur, (chars - 1) * key_bits, d_count, nullptr) != 0 ||
-        hipMemcpy(columns, d_count, sizeof columns, hipMemcpyDeviceToHost) != hipSuccess) {
-        cleanup();
-        return;
-    }
-    uint64_t fullest = 0;
-    for (uint32_t v : columns) fullest = std::max<uint64_t>(fullest, v);
-    uint64_t slots64 = 1024;
-    // twice as many slots as strings, and the fullest column half full (probing stays inside a column: 0.8 % of the headline
-    // batch's step) — or, where that would pass an eighth of the image, room for the fullest column with a quarter to spare
-    while (slots64 < 2 * (uint64_t)n_cur || 4 * slots64 < 5 * fmx::kSuffixGroup * fullest) slots64 <<= 1;
-    {
-        uint64_t roomy = slots64;
-        while (roomy < 2 * fmx::kSuffixGroup * fullest) roomy <<= 1;
-        if (roomy * sizeof(fmx::SuffixSlot) <= idx->d_len / 8) slots64 = roomy;
-    }
-    if (slots64 * sizeof(fmx::SuffixSlot) > std::max<uint64_t>(budget, 1 << 20) * 4 || slots64 > 0x40000000u) {  // (a lopsided alphabet)
-        cleanup();
-        return;
+        cur = 0;
+        if (hipMemset(d_count, 0, 64) != hipSuccess || fmx::launch_suffix_level1(idx->dev, level[0], d_count, cap, nullptr) != 0 ||
+            !counted(&n_cur) || n_cur == 0 || n_cur > cap) {
+            cleanup();
+            return;
+        }
+        chars = 1;
+        while (chars < limit) {
+            uint32_t n_next = 0;
+            if ((uint64_t)n_cur * (uint64_t)(idx->hdr.wt_sigma - 1) > kLevelWorkMax) break;
+            if (hipMemset(d_count, 0, 64) != hipSuccess ||
+                fmx::launch_suffix_expand(idx->dev, idx->n_cu, level[cur], n_cur, chars, key_bits, level[cur ^ 1], d_count, cap, nullptr) != 0 ||
+                !counted(&n_next)) {
+                cleanup();
+                return;
+            }
+            if (n_next == 0 || n_next > cap) break;  // (the next level does not fit: this one is the table)
+            cur ^= 1;
+            n_cur = n_next;
+            ++chars;
+        }
+        if (chars < 2) {
+            cleanup();
+            return;
+        }
+        // the table: kSuffixGroup columns of slots (fm_suffix_home)
+        uint32_t columns[fmx::kSuffixGroup] = {0};
+        if (hipMemset(d_count, 0, 4 * fmx::kSuffixGroup) != hipSuccess ||
+            fmx::launch_suffix_columns(level[cur], n_cur, (chars - 1) * key_bits, d_count, nullptr) != 0 ||
+            hipMemcpy(columns, d_count, sizeof columns, hipMemcpyDeviceToHost) != hipSuccess) {
+            cleanup();
+            return;
+        }
+        uint64_t fullest = 0;
+        for (uint32_t v : columns) fullest = std::max<uint64_t>(fullest, v);
+        slots64 = 1024;
+        // twice as many slots as strings, and the fullest column half full (probing stays inside a column: 0.8 % of the headline
+        // batch's step) — or, where that would pass an eighth of the image, room for the fullest column with a quarter to spare
+        while (slots64 < 2 * (uint64_t)n_cur || 4 * slots64 < 5 * fmx::kSuffixGroup * fullest) slots64 <<= 1;
+        const uint64_t table_max = std::max<uint64_t>(budget, 1 << 20);  // the budget holds for the table itself as well
+        {
+            uint64_t roomy = slots64;
+            while (roomy < 2 * fmx::kSuffixGroup * fullest) roomy <<= 1;
+            if (roomy * sizeof(fmx::SuffixSlot) <= idx->d_len / 8 && roomy * sizeof(fmx::SuffixSlot) <= table_max) slots64 = roomy;
+        }
+        if (slots64 * sizeof(fmx::SuffixSlot) <= table_max && slots64 <= 0x40000000u) break;
     }
     const uint32_t slots = (uint32_t)slots64;
     int log2_slots = 0;
@@ -1239,8 +1274,10 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
     std::atomic<int32_t> issued{0};
     std::atomic<bool> stop{false};
     std::atomic<int> out_error{0};
-    auto drain = [&]() {
-        for (int i = 0; i < kPipeStreams; ++i) (void)hipStreamSynchronize(ps->s[i]);
+    auto drain = [&]() {  // false: a stream ended with an error (a failed kernel or copy of one of the last chunks)
+        bool ok = true;
+        for (int i = 0; i < kPipeStreams; ++i) ok = (hipStreamSynchronize(ps->s[i]) == hipSuccess) && ok;
+        return ok;
     };
     struct DrainOnExit {  // declared after the buffers, before the threads: threads are joined, then the streams drained, then
         PipeStreams *ps;  // the blocks go back to their caches
@@ -1402,7 +1439,12 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
     stop = true;
     if (helper.joinable()) helper.join();
     const double t_joined = now();
-    drain();  // (also on failure: the per-call blocks go back to the cache when this call ends, nothing may still use them)
+    // registered result arrays: nobody has waited for the chunks whose event slot was never reused (all of them, for
+    // fewer than kPipeEvents chunks) — wait for each stage here, so that a failed one is reported instead of FMX_OK
+    if (direct_out && !failed)
+        for (int32_t b = copied.load(); b < issued.load(); ++b) copy_out(b);
+    // (also on failure: the per-call blocks go back to the cache when this call ends, nothing may still use them)
+    if (!drain()) out_error = 1;
     if (timing)
         fprintf(stderr, "[fmx pipe] %d chunks: alloc %.0f us | scan %.0f | copy-in calls %.0f | kernel launches %.0f | copy-out calls %.0f | "
                         "issue loop %.0f | helper join +%.0f | drain +%.0f (direct_out %d)\n",

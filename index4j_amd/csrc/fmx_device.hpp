@@ -1183,7 +1183,8 @@ FMX_HD bool fm_suffix_key(const DevIndex &ix, CodeAt code_at, uint64_t &key) {
         known = known && cj != 0;
         key |= (uint64_t)cj << (j * ix.suffix_key_bits);
     }
-    return known;
+    // (eight codes of 255 / four of 65,535 spell the free slot's mark: that one string takes the loop)
+    return known && key != kSuffixEmpty;
 }
 
 // FM:526-548 for one hit: SA row i = start + 1 + k; LF-walk until a sampled row.

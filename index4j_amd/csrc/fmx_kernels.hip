@@ -441,6 +441,7 @@ __global__ __launch_bounds__(256) void k_suffix_expand(DevIndex ix, const Suffix
     const uint32_t sigma1 = (uint32_t)ix.wt_sigma - 1u;  // codes 1 .. sigma - 1
     const uint64_t work = (uint64_t)n_in * sigma1;
     for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < work; t += (uint64_t)gridDim.x * 256) {
+        if (*reinterpret_cast<volatile uint32_t *>(count) > cap) return;  // the level no longer fits: it will be dropped
         const uint32_t i = (uint32_t)(t / sigma1);
         const int32_t c = (int32_t)(t - (uint64_t)i * sigma1) + 1;
         if (c + 1 >= ix.n_c) continue;
@@ -456,6 +457,7 @@ __global__ __launch_bounds__(256) void k_suffix_insert(DevIndex ix, const Suffix
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_in) return;
     const SuffixSlot me = in[i];
+    if (me.key == kSuffixEmpty) return;  // the one key that reads as a free slot is never tabulated (fm_suffix_key)
     uint32_t h = fm_suffix_home(ix, me.key);
     for (uint32_t probe = 0; probe <= ix.suffix_mask / kSuffixGroup; ++probe, h = (h + kSuffixGroup) & ix.suffix_mask) {
         unsigned long long *key = reinterpret_cast<unsigned long long *>(&slots[h].key);
@@ -1163,7 +1165,9 @@ int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_
     const PlanRec *recs = (plan && plan->recs && plan->n == n) ? static_cast<const PlanRec *>(plan->recs) : nullptr;
     CountPlan none;
     const CountPlan &pl = recs ? *plan : none;
-    const bool translate = recs && plan_is_foreign && pl.code_bits == 8;
+    // a foreign plan's 8-bit code words can be translated only if THIS index's codes fit 8 bits as well: refilled chunks are
+    // made with this index's own alphabet at the kernel's code width (a 300-symbol segment beside an ASCII segment 0)
+    const bool translate = recs && plan_is_foreign && pl.code_bits == 8 && plan_code_bits(ix.wt_sigma) == 8;
     const int mode = !recs ? 0 : (!plan_is_foreign ? 1 : (translate ? 2 : 3));
     DevIndex ix_launch = ix;
     if (!g_suffix_table_use) ix_launch.suffix_table = nullptr;  // (A/B: the same index without its table)

@@ -243,4 +243,11 @@ def test_pipelined_host_buffer_count_from_threads_with_plain_and_registered_arra
         b = bad if nn == n else np.array([0, 8, 4] + [8] * (nn - 2), np.int32)
         rc = ia.lib.fmx_count_batch(fm.handle, work[1][0].ctypes.data, b.ctypes.data, nn, cnt.ctypes.data, None, None)
         assert rc == -1 and b"offsets" in ia.lib.fmx_last_error()
+    # a pair of offsets whose int32 differences wrap to non-negative values (8, 2e9, -2e9, 16: the middle difference is
+    # +294,967,296 in 32 bits) with both chunk ends in range: rejected by the pipelined path too, nothing launched
+    wrap = work[1][1].copy()
+    wrap[300_001] = 2_000_000_000
+    wrap[300_002] = -2_000_000_000
+    rc = ia.lib.fmx_count_batch(fm.handle, work[1][0].ctypes.data, wrap.ctypes.data, n, cnt.ctypes.data, None, None)
+    assert rc == -1 and b"offsets" in ia.lib.fmx_last_error()
     fm.close()

@@ -427,6 +427,57 @@ def test_segment_set_count_and_locate_vs_oracle_and_brute_force():
                 assert (t16[x:x + len(p)] == p).all()
 
 
+def test_segment_set_with_mixed_alphabet_sizes_long_patterns():
+    """segment 0 is plain ASCII (8-bit code words in its plan), segment 1 holds more than 256 symbols, segment 2 is ASCII
+    again: the batch's plan is made with segment 0 and reused by the others, so a segment whose codes need 16 bits must not
+    take the 8-bit translated route (codes >= 256 were OR-ed into 8-bit fields for patterns longer than the
+    record's code word).  Patterns of 9..31 chars, a batch large enough for the planned path; counts and located hits
+    against one oracle per segment"""
+    rnd = random.Random(777)
+    n = 60_000
+    ascii_a = np.array([rnd.randrange(97, 123) if rnd.random() < 0.93 else 10 for _ in range(n)], dtype=np.uint16)
+    wide = np.array([rnd.randrange(0x400, 0x400 + 600) if rnd.random() < 0.5 else rnd.randrange(97, 123) for _ in range(n)],
+                    dtype=np.uint16)
+    wide[::50] = 10
+    ascii_b = np.array([rnd.randrange(97, 110) if rnd.random() < 0.9 else 10 for _ in range(n)], dtype=np.uint16)
+    parts = [ascii_a, wide, ascii_b]
+    segs = [ia.FmIndex(t, 16, True, device=0) for t in parts]
+    assert segs[0].getAlphabetLength() <= 256 < segs[1].getAlphabetLength() and segs[2].getAlphabetLength() <= 256
+    bases = np.cumsum([0] + [len(t) for t in parts[:-1]])
+    sf = ia.SegmentedFmIndex.from_segments(segs, bases)
+    oracles = [orc.OracleFmIndex(t, 16, True) for t in parts]
+    N = 30_000
+    pats = []
+    for i in range(N):
+        t = parts[i % 3]
+        s0 = rnd.randrange(len(t) - 32)
+        p = t[s0:s0 + rnd.randrange(9, 32)].copy()
+        if i % 7 == 0:  # a tail from another segment's alphabet: long, mostly absent
+            o = parts[(i + 1) % 3]
+            k = rnd.randrange(1, 6)
+            p[-k:] = o[s0:s0 + k]
+        pats.append(p)
+    ch, off = ia.pack_patterns(pats)
+    cnt, st, lf = sf.count_batch(ch, off, want_steps=True)
+    exp = np.zeros(N, np.int64)
+    for o in oracles:
+        oc, ost = o.count_batch(ch, off, threads=8)
+        assert int(ost.max()) == 0
+        exp += oc
+    assert (st == 0).all()
+    bad = np.flatnonzero(cnt != exp)
+    assert len(bad) == 0, (len(bad), bad[:5], cnt[bad[:5]], exp[bad[:5]])
+    assert int(exp.sum()) >= N // 2  # the batch really matches
+    locs, found, st2 = sf.locate_batch(ch, off, 3)
+    for i in range(0, N, 29):
+        e = []
+        for o, base in zip(oracles, bases):
+            k, l = o.locate(pats[i], max_matches=3, cap=3)
+            e.extend(int(x) + int(base) for x in l)
+        e = e[:3]
+        assert found[i] == len(e) and list(locs[i, :found[i]]) == e, i
+
+
 @pytest.mark.parametrize("sigma", [40, 255, 256, 700])
 def test_planned_batches_vs_oracle_across_alphabet_sizes(sigma):
     """batches large enough to take the planned path (suffix order + per-pattern code words, 8 codes of 8 bits
