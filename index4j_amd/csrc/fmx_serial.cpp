@@ -241,25 +241,40 @@ std::vector<int> hashmap_order(const FmModel &m) {
 // FM:983-1025.  Returns 0, or 1 truncated / 2 version / 3 malformed.
 int parse_model(const uint8_t *buf, size_t len, FmModel &m, std::string &err) {
     std::vector<uint8_t> plain;
+    bool corrupt_tail = false;
     if (len >= 4 && buf[0] == 0xAC && buf[1] == 0xED && buf[2] == 0x00 && buf[3] == 0x05) {  // SER:89-100
         plain.reserve(len);
+        // ObjectInputStream's block-data reader (java.io.ObjectInputStream.BlockDataInputStream.readBlockHeader / refill), which
+        // works LAZILY — a header is only looked at when FmIndex.read asks for bytes the earlier records did not hold:
+        // payloads of TC_BLOCKDATA 0x77 <u8 len> and TC_BLOCKDATALONG 0x7A <i32 len> records are one byte sequence (a
+        // primitive may straddle records; empty records are legal); TC_RESET 0x79 may stand between records; any other tag
+        // ends the block data (EOFException for a reader that wants more); a negative long length is a
+        // StreamCorruptedException for a reader that gets that far.  So: gather what is well-formed, parse, and let the
+        // parser's "truncated" become "malformed" when the payload ended at a corrupt header.
         size_t pos = 4;
         while (pos < len) {
             size_t bl;
-            if (buf[pos] == 0x77 && pos + 2 <= len) {
+            if (buf[pos] == 0x79) {
+                ++pos;
+                continue;
+            }
+            if (buf[pos] == 0x77) {
+                if (pos + 2 > len) break;
                 bl = buf[pos + 1];
                 pos += 2;
-            } else if (buf[pos] == 0x7A && pos + 5 <= len) {
+            } else if (buf[pos] == 0x7A) {
+                if (pos + 5 > len) break;
+                if (buf[pos + 1] & 0x80) {
+                    corrupt_tail = true;
+                    break;
+                }
                 bl = ((size_t)buf[pos + 1] << 24) | ((size_t)buf[pos + 2] << 16) | ((size_t)buf[pos + 3] << 8) | buf[pos + 4];
                 pos += 5;
             } else {
-                err = "unexpected record tag in ObjectOutputStream framing";
-                return 3;
+                corrupt_tail = buf[pos] < 0x70 || buf[pos] > 0x7E;  // not a type code at all (TC_BASE .. TC_MAX)
+                break;
             }
-            if (pos + bl > len) {
-                err = "truncated block-data record";
-                return 1;
-            }
+            if (bl > len - pos) bl = len - pos;  // a record cut short by the end of the buffer holds what it holds
             plain.insert(plain.end(), buf + pos, buf + pos + bl);
             pos += bl;
         }
@@ -292,6 +307,7 @@ int parse_model(const uint8_t *buf, size_t len, FmModel &m, std::string &err) {
     read_rrr(r, m.sampled);
     read_wavelet(r, m.wt);
     if (!r.err && (m.sample_rate <= 0 || m.length <= 0)) r.err = 3;
+    if (r.err == 1 && corrupt_tail) r.err = 3;
     if (r.err) {
         // SER:35-36: "Incompatible serial versions! Expected version %d but was %d."
         err = r.err == 2 ? "Incompatible serial versions! Expected version 0 but was " + std::to_string(r.bad_version) + "."

@@ -2237,27 +2237,37 @@ static OrcWfbb *wfbb_read(IBuf *b) { /* WFBB:286-322, 1630-1649, 1597-1605 */
  * *status: 0 ok, 1 truncated, 2 "Incompatible serial versions!", 3 malformed. */
 OrcFmIndex *orc_fm_read(const uint8_t *buf, size_t len, int *status) {
     uint8_t *plain = NULL;
+    int corrupt_tail = 0;
     if (len >= 4 && buf[0] == 0xAC && buf[1] == 0xED && buf[2] == 0x00 && buf[3] == 0x05) {
         plain = (uint8_t *)xmalloc(len);
+        /* java.io.ObjectInputStream.BlockDataInputStream.readBlockHeader, read lazily as FmIndex.read pulls bytes:
+         * TC_BLOCKDATA 0x77 <u8>, TC_BLOCKDATALONG 0x7A <i32 >= 0>, TC_RESET 0x79 skipped between records; anything else
+         * ends the block data.  What is well-formed is gathered; a reader that needs more gets "truncated" (1), or
+         * "malformed" (3) when the payload ended at a corrupt header. */
         size_t pos = 4, out = 0;
         while (pos < len) {
             size_t bl;
-            if (buf[pos] == 0x77 && pos + 2 <= len) {
+            if (buf[pos] == 0x79) {
+                ++pos;
+                continue;
+            }
+            if (buf[pos] == 0x77) {
+                if (pos + 2 > len) break;
                 bl = buf[pos + 1];
                 pos += 2;
-            } else if (buf[pos] == 0x7A && pos + 5 <= len) {
+            } else if (buf[pos] == 0x7A) {
+                if (pos + 5 > len) break;
+                if (buf[pos + 1] & 0x80) {
+                    corrupt_tail = 1;
+                    break;
+                }
                 bl = ((size_t)buf[pos + 1] << 24) | ((size_t)buf[pos + 2] << 16) | ((size_t)buf[pos + 3] << 8) | buf[pos + 4];
                 pos += 5;
             } else {
-                free(plain);
-                if (status) *status = 3;
-                return NULL;
+                corrupt_tail = buf[pos] < 0x70 || buf[pos] > 0x7E;
+                break;
             }
-            if (pos + bl > len) {
-                free(plain);
-                if (status) *status = 1;
-                return NULL;
-            }
+            if (bl > len - pos) bl = len - pos;
             memcpy(plain + out, buf + pos, bl);
             out += bl;
             pos += bl;
@@ -2300,7 +2310,7 @@ OrcFmIndex *orc_fm_read(const uint8_t *buf, size_t len, int *status) {
     if (status) *status = 0;
     return f;
 bad:
-    if (status) *status = b.err ? b.err : 3;
+    if (status) *status = b.err ? ((b.err == 1 && corrupt_tail) ? 3 : b.err) : 3;
     free(plain);
     orc_fm_free(f);
     return NULL;
