@@ -738,7 +738,6 @@ def run_count(ctx, args):
                    "count_checksums_rank0": checksums, "count_checksum": checksums[0],
                    "gathered_checksum_all_ranks": int(gathered.astype(np.int64).sum()) if gathered is not None else None,
                    "oracle_checksum_batch0_all_ranks": oracle_checksum, "patterns_checked_vs_oracle": oracle_checked},
-        "count_split_min": 524288 if args.count_split_min is None else args.count_split_min,
         "suffix_table": None if ctx.dry else {
             "chars": table_chars, "bytes": table_bytes,
             "what": "SA interval of every string of `chars` codes that occurs in the text, grown level by level by the index's own "
@@ -1245,9 +1244,6 @@ def main():
                          "table, two batches in flight), so that per-kernel averages and counters describe the timed path only")
     ap.add_argument("--overlap-streams", type=int, default=2,
                     help="streams of the extra `overlapped` measurement (batches in flight); 1 = skip it")
-    ap.add_argument("--count-split-min", type=int, default=None,
-                    help="library option count_split_min (A/B): device-pointer count batches of at least this many patterns run as two "
-                         "halves on two streams inside one call; 0 = one plan + one k_count launch per call")
     ap.add_argument("--share-one-gpu", action="store_true",
                     help="REHEARSAL of the N > 1 code path on a one-GPU box: every rank queries on cuda:0, collectives run "
                          "over gloo on host tensors.  The line says so (`rehearsal`); it is not a measurement.")
@@ -1268,8 +1264,6 @@ def main():
 
     import index4j_amd as ia
 
-    if args.count_split_min is not None:
-        check_rc(ia, ia.lib.fmx_set_option(b"count_split_min", args.count_split_min), "fmx_set_option")
     ctx = Ctx()
     ctx.ia, ctx.torch, ctx.dry = ia, torch, args.dry_run
     ctx.world, ctx.rank = world, int(os.environ.get("RANK", "0"))

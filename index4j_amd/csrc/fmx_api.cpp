@@ -82,13 +82,6 @@ struct fmx_index {
     // erased whenever anything else plans on the stream or its plan scratch moves: a stale handle then simply
     // means "the caller's order" (k_count maps the characters itself) instead of reading another batch's records
     mutable std::map<void *, Plan> plans;
-    // A large device-pointer count batch runs as two halves: the second half's plan + k_count go to a side stream of the
-    // caller's stream, forked and joined by events (count_impl).  One set per caller stream, made on first use.
-    struct SideStream {
-        hipStream_t stream = nullptr;
-        hipEvent_t fork = nullptr, join = nullptr;
-    };
-    mutable std::map<void *, SideStream> side_streams;
 };
 
 namespace {
@@ -100,9 +93,6 @@ std::atomic<int> g_suffix_table_chars{4};  // option "suffix_table_chars": its d
 // host-buffer count(): batches of at least this many patterns go through the pipeline (smaller ones: one copy in, kernels, one copy out)
 std::atomic<int> g_host_pipeline_min{131072};
 std::atomic<int> g_host_pipeline_chunk{262144};  // patterns per stage of that pipeline
-// device-pointer count(): batches of at least this many patterns run as two halves on two streams, so that one half's plan
-// stage overlaps the other's k_count inside ONE call (0 = never)
-std::atomic<int> g_count_split_min{524288};
 std::atomic<int> g_sb_cache_limit{320};  // option "sb_cache_limit": applies to indexes made resident afterwards (tests: 0 = no LDS cache)
 int fail(int code, const std::string &msg) {
     g_err = msg;
@@ -456,11 +446,6 @@ int fmx_set_option(const char *name, int value) {
         g_host_pipeline_min = value;
         return FMX_OK;
     }
-    if (name && !strcmp(name, "count_split_min")) {
-        if (value < 0) return fail(FMX_E_ARG, "bad value");
-        g_count_split_min = value;
-        return FMX_OK;
-    }
     if (name && !strcmp(name, "host_pipeline_chunk")) {
         if (value < 65536) return fail(FMX_E_ARG, "bad value");
         g_host_pipeline_chunk = value;
@@ -578,14 +563,6 @@ void fmx_free_buffer(uint8_t *buf) { free(buf); }
 void fmx_free(fmx_index *idx) {
     if (!idx) return;
     if (idx->device >= 0) (void)hipSetDevice(idx->device);
-    for (auto &kv : idx->side_streams) {  // (their work was joined into the callers' streams; drained before the blocks go)
-        if (kv.second.stream) {
-            (void)hipStreamSynchronize(kv.second.stream);
-            (void)hipStreamDestroy(kv.second.stream);
-        }
-        if (kv.second.fork) (void)hipEventDestroy(kv.second.fork);
-        if (kv.second.join) (void)hipEventDestroy(kv.second.join);
-    }
     for (auto &kv : idx->ws)
         if (kv.second.first) (void)hipFree(kv.second.first);
     if (idx->owns_device && idx->d_blob) (void)hipFree(idx->d_blob);
@@ -914,70 +891,11 @@ int fmx_count_ordered_dev(const fmx_index *idx, const uint16_t *d_pat, const int
     });
 }
 
-// the side stream of a caller's stream (fmx_index::SideStream), made on first use
-static int side_stream_of(const fmx_index *idx, void *stream, fmx_index::SideStream *out) {
-    std::lock_guard<std::mutex> lock(idx->ws_mutex);
-    auto it = idx->side_streams.find(stream);
-    if (it == idx->side_streams.end()) {
-        fmx_index::SideStream s;
-        hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.fork, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.join, hipEventDisableTiming);
-        if (e != hipSuccess) {
-            if (s.stream) (void)hipStreamDestroy(s.stream);
-            if (s.fork) (void)hipEventDestroy(s.fork);
-            if (s.join) (void)hipEventDestroy(s.join);
-            return fail(FMX_E_HIP, std::string("side stream: ") + hipGetErrorString(e));
-        }
-        it = idx->side_streams.emplace(stream, s).first;
-    }
-    *out = it->second;
-    return FMX_OK;
-}
-
-// One call, two halves (device-pointer batches of >= count_split_min patterns): the plan stage is a quarter of a batch's time
-// and nothing of the same batch can run beside it — but the OTHER half's k_count can.  Half A stays on the caller's stream,
-// half B goes to the stream's side stream (forked after everything the caller queued, joined before anything it queues
-// next), issue order plan A, plan B, count A, count B.  Results are those of one launch: every pattern is searched on its own.
-static int count_split(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n, int32_t *d_counts,
-                       int32_t *d_lf_steps, int32_t *d_status, Scratch &scratch) {
-    fmx_index::SideStream side;
-    int rc = side_stream_of(idx, scratch.stream, &side);
-    if (rc) return rc;
-    hipStream_t st = static_cast<hipStream_t>(scratch.stream);
-    const int32_t h = (n / 2 + 63) & ~63;  // whole waves of lane pairs in the first half
-    Scratch scratch_b(idx, side.stream, false);
-    HIP_TRY(hipEventRecord(side.fork, st));
-    HIP_TRY(hipStreamWaitEvent(side.stream, side.fork, 0));
-    fmx::CountPlan plan_a, plan_b;
-    rc = plan_order(idx, d_pat, d_pat_off, h, scratch, &plan_a);
-    if (!rc) rc = plan_order(idx, d_pat, d_pat_off + h, n - h, scratch_b, &plan_b);
-    int e = 0;
-    if (!rc) {
-        e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, &plan_a, false, h, d_counts, d_lf_steps, d_status, nullptr, st);
-        if (!e)
-            e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off + h, &plan_b, false, n - h, d_counts + h,
-                                  d_lf_steps ? d_lf_steps + h : nullptr, d_status ? d_status + h : nullptr, nullptr, side.stream);
-    }
-    // joined whatever happened: the caller's stream must not run ahead of work already queued on the side stream
-    hipError_t je = hipEventRecord(side.join, side.stream);
-    if (je == hipSuccess) je = hipStreamWaitEvent(st, side.join, 0);
-    if (rc) return rc;
-    if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
-    if (je != hipSuccess) return fail(FMX_E_HIP, std::string("joining the side stream: ") + hipGetErrorString(je));
-    return FMX_OK;
-}
-
 static int count_impl(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n, int32_t *d_counts,
                       int32_t *d_lf_steps, int32_t *d_status, Scratch &scratch) {
     int rc = require_device(idx);
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!d_pat_off || !d_counts))) return fail(FMX_E_ARG, "bad arguments");
-    {
-        const int split_min = g_count_split_min.load();
-        if (!scratch.per_call && split_min > 0 && n >= split_min && n >= 128)
-            return count_split(idx, d_pat, d_pat_off, n, d_counts, d_lf_steps, d_status, scratch);
-    }
     fmx::CountPlan plan;
     rc = plan_order(idx, d_pat, d_pat_off, n, scratch, &plan);
     if (rc) return rc;

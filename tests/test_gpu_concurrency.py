@@ -246,8 +246,8 @@ def test_pipelined_host_buffer_count_from_threads_with_plain_and_registered_arra
     # a pair of offsets whose int32 differences wrap to non-negative values (8, 2e9, -2e9, 16: the middle difference is
     # +294,967,296 in 32 bits) with both chunk ends in range: rejected by the pipelined path too, nothing launched
     wrap = work[1][1].copy()
-    wrap[300_001] = 2_000_000_000
-    wrap[300_002] = -2_000_000_000
+    wrap[280_001] = 2_000_000_000
+    wrap[280_002] = -2_000_000_000
     rc = ia.lib.fmx_count_batch(fm.handle, work[1][0].ctypes.data, wrap.ctypes.data, n, cnt.ctypes.data, None, None)
     assert rc == -1 and b"offsets" in ia.lib.fmx_last_error()
     fm.close()
