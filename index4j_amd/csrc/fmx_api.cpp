@@ -25,8 +25,7 @@
 namespace fmx {
 int launch_suffix_level1(const DevIndex &, SuffixSlot *, uint32_t *, uint32_t, hipStream_t);
 int launch_suffix_expand(const DevIndex &, int, const SuffixSlot *, uint32_t, int, int, SuffixSlot *, uint32_t *, uint32_t, hipStream_t);
-int launch_suffix_insert(const DevIndex &, const SuffixSlot *, uint32_t, SuffixSlot *, hipStream_t);
-int launch_suffix_columns(const SuffixSlot *, uint32_t, int, uint32_t *, hipStream_t);
+int launch_suffix_insert(const DevIndex &, const SuffixSlot *, uint32_t, int, SuffixSlot *, hipStream_t);
 int launch_count_plan(const DevIndex &, const uint16_t *, const int32_t *, int32_t, void *, size_t, bool, CountPlan *,
                       hipStream_t);
 int launch_count(const DevIndex &, int, const uint16_t *, const int32_t *, const CountPlan *, bool, int32_t, int32_t *,
@@ -89,7 +88,8 @@ namespace {
 thread_local std::string g_err;
 std::atomic<int> g_wavelet_on_device{1};  // option "wavelet_on_device": 0 = fmx_build_on_device encodes the wavelet tree on the host
 std::atomic<int> g_suffix_table_mb{256};  // option "suffix_table_mb": budget of the suffix table of indexes made resident afterwards (0 = none)
-std::atomic<int> g_suffix_table_chars{4};  // option "suffix_table_chars": its depth (characters; the budget and the key width may cut it)
+std::atomic<int> g_suffix_table_chars{8};  // option "suffix_table_chars": its depth (characters; the size limit and the key width may cut it)
+std::atomic<int> g_suffix_table_image_fraction{8};  // option "suffix_table_image_fraction": the table stays below image / this (0 = only the budget counts)
 // host-buffer count(): batches of at least this many patterns go through the pipeline (smaller ones: one copy in, kernels, one copy out)
 std::atomic<int> g_host_pipeline_min{131072};
 std::atomic<int> g_host_pipeline_chunk{262144};  // patterns per stage of that pipeline
@@ -456,6 +456,11 @@ int fmx_set_option(const char *name, int value) {
         g_suffix_table_chars = value;
         return FMX_OK;
     }
+    if (name && !strcmp(name, "suffix_table_image_fraction")) {  // the table stays below image bytes / value (0: only the budget counts)
+        if (value < 0) return fail(FMX_E_ARG, "bad value");
+        g_suffix_table_image_fraction = value;
+        return FMX_OK;
+    }
     if (name && !strcmp(name, "wavelet_on_device")) {
         g_wavelet_on_device = value != 0;
         return FMX_OK;
@@ -579,10 +584,11 @@ int32_t fmx_extract_enabled(const fmx_index *idx) {
     return idx->has_model ? (idx->model.enable_extract ? 1 : 0) : idx->hdr.enable_extract;
 }
 
-// The suffix table of a resident FM-index (fmx_device.hpp): grown level by level on the device — the strings of k codes
-// that occur in the text, each with its SA interval — up to `suffix_table_chars` characters (what a key of 64 bits holds at
-// most: 8 codes of 8 bits, 4 of 16), or as deep as the budget `suffix_table_mb` carries (32 bytes per string: a slot of 16
-// in a table of twice as many slots).  Then hashed.  Not having one is never an error.
+// The suffix table of a resident FM-index (fmx_device.hpp): grown level by level on the device — the strings of 2, 3, ... codes
+// that occur in the text, each with its SA interval — and ALL levels hashed into one table of 16-byte slots (a pattern shorter
+// than the deepest level still finds its whole search there).  How deep: option `suffix_table_chars` (default 8; at most what
+// a 64-bit key holds: 8 codes of 8 bits, 4 of 16), cut where the table would pass its size limit = the smaller of the budget
+// `suffix_table_mb` and 1 / `suffix_table_image_fraction` of the image (default an eighth).  Not having one is never an error.
 static void build_suffix_table(fmx_index *idx) {
     if (idx->d_suffix_table) {
         (void)hipFree(idx->d_suffix_table);
@@ -600,88 +606,81 @@ static void build_suffix_table(fmx_index *idx) {
     int max_chars = g_suffix_table_chars.load();
     if (max_chars > 64 / key_bits) max_chars = 64 / key_bits;
     if (budget == 0 || max_chars < 2 || idx->hdr.wt_sigma < 2) return;
-    // strings of a level: never more than the text has characters, nor than the budget carries
-    uint64_t cap64 = std::min<uint64_t>(budget / 32, (uint64_t)(uint32_t)idx->hdr.length);
+    uint64_t limit = budget;
+    if (const int frac = g_suffix_table_image_fraction.load(); frac > 0)
+        limit = std::min<uint64_t>(limit, std::max<uint64_t>(idx->d_len / (uint64_t)frac, 64 << 10));
+    // slots for a set of strings: a power of two, half full at most — or, where only that keeps the table inside its limit, 0.7
+    auto slots_for = [&](uint64_t strings) {
+        uint64_t slots = 1024;
+        while (slots < 2 * strings) slots <<= 1;
+        if (slots * sizeof(fmx::SuffixSlot) > limit && slots / 2 >= 1024 && 10 * strings <= 7 * (slots / 2)) slots >>= 1;
+        return slots;
+    };
+    // strings of all levels together: never more than the limit carries at 0.7 load, nor 2^30
+    uint64_t cap64 = limit / sizeof(fmx::SuffixSlot) * 7 / 10;
     if (cap64 < 1024) cap64 = 1024;
-    if (cap64 > 0x7fffffffu) cap64 = 0x7fffffffu;
+    if (cap64 > 0x3fffffffu) cap64 = 0x3fffffffu;
     const uint32_t cap = (uint32_t)cap64;
-    fmx::SuffixSlot *level[2] = {nullptr, nullptr};
+    const uint32_t cap1 = (uint32_t)idx->hdr.wt_sigma;  // level 1: the characters (never inserted: cumulativeCounts has them)
+    fmx::SuffixSlot *level1 = nullptr, *all = nullptr;
     uint32_t *d_count = nullptr;
     void *d_slots = nullptr;
     auto cleanup = [&]() {
         (void)hipGetLastError();
-        for (auto *p : level)
-            if (p) (void)hipFree(p);
+        if (level1) (void)hipFree(level1);
+        if (all) (void)hipFree(all);
         if (d_count) (void)hipFree(d_count);
     };
-    if (hipMalloc(reinterpret_cast<void **>(&level[0]), (size_t)cap * sizeof(fmx::SuffixSlot)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&level[1]), (size_t)cap * sizeof(fmx::SuffixSlot)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&d_count), 4 * fmx::kSuffixGroup + 64) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void **>(&level1), (size_t)cap1 * sizeof(fmx::SuffixSlot)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&all), (size_t)cap * sizeof(fmx::SuffixSlot)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&d_count), 64) != hipSuccess) {
         cleanup();
         return;
     }
     auto counted = [&](uint32_t *out) {  // the level's size, once its kernel has finished
         return hipMemcpy(out, d_count, 4, hipMemcpyDeviceToHost) == hipSuccess;
     };
-    uint32_t n_cur = 0;
-    int chars = 0, cur = 0;
-    uint64_t slots64 = 0;
+    uint32_t n_prev = 0;
+    if (hipMemset(d_count, 0, 64) != hipSuccess || fmx::launch_suffix_level1(idx->dev, level1, d_count, cap1, nullptr) != 0 ||
+        !counted(&n_prev) || n_prev == 0 || n_prev > cap1) {
+        cleanup();
+        return;
+    }
     // work of one level = strings x (sigma - 1) rank pairs, most of them of absent characters: bounded, so that a large
     // alphabet (sigma up to 32,767) does not spend tens of seconds on a level that is thrown away in the end
     constexpr uint64_t kLevelWorkMax = 1ull << 35;
-    // grown to `limit` characters, then sized; a table that would pass the budget (a lopsided alphabet asks for many more
-    // slots than strings) is grown again one character shallower
-    for (int limit = max_chars;; limit = chars - 1) {
-        if (limit < 2) {
+    uint32_t begin[10] = {0};  // strings of `len` codes: all[begin[len] .. begin[len + 1])
+    const fmx::SuffixSlot *prev = level1;
+    uint32_t total = 0;
+    int chars = 1;
+    while (chars < max_chars) {
+        if ((uint64_t)n_prev * (uint64_t)(idx->hdr.wt_sigma - 1) > kLevelWorkMax) break;
+        const uint32_t room = cap - total;
+        uint32_t n_next = 0;
+        if (room == 0) break;
+        if (hipMemset(d_count, 0, 64) != hipSuccess ||
+            fmx::launch_suffix_expand(idx->dev, idx->n_cu, prev, n_prev, chars, key_bits, all + total, d_count, room, nullptr) != 0 ||
+            !counted(&n_next)) {
             cleanup();
             return;
         }
-        cur = 0;
-        if (hipMemset(d_count, 0, 64) != hipSuccess || fmx::launch_suffix_level1(idx->dev, level[0], d_count, cap, nullptr) != 0 ||
-            !counted(&n_cur) || n_cur == 0 || n_cur > cap) {
-            cleanup();
-            return;
-        }
-        chars = 1;
-        while (chars < limit) {
-            uint32_t n_next = 0;
-            if ((uint64_t)n_cur * (uint64_t)(idx->hdr.wt_sigma - 1) > kLevelWorkMax) break;
-            if (hipMemset(d_count, 0, 64) != hipSuccess ||
-                fmx::launch_suffix_expand(idx->dev, idx->n_cu, level[cur], n_cur, chars, key_bits, level[cur ^ 1], d_count, cap, nullptr) != 0 ||
-                !counted(&n_next)) {
-                cleanup();
-                return;
-            }
-            if (n_next == 0 || n_next > cap) break;  // (the next level does not fit: this one is the table)
-            cur ^= 1;
-            n_cur = n_next;
-            ++chars;
-        }
-        if (chars < 2) {
-            cleanup();
-            return;
-        }
-        // the table: kSuffixGroup columns of slots (fm_suffix_home)
-        uint32_t columns[fmx::kSuffixGroup] = {0};
-        if (hipMemset(d_count, 0, 4 * fmx::kSuffixGroup) != hipSuccess ||
-            fmx::launch_suffix_columns(level[cur], n_cur, (chars - 1) * key_bits, d_count, nullptr) != 0 ||
-            hipMemcpy(columns, d_count, sizeof columns, hipMemcpyDeviceToHost) != hipSuccess) {
-            cleanup();
-            return;
-        }
-        uint64_t fullest = 0;
-        for (uint32_t v : columns) fullest = std::max<uint64_t>(fullest, v);
-        slots64 = 1024;
-        // twice as many slots as strings, and the fullest column half full (probing stays inside a column: 0.8 % of the headline
-        // batch's step) — or, where that would pass an eighth of the image, room for the fullest column with a quarter to spare
-        while (slots64 < 2 * (uint64_t)n_cur || 4 * slots64 < 5 * fmx::kSuffixGroup * fullest) slots64 <<= 1;
-        const uint64_t table_max = std::max<uint64_t>(budget, 1 << 20);  // the budget holds for the table itself as well
-        {
-            uint64_t roomy = slots64;
-            while (roomy < 2 * fmx::kSuffixGroup * fullest) roomy <<= 1;
-            if (roomy * sizeof(fmx::SuffixSlot) <= idx->d_len / 8 && roomy * sizeof(fmx::SuffixSlot) <= table_max) slots64 = roomy;
-        }
-        if (slots64 * sizeof(fmx::SuffixSlot) <= table_max && slots64 <= 0x40000000u) break;
+        // (the next level does not fit, or its table would pass the limit: the levels so far are the table)
+        if (n_next == 0 || n_next > room || slots_for((uint64_t)total + n_next) * sizeof(fmx::SuffixSlot) > limit) break;
+        ++chars;
+        begin[chars] = total;
+        prev = all + total;
+        n_prev = n_next;
+        total += n_next;
+        begin[chars + 1] = total;
+    }
+    if (chars < 2) {
+        cleanup();
+        return;
+    }
+    const uint64_t slots64 = slots_for(total);
+    if (slots64 * sizeof(fmx::SuffixSlot) > std::max<uint64_t>(limit, 16 << 10) || slots64 > 0x40000000u) {
+        cleanup();
+        return;
     }
     const uint32_t slots = (uint32_t)slots64;
     int log2_slots = 0;
@@ -690,10 +689,12 @@ static void build_suffix_table(fmx_index *idx) {
     geometry.suffix_chars = chars;
     geometry.suffix_shift = (uint32_t)(64 - (log2_slots - fmx::kSuffixGroupLog2));  // whole groups
     geometry.suffix_mask = slots - 1;
-    if (hipMalloc(&d_slots, (size_t)slots * sizeof(fmx::SuffixSlot)) != hipSuccess ||
-        hipMemset(d_slots, 0xff, (size_t)slots * sizeof(fmx::SuffixSlot)) != hipSuccess ||
-        fmx::launch_suffix_insert(geometry, level[cur], n_cur, static_cast<fmx::SuffixSlot *>(d_slots), nullptr) != 0 ||
-        hipStreamSynchronize(nullptr) != hipSuccess) {
+    bool ok = hipMalloc(&d_slots, (size_t)slots * sizeof(fmx::SuffixSlot)) == hipSuccess &&
+              hipMemset(d_slots, 0xff, (size_t)slots * sizeof(fmx::SuffixSlot)) == hipSuccess;
+    for (int len = 2; ok && len <= chars; ++len)
+        ok = fmx::launch_suffix_insert(geometry, all + begin[len], begin[len + 1] - begin[len], len,
+                                       static_cast<fmx::SuffixSlot *>(d_slots), nullptr) == 0;
+    if (!ok || hipStreamSynchronize(nullptr) != hipSuccess) {
         if (d_slots) (void)hipFree(d_slots);
         cleanup();
         return;
@@ -701,7 +702,7 @@ static void build_suffix_table(fmx_index *idx) {
     cleanup();
     idx->d_suffix_table = d_slots;
     idx->suffix_table_bytes = (size_t)slots * sizeof(fmx::SuffixSlot);
-    idx->suffix_table_strings = n_cur;
+    idx->suffix_table_strings = total;
     idx->dev.suffix_table = static_cast<const fmx::SuffixSlot *>(d_slots);
     idx->dev.suffix_chars = chars;
     idx->dev.suffix_shift = geometry.suffix_shift;

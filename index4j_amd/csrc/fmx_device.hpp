@@ -62,11 +62,12 @@ struct DevIndex {
     const struct Quad *sb_cache;
     int32_t sb_cache_limit;      // stage the cache only for indexes with at most this many superblocks (0 = never)
     uint32_t wt_size;
-    // Suffix table (nullptr: none): the SA interval of every string of `suffix_chars` codes THAT OCCURS IN THE TEXT, i.e.
-    // the state of FM:455-474 after a pattern's last `suffix_chars` characters — an open-addressing hash table of 16-byte
+    // Suffix table (nullptr: none): the SA interval of every string of 2 .. `suffix_chars` codes THAT OCCURS IN THE TEXT,
+    // i.e. the state of FM:455-474 after a pattern's last characters — an open-addressing hash table of 16-byte
     // slots {key, start, end}; key = the codes, the LAST character in the low bits, `suffix_key_bits` (8 or 16, by this
-    // index's alphabet) each: the low bits of a plan record's code word as they stand.  A string that is not in the table
-    // (it does not occur, holds a code of 0, or its search raised a status) is simply looked for with the loop.
+    // index's alphabet) each: the low bits of a plan record's code word as they stand (codes beyond the string: 0).  A string
+    // that is not in the table (it does not occur, holds a code of 0, or its search raised a status) is simply looked for
+    // with the loop.
     const struct SuffixSlot *suffix_table;
     int32_t suffix_chars;
     int32_t suffix_key_bits;
@@ -79,9 +80,7 @@ struct SuffixSlot {
 };
 constexpr uint64_t kSuffixEmpty = ~0ull;
 constexpr uint64_t kSuffixHashMul = 0x9E3779B97F4A7C15ull;
-// Strings that differ only in the low 6 bits of their FIRST character's code (the one a pattern consumes last of the
-// table's characters) share a group of 64 consecutive slots — 1 KiB — and probing moves by whole groups: the lanes of a
-// wave, neighbours in suffix order, then read the same few lines, as they did in a dense table's row.
+// Slots come in groups of 64 — 1 KiB — and probing moves by whole groups (fm_suffix_home).
 constexpr int kSuffixGroupLog2 = 6;
 constexpr uint32_t kSuffixGroup = 1u << kSuffixGroupLog2;
 
@@ -1148,20 +1147,30 @@ FMX_HD bool fm_suffix_extend(const DevIndex &ix, const SuffixSlot &parent, int d
     child.end = (uint32_t)e2;
     return true;
 }
-FMX_HD uint32_t fm_suffix_home(const DevIndex &ix, uint64_t key) {
-    const int top = (ix.suffix_chars - 1) * ix.suffix_key_bits;  // where the first character's code sits
-    const uint64_t low4 = (key >> top) & (kSuffixGroup - 1);
+// Home slot of a key of `len` codes (2 .. suffix_chars; shorter strings leave the key's upper codes 0, which no tabulated
+// string has anywhere).  Strings that differ only in the low 6 bits of their FIRST character's code (the one a pattern
+// consumes last of the table's characters) share a group of 64 consecutive slots — the lanes of a wave, neighbours in suffix
+// order, read the same few lines.  Inside its group a string sits at (those 6 bits) XOR (6 further bits of the hash of the
+// rest): a bijection per group, so the strings of one group never collide with each other, and a character that is frequent
+// in the text does not fill "its" slot column of every group (round 3's table, addressed by the bare 6 bits, had to be made
+// 20 times larger than its strings to keep that column half empty).
+FMX_HD uint32_t fm_suffix_home(const DevIndex &ix, uint64_t key, int len) {
+    const int top = (len - 1) * ix.suffix_key_bits;  // where the first character's code sits
+    const uint64_t low6 = (key >> top) & (kSuffixGroup - 1);
     const uint64_t rest = key & ~((uint64_t)(kSuffixGroup - 1) << top);
-    return ((uint32_t)((rest * kSuffixHashMul) >> ix.suffix_shift) * kSuffixGroup + (uint32_t)low4) & ix.suffix_mask;
+    const uint64_t hash = rest * kSuffixHashMul;
+    const uint32_t group = (uint32_t)(hash >> ix.suffix_shift);
+    const uint32_t turn = (uint32_t)(hash >> (ix.suffix_shift - kSuffixGroupLog2)) & (kSuffixGroup - 1);
+    return (group * kSuffixGroup + ((uint32_t)low6 ^ turn)) & ix.suffix_mask;
 }
-// A pattern of m >= suffix_chars characters whose trailing codes spell `key`: where the search stands after them, if
-// the table says so.  Returns false when the loop has to run from the first character.
-FMX_HD bool fm_suffix_lookup(const DevIndex &ix, uint64_t key, int32_t &start, int32_t &end, int32_t &back) {
-    uint32_t h = fm_suffix_home(ix, key);
-    Quad q = ld_quad(ix.suffix_table + h);  // the home slot answers nearly every lookup (the fullest column is half full at most)
+// A pattern whose trailing `len` codes spell `key`: where the search stands after them, if the table says so.
+// Returns false when the loop has to run from the first character.
+FMX_HD bool fm_suffix_lookup(const DevIndex &ix, uint64_t key, int len, int32_t &start, int32_t &end, int32_t &back) {
+    uint32_t h = fm_suffix_home(ix, key, len);
+    Quad q = ld_quad(ix.suffix_table + h);  // the home slot answers nearly every lookup (the table is at most 0.7 full)
     FMX_PIN_QUAD(q);
     uint64_t k = (uint64_t)q.x | ((uint64_t)q.y << 32);
-    // (ends at a free slot: the table has at least twice as many slots as strings; the bound is for a damaged table)
+    // (ends at a free slot: the table always has free slots in every column; the bound is for a damaged table)
     for (uint32_t probe = 0; k != key && k != kSuffixEmpty && probe < ix.suffix_mask / kSuffixGroup; ++probe) {
         h = (h + kSuffixGroup) & ix.suffix_mask;
         q = ld_quad(ix.suffix_table + h);
@@ -1170,15 +1179,15 @@ FMX_HD bool fm_suffix_lookup(const DevIndex &ix, uint64_t key, int32_t &start, i
     if (k != key) return false;
     start = (int32_t)q.z;
     end = (int32_t)q.w;
-    back = ix.suffix_chars - 1;
+    back = len - 1;
     return true;
 }
-// the key of a pattern's last suffix_chars characters from its codes (code_at(0) = the last character); false: a code of 0
+// the key of a pattern's last `len` characters from its codes (code_at(0) = the last character); false: a code of 0
 template <class CodeAt>
-FMX_HD bool fm_suffix_key(const DevIndex &ix, CodeAt code_at, uint64_t &key) {
+FMX_HD bool fm_suffix_key(const DevIndex &ix, CodeAt code_at, int len, uint64_t &key) {
     key = 0;
     bool known = true;
-    for (int j = 0; j < ix.suffix_chars; ++j) {
+    for (int j = 0; j < len; ++j) {
         const uint32_t cj = (uint32_t)code_at(j);
         known = known && cj != 0;
         key |= (uint64_t)cj << (j * ix.suffix_key_bits);
@@ -1186,6 +1195,8 @@ FMX_HD bool fm_suffix_key(const DevIndex &ix, CodeAt code_at, uint64_t &key) {
     // (eight codes of 255 / four of 65,535 spell the free slot's mark: that one string takes the loop)
     return known && key != kSuffixEmpty;
 }
+// how many of a pattern's m trailing characters the table may answer: every length from 2 to suffix_chars is tabulated
+FMX_HD int fm_suffix_len(const DevIndex &ix, int32_t m) { return m < ix.suffix_chars ? (int)m : ix.suffix_chars; }
 
 // FM:526-548 for one hit: SA row i = start + 1 + k; LF-walk until a sampled row.
 // Returns the text position; *distance = number of LF-steps walked.

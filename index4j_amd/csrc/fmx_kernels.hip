@@ -263,11 +263,13 @@ __device__ __forceinline__ void count_one(const DevIndex &ix, const int16_t *s_m
     if (c == 0) return;  // FM:458-460
     start = ix.C[c];
     end = ix.C[c + 1];
-    if (ix.suffix_table && m >= ix.suffix_chars && ck.n >= ix.suffix_chars) {
-        // the interval after the last suffix_chars characters is tabulated (the table was grown by this very loop over every
-        // string of that many codes that occurs): one 16-byte slot instead of 2 * (suffix_chars - 1) ranks.  The key is the
-        // low bits of the code word where that is written in this index's alphabet; a segment of a set makes it from the
-        // translated codes (a code its alphabet lacks is 0: not tabulated, the loop runs and lets the character decide).
+    int len = ix.suffix_table ? fm_suffix_len(ix, m) : 0;
+    if (ck.n < len) len = ck.n;
+    if (len >= 2) {
+        // the interval after the last `len` characters is tabulated (the table was grown by this very loop over every string
+        // of 2 .. suffix_chars codes that occurs): one 16-byte slot instead of 2 * (len - 1) ranks.  The key is the low bits of
+        // the code word where that is written in this index's alphabet; a segment of a set makes it from the translated codes
+        // (a code its alphabet lacks is 0: not tabulated, the loop runs and lets the character decide).
         uint64_t key;
         bool known = true;
         if (translate || kCodeBits != ix.suffix_key_bits) {
@@ -277,12 +279,13 @@ __device__ __forceinline__ void count_one(const DevIndex &ix, const int16_t *s_m
                     const uint32_t cj = (uint32_t)chunk_code<kCodeBits>(ck, j);
                     return translate ? (uint32_t)(uint16_t)s_xlat[cj] : cj;
                 },
-                key);
+                len, key);
         } else {
-            const int bits = ix.suffix_chars * kCodeBits;
+            const int bits = len * kCodeBits;
             key = bits >= 64 ? ck.lo : (ck.lo & ((1ull << bits) - 1ull));
+            known = key != kSuffixEmpty;  // (a code of 0 inside the key finds nothing: no tabulated string has one)
         }
-        if (known) (void)fm_suffix_lookup(ix, key, start, end, back);
+        if (known) (void)fm_suffix_lookup(ix, key, len, start, end, back);
         tabled = back;  // characters whose rank evaluations the table answered
     }
     bool first_chunk = true;  // the record's word (its codes are the PLAN's: translated in mode 2)
@@ -451,14 +454,14 @@ __global__ __launch_bounds__(256) void k_suffix_expand(DevIndex ix, const Suffix
         if (at < cap) out[at] = child;
     }
 }
-// the last level into the hash table (slots preset to kSuffixEmpty); ix carries the table's geometry (fm_suffix_home)
-__global__ __launch_bounds__(256) void k_suffix_insert(DevIndex ix, const SuffixSlot *__restrict__ in, uint32_t n_in,
+// one level (strings of `len` codes) into the hash table (slots preset to kSuffixEmpty); ix carries the table's geometry (fm_suffix_home)
+__global__ __launch_bounds__(256) void k_suffix_insert(DevIndex ix, const SuffixSlot *__restrict__ in, uint32_t n_in, int len,
                                                        SuffixSlot *__restrict__ slots) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_in) return;
     const SuffixSlot me = in[i];
     if (me.key == kSuffixEmpty) return;  // the one key that reads as a free slot is never tabulated (fm_suffix_key)
-    uint32_t h = fm_suffix_home(ix, me.key);
+    uint32_t h = fm_suffix_home(ix, me.key, len);
     for (uint32_t probe = 0; probe <= ix.suffix_mask / kSuffixGroup; ++probe, h = (h + kSuffixGroup) & ix.suffix_mask) {
         unsigned long long *key = reinterpret_cast<unsigned long long *>(&slots[h].key);
         if (atomicCAS(key, (unsigned long long)kSuffixEmpty, (unsigned long long)me.key) == (unsigned long long)kSuffixEmpty) {
@@ -467,26 +470,7 @@ __global__ __launch_bounds__(256) void k_suffix_insert(DevIndex ix, const Suffix
             return;
         }
     }
-    // (a column of the table is full: cannot happen at half load spread by the hash; the string is then simply not found)
-}
-// how many strings of the last level fall into each of the table's 16 slot columns (the low 4 bits of the first
-// character's code): the table is sized so that the fullest column stays at most half full
-__global__ __launch_bounds__(256) void k_suffix_columns(const SuffixSlot *__restrict__ in, uint32_t n_in, int top_shift,
-                                                        uint32_t *__restrict__ counts) {
-    __shared__ uint32_t s_c[kSuffixGroup];
-    if (threadIdx.x < kSuffixGroup) s_c[threadIdx.x] = 0;
-    __syncthreads();
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_in; i += gridDim.x * 256)
-        atomicAdd(&s_c[(uint32_t)(in[i].key >> top_shift) & (kSuffixGroup - 1)], 1u);
-    __syncthreads();
-    if (threadIdx.x < kSuffixGroup && s_c[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_c[threadIdx.x]);
-}
-int launch_suffix_columns(const SuffixSlot *in, uint32_t n_in, int top_shift, uint32_t *counts, hipStream_t st) {
-    if (n_in == 0) return 0;
-    uint32_t blocks = (n_in + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(k_suffix_columns, dim3(blocks), dim3(256), 0, st, in, n_in, top_shift, counts);
-    return (int)hipGetLastError();
+    // (every slot of this string's probe sequence is taken: cannot happen below 0.7 load spread by the hash; the string is then simply not found)
 }
 int launch_suffix_level1(const DevIndex &ix, SuffixSlot *out, uint32_t *count, uint32_t cap, hipStream_t st) {
     DevIndex plain = ix;
@@ -508,9 +492,9 @@ int launch_suffix_expand(const DevIndex &ix, int n_cu, const SuffixSlot *in, uin
     hipLaunchKernelGGL(k_suffix_expand, dim3((unsigned)blocks), dim3(256), 0, st, plain, in, n_in, depth, key_bits, out, count, cap);
     return (int)hipGetLastError();
 }
-int launch_suffix_insert(const DevIndex &geometry, const SuffixSlot *in, uint32_t n_in, SuffixSlot *slots, hipStream_t st) {
+int launch_suffix_insert(const DevIndex &geometry, const SuffixSlot *in, uint32_t n_in, int len, SuffixSlot *slots, hipStream_t st) {
     if (n_in == 0) return 0;
-    hipLaunchKernelGGL(k_suffix_insert, dim3((n_in + 255) / 256), dim3(256), 0, st, geometry, in, n_in, slots);
+    hipLaunchKernelGGL(k_suffix_insert, dim3((n_in + 255) / 256), dim3(256), 0, st, geometry, in, n_in, len, slots);
     return (int)hipGetLastError();
 }
 

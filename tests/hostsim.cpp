@@ -120,14 +120,16 @@ void sim_count(const uint8_t *blob, const uint16_t *pat, const int32_t *off, int
     }
 }
 
-// mirrors k_count with a suffix table of `chars` characters: the table is grown level by level with fm_suffix_extend (what
-// k_suffix_level1 / k_suffix_expand run), hashed as k_suffix_insert does, and consulted by fm_suffix_key + fm_suffix_lookup
-// (what k_count runs per pattern).  Returns the number of strings in the table.
+// mirrors k_count with a suffix table of up to `chars` characters: the table is grown level by level with fm_suffix_extend
+// (what k_suffix_level1 / k_suffix_expand run), every level of 2 .. chars codes hashed as k_suffix_insert does, and consulted
+// by fm_suffix_key + fm_suffix_lookup (what k_count runs per pattern: a pattern shorter than `chars` looks its whole self
+// up).  Returns the number of strings in the table.
 int64_t sim_count_table(const uint8_t *blob, int32_t chars, const uint16_t *pat, const int32_t *off, int32_t n,
                         int32_t *counts, int32_t *lf, int32_t *status_out, int64_t *answered_steps) {
     DevIndex ix = make_index(blob);
     const int key_bits = ix.wt_sigma <= 256 ? 8 : 16;
     std::vector<SuffixSlot> level;
+    std::vector<std::vector<SuffixSlot>> levels;  // levels[i]: strings of i + 2 codes
     for (int32_t c = 1; c + 1 < ix.n_c && c < ix.wt_sigma; ++c)
         if (ix.C[c] < ix.C[c + 1]) level.push_back(SuffixSlot{(uint64_t)(uint32_t)c, (uint32_t)ix.C[c], (uint32_t)ix.C[c + 1]});
     for (int depth = 1; depth < chars; ++depth) {
@@ -139,14 +141,13 @@ int64_t sim_count_table(const uint8_t *blob, int32_t chars, const uint16_t *pat,
                 if (fm_suffix_extend(ix, parent, depth, c, key_bits, child)) next.push_back(child);
             }
         level.swap(next);
+        levels.push_back(level);
     }
-    // sized as the library does: twice the strings, and room for the fullest of the kSuffixGroup slot columns with a quarter to spare
-    std::vector<uint64_t> column(kSuffixGroup, 0);
-    for (const SuffixSlot &e : level) ++column[(e.key >> ((chars - 1) * key_bits)) & (kSuffixGroup - 1)];
-    uint64_t fullest = 0;
-    for (uint64_t v : column) fullest = v > fullest ? v : fullest;
+    // sized as the library does when nothing limits it: a power of two, half full at most
+    uint64_t total = 0;
+    for (const auto &l : levels) total += l.size();
     uint32_t slots = 1024;
-    while (slots < 2 * (uint64_t)level.size() || 4 * (uint64_t)slots < 5 * (uint64_t)kSuffixGroup * fullest) slots <<= 1;
+    while (slots < 2 * total) slots <<= 1;
     int log2_slots = 0;
     while ((1u << log2_slots) < slots) ++log2_slots;
     std::vector<SuffixSlot> table(slots, SuffixSlot{kSuffixEmpty, 0, 0});
@@ -154,13 +155,15 @@ int64_t sim_count_table(const uint8_t *blob, int32_t chars, const uint16_t *pat,
     ix.suffix_chars = chars;
     ix.suffix_shift = (uint32_t)(64 - (log2_slots - kSuffixGroupLog2));
     ix.suffix_mask = slots - 1;
-    for (const SuffixSlot &e : level) {
-        uint32_t h = fm_suffix_home(ix, e.key);
-        while (table[h].key != kSuffixEmpty) h = (h + kSuffixGroup) & ix.suffix_mask;
-        table[h] = e;
-    }
+    for (size_t i = 0; i < levels.size(); ++i)
+        for (const SuffixSlot &e : levels[i]) {
+            if (e.key == kSuffixEmpty) continue;
+            uint32_t h = fm_suffix_home(ix, e.key, (int)i + 2);
+            while (table[h].key != kSuffixEmpty) h = (h + kSuffixGroup) & ix.suffix_mask;
+            table[h] = e;
+        }
     ix.suffix_table = table.data();
-    const int64_t entries = (int64_t)level.size();
+    const int64_t entries = (int64_t)total;
     int64_t answered = 0;
     for (int32_t p = 0; p < n; ++p) {
         const int32_t beg = off[p], m = off[p + 1] - beg;
@@ -174,8 +177,9 @@ int64_t sim_count_table(const uint8_t *blob, int32_t chars, const uint16_t *pat,
                 start = ix.C[c];
                 end = ix.C[c + 1];
                 uint64_t key;
-                if (m >= chars && fm_suffix_key(ix, [&](int j) { return (uint32_t)fm_map(ix, pat[beg + m - 1 - j]); }, key) &&
-                    fm_suffix_lookup(ix, key, start, end, back))
+                const int len = fm_suffix_len(ix, m);
+                if (len >= 2 && fm_suffix_key(ix, [&](int j) { return (uint32_t)fm_map(ix, pat[beg + m - 1 - j]); }, len, key) &&
+                    fm_suffix_lookup(ix, key, len, start, end, back))
                     answered += 2 * back;
                 while (start < end && back + 1 < m) {
                     ++back;

@@ -537,14 +537,19 @@ def test_suffix_table_changes_nothing_but_the_time():
             o_steps = orc.counters()["lf_steps"]
             seen = set()
             ref = None
-            for mb, depth in ((0, 4), (256, 2), (256, 3), (256, 4), (256, 6), (1, 8)):
+            # (mb, depth, image fraction): the size limit is the smaller of the budget and image / fraction (0: budget alone)
+            for mb, depth, frac in ((0, 4, 0), (256, 2, 0), (256, 3, 0), (256, 4, 0), (256, 6, 0), (1, 8, 0), (256, 8, 8)):
                 assert ia.lib.fmx_set_option(b"suffix_table_mb", mb) == 0
                 assert ia.lib.fmx_set_option(b"suffix_table_chars", depth) == 0
+                assert ia.lib.fmx_set_option(b"suffix_table_image_fraction", frac) == 0
                 fm = ia.FmIndex.read(o.write(False), device=0)
                 k, nbytes = fm.suffix_table_info()
-                # the depth asked for, unless the budget stops the growth earlier (1 MB: 32,768 strings)
+                # the depth asked for, unless the size limit stops the growth earlier (1 MB: 45,875 strings at 0.7 load)
                 assert (k == 0) == (mb == 0) and k <= depth and (k == 0 or nbytes >= 16 * 1024)
-                assert mb != 256 or k == depth
+                assert mb != 256 or frac or k == depth
+                assert k == 0 or nbytes <= (mb << 20)
+                if frac:  # the default policy: an eighth of the image (64 KiB at least)
+                    assert nbytes <= max(fm.device_blob()[1] // frac, 64 << 10) and k >= 2
                 seen.add(k)
                 for use in ((1,) if k == 0 else (1, 0)):
                     assert ia.lib.fmx_set_option(b"suffix_table", use) == 0
@@ -564,7 +569,8 @@ def test_suffix_table_changes_nothing_but_the_time():
             assert len(seen) >= 5  # no table, depths 2, 3, 4, 6 (and what a 1 MB budget allows)
     finally:
         ia.lib.fmx_set_option(b"suffix_table_mb", 256)
-        ia.lib.fmx_set_option(b"suffix_table_chars", 4)
+        ia.lib.fmx_set_option(b"suffix_table_chars", 8)
+        ia.lib.fmx_set_option(b"suffix_table_image_fraction", 8)
         ia.lib.fmx_set_option(b"suffix_table", 1)
 
 

@@ -72,6 +72,7 @@ def main():
         ia.lib.fmx_set_option(b"inv_fast", rnd.choice([1, 1, 1, 0]))  # 0: inverseSelect on the reference's route
         ia.lib.fmx_set_option(b"suffix_table_mb", rnd.choice([256, 256, 1, 0]))  # budget of the suffix table (0: none)
         ia.lib.fmx_set_option(b"suffix_table_chars", rnd.choice([4, 4, 2, 3, 6, 8]))  # its depth
+        ia.lib.fmx_set_option(b"suffix_table_image_fraction", rnd.choice([8, 0, 0, 2]))  # ... and its size against the image's
         ia.lib.fmx_set_option(b"cells_split_blocks", rnd.choice([1 << 20, 64, 256]))  # chunked decoding of the bit vectors
         ia.lib.fmx_set_option(b"boundary_group", rnd.choice([0, 1, 2, 4, 8]))
         try:

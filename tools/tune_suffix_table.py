@@ -30,6 +30,7 @@ def main():
     depths = [int(x) for x in sys.argv[1:]] or [0, 2, 3, 4, 5, 6, 8]
     for depth in depths:
         ia.lib.fmx_set_option(b"suffix_table_mb", 0 if depth == 0 else 4096)
+        ia.lib.fmx_set_option(b"suffix_table_image_fraction", 0)  # the depth asked for, whatever it takes
         ia.lib.fmx_set_option(b"suffix_table_chars", max(depth, 2))
         t0 = time.perf_counter()
         fm.to_device(0)
@@ -53,7 +54,8 @@ def main():
         print("depth asked %d: table of %d chars, %10.2f MB, to_device %.3f s; step %.4f ms; checksums %s"
               % (depth, k, nbytes / 1e6, t_dev, e0.elapsed_time(e1) / 40, sums[:2]), flush=True)
     ia.lib.fmx_set_option(b"suffix_table_mb", 256)
-    ia.lib.fmx_set_option(b"suffix_table_chars", 4)
+    ia.lib.fmx_set_option(b"suffix_table_chars", 8)
+    ia.lib.fmx_set_option(b"suffix_table_image_fraction", 8)
 
 
 if __name__ == "__main__":
