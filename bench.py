@@ -280,9 +280,12 @@ def compact_line(out):
             continue
         if "series" in row:
             for sr in (row["series"] or {}).get("rows", []):
-                sec.append({"config": _short("series %s s=%s%s" % (sr.get("benchmark"), sr.get("sample_rate"),
-                                                                    "" if sr.get("max_matches") is None else " max=%s" % sr["max_matches"]), 40),
-                            "ms": sr.get("ms_per_batch"), "frac": (sr.get("roofline") or {}).get("frac")})
+                name = "series %s s=%s%s" % (sr.get("benchmark"), sr.get("sample_rate", sr.get("sample_size")),
+                                             "" if sr.get("max_matches") is None else " max=%s" % sr["max_matches"])
+                if sr.get("density") is not None:
+                    name += " d=%g" % sr["density"]
+                sec.append({"config": _short(name, 44), "ms": sr.get("ms_per_batch", None if sr.get("build_s") is None else sr["build_s"] * 1e3),
+                            "frac": (sr.get("roofline") or {}).get("frac")})
             continue
         sec.append({"config": _short(str(row.get("config") or row.get("metric")).replace("BASELINE.json ", ""), 48),
                     "ms": row.get("ms", row.get("ms_per_step")), "frac": (row.get("roofline") or {}).get("frac")})
@@ -963,6 +966,13 @@ def run_secondary(ctx, args, q, ref, orc, text, pat, off):
                         ia, torch, orc, dev, text_log2=args.text_log2, queries=args.series_queries,
                         sample_rates=(32,) if args.profiling else (1, 32, 64), max_matches=(1,) if args.profiling else (1, 10, 100, 1000),
                         build_device=ctx.local_rank, log=log)})
+    if args.series_extras:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import series_extras
+
+        res.append({"config": "series_extras: RrrVectorThroughputBenchmark (10 M bits, sampleSize 16/32/64/256, 1 % dense), "
+                              "locateAndExtractBenchmark, ingest + serialized size on the 1,099-symbol text",
+                    "series": series_extras.run_extras(ia, torch, orc, dev, text_log2=args.text_log2, log=log)})
     return res
 
 
@@ -1238,6 +1248,9 @@ def main():
                     help="also run the reference-shaped series (count / locate 1..1000 / extract-32 at sampleRate 1, 32, 64 on the "
                          "1,100-symbol text; ~100 s, most of it the oracle's check); off by default so that the default run stays short")
     ap.add_argument("--no-ref-series", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--series-extras", action="store_true",
+                    help="also run BASELINE.md's remaining rows (tools/series_extras.py): stand-alone RrrVector.rankOnes at 10 M bits, "
+                         "locateAndExtract, ingest time and serialized size on the 1,099-symbol text; each oracle-checked (~60 s)")
     ap.add_argument("--series-queries", type=int, default=1 << 20, help="queries per batch of the reference-shaped series")
     ap.add_argument("--profiling", action="store_true",
                     help="rocprofv3 runs: skip the extra legs that launch the headline kernels in other modes (without the suffix "

@@ -251,6 +251,11 @@ int fmx_rrr_build(const uint8_t *bits, int64_t n, int32_t sample_size, fmx_index
 int fmx_rrr_rank_ones_batch(const fmx_index *idx, const int32_t *positions, int32_t n, int32_t *ranks);
 /* boolean access(int position) RRR:314-349, batched; status = FMX_ST_JAVA_AIOOBE where the reference throws */
 int fmx_rrr_access_batch(const fmx_index *idx, const int32_t *positions, int32_t n, uint8_t *bits, int32_t *status);
+/* the same two calls with operands resident in HBM, asynchronous on `stream` (RrrVectorThroughputBenchmark.java:43-51 is
+ * measured through these: positions in, ranks out, nothing crosses PCIe inside the timed region) */
+int fmx_rrr_rank_ones_batch_dev(const fmx_index *idx, const int32_t *d_positions, int32_t n, int32_t *d_ranks, void *stream);
+int fmx_rrr_access_batch_dev(const fmx_index *idx, const int32_t *d_positions, int32_t n, uint8_t *d_bits, int32_t *d_status,
+                             void *stream);
 
 /* ---- helpers ------------------------------------------------------------------------------ */
 

@@ -32,7 +32,7 @@ SYMBOLS = [
     "fmx_locate_extract_batch", "fmx_locate_lines_batch", "fmx_locate_extract_batch_dev", "fmx_locate_lines_batch_dev",
     "fmx_count_segments", "fmx_locate_segments", "fmx_count_segments_dev", "fmx_locate_segments_dev",
     "fmx_wavelet_build", "fmx_wavelet_rank_batch", "fmx_wavelet_inverse_select_batch",
-    "fmx_rrr_build", "fmx_rrr_rank_ones_batch", "fmx_rrr_access_batch",
+    "fmx_rrr_build", "fmx_rrr_rank_ones_batch", "fmx_rrr_access_batch", "fmx_rrr_rank_ones_batch_dev", "fmx_rrr_access_batch_dev",
     "fmx_convert_byte_pattern", "fmx_status_message", "fmx_status_kind", "fmx_last_error", "fmx_release_scratch", "fmx_device_count", "fmx_set_option",
     "fmx_synth_log", "fmx_synth_log_multichar", "fmx_synth_patterns",
 ]
@@ -93,6 +93,8 @@ def _load():
     L.fmx_rrr_build.argtypes = [vp, C.c_int64, i32, P(vp)]
     L.fmx_rrr_rank_ones_batch.argtypes = [vp, vp, i32, vp]
     L.fmx_rrr_access_batch.argtypes = [vp, vp, i32, vp, vp]
+    L.fmx_rrr_rank_ones_batch_dev.argtypes = [vp, vp, i32, vp, vp]
+    L.fmx_rrr_access_batch_dev.argtypes = [vp, vp, i32, vp, vp, vp]
     L.fmx_convert_byte_pattern.argtypes = [vp, i32, i32, vp, P(i32)]
     L.fmx_status_message.argtypes = [C.c_int]
     L.fmx_status_message.restype = C.c_char_p

@@ -1739,6 +1739,29 @@ int fmx_rrr_rank_ones_batch(const fmx_index *idx, const int32_t *positions, int3
     });
 }
 
+int fmx_rrr_rank_ones_batch_dev(const fmx_index *idx, const int32_t *d_positions, int32_t n, int32_t *d_ranks, void *stream) {
+    return guarded([&]() -> int {
+    int rc = require_device(idx, true);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!d_positions || !d_ranks))) return fail(FMX_E_ARG, "bad arguments");
+    int e = fmx::launch_rrr_rank_ones(idx->dev, idx->n_cu, d_positions, n, d_ranks, static_cast<hipStream_t>(stream));
+    if (e) return fail(FMX_E_HIP, std::string("k_rrr_rank_ones launch: ") + hipGetErrorString((hipError_t)e));
+    return FMX_OK;
+    });
+}
+
+int fmx_rrr_access_batch_dev(const fmx_index *idx, const int32_t *d_positions, int32_t n, uint8_t *d_bits, int32_t *d_status,
+                             void *stream) {
+    return guarded([&]() -> int {
+    int rc = require_device(idx, true);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!d_positions || !d_bits))) return fail(FMX_E_ARG, "bad arguments");
+    int e = fmx::launch_rrr_access(idx->dev, idx->n_cu, d_positions, n, d_bits, d_status, static_cast<hipStream_t>(stream));
+    if (e) return fail(FMX_E_HIP, std::string("k_rrr_access launch: ") + hipGetErrorString((hipError_t)e));
+    return FMX_OK;
+    });
+}
+
 int fmx_rrr_access_batch(const fmx_index *idx, const int32_t *positions, int32_t n, uint8_t *bits, int32_t *status) {
     return guarded([&]() -> int {
     int rc = require_device(idx, true);

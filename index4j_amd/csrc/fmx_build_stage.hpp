@@ -34,7 +34,7 @@ struct SaStageStats {
 int host_sa_stage(const int16_t *seq, int32_t n, int alphabet, int sample_rate, bool extract, SaStage &out);
 // (weak: fmx_build.cpp also links without the HIP translation unit, e.g. in the sanitizer build of the host code)
 // wt != nullptr: the wavelet tree (FM:173, WFBB:130-154) is encoded in HBM as well, from the BWT where it lies
-// (fmx_wt_gpu.hip; alphabets up to kWtMaxSigma codes — larger ones leave wavelet_done false and the BWT in `out`)
+// (fmx_wt_gpu.hip; superblocks of up to kWtMaxSigma distinct symbols — a text with a fuller one leaves wavelet_done false and the BWT in `out`)
 // d_text != nullptr: the text already lies in HBM as raw characters (device_alphabet_stage) and is mapped there
 // through code_of (65,536 entries) instead of being uploaded as `seq`; the stage frees it.
 int device_sa_stage(const int16_t *seq, int32_t n, int sample_rate, bool extract, int device, SaStage &out,
@@ -49,8 +49,9 @@ int device_pack_values(const uint32_t *d_vals, int64_t n_vals, int64_t length, i
                        PackedVec &out, std::string &err) __attribute__((weak));
 int device_rrr_of_bits(const uint64_t *d_bits, int64_t nbits, int sample, RrrModel &m, std::string &err)
     __attribute__((weak));
-constexpr int kWtMaxSigma = 1024;
-// 0 = encoded, 1 = not handled here (alphabet too large, code longer than 31 bits): encode on the host, < 0 = error
+constexpr int kWtMaxSigma = 1536;  // distinct symbols of ONE superblock (a wave's LDS scratch: 38 bytes per symbol, 64 KiB per workgroup)
+// 0 = encoded, 1 = not handled here (a superblock with more symbols than that, a code longer than 31 bits): encode on the
+// host, < 0 = error
 int device_wavelet_stage(const int16_t *d_bwt, int64_t n, int sampling_rate, int alphabet, WfbbModel &w,
                          std::string &err) __attribute__((weak));
 

@@ -14,7 +14,13 @@
 // Phases (kernels): per-superblock symbol counts; the size estimate of WFBB:853-987 for block sizes 2^9..2^16 (the
 // double-precision chain runs on the host from the per-level sums); per-block plan (sizes, one-counts, per-symbol
 // frequencies); scans over the blocks of a superblock (header offsets, bit-vector offsets, ranks at block starts);
-// encode; RRR classes and group sums; RRR offsets and samples.  Alphabets above kWtMaxSigma stay on the host encoder.
+// encode; RRR classes and group sums; RRR offsets and samples.
+// Alphabet: every per-block phase works on the SUPERBLOCK-LOCAL codes of WFBB:838-846 (globalMapping: the symbols present in
+// the superblock, numbered in ascending global order) — the BWT is rewritten into them once (k_wt_localize).  The numbering
+// is order-preserving, so the Huffman tie order (first symbol of a merged list) and the canonical (length, symbol) order are
+// the global alphabet's; only the leaves' u16 symbol is translated back (inverse table per superblock).  LDS and the dense
+// per-block tables are then sized by the largest superblock alphabet, not by the text's: the reference's own data-set shape
+// (1,099 symbols) encodes in HBM; only a superblock holding more than kWtMaxSigma distinct symbols goes to the host encoder.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -268,15 +274,27 @@ __device__ __forceinline__ void wave_canonical(const WaveLds &w, int s, int th) 
 // ---- kernels ---------------------------------------------------------------------------------------------------
 
 // symbol counts of every superblock (the running count[] of WFBB:833-837 is their prefix sum)
-__global__ void k_wt_sb_counts(const int16_t *__restrict__ bwt, int64_t n, int sigma, uint32_t *__restrict__ out) {
+// (use_lds = 0 for alphabets whose histogram does not fit 48 KiB of LDS: atomics on the zeroed output row instead)
+__global__ void k_wt_sb_counts(const int16_t *__restrict__ bwt, int64_t n, int sigma, int use_lds, uint32_t *__restrict__ out) {
     extern __shared__ uint32_t s_hist[];
     const int64_t sb = blockIdx.x;
+    const int64_t beg = sb << kSbLog, end = min(beg + kSbs, n);
+    if (!use_lds) {
+        for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) atomicAdd(&out[sb * sigma + (uint16_t)bwt[i]], 1u);
+        return;
+    }
     for (int i = threadIdx.x; i < sigma; i += blockDim.x) s_hist[i] = 0;
     __syncthreads();
-    const int64_t beg = sb << kSbLog, end = min(beg + kSbs, n);
     for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) atomicAdd(&s_hist[(uint16_t)bwt[i]], 1u);
     __syncthreads();
     for (int i = threadIdx.x; i < sigma; i += blockDim.x) out[sb * sigma + i] = s_hist[i];
+}
+// the BWT in superblock-local codes: globalMapping[superblock][symbol] (WFBB:838-846)
+__global__ void k_wt_localize(const int16_t *__restrict__ bwt, int64_t n, int sigma, const int16_t *__restrict__ gmap,
+                              int16_t *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = gmap[(i >> kSbLog) * sigma + (uint16_t)bwt[i]];
 }
 
 struct LevelSums {
@@ -285,8 +303,8 @@ struct LevelSums {
 };
 
 // WFBB:853-987, per block size 2^level (blockIdx.y = level - 9): the estimate's per-block terms, summed per superblock
-__global__ __launch_bounds__(64) void k_wt_estimate(const int16_t *__restrict__ bwt, int64_t n, int sigma, int sigma_pad,
-                              LevelSums *__restrict__ sums, int *__restrict__ too_deep) {
+__global__ __launch_bounds__(64) void k_wt_estimate(const int16_t *__restrict__ bwt, int64_t n, const int32_t *__restrict__ sb_sigma,
+                              int sigma_pad, LevelSums *__restrict__ sums, int *__restrict__ too_deep) {
     extern __shared__ uint8_t s_raw[];
     const WaveLds w = carve(s_raw, sigma_pad);
     const int level = kMinLog + (int)blockIdx.y;
@@ -302,7 +320,7 @@ __global__ __launch_bounds__(64) void k_wt_estimate(const int16_t *__restrict__ 
         block_histogram(w, sigma_pad, bwt + beg, (uint32_t)(end - beg));
         int th;
         uint64_t unc;
-        const int s = wave_huffman(w, sigma, th, unc);
+        const int s = wave_huffman(w, sb_sigma[sb], th, unc);
         if (threadIdx.x == 0) {
             unsigned long long hdr = (unsigned long long)s * 4 + (unsigned long long)(s - 1) * 2;
             if (th > 1) hdr += (unsigned long long)(th - 1) * 3;
@@ -328,10 +346,13 @@ struct SbPlan {         // per superblock of the batch
     int64_t var_base;   // first byte in the batch's header arena
     int64_t bv_base;    // first 32-bit word in the batch's bit-vector arena
     int64_t map_base;   // first entry in the batch's mapping arena
-    int64_t gmap_row;   // sb * sigma: row of the global mapping table
+    int64_t inv_row;    // first entry of the superblock's row in the inverse table (local code -> global symbol)
+    int32_t sigma;      // symbols present in the superblock = its local alphabet
+    int32_t pad;
 };
 
 // pass 1 of WFBB:400-484 for every block at its superblock's chosen size
+// (sigma = row length of the dense per-block tables: the largest local alphabet of the batch's superblocks)
 __global__ __launch_bounds__(64) void k_wt_plan(const int16_t *__restrict__ bwt, int sigma, int sigma_pad, const SbPlan *__restrict__ plans,
                           BlockInfo *__restrict__ info, uint32_t *__restrict__ freq_dense) {
     extern __shared__ uint8_t s_raw[];
@@ -343,7 +364,7 @@ __global__ __launch_bounds__(64) void k_wt_plan(const int16_t *__restrict__ bwt,
         block_histogram(w, sigma_pad, bwt + beg, (uint32_t)(end - beg));
         int th;
         uint64_t unc;
-        const int s = wave_huffman(w, sigma, th, unc);
+        const int s = wave_huffman(w, p.sigma, th, unc);
         wave_canonical(w, s, th > 31 ? 31 : th);
         uint64_t ones = 0;
         for (int i = lane; i < s; i += 64) ones += (uint64_t)w.hist[w.hsym[i]] * (uint32_t)__popc(w.code[w.hsym[i]]);
@@ -407,7 +428,7 @@ __device__ __forceinline__ void wr16(uint8_t *p, uint32_t v) {
 // pass 2 (WFBB:499-531 + 570-810): variable-size headers, mapping entries and node bit vectors of every block
 __global__ __launch_bounds__(64) void k_wt_encode(const int16_t *__restrict__ bwt, int sigma, int sigma_pad, int sigma_global,
                             const SbPlan *__restrict__ plans, const BlockHeader *__restrict__ headers,
-                            const uint32_t *__restrict__ rank_dense, const int16_t *__restrict__ gmap,
+                            const uint32_t *__restrict__ rank_dense, const uint16_t *__restrict__ inv_table,
                             uint8_t *__restrict__ var_arena, uint32_t *__restrict__ bv_arena,
                             int16_t *__restrict__ map_arena) {
     extern __shared__ uint8_t s_raw[];
@@ -421,7 +442,7 @@ __global__ __launch_bounds__(64) void k_wt_encode(const int16_t *__restrict__ bw
         block_histogram(w, sigma_pad, bwt + beg, count);
         int th;
         uint64_t unc;
-        const int s = wave_huffman(w, sigma, th, unc);
+        const int s = wave_huffman(w, p.sigma, th, unc);
         wave_canonical(w, s, th);
         const BlockHeader bh = headers[p.blk_base + b];
         uint8_t *hdr = var_arena + p.var_base + bh.var_off;
@@ -444,11 +465,11 @@ __global__ __launch_bounds__(64) void k_wt_encode(const int16_t *__restrict__ bw
             const uint32_t ix = w.idx[sym];
             uint8_t *lp = hdr + lvl_bytes + ix * 5;
             const uint32_t rv = ranks[sym];
-            wr16(lp, sym);
+            wr16(lp, inv_table[p.inv_row + sym]);  // the leaf names the GLOBAL symbol (WFBB:774-788)
             lp[2] = (uint8_t)(rv & 0xffu);
             lp[3] = (uint8_t)((rv >> 8) & 0xffu);
             lp[4] = (uint8_t)((rv >> 16) & 0xffu);
-            const int64_t row = gmap[p.gmap_row + sym];
+            const int64_t row = sym;  // = globalMapping[superblock][symbol]: the local code itself
             const int clamp = sigma_global - 2;
             map_arena[p.map_base + row * blocks_per_sb + b] = (int16_t)((int)ix < clamp ? (int)ix : clamp);
         }
@@ -648,19 +669,19 @@ hipError_t upload(DevMem &mem, T **d, const std::vector<T> &h) {
 
 }  // namespace
 
-int device_wavelet_stage(const int16_t *d_bwt, int64_t n, int sampling_rate, int alphabet, WfbbModel &w, std::string &err) {
+int device_wavelet_stage(const int16_t *d_bwt_global, int64_t n, int sampling_rate, int alphabet, WfbbModel &w, std::string &err) {
     const int sigma = alphabet;
-    if (sigma < 1 || sigma > kWtMaxSigma) return 1;  // not handled here: the caller encodes on the host
-    const int sigma_pad = (sigma + 63) & ~63;
+    if (sigma < 1 || sigma > 32768) return 1;  // not handled here: the caller encodes on the host
     const int64_t n_sb = (n + kSbs - 1) >> kSbLog;
     const int64_t n_hb = (n + (1ll << 32) - 1) >> 32;
-    const size_t lds = wave_lds_bytes(sigma_pad);
     DevMem mem;
 
     // symbol counts per superblock -> count[], hyperBlockRank, superBlockRank, globalMapping, sigma (WFBB:812-851)
     uint32_t *d_counts = nullptr;
-    WT_TRY(mem.alloc(&d_counts, (size_t)(n_sb * sigma)));
-    hipLaunchKernelGGL(k_wt_sb_counts, dim3((unsigned)n_sb), dim3(1024), (size_t)sigma * 4, 0, d_bwt, n, sigma, d_counts);
+    const int counts_in_lds = (size_t)sigma * 4 <= (48u << 10) ? 1 : 0;
+    WT_TRY(mem.alloc(&d_counts, (size_t)(n_sb * sigma), !counts_in_lds));
+    hipLaunchKernelGGL(k_wt_sb_counts, dim3((unsigned)n_sb), dim3(1024), counts_in_lds ? (size_t)sigma * 4 : 0, 0, d_bwt_global, n, sigma,
+                       counts_in_lds, d_counts);
     std::vector<uint32_t> sb_counts((size_t)(n_sb * sigma));
     WT_TRY(hipMemcpy(sb_counts.data(), d_counts, sb_counts.size() * 4, hipMemcpyDeviceToHost));
     w.size = n;
@@ -688,6 +709,33 @@ int device_wavelet_stage(const int16_t *d_bwt, int64_t n, int sampling_rate, int
     }
     for (int i = 0; i < sigma; ++i) w.count[(size_t)i] = running[(size_t)i];
 
+    // from here on the BWT holds superblock-local codes; sigma_l = the largest local alphabet (row length of the inverse
+    // table and of the dense per-block tables, LDS per wave)
+    int64_t sigma_l64 = 1;
+    for (int64_t s = 0; s < n_sb; ++s) sigma_l64 = std::max(sigma_l64, sb_sigma[(size_t)s]);
+    if (sigma_l64 > kWtMaxSigma) return 1;  // a superblock with more distinct symbols than a wave's LDS holds: host encoder
+    const int sigma_l = (int)sigma_l64;
+    const int sigma_pad = (sigma_l + 63) & ~63;
+    const size_t lds = wave_lds_bytes(sigma_pad);
+    int16_t *d_gmap = nullptr;
+    uint16_t *d_inv = nullptr;
+    int32_t *d_sbsig = nullptr;
+    {
+        std::vector<uint16_t> inv((size_t)(n_sb * sigma_l), 0);
+        std::vector<int32_t> sbsig((size_t)n_sb);
+        for (int64_t s = 0; s < n_sb; ++s) {
+            sbsig[(size_t)s] = (int32_t)sb_sigma[(size_t)s];
+            for (int i = 0; i < sigma; ++i)
+                if (sb_counts[(size_t)(s * sigma + i)]) inv[(size_t)(s * sigma_l + w.global_mapping[(size_t)(s * sigma + i)])] = (uint16_t)i;
+        }
+        WT_TRY(upload(mem, &d_gmap, w.global_mapping));
+        WT_TRY(upload(mem, &d_inv, inv));
+        WT_TRY(upload(mem, &d_sbsig, sbsig));
+    }
+    int16_t *d_bwt = nullptr;  // (a copy: the caller's BWT stays as it is for the host encoder, should this stage hand the text back)
+    WT_TRY(mem.alloc(&d_bwt, (size_t)n));
+    hipLaunchKernelGGL(k_wt_localize, dim3(4096), dim3(256), 0, 0, d_bwt_global, n, sigma, d_gmap, d_bwt);
+
     // block size of every superblock (WFBB:853-987)
     LevelSums *d_sums = nullptr;
     int *d_flag = nullptr;
@@ -696,7 +744,7 @@ int device_wavelet_stage(const int16_t *d_bwt, int64_t n, int sampling_rate, int
     {
         const int64_t most = n_sb << (kSbLog - kMinLog);
         const unsigned gx = (unsigned)std::min<int64_t>(most, 256 * 64);
-        hipLaunchKernelGGL(k_wt_estimate, dim3(gx, kLevels), dim3(64), lds, 0, d_bwt, n, sigma, sigma_pad, d_sums, d_flag);
+        hipLaunchKernelGGL(k_wt_estimate, dim3(gx, kLevels), dim3(64), lds, 0, d_bwt, n, d_sbsig, sigma_pad, d_sums, d_flag);
     }
     std::vector<LevelSums> sums((size_t)(n_sb * kLevels));
     int too_deep = 0;
@@ -715,9 +763,7 @@ int device_wavelet_stage(const int16_t *d_bwt, int64_t n, int sampling_rate, int
         w.sb[(size_t)s].block_size_log = (int16_t)bsl[(size_t)s];
     }
 
-    int16_t *d_gmap = nullptr;
     uint16_t *d_oov = nullptr;
-    WT_TRY(upload(mem, &d_gmap, w.global_mapping));
     WT_TRY(mem.alloc(&d_oov, 32768));
     WT_TRY(hipMemcpy(d_oov, rrr_offset_of_value(), 32768 * 2, hipMemcpyHostToDevice));
 
@@ -733,7 +779,7 @@ int device_wavelet_stage(const int16_t *d_bwt, int64_t n, int sampling_rate, int
             const int64_t beg = s1 << kSbLog, end = std::min(beg + kSbs, n);
             const int b = bsl[(size_t)s1];
             const int64_t nb = (end - beg + (1ll << b) - 1) >> b;
-            if (!plans.empty() && (blocks + nb) * sigma * 4 > dense_budget) break;
+            if (!plans.empty() && (blocks + nb) * sigma_l * 4 > dense_budget) break;
             SbPlan p;
             p.beg = beg;
             p.end = end;
@@ -742,7 +788,9 @@ int device_wavelet_stage(const int16_t *d_bwt, int64_t n, int sampling_rate, int
             p.blk_base = blocks;
             p.var_base = p.bv_base = 0;
             p.map_base = map_entries;
-            p.gmap_row = s1 * sigma;
+            p.inv_row = s1 * sigma_l;
+            p.sigma = (int32_t)sb_sigma[(size_t)s1];
+            p.pad = 0;
             plans.push_back(p);
             blocks += nb;
             map_entries += sb_sigma[(size_t)s1] * (kSbs >> b);
@@ -756,12 +804,12 @@ int device_wavelet_stage(const int16_t *d_bwt, int64_t n, int sampling_rate, int
         SbTotals *d_totals = nullptr;
         WT_TRY(upload(bm, &d_plans, plans));
         WT_TRY(bm.alloc(&d_info, (size_t)blocks));
-        WT_TRY(bm.alloc(&d_dense, (size_t)(blocks * sigma)));
+        WT_TRY(bm.alloc(&d_dense, (size_t)(blocks * sigma_l)));
         WT_TRY(bm.alloc(&d_headers, (size_t)blocks));
         WT_TRY(bm.alloc(&d_totals, (size_t)nsb));
-        hipLaunchKernelGGL(k_wt_plan, dim3(64, (unsigned)nsb), dim3(64), lds, 0, d_bwt, sigma, sigma_pad, d_plans, d_info,
+        hipLaunchKernelGGL(k_wt_plan, dim3(64, (unsigned)nsb), dim3(64), lds, 0, d_bwt, sigma_l, sigma_pad, d_plans, d_info,
                            d_dense);
-        hipLaunchKernelGGL(k_wt_scan, dim3((unsigned)nsb), dim3(256), 0, 0, sigma, d_plans, d_info, d_dense, d_headers,
+        hipLaunchKernelGGL(k_wt_scan, dim3((unsigned)nsb), dim3(256), 0, 0, sigma_l, d_plans, d_info, d_dense, d_headers,
                            d_totals);
         std::vector<SbTotals> totals((size_t)nsb);
         WT_TRY(hipMemcpy(totals.data(), d_totals, totals.size() * sizeof(SbTotals), hipMemcpyDeviceToHost));
@@ -783,8 +831,8 @@ int device_wavelet_stage(const int16_t *d_bwt, int64_t n, int sampling_rate, int
             const int16_t absent = (int16_t)(sigma - 1);
             if (map_entries) WT_TRY(hipMemsetD16((hipDeviceptr_t)d_map, (unsigned short)absent, (size_t)map_entries));
         }
-        hipLaunchKernelGGL(k_wt_encode, dim3(64, (unsigned)nsb), dim3(64), lds, 0, d_bwt, sigma, sigma_pad, sigma, d_plans,
-                           d_headers, d_dense, d_gmap, d_var, d_bv, d_map);
+        hipLaunchKernelGGL(k_wt_encode, dim3(64, (unsigned)nsb), dim3(64), lds, 0, d_bwt, sigma_l, sigma_pad, sigma, d_plans,
+                           d_headers, d_dense, d_inv, d_var, d_bv, d_map);
 
         // RRR vectors
         std::vector<RrrPlan> rp((size_t)nsb);

@@ -431,6 +431,27 @@ int orc_rrr_rank_ones(const OrcRrr *r, int position) {
     int num_bits_to_use = position - current_bit_position;
     return prefix + __builtin_popcountll(block_value & low_bits_set(num_bits_to_use));
 }
+/* rankOnes over an array of positions (the checker / CPU figure of RrrVectorThroughputBenchmark.java:43-51's shape);
+ * counting mode: algorithmic bytes of every call, merged over the threads */
+void orc_rrr_rank_ones_batch(const OrcRrr *r, const int32_t *positions, int32_t n, int32_t *out, int threads) {
+    (void)threads;
+#ifdef _OPENMP
+    if (threads > 1) {
+        uint64_t ab = 0;
+#pragma omp parallel num_threads(threads) reduction(+ : ab)
+        {
+            memset(&g_cnt, 0, sizeof g_cnt);
+#pragma omp for schedule(static)
+            for (int32_t i = 0; i < n; i++) out[i] = orc_rrr_rank_ones(r, positions[i]);
+            ab += g_cnt.alg_bytes;
+            memset(&g_cnt, 0, sizeof g_cnt);
+        }
+        g_cnt_total.alg_bytes += ab;
+        return;
+    }
+#endif
+    for (int32_t i = 0; i < n; i++) out[i] = orc_rrr_rank_ones(r, positions[i]);
+}
 /* RRR:405-410 */
 int orc_rrr_rank_zeroes(const OrcRrr *r, int position) {
     if (position < 0) return 0;

@@ -71,6 +71,7 @@ OrcRrr *orc_rrr_from_ints(const int32_t *ints, int n_ints, int sample);         
 int orc_rrr_access(const OrcRrr *r, int position, int *status);   /* RRR:314-349 */
 int orc_rrr_rank_ones(const OrcRrr *r, int position);             /* RRR:358-396 */
 int orc_rrr_rank_zeroes(const OrcRrr *r, int position);           /* RRR:405-410 */
+void orc_rrr_rank_ones_batch(const OrcRrr *r, const int32_t *positions, int32_t n, int32_t *out, int threads);
 int orc_rrr_estimated_memory(const OrcRrr *r);                    /* RRR:418-423 */
 void orc_rrr_free(OrcRrr *r);
 /* the three static tables (generated, RRR:104-129, 488-16900) as flat u16 arrays */

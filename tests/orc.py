@@ -43,6 +43,8 @@ def lib():
     L.orc_rrr_access.argtypes = [vp, i32, p(i32)]
     L.orc_rrr_rank_ones.argtypes = [vp, i32]
     L.orc_rrr_rank_zeroes.argtypes = [vp, i32]
+    L.orc_rrr_rank_ones_batch.argtypes = [vp, vp, i32, vp, i32]
+    L.orc_rrr_rank_ones_batch.restype = None
     L.orc_rrr_estimated_memory.argtypes = [vp]
     L.orc_rrr_free.argtypes = [vp]
     for n in ("offset_of_value", "value_of_offset", "cardinality_offsets"):
@@ -133,6 +135,12 @@ class Rrr:
 
     def rank_zeroes(self, pos):
         return lib().orc_rrr_rank_zeroes(self.h, pos)
+
+    def rank_ones_batch(self, positions, threads=1):
+        p = np.ascontiguousarray(positions, dtype=np.int32)
+        out = np.zeros(len(p), np.int32)
+        lib().orc_rrr_rank_ones_batch(self.h, p.ctypes.data, len(p), out.ctypes.data, int(threads))
+        return out
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import index4j_amd as ia
+from index4j_amd import workload
 import orc
 from common import JavaRandom, hdfs_text, occurrences, until_boundary, until_boundary_left, until_boundary_right
 from parity_checks import GpuEngine, check_all
@@ -579,8 +580,9 @@ def test_device_construction_is_byte_identical():
     (FM:173; WFBB:130-154, 362-535, 570-991; RRR:225-286) encoded in HBM — against the ORACLE's builder and the host
     builder: the serialized indexes must be the same bytes.
     Texts: the fixture (763 codes), long repeats (many doubling rounds), a single repeated character (run blocks
-    only: empty bit vectors), embedded sentinels, tiny inputs, DNA, an alphabet above the device encoder's limit
-    (host fallback), extraction on and off."""
+    only: empty bit vectors), embedded sentinels, tiny inputs, DNA, alphabets of 1,960 and 1,100 codes (encoded in HBM
+    over superblock-local codes since round 4), a superblock with more distinct symbols than a wave's LDS holds (host
+    fallback), extraction on and off."""
     rnd = random.Random(99)
     texts = [
         (HD[:120_000], 32), (HD[:50_000], 1), (HD[:33_333], 7),
@@ -590,7 +592,10 @@ def test_device_construction_is_byte_identical():
         ("", 4), ("a", 1), ("ab", 2), ("\0", 3), ("abracadabra", 2),
         ("".join(rnd.choice("ACGT") for _ in range(200_000)), 64),
         ("".join(chr(rnd.randrange(40, 900)) for _ in range(90_000)), 32),
-        ("".join(chr(rnd.randrange(40, 2000)) for _ in range(90_000)), 32),   # 1,960 codes: the host encodes the tree
+        ("".join(chr(rnd.randrange(40, 2000)) for _ in range(90_000)), 32),   # 1,960 codes, all in one superblock: host encoder
+        # 1,960 codes, at most ~1,000 of them in any one superblock (the BWT groups by context): device encoder
+        ("".join(chr(40 + (i >> 11) % 40 * 49 + rnd.randrange(49)) for i in range(2_400_000)), 32),
+        (workload.reference_text(21), 32),  # the reference's data-set shape: ~1,100 symbols
         # characters above the alphabet pass's direct LDS tables (hashed slots, collisions to the global tables)
         ("".join(chr(0x4E00 + int(rnd.expovariate(0.004)) % 5000) if rnd.random() < 0.8 else " " for _ in range(120_000)), 16),
         ("".join(chr(97 + min(25, int(rnd.expovariate(0.9)))) for _ in range(1_200_000)), 32),  # skewed, two superblocks
@@ -602,7 +607,11 @@ def test_device_construction_is_byte_identical():
             assert dev.write(False) == expect, (len(text), sr, extract)
             on_device = dev.build_stats["wavelet_device_seconds"] > 0
             codes = len(set(text)) + 1  # the terminator's code 0 + one per distinct character (FM:396-435)
-            assert on_device == (codes <= 1024), (len(text), codes)
+            # the device encoder takes every text whose superblocks each hold at most 1,536 distinct symbols
+            if codes <= 1536:
+                assert on_device, (len(text), codes)
+            if len(text) <= (1 << 20) and codes > 1537:
+                assert not on_device, (len(text), codes)
     try:  # the host encoder behind the device suffix-array stage (option): same bytes
         assert ia.lib.fmx_set_option(b"wavelet_on_device", 0) == 0
         dev = ia.FmIndex(HD[:120_000], 32, True, device=None, build_device=0)

@@ -36,6 +36,27 @@ def test_reference_series_on_a_1100_symbol_text_matches_the_oracle_row_by_row():
     assert all("rows_where_the_reference_differs_from_the_text" in r for r in rows if r["benchmark"] == "extract")
 
 
+@pytest.mark.gpu
+def test_series_extras_rows_match_the_oracle_at_small_size():
+    """BASELINE.md's remaining rows (tools/series_extras.py, bench.py --series-extras) on small inputs: stand-alone
+    RrrVector.rankOnes through the device-pointer entry point at sampleSize 16 / 32 / 64 / 256 and on a 1 %-dense vector
+    (every rank against the oracle AND the plain bit count), locateAndExtract (all hits, extracted rows of the first
+    queries), ingest + serialized size rows — the tool raises on any mismatch"""
+    import torch
+
+    import series_extras
+
+    dev = torch.device("cuda", 0)
+    rr = series_extras.rrr_rows(ia, torch, orc, dev, lambda *a: None, n_bits=300_007, queries=60_000)
+    assert [(r["density"], r["sample_size"]) for r in rr] == [(0.5, 16), (0.5, 32), (0.5, 64), (0.5, 256), (0.01, 32)]
+    assert all(r["ops_per_s"] > 0 and 4 <= r["alg_bytes_per_op"] < 90 for r in rr)
+    assert rr[3]["alg_bytes_per_op"] > rr[0]["alg_bytes_per_op"]  # sampleSize 256 scans more class nibbles than 16
+    pr = series_extras.pipeline_and_ingest_rows(ia, torch, orc, dev, lambda *a: None, text_log2=21, queries=1500, max_matches=40,
+                                                extract_len=64, check=200)
+    assert [r["benchmark"] for r in pr] == ["ingest + serialized size"] * 2 + ["locateAndExtract"]
+    assert pr[0]["serialized_bytes"] > pr[1]["serialized_bytes"] and pr[2]["hits"] >= 1500
+
+
 def test_multichar_text_has_the_fixture_shape():
     t = workload.reference_text(20)
     assert 1000 <= len(np.unique(t)) <= 1100
