@@ -838,7 +838,9 @@ def measure_host_buffers(ctx, args, q, pat, off, expect, step_ms):
     return {"what": "fmx_count_batch (host buffers, pageable numpy arrays; counts + statuses back) of batch 0: the JNI binding's call "
                     "path.  Chunks of 262,144 patterns travel while the previous chunk is counted (2 streams), results return through "
                     "pinned staging, offsets of equal-length runs are made on the device",
-            "stat": "means of 7 calls (minima: pageable %.3f, registered %.3f ms)" % (min(piped_all), min(registered_all)),
+            "stat": "means of 7 calls (medians: pageable %.3f, registered %.3f ms; minima: %.3f, %.3f)"
+                    % (float(np.median(piped_all)), float(np.median(registered_all)), min(piped_all), min(registered_all)),
+            "ms_per_call_median": float(np.median(piped_all)), "ms_per_call_registered_buffers_median": float(np.median(registered_all)),
             "patterns": n, "ms_per_call": piped, "patterns_per_s": n / piped * 1e3,
             "ms_per_call_unpipelined": plain, "ms_per_call_registered_buffers": registered,
             "ratio_registered_to_max_of_floor_and_device_step": registered / floor,

@@ -9,6 +9,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <immintrin.h>
+
 #include <atomic>
 #include <chrono>
 #include <climits>
@@ -359,19 +361,46 @@ int pipe_streams(int device, PipeStreams **out) {
 }
 
 // One pass over pat_off[lo .. hi]: offsets never decrease and end at or below `limit`; *uniform = every pattern of the
-// run has the same length (then the offsets need not travel: k_fill_offsets).  Branch-free so that it vectorises.
-bool scan_offsets(const int32_t *pat_off, int32_t lo, int32_t hi, int64_t limit, bool *uniform) {
-    // differences in 64 bits: {8, 2000000000, -2000000000, 16} has no negative int32 difference (the second wraps to
-    // +294,967,296) and both ends in range — monotonic offsets with checked ends is what keeps every offset inside
-    const int64_t m0 = (int64_t)pat_off[lo + 1] - pat_off[lo];
-    int64_t neg = 0, diff = 0;
+// run has the same length (then the offsets need not travel: k_fill_offsets).  Branch-free (AVX2 where the host has it); one
+// core reads 1 M offsets in 200-300 us whatever the code — the pass is memory-bound; running it on a thread of its own, ahead
+// of the issuing thread, was measured slower (the thread's start costs more than the pass hides: profiles/r04_experiments.txt).
+// Order is judged by comparing neighbours — never by the sign of a 32-bit difference,
+// which wraps ({8, 2000000000, -2000000000, 16} has no negative int32 difference and both ends in range) — and with
+// monotonic offsets and checked ends every offset lies inside; equality of lengths may use the wrapping difference.
+static bool scan_offsets_plain(const int32_t *o, int32_t lo, int32_t hi, int64_t limit, bool *uniform) {
+    const uint32_t m0 = (uint32_t)o[lo + 1] - (uint32_t)o[lo];
+    uint32_t bad = 0, diff = 0;
     for (int32_t i = lo; i < hi; ++i) {
-        const int64_t d = (int64_t)pat_off[i + 1] - pat_off[i];
-        neg |= d;
-        diff |= d ^ m0;
+        const int32_t a = o[i], b = o[i + 1];
+        bad |= (uint32_t)(b < a);
+        diff |= ((uint32_t)b - (uint32_t)a) ^ m0;
     }
     *uniform = diff == 0;
-    return neg >= 0 && pat_off[lo] >= 0 && (int64_t)pat_off[hi] <= limit;
+    return bad == 0 && o[lo] >= 0 && (int64_t)o[hi] <= limit;
+}
+__attribute__((target("avx2"))) static bool scan_offsets_avx2(const int32_t *o, int32_t lo, int32_t hi, int64_t limit, bool *uniform) {
+    const uint32_t m0 = (uint32_t)o[lo + 1] - (uint32_t)o[lo];
+    __m256i vbad = _mm256_setzero_si256(), vdiff = _mm256_setzero_si256();
+    const __m256i vm0 = _mm256_set1_epi32((int)m0);
+    int32_t i = lo;
+    for (; i + 8 <= hi; i += 8) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(o + i));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(o + i + 1));
+        vbad = _mm256_or_si256(vbad, _mm256_cmpgt_epi32(a, b));
+        vdiff = _mm256_or_si256(vdiff, _mm256_xor_si256(_mm256_sub_epi32(b, a), vm0));
+    }
+    uint32_t bad = !_mm256_testz_si256(vbad, vbad), diff = !_mm256_testz_si256(vdiff, vdiff);
+    for (; i < hi; ++i) {
+        const int32_t a = o[i], b = o[i + 1];
+        bad |= (uint32_t)(b < a);
+        diff |= ((uint32_t)b - (uint32_t)a) ^ m0;
+    }
+    *uniform = diff == 0;
+    return bad == 0 && o[lo] >= 0 && (int64_t)o[hi] <= limit;
+}
+bool scan_offsets(const int32_t *pat_off, int32_t lo, int32_t hi, int64_t limit, bool *uniform) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    return avx2 ? scan_offsets_avx2(pat_off, lo, hi, limit, uniform) : scan_offsets_plain(pat_off, lo, hi, limit, uniform);
 }
 
 // Where a call's device scratch comes from.  Device-pointer entry points: the index's per-(stream, kind) buffers —
