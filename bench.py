@@ -287,7 +287,10 @@ def compact_line(out):
                 sec.append({"config": _short(name, 44), "ms": sr.get("ms_per_batch", None if sr.get("build_s") is None else sr["build_s"] * 1e3),
                             "frac": (sr.get("roofline") or {}).get("frac")})
             continue
-        sec.append({"config": _short(str(row.get("config") or row.get("metric")).replace("BASELINE.json ", ""), 48),
+        cfg_name = row.get("config") or row.get("metric")
+        if isinstance(cfg_name, dict):  # a whole line of another workload (configs[4] inside the N > 1 default run)
+            cfg_name = "configs[4] segments: " + str(cfg_name.get("workload"))
+        sec.append({"config": _short(str(cfg_name).replace("BASELINE.json ", ""), 48),
                     "ms": row.get("ms", row.get("ms_per_step")), "frac": (row.get("roofline") or {}).get("frac")})
     if sec:
         c["secondary"] = sec
