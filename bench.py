@@ -239,7 +239,7 @@ def compact_line(out):
     c["ranks_seen"] = out.get("ranks_seen")
     cfg = out.get("config") or {}
     c["config"] = {"workload": _short(cfg.get("workload"), 260)}
-    for k in ("text_chars", "patterns_per_gpu", "pattern_len", "sample_rate", "batches", "segments", "patterns_total", "max_matches",
+    for k in ("image", "text_chars", "patterns_per_gpu", "pattern_len", "sample_rate", "batches", "segments", "patterns_total", "max_matches",
               "count_checksum", "patterns_checked_vs_oracle"):
         if cfg.get(k) is not None:
             c["config"][k] = cfg[k]
@@ -737,6 +737,7 @@ def run_count(ctx, args):
         "config": {"workload": "count() batch of %d random %d-char patterns per GPU on %d MiB synthetic log text, "
                                "sampleRate=%d (BASELINE.json configs[1]); %d distinct batches rotate through the timed loop"
                                % (n, m, (1 << args.text_log2) >> 20, args.sample_rate, n_batches),
+                   "image": "compact" if args.image_compact else "expanded",
                    "text_chars": 1 << args.text_log2, "patterns_per_gpu": n, "pattern_len": m,
                    "sample_rate": args.sample_rate, "batches": n_batches,
                    "parallelism": "one batch of %d patterns sharded x%d (contiguous shards from rank 0), index image "
@@ -1262,6 +1263,9 @@ def main():
                          "table, two batches in flight), so that per-kernel averages and counters describe the timed path only")
     ap.add_argument("--overlap-streams", type=int, default=2,
                     help="streams of the extra `overlapped` measurement (batches in flight); 1 = skip it")
+    ap.add_argument("--image-compact", action="store_true",
+                    help="run the whole line over COMPACT images (library option image_compact: bit vectors as RRR records, value table "
+                         "in LDS; smaller, slower) — the line says so in config.image")
     ap.add_argument("--share-one-gpu", action="store_true",
                     help="REHEARSAL of the N > 1 code path on a one-GPU box: every rank queries on cuda:0, collectives run "
                          "over gloo on host tensors.  The line says so (`rehearsal`); it is not a measurement.")
@@ -1282,6 +1286,8 @@ def main():
 
     import index4j_amd as ia
 
+    if args.image_compact:
+        check_rc(ia, ia.lib.fmx_set_option(b"image_compact", 1), "fmx_set_option")
     ctx = Ctx()
     ctx.ia, ctx.torch, ctx.dry = ia, torch, args.dry_run
     ctx.world, ctx.rank = world, int(os.environ.get("RANK", "0"))

@@ -68,6 +68,13 @@ int fmx_build_on_device(const uint16_t *text, int32_t n, int32_t sample_rate, in
 /* seconds fmx_build_on_device spent encoding the wavelet tree in HBM; 0 = it was encoded on the host */
 double fmx_build_wavelet_seconds(const fmx_index *idx);
 
+/* Image form (fmx_set_option("image_compact", 0 | 1), applies to images flattened afterwards: fmx_to_device / fmx_blob of an index
+ * that has none yet).  0 (default): the bit vectors of the wavelet tree and the sampled-row bitmap are EXPANDED into 16-byte cells
+ * {ones before, 96 bits} — a rank is one load + three popcounts; 0.64 bytes per text byte resident on the 256 MiB log.
+ * 1 (compact): they stay in the reference's own compression (15-bit blocks as class + offset, RRR:225-286) as 16-block records
+ * + offsets stream, decoded by the kernels through the value-of-offset table in LDS — smaller (bytes per text byte and timings:
+ * DESIGN.md 3), a rank costs a second dependent load.  Results are identical; an image says which form it is, and travels as
+ * before (fmx_blob / fmx_attach_device_blob). */
 /* The suffix table of a resident index: fmx_to_device / fmx_attach_device_blob grow, level by level, the set of strings of
  * *chars codes that OCCUR in the text, each with its SA interval (the state of FM:455-474 after a pattern's last *chars
  * characters, computed by the same rank code the queries run), and hash it: 16-byte slots, twice as many as strings.

@@ -22,36 +22,66 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
+// fmx_kernels.hip is compiled twice: namespace fmx serves expanded images, fmxc compact ones (BlobHeader.compact)
+#define FMX_KERNEL_API                                                                                                  \
+    int launch_suffix_level1(const fmx::DevIndex &, fmx::SuffixSlot *, uint32_t *, uint32_t, hipStream_t);              \
+    int launch_suffix_expand(const fmx::DevIndex &, int, const fmx::SuffixSlot *, uint32_t, int, int, fmx::SuffixSlot *, uint32_t *, uint32_t, hipStream_t); \
+    int launch_suffix_insert(const fmx::DevIndex &, const fmx::SuffixSlot *, uint32_t, int, fmx::SuffixSlot *, hipStream_t); \
+    int launch_count_plan(const fmx::DevIndex &, const uint16_t *, const int32_t *, int32_t, void *, size_t, bool, fmx::CountPlan *, \
+                          hipStream_t);                                                                                 \
+    int launch_count(const fmx::DevIndex &, int, const uint16_t *, const int32_t *, const fmx::CountPlan *, bool, int32_t, int32_t *, \
+                     int32_t *, int32_t *, int32_t *, hipStream_t);                                                     \
+    size_t count_workspace_bytes(const fmx::DevIndex &, int32_t n);                                                     \
+    int launch_locate_walk(const fmx::DevIndex &, int, const int32_t *, int32_t, int32_t, int32_t *, int32_t, int32_t *, \
+                           int32_t *, int32_t *, const int32_t *, hipStream_t);                                         \
+    int launch_extract(const fmx::DevIndex &, int, const int32_t *, const int32_t *, int64_t, uint16_t *, int32_t, int32_t, \
+                       int32_t *, int32_t *, int32_t *, const int32_t *, int32_t, int32_t, hipStream_t);                \
+    int launch_extract_boundary(const fmx::DevIndex &, int, const int32_t *, int64_t, uint16_t, int, uint16_t *, int32_t, \
+                                int32_t, int32_t *, int32_t *, int32_t *, int32_t *, void *, size_t, const int32_t *, int32_t, \
+                                hipStream_t);                                                                           \
+    size_t boundary_workspace_bytes(const fmx::DevIndex &, int64_t n, int n_cu);                                        \
+    int launch_rrr_rank_ones(const fmx::DevIndex &, int, const int32_t *, int32_t, int32_t *, hipStream_t);             \
+    int launch_rrr_access(const fmx::DevIndex &, int, const int32_t *, int32_t, uint8_t *, int32_t *, hipStream_t);     \
+    int launch_segment_add_counts(int64_t *, int64_t *, int32_t *, const int32_t *, const int32_t *, const int32_t *, int32_t, \
+                                  int, hipStream_t);                                                                    \
+    int launch_segment_append_hits(int64_t *, int32_t *, int32_t *, const int32_t *, const int32_t *, const int32_t *, int32_t, \
+                                   int32_t, int64_t, int, hipStream_t);                                                 \
+    int launch_fill_offsets(int32_t *, int32_t, int32_t, int32_t, hipStream_t);                                         \
+    int launch_wt_rank(const fmx::DevIndex &, int, const int64_t *, const int32_t *, int32_t, int64_t *, int32_t *, hipStream_t); \
+    int launch_wt_inverse_select(const fmx::DevIndex &, int, const int64_t *, int32_t, int64_t *, int32_t *, hipStream_t); \
+    int set_option(const char *, int);                                                                                  \
+
 namespace fmx {
-int launch_suffix_level1(const DevIndex &, SuffixSlot *, uint32_t *, uint32_t, hipStream_t);
-int launch_suffix_expand(const DevIndex &, int, const SuffixSlot *, uint32_t, int, int, SuffixSlot *, uint32_t *, uint32_t, hipStream_t);
-int launch_suffix_insert(const DevIndex &, const SuffixSlot *, uint32_t, int, SuffixSlot *, hipStream_t);
-int launch_count_plan(const DevIndex &, const uint16_t *, const int32_t *, int32_t, void *, size_t, bool, CountPlan *,
-                      hipStream_t);
-int launch_count(const DevIndex &, int, const uint16_t *, const int32_t *, const CountPlan *, bool, int32_t, int32_t *,
-                 int32_t *, int32_t *, int32_t *, hipStream_t);
-size_t count_workspace_bytes(const DevIndex &, int32_t n);
-int launch_locate_walk(const DevIndex &, int, const int32_t *, int32_t, int32_t, int32_t *, int32_t, int32_t *,
-                       int32_t *, int32_t *, const int32_t *, hipStream_t);
-int launch_extract(const DevIndex &, int, const int32_t *, const int32_t *, int64_t, uint16_t *, int32_t, int32_t,
-                   int32_t *, int32_t *, int32_t *, const int32_t *, int32_t, int32_t, hipStream_t);
-int launch_extract_boundary(const DevIndex &, int, const int32_t *, int64_t, uint16_t, int, uint16_t *, int32_t,
-                            int32_t, int32_t *, int32_t *, int32_t *, int32_t *, void *, size_t, const int32_t *, int32_t,
-                            hipStream_t);
-size_t boundary_workspace_bytes(const DevIndex &, int64_t n, int n_cu);
-int launch_rrr_rank_ones(const DevIndex &, int, const int32_t *, int32_t, int32_t *, hipStream_t);
-int launch_rrr_access(const DevIndex &, int, const int32_t *, int32_t, uint8_t *, int32_t *, hipStream_t);
-int launch_segment_add_counts(int64_t *, int64_t *, int32_t *, const int32_t *, const int32_t *, const int32_t *, int32_t,
-                              int, hipStream_t);
-int launch_segment_append_hits(int64_t *, int32_t *, int32_t *, const int32_t *, const int32_t *, const int32_t *, int32_t,
-                               int32_t, int64_t, int, hipStream_t);
-int launch_fill_offsets(int32_t *, int32_t, int32_t, int32_t, hipStream_t);
-int launch_wt_rank(const DevIndex &, int, const int64_t *, const int32_t *, int32_t, int64_t *, int32_t *, hipStream_t);
-int launch_wt_inverse_select(const DevIndex &, int, const int64_t *, int32_t, int64_t *, int32_t *, hipStream_t);
-int set_option(const char *, int);
+FMX_KERNEL_API
 }  // namespace fmx
+namespace fmxc {
+FMX_KERNEL_API
+}  // namespace fmxc
+#undef FMX_KERNEL_API
+struct fmx_index;
+static bool image_is_compact(const fmx_index *idx);
+// k_<launcher>(idx, args...): the launcher of the namespace that serves this index's image
+#define FMX_DISPATCH_FN(NAME)                                                                             \
+    template <class... A>                                                                                 \
+    static auto k_##NAME(const fmx_index *idx, A &&...a) {                                                \
+        return image_is_compact(idx) ? fmxc::NAME(std::forward<A>(a)...) : fmx::NAME(std::forward<A>(a)...); \
+    }
+FMX_DISPATCH_FN(launch_suffix_level1)
+FMX_DISPATCH_FN(launch_suffix_expand)
+FMX_DISPATCH_FN(launch_suffix_insert)
+FMX_DISPATCH_FN(launch_count_plan)
+FMX_DISPATCH_FN(launch_count)
+FMX_DISPATCH_FN(count_workspace_bytes)
+FMX_DISPATCH_FN(launch_locate_walk)
+FMX_DISPATCH_FN(launch_extract)
+FMX_DISPATCH_FN(launch_extract_boundary)
+FMX_DISPATCH_FN(boundary_workspace_bytes)
+FMX_DISPATCH_FN(launch_wt_rank)
+FMX_DISPATCH_FN(launch_wt_inverse_select)
+#undef FMX_DISPATCH_FN
 
 struct fmx_index {
     fmx::FmModel model;
@@ -84,6 +114,8 @@ struct fmx_index {
     // means "the caller's order" (k_count maps the characters itself) instead of reading another batch's records
     mutable std::map<void *, Plan> plans;
 };
+
+static bool image_is_compact(const fmx_index *idx) { return idx->hdr.compact != 0; }
 
 namespace {
 
@@ -502,7 +534,15 @@ int fmx_set_option(const char *name, int value) {
         fmx::set_inv_fast(value != 0);
         return FMX_OK;
     }
-    if (!name || fmx::set_option(name, value)) return fail(FMX_E_ARG, "unknown option or bad value");
+    if (name && !strcmp(name, "image_compact")) {  // images flattened from now on keep their bit vectors compressed (fmx.h)
+        fmx::set_image_compact(value);
+        return FMX_OK;
+    }
+    if (!name) return fail(FMX_E_ARG, "unknown option or bad value");
+    {  // launch options go to both kernel sets
+        const int a = fmx::set_option(name, value), b = fmxc::set_option(name, value);
+        if (a || b) return fail(FMX_E_ARG, "unknown option or bad value");
+    }
     return FMX_OK;
     });
 }
@@ -670,7 +710,7 @@ static void build_suffix_table(fmx_index *idx) {
         return hipMemcpy(out, d_count, 4, hipMemcpyDeviceToHost) == hipSuccess;
     };
     uint32_t n_prev = 0;
-    if (hipMemset(d_count, 0, 64) != hipSuccess || fmx::launch_suffix_level1(idx->dev, level1, d_count, cap1, nullptr) != 0 ||
+    if (hipMemset(d_count, 0, 64) != hipSuccess || k_launch_suffix_level1(idx, idx->dev, level1, d_count, cap1, nullptr) != 0 ||
         !counted(&n_prev) || n_prev == 0 || n_prev > cap1) {
         cleanup();
         return;
@@ -688,7 +728,7 @@ static void build_suffix_table(fmx_index *idx) {
         uint32_t n_next = 0;
         if (room == 0) break;
         if (hipMemset(d_count, 0, 64) != hipSuccess ||
-            fmx::launch_suffix_expand(idx->dev, idx->n_cu, prev, n_prev, chars, key_bits, all + total, d_count, room, nullptr) != 0 ||
+            k_launch_suffix_expand(idx, idx->dev, idx->n_cu, prev, n_prev, chars, key_bits, all + total, d_count, room, nullptr) != 0 ||
             !counted(&n_next)) {
             cleanup();
             return;
@@ -721,7 +761,7 @@ static void build_suffix_table(fmx_index *idx) {
     bool ok = hipMalloc(&d_slots, (size_t)slots * sizeof(fmx::SuffixSlot)) == hipSuccess &&
               hipMemset(d_slots, 0xff, (size_t)slots * sizeof(fmx::SuffixSlot)) == hipSuccess;
     for (int len = 2; ok && len <= chars; ++len)
-        ok = fmx::launch_suffix_insert(geometry, all + begin[len], begin[len + 1] - begin[len], len,
+        ok = k_launch_suffix_insert(idx, geometry, all + begin[len], begin[len + 1] - begin[len], len,
                                        static_cast<fmx::SuffixSlot *>(d_slots), nullptr) == 0;
     if (!ok || hipStreamSynchronize(nullptr) != hipSuccess) {
         if (d_slots) (void)hipFree(d_slots);
@@ -858,12 +898,12 @@ static int plan_order(const fmx_index *idx, const uint16_t *d_pat, const int32_t
         idx->plans.erase(scratch.stream);
     }
     void *ws = nullptr;
-    const size_t ws_bytes = fmx::count_workspace_bytes(idx->dev, n);
+    const size_t ws_bytes = k_count_workspace_bytes(idx, idx->dev, n);
     int rc = scratch.get(kWsPlan, ws_bytes, &ws);
     if (rc) return rc;
     if (!ws) return FMX_OK;
     // a per-stream workspace keeps its head zeroed between plans; a per-call block comes from the cache: clear it
-    int e = fmx::launch_count_plan(idx->dev, d_pat, d_pat_off, n, ws, ws_bytes, !scratch.per_call, plan,
+    int e = k_launch_count_plan(idx, idx->dev, d_pat, d_pat_off, n, ws, ws_bytes, !scratch.per_call, plan,
                                    static_cast<hipStream_t>(scratch.stream));
     if (e) {
         // A plan that stopped half way (k_plan_codes ran, k_plan_scatter did not) leaves its histogram in the workspace's
@@ -914,7 +954,7 @@ int fmx_count_ordered_dev(const fmx_index *idx, const uint16_t *d_pat, const int
             it->second.pat_off == d_pat_off)
             plan = it->second.plan;
     }
-    int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, &plan, false, n, d_counts, d_lf_steps, d_status,
+    int e = k_launch_count(idx, idx->dev, idx->n_cu, d_pat, d_pat_off, &plan, false, n, d_counts, d_lf_steps, d_status,
                               nullptr, static_cast<hipStream_t>(stream));
     if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
     return FMX_OK;
@@ -929,7 +969,7 @@ static int count_impl(const fmx_index *idx, const uint16_t *d_pat, const int32_t
     fmx::CountPlan plan;
     rc = plan_order(idx, d_pat, d_pat_off, n, scratch, &plan);
     if (rc) return rc;
-    int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, &plan, false, n, d_counts, d_lf_steps, d_status,
+    int e = k_launch_count(idx, idx->dev, idx->n_cu, d_pat, d_pat_off, &plan, false, n, d_counts, d_lf_steps, d_status,
                               nullptr, static_cast<hipStream_t>(scratch.stream));
     if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
     return FMX_OK;
@@ -955,10 +995,10 @@ static int locate_impl(const fmx_index *idx, const uint16_t *d_pat, const int32_
     fmx::CountPlan plan;
     rc = plan_order(idx, d_pat, d_pat_off, n, scratch, &plan);
     if (rc) return rc;
-    int e = fmx::launch_count(idx->dev, idx->n_cu, d_pat, d_pat_off, &plan, false, n, d_found, d_lf_steps, d_status,
+    int e = k_launch_count(idx, idx->dev, idx->n_cu, d_pat, d_pat_off, &plan, false, n, d_found, d_lf_steps, d_status,
                               d_range_ws, st);
     if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
-    e = fmx::launch_locate_walk(idx->dev, idx->n_cu, d_range_ws, n, max_matches, d_locs, loc_cap, d_found, d_lf_steps,
+    e = k_launch_locate_walk(idx, idx->dev, idx->n_cu, d_range_ws, n, max_matches, d_locs, loc_cap, d_found, d_lf_steps,
                                 d_status, nullptr, st);
     if (e) return fail(FMX_E_HIP, std::string("k_locate_walk launch: ") + hipGetErrorString((hipError_t)e));
     return FMX_OK;
@@ -982,7 +1022,7 @@ int fmx_extract_batch_dev(const fmx_index *idx, const int32_t *d_start, const in
     if (rc) return rc;
     if (n < 0 || dst_len < 0 || (n > 0 && (!d_start || !d_stop || !d_out_len || (!d_dst && dst_len > 0))))
         return fail(FMX_E_ARG, "bad arguments");
-    int e = fmx::launch_extract(idx->dev, idx->n_cu, d_start, d_stop, n, d_dst, dst_len, offset, d_out_len, d_lf_steps,
+    int e = k_launch_extract(idx, idx->dev, idx->n_cu, d_start, d_stop, n, d_dst, dst_len, offset, d_out_len, d_lf_steps,
                                 d_status, nullptr, 0, 0, static_cast<hipStream_t>(stream));
     if (e) return fail(FMX_E_HIP, std::string("k_extract launch: ") + hipGetErrorString((hipError_t)e));
     return FMX_OK;
@@ -995,11 +1035,11 @@ static int boundary_impl(const fmx_index *idx, const int32_t *d_from, int64_t n,
     void *ws = nullptr;
     // two windows of sampleRate characters per lane; an index sampled so sparsely that they would take more than 8 GiB is
     // served by the literal form (no windows) instead of failing on the allocation
-    size_t ws_bytes = fmx::boundary_workspace_bytes(idx->dev, n, idx->n_cu);
+    size_t ws_bytes = k_boundary_workspace_bytes(idx, idx->dev, n, idx->n_cu);
     if (ws_bytes > ((size_t)8 << 30)) ws_bytes = 0;
     int rc = scratch.get(kWsBoundary, ws_bytes, &ws);
     if (rc) return rc;
-    int e = fmx::launch_extract_boundary(idx->dev, idx->n_cu, d_from, n, boundary, mode, d_dst, dst_len, offset,
+    int e = k_launch_extract_boundary(idx, idx->dev, idx->n_cu, d_from, n, boundary, mode, d_dst, dst_len, offset,
                                          d_out_len, d_lf_steps, d_status, d_aux, ws, ws_bytes, slot_found, slots,
                                          static_cast<hipStream_t>(scratch.stream));
     if (e) return fail(FMX_E_HIP, std::string("k_extract_boundary launch: ") + hipGetErrorString((hipError_t)e));
@@ -1040,7 +1080,7 @@ static int locate_extract_impl(const fmx_index *idx, const uint16_t *d_pat, cons
     rc = locate_impl(idx, d_pat, d_pat_off, n, max_matches, d_locs, max_matches, d_found, d_lf_steps, d_status, d_range_ws,
                      scratch);
     if (rc) return rc;
-    int e = fmx::launch_extract(idx->dev, idx->n_cu, d_locs, nullptr, (int64_t)n * max_matches, d_dst, extract_len, 0,
+    int e = k_launch_extract(idx, idx->dev, idx->n_cu, d_locs, nullptr, (int64_t)n * max_matches, d_dst, extract_len, 0,
                                 d_out_len, nullptr, d_hit_status, d_found, max_matches, extract_len,
                                 static_cast<hipStream_t>(scratch.stream));
     if (e) return fail(FMX_E_HIP, std::string("k_extract launch: ") + hipGetErrorString((hipError_t)e));
@@ -1114,7 +1154,7 @@ static int count_segments_impl(const fmx_index *const *segs, int32_t n_segs, con
     if (rc) return rc;
     int32_t *cnt = d_tmp, *lf = d_tmp + n, *sts = d_tmp + 2 * (size_t)n;
     for (int32_t s = 0; s < n_segs; ++s) {
-        int e = fmx::launch_count(segs[s]->dev, segs[s]->n_cu, d_pat, d_pat_off, &plan, s != 0, n, cnt, lf, sts, nullptr, st);
+        int e = k_launch_count(segs[s], segs[s]->dev, segs[s]->n_cu, d_pat, d_pat_off, &plan, s != 0, n, cnt, lf, sts, nullptr, st);
         if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
         e = fmx::launch_segment_add_counts(d_counts, d_lf_steps, d_status, cnt, lf, sts, n, s == 0, st);
         if (e) return fail(FMX_E_HIP, std::string("k_segment_add_counts launch: ") + hipGetErrorString((hipError_t)e));
@@ -1146,12 +1186,12 @@ static int locate_segments_impl(const fmx_index *const *segs, int32_t n_segs, co
     int rc = plan_order(segs[0], d_pat, d_pat_off, n, scratch, &plan);
     if (rc) return rc;
     for (int32_t s = 0; s < n_segs; ++s) {
-        int e = fmx::launch_count(segs[s]->dev, segs[s]->n_cu, d_pat, d_pat_off, &plan, s != 0, n, seg_found, nullptr,
+        int e = k_launch_count(segs[s], segs[s]->dev, segs[s]->n_cu, d_pat, d_pat_off, &plan, s != 0, n, seg_found, nullptr,
                                   seg_status, range, st);
         if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
         // like the caller's loop `n += seg.locate(p, 0, len, locations, maxMatches - n)`: hits already
         // taken from earlier segments shrink this segment's limit
-        e = fmx::launch_locate_walk(segs[s]->dev, segs[s]->n_cu, range, n, max_matches, seg_locs, max_matches, seg_found,
+        e = k_launch_locate_walk(segs[s], segs[s]->dev, segs[s]->n_cu, range, n, max_matches, seg_locs, max_matches, seg_found,
                                     nullptr, seg_status, s ? d_found : nullptr, st);
         if (e) return fail(FMX_E_HIP, std::string("k_locate_walk launch: ") + hipGetErrorString((hipError_t)e));
         e = fmx::launch_segment_append_hits(d_locs, d_found, d_status, seg_locs, seg_found, seg_status, n, max_matches,
@@ -1829,10 +1869,10 @@ static int wavelet_batch(const fmx_index *idx, const int64_t *positions, const i
     int e;
     if (symbols) {
         H2D(d_sym.p, symbols, (size_t)n * 4);
-        e = fmx::launch_wt_rank(idx->dev, idx->n_cu, d_pos.as<int64_t>(), d_sym.as<int32_t>(), n, d_out.as<int64_t>(),
+        e = k_launch_wt_rank(idx, idx->dev, idx->n_cu, d_pos.as<int64_t>(), d_sym.as<int32_t>(), n, d_out.as<int64_t>(),
                                 d_st.as<int32_t>(), nullptr);
     } else {
-        e = fmx::launch_wt_inverse_select(idx->dev, idx->n_cu, d_pos.as<int64_t>(), n, d_out.as<int64_t>(),
+        e = k_launch_wt_inverse_select(idx, idx->dev, idx->n_cu, d_pos.as<int64_t>(), n, d_out.as<int64_t>(),
                                           d_st.as<int32_t>(), nullptr);
     }
     if (e) return fail(FMX_E_HIP, std::string("wavelet kernel launch: ") + hipGetErrorString((hipError_t)e));

@@ -34,7 +34,7 @@ struct Arena {
 
 inline uint32_t off8(size_t byte_off) { return (uint32_t)(byte_off >> 3); }
 
-// RRR:92-103 -> 16-block records + offsets bit stream
+// RRR:92-103 -> 16-block records, and behind them the offsets bit stream (RrrRecord.offset_bit counts from the first record)
 bool flatten_rrr(Arena &A, const RrrModel &r, RrrDesc &d, std::string &err) {
     if (r.sample_size <= 0 || r.classes.width != 4) {
         err = "unsupported RRR parameters";
@@ -49,9 +49,11 @@ bool flatten_rrr(Arena &A, const RrrModel &r, RrrDesc &d, std::string &err) {
     d.total_ones = r.total_ones;
     d.sample = r.sample_size;
     d.node_len = 0;
-    const size_t rec_off = A.alloc((size_t)n_rec * sizeof(RrrRecord) + 64);
+    d.off_bits = 0;
+    const size_t rec_bytes = (size_t)n_rec * sizeof(RrrRecord) + 64;
+    const size_t rec_off = A.alloc(rec_bytes + (r.offsets.size() + 2) * 8);
     d.off_rec = off8(rec_off);
-    uint64_t ones = 0, obits = 0;
+    uint64_t ones = 0, obits = (uint64_t)rec_bytes * 8;
     for (int64_t k = 0; k < n_rec; ++k) {
         RrrRecord rec;
         rec.ones_before = (uint32_t)ones;
@@ -65,13 +67,11 @@ bool flatten_rrr(Arena &A, const RrrModel &r, RrrDesc &d, std::string &err) {
         }
         A.at<RrrRecord>(rec_off)[k] = rec;
     }
-    if (obits > (uint64_t)r.offsets.size() * 64 || obits > 0xffffffffull) {
-        err = "RRR offsets stream shorter than its classes imply";
+    if (obits - (uint64_t)rec_bytes * 8 > (uint64_t)r.offsets.size() * 64 || obits > 0xffffffffull) {
+        err = "RRR offsets stream shorter than its classes imply (or records + stream beyond 512 MiB)";
         return false;
     }
-    const size_t bits_off = A.alloc((r.offsets.size() + 2) * 8);
-    d.off_bits = off8(bits_off);
-    if (!r.offsets.empty()) memcpy(A.at<uint8_t>(bits_off), r.offsets.data(), r.offsets.size() * 8);
+    if (!r.offsets.empty()) memcpy(A.at<uint8_t>(rec_off + rec_bytes), r.offsets.data(), r.offsets.size() * 8);
     return true;
 }
 
@@ -350,6 +350,9 @@ void set_split_blocks(int64_t blocks) { g_split_blocks = blocks < 64 ? 64 : bloc
 // -1 = by alphabet size; 0 / 1 force the row layout of the mapping tables (tests exercise both)
 static std::atomic<int> g_map_by_symbol{-1};
 void set_map_by_symbol(int mode) { g_map_by_symbol = mode; }
+// 1: images flattened from now on keep their bit vectors compressed (BlobHeader.compact)
+static std::atomic<int> g_image_compact{0};
+void set_image_compact(int on) { g_image_compact = on ? 1 : 0; }
 // 0: every present mapping entry says "take the reference's own route" (tests: the slow path alone must give
 // the same answers)
 static std::atomic<int> g_map_fast{1};
@@ -468,10 +471,20 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
         if (m.map_keys[i] >= 0 && m.map_keys[i] < 65536) A.at<int16_t>(off)[m.map_keys[i]] = m.map_vals[i];
     h.off_suffixes = off8(put_packed(A, m.suffixes));
     h.off_positions = m.enable_extract ? off8(put_packed(A, m.positions)) : 0;
+    const bool compact = g_image_compact != 0;
     std::vector<ExpandJob> jobs((size_t)n_sb + 1);
-    if (!expanded_reserve(A, m.sampled, h.sampled, jobs[(size_t)n_sb], err)) return -8;
-
-    h.off_inv = 0;  // no compressed RRR vector in an FM-index image (all bit vectors are expanded)
+    h.off_inv = 0;  // (an expanded image holds no compressed RRR vector: no value table)
+    if (compact) {
+        // the vectors stay what RRR:225-286 made of them — classes and offsets — regrouped into 16-block records; the kernels
+        // decode a block through the value-of-offset table (classes 0..7; staged in LDS)
+        const size_t inv_off = A.alloc((size_t)kInvEntries * 2);
+        memcpy(A.at<uint8_t>(inv_off), rrr_value_of_offset(), (size_t)kInvEntries * 2);
+        h.off_inv = off8(inv_off);
+        if (!flatten_rrr(A, m.sampled, h.sampled, err)) return -8;
+    } else if (!expanded_reserve(A, m.sampled, h.sampled, jobs[(size_t)n_sb], err)) {
+        return -8;
+    }
+    h.compact = compact ? 1 : 0;
 
     // fused (rank, superblock code) table; row n_sb = total counts (WFBB:1063-1069)
     off = A.alloc((size_t)(n_sb + 1) * sigma * sizeof(SbcEntry));
@@ -500,10 +513,14 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
     // bound of the whole image (if that bound should ever fall short, the tables wait for the decoders).
     std::vector<RrrDesc> sb_rrr((size_t)n_sb);
     for (int64_t s = 0; s < n_sb; ++s)
-        if (!expanded_reserve(A, w.sb[(size_t)s].rank_support, sb_rrr[(size_t)s], jobs[(size_t)s], err)) return -8;
-    std::vector<ExpandJob> work;  // the longest vector first, in chunks
-    expanded_jobs(jobs[(size_t)n_sb], work);
-    for (int64_t s = 0; s < n_sb; ++s) expanded_jobs(jobs[(size_t)s], work);
+        if (compact ? !flatten_rrr(A, w.sb[(size_t)s].rank_support, sb_rrr[(size_t)s], err)
+                    : !expanded_reserve(A, w.sb[(size_t)s].rank_support, sb_rrr[(size_t)s], jobs[(size_t)s], err))
+            return -8;
+    std::vector<ExpandJob> work;  // the longest vector first, in chunks (none for a compact image: nothing is decoded)
+    if (!compact) {
+        expanded_jobs(jobs[(size_t)n_sb], work);
+        for (int64_t s = 0; s < n_sb; ++s) expanded_jobs(jobs[(size_t)s], work);
+    }
     std::atomic<size_t> next_job{0};
     std::mutex err_mutex;
     bool failed = false;
@@ -839,18 +856,35 @@ int validate_blob(const uint8_t *b, size_t len, std::string &err) {
         return lo >= sizeof(BlobHeader) && bytes <= len && lo <= len - bytes;
     };
     if (h.checksum != image_checksum(b, len)) return bad("checksum");
-    if (h.kind == 1) {  // stand-alone RrrVector: records + offsets stream + value table
-        const RrrDesc &r = h.sampled;
-        if (r.length < 0 || r.n_blocks < 0 || r.n_rec != r.n_blocks / 16 + 1 ||
-            (int64_t)r.n_blocks < ((int64_t)r.length + 14) / 15)
-            return bad("RrrVector shape");
-        if (!inside(h.off_inv, (uint64_t)kInvEntries * 2) || !inside(r.off_rec, (uint64_t)r.n_rec * sizeof(RrrRecord)) ||
-            !inside(r.off_bits, 16))
-            return bad("RrrVector sections");
+    // a vector in record form: shape, section inside the image, every record's offset pointer inside the stream behind the
+    // records, the running one-counts what the classes say (rankOnes of the sampled-row bitmap indexes `suffixes`)
+    auto records_ok = [&](const RrrDesc &r, bool count_ones) {
+        if (r.length < 0 || r.n_blocks < 0 || r.n_rec != r.n_blocks / 16 + 1 || (int64_t)r.n_blocks < ((int64_t)r.length + 14) / 15 ||
+            (int64_t)r.n_blocks > ((int64_t)r.length + 14) / 15 + 1)
+            return false;
+        const uint64_t rec_bytes = (uint64_t)r.n_rec * sizeof(RrrRecord) + 64;
+        if (!inside(r.off_rec, rec_bytes + 16)) return false;
         const RrrRecord *rec = reinterpret_cast<const RrrRecord *>(b + ((uint64_t)r.off_rec << 3));
-        const uint64_t stream_bits = (len - ((uint64_t)r.off_bits << 3)) * 8;
-        for (int32_t k = 0; k < r.n_rec; ++k)
-            if ((uint64_t)rec[k].offset_bit + 16 * 13 + 64 > stream_bits) return bad("RrrVector offset pointer");
+        const uint64_t avail_bits = (len - ((uint64_t)r.off_rec << 3)) * 8;
+        const uint8_t *bits_needed = rrr_bits_needed();
+        uint64_t ones = 0, obits = rec_bytes * 8;
+        for (int32_t k = 0; k < r.n_rec; ++k) {
+            if ((uint64_t)rec[k].offset_bit != obits || obits + 16 * 13 + 64 > avail_bits) return false;
+            if (count_ones && rec[k].ones_before != ones) return false;
+            for (int j = 0; j < 16; ++j) {
+                const int cls = (int)((rec[k].classes >> (4 * j)) & 15);
+                if ((int64_t)k * 16 + j < r.n_blocks) {
+                    ones += (uint64_t)cls;
+                    obits += bits_needed[cls];
+                } else if (cls) {
+                    return false;
+                }
+            }
+        }
+        return ones == (uint64_t)(uint32_t)r.total_ones;
+    };
+    if (h.kind == 1) {  // stand-alone RrrVector: value table + records + offsets stream
+        if (!inside(h.off_inv, (uint64_t)kInvEntries * 2) || !records_ok(h.sampled, true)) return bad("RrrVector");
         return 0;
     }
     if (h.kind != 0) return bad("kind");
@@ -860,6 +894,8 @@ int validate_blob(const uint8_t *b, size_t len, std::string &err) {
     if (h.bw_suffixes < 1 || h.bw_suffixes > 32 || (h.enable_extract && (h.bw_positions < 1 || h.bw_positions > 32)))
         return bad("bit widths");
     if (h.map_by_symbol != 0 && h.map_by_symbol != 1) return bad("map_by_symbol");
+    if (h.compact != 0 && h.compact != 1) return bad("compact");
+    if (h.compact && !inside(h.off_inv, (uint64_t)kInvEntries * 2)) return bad("value-of-offset table");
     const int64_t n_samples = (int64_t)h.length / h.sample_rate;
     if (h.n_suffixes < n_samples + 1 || (h.enable_extract && h.n_positions < n_samples + 2)) return bad("sample counts");
     auto packed_bytes = [](int64_t n, int width) { return (uint64_t)(words_for_bits(n * width) + 2) * 8; };
@@ -876,11 +912,14 @@ int validate_blob(const uint8_t *b, size_t len, std::string &err) {
     for (int i = 0; i < h.n_c; ++i)
         if (C[i] < 0 || C[i] > h.length) return bad("cumulativeCounts");
     auto cells_ok = [&](const RrrDesc &r) {
+        if (h.compact) return records_ok(r, true);
         return r.length >= 0 && r.n_rec == (int32_t)((int64_t)r.length / kBvCellBits + 2) &&
                inside(r.off_rec, (uint64_t)r.n_rec * sizeof(BvCell));
     };
     if (h.sampled.length != h.length || !cells_ok(h.sampled)) return bad("sampled-row bitmap");
-    {  // rankOnes over this bitmap indexes `suffixes` (FM:541): its running counts must be what its bits say
+    if (h.compact) {
+        if (h.sampled.total_ones < 1 || h.sampled.total_ones > h.n_suffixes) return bad("sampled rows vs suffix samples");
+    } else {  // rankOnes over this bitmap indexes `suffixes` (FM:541): its running counts must be what its bits say
         const BvCell *cells = reinterpret_cast<const BvCell *>(b + ((uint64_t)h.sampled.off_rec << 3));
         uint64_t ones = 0;
         for (int32_t c = 0; c < h.sampled.n_rec; ++c) {

@@ -33,15 +33,17 @@
 namespace fmx {
 
 constexpr uint32_t kBlobMagic = 0x31584D46u;  // "FMX1"
-constexpr uint32_t kBlobVersion = 13;  // 13: monotonicLookUp zero-padded to the alphabet + 1 (fm_char_of)
+constexpr uint32_t kBlobVersion = 14;  // 14: RRR records address their offsets relative to the records; BlobHeader.compact
 
 struct RrrRecord {         // 16 bytes: 16 blocks of 15 bits
     uint32_t ones_before;  // 1-bits in all earlier blocks
-    uint32_t offset_bit;   // bit position of this record's first offset in the offsets stream
+    uint32_t offset_bit;   // bit position of this record's first offset, counted from the vector's FIRST RECORD: the
+                           // offsets stream lies behind the records (RrrDesc.off_rec addresses both; off_bits is free)
     uint64_t classes;      // block j's class in bits [4j, 4j+4)
 };
-// (RRR records serve the FM-index's sampled-suffix bitmap, FM:123: sparse — one bit in sampleRate — so the
-// compressed form is what keeps it small.)
+// Records are the form of the stand-alone RrrVector handles and of every bit vector of a COMPACT image
+// (BlobHeader.compact, option image_compact): the reference's own compression (15-bit blocks as class + offset,
+// RRR:225-286) with a sample — ones before, offset pointer — every 16 blocks instead of every sampleRate.
 
 // The wavelet tree's per-superblock bit vectors (WFBB:116, an RrrVector in the reference) are EXPANDED when the
 // index is flattened for the GPU: Huffman-shaped levels are already near the entropy of the BWT, RRR saves little
@@ -56,10 +58,10 @@ struct BvCell {
 constexpr uint32_t kBvCellBits = 96;
 
 struct RrrDesc {           // 32 bytes; the first 16 are what a rank needs (one dwordx4 load)
-    uint32_t off_rec;      // RrrRecord[n_rec]   (expanded vectors: BvCell[n_rec])
-    uint32_t off_bits;     // offsets bit stream, 64-bit words LSB-first (+2 guard words)   (a superblock's expanded
-                           // vector: offset of its inverseSelect section — InvHdr[n_blocks] + NodeRec[], below; the
-                           // sampled-row bitmap: 0)
+    uint32_t off_rec;      // expanded vectors: BvCell[n_rec]; compressed ones: RrrRecord[n_rec], 64 bytes, then the offsets
+                           // bit stream (64-bit words LSB-first, +2 guard words)
+    uint32_t off_bits;     // a superblock's vector: offset of its inverseSelect section — InvHdr[n_blocks] + NodeRec[],
+                           // below; any other vector: 0
     int32_t length;        // RRR:94
     int32_t total_ones;    // RRR:95
     int32_t n_rec;
@@ -174,7 +176,10 @@ struct BlobHeader {        // 256 bytes
     int32_t kind;            // 0 = FM-index image, 1 = stand-alone RrrVector (fmx_rrr_build)
     uint64_t checksum;       // image_checksum(): body and header (this field taken as zero) — an image that travelled
                              // (RCCL broadcast, fmx_attach_device_blob) is the one the flattener wrote
-    uint8_t reserved[256 - 8 - 8 - 12 * 4 - 8 - 8 * 4 - 32 - 4 - 4 - 8];
+    int32_t compact;         // 1: the image's bit vectors are RrrRecords (+ offsets streams, + the value table at off_inv),
+                             // not BvCells: 0.47 instead of 0.64 bytes per text byte on the 256 MiB log, a rank costs a second
+                             // dependent load and a table lookup in LDS (kernels of namespace fmxc)
+    uint8_t reserved[256 - 8 - 8 - 12 * 4 - 8 - 8 * 4 - 32 - 4 - 4 - 8 - 4];
 };
 static_assert(sizeof(RrrDesc) == 32, "RrrDesc");
 static_assert(sizeof(RrrRecord) == 16, "RrrRecord");

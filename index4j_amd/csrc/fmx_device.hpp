@@ -181,7 +181,7 @@ FMX_HD uint32_t rrr_inv_lookup(const uint16_t *inv, int cls, uint32_t off) {
     const uint64_t w = (cls & 8) ? hi : lo;
     const uint32_t b = (uint32_t)((w >> (16 * (cls & 3))) & 0xffff);
     const bool comp = (cls & 8) != 0;
-    const uint32_t v = inv[comp ? b - off : b + off];
+    const uint32_t v = inv[(comp ? b - off : b + off) & (uint32_t)(kInvEntries - 1)];  // (a damaged offset stays inside the table)
     return comp ? (~v & 0x7fffu) : v;
 }
 
@@ -209,10 +209,20 @@ FMX_HD void rrr_scan_word(uint64_t w, int n, uint32_t &ones, uint32_t &obits) {
     obits += acc;
 }
 
+// FMX_COMPACT = 1: this translation unit serves COMPACT images (BlobHeader.compact): the bit vectors of the FM path are
+// RrrRecords, and every bv_* function below decodes them (fmx_kernels.hip is compiled twice: namespace fmx for expanded
+// images, fmxc for compact ones; the API picks by the image's flag)
+#if !defined(FMX_COMPACT)
+#define FMX_COMPACT 0
+#endif
 // the four fields of an RRR vector a query needs (the first 16 bytes of RrrDesc)
 struct RrrView {
     uint32_t off_rec, off_bits;
     int32_t length, total_ones;
+#if FMX_COMPACT
+    const uint8_t *base;  // the image and the value-of-offset table: what decoding a record needs beside the record
+    const uint16_t *inv;  // (bv_bind)
+#endif
 };
 FMX_HD RrrView rrr_view_from(const Quad &q) {
     RrrView v;
@@ -220,6 +230,10 @@ FMX_HD RrrView rrr_view_from(const Quad &q) {
     v.off_bits = q.y;
     v.length = (int32_t)q.z;
     v.total_ones = (int32_t)q.w;
+#if FMX_COMPACT
+    v.base = nullptr;
+    v.inv = nullptr;
+#endif
     return v;
 }
 FMX_HD RrrView rrr_view(const RrrDesc &d) { return rrr_view_from(ld_quad(&d)); }  // one 16-byte load
@@ -250,7 +264,8 @@ FMX_HD uint32_t rrr_decode_record(const uint8_t *base, const RrrView &d, const u
     rrr_scan_word(rec.classes, (int)j, ones, obits);          // RRR:376-380
     const int cls = (int)((rec.classes >> (4 * j)) & 15);     // RRR:382
     const int nb = rrr_bits_needed(cls);                      // RRR:383
-    const uint32_t *bits = reinterpret_cast<const uint32_t *>(base + ((uint64_t)d.off_bits << 3));
+    // (the offsets stream lies behind the vector's records; offset_bit counts from the first record)
+    const uint32_t *bits = reinterpret_cast<const uint32_t *>(base + ((uint64_t)d.off_rec << 3));
     const uint32_t off = ld_bits(bits, obits, nb);            // RRR:386
     prefix = ones;
     return rrr_inv_lookup(inv, cls, off);                     // RRR:387-390
@@ -323,6 +338,32 @@ FMX_HD int32_t rrr_rank1_access(const uint8_t *base, const RrrView &d, const uin
     return (int32_t)(prefix + (uint32_t)fmx_popc(block & ((1u << t) - 1u)));
 }
 
+#if FMX_COMPACT
+// ---- the FM path's bit vectors in a COMPACT image: 16-block RrrRecords + offsets stream -------------------------------
+// Same interface as the expanded form below: the "cell" of a position is its RECORD (one aligned 16-byte load, requested
+// as early as the expanded form's cell); the rank then takes a second, dependent load (the block's offset bits) and the
+// value-of-offset lookup in LDS.
+struct DevIndex;
+FMX_HD uint32_t bv_clamp(const RrrView &d, int32_t position) {
+    return (uint32_t)(position < 0 ? 0 : (position > d.length ? d.length : position));
+}
+FMX_HD const RrrRecord *bv_cell_ptr(const uint8_t *base, const RrrView &d, uint32_t position) {
+    return rrr_record_ptr(base, d, position);  // (position <= length: n_rec = n_blocks / 16 + 1 records)
+}
+FMX_HD Quad bv_load_cell(const uint8_t *base, const RrrView &d, int32_t position) {
+    return ld_quad(bv_cell_ptr(base, d, bv_clamp(d, position)));
+}
+FMX_HD int32_t bv_rank1_cell(const RrrView &d, const Quad &cell, int32_t position) {
+    return rrr_rank1_record(d.base, d, d.inv, rrr_record_from(cell), position);  // saturates outside [0, length) itself
+}
+FMX_HD int32_t bv_rank1_access_cell(const RrrView &d, const Quad &cell, int32_t position, bool &bit) {
+    return rrr_rank1_access_record(d.base, d, d.inv, rrr_record_from(cell), position, bit);
+}
+// rankOnes(position + 1) from the record of `position` when bit `position` is known to be set (FM:541 after the poll of FM:531)
+FMX_HD int32_t bv_rank1_after_set_bit(const RrrView &d, const Quad &cell, int32_t position) {
+    return bv_rank1_cell(d, cell, position) + 1;
+}
+#else
 // ---- the wavelet tree's bit vectors: expanded 96-bit cells (fmx_blob.hpp BvCell) -------------------------------
 // rankOnes / access with RrrVector's semantics (RRR:358-396, 314-349): rank saturates outside [0, length)
 FMX_HD const BvCell *bv_cell_ptr(const uint8_t *base, const RrrView &d, uint32_t position) {
@@ -363,6 +404,25 @@ FMX_HD int32_t bv_rank1_access_cell(const RrrView &d, const Quad &cell, int32_t 
     const uint32_t r = bv_clamp(d, position) % kBvCellBits;
     bit = position >= 0 && bv_cell_bit(cell, r);
     return (int32_t)(cell.x + bv_cell_prefix(cell, r));
+}
+// rankOnes(position + 1) from the cell of `position` (0 <= position < length) when bit `position` is known to be set
+FMX_HD int32_t bv_rank1_after_set_bit(const RrrView &d, const Quad &cell, int32_t position) {
+    (void)d;
+    return (int32_t)(cell.x + bv_cell_prefix(cell, (uint32_t)position % kBvCellBits)) + 1;
+}
+
+#endif  // FMX_COMPACT
+// what a compact image's views need beside their four fields (nothing in an expanded one)
+template <class Index>
+FMX_HD void bv_bind(RrrView &v, const Index &ix, const uint16_t *inv) {
+#if FMX_COMPACT
+    v.base = ix.base;
+    v.inv = inv ? inv : ix.inv_global;
+#else
+    (void)v;
+    (void)ix;
+    (void)inv;
+#endif
 }
 
 // stand-alone forms (one load each); access reports an out-of-range position through *status like rrr_access
@@ -577,7 +637,8 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
         FMX_PIN_QUAD(view_q);
     }
     const SbHead sh = sb_head_from(head_q);
-    const RrrView rv = rrr_view_from(view_q);
+    RrrView rv = rrr_view_from(view_q);
+    bv_bind(rv, ix, inv);
     const int32_t bsl = sh.bsl;
     const uint32_t block_size = 1u << bsl;
     const int32_t blocks_log = 20 - bsl;
@@ -765,7 +826,7 @@ struct InvView {
     RrrView rv;
     int32_t bsl;
 };
-FMX_HD InvView wt_inv_view(const DevIndex &ix, uint32_t sb_id) {
+FMX_HD InvView wt_inv_view(const DevIndex &ix, uint32_t sb_id, const uint16_t *inv = nullptr) {
     Quad head_q, view_q;
     if (ix.sb_cache) {
         head_q = ix.sb_cache[2 * sb_id];
@@ -779,6 +840,7 @@ FMX_HD InvView wt_inv_view(const DevIndex &ix, uint32_t sb_id) {
     }
     InvView v;
     v.rv = rrr_view_from(view_q);
+    bv_bind(v.rv, ix, inv);
     v.bsl = (int32_t)(int16_t)(head_q.x >> 16);
     return v;
 }
@@ -932,7 +994,7 @@ FMX_HD int32_t wt_inverse_select_from(const DevIndex &ix, uint32_t position, con
 FMX_HD int32_t wt_inverse_select_folded(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t &rank_out,
                                         int32_t &bsl_out, bool &exact_out) {
     (void)inv;
-    const InvView v = wt_inv_view(ix, position >> 20);
+    const InvView v = wt_inv_view(ix, position >> 20, inv);
     bsl_out = v.bsl;
     const Quad ihq = ld_quad(wt_inv_hdr_ptr(ix, v, position));
     return wt_inverse_select_from(ix, position, v, ihq, rank_out, exact_out);
@@ -1013,7 +1075,7 @@ FMX_HD void fm_lf_step2(const DevIndex &ix, const uint16_t *inv, LfChain &a, LfC
         lb = false;
     }
     if (!la && !lb) return;
-    const InvView va = wt_inv_view(ix, la ? pa >> 20 : 0u), vb = wt_inv_view(ix, lb ? pb >> 20 : 0u);
+    const InvView va = wt_inv_view(ix, la ? pa >> 20 : 0u, inv), vb = wt_inv_view(ix, lb ? pb >> 20 : 0u, inv);
     Quad iha = {0, 0, 0, 0}, ihb = {0, 0, 0, 0};
     if (la) iha = ld_quad(wt_inv_hdr_ptr(ix, va, pa));
     if (lb) ihb = ld_quad(wt_inv_hdr_ptr(ix, vb, pb));
@@ -1139,8 +1201,8 @@ FMX_HD void fm_seek_after(const DevIndex &ix, int32_t x, int32_t &row, int32_t &
 // one string of level j (`parent`: its key holds j codes) with code c in front: false = not kept
 FMX_HD bool fm_suffix_extend(const DevIndex &ix, const SuffixSlot &parent, int depth, int32_t c, int key_bits, SuffixSlot &child) {
     int status = ST_OK;
-    const int32_t s2 = wt_rank_folded(ix, nullptr, parent.start, c, status);  // FM:469
-    const int32_t e2 = wt_rank_folded(ix, nullptr, parent.end, c, status);    // FM:470
+    const int32_t s2 = wt_rank_folded(ix, ix.inv_global, parent.start, c, status);  // FM:469
+    const int32_t e2 = wt_rank_folded(ix, ix.inv_global, parent.end, c, status);    // FM:470
     if (status != ST_OK || s2 >= e2) return false;
     child.key = parent.key | ((uint64_t)(uint32_t)c << (depth * key_bits));
     child.start = (uint32_t)s2;
@@ -1204,7 +1266,8 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
                              int &status) {
     int32_t j = start + 1 + k;  // FM:527-529
     distance = 0;
-    const RrrView sv = {ix.sampled.off_rec, ix.sampled.off_bits, ix.sampled.length, ix.sampled.total_ones};
+    RrrView sv = rrr_view_from(Quad{ix.sampled.off_rec, ix.sampled.off_bits, (uint32_t)ix.sampled.length, (uint32_t)ix.sampled.total_ones});
+    bv_bind(sv, ix, inv);
     // Every round polls sampledSuffixes.access(j - 1) (FM:531) and, if the row is not sampled, runs
     // inverseSelect(j - 1) (FM:532): the bitmap cell and the block's InvHdr depend on j alone and are requested together.
     Quad scell = {0, 0, 0, 0};
@@ -1221,7 +1284,7 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
             break;
         }
         // (p < length == the wavelet tree's size: validate_model / validate_blob)
-        const InvView v = wt_inv_view(ix, (uint32_t)p >> 20);
+        const InvView v = wt_inv_view(ix, (uint32_t)p >> 20, inv);
         Quad ihq = ld_quad(wt_inv_hdr_ptr(ix, v, (uint32_t)p));
         scell = ld_quad(bv_cell_ptr(ix.base, sv, (uint32_t)p));
         FMX_PIN_QUAD(ihq);
@@ -1243,7 +1306,7 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
     // (also at j == length, where rankOnes saturates to the total)
     int32_t r;
     if (status == ST_OK)
-        r = (int32_t)(scell.x + bv_cell_prefix(scell, (uint32_t)(j - 1) % kBvCellBits));
+        r = bv_rank1_after_set_bit(sv, scell, j - 1) - 1;
     else {
         // (a walk that ended in a status — the reference throws — reports no position: the read only has to stay inside
         // `suffixes`, whose total_ones entries validate_model / validate_blob guarantee; rankOnes saturates at that total)

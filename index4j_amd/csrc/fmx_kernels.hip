@@ -21,7 +21,24 @@
 #include "fmx_device.hpp"
 #include "fmx_plan.hpp"
 
-namespace fmx {
+// This file is compiled twice (Makefile): as it stands for expanded images (kernels and launchers in namespace fmx), and
+// with -DFMX_COMPACT=1 -DFMX_KNS=fmxc for COMPACT images (fmx_device.hpp: the bv_* functions decode RrrRecords, every FM
+// kernel stages the value-of-offset table in LDS).  The C-ABI layer picks the namespace by the image's flag.
+#if !defined(FMX_KNS)
+#define FMX_KNS fmx
+#endif
+// the value-of-offset table of an FM kernel: none in an expanded image, 32 KiB of LDS in a compact one
+#if FMX_COMPACT
+#define FMX_FM_INV(IX)                                \
+    __shared__ uint16_t s_inv_lds[kInvEntries];       \
+    stage_inverse_table(s_inv_lds, (IX).inv_global);  \
+    const uint16_t *s_inv = s_inv_lds
+#else
+#define FMX_FM_INV(IX) const uint16_t *s_inv = nullptr /* no RRR vector on an expanded image's path */
+#endif
+
+namespace FMX_KNS {
+using namespace fmx;
 
 // Workgroup size is a template parameter (512 / 1024 threads).  Only the stand-alone RrrVector kernels stage the
 // 32 KiB value-of-offset table in LDS.
@@ -242,12 +259,11 @@ __device__ __attribute__((noinline)) CodeChunk chunk_refill(const int16_t *__res
 // common case of a planned batch of short patterns: nothing but shifts in front of a rank).  kChunks = true: further
 // chunks are fetched and mapped on the way (chunk_refill), or — kMode 0 / 3 — all of them.
 template <int kMode, int kCodeBits, bool kChunks>
-__device__ __forceinline__ void count_one(const DevIndex &ix, const int16_t *s_map, const int16_t *s_xlat,
+__device__ __forceinline__ void count_one(const DevIndex &ix, const uint16_t *s_inv, const int16_t *s_map, const int16_t *s_xlat,
                                           const uint16_t *__restrict__ pat, const int32_t *__restrict__ pat_off, int32_t p,
                                           int32_t m, CodeChunk ck, int role, int32_t &start, int32_t &end, int32_t &back,
                                           int32_t &tabled, int &status) {
     constexpr uint32_t code_mask = (1u << kCodeBits) - 1u;
-    const uint16_t *s_inv = nullptr;
     constexpr bool translate = kMode == 2;
     // where the pattern starts: only patterns longer than the record's code word need it (one load, requested here,
     // used by the first refill)
@@ -359,6 +375,7 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
         if (translate)
             s_xlat[c] = (c > 0 && c < plan_sigma) ? (int16_t)fm_map(ix_global, (uint16_t)plan_look_up[c]) : (int16_t)0;
     }
+    FMX_FM_INV(ix_global);
     FMX_WITH_SB_CACHE(ix_global, ix);
     if (!ix.sb_cache) __syncthreads();
     const int role = threadIdx.x & 1;
@@ -403,9 +420,9 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
             status = ST_JAVA_AIOOBE;  // pattern[-1], FM:456-457
         } else if (live) {
             if (chunks)
-                count_one<kMode, kCodeBits, true>(ix, s_map, s_xlat, pat, pat_off, p, m, ck, role, start, end, back, tabled, status);
+                count_one<kMode, kCodeBits, true>(ix, s_inv, s_map, s_xlat, pat, pat_off, p, m, ck, role, start, end, back, tabled, status);
             else
-                count_one<kMode, kCodeBits, false>(ix, s_map, s_xlat, pat, pat_off, p, m, ck, role, start, end, back, tabled, status);
+                count_one<kMode, kCodeBits, false>(ix, s_inv, s_map, s_xlat, pat, pat_off, p, m, ck, role, start, end, back, tabled, status);
         }
         if (!live) continue;  // (whole lane pairs: q is the same for both lanes of a pair)
         // LF-steps of the pattern: two ranks per character after the first (steps_mode 1: only those evaluated here, without
@@ -506,7 +523,7 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix_global, const int32_t *__
                                                         int32_t *__restrict__ lf_steps,
                                                         int32_t *__restrict__ status_out,
                                                         const int32_t *__restrict__ taken) {
-    const uint16_t *s_inv = nullptr;  // no RRR vector on this kernel's path (the sampled-row bitmap is expanded)
+    FMX_FM_INV(ix_global);
     FMX_WITH_SB_CACHE(ix_global, ix);
     const int64_t total = (int64_t)n * slots;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -546,7 +563,7 @@ FMX_EXTRACT_KERNEL(kBlock) void k_extract(DevIndex ix_global, const int32_t *__r
                                   int32_t *__restrict__ out_len, int32_t *__restrict__ lf_steps,
                                   int32_t *__restrict__ status_out, const int32_t *__restrict__ slot_found,
                                   int32_t slots, int32_t fixed_len) {
-    const uint16_t *s_inv = nullptr;  // no RRR vector on this kernel's path (the wavelet tree's are expanded)
+    FMX_FM_INV(ix_global);
     FMX_WITH_SB_CACHE(ix_global, ix);
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) {
@@ -578,7 +595,7 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary(DevIndex ix_global, const in
                                            int32_t *__restrict__ status_out, int32_t *__restrict__ aux_out,
                                            uint16_t *__restrict__ scratch, const int32_t *__restrict__ slot_found,
                                            int32_t slots) {
-    const uint16_t *s_inv = nullptr;  // no RRR vector on this kernel's path (the wavelet tree's are expanded)
+    FMX_FM_INV(ix_global);
     FMX_WITH_SB_CACHE(ix_global, ix);
     const int64_t lanes = (int64_t)gridDim.x * kBlock;
     const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -606,7 +623,7 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix_global, co
                                                  int32_t *__restrict__ lf_steps, int32_t *__restrict__ status_out,
                                                  int32_t *__restrict__ aux_out, uint16_t *__restrict__ scratch,
                                                  const int32_t *__restrict__ slot_found, int32_t slots, int first_fill) {
-    const uint16_t *s_inv = nullptr;  // no RRR vector on this kernel's path (the wavelet tree's are expanded)
+    FMX_FM_INV(ix_global);
     FMX_WITH_SB_CACHE(ix_global, ix);
     const int64_t lanes = (int64_t)gridDim.x * kBlock;
     const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -641,7 +658,7 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix_global, co
 template <int kBlock>
 FMX_KERNEL(kBlock) void k_wt_rank(DevIndex ix, const int64_t *__restrict__ positions, const int32_t *__restrict__ symbols,
                                   int32_t n, int64_t *__restrict__ out, int32_t *__restrict__ status_out) {
-    const uint16_t *s_inv = nullptr;  // no RRR vector on this kernel's path (the wavelet tree's are expanded)
+    FMX_FM_INV(ix);
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) {
         int status = ST_OK;
@@ -664,7 +681,7 @@ FMX_KERNEL(kBlock) void k_wt_rank(DevIndex ix, const int64_t *__restrict__ posit
 template <int kBlock>
 FMX_KERNEL(kBlock) void k_wt_inverse_select(DevIndex ix, const int64_t *__restrict__ positions, int32_t n,
                                             int64_t *__restrict__ out, int32_t *__restrict__ status_out) {
-    const uint16_t *s_inv = nullptr;  // no RRR vector on this kernel's path (the wavelet tree's are expanded)
+    FMX_FM_INV(ix);
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) {
         const int64_t pos = positions[q];
@@ -1339,7 +1356,7 @@ int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, i
     return (int)hipGetLastError();
 }
 
-}  // namespace fmx
+}  // namespace FMX_KNS
 
 #if defined(FMX_DIAG_TIMELINE)
 // (diagnostic builds only; not declared in include/fmx.h) copies {start, end, xcc << 32 | hw id} of the first `groups`

@@ -130,6 +130,7 @@ int validate_model(const FmModel &m, std::string &err);  // 0 ok, -3 malformed: 
 // fmx_blob.cpp
 int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err);
 void set_map_by_symbol(int mode);  // -1 auto, 0 rows by superblock code, 1 rows by global symbol
+void set_image_compact(int on);    // 1: images flattened from now on keep their bit vectors as RRR records (BlobHeader.compact)
 void set_split_blocks(int64_t blocks);  // bit vectors above this many 15-bit blocks are decoded in chunks
 void set_inv_fast(int on);         // 0: inverseSelect takes the reference's own route in every block (tests)
 void set_map_fast(int on);         // 0: every present mapping entry takes the reference's own route (tests)
