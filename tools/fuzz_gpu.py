@@ -75,6 +75,7 @@ def main():
         ia.lib.fmx_set_option(b"suffix_table_image_fraction", rnd.choice([8, 0, 0, 2]))  # ... and its size against the image's
         ia.lib.fmx_set_option(b"cells_split_blocks", rnd.choice([1 << 20, 64, 256]))  # chunked decoding of the bit vectors
         ia.lib.fmx_set_option(b"boundary_group", rnd.choice([0, 1, 2, 4, 8]))
+        ia.lib.fmx_set_option(b"image_compact", rnd.choice([0, 0, 1]))  # bit vectors as RRR records, kernels of namespace fmxc
         try:
             check_all(lambda t, s: GpuEngine(t, s), text, sr, random.Random(rnd.randrange(1 << 30)), n_q=60)
             if cases % 3 == 1:  # the builder with its suffix-array stage on the GPU gives the same bytes

@@ -41,6 +41,8 @@ def sections(blob):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--compact", action="store_true", help="the compact image (option image_compact): the two 'cells' rows are "
+                                                           "then 16-byte RRR records; their offsets streams show up under alignment")
     ap.add_argument("--text-log2", type=int, default=24)
     ap.add_argument("--symbols", type=int, default=1100)
     ap.add_argument("--sample-rate", type=int, default=32)
@@ -48,6 +50,8 @@ def main():
     args = ap.parse_args()
     import index4j_amd as ia
 
+    if args.compact:
+        ia.lib.fmx_set_option(b"image_compact", 1)
     n = 1 << args.text_log2
     text = ia.synth_log_multichar(n, args.symbols) if args.symbols > 70 else ia.synth_log(n)
     fm = ia.FmIndex(text, args.sample_rate, True, device=None, build_device=None if args.build_device < 0 else args.build_device)
