@@ -44,14 +44,23 @@ using namespace fmx;
 // 32 KiB value-of-offset table in LDS.
 // FMX_WAVES_PER_EU asks the register allocator for 8 waves per SIMD (<= 64 VGPRs, <= 80 SGPRs): the
 // kernels are latency-bound chains of dependent loads, so resident waves are what hides latency.
+// (the kernels over compact images carry the record decode: 76-79 VGPRs, 6 waves — no target is forced on them)
+#if FMX_COMPACT
+#define FMX_KERNEL(BLOCK) __global__ __launch_bounds__(BLOCK)
+#else
 #define FMX_KERNEL(BLOCK) __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
+#endif
 // The LF-walk kernels (locate / extract / extractUntilBoundary) carry more state per lane; FMX_WALK_WAVES is the
 // occupancy their register budget is sized for (512 / FMX_WALK_WAVES VGPRs per lane).
 #ifndef FMX_WALK_WAVES
 #define FMX_WALK_WAVES 8
 #endif
+#if FMX_COMPACT
+#define FMX_WALK_KERNEL(BLOCK) __global__ __launch_bounds__(BLOCK)
+#else
 #define FMX_WALK_KERNEL(BLOCK) \
     __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FMX_WALK_WAVES, 8)))
+#endif
 // k_extract: 49.8 ms at a budget for 8 waves, 47.7 ms at 6 (locate -> extract pipeline, tools/bench_pipeline.py)
 #ifndef FMX_EXTRACT_WAVES
 #define FMX_EXTRACT_WAVES 6
@@ -299,7 +308,10 @@ __device__ __forceinline__ void count_one(const DevIndex &ix, const uint16_t *s_
         } else {
             const int bits = len * kCodeBits;
             key = bits >= 64 ? ck.lo : (ck.lo & ((1ull << bits) - 1ull));
-            known = key != kSuffixEmpty;  // (a code of 0 inside the key finds nothing: no tabulated string has one)
+            // The key's TOP code must be a real one: a 0 there (an unknown character) would spell the tabulated string that
+            // is one character SHORTER — whose interval is not this pattern's, which ends at that character (FM:466-468).
+            // (A 0 further down finds nothing: no tabulated string has one below its top.)
+            known = (uint32_t)(key >> (bits - kCodeBits)) != 0u && key != kSuffixEmpty;
         }
         if (known) (void)fm_suffix_lookup(ix, key, len, start, end, back);
         tabled = back;  // characters whose rank evaluations the table answered
@@ -707,7 +719,7 @@ FMX_KERNEL(kBlock) void k_rrr_rank_ones(DevIndex ix, const int32_t *__restrict__
                                         int32_t *__restrict__ out) {
     __shared__ uint16_t s_inv[kInvEntries];
     stage_inverse_table(s_inv, ix.inv_global);
-    const RrrView v = {ix.sampled.off_rec, ix.sampled.off_bits, ix.sampled.length, ix.sampled.total_ones};
+    const RrrView v = rrr_view_from(Quad{ix.sampled.off_rec, ix.sampled.off_bits, (uint32_t)ix.sampled.length, (uint32_t)ix.sampled.total_ones});
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride)
         out[q] = rrr_rank1(ix.base, v, s_inv, positions[q]);
@@ -718,7 +730,7 @@ FMX_KERNEL(kBlock) void k_rrr_access(DevIndex ix, const int32_t *__restrict__ po
                                      uint8_t *__restrict__ out, int32_t *__restrict__ status_out) {
     __shared__ uint16_t s_inv[kInvEntries];
     stage_inverse_table(s_inv, ix.inv_global);
-    const RrrView v = {ix.sampled.off_rec, ix.sampled.off_bits, ix.sampled.length, ix.sampled.total_ones};
+    const RrrView v = rrr_view_from(Quad{ix.sampled.off_rec, ix.sampled.off_bits, (uint32_t)ix.sampled.length, (uint32_t)ix.sampled.total_ones});
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) {
         int status = ST_OK;

@@ -5,6 +5,8 @@
 // Whatever the validators ACCEPT is then queried with the device code itself, compiled for the host
 // (tests/hostsim.cpp), under AddressSanitizer: an out-of-bounds read or an endless loop here is an out-of-bounds read or
 // a hung wave on the GPU.  Usage: fuzz_load <iterations> <seed>; prints one summary line, exit code 0 = clean.
+// Built a second time with -DFMX_COMPACT=1: the same campaign over COMPACT images (option image_compact) and the device
+// header's record-decoding form (what the kernels of namespace fmxc run).
 #include "../hostsim.cpp"
 
 #include <csignal>
@@ -222,6 +224,9 @@ int main(int argc, char **argv) {
     const long iterations = argc > 1 ? atol(argv[1]) : 2000;
     Rng r{argc > 2 ? strtoull(argv[2], nullptr, 10) * 0x9e3779b97f4a7c15ull + 1 : 88172645463325252ull};
     signal(SIGALRM, on_alarm);
+#if FMX_COMPACT
+    fmx::set_image_compact(1);  // built with -DFMX_COMPACT=1: compact images (RRR records) through the decoding form of the device header
+#endif
     struct Base {
         std::vector<uint16_t> text;
         std::vector<uint8_t> ser, blob;

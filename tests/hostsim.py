@@ -8,22 +8,25 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = None
+_LIBS = {}
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        so = os.path.join(_HERE, "libhostsim.so")
+def lib(compact=False):
+    """compact = the device header compiled with -DFMX_COMPACT=1: the bv_* functions decode RRR records (what the kernels of
+    namespace fmxc run over COMPACT images, option image_compact)"""
+    if compact not in _LIBS:
+        so = os.path.join(_HERE, "libhostsim_compact.so" if compact else "libhostsim.so")
         srcs = [os.path.join(_HERE, "hostsim.cpp"),
                 os.path.join(_HERE, "..", "index4j_amd", "csrc", "fmx_device.hpp"),
                 os.path.join(_HERE, "..", "index4j_amd", "csrc", "fmx_blob.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-            subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-o", so, srcs[0]])
-        _LIB = C.CDLL(so)
-        _LIB.sim_wt_rank.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p]
-        _LIB.sim_wt_inverse_select.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
-    return _LIB
+            subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared"] + (["-DFMX_COMPACT=1"] if compact else []) +
+                                  ["-o", so, srcs[0]])
+        L = C.CDLL(so)
+        L.sim_wt_rank.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p]
+        L.sim_wt_inverse_select.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        _LIBS[compact] = L
+    return _LIBS[compact]
 
 
 def reference_route_index(text, sample_rate, enable_extract=True):
@@ -72,6 +75,9 @@ class HostSim:
         self.fm = fm_index  # keeps the blob alive
         self.blob = fm_index.blob()
         self.p = self.blob.ctypes.data
+        # BlobHeader.compact (byte 152): the image's bit vectors are RRR records — the simulation compiled for that form
+        self.compact = bool(int(np.frombuffer(self.blob, np.uint8)[152:156].view(np.int32)[0]))
+        self.L = lib(self.compact)
 
     def wt_rank_batch(self, positions, symbols):
         st = np.zeros(1, np.int32)
@@ -79,22 +85,22 @@ class HostSim:
         sts = np.zeros(len(positions), np.int32)
         for i, (p_, s_) in enumerate(zip(positions, symbols)):
             st[0] = 0
-            out[i] = lib().sim_wt_rank(self.p, int(p_), int(s_), st.ctypes.data)
+            out[i] = self.L.sim_wt_rank(self.p, int(p_), int(s_), st.ctypes.data)
             sts[i] = st[0]
         return out, sts
 
     def wt_rank(self, pos, sym):
         st = np.zeros(1, np.int32)
-        return lib().sim_wt_rank(self.p, pos, sym, st.ctypes.data), int(st[0])
+        return self.L.sim_wt_rank(self.p, pos, sym, st.ctypes.data), int(st[0])
 
     def wt_inverse_select(self, pos):
         r = np.zeros(1, np.int32)
-        c = lib().sim_wt_inverse_select(self.p, pos, r.ctypes.data)
+        c = self.L.sim_wt_inverse_select(self.p, pos, r.ctypes.data)
         return c, int(r[0])
 
     def lf_step_both(self, row):
         out = np.zeros(6, np.int32)
-        lib().sim_lf_step_both(C.c_void_p(self.p), int(row), C.c_void_p(out.ctypes.data))
+        self.L.sim_lf_step_both(C.c_void_p(self.p), int(row), C.c_void_p(out.ctypes.data))
         return out
 
     def count_batch(self, chars, offsets):
@@ -102,7 +108,7 @@ class HostSim:
         offsets = np.ascontiguousarray(offsets, np.int32)
         n = len(offsets) - 1
         counts, lf, st, rng = (np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(2 * n, np.int32))
-        lib().sim_count(C.c_void_p(self.p), C.c_void_p(chars.ctypes.data), C.c_void_p(offsets.ctypes.data), n,
+        self.L.sim_count(C.c_void_p(self.p), C.c_void_p(chars.ctypes.data), C.c_void_p(offsets.ctypes.data), n,
                         C.c_void_p(counts.ctypes.data), C.c_void_p(lf.ctypes.data), C.c_void_p(st.ctypes.data),
                         C.c_void_p(rng.ctypes.data))
         return counts, st, lf, rng
@@ -115,8 +121,8 @@ class HostSim:
         n = len(offsets) - 1
         counts, lf, st = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
         answered = np.zeros(1, np.int64)
-        lib().sim_count_table.restype = C.c_int64
-        entries = lib().sim_count_table(C.c_void_p(self.p), int(table_chars), C.c_void_p(chars.ctypes.data),
+        self.L.sim_count_table.restype = C.c_int64
+        entries = self.L.sim_count_table(C.c_void_p(self.p), int(table_chars), C.c_void_p(chars.ctypes.data),
                                         C.c_void_p(offsets.ctypes.data), n, C.c_void_p(counts.ctypes.data),
                                         C.c_void_p(lf.ctypes.data), C.c_void_p(st.ctypes.data), C.c_void_p(answered.ctypes.data))
         return counts, st, lf, int(answered[0]), int(entries)
@@ -126,7 +132,7 @@ class HostSim:
         n = len(counts)
         locs = np.zeros((n, max(loc_cap, 0)), np.int32)
         found = np.zeros(n, np.int32)
-        lib().sim_locate_walk(C.c_void_p(self.p), C.c_void_p(rng.ctypes.data), n, max_matches,
+        self.L.sim_locate_walk(C.c_void_p(self.p), C.c_void_p(rng.ctypes.data), n, max_matches,
                               C.c_void_p(locs.ctypes.data), loc_cap, C.c_void_p(found.ctypes.data),
                               C.c_void_p(lf.ctypes.data), C.c_void_p(st.ctypes.data))
         return locs, found, st, lf
@@ -138,7 +144,7 @@ class HostSim:
         if dst is None:
             dst = np.zeros((n, dst_len), np.uint16)
         out_len, lf, st = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
-        lib().sim_extract(C.c_void_p(self.p), C.c_void_p(starts.ctypes.data), C.c_void_p(stops.ctypes.data), n,
+        self.L.sim_extract(C.c_void_p(self.p), C.c_void_p(starts.ctypes.data), C.c_void_p(stops.ctypes.data), n,
                           C.c_void_p(dst.ctypes.data), dst_len, offset, C.c_void_p(out_len.ctypes.data),
                           C.c_void_p(lf.ctypes.data), C.c_void_p(st.ctypes.data))
         return dst, out_len, st, lf
@@ -150,7 +156,7 @@ class HostSim:
             dst = np.zeros((n, dst_len), np.uint16)
         out_len, lf, st, aux = (np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32))
         b = boundary if isinstance(boundary, (int, np.integer)) else ord(boundary)
-        lib().sim_extract_boundary(C.c_void_p(self.p), C.c_void_p(froms.ctypes.data), n, C.c_uint16(b), mode,
+        self.L.sim_extract_boundary(C.c_void_p(self.p), C.c_void_p(froms.ctypes.data), n, C.c_uint16(b), mode,
                                    C.c_void_p(dst.ctypes.data), dst_len, offset, C.c_void_p(out_len.ctypes.data),
                                    C.c_void_p(lf.ctypes.data), C.c_void_p(st.ctypes.data), C.c_void_p(aux.ctypes.data), accelerate)
         return dst, out_len, st, aux, lf

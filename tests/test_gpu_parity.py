@@ -575,6 +575,52 @@ def test_suffix_table_changes_nothing_but_the_time():
         ia.lib.fmx_set_option(b"suffix_table", 1)
 
 
+def test_an_unknown_character_at_the_top_of_the_table_key_does_not_find_the_shorter_string():
+    """The table holds every string of 2 .. k codes; a key whose top code is 0 (a character the text does not have, or
+    one outside the alphabet) spells the tabulated string that is one character shorter.  Such a pattern ends at that
+    character with count 0 (FM:466-468) — it must not come back with the shorter string's interval (found by
+    tools/fuzz_gpu.py seed 41 case 336 in round 4: [7, c, c, c] counted like [c, c, c] — one pattern of 20,000: the two
+    keys are equal but hash to different homes, so the lookup only meets the shorter string where their probe paths cross;
+    the fix never looks such a key up).  Planned batches, 8-bit and
+    16-bit code words, the unknown character at every distance from the pattern's end, patterns shorter and longer than
+    the table; counts, statuses, LF-steps and located hits against the oracle."""
+    rnd = random.Random(336)
+    wide = np.array([rnd.randrange(0x400, 0x400 + 500) if rnd.random() < 0.6 else rnd.randrange(97, 110) for _ in range(200_000)],
+                    dtype=np.uint16)
+    for text in (ia.synth_log(1 << 18), wide):
+        o = orc.OracleFmIndex(text, 32, True)
+        assert ia.lib.fmx_set_option(b"suffix_table_image_fraction", 0) == 0  # (a small index: the default policy stops at 2 characters)
+        assert ia.lib.fmx_set_option(b"suffix_table_chars", 4) == 0
+        try:
+            fm = ia.FmIndex.read(o.write(False), device=0)
+        finally:
+            ia.lib.fmx_set_option(b"suffix_table_image_fraction", 8)
+            ia.lib.fmx_set_option(b"suffix_table_chars", 8)
+        k = fm.suffix_table_info()[0]
+        assert k == 4
+        pats = []
+        for i in range(24_000):
+            m = 2 + i % 11
+            s0 = rnd.randrange(len(text) - 16)
+            p = np.array(text[s0:s0 + m], dtype=np.uint16)
+            if i % 2 == 0:
+                p[m - 1 - (i // 2) % m] = 7 if i % 4 == 0 else 0xFFF0  # every distance from the end, incl. the key's top
+            pats.append(p)
+        ch, off = ia.pack_patterns(pats)
+        orc.counters_reset()
+        oc, ost = o.count_batch(ch, off, threads=8)
+        steps = orc.counters()["lf_steps"]
+        cnt, st, lf = fm.count_batch(ch, off, want_steps=True)
+        bad = np.flatnonzero((cnt != oc) | (st != ost))
+        assert len(bad) == 0, (k, len(bad), [(pats[i].tolist(), int(cnt[i]), int(oc[i])) for i in bad[:4]])
+        assert int(lf.astype(np.int64).sum()) == steps
+        locs, found, st2 = fm.locate_batch(ch, off, 2)
+        for i in range(0, 24_000, 53):
+            kk, ll = o.locate(pats[i], max_matches=2, cap=2)
+            assert st2[i] == 0 and found[i] == kk and (locs[i, :kk] == ll).all(), i
+        fm.close()
+
+
 def test_device_construction_is_byte_identical():
     """fmx_build_on_device — suffix array by prefix doubling (FM:329-394) AND the wavelet tree with its RRR vectors
     (FM:173; WFBB:130-154, 362-535, 570-991; RRR:225-286) encoded in HBM — against the ORACLE's builder and the host

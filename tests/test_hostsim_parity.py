@@ -190,3 +190,36 @@ def test_derailed_locate_walks_run_past_the_sample_rate():
     for i, p in enumerate(pats):
         k, l = o.locate(p, max_matches=16, cap=16)
         assert k == found[i] and (l == locs[i, :k]).all(), i
+
+
+def test_compact_images_on_the_host_simulation():
+    """COMPACT images (option image_compact; the kernels of namespace fmxc): the device header compiled with
+    -DFMX_COMPACT=1 — bv_* functions decoding 16-block RRR records + offsets stream through the value-of-offset table —
+    over the host blob: every query kind against the oracle, a suffix table grown and consulted over the compact image.
+    What the GPU suite checks on hardware (tests/test_gpu_compact.py), here on CPU-only machines.  (Sizes are compared
+    there: a 30,000-character image is dominated by the 32 KiB value table.)"""
+    rnd = random.Random(4)
+    assert ia.lib.fmx_set_option(b"image_compact", 1) == 0
+    try:
+        def make(text, sr):
+            h = hostsim.HostSim(ia.FmIndex(text, sr, True, device=None))
+            assert h.compact
+            return h
+
+        check_all(make, HD[:40_000], 16, rnd, n_q=60)
+        check_all(make, HD[:25_000], 1, rnd, n_q=40)
+        check_all(make, "ab\0cd\0\0ef" * 800 + "tail", 4, rnd, n_q=40)
+        text = HD[:30_000]
+        f = ia.FmIndex(text, 8, True, device=None)
+        h = hostsim.HostSim(f)
+        o = orc.OracleFmIndex(text, 8, True)
+        t16 = ia.as_chars(text)
+        pats = [t16[s:s + rnd.randrange(1, 10)] for s in (rnd.randrange(len(t16) - 10) for _ in range(400))]
+        ch, off = ia.pack_patterns(pats)
+        oc, ost = o.count_batch(ch, off)
+        cnt, st, lf, answered, entries = h.count_batch_with_table(3, ch, off)
+        assert (cnt == oc).all() and (st == ost).all() and answered > 0 and entries > 0
+    finally:
+        assert ia.lib.fmx_set_option(b"image_compact", 0) == 0
+    g = ia.FmIndex(HD[:30_000], 8, True, device=None)
+    assert not hostsim.HostSim(g).compact

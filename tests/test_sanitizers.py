@@ -25,14 +25,16 @@ def test_damaged_streams_and_images_never_leave_their_tables(tmp_path):
     a matching checksum go through the product's validators; whatever is accepted is queried with the DEVICE code compiled
     for the host under AddressSanitizer (count, locate, extract, extractUntilBoundary x 3 modes x 3 forms) with a watchdog.
     An out-of-bounds read or an endless walk here would be a memory fault or a hung wave on the GPU."""
-    exe = str(tmp_path / "fuzz_load")
     csrc = os.path.join(ROOT, "index4j_amd", "csrc")
-    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-fno-omit-frame-pointer", "-I" + csrc,
-           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "fuzz_load.cpp")]
-    cmd += [os.path.join(csrc, f) for f in ("fmx_build.cpp", "fmx_serial.cpp", "fmx_blob.cpp", "fmx_synth.cpp")]
-    cmd += ["-lpthread", "-o", exe]
-    subprocess.check_call(cmd)
-    for seed in (1, 2):
-        r = subprocess.run([exe, "1200", str(seed)], capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0 and "ERROR" not in r.stderr and "HANG" not in r.stderr, r.stdout[-2000:] + r.stderr[-6000:]
-        assert r.stdout.startswith("fuzz ok:"), r.stdout
+    # the expanded form (default images), and the same campaign over COMPACT images with the record-decoding device code
+    for name, defs, runs in (("fuzz_load", [], ((1, 1200), (2, 1200))), ("fuzz_load_compact", ["-DFMX_COMPACT=1"], ((3, 1000),))):
+        exe = str(tmp_path / name)
+        cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-fno-omit-frame-pointer"] + defs + ["-I" + csrc,
+               "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "fuzz_load.cpp")]
+        cmd += [os.path.join(csrc, f) for f in ("fmx_build.cpp", "fmx_serial.cpp", "fmx_blob.cpp", "fmx_synth.cpp")]
+        cmd += ["-lpthread", "-o", exe]
+        subprocess.check_call(cmd)
+        for seed, iters in runs:
+            r = subprocess.run([exe, str(iters), str(seed)], capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0 and "ERROR" not in r.stderr and "HANG" not in r.stderr, r.stdout[-2000:] + r.stderr[-6000:]
+            assert r.stdout.startswith("fuzz ok:"), r.stdout

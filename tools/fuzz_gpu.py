@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=240)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--big", action="store_true", help="texts of two to three superblocks with shifting alphabets")
+    ap.add_argument("--only-case", type=int, default=-1,
+                    help="replay ONE case of a seed: the cases before it only draw their random numbers (a FAILED line names seed and case)")
     args = ap.parse_args()
     import index4j_amd as ia
     from parity_checks import GpuEngine, check_all
@@ -66,18 +68,27 @@ def main():
         sr = rnd.choice([1, 2, 3, 8, 16, 32, 64, 100])
         layout = rnd.choice([-1, 0, 1])
         cache = rnd.choice([320, 0])
-        ia.lib.fmx_set_option(b"map_by_symbol", layout)
-        ia.lib.fmx_set_option(b"sb_cache_limit", cache)
-        ia.lib.fmx_set_option(b"map_fast", rnd.choice([1, 1, 1, 0]))  # 0: every mapping entry on the reference's route
-        ia.lib.fmx_set_option(b"inv_fast", rnd.choice([1, 1, 1, 0]))  # 0: inverseSelect on the reference's route
-        ia.lib.fmx_set_option(b"suffix_table_mb", rnd.choice([256, 256, 1, 0]))  # budget of the suffix table (0: none)
-        ia.lib.fmx_set_option(b"suffix_table_chars", rnd.choice([4, 4, 2, 3, 6, 8]))  # its depth
-        ia.lib.fmx_set_option(b"suffix_table_image_fraction", rnd.choice([8, 0, 0, 2]))  # ... and its size against the image's
-        ia.lib.fmx_set_option(b"cells_split_blocks", rnd.choice([1 << 20, 64, 256]))  # chunked decoding of the bit vectors
-        ia.lib.fmx_set_option(b"boundary_group", rnd.choice([0, 1, 2, 4, 8]))
-        ia.lib.fmx_set_option(b"image_compact", rnd.choice([0, 0, 1]))  # bit vectors as RRR records, kernels of namespace fmxc
+        opts = {"map_by_symbol": layout, "sb_cache_limit": cache,
+                "map_fast": rnd.choice([1, 1, 1, 0]),  # 0: every mapping entry on the reference's route
+                "inv_fast": rnd.choice([1, 1, 1, 0]),  # 0: inverseSelect on the reference's route
+                "suffix_table_mb": rnd.choice([256, 256, 1, 0]),  # budget of the suffix table (0: none)
+                "suffix_table_chars": rnd.choice([4, 4, 2, 3, 6, 8]),  # its depth
+                "suffix_table_image_fraction": rnd.choice([8, 0, 0, 2]),  # ... and its size against the image's
+                "cells_split_blocks": rnd.choice([1 << 20, 64, 256]),  # chunked decoding of the bit vectors
+                "boundary_group": rnd.choice([0, 1, 2, 4, 8]),
+                "image_compact": rnd.choice([0, 0, 1])}  # bit vectors as RRR records, kernels of namespace fmxc
+        check_seed = rnd.randrange(1 << 30)
+        if args.only_case >= 0 and cases != args.only_case:
+            if cases % 3 == 1:
+                rnd.random()  # (the draw of the device-construction check below)
+            cases += 1
+            if cases > args.only_case:
+                break
+            continue
+        for k, v in opts.items():
+            assert ia.lib.fmx_set_option(k.encode(), v) == 0, (k, v)
         try:
-            check_all(lambda t, s: GpuEngine(t, s), text, sr, random.Random(rnd.randrange(1 << 30)), n_q=60)
+            check_all(lambda t, s: GpuEngine(t, s), text, sr, random.Random(check_seed), n_q=60)
             if cases % 3 == 1:  # the builder with its suffix-array stage on the GPU gives the same bytes
                 extract = rnd.random() < 0.7
                 a = ia.FmIndex(text, sr, extract, device=None).write(False)
@@ -97,6 +108,11 @@ def main():
                 ch, off = ia.pack_patterns(pats)
                 cnt, st, lf = fm.count_batch(ch, off, want_steps=True)
                 oc, ost = o.count_batch(ch, off, threads=8)
+                if not ((cnt == oc).all() and (st == ost).all()):
+                    bad = np.flatnonzero((cnt != oc) | (st != ost))
+                    print("planned count batch: %d of %d patterns differ; first: %r" % (
+                        len(bad), len(cnt), [(int(i), pats[i].tolist(), int(cnt[i]), int(oc[i]), int(st[i]), int(ost[i])) for i in bad[:5]]),
+                        "suffix table", fm.suffix_table_info(), flush=True)
                 assert (cnt == oc).all() and (st == ost).all(), "planned count batch"
                 locs, found, st2 = fm.locate_batch(ch, off, 3)
                 for k in range(0, 20000, 211):
@@ -106,7 +122,7 @@ def main():
                     except IndexError:  # rank(size) with size % 2^20 == 0: the JVM raises AIOOBE (Q3)
                         assert st2[k] == 9, "planned locate batch: AIOOBE expected"
         except Exception:
-            print("FAILED: seed %d case %d len %d sr %d layout %d cache %d" % (args.seed, cases, len(text), sr, layout, cache), flush=True)
+            print("FAILED: seed %d case %d len %d sr %d options %r" % (args.seed, cases, len(text), sr, opts), flush=True)
             raise
         cases += 1
         if cases % 25 == 0:
