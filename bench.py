@@ -252,7 +252,9 @@ def compact_line(out):
                                        "lf_steps_executed_per_launch", "frac_whole_step", "traffic_frac", "step_ms_incl_plan",
                                        "fabric_line_fills_per_lf_step_executed", "resident_bytes_per_text_byte",
                                        "stage_ms_this_rank")) or {})
-        c["roofline"]["kernel"] = _short(r.get("kernel"), 100)
+        c["roofline"]["kernel"] = _short(r.get("kernel"), 60)
+        if r.get("plan_stage") is not None:
+            c["roofline"]["plan_stage"] = r["plan_stage"]
     b = out.get("cpu_baseline")
     c["cpu_baseline"] = _pick(b, ("value", "unit", "cores", "kind", "lf_steps_per_s")) if b else None
     if b:
@@ -476,20 +478,27 @@ def run_count(ctx, args):
     wall = time.perf_counter() - t0
     step_ms = 0.0 if ctx.dry else ev0.elapsed_time(ev1) / args.steps
 
-    # the dominant kernel alone (k_count over each batch's processing order), HIP events on its stream
+    # the dominant kernel alone, HIP events on its stream.  A batch the library plans (suffix order first: fmx.h
+    # fmx_count_batch_is_planned) is counted over its processing order (plan made once, k_count launched `reps` times); a batch
+    # it counts in the caller's order IS one k_count launch per call.
     kernel_ms_per_batch = []
+    planned = False if ctx.dry else bool(ia.lib.fmx_count_batch_is_planned(q.handle, n))
     if not ctx.dry:
         reps = max(1, args.steps // n_batches)
         for b in range(n_batches):
             plan = C.c_void_p()
-            check_rc(ia, ia.lib.fmx_count_plan_dev(q.handle, d_pats[b].data_ptr(), d_off.data_ptr(), n, C.byref(plan), sp),
-                     "fmx_count_plan_dev")
+            if planned:
+                check_rc(ia, ia.lib.fmx_count_plan_dev(q.handle, d_pats[b].data_ptr(), d_off.data_ptr(), n, C.byref(plan), sp),
+                         "fmx_count_plan_dev")
             torch.cuda.synchronize()
             e0, e1 = hip_events(torch)
             e0.record(stream)
             for _ in range(reps):
-                check_rc(ia, ia.lib.fmx_count_ordered_dev(q.handle, d_pats[b].data_ptr(), d_off.data_ptr(), plan, n,
-                                                          d_cnt[b].data_ptr(), None, None, sp), "fmx_count_ordered_dev")
+                if planned:
+                    check_rc(ia, ia.lib.fmx_count_ordered_dev(q.handle, d_pats[b].data_ptr(), d_off.data_ptr(), plan, n,
+                                                              d_cnt[b].data_ptr(), None, None, sp), "fmx_count_ordered_dev")
+                else:
+                    step(b)
             e1.record(stream)
             torch.cuda.synchronize()
             kernel_ms_per_batch.append(e0.elapsed_time(e1) / reps)
@@ -668,7 +677,10 @@ def run_count(ctx, args):
         traffic_raw = (pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024.0 if pmc else None
         traffic = (pmc["FETCH_SIZE_KiB"] * fetch_factor + pmc["WRITE_SIZE_KiB"]) * 1024.0 if pmc else None
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_count",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "k_count" if planned else "k_count (the batch is counted in the caller's order: no plan stage, the kernel maps "
+                                                    "the characters itself — fmx_count_batch_is_planned)",
+                "plan_stage": planned,
                 "what_frac_means": "ALGORITHMIC bytes of the reference's layout (oracle counting mode) per k_count launch / "
                                    "launch time / peak: distance from a perfect streaming of the reference's own reads, not "
                                    "HBM saturation — the image is L2 / Infinity-Cache resident, see traffic_frac",

@@ -171,6 +171,11 @@ int fmx_count_plan_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_
                        const void **d_plan, void *stream);
 int fmx_count_ordered_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, const void *d_plan,
                           int32_t n, int32_t *d_counts, int32_t *d_lf_steps, int32_t *d_status, void *stream);
+/* 1 if fmx_count_batch_dev / fmx_locate_batch_dev would run the plan stage for a batch of n patterns on this resident index, 0 if
+ * they count in the caller's order.  The plan (suffix order) pays while many patterns share the suffix-table string they start
+ * from; a batch with fewer than "plan_min_per_string" (option, default 16) patterns per string of the table's deepest level
+ * skips it — results are the same either way.  (fmx_count_plan_dev always plans: the caller asked.) */
+int fmx_count_batch_is_planned(const fmx_index *idx, int32_t n);
 int fmx_locate_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
                          int32_t max_matches, int32_t *d_locs, int32_t loc_cap, int32_t *d_found,
                          int32_t *d_lf_steps, int32_t *d_status, int32_t *d_range_ws /* 2*n ints */, void *stream);

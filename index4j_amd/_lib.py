@@ -28,7 +28,7 @@ SYMBOLS = [
     "fmx_input_length", "fmx_alphabet_length", "fmx_sample_rate", "fmx_extract_enabled",
     "fmx_blob", "fmx_to_device", "fmx_attach_device_blob", "fmx_device_blob", "fmx_host_register", "fmx_host_unregister",
     "fmx_count_batch", "fmx_locate_batch", "fmx_extract_batch", "fmx_extract_boundary_batch",
-    "fmx_count_batch_dev", "fmx_count_plan_dev", "fmx_count_ordered_dev", "fmx_locate_batch_dev", "fmx_extract_batch_dev", "fmx_extract_boundary_batch_dev",
+    "fmx_count_batch_dev", "fmx_count_plan_dev", "fmx_count_ordered_dev", "fmx_count_batch_is_planned", "fmx_locate_batch_dev", "fmx_extract_batch_dev", "fmx_extract_boundary_batch_dev",
     "fmx_locate_extract_batch", "fmx_locate_lines_batch", "fmx_locate_extract_batch_dev", "fmx_locate_lines_batch_dev",
     "fmx_count_segments", "fmx_locate_segments", "fmx_count_segments_dev", "fmx_locate_segments_dev",
     "fmx_wavelet_build", "fmx_wavelet_rank_batch", "fmx_wavelet_inverse_select_batch",
@@ -93,6 +93,7 @@ def _load():
     L.fmx_rrr_build.argtypes = [vp, C.c_int64, i32, P(vp)]
     L.fmx_rrr_rank_ones_batch.argtypes = [vp, vp, i32, vp]
     L.fmx_rrr_access_batch.argtypes = [vp, vp, i32, vp, vp]
+    L.fmx_count_batch_is_planned.argtypes = [vp, i32]
     L.fmx_rrr_rank_ones_batch_dev.argtypes = [vp, vp, i32, vp, vp]
     L.fmx_rrr_access_batch_dev.argtypes = [vp, vp, i32, vp, vp, vp]
     L.fmx_convert_byte_pattern.argtypes = [vp, i32, i32, vp, P(i32)]

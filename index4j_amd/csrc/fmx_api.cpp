@@ -99,7 +99,8 @@ struct fmx_index {
     double wavelet_device_seconds = 0;  // fmx_build_on_device: seconds of the wavelet encode in HBM (0: host encoder)
     void *d_suffix_table = nullptr;     // DevIndex.suffix_table (owned, whoever owns the image)
     size_t suffix_table_bytes = 0;
-    uint32_t suffix_table_strings = 0;  // strings of suffix_chars codes the table holds
+    uint32_t suffix_table_strings = 0;  // strings (of 2 .. suffix_chars codes) the table holds
+    uint32_t suffix_table_deepest = 0;  // ... of which strings of suffix_chars codes: what a batch's patterns spread over after the lookup
     fmx::DevIndex dev;
     // per-(stream, kind) scratch of the device-pointer entry points (grow-only; freed with the index):
     // kind 0 = plan stage (order + code words), kind 1 = extractUntilBoundary windows
@@ -123,6 +124,13 @@ thread_local std::string g_err;
 std::atomic<int> g_wavelet_on_device{1};  // option "wavelet_on_device": 0 = fmx_build_on_device encodes the wavelet tree on the host
 std::atomic<int> g_suffix_table_mb{256};  // option "suffix_table_mb": budget of the suffix table of indexes made resident afterwards (0 = none)
 std::atomic<int> g_suffix_table_chars{8};  // option "suffix_table_chars": its depth (characters; the size limit and the key width may cut it)
+// The plan stage (suffix order of a batch) pays while MANY patterns share the table string they start from — their first
+// steps then read the same lines.  Option "plan_min_per_string": a batch is planned only if it holds at least this many
+// patterns per string of the table's deepest level (0 = every batch of sort_min patterns or more is planned).  Measured
+// (tools/depth_sort_probe.py, tools/nosort_probe.py): 1 M patterns over 26 K strings (depth 4): planned 0.168 ms, caller's
+// order 0.179; over 227 K strings (depth 5): 0.150 / 0.141; 65,536 patterns over 227 K: 0.045 / 0.023.
+std::atomic<int> g_plan_min_per_string{16};
+std::atomic<int> g_suffix_table_in_use{1};  // mirror of the kernels' A/B option "suffix_table": launches told to ignore the table plan as if there were none
 std::atomic<int> g_suffix_table_image_fraction{8};  // option "suffix_table_image_fraction": the table stays below image / this (0 = only the budget counts)
 // host-buffer count(): batches of at least this many patterns go through the pipeline (smaller ones: one copy in, kernels, one copy out)
 std::atomic<int> g_host_pipeline_min{131072};
@@ -517,6 +525,11 @@ int fmx_set_option(const char *name, int value) {
         g_suffix_table_chars = value;
         return FMX_OK;
     }
+    if (name && !strcmp(name, "plan_min_per_string")) {
+        if (value < 0) return fail(FMX_E_ARG, "bad value");
+        g_plan_min_per_string = value;
+        return FMX_OK;
+    }
     if (name && !strcmp(name, "suffix_table_image_fraction")) {  // the table stays below image bytes / value (0: only the budget counts)
         if (value < 0) return fail(FMX_E_ARG, "bad value");
         g_suffix_table_image_fraction = value;
@@ -539,6 +552,7 @@ int fmx_set_option(const char *name, int value) {
         return FMX_OK;
     }
     if (!name) return fail(FMX_E_ARG, "unknown option or bad value");
+    if (!strcmp(name, "suffix_table")) g_suffix_table_in_use = value != 0;
     {  // launch options go to both kernel sets
         const int a = fmx::set_option(name, value), b = fmxc::set_option(name, value);
         if (a || b) return fail(FMX_E_ARG, "unknown option or bad value");
@@ -664,6 +678,7 @@ static void build_suffix_table(fmx_index *idx) {
         idx->d_suffix_table = nullptr;
         idx->suffix_table_bytes = 0;
     }
+    idx->suffix_table_strings = idx->suffix_table_deepest = 0;
     idx->dev.suffix_table = nullptr;
     idx->dev.suffix_chars = 0;
     idx->dev.suffix_key_bits = idx->hdr.wt_sigma <= 256 ? 8 : 16;
@@ -772,6 +787,7 @@ static void build_suffix_table(fmx_index *idx) {
     idx->d_suffix_table = d_slots;
     idx->suffix_table_bytes = (size_t)slots * sizeof(fmx::SuffixSlot);
     idx->suffix_table_strings = total;
+    idx->suffix_table_deepest = begin[chars + 1] - begin[chars];
     idx->dev.suffix_table = static_cast<const fmx::SuffixSlot *>(d_slots);
     idx->dev.suffix_chars = chars;
     idx->dev.suffix_shift = geometry.suffix_shift;
@@ -890,13 +906,22 @@ void *fmx_device_blob(const fmx_index *idx, size_t *len) {
 
 // stage 1 of count/locate: processing order of the batch (suffix-key radix sort) — nullptr when the
 // batch is too small to be worth sorting
+// would a batch of n patterns be planned when the library decides (count / locate / segment entry points)?
+static bool plan_pays(const fmx_index *idx, int32_t n) {
+    const int per_string = g_plan_min_per_string.load();
+    if (per_string <= 0 || !idx->dev.suffix_table || idx->suffix_table_deepest == 0 || !g_suffix_table_in_use.load()) return true;
+    return (uint64_t)n >= (uint64_t)per_string * idx->suffix_table_deepest;
+}
+
+// explicit: the caller asked for a plan (fmx_count_plan_dev) — it gets one whatever plan_pays says
 static int plan_order(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n, Scratch &scratch,
-                      fmx::CountPlan *plan) {
+                      fmx::CountPlan *plan, bool explicit_request = false) {
     *plan = fmx::CountPlan();
     if (!scratch.per_call) {  // whatever fmx_count_plan_dev left for this stream is about to be overwritten
         std::lock_guard<std::mutex> lock(idx->ws_mutex);
         idx->plans.erase(scratch.stream);
     }
+    if (!explicit_request && !plan_pays(idx, n)) return FMX_OK;  // the caller's order: k_count maps the characters itself
     void *ws = nullptr;
     const size_t ws_bytes = k_count_workspace_bytes(idx, idx->dev, n);
     int rc = scratch.get(kWsPlan, ws_bytes, &ws);
@@ -927,7 +952,7 @@ int fmx_count_plan_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_
     if (n < 0 || !d_plan || (n > 0 && !d_pat_off)) return fail(FMX_E_ARG, "bad arguments");
     fmx_index::Plan plan;
     Scratch scratch(idx, stream, false);
-    rc = plan_order(idx, d_pat, d_pat_off, n, scratch, &plan.plan);
+    rc = plan_order(idx, d_pat, d_pat_off, n, scratch, &plan.plan, true);
     if (rc) return rc;
     plan.pat = d_pat;
     plan.pat_off = d_pat_off;
@@ -938,6 +963,11 @@ int fmx_count_plan_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_
     *d_plan = plan.plan.recs;
     return FMX_OK;
     });
+}
+
+int fmx_count_batch_is_planned(const fmx_index *idx, int32_t n) {
+    if (!idx || n <= 0) return 0;
+    return (k_count_workspace_bytes(idx, idx->dev, n) != 0 && plan_pays(idx, n)) ? 1 : 0;
 }
 
 int fmx_count_ordered_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, const void *d_plan,

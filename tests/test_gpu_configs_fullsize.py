@@ -19,7 +19,7 @@ import index4j_amd as ia
 import orc
 from index4j_amd import workload
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.plan_policy]  # the configs as shipped: the library decides which batches it plans
 CORES = os.cpu_count() or 1
 M = 8
 
@@ -84,9 +84,16 @@ def test_config1_all_1m_counts_statuses_and_lf_steps(idx32, batch, text256):
 
 
 def test_config1_unplanned_and_planned_paths_agree(idx32, batch):
-    """the 1 M batch goes through the plan stage (suffix order); small slices do not — same answers"""
+    """the 1 M batch under the library's own policy (round 4: counted in the caller's order — 4.6 patterns per string of the
+    5-character table), the same batch with the plan stage forced (suffix order), and small slices — same answers"""
     pat, off, _ = batch
     cnt, st = idx32.fm.count_batch(pat, off)
+    assert ia.lib.fmx_set_option(b"plan_min_per_string", 0) == 0
+    try:
+        forced, st_f = idx32.fm.count_batch(pat, off)
+    finally:
+        ia.lib.fmx_set_option(b"plan_min_per_string", 16)
+    assert (forced == cnt).all() and (st_f == st).all()
     k = 5000  # below sort_min: processed in the caller's order
     for lo in (0, 400_000, (1 << 20) - k):
         c2, s2 = idx32.fm.count_batch(pat[lo * M:(lo + k) * M], off[: k + 1])

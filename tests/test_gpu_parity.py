@@ -1,6 +1,7 @@
 """Parity tests proper: the HIP kernels, called through the C ABI (libfmx.so), against the oracle, the
 committed fixture, brute force, and — at BASELINE.json's sizes — size-independent properties.
 Run with `-m gpu` on an MI355X."""
+import ctypes as C
 import os
 import random
 
@@ -619,6 +620,57 @@ def test_an_unknown_character_at_the_top_of_the_table_key_does_not_find_the_shor
             kk, ll = o.locate(pats[i], max_matches=2, cap=2)
             assert st2[i] == 0 and found[i] == kk and (locs[i, :kk] == ll).all(), i
         fm.close()
+
+
+@pytest.mark.plan_policy
+def test_the_plan_stage_is_skipped_where_it_does_not_pay_and_nothing_else_changes():
+    """fmx_count_batch_is_planned: a batch is planned (suffix order first) only if it holds at least plan_min_per_string
+    (16) patterns per string of the suffix table's deepest level — below that the patterns no longer share their first
+    lines and k_count in the caller's order is faster (round 4).  Counts, statuses, LF-steps and located hits are the same
+    either way; fmx_count_plan_dev still plans when asked."""
+    import torch
+
+    text = ia.synth_log(1 << 22)
+    o = orc.OracleFmIndex(text, 32, True)
+    assert ia.lib.fmx_set_option(b"suffix_table_image_fraction", 0) == 0
+    assert ia.lib.fmx_set_option(b"suffix_table_chars", 4) == 0
+    try:
+        fm = ia.FmIndex.read(o.write(False), device=0)  # 4 characters: ~26,000 strings at the deepest level
+    finally:
+        ia.lib.fmx_set_option(b"suffix_table_image_fraction", 8)
+        ia.lib.fmx_set_option(b"suffix_table_chars", 8)
+    assert fm.suffix_table_info()[0] == 4
+    is_planned = lambda n: ia.lib.fmx_count_batch_is_planned(fm.handle, n)
+    assert is_planned(1000) == 0                       # below sort_min
+    assert is_planned(60_000) == 0 and is_planned(1 << 20) == 1  # 2.3 and 40 patterns per string
+    n = 60_000
+    pat, off, _ = ia.synth_patterns(text, 8, n, seed=11)
+    orc.counters_reset()
+    oc, ost = o.count_batch(pat, off, threads=8)
+    steps = orc.counters()["lf_steps"]
+    results = []
+    for per_string in (16, 0):  # the policy (caller's order), then the plan stage forced
+        assert ia.lib.fmx_set_option(b"plan_min_per_string", per_string) == 0
+        assert is_planned(n) == (1 if per_string == 0 else 0)
+        cnt, st, lf = fm.count_batch(pat, off, want_steps=True)
+        assert (cnt == oc).all() and (st == ost).all() and int(lf.astype(np.int64).sum()) == steps
+        locs, found, st2 = fm.locate_batch(pat, off, 4)
+        results.append((locs.copy(), found.copy()))
+    ia.lib.fmx_set_option(b"plan_min_per_string", 16)
+    live = np.arange(4)[None, :] < results[0][1][:, None]
+    assert (results[0][1] == results[1][1]).all() and (results[0][0][live] == results[1][0][live]).all()
+    # an explicit plan request is honoured whatever the policy says
+    dev = torch.device("cuda", 0)
+    d_pat = torch.from_numpy(pat.view(np.int16)).to(dev)
+    d_off = torch.from_numpy(off).to(dev)
+    d_cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+    plan = C.c_void_p()
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert ia.lib.fmx_count_plan_dev(fm.handle, d_pat.data_ptr(), d_off.data_ptr(), n, C.byref(plan), sp) == 0 and plan.value
+    assert ia.lib.fmx_count_ordered_dev(fm.handle, d_pat.data_ptr(), d_off.data_ptr(), plan, n, d_cnt.data_ptr(), None, None, sp) == 0
+    torch.cuda.synchronize()
+    assert (d_cnt.cpu().numpy() == oc).all()
+    fm.close()
 
 
 def test_device_construction_is_byte_identical():

@@ -20,6 +20,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 @pytest.mark.gpu
+@pytest.mark.plan_policy
 def test_reference_series_on_a_1100_symbol_text_matches_the_oracle_row_by_row():
     import torch
 

@@ -76,7 +76,8 @@ def main():
                 "suffix_table_image_fraction": rnd.choice([8, 0, 0, 2]),  # ... and its size against the image's
                 "cells_split_blocks": rnd.choice([1 << 20, 64, 256]),  # chunked decoding of the bit vectors
                 "boundary_group": rnd.choice([0, 1, 2, 4, 8]),
-                "image_compact": rnd.choice([0, 0, 1])}  # bit vectors as RRR records, kernels of namespace fmxc
+                "image_compact": rnd.choice([0, 0, 1]),  # bit vectors as RRR records, kernels of namespace fmxc
+                "plan_min_per_string": rnd.choice([0, 0, 16])}  # 0: every batch of sort_min patterns is planned; 16: the policy
         check_seed = rnd.randrange(1 << 30)
         if args.only_case >= 0 and cases != args.only_case:
             if cases % 3 == 1:
