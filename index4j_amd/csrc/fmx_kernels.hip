@@ -279,7 +279,7 @@ __device__ __forceinline__ void count_one(const DevIndex &ix, const uint16_t *s_
     int32_t beg = 0;
     if (kChunks) {
         if (m > ck.n) beg = pat_off[p];
-        if (kMode == 0 || kMode == 3) ck = chunk_refill<kCodeBits>(ix.char2code, s_map, pat, beg, m, 0);  // no code word: the first chunk
+        if (kMode == 3) ck = chunk_refill<kCodeBits>(ix.char2code, s_map, pat, beg, m, 0);  // no code word: the first chunk
     }
     // the plan stage left the codes of the trailing characters (no character load and map lookup in front of every rank)
     int32_t c = chunk_code<kCodeBits>(ck, 0);
@@ -392,7 +392,7 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
     if (!ix.sb_cache) __syncthreads();
     const int role = threadIdx.x & 1;
     // codes the record's word carries (mode 3: a foreign plan with 16-bit codes gives the order only)
-    constexpr int n_codes = (kMode == 1 || kMode == 2) ? 64 / kCodeBits : 0;
+    constexpr int n_codes = kMode != 3 ? 64 / kCodeBits : 0;
     const int32_t pairs_per_grid = (int32_t)gridDim.x * kPairs;  // 32-bit indices: n < 2^31, fewer live registers
     // (an XCD-aware block order — a contiguous eighth of the sorted batch per XCD — was measured slower:
     // profiles/r01_i_xcd_remap.txt)
@@ -414,7 +414,17 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
                 m = (int32_t)(rq.w & kPlanLongPattern);
                 if (m == (int32_t)kPlanLongPattern) m = pat_off[p + 1] - pat_off[p];
             } else {
-                m = pat_off[p + 1] - pat_off[p];
+                const int32_t beg0 = pat_off[p];
+                m = pat_off[p + 1] - beg0;
+                if (kMode == 0 && m > 0) {
+                    // the caller's order (no plan stage): the code word of the trailing characters is made here, as k_plan_codes
+                    // makes it — one 16-byte fetch of the pattern's tail, characters mapped through the LDS copy of the map —
+                    // so that short patterns take the lean loop of a planned batch
+                    const TailWords tw = pattern_tail_load(pat, beg0, m);
+                    uint32_t ch[8];
+                    pattern_tail_chars(tw, pat, beg0, m, ch);
+                    ck.lo = pattern_code_word<kCodeBits>(ix, s_map, ch, m);
+                }
             }
         }
         ck.n = m < n_codes ? m : n_codes;
@@ -424,7 +434,7 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
         int32_t tabled = 0;
         // one decision per wave: does any of its patterns run past the record's code word?
 #if defined(FMX_EXPERIMENT_NO_CHUNKS)
-        const bool chunks = kMode == 0 || kMode == 3;
+        const bool chunks = kMode == 3;
 #else
         const bool chunks = n_codes == 0 || __any(m > n_codes);
 #endif
