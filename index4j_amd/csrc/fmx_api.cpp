@@ -130,6 +130,8 @@ std::atomic<int> g_suffix_table_chars{8};  // option "suffix_table_chars": its d
 // (tools/depth_sort_probe.py, tools/nosort_probe.py): 1 M patterns over 26 K strings (depth 4): planned 0.168 ms, caller's
 // order 0.179; over 227 K strings (depth 5): 0.150 / 0.141; 65,536 patterns over 227 K: 0.045 / 0.023.
 std::atomic<int> g_plan_min_per_string{16};
+std::atomic<int> g_plan_sa_min{786432};   // option "plan_sa_min" (plan_pays)
+std::atomic<int> g_plan_sa_key_api{2};     // mirror of the kernels' option "plan_sa_key"
 std::atomic<int> g_suffix_table_in_use{1};  // mirror of the kernels' A/B option "suffix_table": launches told to ignore the table plan as if there were none
 std::atomic<int> g_suffix_table_image_fraction{8};  // option "suffix_table_image_fraction": the table stays below image / this (0 = only the budget counts)
 // host-buffer count(): batches of at least this many patterns go through the pipeline (smaller ones: one copy in, kernels, one copy out)
@@ -525,6 +527,11 @@ int fmx_set_option(const char *name, int value) {
         g_suffix_table_chars = value;
         return FMX_OK;
     }
+    if (name && !strcmp(name, "plan_sa_min")) {
+        if (value < 0) return fail(FMX_E_ARG, "bad value");
+        g_plan_sa_min = value;
+        return FMX_OK;
+    }
     if (name && !strcmp(name, "plan_min_per_string")) {
         if (value < 0) return fail(FMX_E_ARG, "bad value");
         g_plan_min_per_string = value;
@@ -553,6 +560,7 @@ int fmx_set_option(const char *name, int value) {
     }
     if (!name) return fail(FMX_E_ARG, "unknown option or bad value");
     if (!strcmp(name, "suffix_table")) g_suffix_table_in_use = value != 0;
+    if (!strcmp(name, "plan_sa_key") && value >= 0 && value <= 2) g_plan_sa_key_api = value;
     {  // launch options go to both kernel sets
         const int a = fmx::set_option(name, value), b = fmxc::set_option(name, value);
         if (a || b) return fail(FMX_E_ARG, "unknown option or bad value");
@@ -907,9 +915,18 @@ void *fmx_device_blob(const fmx_index *idx, size_t *len) {
 // stage 1 of count/locate: processing order of the batch (suffix-key radix sort) — nullptr when the
 // batch is too small to be worth sorting
 // would a batch of n patterns be planned when the library decides (count / locate / segment entry points)?
+//  * an index with a suffix table, plan ordered by SA row (kernels' option plan_sa_key, the default): the bucket pass costs
+//    ~45 us per 1 M patterns and k_count then runs 0.141 -> 0.089 ms — it pays from about 0.8 M patterns on (option
+//    "plan_sa_min", default 786,432; below: 524,288 patterns 0.087 planned vs 0.079 in the caller's order);
+//  * plan ordered by the trailing characters' codes (no table, or plan_sa_key 0): it pays while MANY patterns share the table
+//    string they start from — at least "plan_min_per_string" (16) patterns per string of the table's deepest level; always
+//    without a table.
 static bool plan_pays(const fmx_index *idx, int32_t n) {
+    const bool table = idx->dev.suffix_table && idx->suffix_table_deepest != 0 && g_suffix_table_in_use.load();
+    if (!table) return true;
+    if (g_plan_sa_key_api.load() != 0) return n >= g_plan_sa_min.load();
     const int per_string = g_plan_min_per_string.load();
-    if (per_string <= 0 || !idx->dev.suffix_table || idx->suffix_table_deepest == 0 || !g_suffix_table_in_use.load()) return true;
+    if (per_string <= 0) return true;
     return (uint64_t)n >= (uint64_t)per_string * idx->suffix_table_deepest;
 }
 

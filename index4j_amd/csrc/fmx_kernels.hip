@@ -806,7 +806,54 @@ __global__ __launch_bounds__(kTileThreads) void k_plan_codes(DevIndex ix, const 
             uint32_t ch[8];
             pattern_tail_chars(tail[k], pat, beg[k], m, ch);
             const uint64_t word = pattern_code_word<kCodeBits>(ix, s_map, ch, m);
-            const uint32_t key = suffix_key(word, kCodeBits, sh.chars, sh.bits);
+            uint32_t key;
+            if (sh.sa_key) {
+                // where the pattern's backward search stands when k_count takes it up: the first SA row of its tabulated suffix
+                // — 0 for a pattern that ends at once.  sa_key 1: the suffix table's own answer (one lookup at a random slot of
+                // the table per pattern: 14 us of the pass); sa_key 2: an ESTIMATE of that row from the table's two-character
+                // strings alone (a few hundred slots: cache-resident) — the row range of the suffix's first two characters,
+                // narrowed character by character by the share the next character has after its predecessor (an order-1 chain:
+                // row ~ s(xy) + |xy| * (F(z|y) + P(z|y) * (F(u|z) + ...)), F / P = where the two-character string yz starts inside
+                // y's rows and how much of them it takes).  The estimate is monotone in the suffix's lexicographic order, which
+                // is all the bucket pass needs; results never depend on it.
+                key = 0;
+                constexpr uint32_t cmask = (1u << kCodeBits) - 1u;
+                const int32_t c_last = (int32_t)(word & cmask);
+                if (m > 0 && c_last != 0) {
+                    int32_t start = ix.C[c_last], end = 0, back = 0;
+                    int len = fm_suffix_len(ix, m);
+                    if (len > 64 / kCodeBits) len = 64 / kCodeBits;
+                    if (len >= 2 && kCodeBits == ix.suffix_key_bits && sh.sa_key == 1) {
+                        const int bits = len * kCodeBits;
+                        const uint64_t tk = bits >= 64 ? word : (word & ((1ull << bits) - 1ull));
+                        if ((uint32_t)(tk >> (bits - kCodeBits)) != 0u && tk != kSuffixEmpty) (void)fm_suffix_lookup(ix, tk, len, start, end, back);
+                    } else if (len >= 2 && kCodeBits == ix.suffix_key_bits) {
+                        // codes of the suffix, w[j] = j characters before the pattern's end; its first character is w[len - 1]
+                        auto code_at = [&](int j) { return (uint32_t)(word >> (j * kCodeBits)) & cmask; };
+                        uint32_t x = code_at(len - 1), y = code_at(len - 2);
+                        float lo = (float)ix.C[x ? x : c_last], width = 0.0f;
+                        int32_t s2 = 0, e2 = 0;
+                        if (x != 0 && y != 0 && fm_suffix_lookup(ix, (uint64_t)y | ((uint64_t)x << kCodeBits), 2, s2, e2, back)) {
+                            lo = (float)s2;
+                            width = (float)(e2 - s2);
+                            for (int j = len - 3; j >= 0 && width >= 1.0f; --j) {
+                                x = y;
+                                y = code_at(j);
+                                if (y == 0 || !fm_suffix_lookup(ix, (uint64_t)y | ((uint64_t)x << kCodeBits), 2, s2, e2, back)) break;
+                                const float cx = (float)ix.C[x], nx = (float)(ix.C[x + 1] - ix.C[x]);
+                                lo += width * ((float)s2 - cx) / nx;
+                                width *= (float)(e2 - s2) / nx;
+                            }
+                        }
+                        start = (int32_t)lo;
+                        if (start < 0) start = 0;
+                        if (start > ix.length) start = ix.length;
+                    }
+                    key = (uint32_t)start;
+                }
+            } else {
+                key = suffix_key(word, kCodeBits, sh.chars, sh.bits);
+            }
             const uint32_t lenf = m < 0 ? 0u : ((uint32_t)m < kPlanLongPattern ? (uint32_t)m : kPlanLongPattern);
             Quad q;
             q.x = (uint32_t)word;
@@ -1034,6 +1081,9 @@ static std::atomic<int> g_sort_min{16384};  // batches at least this large are p
 // 14 bits: plan 0.091 ms, step 0.304 ms; 12 bits: 0.075 / 0.286 ms; 10 bits: 0.071 / 0.286 ms; 8 bits: 0.069 / 0.294 ms
 static std::atomic<int> g_coarse_bits{12};
 static std::atomic<int> g_plan_fine{1};  // 0 = skip the window-local fine order (A/B)
+// 0 = order by the trailing characters' codes even where a suffix table exists; 1 = by the SA row the table answers; 2 = by an
+// estimate of that row from the table's two-character strings (SortShape.sa_key)
+static std::atomic<int> g_plan_sa_key{2};
 static std::atomic<int> g_sort_bits{28};    // full key width: floor(sort_bits / bits-per-code) trailing characters
 
 int set_option(const char *name, int value) {
@@ -1074,8 +1124,14 @@ int set_option(const char *name, int value) {
         g_coarse_bits = value;
         return 0;
     }
+    if (!strcmp(name, "plan_sa_key")) {
+        if (value < 0 || value > 2) return -1;
+        g_plan_sa_key = value;
+        return 0;
+    }
     if (!strcmp(name, "plan_fine")) {
-        g_plan_fine = value != 0;
+        if (value < 0 || value > 2) return -1;
+        g_plan_fine = value;
         return 0;
     }
     if (!strcmp(name, "lds_pad_kb")) {
@@ -1123,6 +1179,12 @@ static SortShape sort_shape(const DevIndex &ix) {
     if (sh.chars < 1) sh.chars = 1;
     if (sh.chars > 64 / plan_code_bits(ix.wt_sigma)) sh.chars = 64 / plan_code_bits(ix.wt_sigma);
     sh.total_bits = sh.chars * sh.bits;
+    sh.sa_key = 0;
+    if (g_plan_sa_key && ix.suffix_table && g_suffix_table_use) {  // order by SA row (SortShape.sa_key)
+        sh.sa_key = g_plan_sa_key;
+        sh.total_bits = 1;
+        while (sh.total_bits < 32 && (1ll << sh.total_bits) <= (long long)ix.length) ++sh.total_bits;
+    }
     sh.coarse_bits = sh.total_bits < coarse_bits ? sh.total_bits : coarse_bits;
     return sh;
 }
@@ -1168,7 +1230,8 @@ int launch_count_plan(const DevIndex &ix, const uint16_t *pat, const int32_t *of
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_plan_scatter, dim3(tiles), dim3(kTileThreads), (size_t)bins * 8, st, recs, n, bins,
                        sh.total_bits - sh.coarse_bits, ghist, cursor, ticket, ordered);
-    if (g_plan_fine)
+    // (the fine pass: for the code key; with the SA-row key 4,096 buckets already are what a full sort gives within 5 %: option 2 forces it)
+    if (g_plan_fine == 2 || (g_plan_fine == 1 && !sh.sa_key))
         hipLaunchKernelGGL(k_plan_fine, dim3((n + kFineWindow - 1) / kFineWindow), dim3(kFineThreads), 0, st, ordered, n);
     plan->recs = ordered;
     plan->n = n;
@@ -1380,7 +1443,7 @@ int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, i
 
 }  // namespace FMX_KNS
 
-#if defined(FMX_DIAG_TIMELINE)
+#if defined(FMX_DIAG_TIMELINE) && !FMX_COMPACT
 // (diagnostic builds only; not declared in include/fmx.h) copies {start, end, xcc << 32 | hw id} of the first `groups`
 // workgroups of the last k_count launch
 extern "C" __attribute__((visibility("default"))) int fmx_diag_timeline(unsigned long long *out, int groups) {
@@ -1390,7 +1453,7 @@ extern "C" __attribute__((visibility("default"))) int fmx_diag_timeline(unsigned
 }
 #endif
 
-#if defined(FMX_DIAG_LINES)
+#if defined(FMX_DIAG_LINES) && !FMX_COMPACT
 // (diagnostic builds only) out == NULL: clear the bitmaps; else copy them out (8 x 2 MiB)
 extern "C" __attribute__((visibility("default"))) int fmx_diag_lines(unsigned *out) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;

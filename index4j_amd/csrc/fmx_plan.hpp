@@ -10,15 +10,19 @@ namespace fmx {
 struct SortShape {
     int bits;         // bits per alphabet code
     int chars;        // trailing characters in the full key
-    int total_bits;   // chars * bits (<= 32)
+    int total_bits;   // chars * bits (<= 32); with sa_key: bits of an SA row number of this index
     int coarse_bits;  // top bits used by the bucket pass
+    int sa_key;       // 1: a pattern's key is the first SA row of its tabulated suffix (the suffix table's answer) — neighbours
+                      // in that order read neighbouring BWT positions in their first step, and LF-mapping keeps rows that are
+                      // preceded by the same character in order: the locality survives the steps; 0: the trailing characters'
+                      // codes, the last character most significant (indexes without a suffix table)
 };
 
 struct CountPlan {
     const void *recs = nullptr;  // PlanRec[n] in processing order (device memory); nullptr = the caller's order
     int32_t n = 0;
     int code_bits = 8;           // width of one code in a record's code word (8, or 16 when sigma > 256)
-    SortShape shape = {1, 1, 1, 1};
+    SortShape shape = {1, 1, 1, 1, 0};
     // the alphabet the code words are written in (the index the plan was made with): code -> char, alphabet size
     const int32_t *look_up = nullptr;
     int32_t sigma = 0;

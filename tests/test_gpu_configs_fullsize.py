@@ -84,16 +84,21 @@ def test_config1_all_1m_counts_statuses_and_lf_steps(idx32, batch, text256):
 
 
 def test_config1_unplanned_and_planned_paths_agree(idx32, batch):
-    """the 1 M batch under the library's own policy (round 4: counted in the caller's order — 4.6 patterns per string of the
-    5-character table), the same batch with the plan stage forced (suffix order), and small slices — same answers"""
+    """the 1 M batch under the library's own policy (the host-buffer path counts it in chunks of 262,144: the caller's order),
+    the same batch with the plan stage forced (ordered by estimated SA row, by the table's SA row, by trailing codes), and
+    small slices — same answers"""
     pat, off, _ = batch
     cnt, st = idx32.fm.count_batch(pat, off)
-    assert ia.lib.fmx_set_option(b"plan_min_per_string", 0) == 0
     try:
-        forced, st_f = idx32.fm.count_batch(pat, off)
+        for sa_key in (2, 1, 0):
+            assert ia.lib.fmx_set_option(b"plan_sa_min", 0) == 0 and ia.lib.fmx_set_option(b"plan_min_per_string", 0) == 0
+            assert ia.lib.fmx_set_option(b"plan_sa_key", sa_key) == 0
+            forced, st_f = idx32.fm.count_batch(pat, off)
+            assert (forced == cnt).all() and (st_f == st).all(), sa_key
     finally:
         ia.lib.fmx_set_option(b"plan_min_per_string", 16)
-    assert (forced == cnt).all() and (st_f == st).all()
+        ia.lib.fmx_set_option(b"plan_sa_min", 786432)
+        ia.lib.fmx_set_option(b"plan_sa_key", 2)
     k = 5000  # below sort_min: processed in the caller's order
     for lo in (0, 400_000, (1 << 20) - k):
         c2, s2 = idx32.fm.count_batch(pat[lo * M:(lo + k) * M], off[: k + 1])

@@ -624,10 +624,11 @@ def test_an_unknown_character_at_the_top_of_the_table_key_does_not_find_the_shor
 
 @pytest.mark.plan_policy
 def test_the_plan_stage_is_skipped_where_it_does_not_pay_and_nothing_else_changes():
-    """fmx_count_batch_is_planned: a batch is planned (suffix order first) only if it holds at least plan_min_per_string
-    (16) patterns per string of the suffix table's deepest level — below that the patterns no longer share their first
-    lines and k_count in the caller's order is faster (round 4).  Counts, statuses, LF-steps and located hits are the same
-    either way; fmx_count_plan_dev still plans when asked."""
+    """fmx_count_batch_is_planned.  Round 4: with the deeper suffix table the plan stage only pays for large batches —
+    ordered by SA row (an estimate from the table's two-character strings; option plan_sa_key 2, 1 = the table's own answer)
+    from plan_sa_min = 786,432 patterns on; ordered by the trailing characters' codes (plan_sa_key 0) while a batch holds at
+    least plan_min_per_string = 16 patterns per string of the table's deepest level.  Counts, statuses, LF-steps and
+    located hits are the same under every order; fmx_count_plan_dev still plans when asked."""
     import torch
 
     text = ia.synth_log(1 << 22)
@@ -641,24 +642,35 @@ def test_the_plan_stage_is_skipped_where_it_does_not_pay_and_nothing_else_change
         ia.lib.fmx_set_option(b"suffix_table_chars", 8)
     assert fm.suffix_table_info()[0] == 4
     is_planned = lambda n: ia.lib.fmx_count_batch_is_planned(fm.handle, n)
-    assert is_planned(1000) == 0                       # below sort_min
-    assert is_planned(60_000) == 0 and is_planned(1 << 20) == 1  # 2.3 and 40 patterns per string
+    assert is_planned(1000) == 0 and is_planned(60_000) == 0 and is_planned(700_000) == 0 and is_planned(1 << 20) == 1
+    assert ia.lib.fmx_set_option(b"plan_sa_key", 0) == 0  # the code-key order: 2.3 and 40 patterns per string
+    assert is_planned(1000) == 0 and is_planned(60_000) == 0 and is_planned(1 << 20) == 1 and is_planned(500_000) == 1
+    assert ia.lib.fmx_set_option(b"plan_sa_key", 2) == 0
     n = 60_000
     pat, off, _ = ia.synth_patterns(text, 8, n, seed=11)
     orc.counters_reset()
     oc, ost = o.count_batch(pat, off, threads=8)
     steps = orc.counters()["lf_steps"]
     results = []
-    for per_string in (16, 0):  # the policy (caller's order), then the plan stage forced
-        assert ia.lib.fmx_set_option(b"plan_min_per_string", per_string) == 0
-        assert is_planned(n) == (1 if per_string == 0 else 0)
-        cnt, st, lf = fm.count_batch(pat, off, want_steps=True)
-        assert (cnt == oc).all() and (st == ost).all() and int(lf.astype(np.int64).sum()) == steps
-        locs, found, st2 = fm.locate_batch(pat, off, 4)
-        results.append((locs.copy(), found.copy()))
-    ia.lib.fmx_set_option(b"plan_min_per_string", 16)
+    try:
+        # the policy (caller's order), then the plan stage forced under each of its three orders
+        for sa_min, sa_key, planned in ((786432, 2, 0), (0, 2, 1), (0, 1, 1), (0, 0, 0)):
+            assert ia.lib.fmx_set_option(b"plan_sa_min", sa_min) == 0 and ia.lib.fmx_set_option(b"plan_sa_key", sa_key) == 0
+            if sa_key == 0:
+                assert ia.lib.fmx_set_option(b"plan_min_per_string", 0) == 0
+                planned = 1
+            assert is_planned(n) == planned
+            cnt, st, lf = fm.count_batch(pat, off, want_steps=True)
+            assert (cnt == oc).all() and (st == ost).all() and int(lf.astype(np.int64).sum()) == steps
+            locs, found, st2 = fm.locate_batch(pat, off, 4)
+            results.append((locs.copy(), found.copy()))
+    finally:
+        ia.lib.fmx_set_option(b"plan_min_per_string", 16)
+        ia.lib.fmx_set_option(b"plan_sa_min", 786432)
+        ia.lib.fmx_set_option(b"plan_sa_key", 2)
     live = np.arange(4)[None, :] < results[0][1][:, None]
-    assert (results[0][1] == results[1][1]).all() and (results[0][0][live] == results[1][0][live]).all()
+    for r in results[1:]:
+        assert (results[0][1] == r[1]).all() and (results[0][0][live] == r[0][live]).all()
     # an explicit plan request is honoured whatever the policy says
     dev = torch.device("cuda", 0)
     d_pat = torch.from_numpy(pat.view(np.int16)).to(dev)

@@ -56,10 +56,20 @@ def main():
     fn = ia.lib.fmx_diag_lines
     fn.argtypes = [C.c_void_p]
     plan = C.c_void_p()
-    assert ia.lib.fmx_count_plan_dev(fm.handle, d_pat.data_ptr(), d_off.data_ptr(), n, C.byref(plan), sp) == 0
-    assert ia.lib.fmx_count_ordered_dev(fm.handle, d_pat.data_ptr(), d_off.data_ptr(), plan, n, d_cnt.data_ptr(), None, None, sp) == 0
+    planned = "--planned" in sys.argv  # default: what fmx_count_batch_dev runs for this batch (round 4: the caller's order)
+
+    def launch():
+        if planned:
+            assert ia.lib.fmx_count_ordered_dev(fm.handle, d_pat.data_ptr(), d_off.data_ptr(), plan, n, d_cnt.data_ptr(), None, None, sp) == 0
+        else:
+            assert ia.lib.fmx_count_batch_dev(fm.handle, d_pat.data_ptr(), d_off.data_ptr(), n, d_cnt.data_ptr(), None, None, sp) == 0
+
+    if planned:
+        assert ia.lib.fmx_count_plan_dev(fm.handle, d_pat.data_ptr(), d_off.data_ptr(), n, C.byref(plan), sp) == 0
+    print("planned launch" if planned else "fmx_count_batch_dev (planned by the library: %d)" % ia.lib.fmx_count_batch_is_planned(fm.handle, n))
+    launch()
     assert fn(None) == 0
-    assert ia.lib.fmx_count_ordered_dev(fm.handle, d_pat.data_ptr(), d_off.data_ptr(), plan, n, d_cnt.data_ptr(), None, None, sp) == 0
+    launch()
     words = np.zeros(8 << 19, dtype=np.uint32)
     assert fn(words.ctypes.data) == 0
     bits = np.unpackbits(words.view(np.uint8).reshape(8, -1), axis=1, bitorder="little")[:, :len(sec)].astype(bool)
