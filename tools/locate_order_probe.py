@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Experiment: configs[2] locate with the batch rearranged by the SA row of each pattern's interval (what a plan-ordered
+k_locate_walk would see) against the caller's (random) order.  Host-side rearrangement only.  GPU box only."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+import index4j_amd as ia  # noqa: E402
+
+dev = torch.device("cuda", 0)
+sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+text, fm, _ = bench.build_or_load_index(ia, 28, 32, "/tmp/fmx_cache")
+fm.to_device(0)
+for K in (100_000, 1 << 20):
+    M, m = 16, 8
+    pat, off, _ = ia.synth_patterns(text, m, K, seed=43)
+    rows = pat.reshape(K, m)
+    d_off = torch.from_numpy(off).to(dev)
+    d_locs = torch.zeros(K * M, dtype=torch.int32, device=dev)
+    d_found = torch.zeros(K, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(K, dtype=torch.int32, device=dev)
+    d_rng = torch.zeros(2 * K, dtype=torch.int32, device=dev)
+
+    def run(p):
+        d_pat = torch.from_numpy(np.ascontiguousarray(p).view(np.int16)).to(dev)
+
+        def f():
+            assert ia.lib.fmx_locate_batch_dev(fm.handle, d_pat.data_ptr(), d_off.data_ptr(), K, M, d_locs.data_ptr(), M, d_found.data_ptr(), None,
+                                               d_st.data_ptr(), d_rng.data_ptr(), sp) == 0
+        for _ in range(3):
+            f()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 10, int(d_found.sum().item())
+
+    t0, h0 = run(rows.reshape(-1))
+    start = d_rng.cpu().numpy().reshape(K, 2)[:, 0].astype(np.int64)
+    order = np.argsort(start, kind="stable")
+    t1, h1 = run(rows[order].reshape(-1))
+    assert h0 == h1
+    print("locate %8d patterns x <= %d hits: caller's order %.4f ms, sorted by SA row %.4f ms (%+.1f %%)" % (K, M, t0, t1, (t1 / t0 - 1) * 100), flush=True)
