@@ -36,7 +36,8 @@
                      int32_t *, int32_t *, int32_t *, hipStream_t);                                                     \
     size_t count_workspace_bytes(const fmx::DevIndex &, int32_t n);                                                     \
     int launch_locate_walk(const fmx::DevIndex &, int, const int32_t *, int32_t, int32_t, int32_t *, int32_t, int32_t *, \
-                           int32_t *, int32_t *, const int32_t *, hipStream_t);                                         \
+                           int32_t *, int32_t *, const int32_t *, void *, size_t, bool, hipStream_t);                   \
+    size_t walk_workspace_bytes(const fmx::DevIndex &, int32_t n);                                                      \
     int launch_extract(const fmx::DevIndex &, int, const int32_t *, const int32_t *, int64_t, uint16_t *, int32_t, int32_t, \
                        int32_t *, int32_t *, int32_t *, const int32_t *, int32_t, int32_t, hipStream_t);                \
     int launch_extract_boundary(const fmx::DevIndex &, int, const int32_t *, int64_t, uint16_t, int, uint16_t *, int32_t, \
@@ -76,6 +77,7 @@ FMX_DISPATCH_FN(launch_count_plan)
 FMX_DISPATCH_FN(launch_count)
 FMX_DISPATCH_FN(count_workspace_bytes)
 FMX_DISPATCH_FN(launch_locate_walk)
+FMX_DISPATCH_FN(walk_workspace_bytes)
 FMX_DISPATCH_FN(launch_extract)
 FMX_DISPATCH_FN(launch_extract_boundary)
 FMX_DISPATCH_FN(boundary_workspace_bytes)
@@ -215,7 +217,7 @@ int require_device(const fmx_index *idx, bool rrr_handle = false) {
     return FMX_OK;
 }
 
-constexpr int kWsPlan = 0, kWsBoundary = 1;
+constexpr int kWsPlan = 0, kWsBoundary = 1, kWsWalk = 2;  // (kWsWalk: the walk order of locate, a plan-like head)
 
 // scratch of at least `bytes` for work enqueued on `stream`; reused across calls on the same stream
 int get_workspace(const fmx_index *idx, void *stream, int kind, size_t bytes, void **out) {
@@ -224,7 +226,8 @@ int get_workspace(const fmx_index *idx, void *stream, int kind, size_t bytes, vo
     std::lock_guard<std::mutex> lock(idx->ws_mutex);
     auto &slot = idx->ws[{stream, kind}];
     if (slot.second < bytes) {
-        if (kind == kWsPlan && bytes < fmx::kPlanHeadBytes) bytes = fmx::kPlanHeadBytes;
+        const bool has_head = kind == kWsPlan || kind == kWsWalk;
+        if (has_head && bytes < fmx::kPlanHeadBytes) bytes = fmx::kPlanHeadBytes;
         if (slot.first) {
             HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
             (void)hipFree(slot.first);
@@ -234,7 +237,7 @@ int get_workspace(const fmx_index *idx, void *stream, int kind, size_t bytes, vo
         void *p = nullptr;
         HIP_TRY(hipMalloc(&p, bytes));
         // the plan kernels expect the head of their workspace zeroed and leave it zeroed (fmx_plan.hpp)
-        if (kind == kWsPlan) HIP_TRY(hipMemsetAsync(p, 0, fmx::kPlanHeadBytes, static_cast<hipStream_t>(stream)));
+        if (has_head) HIP_TRY(hipMemsetAsync(p, 0, fmx::kPlanHeadBytes, static_cast<hipStream_t>(stream)));
         slot = {p, bytes};
     }
     *out = slot.first;
@@ -1030,6 +1033,26 @@ int fmx_count_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32
     });
 }
 
+// k_locate_walk over the ranges of a batch, the patterns taken by the first row of their ranges where the batch is large
+// enough for that to pay (walk_workspace_bytes)
+static int walk_hits(const fmx_index *idx, const int32_t *d_range, int32_t n, int32_t max_matches, int32_t *d_locs,
+                     int32_t loc_cap, int32_t *d_found, int32_t *d_lf_steps, int32_t *d_status, const int32_t *d_taken,
+                     Scratch &scratch) {
+    hipStream_t st = static_cast<hipStream_t>(scratch.stream);
+    void *ws = nullptr;
+    const size_t ws_bytes = k_walk_workspace_bytes(idx, idx->dev, n);
+    int rc = scratch.get(kWsWalk, ws_bytes, &ws);
+    if (rc) return rc;
+    int e = k_launch_locate_walk(idx, idx->dev, idx->n_cu, d_range, n, max_matches, d_locs, loc_cap, d_found, d_lf_steps,
+                                 d_status, d_taken, ws, ws_bytes, !scratch.per_call, st);
+    if (e) {
+        // (an order that stopped half way leaves its histogram in the head of a per-stream workspace: clear it)
+        if (ws && !scratch.per_call) (void)hipMemsetAsync(ws, 0, fmx::kPlanHeadBytes, st);
+        return fail(FMX_E_HIP, std::string("k_locate_walk launch: ") + hipGetErrorString((hipError_t)e));
+    }
+    return FMX_OK;
+}
+
 static int locate_impl(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
                        int32_t max_matches, int32_t *d_locs, int32_t loc_cap, int32_t *d_found, int32_t *d_lf_steps,
                        int32_t *d_status, int32_t *d_range_ws, Scratch &scratch) {
@@ -1045,10 +1068,7 @@ static int locate_impl(const fmx_index *idx, const uint16_t *d_pat, const int32_
     int e = k_launch_count(idx, idx->dev, idx->n_cu, d_pat, d_pat_off, &plan, false, n, d_found, d_lf_steps, d_status,
                               d_range_ws, st);
     if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
-    e = k_launch_locate_walk(idx, idx->dev, idx->n_cu, d_range_ws, n, max_matches, d_locs, loc_cap, d_found, d_lf_steps,
-                                d_status, nullptr, st);
-    if (e) return fail(FMX_E_HIP, std::string("k_locate_walk launch: ") + hipGetErrorString((hipError_t)e));
-    return FMX_OK;
+    return walk_hits(idx, d_range_ws, n, max_matches, d_locs, loc_cap, d_found, d_lf_steps, d_status, nullptr, scratch);
 }
 
 int fmx_locate_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
@@ -1238,9 +1258,19 @@ static int locate_segments_impl(const fmx_index *const *segs, int32_t n_segs, co
         if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
         // like the caller's loop `n += seg.locate(p, 0, len, locations, maxMatches - n)`: hits already
         // taken from earlier segments shrink this segment's limit
-        e = k_launch_locate_walk(segs[s], segs[s]->dev, segs[s]->n_cu, range, n, max_matches, seg_locs, max_matches, seg_found,
-                                    nullptr, seg_status, s ? d_found : nullptr, st);
-        if (e) return fail(FMX_E_HIP, std::string("k_locate_walk launch: ") + hipGetErrorString((hipError_t)e));
+        // (the walk order's scratch belongs to the set's first index, like the plan's: one workspace per stream)
+        {
+            void *ws = nullptr;
+            const size_t ws_bytes = k_walk_workspace_bytes(segs[s], segs[s]->dev, n);
+            rc = scratch.get(kWsWalk, ws_bytes, &ws);
+            if (rc) return rc;
+            e = k_launch_locate_walk(segs[s], segs[s]->dev, segs[s]->n_cu, range, n, max_matches, seg_locs, max_matches,
+                                     seg_found, nullptr, seg_status, s ? d_found : nullptr, ws, ws_bytes, !scratch.per_call, st);
+            if (e) {
+                if (ws && !scratch.per_call) (void)hipMemsetAsync(ws, 0, fmx::kPlanHeadBytes, st);
+                return fail(FMX_E_HIP, std::string("k_locate_walk launch: ") + hipGetErrorString((hipError_t)e));
+            }
+        }
         e = fmx::launch_segment_append_hits(d_locs, d_found, d_status, seg_locs, seg_found, seg_status, n, max_matches,
                                             seg_base[s], s == 0, st);
         if (e) return fail(FMX_E_HIP, std::string("k_segment_append_hits launch: ") + hipGetErrorString((hipError_t)e));

@@ -544,15 +544,26 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix_global, const int32_t *__
                                                         int32_t loc_cap, int32_t slots, int32_t *__restrict__ found,
                                                         int32_t *__restrict__ lf_steps,
                                                         int32_t *__restrict__ status_out,
-                                                        const int32_t *__restrict__ taken) {
+                                                        const int32_t *__restrict__ taken,
+                                                        const PlanRec *__restrict__ order) {
     FMX_FM_INV(ix_global);
     FMX_WITH_SB_CACHE(ix_global, ix);
     const int64_t total = (int64_t)n * slots;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
-        const int32_t p = (int32_t)(t / slots);
+        // order (nullable): the batch's records {start, end, pattern} by the first row of their ranges (k_walk_hist)
+        int32_t p = (int32_t)(t / slots);
         const int32_t k = (int32_t)(t - (int64_t)p * slots);
-        const int32_t start = range[2 * p], end = range[2 * p + 1];
+        int32_t start, end;
+        if (order) {
+            const Quad r = ld_quad(order + p);
+            start = (int32_t)r.x;
+            end = (int32_t)r.y;
+            p = (int32_t)r.z;
+        } else {
+            start = range[2 * p];
+            end = range[2 * p + 1];
+        }
         int32_t hits = start < end ? end - start : 0;
         // segment sets: `taken[p]` hits came from earlier segments, the caller's loop passes maxMatches - taken
         int32_t limit = max_matches;
@@ -873,14 +884,46 @@ __global__ __launch_bounds__(kTileThreads) void k_plan_codes(DevIndex ix, const 
     }
 }
 
+// The walk order of locate: a pattern's hits are the rows start..end-1 of its SA range, and the walks of neighbouring rows
+// read neighbouring lines for as long as the rows are preceded by the same characters (LF-mapping keeps such rows in order)
+// — so k_locate_walk takes the patterns by the first row of their ranges.  Key of a pattern: start (0 = no hits).
+__device__ __forceinline__ uint32_t walk_key(int32_t start, int32_t end) { return start < end && start > 0 ? (uint32_t)start : 0u; }
+
+__global__ __launch_bounds__(kTileThreads) void k_walk_hist(const int32_t *__restrict__ range, int32_t n, int bins, int below,
+                                                            uint32_t *__restrict__ ghist) {
+    extern __shared__ uint32_t s_hist[];
+    for (int i = threadIdx.x; i < bins; i += kTileThreads) s_hist[i] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kTile;
+#pragma unroll
+    for (int k = 0; k < kTileItems; ++k) {
+        const int64_t p = base + (int64_t)k * kTileThreads + threadIdx.x;
+        if (p >= n) continue;
+        const int2 r = *reinterpret_cast<const int2 *>(range + 2 * p);
+        uint32_t c = walk_key(r.x, r.y) >> below;
+        if (c >= (uint32_t)bins) c = (uint32_t)bins - 1u;
+        atomicAdd(&s_hist[c], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < bins; i += kTileThreads) {
+        const uint32_t v = s_hist[i];
+        if (v) atomicAdd(&ghist[i], v);
+    }
+}
+
 // pass 2: records into bucket order (16-byte scattered writes; gathering them later instead costs a 64-byte line
 // through the fabric per record).  ghist = the batch's histogram, cursor = running fill of each bin (zero at entry),
 // ticket = workgroups done (zero at entry); all three are zero again when the kernel has finished.
-__global__ __launch_bounds__(kTileThreads) void k_plan_scatter(const PlanRec *__restrict__ recs_in, int32_t n, int bins,
+// kFromRange (the walk order of locate, k_walk_hist): the records are made here from the batch's SA ranges — {start, end,
+// pattern index, 0}, keyed by start — instead of being read from recs_in.
+template <bool kFromRange>
+__global__ __launch_bounds__(kTileThreads) void k_plan_scatter(const PlanRec *__restrict__ recs_in,
+                                                               const int32_t *__restrict__ range, int32_t n, int bins,
                                                                int below, uint32_t *__restrict__ ghist,
                                                                uint32_t *__restrict__ cursor,
                                                                uint32_t *__restrict__ ticket,
                                                                PlanRec *__restrict__ recs_out) {
+    const int fine_shift = below > 8 ? below - 8 : 0;  // (kFromRange: the fine bin of a record, as k_plan_codes leaves it)
     extern __shared__ uint32_t s_mem[];  // [bins] exclusive scan of ghist, [bins] this workgroup's counts / slots
     __shared__ uint32_t s_wave[kTileThreads / 64];
     __shared__ uint32_t s_last;
@@ -896,7 +939,15 @@ __global__ __launch_bounds__(kTileThreads) void k_plan_scatter(const PlanRec *__
         const int64_t p = base + (int64_t)k * kTileThreads + threadIdx.x;
         bin[k] = 0xffffffffu;
         if (p < n) {
-            mine[k] = ld_quad(recs_in + p);
+            if constexpr (kFromRange) {
+                const int2 r = *reinterpret_cast<const int2 *>(range + 2 * p);
+                mine[k].x = (uint32_t)r.x;
+                mine[k].y = (uint32_t)r.y;
+                mine[k].z = walk_key(r.x, r.y);
+                mine[k].w = ((mine[k].z >> fine_shift) & ((1u << kFineBits) - 1u)) << 22;
+            } else {
+                mine[k] = ld_quad(recs_in + p);
+            }
             uint32_t c = mine[k].z >> below;  // PlanRec.a = the key
             if (c >= (uint32_t)bins) c = (uint32_t)bins - 1u;
             bin[k] = c;
@@ -1084,6 +1135,11 @@ static std::atomic<int> g_plan_fine{1};  // 0 = skip the window-local fine order
 // 0 = order by the trailing characters' codes even where a suffix table exists; 1 = by the SA row the table answers; 2 = by an
 // estimate of that row from the table's two-character strings (SortShape.sa_key)
 static std::atomic<int> g_plan_sa_key{2};
+// locate: batches at least this large walk their hits by the first row of the patterns' SA ranges (0 = always in the caller's
+// order).  Measured on configs[1]'s index, <= 16 hits per pattern (tools/locate_order_probe.py): 16,384 patterns +8 % (the two
+// or three short kernels in front), 32,768 -5 %, 100,000 -24 %, 1,048,576 -43 %.
+static std::atomic<int> g_walk_order_min{32768};
+static std::atomic<int> g_walk_fine{1};  // the window-local fine order on top of the buckets (k_plan_fine; 0: A/B)
 static std::atomic<int> g_sort_bits{28};    // full key width: floor(sort_bits / bits-per-code) trailing characters
 
 int set_option(const char *name, int value) {
@@ -1142,6 +1198,15 @@ int set_option(const char *name, int value) {
     if (!strcmp(name, "sort_min")) {
         if (value < 0) return -1;
         g_sort_min = value;
+        return 0;
+    }
+    if (!strcmp(name, "walk_fine")) {
+        g_walk_fine = value != 0;
+        return 0;
+    }
+    if (!strcmp(name, "walk_order_min")) {
+        if (value < 0) return -1;
+        g_walk_order_min = value;
         return 0;
     }
     if (!strcmp(name, "sort_bits")) {
@@ -1228,7 +1293,7 @@ int launch_count_plan(const DevIndex &ix, const uint16_t *pat, const int32_t *of
                            ghist);
     // (a failed launch here would leave the histogram filled: the caller then clears the workspace's head)
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_plan_scatter, dim3(tiles), dim3(kTileThreads), (size_t)bins * 8, st, recs, n, bins,
+    hipLaunchKernelGGL(k_plan_scatter<false>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 8, st, recs, nullptr, n, bins,
                        sh.total_bits - sh.coarse_bits, ghist, cursor, ticket, ordered);
     // (the fine pass: for the code key; with the SA-row key 4,096 buckets already are what a full sort gives within 5 %: option 2 forces it)
     if (g_plan_fine == 2 || (g_plan_fine == 1 && !sh.sa_key))
@@ -1294,13 +1359,49 @@ int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_
     return (int)hipGetLastError();
 }
 
+// bytes of scratch for the walk order of a batch of n patterns (0 = the batch is walked in the caller's order):
+// head (as a plan's, kPlanHeadBytes, zero between uses) | records in walk order [n]
+size_t walk_workspace_bytes(const DevIndex &ix, int32_t n) {
+    const int walk_min = g_walk_order_min;
+    if (walk_min <= 0 || n < walk_min) return 0;
+    return kPlanHeadBytes + (size_t)n * sizeof(PlanRec) + 64;
+}
+
+// workspace (nullable): walk_workspace_bytes(ix, n) — the patterns are then walked by the first row of their ranges
 int launch_locate_walk(const DevIndex &ix, int n_cu, const int32_t *range, int32_t n, int32_t max_matches,
                        int32_t *locs, int32_t loc_cap, int32_t *found, int32_t *lf, int32_t *status,
-                       const int32_t *taken, hipStream_t st) {
+                       const int32_t *taken, void *workspace, size_t workspace_bytes, bool head_is_zero, hipStream_t st) {
     if (n <= 0) return 0;
     int32_t slots = (max_matches > 0 && max_matches < loc_cap) ? max_matches : loc_cap;
     if (slots < 1) slots = 1;
-    FMX_DISPATCH(k_locate_walk, (int64_t)n * slots, ix, range, n, max_matches, locs, loc_cap, slots, found, lf, status, taken);
+    const PlanRec *order = nullptr;
+    const size_t need = walk_workspace_bytes(ix, n);
+    if (workspace && need != 0 && workspace_bytes >= need && loc_cap > 0) {
+        uint8_t *wsb = static_cast<uint8_t *>(workspace);
+        uint32_t *ghist = reinterpret_cast<uint32_t *>(wsb);
+        uint32_t *cursor = ghist + (1 << kCoarseBitsMax);
+        uint32_t *ticket = cursor + (1 << kCoarseBitsMax);
+        PlanRec *ordered = reinterpret_cast<PlanRec *>(wsb + kPlanHeadBytes);
+        if (!head_is_zero) {
+            hipError_t e = hipMemsetAsync(workspace, 0, kPlanHeadBytes, st);
+            if (e != hipSuccess) return (int)e;
+        }
+        int total_bits = 1;
+        while (total_bits < 32 && (1ll << total_bits) <= (long long)ix.length) ++total_bits;
+        const int coarse_bits = total_bits < g_coarse_bits ? total_bits : (int)g_coarse_bits;
+        const int bins = 1 << coarse_bits, below = total_bits - coarse_bits;
+        const int tiles = (n + kTile - 1) / kTile;
+        hipLaunchKernelGGL(k_walk_hist, dim3(tiles), dim3(kTileThreads), (size_t)bins * 4, st, range, n, bins, below, ghist);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k_plan_scatter<true>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 8, st, nullptr, range, n, bins,
+                           below, ghist, cursor, ticket, ordered);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
+        if (g_walk_fine)
+            hipLaunchKernelGGL(k_plan_fine, dim3((n + kFineWindow - 1) / kFineWindow), dim3(kFineThreads), 0, st, ordered, n);
+        order = ordered;
+    }
+    FMX_DISPATCH(k_locate_walk, (int64_t)n * slots, ix, range, n, max_matches, locs, loc_cap, slots, found, lf, status, taken,
+                 order);
     return (int)hipGetLastError();
 }
 

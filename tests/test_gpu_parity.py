@@ -800,6 +800,72 @@ def test_layout_variants_give_the_same_answers():
         ia.lib.fmx_set_option(b"inv_fast", 1)
 
 
+@pytest.mark.plan_policy
+def test_locate_walks_the_hits_by_the_first_row_of_the_ranges_and_nothing_else_changes():
+    """Round 4: k_locate_walk takes the patterns of a large batch by the first row of their SA ranges (k_walk_hist, k_plan_scatter
+    from the ranges, k_plan_fine; option walk_order_min, default 32,768 patterns): found, positions, statuses (the reference's
+    AIOOBE where `locations` is shorter than the hits wanted) and LF-steps are those of the caller's order and of the oracle.
+    Host-buffer entry (a per-call workspace), device entry (the stream's), a segment set (hits taken by earlier segments)."""
+    import torch
+
+    text = ia.synth_log(1 << 21)
+    o = orc.OracleFmIndex(text, 16, True)
+    fm = ia.FmIndex.read(o.write(False), device=0)
+    t16 = ia.as_chars(text)
+    r = random.Random(5)
+    n = 40_000
+    pats = [t16[a:a + r.choice([0, 1, 2, 3, 5, 8, 13])] for a in (r.randrange(len(t16) - 16) for _ in range(n))]
+    for k in range(0, n, 37):  # patterns without hits
+        pats[k] = np.concatenate([pats[k], np.array([7], np.uint16)])
+    ch, off = ia.pack_patterns(pats)
+    L = ia.lib
+    try:
+        for mm, cap in ((5, 5), (6, 3), (-1, 4)):
+            want = o.locate_batch(ch, off, mm, loc_cap=cap, threads=8)
+            got = {}
+            for walk_min, fine in ((0, 1), (32768, 1), (1, 1), (1, 0)):
+                assert L.fmx_set_option(b"walk_order_min", walk_min) == 0 and L.fmx_set_option(b"walk_fine", fine) == 0
+                got[(walk_min, fine)] = fm.locate_batch(ch, off, mm, loc_cap=cap, want_steps=True)
+            base = got[(0, 1)]
+            live = np.arange(cap)[None, :] < base[1][:, None]
+            assert (base[1] == want[1]).all() and (base[2] == want[2]).all() and (base[0][live] == want[0][live]).all()
+            for g in got.values():
+                assert (g[1] == base[1]).all() and (g[2] == base[2]).all() and (g[3] == base[3]).all()
+                assert (g[0][live] == base[0][live]).all()
+        # device entry points: the stream's workspace serves batches of different sizes one after the other
+        dev = torch.device("cuda", 0)
+        sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        d_pat = torch.from_numpy(ch.view(np.int16)).to(dev)
+        d_off = torch.from_numpy(off).to(dev)
+        assert L.fmx_set_option(b"walk_order_min", 1) == 0 and L.fmx_set_option(b"walk_fine", 1) == 0
+        want = o.locate_batch(ch, off, 4, threads=8)
+        for m in (n, 1000, 17, n, 1):
+            d_locs = torch.full((m * 4,), -1, dtype=torch.int32, device=dev)
+            d_found = torch.zeros(m, dtype=torch.int32, device=dev)
+            d_st = torch.zeros(m, dtype=torch.int32, device=dev)
+            d_rng = torch.zeros(2 * m, dtype=torch.int32, device=dev)
+            assert L.fmx_locate_batch_dev(fm.handle, d_pat.data_ptr(), d_off.data_ptr(), m, 4, d_locs.data_ptr(), 4, d_found.data_ptr(),
+                                          None, d_st.data_ptr(), d_rng.data_ptr(), sp) == 0
+            torch.cuda.synchronize()
+            f = d_found.cpu().numpy()
+            live = np.arange(4)[None, :] < f[:, None]
+            assert (f == want[1][:m]).all() and (d_st.cpu().numpy() == want[2][:m]).all()
+            assert (d_locs.cpu().numpy().reshape(m, 4)[live] == want[0][:m][live]).all()
+        # a segment set: each segment walks its own ranges in its own order, limits shrink by what earlier segments gave
+        seg = ia.SegmentedFmIndex(text, 16, True, device=0, segment_chars=600_000)
+        assert len(seg.segments) >= 3
+        res = []
+        for walk_min in (0, 1):
+            assert L.fmx_set_option(b"walk_order_min", walk_min) == 0
+            res.append(seg.locate_batch(ch, off, 6))
+        assert (res[0][1] == res[1][1]).all() and (res[0][2] == res[1][2]).all() and (res[0][0] == res[1][0]).all()
+        assert int(res[0][1].sum()) > n
+    finally:
+        L.fmx_set_option(b"walk_order_min", 32768)
+        L.fmx_set_option(b"walk_fine", 1)
+    fm.close()
+
+
 def test_api_edge_cases():
     """empty batches, zero-capacity buffers and bad arguments through the C ABI: no kernel launch with bad shapes,
     library-level error codes instead"""

@@ -17,7 +17,7 @@ dev = torch.device("cuda", 0)
 sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 text, fm, _ = bench.build_or_load_index(ia, 28, 32, "/tmp/fmx_cache")
 fm.to_device(0)
-for K in (100_000, 1 << 20):
+for K in (8192, 16384, 32768, 100_000, 1 << 20):
     M, m = 16, 8
     pat, off, _ = ia.synth_patterns(text, m, K, seed=43)
     rows = pat.reshape(K, m)
@@ -43,7 +43,18 @@ for K in (100_000, 1 << 20):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / 10, int(d_found.sum().item())
 
+    assert ia.lib.fmx_set_option(b"walk_order_min", 0) == 0
     t0, h0 = run(rows.reshape(-1))
+    ref = d_locs.clone()
+    assert ia.lib.fmx_set_option(b"walk_order_min", 1) == 0
+    for fine, cb in ((0, 12), (1, 12), (0, 13), (1, 13), (1, 10)):
+        assert ia.lib.fmx_set_option(b"walk_fine", fine) == 0 and ia.lib.fmx_set_option(b"coarse_bits", cb) == 0
+        tw, hw = run(rows.reshape(-1))
+        assert hw == h0 and torch.equal(ref, d_locs)
+        print("   walk_fine %d coarse_bits %d: %.4f ms" % (fine, cb, tw), flush=True)
+    assert ia.lib.fmx_set_option(b"walk_fine", 1) == 0 and ia.lib.fmx_set_option(b"coarse_bits", 12) == 0
+    print("locate %8d patterns: walk in the caller's order %.4f ms, by the first row of the ranges %.4f ms (%+.1f %%)" % (K, t0, tw, (tw / t0 - 1) * 100), flush=True)
+    assert ia.lib.fmx_set_option(b"walk_order_min", 0) == 0
     start = d_rng.cpu().numpy().reshape(K, 2)[:, 0].astype(np.int64)
     order = np.argsort(start, kind="stable")
     t1, h1 = run(rows[order].reshape(-1))
