@@ -240,7 +240,7 @@ def compact_line(out):
     cfg = out.get("config") or {}
     c["config"] = {"workload": _short(cfg.get("workload"), 260)}
     for k in ("image", "text_chars", "patterns_per_gpu", "pattern_len", "sample_rate", "batches", "segments", "patterns_total", "max_matches",
-              "count_checksum", "patterns_checked_vs_oracle"):
+              "count_checksum", "patterns_checked_vs_oracle", "distinct_patterns_batch0"):
         if cfg.get(k) is not None:
             c["config"][k] = cfg[k]
     c["config"]["parallelism"] = "dp%d" % (out.get("n_gpus") or 1)
@@ -417,12 +417,17 @@ def run_count(ctx, args):
     # ---- batches: each ONE batch of world x n patterns made on rank 0, handed out in contiguous shards ----
     n_batches = max(1, args.batches)
     host_batches = []
+    distinct_patterns = None
     d_pats = []
     for b in range(n_batches):
         pat = None
         if ctx.rank == 0:
             pat, _off, _pos = workload.count_batch_patterns(text, world * n, m, seed=workload.PATTERN_SEED + b)
             host_batches.append(pat)
+            if b == 0 and m <= 8:  # (rank 0's own shard: what one GPU's launch sees)
+                rows = np.zeros((n, 8), np.uint16)
+                rows[:, :m] = pat[: n * m].reshape(n, m)
+                distinct_patterns = int(len(np.unique(rows.view(np.uint64), axis=0)))
         d_pats.append(hand_out_patterns(ctx, pat, m, world * n))
     lo, hi = shard_range(world * n, world, ctx.rank)
     assert hi - lo == n
@@ -752,6 +757,10 @@ def run_count(ctx, args):
                    "image": "compact" if args.image_compact else "expanded",
                    "text_chars": 1 << args.text_log2, "patterns_per_gpu": n, "pattern_len": m,
                    "sample_rate": args.sample_rate, "batches": n_batches,
+                   # the synthetic log repeats itself: windows drawn from it at random coincide.  Every pattern is searched (no
+                   # result is shared between equal patterns); equal and near-equal patterns read the same lines, which is what the
+                   # plan's order and the caches turn into speed — a text of higher entropy gains less.
+                   "distinct_patterns_batch0": distinct_patterns,
                    "parallelism": "one batch of %d patterns sharded x%d (contiguous shards from rank 0), index image "
                                   "broadcast and replicated" % (world * n, world),
                    "count_checksums_rank0": checksums, "count_checksum": checksums[0],

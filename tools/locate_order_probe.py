@@ -21,6 +21,7 @@ for K in (8192, 16384, 32768, 100_000, 1 << 20):
     M, m = 16, 8
     pat, off, _ = ia.synth_patterns(text, m, K, seed=43)
     rows = pat.reshape(K, m)
+    p_rows = rows
     d_off = torch.from_numpy(off).to(dev)
     d_locs = torch.zeros(K * M, dtype=torch.int32, device=dev)
     d_found = torch.zeros(K, dtype=torch.int32, device=dev)
@@ -55,7 +56,12 @@ for K in (8192, 16384, 32768, 100_000, 1 << 20):
     assert ia.lib.fmx_set_option(b"walk_fine", 1) == 0 and ia.lib.fmx_set_option(b"coarse_bits", 12) == 0
     print("locate %8d patterns: walk in the caller's order %.4f ms, by the first row of the ranges %.4f ms (%+.1f %%)" % (K, t0, tw, (tw / t0 - 1) * 100), flush=True)
     assert ia.lib.fmx_set_option(b"walk_order_min", 0) == 0
-    start = d_rng.cpu().numpy().reshape(K, 2)[:, 0].astype(np.int64)
+    rng_ = d_rng.cpu().numpy().reshape(K, 2).astype(np.int64)
+    start = rng_[:, 0]
+    hits = np.minimum(np.maximum(rng_[:, 1] - rng_[:, 0], 0), M)
+    hit_rows = np.concatenate([np.arange(a, a + h) for a, h in zip(start[:200000], hits[:200000])])
+    print("   distinct patterns %d of %d, distinct ranges %d; of the first 200,000 patterns' %d hit rows %d are distinct"
+          % (len(np.unique(rows_ := np.ascontiguousarray(p_rows).view([("", p_rows.dtype)] * m))), K, len(np.unique(start)), len(hit_rows), len(np.unique(hit_rows))), flush=True)
     order = np.argsort(start, kind="stable")
     t1, h1 = run(rows[order].reshape(-1))
     assert h0 == h1
