@@ -207,6 +207,9 @@ struct PlanRec {
 static_assert(sizeof(PlanRec) == 16, "PlanRec");
 constexpr uint32_t kPlanLongPattern = 0x3fffffu;
 constexpr int kFineBits = 10;  // width of the window-local order of k_plan_fine (counting sort in LDS)
+constexpr int kFineThreads = 512;
+constexpr int kFineItems = 2;
+constexpr int kFineWindow = kFineThreads * kFineItems;  // 1,024 patterns: the window k_plan_fine orders
 
 // recs (nullable): the plan — the batch's records in processing order; lane pair q takes record q (one coalesced
 // 16-byte load, no gather).  plan_look_up (mode 2): code of the plan's alphabet -> character, to translate code
@@ -545,18 +548,27 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix_global, const int32_t *__
                                                         int32_t *__restrict__ lf_steps,
                                                         int32_t *__restrict__ status_out,
                                                         const int32_t *__restrict__ taken,
-                                                        const PlanRec *__restrict__ order) {
+                                                        const PlanRec *__restrict__ order,
+                                                        const uint32_t *__restrict__ order_idle) {
     FMX_FM_INV(ix_global);
     FMX_WITH_SB_CACHE(ix_global, ix);
-    const int64_t total = (int64_t)n * slots;
+    // order (nullable): the batch's records {start, end, pattern} by the first row of their ranges (k_walk_hist); its first
+    // *order_idle records have nothing to locate.  Whole windows of the fine pass below that mark get one lane per pattern
+    // (a lane that finds hits there after all walks them one after the other), the rest one lane per slot.
+    const int64_t idle = order ? (int64_t)(*order_idle / (uint32_t)kFineWindow) * kFineWindow : 0;
+    const int64_t total = idle + ((int64_t)n - idle) * slots;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
-        // order (nullable): the batch's records {start, end, pattern} by the first row of their ranges (k_walk_hist)
-        int32_t p = (int32_t)(t / slots);
-        const int32_t k = (int32_t)(t - (int64_t)p * slots);
+        int64_t rec = t;
+        int32_t k = 0;
+        if (t >= idle) {
+            rec = idle + (t - idle) / slots;
+            k = (int32_t)((t - idle) - (rec - idle) * slots);
+        }
+        int32_t p = (int32_t)rec;
         int32_t start, end;
         if (order) {
-            const Quad r = ld_quad(order + p);
+            const Quad r = ld_quad(order + rec);
             start = (int32_t)r.x;
             end = (int32_t)r.y;
             p = (int32_t)r.z;
@@ -578,12 +590,14 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix_global, const int32_t *__
             found[p] = located;
             if (wanted > loc_cap && status_out) atomicOr(&status_out[p], ST_JAVA_AIOOBE);
         }
-        if (k >= located) continue;
-        int status = ST_OK;
-        int32_t distance;
-        locs[(int64_t)p * loc_cap + k] = fm_locate_hit(ix, s_inv, start, k, distance, status);
-        if (lf_steps && distance) atomicAdd(&lf_steps[p], distance);
-        if (status && status_out) atomicOr(&status_out[p], status);
+        const int32_t k_end = t < idle ? located : (k < located ? k + 1 : k);
+        for (; k < k_end; ++k) {
+            int status = ST_OK;
+            int32_t distance;
+            locs[(int64_t)p * loc_cap + k] = fm_locate_hit(ix, s_inv, start, k, distance, status);
+            if (lf_steps && distance) atomicAdd(&lf_steps[p], distance);
+            if (status && status_out) atomicOr(&status_out[p], status);
+        }
     }
 }
 
@@ -887,9 +901,24 @@ __global__ __launch_bounds__(kTileThreads) void k_plan_codes(DevIndex ix, const 
 // The walk order of locate: a pattern's hits are the rows start..end-1 of its SA range, and the walks of neighbouring rows
 // read neighbouring lines for as long as the rows are preceded by the same characters (LF-mapping keeps such rows in order)
 // — so k_locate_walk takes the patterns by the first row of their ranges.  Key of a pattern: start (0 = no hits).
-__device__ __forceinline__ uint32_t walk_key(int32_t start, int32_t end) { return start < end && start > 0 ? (uint32_t)start : 0u; }
+// A pattern with nothing to locate — no hits, or (segment sets) its maxMatches already taken from earlier segments — has key
+// 0 and goes into a bin of its own in front of the others (bin = 1 + the key's top bits): k_locate_walk gives such a pattern
+// one lane instead of one per slot.
+__device__ __forceinline__ uint32_t walk_key(int32_t start, int32_t end, const int32_t *__restrict__ taken, int32_t max_matches,
+                                             int64_t p) {
+    if (start >= end) return 0u;
+    if (taken && max_matches - taken[p] <= 0) return 0u;
+    return start > 0 ? (uint32_t)start : 1u;
+}
+__device__ __forceinline__ uint32_t walk_bin(uint32_t key, int below, int bins) {
+    if (key == 0u) return 0u;
+    const uint32_t c = 1u + (key >> below);
+    return c < (uint32_t)bins ? c : (uint32_t)bins - 1u;
+}
 
+// bins: the zero bin + 2^coarse_bits
 __global__ __launch_bounds__(kTileThreads) void k_walk_hist(const int32_t *__restrict__ range, int32_t n, int bins, int below,
+                                                            const int32_t *__restrict__ taken, int32_t max_matches,
                                                             uint32_t *__restrict__ ghist) {
     extern __shared__ uint32_t s_hist[];
     for (int i = threadIdx.x; i < bins; i += kTileThreads) s_hist[i] = 0;
@@ -900,9 +929,7 @@ __global__ __launch_bounds__(kTileThreads) void k_walk_hist(const int32_t *__res
         const int64_t p = base + (int64_t)k * kTileThreads + threadIdx.x;
         if (p >= n) continue;
         const int2 r = *reinterpret_cast<const int2 *>(range + 2 * p);
-        uint32_t c = walk_key(r.x, r.y) >> below;
-        if (c >= (uint32_t)bins) c = (uint32_t)bins - 1u;
-        atomicAdd(&s_hist[c], 1u);
+        atomicAdd(&s_hist[walk_bin(walk_key(r.x, r.y, taken, max_matches, p), below, bins)], 1u);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < bins; i += kTileThreads) {
@@ -918,8 +945,10 @@ __global__ __launch_bounds__(kTileThreads) void k_walk_hist(const int32_t *__res
 // pattern index, 0}, keyed by start — instead of being read from recs_in.
 template <bool kFromRange>
 __global__ __launch_bounds__(kTileThreads) void k_plan_scatter(const PlanRec *__restrict__ recs_in,
-                                                               const int32_t *__restrict__ range, int32_t n, int bins,
-                                                               int below, uint32_t *__restrict__ ghist,
+                                                               const int32_t *__restrict__ range,
+                                                               const int32_t *__restrict__ taken, int32_t max_matches,
+                                                               int32_t n, int bins, int below,
+                                                               uint32_t *__restrict__ ghist,
                                                                uint32_t *__restrict__ cursor,
                                                                uint32_t *__restrict__ ticket,
                                                                PlanRec *__restrict__ recs_out) {
@@ -928,6 +957,9 @@ __global__ __launch_bounds__(kTileThreads) void k_plan_scatter(const PlanRec *__
     __shared__ uint32_t s_wave[kTileThreads / 64];
     __shared__ uint32_t s_last;
     uint32_t *s_scan = s_mem, *s_cnt = s_mem + bins;
+    // (the walk order: how many patterns have nothing to locate = the zero bin, kept for k_locate_walk in the word behind the
+    // ticket; the histogram is complete, and stays until the last workgroup has taken its ticket)
+    if (kFromRange && blockIdx.x == 0 && threadIdx.x == 0) ticket[1] = ghist[0];
     // this workgroup's items per bin (the loads of the scan below overlap these)
     for (int i = threadIdx.x; i < bins; i += kTileThreads) s_cnt[i] = 0;
     __syncthreads();
@@ -943,14 +975,15 @@ __global__ __launch_bounds__(kTileThreads) void k_plan_scatter(const PlanRec *__
                 const int2 r = *reinterpret_cast<const int2 *>(range + 2 * p);
                 mine[k].x = (uint32_t)r.x;
                 mine[k].y = (uint32_t)r.y;
-                mine[k].z = walk_key(r.x, r.y);
+                mine[k].z = walk_key(r.x, r.y, taken, max_matches, p);
                 mine[k].w = ((mine[k].z >> fine_shift) & ((1u << kFineBits) - 1u)) << 22;
+                bin[k] = walk_bin(mine[k].z, below, bins);
             } else {
                 mine[k] = ld_quad(recs_in + p);
+                uint32_t c = mine[k].z >> below;  // PlanRec.a = the key
+                if (c >= (uint32_t)bins) c = (uint32_t)bins - 1u;
+                bin[k] = c;
             }
-            uint32_t c = mine[k].z >> below;  // PlanRec.a = the key
-            if (c >= (uint32_t)bins) c = (uint32_t)bins - 1u;
-            bin[k] = c;
             mine[k].z = (uint32_t)p;  // from here on PlanRec.a = the pattern's index
         }
     }
@@ -1017,9 +1050,6 @@ __global__ __launch_bounds__(kTileThreads) void k_plan_scatter(const PlanRec *__
 // and ranks them by their fine bins with a counting sort in LDS (histogram, scan by one wave, ranked copy), then
 // writes the window back in that order: k_count reads the records with coalesced 16-byte loads.  Which patterns
 // share a wave is what matters, not their order inside it, so 10 key bits per window are as good as a full sort.
-constexpr int kFineThreads = 512;
-constexpr int kFineItems = 2;
-constexpr int kFineWindow = kFineThreads * kFineItems;  // 1,024 patterns
 __global__ __launch_bounds__(kFineThreads) void k_plan_fine(PlanRec *__restrict__ recs, int32_t n) {
     constexpr int n_bins = 1 << kFineBits;
     __shared__ uint32_t s_bin[n_bins];
@@ -1293,7 +1323,7 @@ int launch_count_plan(const DevIndex &ix, const uint16_t *pat, const int32_t *of
                            ghist);
     // (a failed launch here would leave the histogram filled: the caller then clears the workspace's head)
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_plan_scatter<false>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 8, st, recs, nullptr, n, bins,
+    hipLaunchKernelGGL(k_plan_scatter<false>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 8, st, recs, nullptr, nullptr, 0, n, bins,
                        sh.total_bits - sh.coarse_bits, ghist, cursor, ticket, ordered);
     // (the fine pass: for the code key; with the SA-row key 4,096 buckets already are what a full sort gives within 5 %: option 2 forces it)
     if (g_plan_fine == 2 || (g_plan_fine == 1 && !sh.sa_key))
@@ -1375,6 +1405,7 @@ int launch_locate_walk(const DevIndex &ix, int n_cu, const int32_t *range, int32
     int32_t slots = (max_matches > 0 && max_matches < loc_cap) ? max_matches : loc_cap;
     if (slots < 1) slots = 1;
     const PlanRec *order = nullptr;
+    const uint32_t *order_idle = nullptr;
     const size_t need = walk_workspace_bytes(ix, n);
     if (workspace && need != 0 && workspace_bytes >= need && loc_cap > 0) {
         uint8_t *wsb = static_cast<uint8_t *>(workspace);
@@ -1389,19 +1420,21 @@ int launch_locate_walk(const DevIndex &ix, int n_cu, const int32_t *range, int32
         int total_bits = 1;
         while (total_bits < 32 && (1ll << total_bits) <= (long long)ix.length) ++total_bits;
         const int coarse_bits = total_bits < g_coarse_bits ? total_bits : (int)g_coarse_bits;
-        const int bins = 1 << coarse_bits, below = total_bits - coarse_bits;
+        const int bins = (1 << coarse_bits) + 1, below = total_bits - coarse_bits;  // (+ the bin of patterns with nothing to locate)
         const int tiles = (n + kTile - 1) / kTile;
-        hipLaunchKernelGGL(k_walk_hist, dim3(tiles), dim3(kTileThreads), (size_t)bins * 4, st, range, n, bins, below, ghist);
+        hipLaunchKernelGGL(k_walk_hist, dim3(tiles), dim3(kTileThreads), (size_t)bins * 4, st, range, n, bins, below, taken,
+                           max_matches, ghist);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(k_plan_scatter<true>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 8, st, nullptr, range, n, bins,
-                           below, ghist, cursor, ticket, ordered);
+        hipLaunchKernelGGL(k_plan_scatter<true>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 8, st, nullptr, range, taken,
+                           max_matches, n, bins, below, ghist, cursor, ticket, ordered);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
         if (g_walk_fine)
             hipLaunchKernelGGL(k_plan_fine, dim3((n + kFineWindow - 1) / kFineWindow), dim3(kFineThreads), 0, st, ordered, n);
         order = ordered;
+        order_idle = ticket + 1;
     }
     FMX_DISPATCH(k_locate_walk, (int64_t)n * slots, ix, range, n, max_matches, locs, loc_cap, slots, found, lf, status, taken,
-                 order);
+                 order, order_idle);
     return (int)hipGetLastError();
 }
 
