@@ -172,9 +172,14 @@ int fmx_count_plan_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_
 int fmx_count_ordered_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, const void *d_plan,
                           int32_t n, int32_t *d_counts, int32_t *d_lf_steps, int32_t *d_status, void *stream);
 /* 1 if fmx_count_batch_dev / fmx_locate_batch_dev would run the plan stage for a batch of n patterns on this resident index, 0 if
- * they count in the caller's order.  The plan (suffix order) pays while many patterns share the suffix-table string they start
- * from; a batch with fewer than "plan_min_per_string" (option, default 16) patterns per string of the table's deepest level
- * skips it — results are the same either way.  (fmx_count_plan_dev always plans: the caller asked.) */
+ * they count in the caller's order — results are the same either way.  On an index with a suffix table the plan orders the
+ * batch by the (estimated) first SA row of each pattern's tabulated suffix (option "plan_sa_key": 2 = estimated from the table's
+ * two-character strings, the default; 1 = the table's own answer; 0 = by the trailing characters' codes, as on an index
+ * without a table) and pays from "plan_sa_min" patterns on (option, default 786,432); with "plan_sa_key" 0 a batch is planned
+ * if it holds at least "plan_min_per_string" (default 16) patterns per string of the table's deepest level.  An index without a
+ * table plans every batch of "sort_min" patterns or more.  (fmx_count_plan_dev always plans: the caller asked.)
+ * locate has an order of its own on top: batches of "walk_order_min" patterns or more (default 32,768; 0 = never) walk their
+ * hits by the first row of the patterns' SA ranges ("walk_fine" = 0 drops that order's fine pass). */
 int fmx_count_batch_is_planned(const fmx_index *idx, int32_t n);
 int fmx_locate_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
                          int32_t max_matches, int32_t *d_locs, int32_t loc_cap, int32_t *d_found,
@@ -288,7 +293,8 @@ int fmx_device_count(void);
  * "sort_min" = smallest batch that is processed in suffix-sorted order (0 = never), "sort_bits" = sort key width,
  * "boundary_accel" = 0 forces the literal +4-chunk right walk of extractUntilBoundary, "boundary_group" = lanes
  * per extractUntilBoundary query (0 | 2 | 4 | 8 | 16), "coarse_bits" / "plan_fine" = bins and fine pass of the plan
- * stage, "suffix_table" = 0: launches ignore the index's suffix table, "lf_steps_executed_only" = 1: the LF-step
+ * stage, "plan_sa_key" / "plan_sa_min" / "plan_min_per_string" / "walk_order_min" / "walk_fine" = which batches are planned
+ * and by what (fmx_count_batch_is_planned), "suffix_table" = 0: launches ignore the index's suffix table, "lf_steps_executed_only" = 1: the LF-step
  * output of count() leaves out the rank evaluations the suffix table answered (bench.py's executed-work figure; the
  * default reports the reference's count), "boundary_first_fill" = 1: narrower first fill of extractUntilBoundary's
  * text windows (experiment).
