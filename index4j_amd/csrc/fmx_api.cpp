@@ -30,6 +30,7 @@
     int launch_suffix_level1(const fmx::DevIndex &, fmx::SuffixSlot *, uint32_t *, uint32_t, hipStream_t);              \
     int launch_suffix_expand(const fmx::DevIndex &, int, const fmx::SuffixSlot *, uint32_t, int, int, fmx::SuffixSlot *, uint32_t *, uint32_t, hipStream_t); \
     int launch_suffix_insert(const fmx::DevIndex &, const fmx::SuffixSlot *, uint32_t, int, fmx::SuffixSlot *, hipStream_t); \
+    int launch_suffix_order1(const fmx::DevIndex &, float *, hipStream_t);                                              \
     int launch_count_plan(const fmx::DevIndex &, const uint16_t *, const int32_t *, int32_t, void *, size_t, bool, fmx::CountPlan *, \
                           hipStream_t);                                                                                 \
     int launch_count(const fmx::DevIndex &, int, const uint16_t *, const int32_t *, const fmx::CountPlan *, bool, int32_t, int32_t *, \
@@ -73,6 +74,7 @@ static bool image_is_compact(const fmx_index *idx);
 FMX_DISPATCH_FN(launch_suffix_level1)
 FMX_DISPATCH_FN(launch_suffix_expand)
 FMX_DISPATCH_FN(launch_suffix_insert)
+FMX_DISPATCH_FN(launch_suffix_order1)
 FMX_DISPATCH_FN(launch_count_plan)
 FMX_DISPATCH_FN(launch_count)
 FMX_DISPATCH_FN(count_workspace_bytes)
@@ -100,6 +102,7 @@ struct fmx_index {
     bool rrr_only = false;      // built by fmx_rrr_build: only the RrrVector entry points apply
     double wavelet_device_seconds = 0;  // fmx_build_on_device: seconds of the wavelet encode in HBM (0: host encoder)
     void *d_suffix_table = nullptr;     // DevIndex.suffix_table (owned, whoever owns the image)
+    void *d_suffix_order1 = nullptr;    // DevIndex.suffix_order1 (owned likewise)
     size_t suffix_table_bytes = 0;
     uint32_t suffix_table_strings = 0;  // strings (of 2 .. suffix_chars codes) the table holds
     uint32_t suffix_table_deepest = 0;  // ... of which strings of suffix_chars codes: what a batch's patterns spread over after the lookup
@@ -204,6 +207,7 @@ void make_dev_index(fmx_index *idx) {
     d.suffix_key_bits = h.wt_sigma <= 256 ? 8 : 16;
     d.suffix_shift = 0;
     d.suffix_mask = 0;
+    d.suffix_order1 = nullptr;
     d.sb_cache = nullptr;
     d.sb_cache_limit = g_sb_cache_limit;
     d.wt_size = (uint32_t)h.wt_size;
@@ -666,6 +670,7 @@ void fmx_free(fmx_index *idx) {
         if (kv.second.first) (void)hipFree(kv.second.first);
     if (idx->owns_device && idx->d_blob) (void)hipFree(idx->d_blob);
     if (idx->d_suffix_table) (void)hipFree(idx->d_suffix_table);
+    if (idx->d_suffix_order1) (void)hipFree(idx->d_suffix_order1);
     delete idx;
 }
 
@@ -689,8 +694,13 @@ static void build_suffix_table(fmx_index *idx) {
         idx->d_suffix_table = nullptr;
         idx->suffix_table_bytes = 0;
     }
+    if (idx->d_suffix_order1) {
+        (void)hipFree(idx->d_suffix_order1);
+        idx->d_suffix_order1 = nullptr;
+    }
     idx->suffix_table_strings = idx->suffix_table_deepest = 0;
     idx->dev.suffix_table = nullptr;
+    idx->dev.suffix_order1 = nullptr;
     idx->dev.suffix_chars = 0;
     idx->dev.suffix_key_bits = idx->hdr.wt_sigma <= 256 ? 8 : 16;
     idx->dev.suffix_shift = 0;
@@ -803,6 +813,20 @@ static void build_suffix_table(fmx_index *idx) {
     idx->dev.suffix_chars = chars;
     idx->dev.suffix_shift = geometry.suffix_shift;
     idx->dev.suffix_mask = slots - 1;
+    // order-1 statistics of the two-character strings for the plan's sort key (small alphabets; not having them is no error)
+    if (key_bits == 8 && idx->hdr.wt_sigma <= fmx::kOrder1MaxSigma) {
+        void *d_o1 = nullptr;
+        const size_t bytes = (size_t)idx->hdr.wt_sigma * idx->hdr.wt_sigma * 2 * sizeof(float);
+        if (hipMalloc(&d_o1, bytes) == hipSuccess) {
+            if (k_launch_suffix_order1(idx, idx->dev, static_cast<float *>(d_o1), nullptr) == 0 &&
+                hipStreamSynchronize(nullptr) == hipSuccess) {
+                idx->d_suffix_order1 = d_o1;
+                idx->dev.suffix_order1 = static_cast<const float *>(d_o1);
+            } else {
+                (void)hipFree(d_o1);
+            }
+        }
+    }
 }
 
 int fmx_suffix_table_info(const fmx_index *idx, int32_t *chars, int64_t *bytes) {

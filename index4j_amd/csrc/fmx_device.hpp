@@ -73,7 +73,13 @@ struct DevIndex {
     int32_t suffix_key_bits;
     uint32_t suffix_shift;  // group of a key = (its hashed bits * kSuffixHashMul) >> suffix_shift (fm_suffix_home)
     uint32_t suffix_mask;   // slots - 1 (slots: a power of two, >= 1024)
+    // Order-1 statistics of the table's two-character strings (nullptr: none — alphabets above kOrder1MaxSigma codes): entry
+    // [x * wt_sigma + y] = {where the rows of "xy" start inside x's rows, and how much of them they take} as fractions
+    // ((s(xy) - C[x]) / n_x, |xy| / n_x; {0, 0}: "xy" does not occur).  k_plan_codes stages it in LDS and estimates from it
+    // the SA row a pattern's search starts at: its sort key.  Results never depend on it.
+    const float *suffix_order1;
 };
+constexpr int kOrder1MaxSigma = 90;  // 90^2 pairs of two floats = 64,800 bytes of LDS in k_plan_codes
 struct SuffixSlot {
     uint64_t key;  // kSuffixEmpty: free
     uint32_t start, end;

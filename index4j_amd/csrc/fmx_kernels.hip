@@ -540,6 +540,31 @@ int launch_suffix_insert(const DevIndex &geometry, const SuffixSlot *in, uint32_
     return (int)hipGetLastError();
 }
 
+// DevIndex.suffix_order1 from the finished table: one thread per pair of codes (x, y)
+__global__ __launch_bounds__(256) void k_suffix_order1(DevIndex ix, float *__restrict__ out) {
+    const int sigma = ix.wt_sigma;
+    const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (i >= sigma * sigma) return;
+    const int x = i / sigma, y = i - x * sigma;
+    float f = 0.0f, p = 0.0f;
+    if (x != 0 && y != 0) {
+        int32_t s2 = 0, e2 = 0, back = 0;
+        const int32_t cx = ix.C[x], nx = ix.C[x + 1] - cx;
+        if (nx > 0 && fm_suffix_lookup(ix, (uint64_t)y | ((uint64_t)x << ix.suffix_key_bits), 2, s2, e2, back) && e2 > s2) {
+            f = (float)(s2 - cx) / (float)nx;
+            p = (float)(e2 - s2) / (float)nx;
+        }
+    }
+    out[2 * i] = f;
+    out[2 * i + 1] = p;
+}
+int launch_suffix_order1(const DevIndex &ix, float *out, hipStream_t st) {
+    const int pairs = ix.wt_sigma * ix.wt_sigma;
+    if (pairs <= 0 || ix.wt_sigma > kOrder1MaxSigma || !ix.suffix_table) return 0;
+    hipLaunchKernelGGL(k_suffix_order1, dim3((pairs + 255) / 256), dim3(256), 0, st, ix, out);
+    return (int)hipGetLastError();
+}
+
 // FM:526-548: hit k of pattern p is SA row i = start + 1 + k; walk LF until a sampled row.
 template <int kBlock>
 FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix_global, const int32_t *__restrict__ range, int32_t n,
@@ -791,6 +816,12 @@ FMX_KERNEL(kBlock) void k_rrr_access(DevIndex ix, const int32_t *__restrict__ po
 //      sort of each workgroup's 256 records on 10 key bits, in LDS.
 // Two short kernels (round 1: memset + four kernels with a tile-local radix sort, 76 us at 1 M patterns).
 
+// dynamic LDS of k_plan_codes with the order-1 table staged behind the histogram (the launcher and the kernel decide alike)
+constexpr size_t kPlanCodesLdsMax = 64 << 10;
+__host__ __device__ constexpr size_t order1_lds_bytes(int bins, int sigma) {
+    return (size_t)bins * 4 + (size_t)sigma * sigma * 8 + ((size_t)sigma + 1) * 4;
+}
+
 // pass 1: records, coarse keys, global histogram
 template <int kCodeBits>
 __global__ __launch_bounds__(kTileThreads) void k_plan_codes(DevIndex ix, const uint16_t *__restrict__ pat,
@@ -802,6 +833,17 @@ __global__ __launch_bounds__(kTileThreads) void k_plan_codes(DevIndex ix, const 
     const int bins = 1 << sh.coarse_bits;
     for (int i = threadIdx.x; i < bins; i += kTileThreads) s_hist[i] = 0;
     for (int i = threadIdx.x; i < 256; i += kTileThreads) s_map[i] = ix.char2code[i];
+    // sa_key 2 with the order-1 table (small alphabets): the table and cumulativeCounts behind the histogram
+    const int sigma = ix.wt_sigma;
+    const bool o1 = kCodeBits == 8 && sh.sa_key == 2 && ix.suffix_order1 != nullptr && sigma <= kOrder1MaxSigma &&
+                    order1_lds_bytes(bins, sigma) <= kPlanCodesLdsMax;
+    float2 *s_o1 = reinterpret_cast<float2 *>(s_hist + bins);
+    int32_t *s_c = reinterpret_cast<int32_t *>(s_o1 + (o1 ? sigma * sigma : 0));
+    if (o1) {
+        const float2 *src = reinterpret_cast<const float2 *>(ix.suffix_order1);
+        for (int i = threadIdx.x; i < sigma * sigma; i += kTileThreads) s_o1[i] = src[i];
+        for (int i = threadIdx.x; i <= sigma; i += kTileThreads) s_c[i] = ix.C[i];
+    }
     __syncthreads();
     // the fine bin of a record: kFineBits key bits ending 8 bits below the coarse bits (or at the key's end)
     const int below = sh.total_bits - sh.coarse_bits;
@@ -852,6 +894,33 @@ __global__ __launch_bounds__(kTileThreads) void k_plan_codes(DevIndex ix, const 
                         const int bits = len * kCodeBits;
                         const uint64_t tk = bits >= 64 ? word : (word & ((1ull << bits) - 1ull));
                         if ((uint32_t)(tk >> (bits - kCodeBits)) != 0u && tk != kSuffixEmpty) (void)fm_suffix_lookup(ix, tk, len, start, end, back);
+                    } else if (len >= 2 && o1) {
+                        // the same estimate as below from the LDS copy of the order-1 table
+                        auto code_at = [&](int j) { return (uint32_t)(word >> (j * kCodeBits)) & cmask; };
+                        uint32_t x = code_at(len - 1), y = code_at(len - 2);
+                        if (x >= (uint32_t)sigma) x = 0;
+                        if (y >= (uint32_t)sigma) y = 0;
+                        float lo = (float)s_c[x ? x : ((uint32_t)c_last < (uint32_t)sigma ? c_last : 0)], width = 0.0f;
+                        if (x != 0 && y != 0) {
+                            float2 fp = s_o1[x * sigma + y];
+                            if (fp.y > 0.0f) {
+                                const float nx = (float)(s_c[x + 1] - s_c[x]);
+                                lo = (float)s_c[x] + fp.x * nx;
+                                width = fp.y * nx;
+                                for (int j = len - 3; j >= 0 && width >= 1.0f; --j) {
+                                    x = y;
+                                    y = code_at(j);
+                                    if (y == 0 || y >= (uint32_t)sigma) break;
+                                    fp = s_o1[x * sigma + y];
+                                    if (fp.y <= 0.0f) break;
+                                    lo += width * fp.x;
+                                    width *= fp.y;
+                                }
+                            }
+                        }
+                        start = (int32_t)lo;
+                        if (start < 0) start = 0;
+                        if (start > ix.length) start = ix.length;
                     } else if (len >= 2 && kCodeBits == ix.suffix_key_bits) {
                         // codes of the suffix, w[j] = j characters before the pattern's end; its first character is w[len - 1]
                         auto code_at = [&](int j) { return (uint32_t)(word >> (j * kCodeBits)) & cmask; };
@@ -1315,8 +1384,12 @@ int launch_count_plan(const DevIndex &ix, const uint16_t *pat, const int32_t *of
     }
     const int tiles = (n + kTile - 1) / kTile;
     const int code_bits = plan_code_bits(ix.wt_sigma);
+    // (the order-1 table and cumulativeCounts behind the histogram: k_plan_codes' `o1`)
+    const bool o1 = code_bits == 8 && sh.sa_key == 2 && ix.suffix_order1 && ix.wt_sigma <= kOrder1MaxSigma &&
+                    order1_lds_bytes(bins, ix.wt_sigma) <= kPlanCodesLdsMax;
+    const size_t lds_codes = o1 ? order1_lds_bytes(bins, ix.wt_sigma) : (size_t)bins * 4;
     if (code_bits == 8)
-        hipLaunchKernelGGL(k_plan_codes<8>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 4, st, ix, pat, off, n, sh, recs,
+        hipLaunchKernelGGL(k_plan_codes<8>, dim3(tiles), dim3(kTileThreads), lds_codes, st, ix, pat, off, n, sh, recs,
                            ghist);
     else
         hipLaunchKernelGGL(k_plan_codes<16>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 4, st, ix, pat, off, n, sh, recs,

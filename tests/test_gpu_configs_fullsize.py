@@ -124,6 +124,49 @@ def test_config2_locate_100k_every_position_in_sa_order(idx32, batch, text256):
         assert (text256[locs[sel, k][:, None] + np.arange(M)[None, :]] == P[sel]).all()
 
 
+def test_locate_of_the_whole_1m_batch_planned_by_sa_row_and_walked_in_range_order(idx32, batch):
+    """the sizes where both orders of round 4 are live under the library's own policy: the batch is planned (>= 786,432 patterns:
+    ordered by the estimated SA row of the tabulated suffix) and its hits are walked by the first row of their ranges
+    (>= 32,768 patterns) — found, every position, statuses, LF-step total against the oracle for all 1,048,576 patterns"""
+    pat, off, _ = batch
+    n = len(off) - 1
+    assert ia.lib.fmx_count_batch_is_planned(idx32.fm.handle, n) == 1
+    locs, found, st, lf = idx32.fm.locate_batch(pat, off, 16, want_steps=True)
+    orc.counters_reset()
+    olocs, ofound, ost = idx32.oracle.locate_batch(pat, off, 16, threads=CORES)
+    c = orc.counters()
+    assert (st == ost).all() and (st == 0).all() and (found == ofound).all()
+    live = np.arange(16)[None, :] < found[:, None]
+    assert (locs[live] == olocs[live]).all()
+    assert int(lf.astype(np.int64).sum()) == c["lf_steps"]
+
+
+def test_count_of_a_4m_batch_on_the_device_entry_point(idx32, text256):
+    """a batch four times the headline's through fmx_count_batch_dev (one plan, one k_count launch of 4,194,304 lane pairs)"""
+    import ctypes as C
+
+    import torch
+
+    n = 1 << 22
+    pat, off, _ = workload.count_batch_patterns(text256, n, M, seed=workload.PATTERN_SEED + 17)
+    dev = torch.device("cuda", 0)
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d_pat = torch.from_numpy(pat.view(np.int16)).to(dev)
+    d_off = torch.from_numpy(off).to(dev)
+    d_cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_lf = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+    assert ia.lib.fmx_count_batch_is_planned(idx32.fm.handle, n) == 1
+    assert ia.lib.fmx_count_batch_dev(idx32.fm.handle, d_pat.data_ptr(), d_off.data_ptr(), n, d_cnt.data_ptr(), d_lf.data_ptr(),
+                                      d_st.data_ptr(), sp) == 0
+    torch.cuda.synchronize()
+    orc.counters_reset()
+    oc, ost = idx32.oracle.count_batch(pat, off, threads=CORES)
+    c = orc.counters()
+    assert (d_cnt.cpu().numpy() == oc).all() and (d_st.cpu().numpy() == ost).all()
+    assert int(d_lf.cpu().numpy().astype(np.int64).sum()) == c["lf_steps"]
+
+
 def test_config3_extract_until_boundary_100k_on_sample_rate_64(text256, batch):
     pat, off, _ = batch
     K = 100_000
