@@ -374,13 +374,15 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
                                                   int32_t *__restrict__ counts, int32_t *__restrict__ lf_steps,
                                                   int32_t *__restrict__ status_out, int32_t *__restrict__ range_out,
                                                   const int32_t *__restrict__ plan_look_up, int32_t plan_sigma,
-                                                  int steps_mode) {
+                                                  int steps_mode, int regroup) {
     // kCodeBits: width of a code in the record's word and in the chunks — 8 when the alphabet fits (8 codes per word),
     // else 16 (the plan's alphabet in modes 1 / 2, this index's own in modes 0 / 3)
     constexpr int kPairs = kBlock / 2;
     diag_begin();
     __shared__ int16_t s_xlat[256];
     __shared__ int16_t s_map[256];  // this index's character map, characters below 256
+    __shared__ uint32_t s_len_bin[64];     // regrouping by length: bins, then their first slots
+    __shared__ Quad s_len_rec[kBlock / 2];  // ... and the workgroup's records in length order
     constexpr bool planned = kMode != 0;
     constexpr bool translate = kMode == 2;  // only offered for 8-bit code words (plan_sigma <= 256)
     // (staged in front of the superblock cache so that both share ONE barrier: a workgroup lives for a few hundred
@@ -405,7 +407,7 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
     for (int32_t q0 = (int32_t)blockIdx.x * kPairs; q0 < n; q0 += pairs_per_grid) {
 #endif
         const int32_t q = q0 + (int32_t)(threadIdx.x >> 1);
-        const bool live = q < n;
+        bool live = q < n;
         int32_t p = q, m = 0;
         CodeChunk ck = {0ull, 0ull, 0, 0};
         if (live) {
@@ -428,6 +430,47 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
                     pattern_tail_chars(tw, pat, beg0, m, ch);
                     ck.lo = pattern_code_word<kCodeBits>(ix, s_map, ch, m);
                 }
+            }
+        }
+        // Patterns of MIXED LENGTHS (the reference's own benchmark draws 8..31 characters): a wave runs as long as its longest
+        // pattern, so a workgroup in which some wave holds different lengths hands its kPairs records out again by length — a
+        // counting sort in LDS on min(m, 63) — and every wave gets patterns of (nearly) one length.  Which pair runs which
+        // record is free (results go to the pattern's index); the batch's order survives at the workgroup's granularity.
+        // A batch of one length pays one barrier.
+        if (regroup) {
+            const bool wave_mixed = __any(live && m != __shfl(m, 0)) != 0;
+            if (__syncthreads_or(wave_mixed ? 1 : 0)) {
+                const int pair = (int)(threadIdx.x >> 1);
+                const int bin = !live ? 0 : (m < 0 ? 0 : (m > 63 ? 63 : m));
+                if (threadIdx.x < 64) s_len_bin[threadIdx.x] = 0;
+                __syncthreads();
+                uint32_t rank_in_bin = 0;
+                if (role == 0) rank_in_bin = atomicAdd(&s_len_bin[bin], 1u);
+                __syncthreads();
+                if (threadIdx.x < 64) {  // exclusive scan of the 64 bins by the first wave, LONGEST first
+                    const uint32_t v = s_len_bin[63 - threadIdx.x];
+                    uint32_t incl = v;
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t t = __shfl_up(incl, d);
+                        if ((int)threadIdx.x >= d) incl += t;
+                    }
+                    s_len_bin[63 - threadIdx.x] = incl - v;
+                }
+                __syncthreads();
+                if (role == 0) {
+                    Quad r;
+                    r.x = (uint32_t)ck.lo;
+                    r.y = (uint32_t)(ck.lo >> 32);
+                    r.z = live ? (uint32_t)p : 0xffffffffu;
+                    r.w = (uint32_t)m;
+                    s_len_rec[s_len_bin[bin] + rank_in_bin] = r;
+                }
+                __syncthreads();
+                const Quad r = s_len_rec[pair];
+                ck.lo = (uint64_t)r.x | ((uint64_t)r.y << 32);
+                p = (int32_t)r.z;
+                m = (int32_t)r.w;
+                live = r.z != 0xffffffffu;
             }
         }
         ck.n = m < n_codes ? m : n_codes;
@@ -566,6 +609,7 @@ int launch_suffix_order1(const DevIndex &ix, float *out, hipStream_t st) {
 }
 
 // FM:526-548: hit k of pattern p is SA row i = start + 1 + k; walk LF until a sampled row.
+constexpr int kWalkLanes = 128;  // lanes of k_locate_walk per pattern (at most): two waves
 template <int kBlock>
 FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix_global, const int32_t *__restrict__ range, int32_t n,
                                                         int32_t max_matches, int32_t *__restrict__ locs,
@@ -579,16 +623,21 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix_global, const int32_t *__
     FMX_WITH_SB_CACHE(ix_global, ix);
     // order (nullable): the batch's records {start, end, pattern} by the first row of their ranges (k_walk_hist); its first
     // *order_idle records have nothing to locate.  Whole windows of the fine pass below that mark get one lane per pattern
-    // (a lane that finds hits there after all walks them one after the other), the rest one lane per slot.
+    // (a lane that finds hits there after all walks them one after the other); every other pattern gets `slots` lanes, at most
+    // two waves (with maxMatches 1000 most slots stay empty, and a lane per slot spent its time finding that out: 1 M queries
+    // at sampleRate 1 3.3 -> 2.5 ms; a cap of one wave costs maxMatches 100 its second round: +3..+8 %): lane g walks hits g,
+    // g + lanes, ... — adjacent lanes walk adjacent SA rows.
+    const int32_t lanes = slots < kWalkLanes ? slots : kWalkLanes;
     const int64_t idle = order ? (int64_t)(*order_idle / (uint32_t)kFineWindow) * kFineWindow : 0;
-    const int64_t total = idle + ((int64_t)n - idle) * slots;
+    const int64_t total = idle + ((int64_t)n - idle) * lanes;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
         int64_t rec = t;
-        int32_t k = 0;
+        int32_t k = 0, step = 1;
         if (t >= idle) {
-            rec = idle + (t - idle) / slots;
-            k = (int32_t)((t - idle) - (rec - idle) * slots);
+            rec = idle + (t - idle) / lanes;
+            k = (int32_t)((t - idle) - (rec - idle) * lanes);
+            step = lanes;
         }
         int32_t p = (int32_t)rec;
         int32_t start, end;
@@ -615,8 +664,7 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix_global, const int32_t *__
             found[p] = located;
             if (wanted > loc_cap && status_out) atomicOr(&status_out[p], ST_JAVA_AIOOBE);
         }
-        const int32_t k_end = t < idle ? located : (k < located ? k + 1 : k);
-        for (; k < k_end; ++k) {
+        for (; k < located; k += step) {
             int status = ST_OK;
             int32_t distance;
             locs[(int64_t)p * loc_cap + k] = fm_locate_hit(ix, s_inv, start, k, distance, status);
@@ -1223,6 +1271,7 @@ static std::atomic<int> g_boundary_group{4};  // lanes per query of extractUntil
 // first fill of extractUntilBoundary's two text windows: 0 = G intervals on each side, a lane walks one after the other;
 // 1 = G / 2 on each side, one walk per lane (measured, slower); 2 = as 0 with a lane's two walks interleaved (fm_lf_step2)
 static std::atomic<int> g_boundary_first_fill{2};
+static std::atomic<int> g_regroup_by_length{1};  // k_count: workgroups with mixed pattern lengths hand their records out again by length (0: A/B)
 static std::atomic<int> g_steps_executed_only{0};  // 1 = d_lf_steps of count() leave out what the suffix table answered
 static std::atomic<int> g_suffix_table_use{1};  // 0 = k_count ignores the index's suffix table (A/B)
 static std::atomic<int> g_lds_pad_kb{0};   // experiment knob: extra dynamic LDS per workgroup (lowers occupancy)
@@ -1259,6 +1308,10 @@ int set_option(const char *name, int value) {
     if (!strcmp(name, "boundary_group")) {
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return -1;
         g_boundary_group = value;
+        return 0;
+    }
+    if (!strcmp(name, "regroup_by_length")) {
+        g_regroup_by_length = value != 0;
         return 0;
     }
     if (!strcmp(name, "lf_steps_executed_only")) {
@@ -1429,7 +1482,7 @@ int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_
     const int bits = (mode == 1 || mode == 2) ? pl.code_bits : plan_code_bits(ix.wt_sigma);
 #define FMX_COUNT_LAUNCH(BLOCK, MODE, BITS)                                                                           \
     hipLaunchKernelGGL((k_count<BLOCK, MODE, BITS>), grid__, dim3(BLOCK), (size_t)g_lds_pad_kb * 1024, st, ix_launch, pat, \
-                       off, recs, n, counts, lf, status, range, pl.look_up, pl.sigma, (int)g_steps_executed_only)
+                       off, recs, n, counts, lf, status, range, pl.look_up, pl.sigma, (int)g_steps_executed_only, (int)g_regroup_by_length)
 #define FMX_COUNT_MODE(MODE)                                                                                       \
     do {                                                                                                           \
         const int blk__ = g_block;                                                                                 \
@@ -1506,8 +1559,8 @@ int launch_locate_walk(const DevIndex &ix, int n_cu, const int32_t *range, int32
         order = ordered;
         order_idle = ticket + 1;
     }
-    FMX_DISPATCH(k_locate_walk, (int64_t)n * slots, ix, range, n, max_matches, locs, loc_cap, slots, found, lf, status, taken,
-                 order, order_idle);
+    FMX_DISPATCH(k_locate_walk, (int64_t)n * (slots < kWalkLanes ? slots : kWalkLanes), ix, range, n, max_matches, locs, loc_cap,
+                 slots, found, lf, status, taken, order, order_idle);
     return (int)hipGetLastError();
 }
 
