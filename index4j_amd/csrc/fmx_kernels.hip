@@ -367,6 +367,33 @@ __device__ __forceinline__ void diag_begin() {}
 __device__ __forceinline__ void diag_end() {}
 #endif
 
+// The records {code word, pattern index (~0: no pattern), length} of a workgroup's lane pairs handed out again by length (k_count):
+// a counting sort in LDS on min(length, 63), longest first.  Both lanes of a pair pass the same record and get the same one
+// back.  A real call (as chunk_refill): inlined, its registers cost the batches of one length — which never get here — 2 %.
+template <int kBlock>
+__device__ __noinline__ Quad regroup_records(uint32_t *s_bin, Quad *s_rec, Quad mine) {
+    const int32_t m = (int32_t)mine.w;
+    const int bin = mine.z == 0xffffffffu ? 0 : (m < 0 ? 0 : (m > 63 ? 63 : m));
+    if (threadIdx.x < 64) s_bin[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t rank_in_bin = 0;
+    if ((threadIdx.x & 1) == 0) rank_in_bin = atomicAdd(&s_bin[bin], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) {  // exclusive scan of the 64 bins by the first wave, the longest patterns first
+        const uint32_t v = s_bin[63 - threadIdx.x];
+        uint32_t incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if ((int)threadIdx.x >= d) incl += t;
+        }
+        s_bin[63 - threadIdx.x] = incl - v;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 1) == 0) s_rec[s_bin[bin] + rank_in_bin] = mine;
+    __syncthreads();
+    return s_rec[threadIdx.x >> 1];
+}
+
 template <int kBlock, int kMode, int kCodeBits>
 FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__ pat,
                                                   const int32_t *__restrict__ pat_off,
@@ -374,7 +401,8 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
                                                   int32_t *__restrict__ counts, int32_t *__restrict__ lf_steps,
                                                   int32_t *__restrict__ status_out, int32_t *__restrict__ range_out,
                                                   const int32_t *__restrict__ plan_look_up, int32_t plan_sigma,
-                                                  int steps_mode, int regroup) {
+                                                  int steps_mode, int regroup, const uint32_t *__restrict__ plan_mixed,
+                                                  uint32_t plan_epoch) {
     // kCodeBits: width of a code in the record's word and in the chunks — 8 when the alphabet fits (8 codes per word),
     // else 16 (the plan's alphabet in modes 1 / 2, this index's own in modes 0 / 3)
     constexpr int kPairs = kBlock / 2;
@@ -436,37 +464,16 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
         // pattern, so a workgroup in which some wave holds different lengths hands its kPairs records out again by length — a
         // counting sort in LDS on min(m, 63) — and every wave gets patterns of (nearly) one length.  Which pair runs which
         // record is free (results go to the pattern's index); the batch's order survives at the workgroup's granularity.
-        // A batch of one length pays one barrier.
-        if (regroup) {
+        // A batch of one length pays one barrier, a PLANNED one not even that (CountPlan.mixed).
+        if (regroup && (!plan_mixed || *plan_mixed == plan_epoch)) {  // (a plan knows whether its batch holds two lengths)
             const bool wave_mixed = __any(live && m != __shfl(m, 0)) != 0;
             if (__syncthreads_or(wave_mixed ? 1 : 0)) {
-                const int pair = (int)(threadIdx.x >> 1);
-                const int bin = !live ? 0 : (m < 0 ? 0 : (m > 63 ? 63 : m));
-                if (threadIdx.x < 64) s_len_bin[threadIdx.x] = 0;
-                __syncthreads();
-                uint32_t rank_in_bin = 0;
-                if (role == 0) rank_in_bin = atomicAdd(&s_len_bin[bin], 1u);
-                __syncthreads();
-                if (threadIdx.x < 64) {  // exclusive scan of the 64 bins by the first wave, LONGEST first
-                    const uint32_t v = s_len_bin[63 - threadIdx.x];
-                    uint32_t incl = v;
-                    for (int d = 1; d < 64; d <<= 1) {
-                        const uint32_t t = __shfl_up(incl, d);
-                        if ((int)threadIdx.x >= d) incl += t;
-                    }
-                    s_len_bin[63 - threadIdx.x] = incl - v;
-                }
-                __syncthreads();
-                if (role == 0) {
-                    Quad r;
-                    r.x = (uint32_t)ck.lo;
-                    r.y = (uint32_t)(ck.lo >> 32);
-                    r.z = live ? (uint32_t)p : 0xffffffffu;
-                    r.w = (uint32_t)m;
-                    s_len_rec[s_len_bin[bin] + rank_in_bin] = r;
-                }
-                __syncthreads();
-                const Quad r = s_len_rec[pair];
+                Quad mine;
+                mine.x = (uint32_t)ck.lo;
+                mine.y = (uint32_t)(ck.lo >> 32);
+                mine.z = live ? (uint32_t)p : 0xffffffffu;
+                mine.w = (uint32_t)m;
+                const Quad r = regroup_records<kBlock>(s_len_bin, s_len_rec, mine);
                 ck.lo = (uint64_t)r.x | ((uint64_t)r.y << 32);
                 p = (int32_t)r.z;
                 m = (int32_t)r.w;
@@ -590,7 +597,7 @@ __global__ __launch_bounds__(256) void k_suffix_order1(DevIndex ix, float *__res
     if (i >= sigma * sigma) return;
     const int x = i / sigma, y = i - x * sigma;
     float f = 0.0f, p = 0.0f;
-    if (x != 0 && y != 0) {
+    if (x != 0 && y != 0 && x + 1 < ix.n_c) {
         int32_t s2 = 0, e2 = 0, back = 0;
         const int32_t cx = ix.C[x], nx = ix.C[x + 1] - cx;
         if (nx > 0 && fm_suffix_lookup(ix, (uint64_t)y | ((uint64_t)x << ix.suffix_key_bits), 2, s2, e2, back) && e2 > s2) {
@@ -875,7 +882,8 @@ template <int kCodeBits>
 __global__ __launch_bounds__(kTileThreads) void k_plan_codes(DevIndex ix, const uint16_t *__restrict__ pat,
                                                              const int32_t *__restrict__ pat_off, int32_t n,
                                                              SortShape sh, PlanRec *__restrict__ recs,
-                                                             uint32_t *__restrict__ ghist) {
+                                                             uint32_t *__restrict__ ghist, uint32_t *__restrict__ mixed,
+                                                             uint32_t epoch) {
     extern __shared__ uint32_t s_hist[];
     __shared__ int16_t s_map[256];
     const int bins = 1 << sh.coarse_bits;
@@ -890,13 +898,15 @@ __global__ __launch_bounds__(kTileThreads) void k_plan_codes(DevIndex ix, const 
     if (o1) {
         const float2 *src = reinterpret_cast<const float2 *>(ix.suffix_order1);
         for (int i = threadIdx.x; i < sigma * sigma; i += kTileThreads) s_o1[i] = src[i];
-        for (int i = threadIdx.x; i <= sigma; i += kTileThreads) s_c[i] = ix.C[i];
+        for (int i = threadIdx.x; i <= sigma; i += kTileThreads) s_c[i] = i < ix.n_c ? ix.C[i] : ix.length;
     }
     __syncthreads();
     // the fine bin of a record: kFineBits key bits ending 8 bits below the coarse bits (or at the key's end)
     const int below = sh.total_bits - sh.coarse_bits;
     const int fine_shift = below > 8 ? below - 8 : 0;
     const int64_t base = (int64_t)blockIdx.x * kTile;
+    const int32_t m_first = pat_off[1] - pat_off[0];  // (n >= 1) the batch is of ONE length if every pattern has this one
+    bool differs = false;
     constexpr int kGroup = kTileItems < 4 ? kTileItems : 4;  // patterns whose loads a thread keeps in flight together
     for (int k0 = 0; k0 < kTileItems; k0 += kGroup) {
         int32_t beg[kGroup], len[kGroup];
@@ -918,6 +928,7 @@ __global__ __launch_bounds__(kTileThreads) void k_plan_codes(DevIndex ix, const 
             const int64_t p = base + (int64_t)(k0 + k) * kTileThreads + threadIdx.x;
             if (p >= n) continue;
             const int32_t m = len[k];
+            differs |= m != m_first;
             uint32_t ch[8];
             pattern_tail_chars(tail[k], pat, beg[k], m, ch);
             const uint64_t word = pattern_code_word<kCodeBits>(ix, s_map, ch, m);
@@ -1008,7 +1019,11 @@ __global__ __launch_bounds__(kTileThreads) void k_plan_codes(DevIndex ix, const 
             atomicAdd(&s_hist[c], 1u);
         }
     }
-    __syncthreads();
+    // (one store per workgroup at most, and none once the word holds the epoch: thousands of stores to one address queue up)
+    if (__syncthreads_or(differs ? 1 : 0) && threadIdx.x == 0) {
+        volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(mixed);
+        if (*flag != epoch) *flag = epoch;
+    }
     for (int i = threadIdx.x; i < bins; i += kTileThreads) {
         const uint32_t v = s_hist[i];
         if (v) atomicAdd(&ghist[i], v);
@@ -1437,16 +1452,19 @@ int launch_count_plan(const DevIndex &ix, const uint16_t *pat, const int32_t *of
     }
     const int tiles = (n + kTile - 1) / kTile;
     const int code_bits = plan_code_bits(ix.wt_sigma);
+    static std::atomic<uint32_t> plan_epoch{0};
+    uint32_t epoch = ++plan_epoch;
+    if (epoch == 0) epoch = ++plan_epoch;  // (0 = the value of a fresh workspace)
     // (the order-1 table and cumulativeCounts behind the histogram: k_plan_codes' `o1`)
     const bool o1 = code_bits == 8 && sh.sa_key == 2 && ix.suffix_order1 && ix.wt_sigma <= kOrder1MaxSigma &&
                     order1_lds_bytes(bins, ix.wt_sigma) <= kPlanCodesLdsMax;
     const size_t lds_codes = o1 ? order1_lds_bytes(bins, ix.wt_sigma) : (size_t)bins * 4;
     if (code_bits == 8)
         hipLaunchKernelGGL(k_plan_codes<8>, dim3(tiles), dim3(kTileThreads), lds_codes, st, ix, pat, off, n, sh, recs,
-                           ghist);
+                           ghist, ticket + 2, epoch);
     else
         hipLaunchKernelGGL(k_plan_codes<16>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 4, st, ix, pat, off, n, sh, recs,
-                           ghist);
+                           ghist, ticket + 2, epoch);
     // (a failed launch here would leave the histogram filled: the caller then clears the workspace's head)
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_plan_scatter<false>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 8, st, recs, nullptr, nullptr, 0, n, bins,
@@ -1455,6 +1473,8 @@ int launch_count_plan(const DevIndex &ix, const uint16_t *pat, const int32_t *of
     if (g_plan_fine == 2 || (g_plan_fine == 1 && !sh.sa_key))
         hipLaunchKernelGGL(k_plan_fine, dim3((n + kFineWindow - 1) / kFineWindow), dim3(kFineThreads), 0, st, ordered, n);
     plan->recs = ordered;
+    plan->mixed = ticket + 2;
+    plan->epoch = epoch;
     plan->n = n;
     plan->code_bits = code_bits;
     plan->shape = sh;
@@ -1482,7 +1502,7 @@ int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_
     const int bits = (mode == 1 || mode == 2) ? pl.code_bits : plan_code_bits(ix.wt_sigma);
 #define FMX_COUNT_LAUNCH(BLOCK, MODE, BITS)                                                                           \
     hipLaunchKernelGGL((k_count<BLOCK, MODE, BITS>), grid__, dim3(BLOCK), (size_t)g_lds_pad_kb * 1024, st, ix_launch, pat, \
-                       off, recs, n, counts, lf, status, range, pl.look_up, pl.sigma, (int)g_steps_executed_only, (int)g_regroup_by_length)
+                       off, recs, n, counts, lf, status, range, pl.look_up, pl.sigma, (int)g_steps_executed_only, (int)g_regroup_by_length, recs ? pl.mixed : nullptr, pl.epoch)
 #define FMX_COUNT_MODE(MODE)                                                                                       \
     do {                                                                                                           \
         const int blk__ = g_block;                                                                                 \

@@ -26,6 +26,10 @@ struct CountPlan {
     // the alphabet the code words are written in (the index the plan was made with): code -> char, alphabet size
     const int32_t *look_up = nullptr;
     int32_t sigma = 0;
+    // *mixed == epoch: the batch holds patterns of different lengths (k_plan_codes stores the plan's epoch there when it sees
+    // two lengths; never reset — the next plan has another epoch).  k_count regroups its workgroups by length only then.
+    const uint32_t *mixed = nullptr;
+    uint32_t epoch = 0;
 };
 
 // head of the plan workspace: histogram, cursors, ticket — all zero between plans (k_plan_scatter restores that)
