@@ -866,6 +866,44 @@ def test_locate_walks_the_hits_by_the_first_row_of_the_ranges_and_nothing_else_c
     fm.close()
 
 
+def test_workgroups_regrouped_by_pattern_length_give_the_same_answers():
+    """Round 4: a k_count workgroup in which some wave holds patterns of different lengths hands its records out again by length
+    (option regroup_by_length; planned batches of ONE length skip the vote: CountPlan.mixed).  Lengths 0 (the reference's AIOOBE),
+    1..70 (beyond the 63 of the sort's last bin, beyond the code word), absent characters, a batch that does not fill its last
+    workgroup; planned and in the caller's order; counts, statuses, LF-steps and located hits against the oracle."""
+    text = ia.synth_log(1 << 20)
+    o = orc.OracleFmIndex(text, 16, True)
+    fm = ia.FmIndex.read(o.write(False), device=0)
+    t16 = ia.as_chars(text)
+    r = random.Random(9)
+    L = ia.lib
+    try:
+        for n, lens in ((20_001, list(range(0, 71))), (20_001, [8]), (777, [3, 9, 30]), (16_500, [8, 8, 8, 8, 9])):
+            pats = [t16[a:a + r.choice(lens)] for a in (r.randrange(len(t16) - 80) for _ in range(n))]
+            for k in range(0, n, 53):
+                if len(pats[k]):
+                    pats[k] = pats[k].copy()
+                    pats[k][r.randrange(len(pats[k]))] = 7
+            ch, off = ia.pack_patterns(pats)
+            oc, ost = o.count_batch(ch, off, threads=8)
+            want = o.locate_batch(ch, off, 3, threads=8)
+            for regroup in (1, 0):
+                for sort_min in (16384, 1 << 30):  # planned (the suite forces plans from sort_min on) / the caller's order
+                    assert L.fmx_set_option(b"regroup_by_length", regroup) == 0 and L.fmx_set_option(b"sort_min", sort_min) == 0
+                    cnt, st, lf = fm.count_batch(ch, off, want_steps=True)
+                    assert (cnt == oc).all() and (st == ost).all(), (n, lens, regroup, sort_min)
+                    if regroup == 1 and sort_min == 16384:
+                        lf_ref = lf
+                    assert (lf == lf_ref).all()
+                    locs, found, st2 = fm.locate_batch(ch, off, 3)
+                    live = np.arange(3)[None, :] < want[1][:, None]
+                    assert (found == want[1]).all() and (st2 == want[2]).all() and (locs[live] == want[0][live]).all()
+    finally:
+        L.fmx_set_option(b"regroup_by_length", 1)
+        L.fmx_set_option(b"sort_min", 16384)
+    fm.close()
+
+
 def test_api_edge_cases():
     """empty batches, zero-capacity buffers and bad arguments through the C ABI: no kernel launch with bad shapes,
     library-level error codes instead"""
