@@ -1276,18 +1276,19 @@ static int locate_segments_impl(const fmx_index *const *segs, int32_t n_segs, co
     fmx::CountPlan plan;
     int rc = plan_order(segs[0], d_pat, d_pat_off, n, scratch, &plan);
     if (rc) return rc;
+    // (the walk order's scratch belongs to the set's first index, like the plan's: ONE block for all segments — the size only
+    // depends on n)
+    void *ws = nullptr;
+    const size_t ws_bytes = k_walk_workspace_bytes(segs[0], segs[0]->dev, n);
+    rc = scratch.get(kWsWalk, ws_bytes, &ws);
+    if (rc) return rc;
     for (int32_t s = 0; s < n_segs; ++s) {
         int e = k_launch_count(segs[s], segs[s]->dev, segs[s]->n_cu, d_pat, d_pat_off, &plan, s != 0, n, seg_found, nullptr,
                                   seg_status, range, st);
         if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
         // like the caller's loop `n += seg.locate(p, 0, len, locations, maxMatches - n)`: hits already
         // taken from earlier segments shrink this segment's limit
-        // (the walk order's scratch belongs to the set's first index, like the plan's: one workspace per stream)
         {
-            void *ws = nullptr;
-            const size_t ws_bytes = k_walk_workspace_bytes(segs[s], segs[s]->dev, n);
-            rc = scratch.get(kWsWalk, ws_bytes, &ws);
-            if (rc) return rc;
             e = k_launch_locate_walk(segs[s], segs[s]->dev, segs[s]->n_cu, range, n, max_matches, seg_locs, max_matches,
                                      seg_found, nullptr, seg_status, s ? d_found : nullptr, ws, ws_bytes, !scratch.per_call, st);
             if (e) {
