@@ -141,6 +141,7 @@ std::atomic<int> g_suffix_table_in_use{1};  // mirror of the kernels' A/B option
 std::atomic<int> g_suffix_table_image_fraction{8};  // option "suffix_table_image_fraction": the table stays below image / this (0 = only the budget counts)
 // host-buffer count(): batches of at least this many patterns go through the pipeline (smaller ones: one copy in, kernels, one copy out)
 std::atomic<int> g_host_pipeline_min{131072};
+std::atomic<int> g_host_direct_stores{1};  // option "host_direct_stores": the pipeline's kernels store results straight into registered arrays
 std::atomic<int> g_host_pipeline_chunk{262144};  // patterns per stage of that pipeline
 std::atomic<int> g_sb_cache_limit{320};  // option "sb_cache_limit": applies to indexes made resident afterwards (tests: 0 = no LDS cache)
 int fail(int code, const std::string &msg) {
@@ -517,6 +518,10 @@ int fmx_set_option(const char *name, int value) {
     if (name && !strcmp(name, "suffix_table_mb")) {  // budget for the suffix table of indexes made resident from now on
         if (value < 0 || value > (1 << 16)) return fail(FMX_E_ARG, "bad value");
         g_suffix_table_mb = value;
+        return FMX_OK;
+    }
+    if (name && !strcmp(name, "host_direct_stores")) {
+        g_host_direct_stores = value != 0;
         return FMX_OK;
     }
     if (name && !strcmp(name, "host_pipeline_min")) {  // host-buffer count(): batches at least this large are pipelined (0 = never)
@@ -1425,10 +1430,27 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
     PinBuf h_cnt, h_lf, h_st;
     HIP_TRY(d_pat.alloc((size_t)total_chars * 2 + 8));
     HIP_TRY(d_off.alloc(((size_t)n + 1 + (size_t)n_chunks) * 4));  // every chunk its own run of offsets (n_c + 1 entries)
-    HIP_TRY(d_cnt.alloc((size_t)n * 4));
-    if (lf_steps) HIP_TRY(d_lf.alloc((size_t)n * 4));
-    if (status) HIP_TRY(d_st.alloc((size_t)n * 4));
     int32_t *o_cnt = counts, *o_lf = lf_steps, *o_st = status;  // where the D2H copies land
+    // Registered result arrays are mapped into the device's address space: k_count then STORES counts, statuses and LF-steps
+    // straight into them (a chunk of the pipeline is counted in the caller's order, so a wave's stores are consecutive words:
+    // whole PCIe writes) — no result copies at all, which also leaves the link's other direction to the characters coming in.
+    int32_t *m_cnt = nullptr, *m_lf = nullptr, *m_st = nullptr;
+    bool stores_out = false;
+    if (direct_out && g_host_direct_stores.load()) {
+        void *a = nullptr, *b = nullptr, *c = nullptr;
+        stores_out = hipHostGetDevicePointer(&a, counts, 0) == hipSuccess &&
+                     (!lf_steps || hipHostGetDevicePointer(&b, lf_steps, 0) == hipSuccess) &&
+                     (!status || hipHostGetDevicePointer(&c, status, 0) == hipSuccess);
+        if (!stores_out) (void)hipGetLastError();
+        m_cnt = static_cast<int32_t *>(a);
+        m_lf = static_cast<int32_t *>(b);
+        m_st = static_cast<int32_t *>(c);
+    }
+    if (!stores_out) {
+        HIP_TRY(d_cnt.alloc((size_t)n * 4));
+        if (lf_steps) HIP_TRY(d_lf.alloc((size_t)n * 4));
+        if (status) HIP_TRY(d_st.alloc((size_t)n * 4));
+    }
     if (!direct_out) {
         HIP_TRY(h_cnt.alloc((size_t)n * 4));
         o_cnt = h_cnt.as<int32_t>();
@@ -1584,14 +1606,28 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
         t_in += now() - t0;
         t0 = now();
         scratches.emplace_back(new Scratch(idx, s_k, true));
-        rc = count_impl(idx, d_pat.as<uint16_t>(), d_off_c, n_c, d_cnt.as<int32_t>() + lo, lf_steps ? d_lf.as<int32_t>() + lo : nullptr,
-                        status ? d_st.as<int32_t>() + lo : nullptr, *scratches.back());
+        if (stores_out)
+            rc = count_impl(idx, d_pat.as<uint16_t>(), d_off_c, n_c, m_cnt + lo, lf_steps ? m_lf + lo : nullptr, status ? m_st + lo : nullptr,
+                            *scratches.back());
+        else
+            rc = count_impl(idx, d_pat.as<uint16_t>(), d_off_c, n_c, d_cnt.as<int32_t>() + lo, lf_steps ? d_lf.as<int32_t>() + lo : nullptr,
+                            status ? d_st.as<int32_t>() + lo : nullptr, *scratches.back());
         if (rc) {
             failed = rc;
             break;
         }
         t_launch += now() - t0;
         t0 = now();
+        if (stores_out) {  // the chunk's results are in the caller's arrays when its kernel has ended
+            e = hipEventRecord(ps->done[slot], s_k);
+            if (e != hipSuccess) {
+                failed = fail(FMX_E_HIP, std::string("host-buffer pipeline, results: ") + hipGetErrorString(e));
+                break;
+            }
+            issued.store(c + 1, std::memory_order_release);
+            t_out += now() - t0;
+            continue;
+        }
         e = hipEventRecord(ps->counted[slot], s_k);
         if (e == hipSuccess) e = hipStreamWaitEvent(s_out, ps->counted[slot], 0);
         if (e == hipSuccess) e = hipMemcpyAsync(o_cnt + lo, d_cnt.as<int32_t>() + lo, (size_t)n_c * 4, hipMemcpyDeviceToHost, s_out);

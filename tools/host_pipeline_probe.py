@@ -10,6 +10,8 @@ fm = ia.FmIndex(text, 32, True, device=0, build_device=0)
 n = 1 << 20
 if os.environ.get("FMX_CHUNK"):
     assert ia.lib.fmx_set_option(b"host_pipeline_chunk", int(os.environ["FMX_CHUNK"])) == 0
+if os.environ.get("FMX_DIRECT"):
+    assert ia.lib.fmx_set_option(b"host_direct_stores", int(os.environ["FMX_DIRECT"])) == 0
 pat, off, pos = workload.count_batch_patterns(text, n, 8)
 counts = np.zeros(n, np.int32); status = np.zeros(n, np.int32)
 def call():
@@ -20,3 +22,6 @@ def call():
 print("pageable  ", " ".join("%.3f" % call() for _ in range(12)), file=sys.stderr)
 for a in (pat, off, counts, status): ia.lib.fmx_host_register(a.ctypes.data, a.nbytes)
 print("registered", " ".join("%.3f" % call() for _ in range(12)), file=sys.stderr)
+ref, _ = fm.count_batch(pat, off)
+assert (ref == counts).all() and (status == 0).all()
+print("results equal", file=sys.stderr)
