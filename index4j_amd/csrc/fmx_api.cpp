@@ -141,6 +141,7 @@ std::atomic<int> g_suffix_table_in_use{1};  // mirror of the kernels' A/B option
 std::atomic<int> g_suffix_table_image_fraction{8};  // option "suffix_table_image_fraction": the table stays below image / this (0 = only the budget counts)
 // host-buffer count(): batches of at least this many patterns go through the pipeline (smaller ones: one copy in, kernels, one copy out)
 std::atomic<int> g_host_pipeline_min{131072};
+std::atomic<int> g_host_mapped{1};  // option "host_mapped": every array of a host-buffer count registered -> one launch over the mapped arrays, no copies
 std::atomic<int> g_host_direct_stores{1};  // option "host_direct_stores": the pipeline's kernels store results straight into registered arrays
 std::atomic<int> g_host_pipeline_chunk{262144};  // patterns per stage of that pipeline
 std::atomic<int> g_sb_cache_limit{320};  // option "sb_cache_limit": applies to indexes made resident afterwards (tests: 0 = no LDS cache)
@@ -518,6 +519,10 @@ int fmx_set_option(const char *name, int value) {
     if (name && !strcmp(name, "suffix_table_mb")) {  // budget for the suffix table of indexes made resident from now on
         if (value < 0 || value > (1 << 16)) return fail(FMX_E_ARG, "bad value");
         g_suffix_table_mb = value;
+        return FMX_OK;
+    }
+    if (name && !strcmp(name, "host_mapped")) {
+        g_host_mapped = value != 0;
         return FMX_OK;
     }
     if (name && !strcmp(name, "host_direct_stores")) {
@@ -1040,14 +1045,21 @@ int fmx_count_ordered_dev(const fmx_index *idx, const uint16_t *d_pat, const int
     });
 }
 
+// allow_plan = false: the batch is counted in the caller's order whatever the policy says (the mapped host-buffer path: a plan
+// would read the characters over PCIe in one kernel and leave the counting to the next — nothing would overlap)
 static int count_impl(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n, int32_t *d_counts,
-                      int32_t *d_lf_steps, int32_t *d_status, Scratch &scratch) {
+                      int32_t *d_lf_steps, int32_t *d_status, Scratch &scratch, bool allow_plan = true) {
     int rc = require_device(idx);
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!d_pat_off || !d_counts))) return fail(FMX_E_ARG, "bad arguments");
     fmx::CountPlan plan;
-    rc = plan_order(idx, d_pat, d_pat_off, n, scratch, &plan);
-    if (rc) return rc;
+    if (allow_plan) {
+        rc = plan_order(idx, d_pat, d_pat_off, n, scratch, &plan);
+        if (rc) return rc;
+    } else if (!scratch.per_call) {
+        std::lock_guard<std::mutex> lock(idx->ws_mutex);
+        idx->plans.erase(scratch.stream);
+    }
     int e = k_launch_count(idx, idx->dev, idx->n_cu, d_pat, d_pat_off, &plan, false, n, d_counts, d_lf_steps, d_status,
                               nullptr, static_cast<hipStream_t>(scratch.stream));
     if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
@@ -1406,6 +1418,50 @@ static bool is_pinned(const void *p) {
     return a.type == hipMemoryTypeHost;
 }
 
+// fmx_count_batch with EVERY array registered (option "host_mapped", default 1): no copies at all — k_count reads the characters
+// (and the offsets, unless the patterns are of one length: those offsets are made on the device) from the caller's mapped arrays
+// and stores its results into them; the launch streams the batch over PCIe while it counts.  Returns -1 if the arrays are not
+// all mapped (the caller then takes the pipeline).
+static int count_batch_mapped(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n, int32_t *counts,
+                              int32_t *lf_steps, int32_t *status) {
+    void *m_pat = nullptr, *m_off = nullptr, *m_cnt = nullptr, *m_lf = nullptr, *m_st = nullptr;
+    const bool mapped = hipHostGetDevicePointer(&m_pat, const_cast<uint16_t *>(pat), 0) == hipSuccess &&
+                        hipHostGetDevicePointer(&m_off, const_cast<int32_t *>(pat_off), 0) == hipSuccess &&
+                        hipHostGetDevicePointer(&m_cnt, counts, 0) == hipSuccess &&
+                        (!lf_steps || hipHostGetDevicePointer(&m_lf, lf_steps, 0) == hipSuccess) &&
+                        (!status || hipHostGetDevicePointer(&m_st, status, 0) == hipSuccess);
+    if (!mapped) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    const int64_t total_chars = pat_off[n];
+    bool uniform = false;
+    if (pat_off[0] < 0 || total_chars < pat_off[0] || !scan_offsets(pat_off, 0, n, total_chars, &uniform))
+        return fail(FMX_E_ARG, "pattern offsets decrease or leave the batch");
+    PipeStreams *ps = nullptr;
+    int rc = pipe_streams(idx->device, &ps);
+    if (rc) return rc;
+    hipStream_t st = ps->s[1];
+    // ONE launch for the whole batch (in chunks — the host's pass over the offsets of chunk c + 1 beside the kernel of chunk c —
+    // it was slower: 0.525 ms in four launches, 0.482 in two, 0.455 in one; a kernel that is fed over the link wants every
+    // wave of the chip asking at once)
+    DevBuf d_off;
+    const int32_t *offsets = static_cast<const int32_t *>(m_off);
+    if (uniform) {
+        HIP_TRY(d_off.alloc(((size_t)n + 1) * 4));
+        if (int e = fmx::launch_fill_offsets(d_off.as<int32_t>(), pat_off[0], pat_off[1] - pat_off[0], n + 1, st))
+            return fail(FMX_E_HIP, std::string("offsets: ") + hipGetErrorString((hipError_t)e));
+        offsets = d_off.as<int32_t>();
+    }
+    Scratch scratch(idx, st, true);
+    rc = count_impl(idx, static_cast<const uint16_t *>(m_pat), offsets, n, static_cast<int32_t *>(m_cnt), static_cast<int32_t *>(m_lf),
+                    static_cast<int32_t *>(m_st), scratch, false);
+    const hipError_t e = hipStreamSynchronize(st);  // (also on failure: the per-call blocks go back to the cache below)
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(FMX_E_HIP, std::string("mapped count: ") + hipGetErrorString(e));
+    return FMX_OK;
+}
+
 // fmx_count_batch for large batches — what a JNI binding's count(char[][]) costs is PCIe, not the kernels: the batch goes
 // to the GPU in chunks, chunk c's transfer overlapping the kernels of chunk c - 1 and the return of chunk c - 2 (three streams); offsets of equal-length
 // runs are made on the device instead of being shipped; the offsets are validated chunk by chunk on the way (the same
@@ -1672,7 +1728,13 @@ int fmx_count_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pa
     HIP_TRY(hipSetDevice(idx->device));
     {
         const int pipe_min = g_host_pipeline_min;
-        if (pipe_min > 0 && n >= pipe_min) return count_batch_pipelined(idx, pat, pat_off, n, counts, lf_steps, status);
+        if (pipe_min > 0 && n >= pipe_min) {
+            if (g_host_mapped.load()) {
+                const int r = count_batch_mapped(idx, pat, pat_off, n, counts, lf_steps, status);
+                if (r != -1) return r;
+            }
+            return count_batch_pipelined(idx, pat, pat_off, n, counts, lf_steps, status);
+        }
     }
     rc = check_offsets(pat_off, n);
     if (rc) return rc;

@@ -180,7 +180,8 @@ def test_attach_rejects_damaged_images():
 
 def test_pipelined_host_buffer_count_from_threads_with_plain_and_registered_arrays():
     """fmx_count_batch above host_pipeline_min patterns travels in chunks (feeder thread, three streams, results through
-    pinned staging or straight into registered arrays): same counts, statuses and LF-steps as the oracle — from several
+    pinned staging or straight into registered arrays) — or, with every array registered, not at all: one launch reads and writes
+    the caller's mapped arrays: same counts, statuses and LF-steps as the oracle — from several
     host threads at once, patterns of 8..31 characters (offsets shipped) and of one length (offsets made on the device),
     pageable and registered (fmx_host_register) arrays; offsets that run backwards are refused before anything is launched"""
     from index4j_amd import workload
@@ -222,12 +223,20 @@ def test_pipelined_host_buffer_count_from_threads_with_plain_and_registered_arra
         except Exception as e:  # noqa: BLE001
             errors.append((k, registered, repr(e)))
 
-    threads = [threading.Thread(target=run, args=(k, k >= 2)) for k in range(4)]
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    assert not errors, errors
+    # registered arrays: one launch over the mapped arrays (option host_mapped, the default), then the chunk pipeline with the
+    # kernels storing straight into the registered result arrays (host_direct_stores), then with result copies
+    try:
+        for mapped, direct in ((1, 1), (0, 1), (0, 0)):
+            assert ia.lib.fmx_set_option(b"host_mapped", mapped) == 0 and ia.lib.fmx_set_option(b"host_direct_stores", direct) == 0
+            threads = [threading.Thread(target=run, args=(k, k >= 2)) for k in range(4)]
+            for th in threads:
+                th.start()
+            for th in threads:
+                th.join()
+            assert not errors, (mapped, direct, errors)
+    finally:
+        ia.lib.fmx_set_option(b"host_mapped", 1)
+        ia.lib.fmx_set_option(b"host_direct_stores", 1)
     # the unpipelined path (option) gives the same
     ia.lib.fmx_set_option(b"host_pipeline_min", 0)
     try:
@@ -250,4 +259,15 @@ def test_pipelined_host_buffer_count_from_threads_with_plain_and_registered_arra
     wrap[280_002] = -2_000_000_000
     rc = ia.lib.fmx_count_batch(fm.handle, work[1][0].ctypes.data, wrap.ctypes.data, n, cnt.ctypes.data, None, None)
     assert rc == -1 and b"offsets" in ia.lib.fmx_last_error()
+    # ... and by the mapped path (every array registered): refused before the launch reads a character
+    arrays = (work[1][0], wrap, bad, cnt)
+    for a in arrays:
+        assert ia.lib.fmx_host_register(a.ctypes.data, a.nbytes) == 0
+    try:
+        for b in (wrap, bad):
+            rc = ia.lib.fmx_count_batch(fm.handle, work[1][0].ctypes.data, b.ctypes.data, n, cnt.ctypes.data, None, None)
+            assert rc == -1 and b"offsets" in ia.lib.fmx_last_error()
+    finally:
+        for a in arrays:
+            ia.lib.fmx_host_unregister(a.ctypes.data)
     fm.close()

@@ -10,6 +10,8 @@ fm = ia.FmIndex(text, 32, True, device=0, build_device=0)
 n = 1 << 20
 if os.environ.get("FMX_CHUNK"):
     assert ia.lib.fmx_set_option(b"host_pipeline_chunk", int(os.environ["FMX_CHUNK"])) == 0
+if os.environ.get("FMX_MAPPED"):
+    assert ia.lib.fmx_set_option(b"host_mapped", int(os.environ["FMX_MAPPED"])) == 0
 if os.environ.get("FMX_DIRECT"):
     assert ia.lib.fmx_set_option(b"host_direct_stores", int(os.environ["FMX_DIRECT"])) == 0
 pat, off, pos = workload.count_batch_patterns(text, n, 8)
