@@ -1773,28 +1773,47 @@ int fmx_locate_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *p
     const size_t chars = (size_t)(pat_off[n] > 0 ? pat_off[n] : 0);
     const size_t loc_bytes = (size_t)n * (size_t)loc_cap * 4;
     DevBuf d_pat, d_off, d_locs, d_found, d_lf, d_st, d_ws;
-    HIP_TRY(d_pat.alloc(chars * 2 + 8));
+    // Registered `locations` / pattern arrays (fmx_host_register) are mapped into the device's address space: k_locate_walk then
+    // stores the hits straight into the caller's rows — only the slots it fills travel, and they travel once (the array is in /
+    // out, FM:504: unmapped it goes up and comes down whole) — and k_count reads the characters where they are.
+    // found / LF-steps / statuses stay in HBM: the kernels update them with atomics.
+    void *m_locs = nullptr, *m_pat = nullptr;
+    const bool mapped_ok = g_host_mapped.load() != 0;
+    const bool locs_mapped = mapped_ok && loc_bytes && hipHostGetDevicePointer(&m_locs, locs, 0) == hipSuccess;
+    const bool pat_mapped = mapped_ok && chars && hipHostGetDevicePointer(&m_pat, const_cast<uint16_t *>(pat), 0) == hipSuccess;
+    if (!locs_mapped || !pat_mapped) (void)hipGetLastError();
+    if (!pat_mapped) HIP_TRY(d_pat.alloc(chars * 2 + 8));
     HIP_TRY(d_off.alloc((size_t)(n + 1) * 4));
-    HIP_TRY(d_locs.alloc(loc_bytes));
+    if (!locs_mapped) HIP_TRY(d_locs.alloc(loc_bytes));
     HIP_TRY(d_found.alloc((size_t)n * 4));
-    HIP_TRY(d_lf.alloc((size_t)n * 4));
-    HIP_TRY(d_st.alloc((size_t)n * 4));
+    if (lf_steps) HIP_TRY(d_lf.alloc((size_t)n * 4));
+    if (status) HIP_TRY(d_st.alloc((size_t)n * 4));
     HIP_TRY(d_ws.alloc((size_t)n * 8));
-    if (chars) H2D(d_pat.p, pat, chars * 2);
-    H2D(d_off.p, pat_off, (size_t)(n + 1) * 4);
-    // `locations` is in/out (FM:504: the caller's array; slots beyond the hits keep the caller's values): it travels up and
-    // down whole.  (Bringing the rows back through pinned staging and copying found[i] slots per row instead was measured
-    // slower — 1.23 vs 1.05 ms on configs[2]: profiles/r03_experiments.txt §12.)
-    if (loc_bytes) H2D(d_locs.p, locs, loc_bytes);
-    Scratch scratch(idx, nullptr, true);
-    rc = locate_impl(idx, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, max_matches, d_locs.as<int32_t>(), loc_cap,
-                     d_found.as<int32_t>(), d_lf.as<int32_t>(), d_st.as<int32_t>(), d_ws.as<int32_t>(), scratch);
-    HIP_TRY(hipDeviceSynchronize());
+    // one stream, one wait: the small arrays go by asynchronous copies (DMA when the caller registered them, staged otherwise)
+    PipeStreams *ps = nullptr;
+    rc = pipe_streams(idx->device, &ps);
     if (rc) return rc;
-    if (loc_bytes) D2H(locs, d_locs.p, loc_bytes);
-    D2H(found, d_found.p, (size_t)n * 4);
-    if (lf_steps) D2H(lf_steps, d_lf.p, (size_t)n * 4);
-    if (status) D2H(status, d_st.p, (size_t)n * 4);
+    hipStream_t st = ps->s[1];
+    Scratch scratch(idx, st, true);
+    struct SyncOnExit {  // whatever leaves this function first waits for the stream, THEN the per-call blocks (declared above)
+        hipStream_t s;   // return to their cache
+        ~SyncOnExit() { (void)hipStreamSynchronize(s); }
+    } sync_on_exit{st};
+    if (chars && !pat_mapped) HIP_TRY(hipMemcpyAsync(d_pat.p, pat, chars * 2, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_off.p, pat_off, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
+    // `locations` is in/out (FM:504: the caller's array; slots beyond the hits keep the caller's values): unmapped it travels up
+    // and down whole.  (Bringing the rows back through pinned staging and copying found[i] slots per row instead was measured
+    // slower — 1.23 vs 1.05 ms on configs[2]: profiles/r03_experiments.txt §12.)
+    if (loc_bytes && !locs_mapped) HIP_TRY(hipMemcpyAsync(d_locs.p, locs, loc_bytes, hipMemcpyHostToDevice, st));
+    rc = locate_impl(idx, pat_mapped ? static_cast<const uint16_t *>(m_pat) : d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, max_matches,
+                     locs_mapped ? static_cast<int32_t *>(m_locs) : d_locs.as<int32_t>(), loc_cap, d_found.as<int32_t>(),
+                     lf_steps ? d_lf.as<int32_t>() : nullptr, status ? d_st.as<int32_t>() : nullptr, d_ws.as<int32_t>(), scratch);
+    if (rc) return rc;
+    if (loc_bytes && !locs_mapped) HIP_TRY(hipMemcpyAsync(locs, d_locs.p, loc_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(found, d_found.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    if (lf_steps) HIP_TRY(hipMemcpyAsync(lf_steps, d_lf.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    if (status) HIP_TRY(hipMemcpyAsync(status, d_st.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return FMX_OK;
     });
 }
@@ -1880,6 +1899,80 @@ int fmx_locate_lines_batch(const fmx_index *idx, const uint16_t *pat, const int3
     });
 }
 
+// Host-buffer extract / extractUntilBoundary: destination rows are in/out (entries the walk does not write keep the caller's
+// values — FM:564, FM:640: the caller's array), so they travel up AND down whole, and they are what such a call costs (100,000
+// rows of 1,024 chars: 195 MB each way).  The queries go in a few chunks over three streams — rows of chunk c + 1 on their way
+// up, the kernels of chunk c, rows of chunk c - 1 on their way down — with asynchronous copies (DMA at the link's rate for
+// arrays the caller registered, staged otherwise) and ONE wait at the end.  launch(lo, n_c, stream): the chunk's kernels.
+extern "C++" {
+struct HostColumn {  // one int32 per query
+    const void *in;  // caller's array to ship up (nullptr: none)
+    void *out;       // caller's array to bring down (nullptr: none)
+    DevBuf *dev;
+};
+template <class Launch>
+static int rows_pipeline_host(const fmx_index *idx, int32_t n, uint16_t *dst, int32_t dst_len, DevBuf &d_dst,
+                              std::initializer_list<HostColumn> columns, Launch &&launch) {
+    PipeStreams *ps = nullptr;
+    int rc = pipe_streams(idx->device, &ps);
+    if (rc) return rc;
+    hipStream_t s_in = ps->s[0], s_k = ps->s[1], s_out = ps->s[2];
+    struct DrainOnExit {  // (declared after the caller's buffers: whatever leaves first waits for the streams)
+        PipeStreams *ps;
+        ~DrainOnExit() {
+            for (int i = 0; i < kPipeStreams; ++i) (void)hipStreamSynchronize(ps->s[i]);
+        }
+    } drain_on_exit{ps};
+    const size_t row_bytes = (size_t)dst_len * 2;
+    if (row_bytes && !is_pinned(dst)) {
+        // pageable rows: the plain copies (from pageable memory they run at twice the rate of the asynchronous ones), one launch
+        for (const HostColumn &col : columns)
+            if (col.in) HIP_TRY(hipMemcpy(col.dev->p, col.in, (size_t)n * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_dst.p, dst, (size_t)n * row_bytes, hipMemcpyHostToDevice));
+        rc = launch(0, n, s_k);
+        HIP_TRY(hipStreamSynchronize(s_k));
+        if (rc) return rc;
+        HIP_TRY(hipMemcpy(dst, d_dst.p, (size_t)n * row_bytes, hipMemcpyDeviceToHost));
+        for (const HostColumn &col : columns)
+            if (col.out) HIP_TRY(hipMemcpy(col.out, col.dev->p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        return FMX_OK;
+    }
+    // (registered rows brought DOWN by a copy kernel into the mapped array, so that the two directions would not share the DMA
+    // engine: 10.8 ms against 10.2 with DMA both ways for 2 x 195 MB — what limits is the rate of DMA to and from REGISTERED
+    // pageable memory, scattered 4 KB pages; profiles/r04_experiments.txt 16)
+    // chunks of at least 4 MB of rows and 8,192 queries, at most 8 of them
+    int64_t chunk = ((int64_t)n + 7) / 8;
+    const int64_t min_rows = row_bytes ? (int64_t)(((size_t)4 << 20) / row_bytes) + 1 : n;
+    chunk = std::max<int64_t>(chunk, std::max<int64_t>(8192, min_rows));
+    int c = 0;
+    for (int64_t lo = 0; lo < n; lo += chunk, ++c) {
+        const int32_t n_c = (int32_t)std::min<int64_t>(chunk, (int64_t)n - lo);
+        for (const HostColumn &col : columns)
+            if (col.in)
+                HIP_TRY(hipMemcpyAsync(col.dev->as<int32_t>() + lo, static_cast<const int32_t *>(col.in) + lo, (size_t)n_c * 4,
+                                       hipMemcpyHostToDevice, s_in));
+        if (row_bytes)
+            HIP_TRY(hipMemcpyAsync(d_dst.as<uint16_t>() + lo * dst_len, dst + lo * dst_len, (size_t)n_c * row_bytes, hipMemcpyHostToDevice,
+                                   s_in));
+        HIP_TRY(hipEventRecord(ps->in[c], s_in));
+        HIP_TRY(hipStreamWaitEvent(s_k, ps->in[c], 0));
+        rc = launch((int32_t)lo, n_c, s_k);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(ps->counted[c], s_k));
+        HIP_TRY(hipStreamWaitEvent(s_out, ps->counted[c], 0));
+        if (row_bytes)
+            HIP_TRY(hipMemcpyAsync(dst + lo * dst_len, d_dst.as<uint16_t>() + lo * dst_len, (size_t)n_c * row_bytes, hipMemcpyDeviceToHost,
+                                   s_out));
+        for (const HostColumn &col : columns)
+            if (col.out)
+                HIP_TRY(hipMemcpyAsync(static_cast<int32_t *>(col.out) + lo, col.dev->as<int32_t>() + lo, (size_t)n_c * 4,
+                                       hipMemcpyDeviceToHost, s_out));
+    }
+    for (int i = 0; i < kPipeStreams; ++i) HIP_TRY(hipStreamSynchronize(ps->s[i]));
+    return FMX_OK;
+}
+}  // extern "C++"
+
 int fmx_extract_batch(const fmx_index *idx, const int32_t *start, const int32_t *stop, int32_t n, uint16_t *dst,
                       int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf_steps, int32_t *status) {
     return guarded([&]() -> int {
@@ -1897,18 +1990,14 @@ int fmx_extract_batch(const fmx_index *idx, const int32_t *start, const int32_t 
     HIP_TRY(d_len.alloc((size_t)n * 4));
     HIP_TRY(d_lf.alloc((size_t)n * 4));
     HIP_TRY(d_st.alloc((size_t)n * 4));
-    H2D(d_a.p, start, (size_t)n * 4);
-    H2D(d_b.p, stop, (size_t)n * 4);
-    if (dst_bytes) H2D(d_dst.p, dst, dst_bytes);  // destination arrays are in/out
-    rc = fmx_extract_batch_dev(idx, d_a.as<int32_t>(), d_b.as<int32_t>(), n, d_dst.as<uint16_t>(), dst_len, offset,
-                               d_len.as<int32_t>(), d_lf.as<int32_t>(), d_st.as<int32_t>(), nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    if (dst_bytes) D2H(dst, d_dst.p, dst_bytes);
-    D2H(out_len, d_len.p, (size_t)n * 4);
-    if (lf_steps) D2H(lf_steps, d_lf.p, (size_t)n * 4);
-    if (status) D2H(status, d_st.p, (size_t)n * 4);
-    return FMX_OK;
+    return rows_pipeline_host(idx, n, dst, dst_len, d_dst,
+                              {{start, nullptr, &d_a}, {stop, nullptr, &d_b}, {nullptr, out_len, &d_len}, {nullptr, lf_steps, &d_lf},
+                               {nullptr, status, &d_st}},
+                              [&](int32_t lo, int32_t n_c, hipStream_t st) {
+                                  return fmx_extract_batch_dev(idx, d_a.as<int32_t>() + lo, d_b.as<int32_t>() + lo, n_c,
+                                                               d_dst.as<uint16_t>() + (int64_t)lo * dst_len, dst_len, offset,
+                                                               d_len.as<int32_t>() + lo, d_lf.as<int32_t>() + lo, d_st.as<int32_t>() + lo, st);
+                              });
     });
 }
 
@@ -1930,19 +2019,17 @@ int fmx_extract_boundary_batch(const fmx_index *idx, const int32_t *from, int32_
     HIP_TRY(d_lf.alloc((size_t)n * 4));
     HIP_TRY(d_st.alloc((size_t)n * 4));
     HIP_TRY(d_aux.alloc((size_t)n * 4));
-    H2D(d_a.p, from, (size_t)n * 4);
-    if (dst_bytes) H2D(d_dst.p, dst, dst_bytes);
-    Scratch scratch(idx, nullptr, true);
-    rc = boundary_impl(idx, d_a.as<int32_t>(), n, boundary, mode, d_dst.as<uint16_t>(), dst_len, offset, d_len.as<int32_t>(),
-                       d_lf.as<int32_t>(), d_st.as<int32_t>(), d_aux.as<int32_t>(), nullptr, 0, scratch);
-    HIP_TRY(hipDeviceSynchronize());
-    if (rc) return rc;
-    if (dst_bytes) D2H(dst, d_dst.p, dst_bytes);
-    D2H(out_len, d_len.p, (size_t)n * 4);
-    if (lf_steps) D2H(lf_steps, d_lf.p, (size_t)n * 4);
-    if (status) D2H(status, d_st.p, (size_t)n * 4);
-    if (aux) D2H(aux, d_aux.p, (size_t)n * 4);
-    return FMX_OK;
+    std::vector<std::unique_ptr<Scratch>> scratches;  // (a chunk's window scratch lives until the call has drained)
+    return rows_pipeline_host(idx, n, dst, dst_len, d_dst,
+                              {{from, nullptr, &d_a}, {nullptr, out_len, &d_len}, {nullptr, lf_steps, &d_lf}, {nullptr, status, &d_st},
+                               {nullptr, aux, &d_aux}},
+                              [&](int32_t lo, int32_t n_c, hipStream_t st) {
+                                  scratches.emplace_back(new Scratch(idx, st, true));
+                                  return boundary_impl(idx, d_a.as<int32_t>() + lo, n_c, boundary, mode,
+                                                       d_dst.as<uint16_t>() + (int64_t)lo * dst_len, dst_len, offset, d_len.as<int32_t>() + lo,
+                                                       d_lf.as<int32_t>() + lo, d_st.as<int32_t>() + lo, d_aux.as<int32_t>() + lo, nullptr, 0,
+                                                       *scratches.back());
+                              });
     });
 }
 

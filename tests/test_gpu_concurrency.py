@@ -271,3 +271,79 @@ def test_pipelined_host_buffer_count_from_threads_with_plain_and_registered_arra
         for a in arrays:
             ia.lib.fmx_host_unregister(a.ctypes.data)
     fm.close()
+
+
+def test_host_entry_points_with_registered_arrays_give_the_same_rows():
+    """Round 4: fmx_locate_batch stores its hits straight into a registered `locations` array (only the slots it fills travel) and
+    reads registered patterns in place; fmx_extract_batch / fmx_extract_boundary_batch move registered destination rows in chunks
+    over three streams.  Same results as with plain arrays and as the oracle, entries the walks do not write keep the caller's
+    values (the arrays are in/out)."""
+    text = ia.synth_log(1 << 21)
+    fm = ia.FmIndex(text, 16, True, device=0)
+    o = orc.OracleFmIndex.read(fm.write(False))
+    L = ia.lib
+    n, M, m = 40_000, 5, 6
+    pat, off, pos = ia.synth_patterns(text, m, n, seed=8)
+    pat = pat.copy()
+    pat[7 * m] = 7  # a pattern without hits
+    want_l, want_f, want_s = o.locate_batch(pat, off, M, threads=8, fill=-7)
+
+    def with_registered(arrays, fn):
+        for a in arrays:
+            assert L.fmx_host_register(a.ctypes.data, a.nbytes) == 0
+        try:
+            fn()
+        finally:
+            for a in arrays:
+                L.fmx_host_unregister(a.ctypes.data)
+
+    for registered in (False, True):
+        locs = np.full((n, M), -7, np.int32)
+        found = np.zeros(n, np.int32)
+        st = np.zeros(n, np.int32)
+        lf = np.zeros(n, np.int32)
+
+        def locate():
+            assert L.fmx_locate_batch(fm.handle, pat.ctypes.data, off.ctypes.data, n, M, locs.ctypes.data, M, found.ctypes.data,
+                                      lf.ctypes.data, st.ctypes.data) == 0
+
+        if registered:
+            with_registered((pat, off, locs, found, st, lf), locate)
+        else:
+            locate()
+        assert (found == want_f).all() and (st == want_s).all() and (locs == want_l).all(), registered
+    # extract: rows of 300 chars (five chunks of the pipeline), windows of 1..200 chars, some past the text's end
+    rnd = np.random.default_rng(3)
+    cap = 300
+    starts = rnd.integers(0, len(text) - 10, n).astype(np.int32)
+    stops = (starts + rnd.integers(1, 200, n)).astype(np.int32)
+    want_d, want_n, want_s = o.extract_batch(starts, stops, cap, offset=3, threads=8, fill=0xABCD)
+    froms = np.ascontiguousarray(pos[:n]).astype(np.int32)
+    want_bd, want_bn, want_bs, want_ba = o.extract_until_boundary_batch(0, froms, "\n", cap, offset=2, threads=8, fill=0xABCD)
+    for registered in (False, True):
+        dst = np.full((n, cap), 0xABCD, np.uint16)
+        ol = np.zeros(n, np.int32)
+        st = np.zeros(n, np.int32)
+        aux = np.zeros(n, np.int32)
+
+        def extract():
+            assert L.fmx_extract_batch(fm.handle, starts.ctypes.data, stops.ctypes.data, n, dst.ctypes.data, cap, 3, ol.ctypes.data, None,
+                                       st.ctypes.data) == 0
+
+        if registered:
+            with_registered((starts, stops, dst, ol, st), extract)
+        else:
+            extract()
+        assert (ol == want_n).all() and (st == want_s).all() and (dst == want_d).all(), registered
+        dst[:] = 0xABCD
+
+        def boundary():
+            assert L.fmx_extract_boundary_batch(fm.handle, froms.ctypes.data, n, 10, 0, dst.ctypes.data, cap, 2, ol.ctypes.data, None,
+                                                st.ctypes.data, aux.ctypes.data) == 0
+
+        if registered:
+            with_registered((froms, dst, ol, st, aux), boundary)
+        else:
+            boundary()
+        assert (ol == want_bn).all() and (st == want_bs).all() and (aux == want_ba).all() and (dst == want_bd).all(), registered
+    fm.close()
