@@ -1418,23 +1418,35 @@ static bool is_pinned(const void *p) {
     return a.type == hipMemoryTypeHost;
 }
 
+// device address of a registered (mapped) host array, or nullptr: BOTH ends of [p, p + bytes) must be mapped, one range (a caller
+// that registered only the head of an array must not have a kernel write past it)
+static void *mapped_range(const void *p, size_t bytes) {
+    if (!p || bytes == 0) return nullptr;
+    void *lo = nullptr, *hi = nullptr;
+    const char *c = static_cast<const char *>(p);
+    if (hipHostGetDevicePointer(&lo, const_cast<char *>(c), 0) != hipSuccess ||
+        hipHostGetDevicePointer(&hi, const_cast<char *>(c) + bytes - 1, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return static_cast<char *>(hi) - static_cast<char *>(lo) == (ptrdiff_t)(bytes - 1) ? lo : nullptr;
+}
+
 // fmx_count_batch with EVERY array registered (option "host_mapped", default 1): no copies at all — k_count reads the characters
 // (and the offsets, unless the patterns are of one length: those offsets are made on the device) from the caller's mapped arrays
 // and stores its results into them; the launch streams the batch over PCIe while it counts.  Returns -1 if the arrays are not
 // all mapped (the caller then takes the pipeline).
 static int count_batch_mapped(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n, int32_t *counts,
                               int32_t *lf_steps, int32_t *status) {
-    void *m_pat = nullptr, *m_off = nullptr, *m_cnt = nullptr, *m_lf = nullptr, *m_st = nullptr;
-    const bool mapped = hipHostGetDevicePointer(&m_pat, const_cast<uint16_t *>(pat), 0) == hipSuccess &&
-                        hipHostGetDevicePointer(&m_off, const_cast<int32_t *>(pat_off), 0) == hipSuccess &&
-                        hipHostGetDevicePointer(&m_cnt, counts, 0) == hipSuccess &&
-                        (!lf_steps || hipHostGetDevicePointer(&m_lf, lf_steps, 0) == hipSuccess) &&
-                        (!status || hipHostGetDevicePointer(&m_st, status, 0) == hipSuccess);
-    if (!mapped) {
-        (void)hipGetLastError();
-        return -1;
-    }
+    // (the ends of the batch first: the size of the characters' range comes from the last offset)
+    if (pat_off[0] < 0 || pat_off[n] < pat_off[0]) return fail(FMX_E_ARG, "pattern offsets start below 0 or decrease");
     const int64_t total_chars = pat_off[n];
+    void *m_off = mapped_range(pat_off, ((size_t)n + 1) * 4);
+    void *m_pat = total_chars ? mapped_range(pat, (size_t)total_chars * 2) : m_off;  // (no characters: never read)
+    void *m_cnt = mapped_range(counts, (size_t)n * 4);
+    void *m_lf = lf_steps ? mapped_range(lf_steps, (size_t)n * 4) : nullptr;
+    void *m_st = status ? mapped_range(status, (size_t)n * 4) : nullptr;
+    if (!m_off || !m_pat || !m_cnt || (lf_steps && !m_lf) || (status && !m_st)) return -1;
     bool uniform = false;
     if (pat_off[0] < 0 || total_chars < pat_off[0] || !scan_offsets(pat_off, 0, n, total_chars, &uniform))
         return fail(FMX_E_ARG, "pattern offsets decrease or leave the batch");
@@ -1493,14 +1505,10 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
     int32_t *m_cnt = nullptr, *m_lf = nullptr, *m_st = nullptr;
     bool stores_out = false;
     if (direct_out && g_host_direct_stores.load()) {
-        void *a = nullptr, *b = nullptr, *c = nullptr;
-        stores_out = hipHostGetDevicePointer(&a, counts, 0) == hipSuccess &&
-                     (!lf_steps || hipHostGetDevicePointer(&b, lf_steps, 0) == hipSuccess) &&
-                     (!status || hipHostGetDevicePointer(&c, status, 0) == hipSuccess);
-        if (!stores_out) (void)hipGetLastError();
-        m_cnt = static_cast<int32_t *>(a);
-        m_lf = static_cast<int32_t *>(b);
-        m_st = static_cast<int32_t *>(c);
+        m_cnt = static_cast<int32_t *>(mapped_range(counts, (size_t)n * 4));
+        m_lf = lf_steps ? static_cast<int32_t *>(mapped_range(lf_steps, (size_t)n * 4)) : nullptr;
+        m_st = status ? static_cast<int32_t *>(mapped_range(status, (size_t)n * 4)) : nullptr;
+        stores_out = m_cnt && (!lf_steps || m_lf) && (!status || m_st);
     }
     if (!stores_out) {
         HIP_TRY(d_cnt.alloc((size_t)n * 4));
@@ -1777,11 +1785,10 @@ int fmx_locate_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *p
     // stores the hits straight into the caller's rows — only the slots it fills travel, and they travel once (the array is in /
     // out, FM:504: unmapped it goes up and comes down whole) — and k_count reads the characters where they are.
     // found / LF-steps / statuses stay in HBM: the kernels update them with atomics.
-    void *m_locs = nullptr, *m_pat = nullptr;
     const bool mapped_ok = g_host_mapped.load() != 0;
-    const bool locs_mapped = mapped_ok && loc_bytes && hipHostGetDevicePointer(&m_locs, locs, 0) == hipSuccess;
-    const bool pat_mapped = mapped_ok && chars && hipHostGetDevicePointer(&m_pat, const_cast<uint16_t *>(pat), 0) == hipSuccess;
-    if (!locs_mapped || !pat_mapped) (void)hipGetLastError();
+    void *m_locs = mapped_ok ? mapped_range(locs, loc_bytes) : nullptr;
+    void *m_pat = mapped_ok ? mapped_range(pat, chars * 2) : nullptr;
+    const bool locs_mapped = m_locs != nullptr, pat_mapped = m_pat != nullptr;
     if (!pat_mapped) HIP_TRY(d_pat.alloc(chars * 2 + 8));
     HIP_TRY(d_off.alloc((size_t)(n + 1) * 4));
     if (!locs_mapped) HIP_TRY(d_locs.alloc(loc_bytes));

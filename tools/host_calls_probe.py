@@ -72,3 +72,23 @@ print("fmx_extract_boundary_batch 100,000 lines, registered: mean %.3f median %.
 assert (dst == ref).all()
 for a in arrays:
     ia.lib.fmx_host_unregister(a.ctypes.data)
+
+# the fused pipeline of a "grep": locate + the line of every hit (fmx_locate_lines_batch), 20,000 patterns x <= 8 hits, rows of 256 chars
+K2, M2, cap2 = 20_000, 8, 256
+pat2, off2 = pat[: K2 * m], off[: K2 + 1]
+locs2 = np.zeros((K2, M2), np.int32)
+found2 = np.zeros(K2, np.int32)
+dst2 = np.zeros((K2 * M2, cap2), np.uint16)
+ol2 = np.zeros(K2 * M2, np.int32)
+st3 = np.zeros(K2, np.int32)
+hst = np.zeros(K2 * M2, np.int32)
+haux = np.zeros(K2 * M2, np.int32)
+
+
+def lines():
+    assert ia.lib.fmx_locate_lines_batch(fm.handle, pat2.ctypes.data, off2.ctypes.data, K2, M2, 10, 0, cap2, locs2.ctypes.data, found2.ctypes.data,
+                                         dst2.ctypes.data, ol2.ctypes.data, None, st3.ctypes.data, hst.ctypes.data, haux.ctypes.data) == 0
+
+
+print("fmx_locate_lines_batch 20,000 patterns x <= 8 hits, rows of 256 chars (%d MB): mean %.3f median %.3f min %.3f ms"
+      % ((dst2.nbytes >> 20,) + timed(lines, 8)), flush=True)
