@@ -9,7 +9,8 @@ def timed(fn,reps=40):
     e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True); e0.record()
     for i in range(reps): fn(i)
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1)/reps
-for n in (393216, 524288, 655360, 786432, 917504, 1048576, 2097152, 4194304):
+import os
+for n in [int(x) for x in os.environ.get('FMX_SIZES','393216,524288,655360,786432,917504,1048576,2097152,4194304').split(',')]:
     bs=[]
     for b in range(3):
         pat,off,_=ia.synth_patterns(text,8,n,seed=43+b)
