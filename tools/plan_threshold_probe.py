@@ -10,6 +10,7 @@ def timed(fn,reps=40):
     for i in range(reps): fn(i)
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1)/reps
 import os
+if os.environ.get('FMX_COARSE'): assert ia.lib.fmx_set_option(b'coarse_bits', int(os.environ['FMX_COARSE'])) == 0
 for n in [int(x) for x in os.environ.get('FMX_SIZES','393216,524288,655360,786432,917504,1048576,2097152,4194304').split(',')]:
     bs=[]
     for b in range(3):
