@@ -1529,19 +1529,6 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
     // Registered result arrays are mapped into the device's address space: k_count then STORES counts, statuses and LF-steps
     // straight into them (a chunk of the pipeline is counted in the caller's order, so a wave's stores are consecutive words:
     // whole PCIe writes) — no result copies at all, which also leaves the link's other direction to the characters coming in.
-    int32_t *m_cnt = nullptr, *m_lf = nullptr, *m_st = nullptr;
-    bool stores_out = false;
-    if (direct_out && g_host_direct_stores.load()) {
-        m_cnt = static_cast<int32_t *>(mapped_range(counts, (size_t)n * 4));
-        m_lf = lf_steps ? static_cast<int32_t *>(mapped_range(lf_steps, (size_t)n * 4)) : nullptr;
-        m_st = status ? static_cast<int32_t *>(mapped_range(status, (size_t)n * 4)) : nullptr;
-        stores_out = m_cnt && (!lf_steps || m_lf) && (!status || m_st);
-    }
-    if (!stores_out) {
-        HIP_TRY(d_cnt.alloc((size_t)n * 4));
-        if (lf_steps) HIP_TRY(d_lf.alloc((size_t)n * 4));
-        if (status) HIP_TRY(d_st.alloc((size_t)n * 4));
-    }
     if (!direct_out) {
         HIP_TRY(h_cnt.alloc((size_t)n * 4));
         o_cnt = h_cnt.as<int32_t>();
@@ -1553,6 +1540,21 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
             HIP_TRY(h_st.alloc((size_t)n * 4));
             o_st = h_st.as<int32_t>();
         }
+    }
+    // (plain result arrays: the same stores go into the pinned STAGING the helper thread copies out of — o_cnt / o_lf / o_st
+    // are registered arrays of the caller or that staging, mapped either way)
+    int32_t *m_cnt = nullptr, *m_lf = nullptr, *m_st = nullptr;
+    bool stores_out = false;
+    if (g_host_direct_stores.load()) {
+        m_cnt = static_cast<int32_t *>(mapped_range(o_cnt, (size_t)n * 4));
+        m_lf = lf_steps ? static_cast<int32_t *>(mapped_range(o_lf, (size_t)n * 4)) : nullptr;
+        m_st = status ? static_cast<int32_t *>(mapped_range(o_st, (size_t)n * 4)) : nullptr;
+        stores_out = m_cnt && (!lf_steps || m_lf) && (!status || m_st);
+    }
+    if (!stores_out) {
+        HIP_TRY(d_cnt.alloc((size_t)n * 4));
+        if (lf_steps) HIP_TRY(d_lf.alloc((size_t)n * 4));
+        if (status) HIP_TRY(d_st.alloc((size_t)n * 4));
     }
     std::vector<std::unique_ptr<Scratch>> scratches;
     int failed = FMX_OK;
