@@ -121,7 +121,9 @@ void *fmx_device_blob(const fmx_index *idx, size_t *len);
  * host-buffer entry points move it by DMA without staging copies; buffers that are not registered work all the same.
  * fmx_count_batch with ALL of its arrays registered copies nothing: one launch reads the patterns from the mapped arrays and
  * stores counts / LF-steps / statuses into them (option "host_mapped" = 0: the chunk pipeline instead; "host_direct_stores" = 0:
- * that pipeline with result copies).  (hipHostRegister / hipHostUnregister; pages stay locked until unregistered.) */
+ * that pipeline with result copies).  Register WHOLE arrays: an array registered only in part is never handed to a kernel (both
+ * ends are checked), but the HIP runtime refuses to copy such a range (FMX_E_HIP).
+ * (hipHostRegister / hipHostUnregister; pages stay locked until unregistered.) */
 int fmx_host_register(void *p, size_t bytes);
 int fmx_host_unregister(void *p);
 

@@ -1435,6 +1435,11 @@ int fmx_locate_segments(const fmx_index *const *segs, int32_t n_segs, const int6
 constexpr int32_t kPipeChunkMin = 65536;  // smallest stage of the pipeline (patterns)
 
 // is `p` host memory the GPU can DMA from / to directly (hipHostMalloc, hipHostRegister / fmx_host_register)?
+static bool is_pinned(const void *p);
+// ... from its first byte to its last (a caller that registered only the head of an array gets the staged path)
+static bool is_pinned_range(const void *p, size_t bytes) {
+    return bytes == 0 ? is_pinned(p) : is_pinned(p) && is_pinned(static_cast<const char *>(p) + bytes - 1);
+}
 static bool is_pinned(const void *p) {
     if (!p) return false;
     hipPointerAttribute_t a;
@@ -1520,7 +1525,8 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
     std::vector<int32_t> bounds(1, 0);
     while (bounds.back() < n) bounds.push_back((int32_t)std::min<int64_t>(n, (int64_t)bounds.back() + chunk));
     const int32_t n_chunks = (int32_t)bounds.size() - 1;
-    const bool direct_out = is_pinned(counts) && (!lf_steps || is_pinned(lf_steps)) && (!status || is_pinned(status));
+    const bool direct_out = is_pinned_range(counts, (size_t)n * 4) && (!lf_steps || is_pinned_range(lf_steps, (size_t)n * 4)) &&
+                            (!status || is_pinned_range(status, (size_t)n * 4));
     DevBuf d_pat, d_off, d_cnt, d_lf, d_st;
     PinBuf h_cnt, h_lf, h_st;
     HIP_TRY(d_pat.alloc((size_t)total_chars * 2 + 8));
@@ -1618,7 +1624,7 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
     double t_scan = 0, t_in = 0, t_launch = 0, t_out = 0;
     const double t_begin = now();
     hipStream_t s_in = ps->s[0], s_k = ps->s[1], s_out = ps->s[2];
-    const bool in_pinned = is_pinned(pat) && is_pinned(pat_off);
+    const bool in_pinned = is_pinned_range(pat, (size_t)total_chars * 2) && is_pinned_range(pat_off, ((size_t)n + 1) * 4);
     // A pageable source is staged by whichever thread calls the copy: a FEEDER thread pushes the chunks' characters one
     // after the other with the plain copy (twice the rate of the asynchronous one from pageable memory; it returns when
     // the bytes are in HBM, so the kernels need no event), so that the link stays busy while this thread checks the
@@ -1975,7 +1981,7 @@ static int rows_pipeline_host(const fmx_index *idx, int32_t n, uint16_t *dst, in
         }
     } drain_on_exit{ps};
     const size_t row_bytes = (size_t)dst_len * 2;
-    if (row_bytes && !is_pinned(dst)) {
+    if (row_bytes && !is_pinned_range(dst, (size_t)n * row_bytes)) {
         // pageable rows: the plain copies (from pageable memory they run at twice the rate of the asynchronous ones), one launch
         for (const HostColumn &col : columns)
             if (col.in) HIP_TRY(hipMemcpy(col.dev->p, col.in, (size_t)n * 4, hipMemcpyHostToDevice));
