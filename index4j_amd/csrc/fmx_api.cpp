@@ -43,8 +43,9 @@
                        int32_t *, int32_t *, int32_t *, const int32_t *, int32_t, int32_t, hipStream_t);                \
     int launch_extract_boundary(const fmx::DevIndex &, int, const int32_t *, int64_t, uint16_t, int, uint16_t *, int32_t, \
                                 int32_t, int32_t *, int32_t *, int32_t *, int32_t *, void *, size_t, const int32_t *, int32_t, \
-                                hipStream_t);                                                                           \
+                                void *, size_t, bool, hipStream_t);                                                     \
     size_t boundary_workspace_bytes(const fmx::DevIndex &, int64_t n, int n_cu);                                        \
+    size_t boundary_order_bytes(const fmx::DevIndex &, int64_t n);                                                      \
     int launch_rrr_rank_ones(const fmx::DevIndex &, int, const int32_t *, int32_t, int32_t *, hipStream_t);             \
     int launch_rrr_access(const fmx::DevIndex &, int, const int32_t *, int32_t, uint8_t *, int32_t *, hipStream_t);     \
     int launch_segment_add_counts(int64_t *, int64_t *, int32_t *, const int32_t *, const int32_t *, const int32_t *, int32_t, \
@@ -83,6 +84,7 @@ FMX_DISPATCH_FN(walk_workspace_bytes)
 FMX_DISPATCH_FN(launch_extract)
 FMX_DISPATCH_FN(launch_extract_boundary)
 FMX_DISPATCH_FN(boundary_workspace_bytes)
+FMX_DISPATCH_FN(boundary_order_bytes)
 FMX_DISPATCH_FN(launch_wt_rank)
 FMX_DISPATCH_FN(launch_wt_inverse_select)
 #undef FMX_DISPATCH_FN
@@ -1164,10 +1166,19 @@ static int boundary_impl(const fmx_index *idx, const int32_t *d_from, int64_t n,
     if (ws_bytes > ((size_t)8 << 30)) ws_bytes = 0;
     int rc = scratch.get(kWsBoundary, ws_bytes, &ws);
     if (rc) return rc;
+    // large batches take their queries by text position (the walk order's workspace: the locate stage of a pipeline is done with it)
+    void *order_ws = nullptr;
+    const size_t order_bytes = k_boundary_order_bytes(idx, idx->dev, n);
+    rc = scratch.get(kWsWalk, order_bytes, &order_ws);
+    if (rc) return rc;
     int e = k_launch_extract_boundary(idx, idx->dev, idx->n_cu, d_from, n, boundary, mode, d_dst, dst_len, offset,
-                                         d_out_len, d_lf_steps, d_status, d_aux, ws, ws_bytes, slot_found, slots,
-                                         static_cast<hipStream_t>(scratch.stream));
-    if (e) return fail(FMX_E_HIP, std::string("k_extract_boundary launch: ") + hipGetErrorString((hipError_t)e));
+                                         d_out_len, d_lf_steps, d_status, d_aux, ws, ws_bytes, slot_found, slots, order_ws,
+                                         order_bytes, !scratch.per_call, static_cast<hipStream_t>(scratch.stream));
+    if (e) {
+        if (order_ws && !scratch.per_call)
+            (void)hipMemsetAsync(order_ws, 0, fmx::kPlanHeadBytes, static_cast<hipStream_t>(scratch.stream));
+        return fail(FMX_E_HIP, std::string("k_extract_boundary launch: ") + hipGetErrorString((hipError_t)e));
+    }
     return FMX_OK;
 }
 

@@ -721,13 +721,14 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary(DevIndex ix_global, const in
                                            int32_t *__restrict__ out_len, int32_t *__restrict__ lf_steps,
                                            int32_t *__restrict__ status_out, int32_t *__restrict__ aux_out,
                                            uint16_t *__restrict__ scratch, const int32_t *__restrict__ slot_found,
-                                           int32_t slots) {
+                                           int32_t slots, const PlanRec *__restrict__ order) {
     FMX_FM_INV(ix_global);
     FMX_WITH_SB_CACHE(ix_global, ix);
     const int64_t lanes = (int64_t)gridDim.x * kBlock;
     const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int32_t mapped_boundary = fm_map(ix, boundary);  // FM:658
-    for (int64_t q = lane; q < n; q += lanes) {
+    for (int64_t t = lane; t < n; t += lanes) {
+        const int64_t q = order ? (int64_t)ld_quad(order + t).z : t;  // (the queries by text position: launch_extract_boundary)
         if (slot_found && (int32_t)(q % slots) >= slot_found[q / slots]) continue;
         int status = ST_OK;
         int32_t steps, aux;
@@ -749,7 +750,8 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix_global, co
                                                  int32_t dst_len, int32_t offset, int32_t *__restrict__ out_len,
                                                  int32_t *__restrict__ lf_steps, int32_t *__restrict__ status_out,
                                                  int32_t *__restrict__ aux_out, uint16_t *__restrict__ scratch,
-                                                 const int32_t *__restrict__ slot_found, int32_t slots, int first_fill) {
+                                                 const int32_t *__restrict__ slot_found, int32_t slots, int first_fill,
+                                                 const PlanRec *__restrict__ order) {
     FMX_FM_INV(ix_global);
     FMX_WITH_SB_CACHE(ix_global, ix);
     const int64_t lanes = (int64_t)gridDim.x * kBlock;
@@ -757,7 +759,10 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix_global, co
     const int g = threadIdx.x % G;
     const int64_t groups = lanes / G;
     const int32_t mapped_boundary = fm_map(ix, boundary);  // FM:658
-    for (int64_t q = lane / G; q < n; q += groups) {
+    for (int64_t t = lane / G; t < n; t += groups) {
+        // order (nullable): the queries by text position — equal and neighbouring `from` fetch the same sample intervals, and
+        // walked by neighbouring groups those walks read the same lines (launch_extract_boundary)
+        const int64_t q = order ? (int64_t)ld_quad(order + t).z : t;
         if (slot_found && (int32_t)(q % slots) >= slot_found[q / slots]) continue;  // group-uniform
         int status = ST_OK;
         int32_t steps, aux;
@@ -1048,10 +1053,22 @@ __device__ __forceinline__ uint32_t walk_bin(uint32_t key, int below, int bins) 
     return c < (uint32_t)bins ? c : (uint32_t)bins - 1u;
 }
 
+// what a record of the walk order is made from: the SA range of pattern p (locate) — or, range == nullptr, query p of
+// extractUntilBoundary: {from, from + 1}, the order being the TEXT position (queries at equal and neighbouring positions fetch
+// the same sample intervals: the same walks side by side); an absent slot of the pipeline form has nothing to do: {0, 0}
+__device__ __forceinline__ int2 walk_pair(const int32_t *__restrict__ range, const int32_t *__restrict__ froms,
+                                          const int32_t *__restrict__ slot_found, int32_t slots, int64_t p) {
+    if (range) return *reinterpret_cast<const int2 *>(range + 2 * p);
+    if (slot_found && (int32_t)(p % slots) >= slot_found[p / slots]) return make_int2(0, 0);
+    const int32_t f = froms[p];
+    return make_int2(f, f < INT32_MAX ? f + 1 : f);
+}
+
 // bins: the zero bin + 2^coarse_bits
 __global__ __launch_bounds__(kTileThreads) void k_walk_hist(const int32_t *__restrict__ range, int32_t n, int bins, int below,
                                                             const int32_t *__restrict__ taken, int32_t max_matches,
-                                                            uint32_t *__restrict__ ghist) {
+                                                            uint32_t *__restrict__ ghist, const int32_t *__restrict__ froms,
+                                                            const int32_t *__restrict__ slot_found, int32_t slots) {
     extern __shared__ uint32_t s_hist[];
     for (int i = threadIdx.x; i < bins; i += kTileThreads) s_hist[i] = 0;
     __syncthreads();
@@ -1060,7 +1077,7 @@ __global__ __launch_bounds__(kTileThreads) void k_walk_hist(const int32_t *__res
     for (int k = 0; k < kTileItems; ++k) {
         const int64_t p = base + (int64_t)k * kTileThreads + threadIdx.x;
         if (p >= n) continue;
-        const int2 r = *reinterpret_cast<const int2 *>(range + 2 * p);
+        const int2 r = walk_pair(range, froms, slot_found, slots, p);
         atomicAdd(&s_hist[walk_bin(walk_key(r.x, r.y, taken, max_matches, p), below, bins)], 1u);
     }
     __syncthreads();
@@ -1083,7 +1100,10 @@ __global__ __launch_bounds__(kTileThreads) void k_plan_scatter(const PlanRec *__
                                                                uint32_t *__restrict__ ghist,
                                                                uint32_t *__restrict__ cursor,
                                                                uint32_t *__restrict__ ticket,
-                                                               PlanRec *__restrict__ recs_out) {
+                                                               PlanRec *__restrict__ recs_out,
+                                                               const int32_t *__restrict__ froms = nullptr,
+                                                               const int32_t *__restrict__ slot_found = nullptr,
+                                                               int32_t slots = 1) {
     const int fine_shift = below > 8 ? below - 8 : 0;  // (kFromRange: the fine bin of a record, as k_plan_codes leaves it)
     extern __shared__ uint32_t s_mem[];  // [bins] exclusive scan of ghist, [bins] this workgroup's counts / slots
     __shared__ uint32_t s_wave[kTileThreads / 64];
@@ -1104,7 +1124,7 @@ __global__ __launch_bounds__(kTileThreads) void k_plan_scatter(const PlanRec *__
         bin[k] = 0xffffffffu;
         if (p < n) {
             if constexpr (kFromRange) {
-                const int2 r = *reinterpret_cast<const int2 *>(range + 2 * p);
+                const int2 r = walk_pair(range, froms, slot_found, slots, p);
                 mine[k].x = (uint32_t)r.x;
                 mine[k].y = (uint32_t)r.y;
                 mine[k].z = walk_key(r.x, r.y, taken, max_matches, p);
@@ -1302,6 +1322,9 @@ static std::atomic<int> g_plan_sa_key{2};
 // order).  Measured on configs[1]'s index, <= 16 hits per pattern (tools/locate_order_probe.py): 16,384 patterns +8 % (the two
 // or three short kernels in front), 32,768 -5 %, 100,000 -24 %, 1,048,576 -43 %.
 static std::atomic<int> g_walk_order_min{32768};
+// extractUntilBoundary: batches at least this large take their queries by text position (0 = always the caller's order):
+// 100,000 hit locations of configs[3] (40,024 distinct) 1.93 -> 1.74 ms sorted on the host (tools/boundary_order_probe.py)
+static std::atomic<int> g_boundary_order_min{32768};
 static std::atomic<int> g_walk_fine{1};  // the window-local fine order on top of the buckets (k_plan_fine; 0: A/B)
 static std::atomic<int> g_sort_bits{28};    // full key width: floor(sort_bits / bits-per-code) trailing characters
 
@@ -1369,6 +1392,11 @@ int set_option(const char *name, int value) {
     }
     if (!strcmp(name, "walk_fine")) {
         g_walk_fine = value != 0;
+        return 0;
+    }
+    if (!strcmp(name, "boundary_order_min")) {
+        if (value < 0) return -1;
+        g_boundary_order_min = value;
         return 0;
     }
     if (!strcmp(name, "walk_order_min")) {
@@ -1569,7 +1597,7 @@ int launch_locate_walk(const DevIndex &ix, int n_cu, const int32_t *range, int32
         const int bins = (1 << coarse_bits) + 1, below = total_bits - coarse_bits;  // (+ the bin of patterns with nothing to locate)
         const int tiles = (n + kTile - 1) / kTile;
         hipLaunchKernelGGL(k_walk_hist, dim3(tiles), dim3(kTileThreads), (size_t)bins * 4, st, range, n, bins, below, taken,
-                           max_matches, ghist);
+                           max_matches, ghist, nullptr, nullptr, 1);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(k_plan_scatter<true>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 8, st, nullptr, range, taken,
                            max_matches, n, bins, below, ghist, cursor, ticket, ordered);
@@ -1678,11 +1706,48 @@ size_t boundary_workspace_bytes(const DevIndex &ix, int64_t n, int n_cu) {
     return need;  // (a racing change of groups_per_cu / boundary_group at worst makes the launch take the literal form)
 }
 
+// bytes of scratch for taking n extractUntilBoundary queries by text position (0 = the caller's order): head | records [n]
+size_t boundary_order_bytes(const DevIndex &ix, int64_t n) {
+    const int order_min = g_boundary_order_min;
+    if (order_min <= 0 || n < order_min || n > INT32_MAX) return 0;
+    return kPlanHeadBytes + (size_t)n * sizeof(PlanRec) + 64;
+}
+
+// order_ws (nullable): boundary_order_bytes(ix, n) — the queries are then taken by their text position
 int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, int64_t n, uint16_t boundary, int mode,
                             uint16_t *dst, int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf,
                             int32_t *status, int32_t *aux, void *workspace, size_t workspace_bytes,
-                            const int32_t *slot_found, int32_t slots, hipStream_t st) {
+                            const int32_t *slot_found, int32_t slots, void *order_ws, size_t order_ws_bytes, bool head_is_zero,
+                            hipStream_t st) {
     if (n <= 0) return 0;
+    const PlanRec *order = nullptr;
+    const size_t order_need = boundary_order_bytes(ix, n);
+    if (order_ws && order_need != 0 && order_ws_bytes >= order_need) {
+        uint8_t *wsb = static_cast<uint8_t *>(order_ws);
+        uint32_t *ghist = reinterpret_cast<uint32_t *>(wsb);
+        uint32_t *cursor = ghist + (1 << kCoarseBitsMax);
+        uint32_t *ticket = cursor + (1 << kCoarseBitsMax);
+        PlanRec *ordered = reinterpret_cast<PlanRec *>(wsb + kPlanHeadBytes);
+        if (!head_is_zero) {
+            hipError_t e = hipMemsetAsync(order_ws, 0, kPlanHeadBytes, st);
+            if (e != hipSuccess) return (int)e;
+        }
+        int total_bits = 1;
+        while (total_bits < 32 && (1ll << total_bits) <= (long long)ix.length) ++total_bits;
+        const int coarse_bits = total_bits < g_coarse_bits ? total_bits : (int)g_coarse_bits;
+        const int bins = (1 << coarse_bits) + 1, below = total_bits - coarse_bits;
+        const int32_t n32 = (int32_t)n;
+        const int tiles = (n32 + kTile - 1) / kTile;
+        hipLaunchKernelGGL(k_walk_hist, dim3(tiles), dim3(kTileThreads), (size_t)bins * 4, st, nullptr, n32, bins, below, nullptr, 0,
+                           ghist, from, slot_found, slots < 1 ? 1 : slots);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k_plan_scatter<true>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 8, st, nullptr, nullptr, nullptr, 0, n32,
+                           bins, below, ghist, cursor, ticket, ordered, from, slot_found, slots < 1 ? 1 : slots);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k_plan_fine, dim3((n32 + kFineWindow - 1) / kFineWindow), dim3(kFineThreads), 0, st, ordered, n32);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
+        order = ordered;
+    }
     const BoundaryShape shape = boundary_shape();
     const int blk = shape.block;
     const int blocks_accel = grid_for(n * (shape.group ? shape.group : 1), blk, n_cu);  // the grid the scratch is sized for
@@ -1696,10 +1761,10 @@ int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, i
     do {                                                                                                                \
         if (blk == 1024)                                                                                                \
             hipLaunchKernelGGL((k_extract_boundary_group<1024, GG>), grid, dim3(1024), 0, st, ix, from, n, boundary, mode, dst, \
-                               dst_len, offset, out_len, lf, status, aux, scratch, slot_found, slots, first_fill);      \
+                               dst_len, offset, out_len, lf, status, aux, scratch, slot_found, slots, first_fill, order); \
         else                                                                                                            \
             hipLaunchKernelGGL((k_extract_boundary_group<512, GG>), grid, dim3(512), 0, st, ix, from, n, boundary, mode, dst,  \
-                               dst_len, offset, out_len, lf, status, aux, scratch, slot_found, slots, first_fill);      \
+                               dst_len, offset, out_len, lf, status, aux, scratch, slot_found, slots, first_fill, order); \
     } while (0)
     if (G == 1)
         FMX_LAUNCH_GROUP(1);
@@ -1713,10 +1778,10 @@ int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, i
         FMX_LAUNCH_GROUP(16);
     else if (blk == 1024)
         hipLaunchKernelGGL(k_extract_boundary<1024>, grid, dim3(1024), 0, st, ix, from, n, boundary, mode, dst, dst_len, offset,
-                           out_len, lf, status, aux, scratch, slot_found, slots);
+                           out_len, lf, status, aux, scratch, slot_found, slots, order);
     else
         hipLaunchKernelGGL(k_extract_boundary<512>, grid, dim3(512), 0, st, ix, from, n, boundary, mode, dst, dst_len, offset,
-                           out_len, lf, status, aux, scratch, slot_found, slots);
+                           out_len, lf, status, aux, scratch, slot_found, slots, order);
 #undef FMX_LAUNCH_GROUP
     return (int)hipGetLastError();
 }

@@ -14,7 +14,7 @@ except ImportError:  # the C-ABI tests do not need it
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "plan_policy: the test runs under the library's own plan policy (plan_sa_min = 786,432, plan_min_per_string = 16, walk_order_min = 32,768) "
+    config.addinivalue_line("markers", "plan_policy: the test runs under the library's own plan policy (plan_sa_min = 786,432, plan_min_per_string = 16, walk_order_min = boundary_order_min = 32,768) "
                                        "instead of the GPU suite's default of planning every batch of sort_min patterns or more")
 
 
@@ -34,9 +34,11 @@ def _plan_every_large_batch(request):
     ia.lib.fmx_set_option(b"plan_min_per_string", 0)
     ia.lib.fmx_set_option(b"plan_sa_min", 0)
     ia.lib.fmx_set_option(b"walk_order_min", 1)  # ... and locate walks every batch by the first row of the ranges
+    ia.lib.fmx_set_option(b"boundary_order_min", 1)  # ... extractUntilBoundary takes every batch by text position
     try:
         yield
     finally:
         ia.lib.fmx_set_option(b"plan_min_per_string", 16)
         ia.lib.fmx_set_option(b"plan_sa_min", 786432)
         ia.lib.fmx_set_option(b"walk_order_min", 32768)
+        ia.lib.fmx_set_option(b"boundary_order_min", 32768)

@@ -82,6 +82,7 @@ def main():
                 "plan_sa_key": rnd.choice([2, 2, 1, 0]),
                 "walk_order_min": rnd.choice([1, 1, 0, 32768]),  # locate: hits walked by the first row of the ranges from this batch size on
                 "walk_fine": rnd.choice([1, 1, 0]),
+                "boundary_order_min": rnd.choice([1, 1, 0, 32768]),  # extractUntilBoundary: queries by text position from this batch size on
                 "regroup_by_length": rnd.choice([1, 1, 0])}  # k_count: workgroups with mixed pattern lengths regroup by length  # the plan's order: estimated SA row / the table's answer / trailing codes
         check_seed = rnd.randrange(1 << 30)
         if args.only_case >= 0 and cases != args.only_case:
