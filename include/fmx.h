@@ -183,7 +183,8 @@ int fmx_count_ordered_dev(const fmx_index *idx, const uint16_t *d_pat, const int
  * if it holds at least "plan_min_per_string" (default 16) patterns per string of the table's deepest level.  An index without a
  * table plans every batch of "sort_min" patterns or more.  (fmx_count_plan_dev always plans: the caller asked.)
  * locate has an order of its own on top: batches of "walk_order_min" patterns or more (default 32,768; 0 = never) walk their
- * hits by the first row of the patterns' SA ranges ("walk_fine" = 0 drops that order's fine pass). */
+ * hits by the first row of the patterns' SA ranges ("walk_fine" = 0 drops that order's fine pass); extractUntilBoundary batches
+ * of "boundary_order_min" queries or more (default 32,768) are taken by text position.  No order changes a result. */
 int fmx_count_batch_is_planned(const fmx_index *idx, int32_t n);
 int fmx_locate_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
                          int32_t max_matches, int32_t *d_locs, int32_t loc_cap, int32_t *d_found,
@@ -297,7 +298,7 @@ int fmx_device_count(void);
  * "sort_min" = smallest batch that is processed in suffix-sorted order (0 = never), "sort_bits" = sort key width,
  * "boundary_accel" = 0 forces the literal +4-chunk right walk of extractUntilBoundary, "boundary_group" = lanes
  * per extractUntilBoundary query (0 | 2 | 4 | 8 | 16), "coarse_bits" / "plan_fine" = bins and fine pass of the plan
- * stage, "plan_sa_key" / "plan_sa_min" / "plan_min_per_string" / "walk_order_min" / "walk_fine" = which batches are planned
+ * stage, "plan_sa_key" / "plan_sa_min" / "plan_min_per_string" / "walk_order_min" / "walk_fine" / "boundary_order_min" = which batches are planned
  * and by what (fmx_count_batch_is_planned), "suffix_table" = 0: launches ignore the index's suffix table, "lf_steps_executed_only" = 1: the LF-step
  * output of count() leaves out the rank evaluations the suffix table answered (bench.py's executed-work figure; the
  * default reports the reference's count), "boundary_first_fill" = 1: narrower first fill of extractUntilBoundary's
