@@ -40,7 +40,7 @@
                            int32_t *, int32_t *, const int32_t *, void *, size_t, bool, hipStream_t);                   \
     size_t walk_workspace_bytes(const fmx::DevIndex &, int32_t n);                                                      \
     int launch_extract(const fmx::DevIndex &, int, const int32_t *, const int32_t *, int64_t, uint16_t *, int32_t, int32_t, \
-                       int32_t *, int32_t *, int32_t *, const int32_t *, int32_t, int32_t, hipStream_t);                \
+                       int32_t *, int32_t *, int32_t *, const int32_t *, int32_t, int32_t, void *, size_t, bool, hipStream_t); \
     int launch_extract_boundary(const fmx::DevIndex &, int, const int32_t *, int64_t, uint16_t, int, uint16_t *, int32_t, \
                                 int32_t, int32_t *, int32_t *, int32_t *, int32_t *, void *, size_t, const int32_t *, int32_t, \
                                 void *, size_t, bool, hipStream_t);                                                     \
@@ -1150,7 +1150,7 @@ int fmx_extract_batch_dev(const fmx_index *idx, const int32_t *d_start, const in
     if (n < 0 || dst_len < 0 || (n > 0 && (!d_start || !d_stop || !d_out_len || (!d_dst && dst_len > 0))))
         return fail(FMX_E_ARG, "bad arguments");
     int e = k_launch_extract(idx, idx->dev, idx->n_cu, d_start, d_stop, n, d_dst, dst_len, offset, d_out_len, d_lf_steps,
-                                d_status, nullptr, 0, 0, static_cast<hipStream_t>(stream));
+                                d_status, nullptr, 0, 0, nullptr, 0, true, static_cast<hipStream_t>(stream));
     if (e) return fail(FMX_E_HIP, std::string("k_extract launch: ") + hipGetErrorString((hipError_t)e));
     return FMX_OK;
     });
@@ -1216,10 +1216,19 @@ static int locate_extract_impl(const fmx_index *idx, const uint16_t *d_pat, cons
     rc = locate_impl(idx, d_pat, d_pat_off, n, max_matches, d_locs, max_matches, d_found, d_lf_steps, d_status, d_range_ws,
                      scratch);
     if (rc) return rc;
+    // (the hits by text position: hits of equal patterns are equal positions; the walk order's workspace is free again)
+    void *order_ws = nullptr;
+    const size_t order_bytes = k_boundary_order_bytes(idx, idx->dev, (int64_t)n * max_matches);
+    rc = scratch.get(kWsWalk, order_bytes, &order_ws);
+    if (rc) return rc;
     int e = k_launch_extract(idx, idx->dev, idx->n_cu, d_locs, nullptr, (int64_t)n * max_matches, d_dst, extract_len, 0,
-                                d_out_len, nullptr, d_hit_status, d_found, max_matches, extract_len,
-                                static_cast<hipStream_t>(scratch.stream));
-    if (e) return fail(FMX_E_HIP, std::string("k_extract launch: ") + hipGetErrorString((hipError_t)e));
+                                d_out_len, nullptr, d_hit_status, d_found, max_matches, extract_len, order_ws, order_bytes,
+                                !scratch.per_call, static_cast<hipStream_t>(scratch.stream));
+    if (e) {
+        if (order_ws && !scratch.per_call)
+            (void)hipMemsetAsync(order_ws, 0, fmx::kPlanHeadBytes, static_cast<hipStream_t>(scratch.stream));
+        return fail(FMX_E_HIP, std::string("k_extract launch: ") + hipGetErrorString((hipError_t)e));
+    }
     return FMX_OK;
 }
 

@@ -689,11 +689,14 @@ FMX_EXTRACT_KERNEL(kBlock) void k_extract(DevIndex ix_global, const int32_t *__r
                                   int64_t n, uint16_t *__restrict__ dst, int32_t dst_len, int32_t offset,
                                   int32_t *__restrict__ out_len, int32_t *__restrict__ lf_steps,
                                   int32_t *__restrict__ status_out, const int32_t *__restrict__ slot_found,
-                                  int32_t slots, int32_t fixed_len) {
+                                  int32_t slots, int32_t fixed_len, const PlanRec *__restrict__ order) {
     FMX_FM_INV(ix_global);
     FMX_WITH_SB_CACHE(ix_global, ix);
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += stride) {
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < n; t += stride) {
+        // order (nullable; the pipeline form): the hits by text position — hits of equal patterns are equal positions, and equal
+        // extractions walked by neighbouring lanes read the same lines (launch_extract)
+        const int64_t q = order ? (int64_t)ld_quad(order + t).z : t;
         if (slot_found && (int32_t)(q % slots) >= slot_found[q / slots]) continue;
         int status = ST_OK;
         int32_t steps;
@@ -1666,11 +1669,54 @@ int launch_rrr_access(const DevIndex &ix, int n_cu, const int32_t *pos, int32_t 
     return (int)hipGetLastError();
 }
 
+// bytes of scratch for taking n extractUntilBoundary queries by text position (0 = the caller's order): head | records [n]
+size_t boundary_order_bytes(const DevIndex &ix, int64_t n) {
+    const int order_min = g_boundary_order_min;
+    if (order_min <= 0 || n < order_min || n > INT32_MAX) return 0;
+    return kPlanHeadBytes + (size_t)n * sizeof(PlanRec) + 64;
+}
+
+// the three passes of a walk order keyed by text position: records {position, position + 1, query} into `ordered`
+static int launch_position_order(const DevIndex &ix, const int32_t *positions, int32_t n, const int32_t *slot_found, int32_t slots,
+                                 void *order_ws, bool head_is_zero, PlanRec *ordered, hipStream_t st) {
+    uint8_t *wsb = static_cast<uint8_t *>(order_ws);
+    uint32_t *ghist = reinterpret_cast<uint32_t *>(wsb);
+    uint32_t *cursor = ghist + (1 << kCoarseBitsMax);
+    uint32_t *ticket = cursor + (1 << kCoarseBitsMax);
+    if (!head_is_zero) {
+        hipError_t e = hipMemsetAsync(order_ws, 0, kPlanHeadBytes, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    int total_bits = 1;
+    while (total_bits < 32 && (1ll << total_bits) <= (long long)ix.length) ++total_bits;
+    const int coarse_bits = total_bits < g_coarse_bits ? total_bits : (int)g_coarse_bits;
+    const int bins = (1 << coarse_bits) + 1, below = total_bits - coarse_bits;
+    const int tiles = (n + kTile - 1) / kTile;
+    hipLaunchKernelGGL(k_walk_hist, dim3(tiles), dim3(kTileThreads), (size_t)bins * 4, st, nullptr, n, bins, below, nullptr, 0, ghist,
+                       positions, slot_found, slots < 1 ? 1 : slots);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_plan_scatter<true>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 8, st, nullptr, nullptr, nullptr, 0, n, bins,
+                       below, ghist, cursor, ticket, ordered, positions, slot_found, slots < 1 ? 1 : slots);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_plan_fine, dim3((n + kFineWindow - 1) / kFineWindow), dim3(kFineThreads), 0, st, ordered, n);
+    return (int)hipGetLastError();
+}
+
+// order_ws (nullable): boundary_order_bytes(ix, n) — only offered for the pipeline form (slot_found != nullptr), whose
+// positions are hits and repeat; extractions at random positions gain nothing from an order (profiles/r04_experiments.txt 10)
 int launch_extract(const DevIndex &ix, int n_cu, const int32_t *start, const int32_t *stop, int64_t n, uint16_t *dst,
                    int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf, int32_t *status,
-                   const int32_t *slot_found, int32_t slots, int32_t fixed_len, hipStream_t st) {
+                   const int32_t *slot_found, int32_t slots, int32_t fixed_len, void *order_ws, size_t order_ws_bytes,
+                   bool head_is_zero, hipStream_t st) {
     if (n <= 0) return 0;
-    FMX_DISPATCH(k_extract, n, ix, start, stop, n, dst, dst_len, offset, out_len, lf, status, slot_found, slots, fixed_len);
+    const PlanRec *order = nullptr;
+    const size_t order_need = slot_found ? boundary_order_bytes(ix, n) : 0;
+    if (order_ws && order_need != 0 && order_ws_bytes >= order_need) {
+        PlanRec *ordered = reinterpret_cast<PlanRec *>(static_cast<uint8_t *>(order_ws) + kPlanHeadBytes);
+        if (int e = launch_position_order(ix, start, (int32_t)n, slot_found, slots, order_ws, head_is_zero, ordered, st)) return e;
+        order = ordered;
+    }
+    FMX_DISPATCH(k_extract, n, ix, start, stop, n, dst, dst_len, offset, out_len, lf, status, slot_found, slots, fixed_len, order);
     return (int)hipGetLastError();
 }
 
@@ -1706,13 +1752,6 @@ size_t boundary_workspace_bytes(const DevIndex &ix, int64_t n, int n_cu) {
     return need;  // (a racing change of groups_per_cu / boundary_group at worst makes the launch take the literal form)
 }
 
-// bytes of scratch for taking n extractUntilBoundary queries by text position (0 = the caller's order): head | records [n]
-size_t boundary_order_bytes(const DevIndex &ix, int64_t n) {
-    const int order_min = g_boundary_order_min;
-    if (order_min <= 0 || n < order_min || n > INT32_MAX) return 0;
-    return kPlanHeadBytes + (size_t)n * sizeof(PlanRec) + 64;
-}
-
 // order_ws (nullable): boundary_order_bytes(ix, n) — the queries are then taken by their text position
 int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, int64_t n, uint16_t boundary, int mode,
                             uint16_t *dst, int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf,
@@ -1723,29 +1762,8 @@ int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, i
     const PlanRec *order = nullptr;
     const size_t order_need = boundary_order_bytes(ix, n);
     if (order_ws && order_need != 0 && order_ws_bytes >= order_need) {
-        uint8_t *wsb = static_cast<uint8_t *>(order_ws);
-        uint32_t *ghist = reinterpret_cast<uint32_t *>(wsb);
-        uint32_t *cursor = ghist + (1 << kCoarseBitsMax);
-        uint32_t *ticket = cursor + (1 << kCoarseBitsMax);
-        PlanRec *ordered = reinterpret_cast<PlanRec *>(wsb + kPlanHeadBytes);
-        if (!head_is_zero) {
-            hipError_t e = hipMemsetAsync(order_ws, 0, kPlanHeadBytes, st);
-            if (e != hipSuccess) return (int)e;
-        }
-        int total_bits = 1;
-        while (total_bits < 32 && (1ll << total_bits) <= (long long)ix.length) ++total_bits;
-        const int coarse_bits = total_bits < g_coarse_bits ? total_bits : (int)g_coarse_bits;
-        const int bins = (1 << coarse_bits) + 1, below = total_bits - coarse_bits;
-        const int32_t n32 = (int32_t)n;
-        const int tiles = (n32 + kTile - 1) / kTile;
-        hipLaunchKernelGGL(k_walk_hist, dim3(tiles), dim3(kTileThreads), (size_t)bins * 4, st, nullptr, n32, bins, below, nullptr, 0,
-                           ghist, from, slot_found, slots < 1 ? 1 : slots);
-        if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(k_plan_scatter<true>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 8, st, nullptr, nullptr, nullptr, 0, n32,
-                           bins, below, ghist, cursor, ticket, ordered, from, slot_found, slots < 1 ? 1 : slots);
-        if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(k_plan_fine, dim3((n32 + kFineWindow - 1) / kFineWindow), dim3(kFineThreads), 0, st, ordered, n32);
-        if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
+        PlanRec *ordered = reinterpret_cast<PlanRec *>(static_cast<uint8_t *>(order_ws) + kPlanHeadBytes);
+        if (int e = launch_position_order(ix, from, (int32_t)n, slot_found, slots, order_ws, head_is_zero, ordered, st)) return e;
         order = ordered;
     }
     const BoundaryShape shape = boundary_shape();
