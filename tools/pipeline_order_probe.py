@@ -1,4 +1,5 @@
-"""A/B of option boundary_order_min on the fused pipelines (tools/bench_pipeline.py: locateAndExtract and the grep pipeline, 20,000 queries x\n<= 1,000 hits): hits taken by text position against the slot order.  GPU box only."""
+"""A/B of option boundary_order_min on the fused pipelines (tools/bench_pipeline.py: locateAndExtract and the grep pipeline, 20,000 queries x
+<= 1,000 hits): hits taken by text position against the slot order.  GPU box only."""
 import contextlib, io, json, os, runpy, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
