@@ -301,8 +301,8 @@ int fmx_device_count(void);
  * stage, "plan_sa_key" / "plan_sa_min" / "plan_min_per_string" / "walk_order_min" / "walk_fine" / "boundary_order_min" = which batches are planned
  * and by what (fmx_count_batch_is_planned), "suffix_table" = 0: launches ignore the index's suffix table, "lf_steps_executed_only" = 1: the LF-step
  * output of count() leaves out the rank evaluations the suffix table answered (bench.py's executed-work figure; the
- * default reports the reference's count), "boundary_first_fill" = 1: narrower first fill of extractUntilBoundary's
- * text windows (experiment).
+ * default reports the reference's count), "boundary_first_fill" = 0: a lane of extractUntilBoundary walks its two
+ * sample intervals one after the other instead of interleaved (A/B; 2 = default).
  * Applied when an index is flattened or becomes resident afterwards: "suffix_table_mb" / "suffix_table_chars" (budget
  * and depth of the suffix table, 0 = none), "sb_cache_limit" (superblocks whose headers are staged in LDS), "map_by_symbol" / "map_fast" / "inv_fast"
  * (layout of the image: tests force the reference's own routes with them).  Applied by fmx_build_on_device:

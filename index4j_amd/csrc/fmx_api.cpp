@@ -105,6 +105,7 @@ struct fmx_index {
     double wavelet_device_seconds = 0;  // fmx_build_on_device: seconds of the wavelet encode in HBM (0: host encoder)
     void *d_suffix_table = nullptr;     // DevIndex.suffix_table (owned, whoever owns the image)
     void *d_suffix_order1 = nullptr;    // DevIndex.suffix_order1 (owned likewise)
+    void *d_self = nullptr;             // DevIndex.self: the resident copy of `dev` the kernels' cold routes read (owned likewise)
     size_t suffix_table_bytes = 0;
     uint32_t suffix_table_strings = 0;  // strings (of 2 .. suffix_chars codes) the table holds
     uint32_t suffix_table_deepest = 0;  // ... of which strings of suffix_chars codes: what a batch's patterns spread over after the lookup
@@ -215,6 +216,21 @@ void make_dev_index(fmx_index *idx) {
     d.sb_cache = nullptr;
     d.sb_cache_limit = g_sb_cache_limit;
     d.wt_size = (uint32_t)h.wt_size;
+    d.self = nullptr;
+}
+
+// DevIndex.self: a copy of the launch-independent DevIndex in HBM (no LDS cache, no suffix table: a cold route needs neither),
+// pointing at itself.  Called after make_dev_index, on the index's device.
+int publish_dev_index(fmx_index *idx) {
+    if (!idx->d_self) HIP_TRY(hipMalloc(&idx->d_self, sizeof(fmx::DevIndex)));
+    fmx::DevIndex copy = idx->dev;
+    copy.self = static_cast<const fmx::DevIndex *>(idx->d_self);
+    copy.sb_cache = nullptr;
+    copy.suffix_table = nullptr;
+    copy.suffix_order1 = nullptr;
+    HIP_TRY(hipMemcpy(idx->d_self, &copy, sizeof(copy), hipMemcpyHostToDevice));
+    idx->dev.self = copy.self;
+    return FMX_OK;
 }
 
 int require_device(const fmx_index *idx, bool rrr_handle = false) {
@@ -700,6 +716,7 @@ void fmx_free(fmx_index *idx) {
     if (idx->owns_device && idx->d_blob) (void)hipFree(idx->d_blob);
     if (idx->d_suffix_table) (void)hipFree(idx->d_suffix_table);
     if (idx->d_suffix_order1) (void)hipFree(idx->d_suffix_order1);
+    if (idx->d_self) (void)hipFree(idx->d_self);
     delete idx;
 }
 
@@ -901,6 +918,7 @@ int fmx_to_device(fmx_index *idx, int device) {
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     idx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     make_dev_index(idx);
+    if (int rc2 = publish_dev_index(idx)) return rc2;
     build_suffix_table(idx);
     return FMX_OK;
     });
@@ -935,6 +953,7 @@ int fmx_attach_device_blob(void *device_blob, size_t len, int device, fmx_index 
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     idx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     make_dev_index(idx.get());
+    if (int rc2 = publish_dev_index(idx.get())) return rc2;
     build_suffix_table(idx.get());
     *out = idx.release();
     return FMX_OK;

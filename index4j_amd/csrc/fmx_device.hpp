@@ -23,8 +23,16 @@
 
 #if defined(__HIPCC__)
 #define FMX_HD __device__ inline __attribute__((always_inline))
+// A COLD route: ONE real function per code object instead of a copy at every call site of the LF-walk kernels (the
+// reference's own routes through the wavelet tree, met on block boundaries and quirk paths: a fraction of a percent of the
+// LF-steps, but 80 % of the kernels' instructions when inlined at each of their ten-odd call sites).  It takes the index as a
+// pointer to the resident copy of the launch-independent DevIndex (DevIndex.self), not a stack copy of the kernel's.
+#define FMX_COLD static __device__ __attribute__((noinline, unused))
+#define FMX_SELF(ix) ((ix).self)
 #else
 #define FMX_HD inline
+#define FMX_COLD inline
+#define FMX_SELF(ix) (&(ix))
 #endif
 
 namespace fmx {
@@ -78,6 +86,8 @@ struct DevIndex {
     // ((s(xy) - C[x]) / n_x, |xy| / n_x; {0, 0}: "xy" does not occur).  k_plan_codes stages it in LDS and estimates from it
     // the SA row a pattern's search starts at: its sort key.  Results never depend on it.
     const float *suffix_order1;
+    // this index's DevIndex as the API layer keeps it in HBM (no LDS cache, no launch option applied): what a cold route reads
+    const DevIndex *self;
 };
 constexpr int kOrder1MaxSigma = 90;  // 90^2 pairs of two floats = 64,800 bytes of LDS in k_plan_codes
 struct SuffixSlot {
@@ -613,8 +623,16 @@ FMX_HD int32_t fm_c_or_zero(const DevIndex &ix, int32_t symbol) {
 // With the superblock's header at hand (ix.sb_cache, staged in LDS by the kernel) and the mapping rows indexed by
 // the global symbol, the mapping entry and the block header are requested together with the superblock entry:
 //   {superblock entry, mapping entry, block header} -> first cell -> ...
-FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t symbol, int &status,
-                              bool &suspect) {
+// what a cold route hands back: its value and, packed, the status / flags it would have set
+struct ColdOut {
+    int32_t value, aux;
+};
+FMX_COLD ColdOut wt_rank_folded_cold(const DevIndex *self, uint32_t position, int32_t symbol);
+// kHot: the copy inlined into a kernel's loop — the common path and the cheap exits here, everything else (the reference's own
+// route, the literal next-block arithmetic) by ONE call of the cold copy, which is this very function with kHot = false.
+template <bool kHot>
+FMX_HD int32_t wt_rank_folded_t(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t symbol, int &status,
+                                bool &suspect) {
     const Quad *sb_cache = ix.sb_cache;
     if (position == 0) return fm_c_or_zero(ix, symbol);                 // WFBB:1012-1014
     if (position > ix.wt_size) position = ix.wt_size;                   // WFBB:1015-1017
@@ -678,6 +696,12 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
         // WFBB:1096-1108 reads the u24 of leaf `mapping value` of that block.  A fast entry (never clamped, see
         // fmx_blob.hpp) of a block with a tree IS that leaf's u24, the symbol's own: not suspect.
         if (ntag >= 1u && ntag <= kMapMaxLen) return e.rank + (int32_t)(nq.x >> 8);
+        if constexpr (kHot) {
+            const ColdOut r = wt_rank_folded_cold(FMX_SELF(ix), position, symbol);
+            if (r.aux & 0xff) status = r.aux & 0xff;
+            if (r.aux >> 8) suspect = true;
+            return r.value;
+        }
         // run block (tree height 0: the reference reads 4 bytes early, Q11) or an entry on the reference's route
         // (clamped, no fix-up here: Q2): the literal address arithmetic of WFBB:1080-1081
         const int32_t block_c = ntag == kMapSlow ? (int32_t)(nq.x >> 8) : 0;
@@ -730,6 +754,12 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
 
     // The reference's own route (codes longer than 16 bits, clamped mapping entries): block header, leaf entry,
     // clamped-mapping fix-up, code rebuilt from the level table, walk over the level table and cumulative counts.
+    if constexpr (kHot) {
+        const ColdOut r = wt_rank_folded_cold(FMX_SELF(ix), position, symbol);
+        if (r.aux & 0xff) status = r.aux & 0xff;
+        if (r.aux >> 8) suspect = true;
+        return r.value;
+    }
     int32_t block_c = (int32_t)(mq.x >> 8);
     Quad bhq = ld_quad(bhs + block_id);  // WFBB:1113
     FMX_PIN_QUAD(bhq);
@@ -807,9 +837,34 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
     return e.rank + rank_block + t.node_rank;  // WFBB:1281-1284
 }
 
+FMX_COLD ColdOut wt_rank_folded_cold(const DevIndex *self, uint32_t position, int32_t symbol) {
+    int status = ST_OK;
+    bool suspect = false;
+    ColdOut r;
+    r.value = wt_rank_folded_t<false>(*self, nullptr, position, symbol, status, suspect);
+    r.aux = status | (suspect ? 0x100 : 0);
+    return r;
+}
+// rank inside a kernel's loop (k_count: two of these per pattern character): every route inlined — a call in that loop, however
+// rarely taken, costs the kernel 10-15 spilled VGPRs at its 64-register budget and 1.5 % of the headline (measured, round 5;
+// FMX_COUNT_COLD_ROUTE = 1 builds the other form)
+#if !defined(FMX_COUNT_COLD_ROUTE)
+#define FMX_COUNT_COLD_ROUTE 0
+#endif
+FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t symbol, int &status,
+                              bool &suspect) {
+    return wt_rank_folded_t<FMX_COUNT_COLD_ROUTE != 0>(ix, inv, position, symbol, status, suspect);
+}
 FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t symbol, int &status) {
     bool suspect = false;
-    return wt_rank_folded(ix, inv, position, symbol, status, suspect);
+    return wt_rank_folded_t<FMX_COUNT_COLD_ROUTE != 0>(ix, inv, position, symbol, status, suspect);
+}
+// the whole of it by one call: the LF-walks need rank() only where a step crosses a block boundary or meets a quirk
+FMX_HD int32_t wt_rank_folded_rare(const DevIndex &ix, uint32_t position, int32_t symbol, int &status, bool &suspect) {
+    const ColdOut r = wt_rank_folded_cold(FMX_SELF(ix), position, symbol);
+    if (r.aux & 0xff) status = r.aux & 0xff;
+    if (r.aux >> 8) suspect = true;
+    return r.value;
 }
 // WaveletFixedBlockBoosting.rank as the reference returns it
 FMX_HD int32_t wt_rank(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t symbol, int &status,
@@ -957,7 +1012,28 @@ FMX_HD int32_t wt_inverse_select_reference_route(const DevIndex &ix, uint32_t po
     return c;
 }
 
+// ... as ONE real function per code object (FMX_COLD): blocks on that route are rare, its code is long
+FMX_COLD ColdOut wt_inverse_select_route_cold(const DevIndex *self, uint32_t position) {
+    const InvView v = wt_inv_view(*self, position >> 20, nullptr);
+    int32_t rank = 0;
+    bool exact = true;
+    const int32_t c = wt_inverse_select_reference_route(*self, position, v, rank, exact);
+    ColdOut r;
+    r.value = rank;
+    r.aux = (c & 0xffff) | (exact ? 0x10000 : 0);
+    return r;
+}
+FMX_HD int32_t wt_inverse_select_route_rare(const DevIndex &ix, uint32_t position, int32_t &rank_out, bool &exact_out) {
+    const ColdOut r = wt_inverse_select_route_cold(FMX_SELF(ix), position);
+    rank_out = r.value;
+    exact_out = (r.aux & 0x10000) != 0;
+    return r.aux & 0xffff;
+}
+
 // the walk with the block's InvHdr at hand
+// kCold: the rare routes of an LF-step by a call (extractUntilBoundary: 15,800 -> 3,700 instructions, 114 -> 94 VGPRs) or inlined
+// (locate / extract at their 64-register budgets: the call's spills cost them 1 %)
+template <bool kCold = true>
 FMX_HD int32_t wt_inverse_select_from(const DevIndex &ix, uint32_t position, const InvView &v, const Quad &ihq,
                                       int32_t &rank_out, bool &exact_out) {
     const uint32_t block_index = position & ((1u << v.bsl) - 1u);
@@ -967,7 +1043,9 @@ FMX_HD int32_t wt_inverse_select_from(const DevIndex &ix, uint32_t position, con
         rank_out = (int32_t)ihq.z + (int32_t)block_index;
         return (int32_t)ihq.y;
     }
-    if (ihq.x & kInvSlow) return wt_inverse_select_reference_route(ix, position, v, rank_out, exact_out);
+    if (ihq.x & kInvSlow)
+        return kCold ? wt_inverse_select_route_rare(ix, position, rank_out, exact_out)
+                     : wt_inverse_select_reference_route(ix, position, v, rank_out, exact_out);
     const RrrView &rv = v.rv;
     const NodeRec *nodes = reinterpret_cast<const NodeRec *>(ix.base + ((uint64_t)rv.off_bits << 3)) + ihq.z;
     uint32_t node_b = ihq.y;
@@ -997,13 +1075,14 @@ FMX_HD int32_t wt_inverse_select_from(const DevIndex &ix, uint32_t position, con
     }
 }
 
+template <bool kCold = true>
 FMX_HD int32_t wt_inverse_select_folded(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t &rank_out,
                                         int32_t &bsl_out, bool &exact_out) {
     (void)inv;
     const InvView v = wt_inv_view(ix, position >> 20, inv);
     bsl_out = v.bsl;
     const Quad ihq = ld_quad(wt_inv_hdr_ptr(ix, v, position));
-    return wt_inverse_select_from(ix, position, v, ihq, rank_out, exact_out);
+    return wt_inverse_select_from<kCold>(ix, position, v, ihq, rank_out, exact_out);
 }
 
 FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t &rank_out) {
@@ -1026,14 +1105,17 @@ FMX_HD int32_t fm_map(const DevIndex &ix, uint16_t ch) { return ix.char2code[ch]
 // (Q1, WFBB:1332).  Only then is the second call skipped; every other case runs rank() as the reference
 // does, so all of its quirks (next-block path, Q3) are preserved.  tests/test_fused_lf.py checks the
 // equivalence exhaustively on quirk-heavy inputs.
+template <bool kCold = true>
 FMX_HD int32_t fm_lf_finish(const DevIndex &ix, const uint16_t *inv, int32_t row, int32_t c, int32_t rank_before,
                             int32_t bsl, bool exact_symbol, int &status, bool &suspect) {
     const bool same_block = ((uint32_t)row & ((1u << bsl) - 1u)) != 0 && (uint32_t)row <= ix.wt_size;
     // a run block whose symbol is >= 256 reports a masked symbol: rank(row, masked c) must really be evaluated
     if (!exact_symbol) suspect = true;  // Q1
     if (same_block && exact_symbol) return rank_before + 1;
-    return wt_rank_folded(ix, inv, (uint32_t)row, c, status, suspect);
+    if (kCold) return wt_rank_folded_rare(ix, (uint32_t)row, c, status, suspect);
+    return wt_rank_folded_t<false>(ix, inv, (uint32_t)row, c, status, suspect);
 }
+template <bool kCold = true>
 FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, int32_t &c_out, int &status,
                           bool &suspect) {
     const uint32_t p = (uint32_t)(row - 1);
@@ -1045,13 +1127,14 @@ FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, 
     int32_t rank_before;
     int32_t bsl_i;
     bool exact_symbol;
-    const int32_t c = (int32_t)(int16_t)wt_inverse_select_folded(ix, inv, p, rank_before, bsl_i, exact_symbol);  // C[c] + rank
+    const int32_t c = (int32_t)(int16_t)wt_inverse_select_folded<kCold>(ix, inv, p, rank_before, bsl_i, exact_symbol);  // C[c] + rank
     c_out = c;
-    return fm_lf_finish(ix, inv, row, c, rank_before, bsl_i, exact_symbol, status, suspect);
+    return fm_lf_finish<kCold>(ix, inv, row, c, rank_before, bsl_i, exact_symbol, status, suspect);
 }
+template <bool kCold = true>
 FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, int32_t &c_out, int &status) {
     bool suspect = false;
-    return fm_lf_step(ix, inv, row, c_out, status, suspect);
+    return fm_lf_step<kCold>(ix, inv, row, c_out, status, suspect);
 }
 
 // TWO independent LF-steps of one lane, their loads in flight together (round 3: extractUntilBoundary fetches the sample
@@ -1163,14 +1246,14 @@ FMX_HD void fm_lf_step2(const DevIndex &ix, const uint16_t *inv, LfChain &a, LfC
         rank_a = (int32_t)iha.z + (int32_t)bia;
         ca = (int32_t)iha.y;
     } else if (la && (iha.x & kInvSlow)) {
-        ca = wt_inverse_select_reference_route(ix, pa, va, rank_a, exact_a);
+        ca = wt_inverse_select_route_rare(ix, pa, rank_a, exact_a);
     }
     if (lb && (ihb.x & kInvRun)) {
         exact_b = (ihb.x & kInvMasked) == 0;
         rank_b = (int32_t)ihb.z + (int32_t)bib;
         cb = (int32_t)ihb.y;
     } else if (lb && (ihb.x & kInvSlow)) {
-        cb = wt_inverse_select_reference_route(ix, pb, vb, rank_b, exact_b);
+        cb = wt_inverse_select_route_rare(ix, pb, rank_b, exact_b);
     }
     if (la) {
         a.c = (int32_t)(int16_t)ca;
@@ -1300,8 +1383,8 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
         if (sampled_row) break;
         int32_t rank_before;
         bool exact, suspect = false;
-        const int32_t c = (int32_t)(int16_t)wt_inverse_select_from(ix, (uint32_t)p, v, ihq, rank_before, exact);
-        j = fm_lf_finish(ix, inv, j, c, rank_before, v.bsl, exact, status, suspect);  // FM:532-535
+        const int32_t c = (int32_t)(int16_t)wt_inverse_select_from<false>(ix, (uint32_t)p, v, ihq, rank_before, exact);
+        j = fm_lf_finish<false>(ix, inv, j, c, rank_before, v.bsl, exact, status, suspect);  // FM:532-535
         ++distance;
         if (distance > walk_limit) {  // bounds the walk on a damaged index (see walk_limit above)
             status = ST_JAVA_AIOOBE;
@@ -1352,7 +1435,7 @@ FMX_HD int32_t fm_extract(const DevIndex &ix, const uint16_t *inv, int32_t start
     int32_t remaining = range, distance = 0;
     while (remaining > 0) {  // FM:596-606
         int32_t c;
-        row = fm_lf_step(ix, inv, row, c, status);
+        row = fm_lf_step<false>(ix, inv, row, c, status);
         ++steps;
         if (distance >= skip) {
             const int32_t idx = remaining - 1 + offset;
@@ -1460,8 +1543,19 @@ FMX_HD int32_t fm_boundary_right_literal(const DevIndex &ix, const uint16_t *inv
 
 // codes of text positions [k*s, min((k+1)*s, length)) into buf[(pos - k*s) * stride] with one walk from the
 // ISA sample k+1 (the wrap entry for the last interval, FM:367-369); returns false if any step is suspect
+// Where an interval holds the boundary character / the sentinel code 0 (bit j = offset j of the interval; sample rates up to
+// 64): noted by the walk that fetches the interval, so that the replay can FIND a line's two ends instead of scanning for them
+// character by character (fm_extract_boundary_group's fast path).
+struct IntervalMarks {
+    uint64_t boundary, zero;
+};
+FMX_HD void marks_note(IntervalMarks &m, int32_t offset, int32_t c, int32_t mapped_boundary) {
+    const uint64_t bit = 1ull << (offset & 63);
+    if (c == mapped_boundary) m.boundary |= bit;
+    if (c == 0) m.zero |= bit;
+}
 FMX_HD bool fm_fetch_interval(const DevIndex &ix, const uint16_t *inv, int32_t k, uint16_t *buf, int64_t stride,
-                              int32_t &steps, int &status) {
+                              int32_t &steps, int &status, IntervalMarks *marks = nullptr, int32_t mapped_boundary = -1) {
     const int32_t s = ix.sample_rate;
     const int64_t top64 = (int64_t)(k + 1) * s;
     const int32_t top = top64 < ix.length ? (int32_t)top64 : ix.length;
@@ -1472,13 +1566,15 @@ FMX_HD bool fm_fetch_interval(const DevIndex &ix, const uint16_t *inv, int32_t k
         row = fm_lf_step(ix, inv, row, c, status, suspect);
         ++steps;
         buf[(pos - k * s) * stride] = (uint16_t)c;
+        if (marks) marks_note(*marks, pos - k * s, (int32_t)(uint16_t)c, mapped_boundary);
     }
     return !suspect && status == ST_OK;
 }
 
 // two intervals with the two walks interleaved (fm_lf_step2): ka / kb < 0 = nothing to fetch on that side
 FMX_HD bool fm_fetch_interval2(const DevIndex &ix, const uint16_t *inv, int32_t ka, uint16_t *bufa, int32_t kb, uint16_t *bufb,
-                               int64_t stride, int32_t &steps_a, int32_t &steps_b, int &status) {
+                               int64_t stride, int32_t &steps_a, int32_t &steps_b, int &status, IntervalMarks *marks_a = nullptr,
+                               IntervalMarks *marks_b = nullptr, int32_t mapped_boundary = -1) {
     const int32_t s = ix.sample_rate;
     int32_t na = 0, nb = 0;
     LfChain a = {0, 0, false}, b = {0, 0, false};
@@ -1500,6 +1596,8 @@ FMX_HD bool fm_fetch_interval2(const DevIndex &ix, const uint16_t *inv, int32_t 
         fm_lf_step2(ix, inv, a, b, status, suspect);
         if (a.on) bufa[(int64_t)(na - 1 - i) * stride] = (uint16_t)a.c;
         if (b.on) bufb[(int64_t)(nb - 1 - i) * stride] = (uint16_t)b.c;
+        if (marks_a && a.on) marks_note(*marks_a, na - 1 - i, (int32_t)(uint16_t)a.c, mapped_boundary);
+        if (marks_b && b.on) marks_note(*marks_b, nb - 1 - i, (int32_t)(uint16_t)b.c, mapped_boundary);
     }
     steps_a += na;
     steps_b += nb;
@@ -1674,6 +1772,11 @@ struct TextWindow {
     int32_t g;        // this lane's index in the group
     int32_t steps;    // LF-steps this lane walked
     bool suspect;     // some walk of the group touched a quirk path -> redo the query literally
+    // what the lane's walk of the window's FIRST fill saw: interval marks_k (-1: none) holds the boundary / the sentinel where
+    // `marks` says (later refills do not maintain them: the fast replay runs right after the first fill)
+    int32_t mapped_boundary;
+    int32_t marks_k;
+    IntervalMarks marks;
 };
 
 template <int G>
@@ -1685,6 +1788,26 @@ FMX_HD bool group_any(bool v) {
 #else
     return v;
 #endif
+}
+template <int G>
+FMX_HD int32_t group_max(int32_t v) {
+#if defined(__HIPCC__)
+    for (int m = 1; m < G; m <<= 1) {
+        const int32_t o = __shfl_xor(v, m);
+        v = o > v ? o : v;
+    }
+#endif
+    return v;
+}
+template <int G>
+FMX_HD int32_t group_min(int32_t v) {
+#if defined(__HIPCC__)
+    for (int m = 1; m < G; m <<= 1) {
+        const int32_t o = __shfl_xor(v, m);
+        v = o < v ? o : v;
+    }
+#endif
+    return v;
 }
 template <int G>
 FMX_HD int32_t group_sum(int32_t v) {
@@ -1723,48 +1846,16 @@ FMX_HD void window_refill(const DevIndex &ix, const uint16_t *inv, TextWindow<G>
         w.k_lo = lo;
         w.n = G;
         mine = lo + w.g;
+        w.marks_k = (mine >= 0 && mine <= k_max) ? mine : -1;
+        w.marks.boundary = w.marks.zero = 0;
     }
     bool ok = true;
     if (mine >= 0 && mine <= k_max) {
         int status = ST_OK;
-        ok = fm_fetch_interval(ix, inv, mine, window_slot<G>(w, mine), w.row_stride, w.steps, status);
+        ok = fm_fetch_interval(ix, inv, mine, window_slot<G>(w, mine), w.row_stride, w.steps, status,
+                               mine == w.marks_k ? &w.marks : nullptr, w.mapped_boundary);
     }
     if (group_any<G>(!ok)) w.suspect = true;
-}
-
-// A narrower first fill (option boundary_first_fill = 1; measured, not the default — profiles/r03_experiments.txt), at
-// ONE program point for the whole group: half of the lanes fetch the intervals up to k0 (the left part and
-// text[from ..]), the other half those behind it — one walk per lane.  A line of log text is two or three sample
-// intervals long; text beyond these G intervals is fetched when the replay asks for it, the windows growing into their
-// free slots.  The default fetches G intervals on each side up front: 8 walks per query where 3 are needed, but no lane
-// ever waits for another query's refill.
-template <int G>
-FMX_HD void window_fill_both(const DevIndex &ix, const uint16_t *inv, TextWindow<G> &wl, TextWindow<G> &wr, int32_t k0,
-                             bool want_right) {
-    constexpr int H = G / 2;
-    const int32_t k_max = (ix.length - 1) / wl.s;
-    int32_t lo = k0 - (H - 1);
-    if (lo < 0) lo = 0;
-    wl.k_lo = lo;
-    wl.n = k0 - lo + 1;
-    wr.k_lo = k0 + 1;
-    wr.n = H;
-    // ONE call site for all lanes (an if / else around two walks would run them one after the other)
-    int32_t mine = -1;
-    uint16_t *slot = wl.buf;
-    if (wl.g < H) {
-        if (lo + wl.g <= k0) mine = lo + wl.g;
-        slot = window_slot<G>(wl, lo + wl.g);
-    } else if (want_right) {
-        if (k0 + 1 + (wl.g - H) <= k_max) mine = k0 + 1 + (wl.g - H);
-        slot = window_slot<G>(wr, k0 + 1 + (wl.g - H));
-    }
-    bool ok = true;
-    if (mine >= 0) {
-        int status = ST_OK;
-        ok = fm_fetch_interval(ix, inv, mine, slot, wl.row_stride, wl.steps, status);
-    }
-    if (group_any<G>(!ok)) wl.suspect = true;
 }
 
 // The default first fill — G intervals on each side — with every lane's two walks interleaved (fm_fetch_interval2): what
@@ -1786,8 +1877,12 @@ FMX_HD void window_fill_pairs(const DevIndex &ix, const uint16_t *inv, TextWindo
         if (mine_r > k_max) mine_r = -1;
     }
     int status = ST_OK;
+    wl.marks_k = mine_l;
+    wr.marks_k = mine_r;
+    wl.marks.boundary = wl.marks.zero = wr.marks.boundary = wr.marks.zero = 0;
     const bool ok = fm_fetch_interval2(ix, inv, mine_l, window_slot<G>(wl, mine_l < 0 ? 0 : mine_l), mine_r,
-                                       window_slot<G>(wr, mine_r < 0 ? 0 : mine_r), wl.row_stride, wl.steps, wr.steps, status);
+                                       window_slot<G>(wr, mine_r < 0 ? 0 : mine_r), wl.row_stride, wl.steps, wr.steps, status,
+                                       &wl.marks, &wr.marks, wl.mapped_boundary);
     if (group_any<G>(!ok)) {
         wl.suspect = true;
         if (want_right) wr.suspect = true;
@@ -1801,17 +1896,86 @@ FMX_HD int32_t window_code_at(const DevIndex &ix, const uint16_t *inv, TextWindo
     return window_slot<G>(w, k)[(int64_t)(pos - k * w.s) * w.row_stride];
 }
 
+FMX_HD int fmx_clzll(uint64_t v) { return __builtin_clzll(v); }  // (v != 0)
+FMX_HD int fmx_ctzll(uint64_t v) { return __builtin_ctzll(v); }
+
+// The replay of extractUntilBoundary (mode 0, FM:640-759) for the common case, WITHOUT walking the text character by
+// character: the first fill's walks noted where their intervals hold the boundary and the sentinel (TextWindow.marks), so the
+// line's two ends are two bit searches and a group reduction, and what the reference's loops leave in `destination` is
+// known in closed form —
+//   left part (FM:655-690): text(lb, from) is written at the END of destination going down, then moved to `offset`: both
+//     copies stay (the temporary one is part of the row the caller sees);
+//   right part (FM:692-758): whole +4 chunks text[from, E), E = the end of the chunk that holds the first boundary rb >= from
+//     (the characters behind rb inside that chunk are written too), at offset + downLen; return downLen + (rb - from).
+// The G lanes of the group write those characters side by side (lane g: every G-th one) instead of ONE lane writing while
+// all G replay the same loops.  Anything else — an end outside the fetched windows, `from` on a boundary (FM:725-728), a line
+// that reaches the text's end (FM:745-752) or does not fit its destination with room to spare (FM:732-737 and overlapping
+// copies) — returns false and the literal replay below runs as before.  The result of the test is the same in every lane of
+// the group.
+template <int G>
+FMX_HD bool fm_boundary_replay_marked(const DevIndex &ix, const TextWindow<G> &wl, const TextWindow<G> &wr, int32_t from,
+                                      int32_t k0, uint16_t *dest, int32_t dst_len, int32_t offset, int32_t &ret) {
+    const int32_t s = wl.s;
+    const int32_t o = from - k0 * s;  // 0 <= o < s <= 64
+    const uint64_t below = (1ull << o) - 1ull;
+    // lb: the nearest position below `from` that holds the boundary or the sentinel (FM:674-680); -1 = the text's start
+    int32_t cand = -1;
+    if (wl.marks_k >= 0 && wl.marks_k <= k0) {
+        uint64_t m = wl.marks.boundary | wl.marks.zero;
+        if (wl.marks_k == k0) m &= below;
+        if (m) cand = wl.marks_k * s + 63 - fmx_clzll(m);
+    }
+    const int32_t lb = group_max<G>(cand);
+    if (lb < 0 && wl.k_lo != 0) return false;  // the line starts left of the window
+    // rb: the first position >= from that holds the boundary
+    int32_t rc = INT32_MAX;
+    if (wl.marks_k == k0) {
+        const uint64_t m = wl.marks.boundary & ~below;
+        if (m) rc = k0 * s + fmx_ctzll(m);
+    }
+    if (wr.marks_k > k0 && wr.marks.boundary) {
+        const int32_t r2 = wr.marks_k * s + fmx_ctzll(wr.marks.boundary);
+        rc = r2 < rc ? r2 : rc;
+    }
+    const int32_t rb = group_min<G>(rc);
+    if (rb == INT32_MAX || rb <= from) return false;  // not in the windows / `from` itself is the boundary
+    const int32_t a = from - lb - 1;  // downLen
+    const int64_t e = (int64_t)from + 4 * (int64_t)((rb - from) / 4 + 1);  // end of rb's chunk
+    if (e >= (int64_t)ix.length - 1) return false;  // the last chunk is clamped / ends the loop by itself (FM:745-752)
+    const int32_t k_last = (int32_t)((e - 1) / s);
+    if (k_last > k0 && (wr.k_lo < 0 || k_last >= wr.k_lo + wr.n)) return false;
+    const int64_t right_len = e - from;
+    if (offset < 0 || a >= dst_len || (int64_t)offset + a + right_len > (int64_t)dst_len - a) return false;
+    uint16_t *tmp = dest + (dst_len - a);
+    for (int32_t i = wl.g; i < a; i += G) {
+        const int32_t pos = lb + 1 + i, k = pos / s;
+        const uint16_t ch = fm_char_of(ix, (int32_t)window_slot<G>(wl, k)[(int64_t)(pos - k * s) * wl.row_stride]);
+        tmp[i] = ch;          // FM:682
+        dest[offset + i] = ch;  // FM:690
+    }
+    uint16_t *up = dest + offset + a;
+    for (int32_t i = wl.g; i < (int32_t)right_len; i += G) {
+        const int32_t pos = from + i, k = pos / s;
+        const TextWindow<G> &w = k <= k0 ? wl : wr;
+        up[i] = fm_char_of(ix, (int32_t)window_slot<G>(w, k)[(int64_t)(pos - k * s) * w.row_stride]);  // FM:738-739
+    }
+    ret = a + (rb - from);  // FM:758
+    return true;
+}
+
 // Same results as fm_extract_boundary (FM:640-922).  `clean` = false: a walk was suspect, nothing can be
 // trusted — the caller reruns the query with the literal form.  steps: LF-steps walked by the whole group.
 // buf: two windows of G intervals per group (left window, then right window `win_stride` elements further).
 // Both windows are fetched up front, at ONE program point, so that all lanes of a wave walk their intervals
 // together; later refills (lines longer than a window) happen wherever the replay needs them.
-template <int G>
+// kMode >= 0: the mode as a compile-time constant (the kernels: one instance per mode, each without the other two's code)
+template <int G, int kMode = -1>
 FMX_HD int32_t fm_extract_boundary_group(const DevIndex &ix, const uint16_t *inv, int mode, int32_t from,
                                          int32_t mapped_boundary, uint16_t *dest, int32_t dst_len, int32_t offset,
                                          int32_t &steps, int &status, int32_t &aux, uint16_t *buf, int64_t row_stride,
                                          int64_t slot_stride, int64_t win_stride, int32_t g, bool &clean,
-                                         bool first_fill_halves = false, bool pair_walks = false) {
+                                         bool pair_walks = false) {
+    if (kMode >= 0) mode = kMode;
     steps = 0;
     aux = 0;
     clean = true;
@@ -1839,17 +2003,20 @@ FMX_HD int32_t fm_extract_boundary_group(const DevIndex &ix, const uint16_t *inv
     }
     const int32_t s = ix.sample_rate;
     const int32_t k0 = from / s;
-    TextWindow<G> wl = {buf, row_stride, slot_stride, s, -1, 0, g, 0, false};               // intervals <= k0
-    TextWindow<G> wr = {buf + win_stride, row_stride, slot_stride, s, -1, 0, g, 0, false};  // intervals > k0
-    if (G >= 2 && first_fill_halves) {
-        window_fill_both<G>(ix, inv, wl, wr, k0, mode != 1);        // [k0-G/2+1, k0] and [k0+1, k0+G/2], one walk per lane
-    } else if (pair_walks) {
+    TextWindow<G> wl = {buf, row_stride, slot_stride, s, -1, 0, g, 0, false, mapped_boundary, -1, {0, 0}};               // intervals <= k0
+    TextWindow<G> wr = {buf + win_stride, row_stride, slot_stride, s, -1, 0, g, 0, false, mapped_boundary, -1, {0, 0}};  // intervals > k0
+    if (pair_walks) {
         window_fill_pairs<G>(ix, inv, wl, wr, k0, mode != 1);       // the same two windows, a lane's two walks interleaved
     } else {
         window_refill<G>(ix, inv, wl, k0, -1);                      // [k0-G+1, k0]: the left part and text[from..]
         if (mode != 1) window_refill<G>(ix, inv, wr, k0 + 1, +1);   // [k0+1, k0+G]
     }
     int32_t ret = 0;
+    if (mode == 0 && s <= 64 && !wl.suspect && !wr.suspect &&
+        fm_boundary_replay_marked<G>(ix, wl, wr, from, k0, dest, dst_len, offset, ret)) {
+        steps = group_sum<G>(wl.steps + wr.steps);
+        return ret;
+    }
     bool finished = false;
     int32_t down_len = 0;
     if (mode != 2) {  // left part (FM:655-690 / FM:788-828): text[from-1], text[from-2], ... until boundary / start

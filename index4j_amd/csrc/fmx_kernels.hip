@@ -616,6 +616,7 @@ int launch_suffix_order1(const DevIndex &ix, float *out, hipStream_t st) {
 }
 
 // FM:526-548: hit k of pattern p is SA row i = start + 1 + k; walk LF until a sampled row.
+constexpr int kRedoHead = 4;    // ints in front of a redo list's entries ({count, 0, 0, 0}: 16 bytes)
 constexpr int kWalkLanes = 128;  // lanes of k_locate_walk per pattern (at most): two waves
 template <int kBlock>
 FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix_global, const int32_t *__restrict__ range, int32_t n,
@@ -718,20 +719,27 @@ FMX_EXTRACT_KERNEL(kBlock) void k_extract(DevIndex ix_global, const int32_t *__r
 // FM:640-759 (mode 0), FM:772-831 (mode 1), FM:844-922 (mode 2), one lane per query.  `scratch` (nullable) holds
 // sample_rate codes per lane of the grid (element j of lane t at scratch[j * lanes + t]) for the
 // interval-buffered right walk (fm_boundary_right_blocks); without it the literal form runs.
+// redo (nullable): {count, 0, 0, 0, queries...} — the queries the group kernel could not answer (a walk met a quirk path of the
+// wavelet tree): only those are run, literally, and their LF-steps are ADDED to what the group kernel already walked for them.
 template <int kBlock>
 FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary(DevIndex ix_global, const int32_t *__restrict__ froms, int64_t n, uint16_t boundary,
                                            int mode, uint16_t *__restrict__ dst, int32_t dst_len, int32_t offset,
                                            int32_t *__restrict__ out_len, int32_t *__restrict__ lf_steps,
                                            int32_t *__restrict__ status_out, int32_t *__restrict__ aux_out,
                                            uint16_t *__restrict__ scratch, const int32_t *__restrict__ slot_found,
-                                           int32_t slots, const PlanRec *__restrict__ order) {
+                                           int32_t slots, const PlanRec *__restrict__ order,
+                                           const int32_t *__restrict__ redo) {
+    if (redo) {
+        n = redo[0];
+        if (n <= 0) return;  // (nearly every launch: no superblock header is staged for nothing)
+    }
     FMX_FM_INV(ix_global);
     FMX_WITH_SB_CACHE(ix_global, ix);
     const int64_t lanes = (int64_t)gridDim.x * kBlock;
     const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int32_t mapped_boundary = fm_map(ix, boundary);  // FM:658
     for (int64_t t = lane; t < n; t += lanes) {
-        const int64_t q = order ? (int64_t)ld_quad(order + t).z : t;  // (the queries by text position: launch_extract_boundary)
+        const int64_t q = redo ? (int64_t)redo[kRedoHead + t] : order ? (int64_t)ld_quad(order + t).z : t;  // (the queries by text position: launch_extract_boundary)
         if (slot_found && (int32_t)(q % slots) >= slot_found[q / slots]) continue;
         int status = ST_OK;
         int32_t steps, aux;
@@ -739,7 +747,7 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary(DevIndex ix_global, const in
                                                 dst_len, offset, steps, status, aux, scratch ? scratch + lane : nullptr,
                                                 lanes);
         out_len[q] = status ? 0 : ret;
-        if (lf_steps) lf_steps[q] = steps;
+        if (lf_steps) lf_steps[q] = redo ? lf_steps[q] + steps : steps;
         if (status_out) status_out[q] = status;
         if (aux_out) aux_out[q] = aux;
     }
@@ -747,14 +755,17 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary(DevIndex ix_global, const in
 
 // Group-cooperative extractUntilBoundary: G lanes per query (fm_extract_boundary_group); the window of a group
 // is G consecutive lane columns of `scratch` (left window in the first half, right window in the second).
-template <int kBlock, int G>
+// kMode: the mode (0 / 1 / 2) as a compile-time constant — each instance carries one mode's replay.  A query whose walks met a
+// quirk path (`clean` false) is not answered here: its index goes onto the `redo` list ({count, 0, 0, 0, queries...}), which a
+// launch of the literal k_extract_boundary behind this kernel works off — the literal form is not part of this kernel's body.
+template <int kBlock, int G, int kMode>
 FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix_global, const int32_t *__restrict__ froms, int64_t n,
-                                                 uint16_t boundary, int mode, uint16_t *__restrict__ dst,
+                                                 uint16_t boundary, uint16_t *__restrict__ dst,
                                                  int32_t dst_len, int32_t offset, int32_t *__restrict__ out_len,
                                                  int32_t *__restrict__ lf_steps, int32_t *__restrict__ status_out,
                                                  int32_t *__restrict__ aux_out, uint16_t *__restrict__ scratch,
-                                                 const int32_t *__restrict__ slot_found, int32_t slots, int first_fill,
-                                                 const PlanRec *__restrict__ order) {
+                                                 const int32_t *__restrict__ slot_found, int32_t slots, int pair_walks,
+                                                 const PlanRec *__restrict__ order, int32_t *__restrict__ redo) {
     FMX_FM_INV(ix_global);
     FMX_WITH_SB_CACHE(ix_global, ix);
     const int64_t lanes = (int64_t)gridDim.x * kBlock;
@@ -771,20 +782,18 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix_global, co
         int32_t steps, aux;
         bool clean;
         uint16_t *dest = dst + q * (int64_t)dst_len;
-        int32_t ret = fm_extract_boundary_group<G>(ix, s_inv, mode, froms[q], mapped_boundary, dest, dst_len, offset, steps,
-                                                   status, aux, scratch + (lane - g), lanes, 1, lanes * (int64_t)ix.sample_rate, g, clean,
-                                                   first_fill == 1, first_fill == 2);
-        if (!clean && g == 0) {  // a walk met a quirk path of the wavelet tree: literal form (rare)
-            int32_t steps2;
-            status = ST_OK;
-            ret = fm_extract_boundary(ix, s_inv, mode, froms[q], mapped_boundary, dest, dst_len, offset, steps2, status, aux);
-            steps += steps2;
-        }
+        const int32_t ret = fm_extract_boundary_group<G, kMode>(ix, s_inv, kMode, froms[q], mapped_boundary, dest, dst_len, offset, steps,
+                                                                status, aux, scratch + (lane - g), lanes, 1, lanes * (int64_t)ix.sample_rate, g,
+                                                                clean, pair_walks != 0);
         if (g == 0) {
-            out_len[q] = status ? 0 : ret;
             if (lf_steps) lf_steps[q] = steps;
-            if (status_out) status_out[q] = status;
-            if (aux_out) aux_out[q] = aux;
+            if (!clean) {  // (rare) the literal form answers it: k_extract_boundary over the redo list
+                redo[kRedoHead + atomicAdd(&redo[0], 1)] = (int32_t)q;
+            } else {
+                out_len[q] = status ? 0 : ret;
+                if (status_out) status_out[q] = status;
+                if (aux_out) aux_out[q] = aux;
+            }
         }
     }
 }
@@ -1307,7 +1316,7 @@ static std::atomic<int> g_groups_per_cu{16};
 static std::atomic<int> g_boundary_accel{1};  // 0 = literal right walk of extractUntilBoundary (A/B and fallback)
 static std::atomic<int> g_boundary_group{4};  // lanes per query of extractUntilBoundary (0 = one lane per query)
 // first fill of extractUntilBoundary's two text windows: 0 = G intervals on each side, a lane walks one after the other;
-// 1 = G / 2 on each side, one walk per lane (measured, slower); 2 = as 0 with a lane's two walks interleaved (fm_lf_step2)
+// 2 = the same with a lane's two walks interleaved (fm_lf_step2)
 static std::atomic<int> g_boundary_first_fill{2};
 static std::atomic<int> g_regroup_by_length{1};  // k_count: workgroups with mixed pattern lengths hand their records out again by length (0: A/B)
 static std::atomic<int> g_steps_executed_only{0};  // 1 = d_lf_steps of count() leave out what the suffix table answered
@@ -1360,7 +1369,7 @@ int set_option(const char *name, int value) {
         return 0;
     }
     if (!strcmp(name, "boundary_first_fill")) {
-        if (value < 0 || value > 2) return -1;
+        if (value != 0 && value != 2) return -1;  // (1, half-width windows, was measured slower in round 3 and is gone)
         g_boundary_first_fill = value;
         return 0;
     }
@@ -1736,9 +1745,11 @@ static BoundaryShape boundary_shape() {
 static size_t boundary_bytes_for_grid(const DevIndex &ix, int blocks, const BoundaryShape &b) {
     return (size_t)blocks * (size_t)b.block * (size_t)ix.sample_rate * sizeof(uint16_t) * 2 + 256;  // two windows
 }
+// (behind the windows: the redo list of the group kernel — {count, 0, 0, 0} + one int per query)
+static size_t boundary_redo_bytes(int64_t n) { return ((size_t)kRedoHead + (size_t)n) * sizeof(int32_t) + 64; }
 static size_t boundary_bytes_for(const DevIndex &ix, int64_t n, int n_cu, const BoundaryShape &b) {
     if (!b.accel || n <= 0) return 0;
-    return boundary_bytes_for_grid(ix, grid_for(n * (b.group ? b.group : 1), b.block, n_cu), b);
+    return boundary_bytes_for_grid(ix, grid_for(n * (b.group ? b.group : 1), b.block, n_cu), b) + boundary_redo_bytes(n);
 }
 size_t boundary_workspace_bytes(const DevIndex &ix, int64_t n, int n_cu) {
     // upper bound over the workgroup sizes: whatever shape the launch snapshots fits
@@ -1769,20 +1780,31 @@ int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, i
     const BoundaryShape shape = boundary_shape();
     const int blk = shape.block;
     const int blocks_accel = grid_for(n * (shape.group ? shape.group : 1), blk, n_cu);  // the grid the scratch is sized for
-    uint16_t *scratch = (workspace && shape.accel && workspace_bytes >= boundary_bytes_for_grid(ix, blocks_accel, shape))
+    const size_t windows_bytes = boundary_bytes_for_grid(ix, blocks_accel, shape);
+    uint16_t *scratch = (workspace && shape.accel && workspace_bytes >= windows_bytes + boundary_redo_bytes(n))
                             ? static_cast<uint16_t *>(workspace)
                             : nullptr;
     const int G = scratch ? shape.group : 0;
-    const int first_fill = g_boundary_first_fill;
+    const int pair_walks = g_boundary_first_fill != 0;
     const dim3 grid(scratch ? blocks_accel : grid_for(n, blk, n_cu));
+    // the group kernel's redo list lives behind the windows; its count is cleared in front of every launch
+    int32_t *redo = (scratch && G > 0) ? reinterpret_cast<int32_t *>(static_cast<uint8_t *>(workspace) + ((windows_bytes + 15) & ~(size_t)15)) : nullptr;
+    if (redo)
+        if (hipError_t e = hipMemsetAsync(redo, 0, kRedoHead * sizeof(int32_t), st); e != hipSuccess) return (int)e;
+#define FMX_LAUNCH_GROUP_MODE(BLK, GG, MODE)                                                                              \
+    hipLaunchKernelGGL((k_extract_boundary_group<BLK, GG, MODE>), grid, dim3(BLK), 0, st, ix, from, n, boundary, dst, dst_len, \
+                       offset, out_len, lf, status, aux, scratch, slot_found, slots, pair_walks, order, redo)
 #define FMX_LAUNCH_GROUP(GG)                                                                                            \
     do {                                                                                                                \
-        if (blk == 1024)                                                                                                \
-            hipLaunchKernelGGL((k_extract_boundary_group<1024, GG>), grid, dim3(1024), 0, st, ix, from, n, boundary, mode, dst, \
-                               dst_len, offset, out_len, lf, status, aux, scratch, slot_found, slots, first_fill, order); \
-        else                                                                                                            \
-            hipLaunchKernelGGL((k_extract_boundary_group<512, GG>), grid, dim3(512), 0, st, ix, from, n, boundary, mode, dst,  \
-                               dst_len, offset, out_len, lf, status, aux, scratch, slot_found, slots, first_fill, order); \
+        if (blk == 1024) {                                                                                              \
+            if (mode == 0) FMX_LAUNCH_GROUP_MODE(1024, GG, 0);                                                          \
+            else if (mode == 1) FMX_LAUNCH_GROUP_MODE(1024, GG, 1);                                                     \
+            else FMX_LAUNCH_GROUP_MODE(1024, GG, 2);                                                                    \
+        } else {                                                                                                        \
+            if (mode == 0) FMX_LAUNCH_GROUP_MODE(512, GG, 0);                                                           \
+            else if (mode == 1) FMX_LAUNCH_GROUP_MODE(512, GG, 1);                                                      \
+            else FMX_LAUNCH_GROUP_MODE(512, GG, 2);                                                                     \
+        }                                                                                                               \
     } while (0)
     if (G == 1)
         FMX_LAUNCH_GROUP(1);
@@ -1796,11 +1818,20 @@ int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, i
         FMX_LAUNCH_GROUP(16);
     else if (blk == 1024)
         hipLaunchKernelGGL(k_extract_boundary<1024>, grid, dim3(1024), 0, st, ix, from, n, boundary, mode, dst, dst_len, offset,
-                           out_len, lf, status, aux, scratch, slot_found, slots, order);
+                           out_len, lf, status, aux, scratch, slot_found, slots, order, nullptr);
     else
         hipLaunchKernelGGL(k_extract_boundary<512>, grid, dim3(512), 0, st, ix, from, n, boundary, mode, dst, dst_len, offset,
-                           out_len, lf, status, aux, scratch, slot_found, slots, order);
+                           out_len, lf, status, aux, scratch, slot_found, slots, order, nullptr);
 #undef FMX_LAUNCH_GROUP
+#undef FMX_LAUNCH_GROUP_MODE
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
+    if (redo) {
+        // what the group kernel left on its redo list (usually nothing: the launch then ends at its first instruction), literally;
+        // a few workgroups grid-stride over the list
+        const dim3 redo_grid(n < 64 * 512 ? (unsigned)((n + 511) / 512) : 64u);
+        hipLaunchKernelGGL(k_extract_boundary<512>, redo_grid, dim3(512), 0, st, ix, from, n, boundary, mode, dst, dst_len, offset,
+                           out_len, lf, status, aux, nullptr, slot_found, slots, nullptr, redo);
+    }
     return (int)hipGetLastError();
 }
 

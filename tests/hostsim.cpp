@@ -42,6 +42,7 @@ static DevIndex make_index(const uint8_t *b) {
     d.sb_cache_limit = 0;
     d.wt_size = (uint32_t)h.wt_size;
     d.suffix_table = nullptr;
+    d.self = nullptr;
     d.suffix_chars = 0;
     d.suffix_key_bits = h.wt_sigma <= 256 ? 8 : 16;
     d.suffix_shift = 0;
@@ -258,7 +259,7 @@ void sim_extract_boundary(const uint8_t *blob, const int32_t *froms, int32_t n, 
             bool clean;
             ret = fm_extract_boundary_group<1>(ix, ix.inv_global, mode, froms[q], mapped_boundary, dst + (int64_t)q * dst_len,
                                                dst_len, offset, steps, status, aux, scratch, 1, 1, ix.sample_rate + 1, 0, clean,
-                                               false, accelerate == 3);
+                                               accelerate == 3);
             if (!clean) {
                 status = ST_OK;
                 ret = fm_extract_boundary(ix, ix.inv_global, mode, froms[q], mapped_boundary, dst + (int64_t)q * dst_len,
