@@ -74,6 +74,35 @@ def pmc_counters(text_log2, patterns, sample_rate):
         return None, "no usable profile (%s)" % e
 
 
+def pmc_row_lookup():
+    """-> lookup(row key, queries) = bytes the memory system moved per call of that row (FETCH_SIZE x calibration + WRITE_SIZE
+    summed over the row's kernels: tools/profile_rows.sh -> profiles/pmc_latest.json `rows`), or None when the counters on file
+    were taken on other kernel sources or another batch size"""
+    try:
+        p = json.load(open(PMC_FILE))
+    except (OSError, ValueError):
+        return lambda key, queries: None
+    rows = p.get("rows") or {}
+    fresh = p.get("rows_kernel_source_sha") == kernel_source_sha()
+    # (tools/calibrate_fetch.py: a scattered 16-byte load that misses fills a 64-byte sector, which is what FETCH_SIZE tallies: x 1)
+    factor = ((p.get("calibration") or {}).get("fabric_bytes_per_FETCH_SIZE_byte")) or 1.0
+
+    def lookup(key, queries):
+        r = rows.get(key)
+        if not fresh or not r or (queries is not None and r.get("queries") not in (None, queries)):
+            return None
+        return (r["FETCH_SIZE_KiB"] * factor + r["WRITE_SIZE_KiB"]) * 1024.0
+
+    return lookup
+
+
+def ref_series_module():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ref_series
+
+    return ref_series
+
+
 def build_or_load_index(ia, text_log2, sample_rate, cache_dir, build_device=0, seed=42):
     """index of 2^text_log2 chars of synthetic log; the serialized form is cached under cache_dir.
     Construction runs its suffix-array stage on GPU `build_device` (same index, byte for byte: fmx_build_on_device);
@@ -249,7 +278,7 @@ def compact_line(out):
     if r:
         c["roofline"]["traffic"] = r.get("traffic")
         c["roofline"].update(_pick(r, ("kernel_ms", "alg_bytes_executed_per_launch", "alg_bytes_per_lf_step",
-                                       "lf_steps_executed_per_launch", "frac_whole_step", "traffic_frac", "step_ms_incl_plan",
+                                       "lf_steps_executed_per_launch", "frac_whole_step", "traffic_frac", "frac_algorithmic", "step_ms_incl_plan",
                                        "fabric_line_fills_per_lf_step_executed", "resident_bytes_per_text_byte",
                                        "stage_ms_this_rank")) or {})
         c["roofline"]["kernel"] = _short(r.get("kernel"), 60)
@@ -286,16 +315,20 @@ def compact_line(out):
                                              "" if sr.get("max_matches") is None else " max=%s" % sr["max_matches"])
                 if sr.get("density") is not None:
                     name += " d=%g" % sr["density"]
-                sec.append({"config": _short(name, 44), "ms": sr.get("ms_per_batch", None if sr.get("build_s") is None else sr["build_s"] * 1e3),
-                            "frac": (sr.get("roofline") or {}).get("frac")})
+                rf = sr.get("roofline") or {}
+                sec.append({"config": _short(sr.get("key") or name, 44), "ms": sr.get("ms_per_batch", None if sr.get("build_s") is None else sr["build_s"] * 1e3),
+                            "frac": rf.get("frac"), "alg": rf.get("frac_algorithmic"), "tfrac": rf.get("traffic_frac")})
             continue
         cfg_name = row.get("config") or row.get("metric")
         if isinstance(cfg_name, dict):  # a whole line of another workload (configs[4] inside the N > 1 default run)
             cfg_name = "configs[4] segments: " + str(cfg_name.get("workload"))
+        rf = row.get("roofline") or {}
         sec.append({"config": _short(str(cfg_name).replace("BASELINE.json ", ""), 48),
-                    "ms": row.get("ms", row.get("ms_per_step")), "frac": (row.get("roofline") or {}).get("frac")})
+                    "ms": row.get("ms", row.get("ms_per_step")), "frac": rf.get("frac"), "alg": rf.get("frac_algorithmic"),
+                    "tfrac": rf.get("traffic_frac")})
     if sec:
         c["secondary"] = sec
+        c["secondary_keys"] = "frac = the row's roofline fraction (rule: ref_series.settle_frac), alg = by algorithmic bytes, tfrac = by counter traffic"
     exact = ("bound", "achieved", "peak", "unit", "frac", "traffic", "value", "cores", "kind")
     for blk in ("roofline", "cpu_baseline"):
         if c.get(blk):
@@ -676,7 +709,8 @@ def run_count(ctx, args):
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         pmc, why = pmc_counters(args.text_log2, n, args.sample_rate)
         # FETCH_SIZE tallies a fabric read request at 64 bytes; tools/calibrate_fetch.py measures what a request carries on
-        # this GPU (a 128-byte line, for streamed and for scattered 16-byte loads alike) and stores the factor beside the counters
+        # this GPU — 128 bytes for a streamed read, a 64-byte sector for a scattered 16-byte load that misses (its `halves` case,
+        # round 5; rounds 3 / 4 had assumed whole lines and doubled the figure) — and stores the factor beside the counters
         cal = (pmc or {}).get("calibration") or {}
         fetch_factor = cal.get("fabric_bytes_per_FETCH_SIZE_byte") or 1.0
         traffic_raw = (pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024.0 if pmc else None
@@ -722,9 +756,12 @@ def run_count(ctx, args):
                 "resident_bytes_per_text_byte": (image_bytes + table_bytes) / float(1 << args.text_log2),
                 "frac_reference_equivalent": alg_bytes_reference / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs}
+        ref_series_module().settle_frac(roof, kernel_ms, traffic, ratio_rule=False)
     secondary = None
     if world == 1 and ref is not None and not args.no_secondary:
         secondary = run_secondary(ctx, args, q, ref, orc, text, host_batches[0], off_host)
+        if secondary is not None and not args.no_segments_share and not args.profiling:
+            secondary.append(segments_share_row(ctx, args))
     elif segments_line is not None:
         secondary = [segments_line]
     host_buffers = None
@@ -794,6 +831,38 @@ def run_count(ctx, args):
     if getattr(ctx, "shared", False):
         out["rehearsal"] = "N ranks sharing ONE GPU, collectives over gloo on host tensors: checks the N > 1 code path end to end, measures nothing"
     return out
+
+
+SHARE_PATTERNS = 1 << 20  # configs[4]: 8,388,608 patterns over 8 GPUs
+
+
+def segments_share_row(ctx, args, steps=4, warmup=1, check=4000):
+    """One HBM-resident row on the N = 1 line: one GPU's share of BASELINE.json configs[4] — count() +
+    locate(maxMatches 16) of 8,388,608 / 8 patterns over all 8 segment indexes.  The segment images (1.35 GB) do not fit the 256
+    MiB Infinity Cache, so this row's bytes do come from HBM; every other row of the line works on an image the cache holds."""
+    seg_args = argparse.Namespace(**vars(args))
+    seg_args.patterns_total, seg_args.steps, seg_args.warmup, seg_args.segments_check = SHARE_PATTERNS, steps, warmup, check
+    t0 = time.time()
+    line = run_segments(ctx, seg_args)
+    roof = line.get("roofline") or {}
+    ms = line["ms_per_step"]
+    alg = roof.get("alg_bytes_executed_per_step_per_gpu")
+    row_roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "achieved": None if not alg else alg / (ms * 1e-3) / 1e9, "frac": None if not alg else alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "kernels": "8 x (k_count + k_segment_add_counts) + 8 x (k_count + walk order + k_locate_walk + k_segment_append_hits)",
+                "stage_ms": roof.get("stage_ms_this_rank"), "frac_per_stage_algorithmic": roof.get("frac_per_stage"),
+                "image_bytes": (line.get("config") or {}).get("image_bytes_per_gpu"),
+                "note": "both stages' algorithmic bytes (oracle counting mode on the checked sample, scaled to the batch, minus what the "
+                        "segments' suffix tables answer) over the whole step's time; the image set is HBM-resident"}
+    ref_series_module().settle_frac(row_roof, ms, pmc_row_lookup()("configs[4] share", SHARE_PATTERNS))
+    log("[bench] configs[4] per-GPU share: %.2f ms per step (%.0f s with build and oracle sample)" % (ms, time.time() - t0))
+    return {"config": "BASELINE.json configs[4] per-GPU share: count() + locate(maxMatches 16) of %d patterns over %d segment indexes of "
+                      "2^%d chars, %.2f GB of images resident (beyond the Infinity Cache)"
+                      % (SHARE_PATTERNS, args.segments, args.segment_log2, ((line.get("config") or {}).get("image_bytes_per_gpu") or 0) / 1e9),
+            "ms": ms, "patterns_per_s": line.get("value"), "roofline": row_roof,
+            "checked_vs_oracle": "%s patterns against the %d oracle indexes: counts, found, every position"
+                                 % ((line.get("config") or {}).get("patterns_checked_vs_oracle"), args.segments),
+            "count_checksum": (line.get("config") or {}).get("count_checksum_all_ranks"), "hits": (line.get("config") or {}).get("hits_all_ranks")}
 
 
 def measure_host_buffers(ctx, args, q, pat, off, expect, step_ms):
@@ -886,6 +955,8 @@ def run_secondary(ctx, args, q, ref, orc, text, pat, off):
     K = min(100_000, len(off) - 1)
     M = 16
     res = []
+    rs = ref_series_module()
+    traffic_of = pmc_row_lookup()
 
     def timed(fn, reps):
         # MEAN over 3 x reps back-to-back calls between one HIP-event pair: the headline's standard (minima until round 3)
@@ -952,6 +1023,7 @@ def run_secondary(ctx, args, q, ref, orc, text, pat, off):
                                      "HBM: hits of equal and nested ranges are walked side by side (walk order) and share their lines in "
                                      "L1 / L2, which is how the figure can pass what streaming from HBM allows" % table_chars},
                 "checked_vs_oracle": "all %d patterns: found, every position (SA order), LF-step total" % K})
+    rs.settle_frac(res[-1]["roofline"], ms, traffic_of("configs[2]", K))
 
     # ---- configs[3]: extractUntilBoundary('\n') of the first hit of each pattern, sampleRate-64 index ----
     _t, fm64, path64 = build_or_load_index(ia, args.text_log2, 64, args.cache_dir, build_device=ctx.local_rank)
@@ -999,18 +1071,18 @@ def run_secondary(ctx, args, q, ref, orc, text, pat, off):
                                      "oracle's algorithmic bytes per step; frac_reference_equivalent the steps of the REFERENCE's walk "
                                      "(one re-seek per 4 characters, FM:697-743) over the same time"},
                 "checked_vs_oracle": "all %d queries: lengths, statuses, whole destination rows" % K})
+    rs.settle_frac(res[-1]["roofline"], ms, traffic_of("configs[3]", K))
     fm64.close()
     # ---- the reference's own benchmark shapes on a text with the published data set's alphabet size ----
-    if args.series and not args.no_ref_series:
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import ref_series
-
-        res.append({"config": "reference_series: FmIndexThroughputBenchmark's count / locate (maxMatches 1, 10, 100, 1000) / "
-                              "extract (32 chars) at sampleRate 1, 32, 64, queries of 8..31 chars sampled from a ~1,100-symbol text",
-                    "series": ref_series.run_series(
+    # The DEFAULT run carries the published shape's six rows (count, locate 1 / 100, extract 32 at sampleRate 32; count and extract
+    # at sampleRate 1: ref_series.DEFAULT_PLAN); --series runs all 18 (sampleRate 1 / 32 / 64 x maxMatches 1 / 10 / 100 / 1000).
+    if not args.no_ref_series and not args.profiling:
+        res.append({"config": "reference_series: FmIndexThroughputBenchmark's count / locate / extract (32 chars), queries of 8..31 "
+                              "chars sampled from a ~1,100-symbol text (%s)" % ("all 18 rows" if args.series else "the default six rows"),
+                    "series": rs.run_series(
                         ia, torch, orc, dev, text_log2=args.text_log2, queries=args.series_queries,
-                        sample_rates=(32,) if args.profiling else (1, 32, 64), max_matches=(1,) if args.profiling else (1, 10, 100, 1000),
-                        build_device=ctx.local_rank, log=log)})
+                        plan=rs.full_plan() if args.series else rs.DEFAULT_PLAN,
+                        build_device=ctx.local_rank, log=log, traffic_lookup=traffic_of)})
     if args.series_extras:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import series_extras
@@ -1292,7 +1364,9 @@ def main():
     ap.add_argument("--series", action="store_true",
                     help="also run the reference-shaped series (count / locate 1..1000 / extract-32 at sampleRate 1, 32, 64 on the "
                          "1,100-symbol text; ~100 s, most of it the oracle's check); off by default so that the default run stays short")
-    ap.add_argument("--no-ref-series", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--no-ref-series", action="store_true", help="skip the reference-shaped series (six rows in the default run)")
+    ap.add_argument("--no-segments-share", action="store_true",
+                    help="skip the configs[4] per-GPU share at N = 1 (the one row of the line whose image set does not fit the Infinity Cache)")
     ap.add_argument("--series-extras", action="store_true",
                     help="also run BASELINE.md's remaining rows (tools/series_extras.py): stand-alone RrrVector.rankOnes at 10 M bits, "
                          "locateAndExtract, ingest time and serialized size on the 1,099-symbol text; each oracle-checked (~60 s)")

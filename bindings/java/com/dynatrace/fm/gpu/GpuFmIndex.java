@@ -183,6 +183,16 @@ public final class GpuFmIndex implements AutoCloseable {
         return nativeSave(handle, framed);
     }
 
+    /**
+     * FmIndex.write iterates a HashMap's keySet() (FM:956-960); toSerialized reproduces that order by replaying the map's puts.
+     * {@code false}: a JVM would have turned one of the map's buckets into a tree bin (9 keys in one slot of a table of 64 slots
+     * or more), whose iteration order is not modelled — the stream still loads with FmIndex.read (its reader does not depend on
+     * the order) but may differ from index4j's own bytes inside that bucket (fmx.h: fmx_save_key_order_modelled).
+     */
+    public boolean isSerializedFormVerified() {
+        return nativeSavedOrderModelled(handle);
+    }
+
     @Override
     public void close() {
         if (handle != 0) {
@@ -240,6 +250,8 @@ public final class GpuFmIndex implements AutoCloseable {
     private static native long nativeLoad(byte[] serialized, int device) throws IOException;
 
     private static native byte[] nativeSave(long handle, boolean framed);
+
+    private static native boolean nativeSavedOrderModelled(long handle);
 
     private static native long nativeBuild(char[] text, int sampleRate, boolean enableExtraction, int device,
             boolean buildOnGpu);

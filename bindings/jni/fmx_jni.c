@@ -76,6 +76,16 @@ JNIEXPORT jbyteArray JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeSave(JNI
     return out;
 }
 
+/* whether toSerialized()'s character-map order is the replayed HashMap order (fmx.h fmx_save_key_order_modelled) */
+JNIEXPORT jboolean JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeSavedOrderModelled(JNIEnv *env, jclass c, jlong h) {
+    int rc = fmx_save_key_order_modelled((const fmx_index *)(intptr_t)h);
+    if (rc < 0) {
+        throw_lib_error(env, rc);
+        return JNI_FALSE;
+    }
+    return rc == 1 ? JNI_TRUE : JNI_FALSE;
+}
+
 /* buildOnGpu: the constructor's suffix-array stage (FM:329-394) runs on `device` — same index, byte for byte */
 JNIEXPORT jlong JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeBuild(JNIEnv *env, jclass c, jcharArray text,
                                                                         jint sampleRate, jboolean extract, jint device,

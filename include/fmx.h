@@ -94,6 +94,13 @@ int fmx_load(const uint8_t *ser, size_t len, fmx_index **out);
 /* FmIndex.write(ObjectOutput) FM:948-975; framed != 0 adds the SER:67-79 ObjectOutputStream framing.
  * *buf is owned by the library until fmx_free_buffer. */
 int fmx_save(const fmx_index *idx, int framed, uint8_t **buf, size_t *len);
+/* FM:956-960 writes the character map in java.util.HashMap's keySet() order, which fmx_save reproduces by replaying the map's
+ * puts (capacity doubling, the resize a 9-node bucket forces below 64 slots, insertion order inside a bucket).  1 = that replay
+ * covers this index; 0 = a JVM would have turned one of the buckets into a TREE bin (9 keys in one slot at 64 slots or more:
+ * thousands of symbols whose codes collide modulo the table size), whose iteration order is not modelled — fmx_save's stream is
+ * still one FmIndex.read accepts (its reader does not depend on the order, FM:992-998) but may differ from a JVM's bytes inside
+ * that bucket; < 0 = error.  The Java shim reports it as GpuFmIndex.isSerializedFormVerified(). */
+int fmx_save_key_order_modelled(const fmx_index *idx);
 void fmx_free_buffer(uint8_t *buf);
 void fmx_free(fmx_index *idx);
 

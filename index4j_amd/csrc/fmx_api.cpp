@@ -31,7 +31,7 @@
     int launch_suffix_expand(const fmx::DevIndex &, int, const fmx::SuffixSlot *, uint32_t, int, int, fmx::SuffixSlot *, uint32_t *, uint32_t, hipStream_t); \
     int launch_suffix_insert(const fmx::DevIndex &, const fmx::SuffixSlot *, uint32_t, int, fmx::SuffixSlot *, hipStream_t); \
     int launch_suffix_order1(const fmx::DevIndex &, float *, hipStream_t);                                              \
-    int launch_count_plan(const fmx::DevIndex &, const uint16_t *, const int32_t *, int32_t, void *, size_t, bool, fmx::CountPlan *, \
+    int launch_count_plan(const fmx::DevIndex &, int, const uint16_t *, const int32_t *, int32_t, void *, size_t, bool, fmx::CountPlan *, \
                           hipStream_t);                                                                                 \
     int launch_count(const fmx::DevIndex &, int, const uint16_t *, const int32_t *, const fmx::CountPlan *, bool, int32_t, int32_t *, \
                      int32_t *, int32_t *, int32_t *, hipStream_t);                                                     \
@@ -122,6 +122,13 @@ struct fmx_index {
     // erased whenever anything else plans on the stream or its plan scratch moves: a stale handle then simply
     // means "the caller's order" (k_count maps the characters itself) instead of reading another batch's records
     mutable std::map<void *, Plan> plans;
+    // a side stream (+ events) per caller's stream for the segment-set entry points: segment s + 1's range search runs beside
+    // segment s's walk (locate_segments_impl); created on first use, destroyed with the index
+    struct SideLane {
+        hipStream_t s = nullptr;
+        std::vector<hipEvent_t> ev;
+    };
+    mutable std::map<void *, SideLane> side;
 };
 
 static bool image_is_compact(const fmx_index *idx) { return idx->hdr.compact != 0; }
@@ -241,7 +248,28 @@ int require_device(const fmx_index *idx, bool rrr_handle = false) {
     return FMX_OK;
 }
 
-constexpr int kWsPlan = 0, kWsBoundary = 1, kWsWalk = 2;  // (kWsWalk: the walk order of locate, a plan-like head)
+constexpr int kWsPlan = 0, kWsBoundary = 1, kWsWalk = 2, kWsSegRange = 3;  // (kWsWalk: the walk order of locate, a plan-like head; kWsSegRange: a segment set's second {found, status, range} buffers)
+std::atomic<int> g_segments_overlap{1};  // option "segments_overlap": 0 = a segment set's kernels all on the caller's stream (A/B)
+
+// the side stream of `stream` with at least n_events events (nullptr: could not be made — the caller stays on one stream)
+fmx_index::SideLane *side_lane(const fmx_index *idx, void *stream, size_t n_events) {
+    std::lock_guard<std::mutex> lock(idx->ws_mutex);
+    fmx_index::SideLane &l = idx->side[stream];
+    if (!l.s && hipStreamCreateWithFlags(&l.s, hipStreamNonBlocking) != hipSuccess) {
+        l.s = nullptr;
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    while (l.ev.size() < n_events) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        l.ev.push_back(e);
+    }
+    return &l;
+}
 
 // scratch of at least `bytes` for work enqueued on `stream`; reused across calls on the same stream
 int get_workspace(const fmx_index *idx, void *stream, int kind, size_t bytes, void **out) {
@@ -613,6 +641,10 @@ int fmx_set_option(const char *name, int value) {
     if (!name) return fail(FMX_E_ARG, "unknown option or bad value");
     if (!strcmp(name, "suffix_table")) g_suffix_table_in_use = value != 0;
     if (!strcmp(name, "plan_sa_key") && value >= 0 && value <= 2) g_plan_sa_key_api = value;
+    if (!strcmp(name, "segments_overlap")) {
+        g_segments_overlap = value != 0;
+        return FMX_OK;
+    }
     {  // launch options go to both kernel sets
         const int a = fmx::set_option(name, value), b = fmxc::set_option(name, value);
         if (a || b) return fail(FMX_E_ARG, "unknown option or bad value");
@@ -706,6 +738,15 @@ int fmx_save(const fmx_index *idx, int framed, uint8_t **buf, size_t *len) {
     });
 }
 
+int fmx_save_key_order_modelled(const fmx_index *idx) {
+    return guarded([&]() -> int {
+    if (!idx) return fail(FMX_E_ARG, "null argument");
+    if (!idx->has_model || idx->wavelet_only || idx->rrr_only)
+        return fail(FMX_E_ARG, "nothing to serialize (device-attached or wavelet-only handle)");
+    return fmx::key_order_is_modelled(idx->model) ? 1 : 0;
+    });
+}
+
 void fmx_free_buffer(uint8_t *buf) { free(buf); }
 
 void fmx_free(fmx_index *idx) {
@@ -717,6 +758,13 @@ void fmx_free(fmx_index *idx) {
     if (idx->d_suffix_table) (void)hipFree(idx->d_suffix_table);
     if (idx->d_suffix_order1) (void)hipFree(idx->d_suffix_order1);
     if (idx->d_self) (void)hipFree(idx->d_self);
+    for (auto &kv : idx->side) {
+        for (hipEvent_t e : kv.second.ev) (void)hipEventDestroy(e);
+        if (kv.second.s) {
+            (void)hipStreamSynchronize(kv.second.s);
+            (void)hipStreamDestroy(kv.second.s);
+        }
+    }
     delete idx;
 }
 
@@ -1020,7 +1068,7 @@ static int plan_order(const fmx_index *idx, const uint16_t *d_pat, const int32_t
     if (rc) return rc;
     if (!ws) return FMX_OK;
     // a per-stream workspace keeps its head zeroed between plans; a per-call block comes from the cache: clear it
-    int e = k_launch_count_plan(idx, idx->dev, d_pat, d_pat_off, n, ws, ws_bytes, !scratch.per_call, plan,
+    int e = k_launch_count_plan(idx, idx->dev, idx->n_cu, d_pat, d_pat_off, n, ws, ws_bytes, !scratch.per_call, plan,
                                    static_cast<hipStream_t>(scratch.stream));
     if (e) {
         // A plan that stopped half way (k_plan_codes ran, k_plan_scatter did not) leaves its histogram in the workspace's
@@ -1355,23 +1403,59 @@ static int locate_segments_impl(const fmx_index *const *segs, int32_t n_segs, co
     const size_t ws_bytes = k_walk_workspace_bytes(segs[0], segs[0]->dev, n);
     rc = scratch.get(kWsWalk, ws_bytes, &ws);
     if (rc) return rc;
+    // Segment s + 1's range search depends on the batch and its plan alone: it runs on a side stream BESIDE segment s's walk,
+    // into a second set of {found, status, range} buffers (the sets alternate; the side stream waits for the append that last
+    // read the set it is about to overwrite).  Two event edges per segment (~10 us) against a range search of 0.1 ms per million
+    // patterns: only for batches that large, and only for the per-stream form (a host call's own stream lives for one call).
+    int32_t *set_found[2] = {seg_found, nullptr}, *set_status[2] = {seg_status, nullptr}, *set_range[2] = {range, nullptr};
+    fmx_index::SideLane *lane = nullptr;
+    if (g_segments_overlap && !scratch.per_call && n_segs > 1 && n >= 262144) {
+        void *second = nullptr;
+        rc = scratch.get(kWsSegRange, (size_t)n * 4 * sizeof(int32_t), &second);
+        if (rc) return rc;
+        lane = side_lane(segs[0], scratch.stream, 2 * (size_t)n_segs + 1);
+        if (lane) {
+            set_found[1] = static_cast<int32_t *>(second);
+            set_status[1] = set_found[1] + n;
+            set_range[1] = set_found[1] + 2 * (size_t)n;
+        }
+    }
+    auto count_into = [&](int32_t s, hipStream_t on) {
+        return k_launch_count(segs[s], segs[s]->dev, segs[s]->n_cu, d_pat, d_pat_off, &plan, s != 0, n, set_found[lane ? s & 1 : 0],
+                              nullptr, set_status[lane ? s & 1 : 0], set_range[lane ? s & 1 : 0], on);
+    };
+    // (events of the lane: [0] = the plan is made, [1 + s] = segment s's ranges are there, [1 + n_segs + s] = segment s is appended)
+    auto ev = [&](size_t i) { return lane->ev[i]; };
+    int e = count_into(0, st);
+    if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
+    if (lane) {
+        HIP_TRY(hipEventRecord(ev(0), st));  // (behind the plan and segment 0's search: the side stream starts from here)
+        HIP_TRY(hipStreamWaitEvent(lane->s, ev(0), 0));
+    }
     for (int32_t s = 0; s < n_segs; ++s) {
-        int e = k_launch_count(segs[s], segs[s]->dev, segs[s]->n_cu, d_pat, d_pat_off, &plan, s != 0, n, seg_found, nullptr,
-                                  seg_status, range, st);
-        if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
+        const int b = lane ? s & 1 : 0;
+        if (lane && s + 1 < n_segs) {
+            if (s >= 1) HIP_TRY(hipStreamWaitEvent(lane->s, ev(1 + (size_t)n_segs + (size_t)(s - 1)), 0));  // set (s + 1) & 1 was segment s - 1's
+            e = count_into(s + 1, lane->s);
+            if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
+            HIP_TRY(hipEventRecord(ev(1 + (size_t)(s + 1)), lane->s));
+        } else if (!lane && s >= 1) {
+            e = count_into(s, st);
+            if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
+        }
+        if (lane && s >= 1) HIP_TRY(hipStreamWaitEvent(st, ev(1 + (size_t)s), 0));
         // like the caller's loop `n += seg.locate(p, 0, len, locations, maxMatches - n)`: hits already
         // taken from earlier segments shrink this segment's limit
-        {
-            e = k_launch_locate_walk(segs[s], segs[s]->dev, segs[s]->n_cu, range, n, max_matches, seg_locs, max_matches,
-                                     seg_found, nullptr, seg_status, s ? d_found : nullptr, ws, ws_bytes, !scratch.per_call, st);
-            if (e) {
-                if (ws && !scratch.per_call) (void)hipMemsetAsync(ws, 0, fmx::kPlanHeadBytes, st);
-                return fail(FMX_E_HIP, std::string("k_locate_walk launch: ") + hipGetErrorString((hipError_t)e));
-            }
+        e = k_launch_locate_walk(segs[s], segs[s]->dev, segs[s]->n_cu, set_range[b], n, max_matches, seg_locs, max_matches,
+                                 set_found[b], nullptr, set_status[b], s ? d_found : nullptr, ws, ws_bytes, !scratch.per_call, st);
+        if (e) {
+            if (ws && !scratch.per_call) (void)hipMemsetAsync(ws, 0, fmx::kPlanHeadBytes, st);
+            return fail(FMX_E_HIP, std::string("k_locate_walk launch: ") + hipGetErrorString((hipError_t)e));
         }
-        e = fmx::launch_segment_append_hits(d_locs, d_found, d_status, seg_locs, seg_found, seg_status, n, max_matches,
+        e = fmx::launch_segment_append_hits(d_locs, d_found, d_status, seg_locs, set_found[b], set_status[b], n, max_matches,
                                             seg_base[s], s == 0, st);
         if (e) return fail(FMX_E_HIP, std::string("k_segment_append_hits launch: ") + hipGetErrorString((hipError_t)e));
+        if (lane && s + 2 < n_segs) HIP_TRY(hipEventRecord(ev(1 + (size_t)n_segs + (size_t)s), st));
     }
     return FMX_OK;
 }

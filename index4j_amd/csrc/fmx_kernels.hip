@@ -894,6 +894,135 @@ __host__ __device__ constexpr size_t order1_lds_bytes(int bins, int sigma) {
     return (size_t)bins * 4 + (size_t)sigma * sigma * 8 + ((size_t)sigma + 1) * 4;
 }
 
+// what the plan kernels keep in LDS beside their histogram (k_plan_codes, k_plan_fused)
+struct PlanTables {
+    const int16_t *s_map;  // the character map's first 256 entries
+    const float2 *s_o1;    // the order-1 table (o1) ...
+    const int32_t *s_c;    // ... and cumulativeCounts
+    bool o1;
+    int sigma, below, fine_shift, bins;
+};
+__device__ __forceinline__ bool plan_uses_order1(const DevIndex &ix, const SortShape &sh, int code_bits, int bins, size_t extra_lds) {
+    return code_bits == 8 && sh.sa_key == 2 && ix.suffix_order1 != nullptr && ix.wt_sigma <= kOrder1MaxSigma &&
+           order1_lds_bytes(bins, ix.wt_sigma) + extra_lds <= kPlanCodesLdsMax;
+}
+// stages the tables behind `after` (the first free LDS word); the caller's barrier follows
+__device__ __forceinline__ PlanTables plan_tables_stage(const DevIndex &ix, const SortShape &sh, int16_t *s_map, uint32_t *after, bool o1) {
+    PlanTables t;
+    t.sigma = ix.wt_sigma;
+    t.bins = 1 << sh.coarse_bits;
+    t.below = sh.total_bits - sh.coarse_bits;
+    t.fine_shift = t.below > 8 ? t.below - 8 : 0;  // the fine bin of a record: kFineBits key bits ending 8 bits below the coarse bits
+    t.o1 = o1;
+    for (int i = threadIdx.x; i < 256; i += kTileThreads) s_map[i] = ix.char2code[i];
+    float2 *s_o1 = reinterpret_cast<float2 *>(after);
+    int32_t *s_c = reinterpret_cast<int32_t *>(s_o1 + (o1 ? t.sigma * t.sigma : 0));
+    if (o1) {
+        const float2 *src = reinterpret_cast<const float2 *>(ix.suffix_order1);
+        for (int i = threadIdx.x; i < t.sigma * t.sigma; i += kTileThreads) s_o1[i] = src[i];
+        for (int i = threadIdx.x; i <= t.sigma; i += kTileThreads) s_c[i] = i < ix.n_c ? ix.C[i] : ix.length;
+    }
+    t.s_map = s_map;
+    t.s_o1 = s_o1;
+    t.s_c = s_c;
+    return t;
+}
+
+// the record of ONE pattern — {code word, key, length | fine bin} — and its bin of the bucket pass
+template <int kCodeBits>
+__device__ __forceinline__ Quad plan_record(const DevIndex &ix, const PlanTables &L, const SortShape &sh, const uint16_t *__restrict__ pat,
+                                            int32_t beg, int32_t m, const TailWords &tail, uint32_t &bin) {
+    const int sigma = L.sigma;
+    uint32_t ch[8];
+    pattern_tail_chars(tail, pat, beg, m, ch);
+    const uint64_t word = pattern_code_word<kCodeBits>(ix, L.s_map, ch, m);
+    uint32_t key;
+    if (sh.sa_key) {
+        // where the pattern's backward search stands when k_count takes it up: the first SA row of its tabulated suffix
+        // — 0 for a pattern that ends at once.  sa_key 1: the suffix table's own answer (one lookup at a random slot of
+        // the table per pattern: 14 us of the pass); sa_key 2: an ESTIMATE of that row from the table's two-character
+        // strings alone (a few hundred slots: cache-resident) — the row range of the suffix's first two characters,
+        // narrowed character by character by the share the next character has after its predecessor (an order-1 chain:
+        // row ~ s(xy) + |xy| * (F(z|y) + P(z|y) * (F(u|z) + ...)), F / P = where the two-character string yz starts inside
+        // y's rows and how much of them it takes).  The estimate is monotone in the suffix's lexicographic order, which
+        // is all the bucket pass needs; results never depend on it.
+        key = 0;
+        constexpr uint32_t cmask = (1u << kCodeBits) - 1u;
+        const int32_t c_last = (int32_t)(word & cmask);
+        if (m > 0 && c_last != 0) {
+            int32_t start = ix.C[c_last], end = 0, back = 0;
+            int len = fm_suffix_len(ix, m);
+            if (len > 64 / kCodeBits) len = 64 / kCodeBits;
+            if (len >= 2 && kCodeBits == ix.suffix_key_bits && sh.sa_key == 1) {
+                const int bits = len * kCodeBits;
+                const uint64_t tk = bits >= 64 ? word : (word & ((1ull << bits) - 1ull));
+                if ((uint32_t)(tk >> (bits - kCodeBits)) != 0u && tk != kSuffixEmpty) (void)fm_suffix_lookup(ix, tk, len, start, end, back);
+            } else if (len >= 2 && L.o1) {
+                // the same estimate as below from the LDS copy of the order-1 table
+                auto code_at = [&](int j) { return (uint32_t)(word >> (j * kCodeBits)) & cmask; };
+                uint32_t x = code_at(len - 1), y = code_at(len - 2);
+                if (x >= (uint32_t)sigma) x = 0;
+                if (y >= (uint32_t)sigma) y = 0;
+                float lo = (float)L.s_c[x ? x : ((uint32_t)c_last < (uint32_t)sigma ? c_last : 0)], width = 0.0f;
+                if (x != 0 && y != 0) {
+                    float2 fp = L.s_o1[x * sigma + y];
+                    if (fp.y > 0.0f) {
+                        const float nx = (float)(L.s_c[x + 1] - L.s_c[x]);
+                        lo = (float)L.s_c[x] + fp.x * nx;
+                        width = fp.y * nx;
+                        for (int j = len - 3; j >= 0 && width >= 1.0f; --j) {
+                            x = y;
+                            y = code_at(j);
+                            if (y == 0 || y >= (uint32_t)sigma) break;
+                            fp = L.s_o1[x * sigma + y];
+                            if (fp.y <= 0.0f) break;
+                            lo += width * fp.x;
+                            width *= fp.y;
+                        }
+                    }
+                }
+                start = (int32_t)lo;
+                if (start < 0) start = 0;
+                if (start > ix.length) start = ix.length;
+            } else if (len >= 2 && kCodeBits == ix.suffix_key_bits) {
+                // codes of the suffix, w[j] = j characters before the pattern's end; its first character is w[len - 1]
+                auto code_at = [&](int j) { return (uint32_t)(word >> (j * kCodeBits)) & cmask; };
+                uint32_t x = code_at(len - 1), y = code_at(len - 2);
+                float lo = (float)ix.C[x ? x : c_last], width = 0.0f;
+                int32_t s2 = 0, e2 = 0;
+                if (x != 0 && y != 0 && fm_suffix_lookup(ix, (uint64_t)y | ((uint64_t)x << kCodeBits), 2, s2, e2, back)) {
+                    lo = (float)s2;
+                    width = (float)(e2 - s2);
+                    for (int j = len - 3; j >= 0 && width >= 1.0f; --j) {
+                        x = y;
+                        y = code_at(j);
+                        if (y == 0 || !fm_suffix_lookup(ix, (uint64_t)y | ((uint64_t)x << kCodeBits), 2, s2, e2, back)) break;
+                        const float cx = (float)ix.C[x], nx = (float)(ix.C[x + 1] - ix.C[x]);
+                        lo += width * ((float)s2 - cx) / nx;
+                        width *= (float)(e2 - s2) / nx;
+                    }
+                }
+                start = (int32_t)lo;
+                if (start < 0) start = 0;
+                if (start > ix.length) start = ix.length;
+            }
+            key = (uint32_t)start;
+        }
+    } else {
+        key = suffix_key(word, kCodeBits, sh.chars, sh.bits);
+    }
+    const uint32_t lenf = m < 0 ? 0u : ((uint32_t)m < kPlanLongPattern ? (uint32_t)m : kPlanLongPattern);
+    Quad q;
+    q.x = (uint32_t)word;
+    q.y = (uint32_t)(word >> 32);
+    q.z = key;
+    q.w = lenf | (((key >> L.fine_shift) & ((1u << kFineBits) - 1u)) << 22);  // (PlanRec.a / .m)
+    uint32_t c = key >> L.below;
+    if (c >= (uint32_t)L.bins) c = (uint32_t)L.bins - 1u;  // cannot happen for a validated index (codes < 2^bits)
+    bin = c;
+    return q;
+}
+
 // pass 1: records, coarse keys, global histogram
 template <int kCodeBits>
 __global__ __launch_bounds__(kTileThreads) void k_plan_codes(DevIndex ix, const uint16_t *__restrict__ pat,
@@ -905,22 +1034,9 @@ __global__ __launch_bounds__(kTileThreads) void k_plan_codes(DevIndex ix, const 
     __shared__ int16_t s_map[256];
     const int bins = 1 << sh.coarse_bits;
     for (int i = threadIdx.x; i < bins; i += kTileThreads) s_hist[i] = 0;
-    for (int i = threadIdx.x; i < 256; i += kTileThreads) s_map[i] = ix.char2code[i];
     // sa_key 2 with the order-1 table (small alphabets): the table and cumulativeCounts behind the histogram
-    const int sigma = ix.wt_sigma;
-    const bool o1 = kCodeBits == 8 && sh.sa_key == 2 && ix.suffix_order1 != nullptr && sigma <= kOrder1MaxSigma &&
-                    order1_lds_bytes(bins, sigma) <= kPlanCodesLdsMax;
-    float2 *s_o1 = reinterpret_cast<float2 *>(s_hist + bins);
-    int32_t *s_c = reinterpret_cast<int32_t *>(s_o1 + (o1 ? sigma * sigma : 0));
-    if (o1) {
-        const float2 *src = reinterpret_cast<const float2 *>(ix.suffix_order1);
-        for (int i = threadIdx.x; i < sigma * sigma; i += kTileThreads) s_o1[i] = src[i];
-        for (int i = threadIdx.x; i <= sigma; i += kTileThreads) s_c[i] = i < ix.n_c ? ix.C[i] : ix.length;
-    }
+    const PlanTables L = plan_tables_stage(ix, sh, s_map, s_hist + bins, plan_uses_order1(ix, sh, kCodeBits, bins, 0));
     __syncthreads();
-    // the fine bin of a record: kFineBits key bits ending 8 bits below the coarse bits (or at the key's end)
-    const int below = sh.total_bits - sh.coarse_bits;
-    const int fine_shift = below > 8 ? below - 8 : 0;
     const int64_t base = (int64_t)blockIdx.x * kTile;
     const int32_t m_first = pat_off[1] - pat_off[0];  // (n >= 1) the batch is of ONE length if every pattern has this one
     bool differs = false;
@@ -944,95 +1060,10 @@ __global__ __launch_bounds__(kTileThreads) void k_plan_codes(DevIndex ix, const 
         for (int k = 0; k < kGroup; ++k) {
             const int64_t p = base + (int64_t)(k0 + k) * kTileThreads + threadIdx.x;
             if (p >= n) continue;
-            const int32_t m = len[k];
-            differs |= m != m_first;
-            uint32_t ch[8];
-            pattern_tail_chars(tail[k], pat, beg[k], m, ch);
-            const uint64_t word = pattern_code_word<kCodeBits>(ix, s_map, ch, m);
-            uint32_t key;
-            if (sh.sa_key) {
-                // where the pattern's backward search stands when k_count takes it up: the first SA row of its tabulated suffix
-                // — 0 for a pattern that ends at once.  sa_key 1: the suffix table's own answer (one lookup at a random slot of
-                // the table per pattern: 14 us of the pass); sa_key 2: an ESTIMATE of that row from the table's two-character
-                // strings alone (a few hundred slots: cache-resident) — the row range of the suffix's first two characters,
-                // narrowed character by character by the share the next character has after its predecessor (an order-1 chain:
-                // row ~ s(xy) + |xy| * (F(z|y) + P(z|y) * (F(u|z) + ...)), F / P = where the two-character string yz starts inside
-                // y's rows and how much of them it takes).  The estimate is monotone in the suffix's lexicographic order, which
-                // is all the bucket pass needs; results never depend on it.
-                key = 0;
-                constexpr uint32_t cmask = (1u << kCodeBits) - 1u;
-                const int32_t c_last = (int32_t)(word & cmask);
-                if (m > 0 && c_last != 0) {
-                    int32_t start = ix.C[c_last], end = 0, back = 0;
-                    int len = fm_suffix_len(ix, m);
-                    if (len > 64 / kCodeBits) len = 64 / kCodeBits;
-                    if (len >= 2 && kCodeBits == ix.suffix_key_bits && sh.sa_key == 1) {
-                        const int bits = len * kCodeBits;
-                        const uint64_t tk = bits >= 64 ? word : (word & ((1ull << bits) - 1ull));
-                        if ((uint32_t)(tk >> (bits - kCodeBits)) != 0u && tk != kSuffixEmpty) (void)fm_suffix_lookup(ix, tk, len, start, end, back);
-                    } else if (len >= 2 && o1) {
-                        // the same estimate as below from the LDS copy of the order-1 table
-                        auto code_at = [&](int j) { return (uint32_t)(word >> (j * kCodeBits)) & cmask; };
-                        uint32_t x = code_at(len - 1), y = code_at(len - 2);
-                        if (x >= (uint32_t)sigma) x = 0;
-                        if (y >= (uint32_t)sigma) y = 0;
-                        float lo = (float)s_c[x ? x : ((uint32_t)c_last < (uint32_t)sigma ? c_last : 0)], width = 0.0f;
-                        if (x != 0 && y != 0) {
-                            float2 fp = s_o1[x * sigma + y];
-                            if (fp.y > 0.0f) {
-                                const float nx = (float)(s_c[x + 1] - s_c[x]);
-                                lo = (float)s_c[x] + fp.x * nx;
-                                width = fp.y * nx;
-                                for (int j = len - 3; j >= 0 && width >= 1.0f; --j) {
-                                    x = y;
-                                    y = code_at(j);
-                                    if (y == 0 || y >= (uint32_t)sigma) break;
-                                    fp = s_o1[x * sigma + y];
-                                    if (fp.y <= 0.0f) break;
-                                    lo += width * fp.x;
-                                    width *= fp.y;
-                                }
-                            }
-                        }
-                        start = (int32_t)lo;
-                        if (start < 0) start = 0;
-                        if (start > ix.length) start = ix.length;
-                    } else if (len >= 2 && kCodeBits == ix.suffix_key_bits) {
-                        // codes of the suffix, w[j] = j characters before the pattern's end; its first character is w[len - 1]
-                        auto code_at = [&](int j) { return (uint32_t)(word >> (j * kCodeBits)) & cmask; };
-                        uint32_t x = code_at(len - 1), y = code_at(len - 2);
-                        float lo = (float)ix.C[x ? x : c_last], width = 0.0f;
-                        int32_t s2 = 0, e2 = 0;
-                        if (x != 0 && y != 0 && fm_suffix_lookup(ix, (uint64_t)y | ((uint64_t)x << kCodeBits), 2, s2, e2, back)) {
-                            lo = (float)s2;
-                            width = (float)(e2 - s2);
-                            for (int j = len - 3; j >= 0 && width >= 1.0f; --j) {
-                                x = y;
-                                y = code_at(j);
-                                if (y == 0 || !fm_suffix_lookup(ix, (uint64_t)y | ((uint64_t)x << kCodeBits), 2, s2, e2, back)) break;
-                                const float cx = (float)ix.C[x], nx = (float)(ix.C[x + 1] - ix.C[x]);
-                                lo += width * ((float)s2 - cx) / nx;
-                                width *= (float)(e2 - s2) / nx;
-                            }
-                        }
-                        start = (int32_t)lo;
-                        if (start < 0) start = 0;
-                        if (start > ix.length) start = ix.length;
-                    }
-                    key = (uint32_t)start;
-                }
-            } else {
-                key = suffix_key(word, kCodeBits, sh.chars, sh.bits);
-            }
-            const uint32_t lenf = m < 0 ? 0u : ((uint32_t)m < kPlanLongPattern ? (uint32_t)m : kPlanLongPattern);
-            Quad q;
-            q.x = (uint32_t)word;
-            q.y = (uint32_t)(word >> 32);
-            q.z = key;
-            q.w = lenf | (((key >> fine_shift) & ((1u << kFineBits) - 1u)) << 22);  // (PlanRec.a / .m)
+            differs |= len[k] != m_first;
+            uint32_t c;
+            const Quad q = plan_record<kCodeBits>(ix, L, sh, pat, beg[k], len[k], tail[k], c);
             *reinterpret_cast<Quad *>(recs + p) = q;
-            uint32_t c = key >> below;
-            if (c >= (uint32_t)bins) c = (uint32_t)bins - 1u;  // cannot happen for a validated index (codes < 2^bits)
             atomicAdd(&s_hist[c], 1u);
         }
     }
@@ -1044,6 +1075,160 @@ __global__ __launch_bounds__(kTileThreads) void k_plan_codes(DevIndex ix, const 
     for (int i = threadIdx.x; i < bins; i += kTileThreads) {
         const uint32_t v = s_hist[i];
         if (v) atomicAdd(&ghist[i], v);
+    }
+}
+
+// The plan stage as ONE launch (round 5; k_plan_codes + k_plan_scatter: 22 + 21 us at 1 M patterns, two thirds of it
+// start-up, drain and the records' round trip through memory).  A workgroup keeps its tile's records in REGISTERS, publishes
+// the tile's histogram with RETURNING atomic adds — what an add returns is this tile's first slot inside the bin: the cursor
+// pass of k_plan_scatter is gone —, meets the other workgroups at a grid barrier, scans the complete histogram (agent-scope
+// loads: the counts live where the atomics executed, not in this XCD's L2) and scatters its records.
+// The barrier is BOUNDED: launch_count_plan offers this kernel only to batches of at most one tile per CU, but what else
+// runs on the device (another stream's k_count, another process) decides whether all tiles are resident at once.  A workgroup
+// that has polled `spin_limit` times raises ABORT in the barrier word; from then on every workgroup writes its records at
+// their own indices instead: a valid plan in the caller's order (k_count runs as planned, only unsorted).  The word decides
+// for all (see the barrier below).  Histogram, barrier word and ticket are zero again when the last workgroup leaves (as
+// k_plan_scatter leaves them).
+constexpr uint32_t kPlanAbort = 0x80000000u;
+template <int kCodeBits>
+__global__ __launch_bounds__(kTileThreads) void k_plan_fused(DevIndex ix, const uint16_t *__restrict__ pat,
+                                                             const int32_t *__restrict__ pat_off, int32_t n, SortShape sh,
+                                                             PlanRec *__restrict__ recs_out, uint32_t *__restrict__ ghist,
+                                                             uint32_t *__restrict__ ticket, uint32_t *__restrict__ mixed,
+                                                             uint32_t epoch, uint32_t spin_limit) {
+    // [bins] this tile's counts, then its first slots | the tables of the records' keys; behind the barrier, when the records
+    // are made: [bins] scan of the histogram
+    extern __shared__ uint32_t s_mem[];
+    __shared__ int16_t s_map[256];
+    __shared__ uint32_t s_wave[kTileThreads / 64];
+    __shared__ uint32_t s_go;
+    const int bins = 1 << sh.coarse_bits;
+    uint32_t *s_cnt = s_mem, *s_scan = s_mem + bins;
+    uint32_t *bar = ticket + 3;
+    for (int i = threadIdx.x; i < bins; i += kTileThreads) s_cnt[i] = 0;
+    const PlanTables L = plan_tables_stage(ix, sh, s_map, s_mem + bins, plan_uses_order1(ix, sh, kCodeBits, bins, 0));
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kTile;
+    const int32_t m_first = pat_off[1] - pat_off[0];
+    bool differs = false;
+    Quad rec[kTileItems];
+    uint32_t bin[kTileItems], rank[kTileItems];
+    {
+        int32_t beg[kTileItems], len[kTileItems];
+        TailWords tail[kTileItems];
+#pragma unroll
+        for (int k = 0; k < kTileItems; ++k) {
+            const int64_t p = base + (int64_t)k * kTileThreads + threadIdx.x;
+            beg[k] = 0;
+            len[k] = -1;
+            if (p < n) {
+                beg[k] = pat_off[p];
+                len[k] = pat_off[p + 1] - beg[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kTileItems; ++k) tail[k] = pattern_tail_load(pat, beg[k], len[k]);
+#pragma unroll
+        for (int k = 0; k < kTileItems; ++k) {
+            const int64_t p = base + (int64_t)k * kTileThreads + threadIdx.x;
+            bin[k] = 0xffffffffu;
+            rank[k] = 0;
+            if (p >= n) continue;
+            differs |= len[k] != m_first;
+            rec[k] = plan_record<kCodeBits>(ix, L, sh, pat, beg[k], len[k], tail[k], bin[k]);
+            rec[k].z = (uint32_t)p;  // PlanRec.a of the final order: the pattern's index
+            rank[k] = atomicAdd(&s_cnt[bin[k]], 1u);
+        }
+    }
+    if (__syncthreads_or(differs ? 1 : 0) && threadIdx.x == 0) {
+        volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(mixed);
+        if (*flag != epoch) *flag = epoch;
+    }
+    // publish: one returning add per (tile, non-empty bin); all of a thread's adds are issued before the first result is used
+    for (int i0 = 0; i0 < bins; i0 += kTileThreads * 8) {
+        uint32_t got[8], cnt[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * kTileThreads + (int)threadIdx.x;
+            cnt[k] = i < bins ? s_cnt[i] : 0u;
+            got[k] = cnt[k] ? atomicAdd(&ghist[i], cnt[k]) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * kTileThreads + (int)threadIdx.x;
+            if (i < bins) s_cnt[i] = got[k];  // from here on: this tile's first slot inside the bin
+        }
+    }
+    __syncthreads();  // every add of this tile has returned: it is part of the histogram
+    if (threadIdx.x == 0) {
+        // arrive with ONE add (a compare-and-swap loop here serialised the 256 arrivals: 0.5 ms).  The abort bit can only be
+        // set by a compare-and-swap against an INCOMPLETE count, so "bit set" and "count complete without the bit" exclude each
+        // other for good: whoever sees the bit gives up (arrivals after it included, whatever their adds do to the count),
+        // whoever sees the complete count without it passes.
+        uint32_t go = 0;
+        uint32_t v = atomicAdd(bar, 1u) + 1u;
+        for (uint32_t polls = 0; !go; ++polls) {
+            if (v & kPlanAbort)
+                go = 2;
+            else if (v == gridDim.x)
+                go = 1;
+            else if (polls >= spin_limit) {
+                const uint32_t seen = atomicCAS(bar, v, v | kPlanAbort);
+                v = seen == v ? (v | kPlanAbort) : seen;
+            } else {
+                __builtin_amdgcn_s_sleep(4);
+                v = __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        s_go = go;
+    }
+    __syncthreads();
+    if (s_go == 1) {
+        // exclusive scan of the complete histogram: coalesced agent-scope loads into LDS, per-thread chunks of consecutive
+        // bins, wave scan, wave totals through LDS (k_plan_scatter's scan)
+        for (int i = threadIdx.x; i < bins; i += kTileThreads) s_scan[i] = __hip_atomic_load(&ghist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int per = (bins + kTileThreads - 1) / kTileThreads;
+        const int lo = (int)threadIdx.x * per;
+        uint32_t sum = 0;
+        for (int i = lo; i < lo + per && i < bins; ++i) sum += s_scan[i];
+        uint32_t incl = sum;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        for (int w = 0; w < wave; ++w) before += s_wave[w];
+        uint32_t run = before + incl - sum;
+        for (int i = lo; i < lo + per && i < bins; ++i) {
+            const uint32_t c = s_scan[i];
+            s_scan[i] = run;
+            run += c;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kTileItems; ++k)
+            if (bin[k] != 0xffffffffu)
+                *reinterpret_cast<Quad *>(recs_out + (s_scan[bin[k]] + s_cnt[bin[k]] + rank[k])) = rec[k];
+    } else {
+        // aborted: the records at their own indices — the caller's order, with code words
+#pragma unroll
+        for (int k = 0; k < kTileItems; ++k)
+            if (bin[k] != 0xffffffffu) *reinterpret_cast<Quad *>(recs_out + (base + (int64_t)k * kTileThreads + threadIdx.x)) = rec[k];
+    }
+    // the last workgroup to leave zeroes histogram, barrier word and ticket for the next plan in this workspace
+    __syncthreads();
+    if (threadIdx.x == 0) s_go = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (s_go) {
+        for (int i = threadIdx.x; i < bins; i += kTileThreads) ghist[i] = 0;
+        if (threadIdx.x == 0) {
+            *bar = 0;
+            *ticket = 0;
+        }
     }
 }
 
@@ -1330,6 +1515,9 @@ static std::atomic<int> g_plan_fine{1};  // 0 = skip the window-local fine order
 // 0 = order by the trailing characters' codes even where a suffix table exists; 1 = by the SA row the table answers; 2 = by an
 // estimate of that row from the table's two-character strings (SortShape.sa_key)
 static std::atomic<int> g_plan_sa_key{2};
+// 1 = the plan stage of a batch of at most one tile per CU is ONE launch (k_plan_fused); 0 = k_plan_codes + k_plan_scatter (A/B)
+static std::atomic<int> g_plan_fused{1};
+static std::atomic<int> g_plan_spin_limit{4096};  // polls of k_plan_fused's barrier before a workgroup aborts the order (~1 us each)
 // locate: batches at least this large walk their hits by the first row of the patterns' SA ranges (0 = always in the caller's
 // order).  Measured on configs[1]'s index, <= 16 hits per pattern (tools/locate_order_probe.py): 16,384 patterns +8 % (the two
 // or three short kernels in front), 32,768 -5 %, 100,000 -24 %, 1,048,576 -43 %.
@@ -1385,6 +1573,15 @@ int set_option(const char *name, int value) {
     if (!strcmp(name, "plan_sa_key")) {
         if (value < 0 || value > 2) return -1;
         g_plan_sa_key = value;
+        return 0;
+    }
+    if (!strcmp(name, "plan_fused")) {
+        g_plan_fused = value != 0;
+        return 0;
+    }
+    if (!strcmp(name, "plan_spin_limit")) {
+        if (value < 0) return -1;
+        g_plan_spin_limit = value;
         return 0;
     }
     if (!strcmp(name, "plan_fine")) {
@@ -1473,7 +1670,7 @@ size_t count_workspace_bytes(const DevIndex &ix, int32_t n) {
 // Orders a batch: plan->recs = the patterns' records in processing order (nullptr: batch too small, or no
 // workspace).  workspace: count_workspace_bytes(ix, n); head_is_zero: the workspace's head is known to be zero
 // (a per-stream workspace keeps that invariant itself), else it is cleared first.  Returns a hipError_t value.
-int launch_count_plan(const DevIndex &ix, const uint16_t *pat, const int32_t *off, int32_t n, void *workspace,
+int launch_count_plan(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_t *off, int32_t n, void *workspace,
                       size_t workspace_bytes, bool head_is_zero, CountPlan *plan, hipStream_t st) {
     *plan = CountPlan();
     const size_t need = count_workspace_bytes(ix, n);
@@ -1499,6 +1696,19 @@ int launch_count_plan(const DevIndex &ix, const uint16_t *pat, const int32_t *of
     const bool o1 = code_bits == 8 && sh.sa_key == 2 && ix.suffix_order1 && ix.wt_sigma <= kOrder1MaxSigma &&
                     order1_lds_bytes(bins, ix.wt_sigma) <= kPlanCodesLdsMax;
     const size_t lds_codes = o1 ? order1_lds_bytes(bins, ix.wt_sigma) : (size_t)bins * 4;
+    // ONE launch (k_plan_fused) while every tile can be resident at once — a tile per CU at most — and no fine pass follows (its
+    // window order needs the bucket order complete); else k_plan_codes + k_plan_scatter
+    const bool fine_pass = g_plan_fine == 2 || (g_plan_fine == 1 && !sh.sa_key);
+    if (g_plan_fused && !fine_pass && n_cu > 0 && tiles <= n_cu) {
+        const size_t lds_fused = std::max(lds_codes, (size_t)bins * 8);
+        const uint32_t spin_limit = (uint32_t)g_plan_spin_limit.load();
+        if (code_bits == 8)
+            hipLaunchKernelGGL(k_plan_fused<8>, dim3(tiles), dim3(kTileThreads), lds_fused, st, ix, pat, off, n, sh, ordered, ghist, ticket,
+                               ticket + 2, epoch, spin_limit);
+        else
+            hipLaunchKernelGGL(k_plan_fused<16>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 8, st, ix, pat, off, n, sh, ordered, ghist,
+                               ticket, ticket + 2, epoch, spin_limit);
+    } else {
     if (code_bits == 8)
         hipLaunchKernelGGL(k_plan_codes<8>, dim3(tiles), dim3(kTileThreads), lds_codes, st, ix, pat, off, n, sh, recs,
                            ghist, ticket + 2, epoch);
@@ -1509,6 +1719,7 @@ int launch_count_plan(const DevIndex &ix, const uint16_t *pat, const int32_t *of
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_plan_scatter<false>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 8, st, recs, nullptr, nullptr, 0, n, bins,
                        sh.total_bits - sh.coarse_bits, ghist, cursor, ticket, ordered);
+    }
     // (the fine pass: for the code key; with the SA-row key 4,096 buckets already are what a full sort gives within 5 %: option 2 forces it)
     if (g_plan_fine == 2 || (g_plan_fine == 1 && !sh.sa_key))
         hipLaunchKernelGGL(k_plan_fine, dim3((n + kFineWindow - 1) / kFineWindow), dim3(kFineThreads), 0, st, ordered, n);

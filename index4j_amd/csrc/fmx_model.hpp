@@ -125,6 +125,9 @@ const uint8_t *rrr_bits_needed();       // 16 entries  (BITS_NEEDED_BINOMIAL_COE
 // fmx_serial.cpp
 int parse_model(const uint8_t *buf, size_t len, FmModel &out, std::string &err);
 void emit_model(const FmModel &m, bool framed, std::vector<uint8_t> &out);
+// false: a JVM's HashMap would have turned one of the key map's buckets into a tree bin, whose iteration order emit_model does
+// not model (fmx_serial.cpp hashmap_order): the stream is valid, its key order inside that bucket unverified
+bool key_order_is_modelled(const FmModel &m);
 int validate_model(const FmModel &m, std::string &err);  // 0 ok, -3 malformed: run on every parsed stream (fmx_load)
 
 // fmx_blob.cpp

@@ -222,21 +222,59 @@ void write_wavelet(Writer &w, const WfbbModel &m) {  // WFBB:1544-1570
     }
 }
 
-// java.util.HashMap<Integer,Short>.keySet() order for FM:956-960: capacity = smallest power of two
-// >= 16 with n <= 0.75 * cap; bucket = key & (cap - 1) for char keys; insertion order inside a bucket
-// (bins treeified at >= 8 colliding keys are not modelled).
-std::vector<int> hashmap_order(const FmModel &m) {
+// java.util.HashMap<Integer,Short>.keySet() order for FM:956-960, by replaying the puts (JDK 8+ HashMap.putVal / resize,
+// stated from knowledge: no JVM here): the table starts at 16 slots and doubles when the size passes 0.75 x capacity — and
+// also when a put makes a bucket 9 nodes long while the table has fewer than 64 slots (treeifyBin resizes instead of
+// treeifying below MIN_TREEIFY_CAPACITY); slot = (h ^ (h >>> 16)) & (capacity - 1) with h = the int key; a resize splits every
+// bucket in two keeping the nodes' relative order, so a bucket holds its keys in insertion order; keySet() walks the slots
+// upwards.  A bucket that reaches 9 nodes at 64 slots or more becomes a red-black TREE bin, whose iteration order (root moved
+// to the front, later nodes linked behind their tree parents) this replay does NOT model: `treeified` reports it, the order
+// returned is the plain-bucket one, and fmx_save_key_order_modelled() tells the caller that the bytes — a stream FmIndex.read
+// accepts, its reader is order-agnostic (FM:992-998) — may differ from a JVM's inside that bucket.
+// map_keys is in insertion order: '\0' first, then first appearance (FM:396-420), or the order of the stream it was read from.
+std::vector<int> hashmap_order(const FmModel &m, bool *treeified) {
     const int n = (int)m.map_keys.size();
-    int cap = 16;
-    while (n > (cap * 3) / 4) cap <<= 1;
-    std::vector<int> start((size_t)cap + 1, 0), order((size_t)n);
-    for (int i = 0; i < n; ++i) ++start[(size_t)(m.map_keys[(size_t)i] & (cap - 1)) + 1];
-    for (int i = 0; i < cap; ++i) start[(size_t)i + 1] += start[(size_t)i];
-    for (int i = 0; i < n; ++i) order[(size_t)start[(size_t)(m.map_keys[(size_t)i] & (cap - 1))]++] = i;
+    uint32_t cap = 16;
+    bool tree = false;
+    std::vector<std::vector<int>> bins(cap);
+    auto slot_of = [&](int i, uint32_t c) {
+        const uint32_t h = (uint32_t)m.map_keys[(size_t)i];
+        return (h ^ (h >> 16)) & (c - 1);
+    };
+    auto resize = [&]() {
+        std::vector<std::vector<int>> next((size_t)cap * 2);
+        for (uint32_t b = 0; b < cap; ++b)
+            for (int i : bins[b]) next[slot_of(i, cap * 2)].push_back(i);  // (b or b + cap: relative order kept)
+        bins.swap(next);
+        cap *= 2;
+    };
+    for (int i = 0; i < n; ++i) {
+        std::vector<int> &bin = bins[slot_of(i, cap)];
+        const size_t before = bin.size();
+        bin.push_back(i);
+        if (before >= 8) {  // putVal: binCount >= TREEIFY_THRESHOLD - 1 -> treeifyBin
+            if (cap < 64)
+                resize();
+            else
+                tree = true;
+        }
+        if ((uint32_t)(i + 1) > cap / 4 * 3) resize();  // ++size > threshold
+    }
+    std::vector<int> order;
+    order.reserve((size_t)n);
+    for (uint32_t b = 0; b < cap; ++b)
+        for (int i : bins[b]) order.push_back(i);
+    if (treeified) *treeified = tree;
     return order;
 }
 
 }  // namespace
+
+bool key_order_is_modelled(const FmModel &m) {
+    bool tree = false;
+    (void)hashmap_order(m, &tree);
+    return !tree;
+}
 
 // FM:983-1025.  Returns 0, or 1 truncated / 2 version / 3 malformed.
 int parse_model(const uint8_t *buf, size_t len, FmModel &m, std::string &err) {
@@ -328,7 +366,7 @@ void emit_model(const FmModel &m, bool framed, std::vector<uint8_t> &out) {
     w.i32(m.bw_positions);
     w.i32(m.length);
     w.i32((int32_t)m.map_keys.size());
-    for (int i : hashmap_order(m)) {
+    for (int i : hashmap_order(m, nullptr)) {
         w.i32(m.map_keys[(size_t)i]);
         w.i16(m.map_vals[(size_t)i]);
     }

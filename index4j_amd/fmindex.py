@@ -122,6 +122,14 @@ class FmIndex:
         finally:
             lib.fmx_free_buffer(buf)
 
+    def serialized_key_order_is_modelled(self):
+        """False: a JVM's HashMap would have made one of the character map's buckets a tree bin, whose iteration order write()
+        does not model (fmx.h fmx_save_key_order_modelled): the stream is valid, its key order in that bucket unverified"""
+        rc = lib.fmx_save_key_order_modelled(self._h)
+        if rc < 0:
+            check(rc, "fmx_save_key_order_modelled")
+        return rc == 1
+
     @classmethod
     def attach_device_blob(cls, device_ptr, nbytes, device):
         """adopt a blob already in HBM (e.g. received through an RCCL broadcast)"""

@@ -2039,20 +2039,46 @@ static void wfbb_write(const OrcWfbb *w, OBuf *b) { /* WFBB:1544-1570, 1651-1667
     }
 }
 
-/* java.util.HashMap<Integer,Short>.keySet() iteration order for FM:956-960 (JDK behaviour, stated
- * from knowledge — unverifiable here): table capacity = smallest power of two >= 16 with
- * n <= 0.75*cap; bucket = key & (cap-1) for keys < 65536; insertion order inside a bucket
- * (treeified bins, >= 8 colliding keys, are not modelled). */
+/* java.util.HashMap<Integer,Short>.keySet() iteration order for FM:956-960 (JDK 8+ behaviour, stated from knowledge —
+ * unverifiable here), by replaying the puts in insertion order: 16 slots at first; doubling when the size passes 0.75 x
+ * capacity, and when a put makes a bucket 9 nodes long below 64 slots (treeifyBin resizes instead); slot = (h ^ (h >>> 16)) &
+ * (capacity - 1); a resize keeps the relative order inside each half of a split bucket.  Tree bins (a 9-node bucket at >= 64
+ * slots) are not modelled: the plain-bucket order is written. */
 static void hashmap_order(const OrcFmIndex *f, int *order) {
-    int cap = 16;
-    while (f->n_keys > (cap * 3) / 4) cap <<= 1;
-    int k = 0;
-    /* stable bucket sort */
+    int n = f->n_keys;
+    uint32_t cap = 16;
+    /* slot of every key under the current capacity, recomputed per resize; bucket sizes for the 9-node rule */
+    int *size_of = (int *)xcalloc(16, sizeof(int));
+    for (int i = 0; i < n; i++) {
+        uint32_t h = (uint32_t)f->map_keys[i];
+        uint32_t slot = (h ^ (h >> 16)) & (cap - 1);
+        int before = size_of[slot]++;
+        int grow = 0;
+        if (before >= 8 && cap < 64) grow = 1;
+        for (int pass = 0; pass < 2; pass++) {
+            if (pass == 1) grow = (uint32_t)(i + 1) > cap / 4 * 3;
+            if (!grow) continue;
+            cap *= 2;
+            free(size_of);
+            size_of = (int *)xcalloc(cap, sizeof(int));
+            for (int j = 0; j <= i; j++) {
+                uint32_t hj = (uint32_t)f->map_keys[j];
+                size_of[(hj ^ (hj >> 16)) & (cap - 1)]++;
+            }
+        }
+    }
+    free(size_of);
+    /* stable bucket sort under the final capacity (= insertion order inside a bucket) */
     int *cnt = (int *)xcalloc((size_t)cap + 1, sizeof(int));
-    for (int i = 0; i < f->n_keys; i++) cnt[(f->map_keys[i] & (cap - 1)) + 1]++;
-    for (int i = 0; i < cap; i++) cnt[i + 1] += cnt[i];
-    for (int i = 0; i < f->n_keys; i++) order[cnt[f->map_keys[i] & (cap - 1)]++] = i;
-    (void)k;
+    for (int i = 0; i < n; i++) {
+        uint32_t h = (uint32_t)f->map_keys[i];
+        cnt[((h ^ (h >> 16)) & (cap - 1)) + 1]++;
+    }
+    for (uint32_t i = 0; i < cap; i++) cnt[i + 1] += cnt[i];
+    for (int i = 0; i < n; i++) {
+        uint32_t h = (uint32_t)f->map_keys[i];
+        order[cnt[(h ^ (h >> 16)) & (cap - 1)]++] = i;
+    }
     free(cnt);
 }
 

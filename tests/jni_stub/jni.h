@@ -8,6 +8,8 @@
 #include <stdint.h>
 
 typedef uint8_t jboolean;
+#define JNI_FALSE 0
+#define JNI_TRUE 1
 typedef int8_t jbyte;
 typedef uint16_t jchar;
 typedef int16_t jshort;

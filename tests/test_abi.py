@@ -80,6 +80,20 @@ def test_jni_glue_type_checks_against_fmx_h():
     declared = set(re.findall(r"\bnative\s+[\w\[\]]+\s+(native\w+)\s*\(", java))
     defined = set(re.findall(r"Java_com_dynatrace_fm_gpu_GpuFmIndex_(native\w+)\s*\(", glue))
     assert declared and declared == defined, (sorted(declared - defined), sorted(defined - declared))
+    # ... with the same number of arguments on both sides (the glue's entries take JNIEnv * and jclass first)
+    def arity(params):
+        params = params.strip()
+        return 0 if not params else len([p for p in params.split(",") if p.strip()])
+
+    java_args = {m.group(1): arity(m.group(2)) for m in re.finditer(r"\bnative\s+[\w\[\]]+\s+(native\w+)\s*\(([^)]*)\)", java)}
+    glue_args = {m.group(1): arity(m.group(2)) - 2
+                 for m in re.finditer(r"Java_com_dynatrace_fm_gpu_GpuFmIndex_(native\w+)\s*\(([^)]*)\)", glue)}
+    assert java_args == glue_args, {k: (java_args.get(k), glue_args.get(k)) for k in java_args if java_args.get(k) != glue_args.get(k)}
+    # the parity test a maintainer with a JDK runs (bindings/build.sh) only calls methods the shim has
+    test_src = open(os.path.join(ROOT, "bindings", "java", "test", "com", "dynatrace", "fm", "gpu", "GpuFmIndexParityTest.java")).read()
+    public = set(re.findall(r"\bpublic\s+(?:static\s+)?[\w\[\]<>]+\s+(\w+)\s*\(", java))
+    for called in set(re.findall(r"\bgpu\.(\w+)\s*\(", test_src)) - {"run"}:  # (`gpu.run`: a lambda parameter of the test's own)
+        assert called in public, "GpuFmIndexParityTest calls %s, which GpuFmIndex does not declare" % called
 
 
 def test_fmx_h_is_plain_c():

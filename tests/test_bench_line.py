@@ -65,3 +65,56 @@ def test_contract_line_sheds_optional_blocks_before_it_grows():
     assert len(line) < b.COMPACT_LIMIT
     c = json.loads(line)
     assert c["value"] == rec["value"] and c["roofline"]["frac"] == rec["roofline"]["frac"]
+
+
+def _ref_series():
+    spec = importlib.util.spec_from_file_location("ref_series_mod", os.path.join(ROOT, "tools", "ref_series.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_no_frac_above_one_leaves_the_rule():
+    """a `frac` is a fraction.  The algorithmic figure of locate passed 1.0 in round 4 (hits of equal ranges
+    share their lines); the rule reports the counter figure there and keeps the algorithmic one under its own name."""
+    rs = _ref_series()
+    ms = 0.4
+    # algorithmic 1.003, counters 0.55 -> frac = the counter figure
+    alg_bytes = 1.003 * rs.HBM_PEAK_GBS * 1e9 * ms * 1e-3
+    traffic = 0.55 * rs.HBM_PEAK_GBS * 1e9 * ms * 1e-3
+    r = rs.settle_frac({"frac": 1.003, "achieved": alg_bytes / (ms * 1e-3) / 1e9}, ms, traffic)
+    assert abs(r["frac"] - 0.55) < 1e-9 and abs(r["frac_algorithmic"] - 1.003) < 1e-9 and abs(r["traffic_frac"] - 0.55) < 1e-9
+    assert r["frac"] <= 1.0 and r["traffic"] == traffic
+    # algorithmic 0.68, counters 0.27: more than 1.5 x apart -> the counter figure
+    r = rs.settle_frac({"frac": 0.68, "achieved": 0.68 * rs.HBM_PEAK_GBS}, ms, 0.27 * rs.HBM_PEAK_GBS * 1e9 * ms * 1e-3)
+    assert abs(r["frac"] - 0.27) < 1e-9 and r["frac_algorithmic"] == 0.68
+    # algorithmic 0.71, counters 0.62: the algorithmic figure stands
+    r = rs.settle_frac({"frac": 0.71, "achieved": 0.71 * rs.HBM_PEAK_GBS}, ms, 0.62 * rs.HBM_PEAK_GBS * 1e9 * ms * 1e-3)
+    assert r["frac"] == 0.71 and abs(r["traffic_frac"] - 0.62) < 1e-9
+    # no counters on file: a figure above 1 is withheld, one below stays
+    r = rs.settle_frac({"frac": 1.2, "achieved": 1.2 * rs.HBM_PEAK_GBS}, ms, None)
+    assert r["frac"] is None and r["frac_algorithmic"] == 1.2 and r["traffic_frac"] is None
+    r = rs.settle_frac({"frac": 0.5, "achieved": 0.5 * rs.HBM_PEAK_GBS}, ms, None)
+    assert r["frac"] == 0.5
+
+
+def test_secondary_rows_of_the_contract_line_carry_both_fractions():
+    b = _bench()
+    rs = _ref_series()
+    rec = json.loads(open(os.path.join(ROOT, "profiles", "r03_f_bench_unprofiled.json")).read().strip().splitlines()[-1])
+    rec = copy.deepcopy(rec)
+    rows = []
+    for s, wanted in rs.DEFAULT_PLAN:
+        for bench, mm in wanted:
+            roof = rs.settle_frac({"frac": 1.1, "achieved": 1.1 * rs.HBM_PEAK_GBS}, 1.0, 0.5 * rs.HBM_PEAK_GBS * 1e9 * 1e-3)
+            rows.append({"benchmark": bench, "sample_rate": s, "key": rs.row_key(bench, mm, s), "ms_per_batch": 1.0, "roofline": roof})
+    rec["secondary"] = [{"config": "configs[2]", "ms": 0.4, "roofline": rs.settle_frac({"frac": 1.003, "achieved": 1.0}, 0.4, 1.7e9)},
+                        {"config": "reference_series", "series": {"rows": rows}}]
+    line = b.compact_line(rec)
+    assert len(line) < b.COMPACT_LIMIT
+    c = json.loads(line)
+    assert len(c["secondary"]) == 1 + 6
+    for row in c["secondary"]:
+        assert row["frac"] is None or row["frac"] <= 1.0
+        assert "alg" in row and "tfrac" in row
+    assert [r["config"] for r in c["secondary"][1:]] == [rs.row_key(bn, mm, s) for s, w in rs.DEFAULT_PLAN for bn, mm in w]

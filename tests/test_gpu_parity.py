@@ -904,6 +904,47 @@ def test_workgroups_regrouped_by_pattern_length_give_the_same_answers():
     fm.close()
 
 
+def test_the_plan_stage_as_one_launch_gives_the_same_answers_also_when_its_barrier_gives_up():
+    """Round 5: k_plan_fused (records in registers, tickets from the histogram's atomic adds, a bounded grid barrier) against
+    k_plan_codes + k_plan_scatter (option plan_fused = 0), on 8-bit and 16-bit code words, one length and mixed lengths, a batch
+    that does not fill its last tile — and with the barrier's patience set to nothing (plan_spin_limit = 0): workgroups abort
+    the order and write their records at their own indices, a valid plan in the caller's order.  Counts, statuses, LF-steps and
+    located hits against the oracle every time; the workspace's head must come back zeroed (the next plan works)."""
+    L = ia.lib
+    r = random.Random(5)
+    texts = [ia.synth_log(1 << 20), ia.synth_log_multichar(1 << 20, 600)]
+    try:
+        for text in texts:
+            o = orc.OracleFmIndex(text, 16, True)
+            fm = ia.FmIndex.read(o.write(False), device=0)
+            t16 = ia.as_chars(text)
+            for n, lens in ((40_000, [8]), (70_001, [1, 5, 8, 13, 31]), (20_000, list(range(0, 40)))):
+                pats = [t16[a:a + r.choice(lens)] for a in (r.randrange(len(t16) - 80) for _ in range(n))]
+                for k in range(0, n, 97):
+                    if len(pats[k]):
+                        pats[k] = pats[k].copy()
+                        pats[k][r.randrange(len(pats[k]))] = 7
+                ch, off = ia.pack_patterns(pats)
+                oc, ost = o.count_batch(ch, off, threads=8)
+                want = o.locate_batch(ch, off, 3, threads=8)
+                lf_ref = None
+                for fused, spin in ((1, 4096), (0, 4096), (1, 0), (1, 4096)):
+                    assert L.fmx_set_option(b"plan_fused", fused) == 0 and L.fmx_set_option(b"plan_spin_limit", spin) == 0
+                    assert L.fmx_count_batch_is_planned(fm.handle, n) == 1
+                    for _ in range(2):  # (twice: the second plan finds the head as the first left it)
+                        cnt, st, lf = fm.count_batch(ch, off, want_steps=True)
+                        assert (cnt == oc).all() and (st == ost).all(), (n, lens, fused, spin)
+                        lf_ref = lf if lf_ref is None else lf_ref
+                        assert (lf == lf_ref).all()
+                    locs, found, st2 = fm.locate_batch(ch, off, 3)
+                    live = np.arange(3)[None, :] < want[1][:, None]
+                    assert (found == want[1]).all() and (st2 == want[2]).all() and (locs[live] == want[0][live]).all()
+            fm.close()
+    finally:
+        L.fmx_set_option(b"plan_fused", 1)
+        L.fmx_set_option(b"plan_spin_limit", 4096)
+
+
 def test_api_edge_cases():
     """empty batches, zero-capacity buffers and bad arguments through the C ABI: no kernel launch with bad shapes,
     library-level error codes instead"""

@@ -45,7 +45,7 @@ def main():
     doc = {"what": "rocprofv3 FETCH_SIZE (KiB) against known bytes, gfx950: scattered = 16-byte loads from DISTINCT 128-byte "
                    "lines of a %d MiB table (each line once), stream = the same number of 16-byte loads, consecutive" % args.table_mib,
            "cases": {}}
-    for name, extra in (("scatter", []), ("stream", ["1"])):
+    for name, extra in (("scatter", []), ("stream", ["1"]), ("halves", ["2"])):
         a = [str(args.table_mib), str(args.loads)] + extra
         info, v1, err1 = run_counter(exe, a, ["FETCH_SIZE"], os.path.join(work, name + "_fetch"))
         _, v2, err2 = run_counter(exe, a, ["TCC_MISS_sum", "TCC_EA0_RDREQ_sum"], os.path.join(work, name + "_tcc"))
@@ -57,21 +57,35 @@ def main():
                     FETCH_bytes_per_load=fetch_bytes / info["loads"])
         doc["cases"][name] = case
     sc, stc = doc["cases"]["scatter"], doc["cases"]["stream"]
+    hv = doc["cases"]["halves"]
+    # does a scattered miss fill the whole 128-byte line, or a 64-byte sector?  `halves` touches both halves of each line it
+    # visits: ~1 request per line = whole lines (the x 2 below holds for scattered loads too), ~2 = sectors (x 1)
+    doc["requests_per_line_when_both_halves_are_read"] = hv["TCC_EA0_RDREQ"] / hv["loads"] if hv.get("TCC_EA0_RDREQ") else None
     doc["scattered_16B_load"] = {"FETCH_SIZE_bytes_per_load": sc["FETCH_bytes_per_load"]}
     doc["streaming_16B_load"] = {"FETCH_SIZE_bytes_per_load": stc["FETCH_bytes_per_load"],
                                  "fraction_of_bytes_loaded": stc["FETCH_SIZE_bytes"] / stc["bytes_loaded"]}
-    # What one fabric read request carries: the streaming case loads every byte of the lines it touches, so
-    # bytes_loaded / TCC_EA0_RDREQ is the request size (128 on gfx950: one request per 128-byte L2 line, tallied by
-    # FETCH_SIZE at 64).  A scattered load costs one such request as well, so the bytes that really cross the fabric are
-    # requests x that size for BOTH patterns: FETCH_SIZE x (size / 64).
+    # What one fabric read request carries.  The STREAMING case loads every byte of the lines it touches:
+    # bytes_loaded / TCC_EA0_RDREQ is its request size (128 on gfx950, tallied by FETCH_SIZE at 64: the guide's "double it").
+    # A SCATTERED 16-byte load that misses costs one request too — of what size?  The `halves` case reads both 64-byte halves
+    # of every line it visits, the second load depending on the first: ~1 request per line would mean a miss fills the whole
+    # 128-byte line, ~2 mean it fills a 64-byte SECTOR — then FETCH_SIZE's 64 bytes per request are exactly what a scattered
+    # miss moves, and the factor for scattered loads is 1, not 2.  (Rounds 3 and 4 assumed whole lines without this case and
+    # doubled the LF kernels' traffic.)
     req_bytes = stc["bytes_loaded"] / stc["TCC_EA0_RDREQ"] if stc.get("TCC_EA0_RDREQ") else None
+    doc["fabric_read_request_bytes_streaming"] = req_bytes
     doc["fabric_read_request_bytes"] = req_bytes
     doc["requests_per_scattered_load"] = sc["TCC_EA0_RDREQ"] / sc["loads"] if sc.get("TCC_EA0_RDREQ") else None
-    doc["fabric_bytes_per_FETCH_SIZE_byte"] = req_bytes / 64.0 if req_bytes else None
-    doc["reading"] = ("FETCH_SIZE = TCC_EA0_RDREQ x 64 B, but a request fills a whole %.0f-byte L2 line (the streaming case moves "
-                      "%.0f bytes per request); a scattered 16-byte load that misses costs one request too.  Absolute fabric read "
-                      "bytes = FETCH_SIZE x %.2f for both patterns" % (req_bytes or 0, req_bytes or 0, (req_bytes or 0) / 64.0))
-    # the ceiling of the LF kernels' access pattern: random 16-byte loads = random 128-byte lines per second
+    per_line = doc.get("requests_per_line_when_both_halves_are_read")
+    sectors = per_line is not None and per_line > 1.5
+    doc["scattered_miss_fills"] = "a 64-byte sector" if sectors else "the whole 128-byte line"
+    doc["fabric_bytes_per_FETCH_SIZE_byte_streaming"] = req_bytes / 64.0 if req_bytes else None
+    doc["fabric_bytes_per_FETCH_SIZE_byte"] = 1.0 if sectors else (req_bytes / 64.0 if req_bytes else None)
+    doc["reading"] = ("FETCH_SIZE = TCC_EA0_RDREQ x 64 B.  A streamed read issues %.0f-byte requests (FETCH_SIZE x %.2f = bytes moved); a "
+                      "scattered 16-byte load that misses issues ONE request and — both halves of a line read one after the other cost "
+                      "%.2f requests per line — fills %s: for the LF kernels' scattered loads bytes moved = FETCH_SIZE x %.2f" % (
+                          req_bytes or 0, (req_bytes or 0) / 64.0, per_line or 0, doc["scattered_miss_fills"],
+                          doc["fabric_bytes_per_FETCH_SIZE_byte"] or 0))
+    # the ceiling of the LF kernels' access pattern: random 16-byte loads per second (each a sector fill)
     rl = os.path.join(work, "random_lines")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950",
                            os.path.join(ROOT, "tools", "microbench", "random_lines.hip"), "-o", rl])

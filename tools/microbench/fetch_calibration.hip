@@ -22,6 +22,20 @@ __global__ __launch_bounds__(512) void k_calib_scatter(const Q *__restrict__ tab
     }
     if (acc == 0x12345678u) *out = acc;
 }
+// both 64-byte halves of every line it visits (two 16-byte loads, 64 bytes apart): one fabric request per LINE means a miss
+// fills the whole 128-byte line; two mean it fills 64-byte sectors
+__global__ __launch_bounds__(512) void k_calib_halves(const Q *__restrict__ table, uint64_t lines, uint64_t loads, uint64_t mult,
+                                                      uint32_t *out) {
+    uint32_t acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 512 + threadIdx.x; i < loads; i += (uint64_t)gridDim.x * 512) {
+        const uint64_t line = (i * mult) % lines;
+        const Q v = table[line * 8 + (i & 3)];
+        acc += v.x ^ v.y ^ v.z ^ v.w;
+        const Q w = table[line * 8 + 4 + ((i + v.x) & 3)];  // (address depends on the first load: never merged into one access)
+        acc += w.x ^ w.y ^ w.z ^ w.w;
+    }
+    if (acc == 0x12345678u) *out = acc;
+}
 __global__ __launch_bounds__(512) void k_calib_stream(const Q *__restrict__ table, uint64_t loads, uint32_t *out) {
     uint32_t acc = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * 512 + threadIdx.x; i < loads; i += (uint64_t)gridDim.x * 512) {
@@ -50,7 +64,9 @@ int main(int argc, char **argv) {
     (void)hipEventCreate(&e1);
     // ONE measured launch (a second launch over the same lines would find part of them in the Infinity Cache)
     (void)hipEventRecord(e0);
-    if (stream)
+    if (stream == 2)
+        hipLaunchKernelGGL(k_calib_halves, dim3(4096), dim3(512), 0, 0, table, lines, loads, mult, out);
+    else if (stream)
         hipLaunchKernelGGL(k_calib_stream, dim3(4096), dim3(512), 0, 0, table, loads, out);
     else
         hipLaunchKernelGGL(k_calib_scatter, dim3(4096), dim3(512), 0, 0, table, lines, loads, mult, out);
@@ -60,7 +76,7 @@ int main(int argc, char **argv) {
     (void)hipEventElapsedTime(&ms, e0, e1);
     printf("{\"kernel\": \"%s\", \"table_MiB\": %llu, \"loads\": %llu, \"bytes_loaded\": %llu, \"unique_lines_128B\": %llu, \"ms\": %.4f, "
            "\"loads_per_s\": %.4g}\n",
-           stream ? "k_calib_stream" : "k_calib_scatter", (unsigned long long)mib, (unsigned long long)loads,
-           (unsigned long long)(loads * 16), (unsigned long long)(stream ? loads / 8 : loads), ms, loads / (ms * 1e-3));
+           stream == 2 ? "k_calib_halves" : stream ? "k_calib_stream" : "k_calib_scatter", (unsigned long long)mib, (unsigned long long)loads,
+           (unsigned long long)(loads * (stream == 2 ? 32 : 16)), (unsigned long long)(stream == 1 ? loads / 8 : loads), ms, loads / (ms * 1e-3));
     return 0;
 }

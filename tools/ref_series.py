@@ -30,6 +30,59 @@ PUBLISHED = {("locate", 1, 1): 57444, ("locate", 1, 32): 26031, ("locate", 1, 64
              ("extract", 32, 64): 12451}
 
 
+def row_key(bench, mm, s):
+    """name of a series row: what bench.py's contract line, tools/pmc_rows.py and profiles/pmc_latest.json call it"""
+    return "series %s%s s=%d" % (bench, "" if mm is None else "(%d)" % mm, s)
+
+
+# the rows of bench.py's DEFAULT run (VERDICT r4 item 1): the reference's published shape at sampleRate 32 and the weak rows at 1
+DEFAULT_PLAN = ((32, (("count", None), ("locate", 1), ("locate", 100), ("extract", 32))),
+                (1, (("count", None), ("extract", 32))))
+
+
+def full_plan(sample_rates=(1, 32, 64), max_matches=(1, 10, 100, 1000)):
+    return tuple((s, (("count", None),) + tuple(("locate", mm) for mm in max_matches) + (("extract", 32),)) for s in sample_rates)
+
+
+def series_queries(Q, s, bench, mm, bounded=True):
+    """queries of a row: the locate rows with maxMatches 100 / 1000 (sampleRate > 1) take the first Q / 4 and Q / 16 of the batch"""
+    if bench != "locate" or not bounded or mm < 100 or s == 1:
+        return Q
+    return max(1, Q // (4 if mm < 1000 else 16))
+
+
+def settle_frac(roof, ms, traffic, ratio_rule=True):
+    """One rule for every `frac` on bench.py's lines.  ratio_rule = False (the contract's own `roofline`
+    object, whose `achieved` the task defines as algorithmic bytes / launch time): only the "never above 1" half applies, the
+    counter figure stands beside it as traffic / traffic_frac.  roof["frac"] comes in as the ALGORITHMIC fraction
+    (oracle-counted bytes of the executed LF-steps / time / peak).  `traffic` = bytes the memory system moved per call by the
+    committed counters (FETCH_SIZE x calibration + WRITE_SIZE; None: no counters for these kernel sources).  The algorithmic
+    figure stays under `frac_algorithmic`; `frac` is the counter figure wherever the algorithmic one exceeds 1 or 1.5 x the
+    counter figure (its numerator then counts bytes that lanes shared in L1 / L2 and the memory system never moved)."""
+    alg = roof.get("frac")
+    roof["frac_algorithmic"] = alg
+    roof["achieved_algorithmic"] = roof.get("achieved")
+    roof["traffic"] = traffic
+    if traffic:
+        tf = traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        roof["traffic_frac"] = tf
+        if alg is not None and (alg > 1.0 or (ratio_rule and alg > 1.5 * tf)):
+            roof["frac"] = tf
+            roof["achieved"] = traffic / (ms * 1e-3) / 1e9
+            roof["frac_is"] = "counter traffic (the algorithmic figure counts bytes that equal work side by side shares in L1 / L2)"
+        else:
+            roof["frac_is"] = "algorithmic bytes"
+    else:
+        roof["traffic_frac"] = None
+        if alg is not None and alg > 1.0:  # no counters to fall back to: never report a fraction above 1
+            roof["frac"] = None
+            roof["achieved"] = None
+            roof["frac_is"] = "withheld: the algorithmic figure exceeds 1 and no counter traffic is on file for these kernel sources"
+        else:
+            roof["frac_is"] = "algorithmic bytes"
+    return roof
+
+
 def _timed(torch, stream, fn, reps):
     """MEAN milliseconds per call over 3 x reps back-to-back calls between one HIP-event pair (the same standard as the
     headline's ms_per_step; minima were reported until round 3)"""
@@ -45,11 +98,18 @@ def _timed(torch, stream, fn, reps):
 
 
 def run_series(ia, torch, orc, dev, text_log2=28, queries=1 << 20, sample_rates=(1, 32, 64), max_matches=(1, 10, 100, 1000),
-               symbols=None, build_device=0, log=lambda *a: None, bounded=True):
+               symbols=None, build_device=0, log=lambda *a: None, bounded=True, plan=None, check=True, calls=None,
+               traffic_lookup=None):
     """bounded: the locate rows with maxMatches 100 / 1000 (sampleRate > 1) take the first queries / 4 and queries / 16 of the batch — the
     oracle's check of every located position is what takes the time (256 host cores: 150 s for 262,144 queries x 1000 at
-    sampleRate 64), and bench.py's default run has to finish within minutes"""
+    sampleRate 64), and bench.py's default run has to finish within minutes.
+    plan: ((sampleRate, ((benchmark, maxMatches | chars | None), ...)), ...) — the rows to run (default: every row of
+    sample_rates x max_matches).  check = False (counter passes, tools/pmc_rows.py): no oracle, every row's call is launched
+    `calls` times and nothing is reported.  traffic_lookup(row key, queries) -> bytes per call by the committed counters."""
     from index4j_amd import workload
+
+    if plan is None:
+        plan = full_plan(sample_rates, max_matches)
 
     symbols = workload.REFERENCE_SYMBOLS if symbols is None else symbols
     t_start = time.time()
@@ -90,7 +150,7 @@ def run_series(ia, torch, orc, dev, text_log2=28, queries=1 << 20, sample_rates=
         if rc != 0:
             raise RuntimeError("%s failed: %s" % (what, ia.lib.fmx_last_error().decode()))
 
-    for s in sample_rates:
+    for s, wanted in plan:
         t0 = time.time()
         fm = ia.FmIndex(text, s, True, device=None, build_device=build_device)
         t_build = time.time() - t0
@@ -98,7 +158,7 @@ def run_series(ia, torch, orc, dev, text_log2=28, queries=1 << 20, sample_rates=
         t1 = time.time()
         fm.to_device(dev.index or 0)
         t_dev = time.time() - t1
-        ref = orc.OracleFmIndex.read(ser)
+        ref = orc.OracleFmIndex.read(ser) if check else None
         image_bytes = fm.device_blob()[1]
         table_chars, table_bytes = fm.suffix_table_info()
         info["indexes"].append({"sample_rate": s, "build_s": t_build, "flatten_upload_table_s": t_dev,
@@ -121,7 +181,12 @@ def run_series(ia, torch, orc, dev, text_log2=28, queries=1 << 20, sample_rates=
             c = orc.counters()
             return c["alg_bytes"], c["lf_steps"]
 
-        table_alg, table_steps = table_part(Q)
+        table_alg, table_steps = table_part(Q) if check else (0, 0)
+
+        def launches_only(fn):  # (counter passes: the row's call, nothing else)
+            for _ in range(calls or 3):
+                fn()
+            torch.cuda.synchronize()
 
         def row(bench, mm, ms, units, c, extra, n_q=None):
             n_q = Q if n_q is None else n_q
@@ -138,11 +203,15 @@ def run_series(ia, torch, orc, dev, text_log2=28, queries=1 << 20, sample_rates=
                  "published_reference_ops_per_s_1core_xeon": PUBLISHED.get((bench, mm, s))}
             if mm is not None:
                 r["max_matches" if bench == "locate" else "chars"] = mm
+            r["key"] = row_key(bench, mm, s)
+            settle_frac(r["roofline"], ms, traffic_lookup(r["key"], n_q) if traffic_lookup else None)
             r.update(units)
             r.update(extra)
             rows.append(r)
-            log("[series] s=%d %s%s: %.3f ms, %.3g ops/s, frac %.2f" % (s, bench, "" if mm is None else "(%d)" % mm, ms,
-                                                                         r["ops_per_s"], r["roofline"]["frac"]))
+            rf = r["roofline"]
+            log("[series] s=%d %s%s: %.3f ms, %.3g ops/s, frac %s (algorithmic %.2f, counter traffic %s)" % (
+                s, bench, "" if mm is None else "(%d)" % mm, ms, r["ops_per_s"], "-" if rf["frac"] is None else "%.2f" % rf["frac"],
+                rf["frac_algorithmic"], "-" if rf["traffic_frac"] is None else "%.2f" % rf["traffic_frac"]))
 
         # ---- countBenchmark ----
         def count(with_lf):
@@ -150,21 +219,24 @@ def run_series(ia, torch, orc, dev, text_log2=28, queries=1 << 20, sample_rates=
                                                 d_lf.data_ptr() if with_lf else None, d_st.data_ptr() if with_lf else None, sp),
                      "fmx_count_batch_dev")
 
-        count(True)
-        torch.cuda.synchronize()
-        orc.counters_reset()
-        oc, ost = ref.count_batch(pat, off, threads=cores)
-        c = orc.counters()
-        if not ((d_cnt.cpu().numpy() == oc).all() and (d_st.cpu().numpy() == ost).all()
-                and int(d_lf.sum(dtype=torch.int64).item()) == c["lf_steps"]):
-            raise RuntimeError("count differs from the oracle (sampleRate %d)" % s)
-        row("count", None, _timed(torch, stream, lambda: count(False), 10), {"matches": int(oc.astype(np.int64).sum())}, c,
-            {"checked_vs_oracle": "all %d counts, statuses, LF-step total" % Q})
+        if ("count", None) in wanted and not check:
+            launches_only(lambda: count(False))
+        elif ("count", None) in wanted:
+            count(True)
+            torch.cuda.synchronize()
+            orc.counters_reset()
+            oc, ost = ref.count_batch(pat, off, threads=cores)
+            c = orc.counters()
+            if not ((d_cnt.cpu().numpy() == oc).all() and (d_st.cpu().numpy() == ost).all()
+                    and int(d_lf.sum(dtype=torch.int64).item()) == c["lf_steps"]):
+                raise RuntimeError("count differs from the oracle (sampleRate %d)" % s)
+            row("count", None, _timed(torch, stream, lambda: count(False), 10), {"matches": int(oc.astype(np.int64).sum())}, c,
+                {"checked_vs_oracle": "all %d counts, statuses, LF-step total" % Q})
 
         # ---- locateBenchmark ----
-        for mm in max_matches:
+        for mm in [w[1] for w in wanted if w[0] == "locate"]:
             # (sampleRate 1 has no walks to check: its rows keep every query)
-            Qm = Q if not bounded or mm < 100 or s == 1 else max(1, Q // (4 if mm < 1000 else 16))
+            Qm = series_queries(Q, s, "locate", mm, bounded)
             d_locs = torch.zeros(Qm * mm, dtype=torch.int32, device=dev)
 
             def locate(with_lf):
@@ -172,6 +244,10 @@ def run_series(ia, torch, orc, dev, text_log2=28, queries=1 << 20, sample_rates=
                                                      d_found.data_ptr(), d_lf.data_ptr() if with_lf else None, d_st.data_ptr(),
                                                      d_rng.data_ptr(), sp), "fmx_locate_batch_dev")
 
+            if not check:
+                launches_only(lambda: locate(False))
+                del d_locs
+                continue
             d_lf.zero_()
             d_st.zero_()
             locate(True)
@@ -200,6 +276,12 @@ def run_series(ia, torch, orc, dev, text_log2=28, queries=1 << 20, sample_rates=
                                                   d_len.data_ptr(), d_lf.data_ptr() if with_lf else None, d_st.data_ptr(), sp),
                      "fmx_extract_batch_dev")
 
+        if not any(w[0] == "extract" for w in wanted) or not check:
+            if any(w[0] == "extract" for w in wanted):
+                launches_only(lambda: extract(False))
+            fm.close()
+            del ref
+            continue
         extract(True)
         torch.cuda.synchronize()
         orc.counters_reset()
@@ -260,7 +342,7 @@ def main():
     for r in out["rows"]:
         print("s=%-3d %-8s %-5s %7d q %9.3f ms  %10.4g ops/s  (published %s)  executed %.3g LF-steps/s  frac %.3f" % (
             r["sample_rate"], r["benchmark"], r.get("max_matches", r.get("chars", "")), r["queries"], r["ms_per_batch"], r["ops_per_s"],
-            r["published_reference_ops_per_s_1core_xeon"], r["lf_steps_per_s_executed"], r["roofline"]["frac"]))
+            r["published_reference_ops_per_s_1core_xeon"], r["lf_steps_per_s_executed"], r["roofline"]["frac_algorithmic"]))
 
 
 if __name__ == "__main__":
