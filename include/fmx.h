@@ -68,23 +68,17 @@ int fmx_build_on_device(const uint16_t *text, int32_t n, int32_t sample_rate, in
 /* seconds fmx_build_on_device spent encoding the wavelet tree in HBM; 0 = it was encoded on the host */
 double fmx_build_wavelet_seconds(const fmx_index *idx);
 
-/* Image form (fmx_set_option("image_compact", 0 | 1), applies to images flattened afterwards: fmx_to_device / fmx_blob of an index
- * that has none yet).  0 (default): the bit vectors of the wavelet tree and the sampled-row bitmap are EXPANDED into 16-byte cells
- * {ones before, 96 bits} — a rank is one load + three popcounts; 0.64 bytes per text byte resident on the 256 MiB log.
- * 1 (compact): they stay in the reference's own compression (15-bit blocks as class + offset, RRR:225-286) as 16-block records
- * + offsets stream, decoded by the kernels through the value-of-offset table in LDS — smaller (bytes per text byte and timings:
- * DESIGN.md 3), a rank costs a second dependent load.  Results are identical; an image says which form it is, and travels as
- * before (fmx_blob / fmx_attach_device_blob). */
-/* The suffix table of a resident index: fmx_to_device / fmx_attach_device_blob grow, level by level, the set of strings of
- * *chars codes that OCCUR in the text, each with its SA interval (the state of FM:455-474 after a pattern's last *chars
- * characters, computed by the same rank code the queries run), and hash it: 16-byte slots, twice as many as strings.
- * Depth: option "suffix_table_chars" (default 4; at most what a 64-bit key holds: 8 codes of 8 bits, 4 of 16), cut where a
- * level would pass the budget (option "suffix_table_mb", default 256, 32 bytes per string; 0 = no table).  count / locate
- * batches start from it: one slot instead of 2 * (chars - 1) rank evaluations; a string that is not in it (it does not
- * occur, holds an unknown character, or its search raised a status) is searched by the loop.  Results, statuses and
- * LF-step counts are unchanged (option "suffix_table" = 0 makes launches ignore it, for A/B).  *chars = 0: no table;
- * *bytes = the table's size (8 MB for the 26,064 four-character strings of the 256 MiB synthetic log: sized so that the
- * fullest of its 16 slot columns stays half full; never above the budget). */
+/* The suffix table of a resident index: fmx_to_device / fmx_attach_device_blob grow, level by level and with the very rank code the
+ * queries run, the strings of 2, 3, ... codes that OCCUR in the text, each with its SA interval (the state of FM:455-474 after
+ * a pattern's last characters), and hash ALL levels into one open-addressing table of 16-byte slots {key, start, end} (groups
+ * of 64 slots, in-group slot = low bits of the first character's code XOR hash bits of the rest; at most 0.5 full, 0.7 where
+ * only that keeps it inside its limit).  Depth *chars: as deep as a 64-bit key holds (8 codes of 8 bits, 4 of 16; option
+ * "suffix_table_chars" caps it) while the table stays below the smaller of the budget (option "suffix_table_mb", default 256; 0
+ * = no table) and 1 / "suffix_table_image_fraction" of the image (default an eighth): 5 characters in 8.4 MB on the 256 MiB
+ * synthetic log.  count / locate batches start from it: one slot instead of 2 * (k - 1) rank evaluations for a pattern's last k
+ * <= *chars characters; a string that is not in it (it does not occur, holds an unknown character, or its search raised a
+ * status) is searched by the loop.  Results, statuses and LF-step counts are unchanged (option "suffix_table" = 0 makes
+ * launches ignore it, for A/B).  *chars = 0: no table; *bytes = the table's size. */
 int fmx_suffix_table_info(const fmx_index *idx, int32_t *chars, int64_t *bytes);
 
 /* FmIndex.read(ObjectInput) FM:983-1025; also accepts the ObjectOutputStream-framed form produced by
@@ -128,8 +122,11 @@ void *fmx_device_blob(const fmx_index *idx, size_t *len);
  * host-buffer entry points move it by DMA without staging copies; buffers that are not registered work all the same.
  * fmx_count_batch with ALL of its arrays registered copies nothing: one launch reads the patterns from the mapped arrays and
  * stores counts / LF-steps / statuses into them (option "host_mapped" = 0: the chunk pipeline instead; "host_direct_stores" = 0:
- * that pipeline with result copies).  Register WHOLE arrays: an array registered only in part is never handed to a kernel (both
- * ends are checked), but the HIP runtime refuses to copy such a range (FMX_E_HIP).
+ * that pipeline with result copies).  Register WHOLE arrays: a kernel is only handed an array that lies inside ONE range
+ * registered through THIS function (the library keeps the table; an array pinned some other way, or spanning two
+ * registrations, takes the staged copies), and the HIP runtime refuses to copy a range registered only in part (FMX_E_HIP).
+ * A registered array must stay registered, and must not be written by the caller, while a call that was given it is in
+ * flight: the kernels read and write its pages directly, and the offsets are validated on the host before the launch.
  * (hipHostRegister / hipHostUnregister; pages stay locked until unregistered.) */
 int fmx_host_register(void *p, size_t bytes);
 int fmx_host_unregister(void *p);
@@ -193,6 +190,10 @@ int fmx_count_ordered_dev(const fmx_index *idx, const uint16_t *d_pat, const int
  * hits by the first row of the patterns' SA ranges ("walk_fine" = 0 drops that order's fine pass); extractUntilBoundary batches
  * of "boundary_order_min" queries or more (default 32,768) are taken by text position.  No order changes a result. */
 int fmx_count_batch_is_planned(const fmx_index *idx, int32_t n);
+/* The same question for every batch policy: kind 0 = count() planned (as above), 1 = locate() walks its hits by the first row
+ * of the patterns' SA ranges ("walk_order_min"), 2 = extractUntilBoundary takes its queries by text position
+ * ("boundary_order_min").  1 / 0; results never depend on the answer. */
+int fmx_batch_policy(const fmx_index *idx, int kind, int64_t n);
 int fmx_locate_batch_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_t *d_pat_off, int32_t n,
                          int32_t max_matches, int32_t *d_locs, int32_t loc_cap, int32_t *d_found,
                          int32_t *d_lf_steps, int32_t *d_status, int32_t *d_range_ws /* 2*n ints */, void *stream);
@@ -258,6 +259,13 @@ int fmx_count_segments_dev(const fmx_index *const *segs, int32_t n_segs, const u
 int fmx_locate_segments_dev(const fmx_index *const *segs, int32_t n_segs, const int64_t *seg_base, const uint16_t *d_pat,
                             const int32_t *d_pat_off, int32_t n, int32_t max_matches, int64_t *d_locs, int32_t *d_found,
                             int32_t *d_status, int32_t *d_tmp, void *stream);
+/* count() AND locate() of one batch over a segment set in one pass: the range search of a segment (FM:455-474 = FM:506-523)
+ * yields both the count and the SA range its hits are located from, so this costs one search per segment where
+ * fmx_count_segments_dev + fmx_locate_segments_dev cost two.  Same outputs as the two calls (d_counts / d_lf_steps: int64 sums
+ * over the segments, d_lf_steps may be NULL: the LF-steps of the searches, not of the walks); d_tmp = 4*n + n*max_matches ints. */
+int fmx_count_locate_segments_dev(const fmx_index *const *segs, int32_t n_segs, const int64_t *seg_base, const uint16_t *d_pat,
+                                  const int32_t *d_pat_off, int32_t n, int32_t max_matches, int64_t *d_counts, int64_t *d_lf_steps,
+                                  int64_t *d_locs, int32_t *d_found, int32_t *d_status, int32_t *d_tmp, void *stream);
 
 /* ---- WaveletFixedBlockBoosting as a stand-alone structure (the reference's public class, WFBB:130-154) ----
  * `sequence` = symbols already mapped to small non-negative integers (short[] text of WFBB:130).  The handle
@@ -315,6 +323,13 @@ int fmx_device_count(void);
  * (layout of the image: tests force the reference's own routes with them).  Applied by fmx_build_on_device:
  * "wavelet_on_device" = 0 encodes the wavelet tree on the host.
  * Results are identical for every setting. */
+/* Image form (fmx_set_option("image_compact", 0 | 1), applies to images flattened afterwards: fmx_to_device / fmx_blob of an index
+ * that has none yet).  0 (default): the bit vectors of the wavelet tree and the sampled-row bitmap are EXPANDED into 16-byte cells
+ * {ones before, 96 bits} — a rank is one load + three popcounts; 0.64 bytes per text byte resident on the 256 MiB log.
+ * 1 (compact): they stay in the reference's own compression (15-bit blocks as class + offset, RRR:225-286) as 16-block records
+ * + offsets stream, decoded by the kernels through the value-of-offset table in LDS — smaller (bytes per text byte and timings:
+ * DESIGN.md 3), a rank costs a second dependent load.  Results are identical; an image says which form it is, and travels as
+ * before (fmx_blob / fmx_attach_device_blob). */
 int fmx_set_option(const char *name, int value);
 
 /* deterministic synthetic workload (bench / tests): see index4j_amd/csrc/fmx_synth.cpp */

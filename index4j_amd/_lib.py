@@ -28,9 +28,9 @@ SYMBOLS = [
     "fmx_input_length", "fmx_alphabet_length", "fmx_sample_rate", "fmx_extract_enabled",
     "fmx_blob", "fmx_to_device", "fmx_attach_device_blob", "fmx_device_blob", "fmx_host_register", "fmx_host_unregister",
     "fmx_count_batch", "fmx_locate_batch", "fmx_extract_batch", "fmx_extract_boundary_batch",
-    "fmx_count_batch_dev", "fmx_count_plan_dev", "fmx_count_ordered_dev", "fmx_count_batch_is_planned", "fmx_locate_batch_dev", "fmx_extract_batch_dev", "fmx_extract_boundary_batch_dev",
+    "fmx_count_batch_dev", "fmx_count_plan_dev", "fmx_count_ordered_dev", "fmx_count_batch_is_planned", "fmx_batch_policy", "fmx_locate_batch_dev", "fmx_extract_batch_dev", "fmx_extract_boundary_batch_dev",
     "fmx_locate_extract_batch", "fmx_locate_lines_batch", "fmx_locate_extract_batch_dev", "fmx_locate_lines_batch_dev",
-    "fmx_count_segments", "fmx_locate_segments", "fmx_count_segments_dev", "fmx_locate_segments_dev",
+    "fmx_count_segments", "fmx_locate_segments", "fmx_count_segments_dev", "fmx_locate_segments_dev", "fmx_count_locate_segments_dev",
     "fmx_wavelet_build", "fmx_wavelet_rank_batch", "fmx_wavelet_inverse_select_batch",
     "fmx_rrr_build", "fmx_rrr_rank_ones_batch", "fmx_rrr_access_batch", "fmx_rrr_rank_ones_batch_dev", "fmx_rrr_access_batch_dev",
     "fmx_convert_byte_pattern", "fmx_status_message", "fmx_status_kind", "fmx_last_error", "fmx_release_scratch", "fmx_device_count", "fmx_set_option",
@@ -56,6 +56,7 @@ def _load():
     L.fmx_load.argtypes = [vp, sz, P(vp)]
     L.fmx_save.argtypes = [vp, C.c_int, P(vp), P(sz)]
     L.fmx_save_key_order_modelled.argtypes = [vp]
+    L.fmx_batch_policy.argtypes = [vp, C.c_int, C.c_int64]
     L.fmx_free_buffer.argtypes = [vp]
     L.fmx_free_buffer.restype = None
     L.fmx_free.argtypes = [vp]
@@ -88,6 +89,7 @@ def _load():
     L.fmx_locate_segments.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp, vp, vp]
     L.fmx_count_segments_dev.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     L.fmx_locate_segments_dev.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
+    L.fmx_count_locate_segments_dev.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     L.fmx_wavelet_build.argtypes = [vp, C.c_int64, i32, P(vp)]
     L.fmx_wavelet_rank_batch.argtypes = [vp, vp, vp, i32, vp, vp]
     L.fmx_wavelet_inverse_select_batch.argtypes = [vp, vp, i32, vp, vp]

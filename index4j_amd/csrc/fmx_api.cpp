@@ -154,15 +154,26 @@ std::atomic<int> g_host_pipeline_min{131072};
 std::atomic<int> g_host_mapped{1};  // option "host_mapped": every array of a host-buffer count registered -> one launch over the mapped arrays, no copies
 std::atomic<int> g_host_direct_stores{1};  // option "host_direct_stores": the pipeline's kernels store results straight into registered arrays
 std::atomic<int> g_host_pipeline_chunk{262144};  // patterns per stage of that pipeline
+// what fmx_host_register pinned: start -> bytes (mapped_range trusts nothing else)
+std::mutex g_registered_mutex;
+std::map<uintptr_t, size_t> g_registered;
 std::atomic<int> g_sb_cache_limit{320};  // option "sb_cache_limit": applies to indexes made resident afterwards (tests: 0 = no LDS cache)
 int fail(int code, const std::string &msg) {
     g_err = msg;
+    // a failed runtime call also stays behind as the thread's "last error": taken off with the report, or the NEXT call's
+    // launchers — which ask hipGetLastError() after their launches — would report this call's failure as their own
+    if (code == FMX_E_HIP) (void)hipGetLastError();
     return code;
 }
+// (a failed runtime call also leaves its error as the thread's "last error": taken off here, or the next call's launchers —
+// which ask hipGetLastError() after their launches — would report this call's failure as their own)
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
         hipError_t e__ = (expr);                                                              \
-        if (e__ != hipSuccess) return fail(FMX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+        if (e__ != hipSuccess) {                                                              \
+            (void)hipGetLastError();                                                          \
+            return fail(FMX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));       \
+        }                                                                                     \
     } while (0)
 
 int ensure_blob(fmx_index *idx) {
@@ -248,7 +259,7 @@ int require_device(const fmx_index *idx, bool rrr_handle = false) {
     return FMX_OK;
 }
 
-constexpr int kWsPlan = 0, kWsBoundary = 1, kWsWalk = 2, kWsSegRange = 3;  // (kWsWalk: the walk order of locate, a plan-like head; kWsSegRange: a segment set's second {found, status, range} buffers)
+constexpr int kWsPlan = 0, kWsBoundary = 1, kWsWalk = 2, kWsSegRange = 3, kWsSegCounts = 4;  // (kWsWalk: the walk order of locate, a plan-like head; kWsSegRange: a segment set's second {found, status, range} buffers)
 std::atomic<int> g_segments_overlap{1};  // option "segments_overlap": 0 = a segment set's kernels all on the caller's stream (A/B)
 
 // the side stream of `stream` with at least n_events events (nullptr: could not be made — the caller stays on one stream)
@@ -424,14 +435,45 @@ struct PipeStreams {
     hipStream_t s[kPipeStreams] = {nullptr, nullptr, nullptr};
     hipEvent_t in[kPipeEvents] = {}, counted[kPipeEvents] = {}, done[kPipeEvents] = {};
 };
+// Sets whose thread has ended wait here for the next thread that needs one (a JVM's worker threads come and go: without this
+// every new thread made 3 streams and 48 events that nobody ever used again).  Never destroyed: a thread_local destructor may
+// run while the HIP runtime is shutting down, so it only hands its sets back.
+struct PipePool {
+    std::mutex mutex;
+    std::vector<PipeStreams *> idle;
+};
+PipePool &pipe_pool() {
+    static PipePool *pool = new PipePool();  // (leaked on purpose: outlives every thread_local destructor)
+    return *pool;
+}
+struct ThreadPipeSets {
+    std::vector<PipeStreams *> sets;
+    ~ThreadPipeSets() {
+        PipePool &pool = pipe_pool();
+        std::lock_guard<std::mutex> lock(pool.mutex);
+        for (PipeStreams *p : sets) pool.idle.push_back(p);
+    }
+};
 int pipe_streams(int device, PipeStreams **out) {
     // one set per device this thread has used (a thread that alternates between devices keeps both; nothing is re-created)
-    thread_local std::vector<PipeStreams *> sets;
+    thread_local ThreadPipeSets mine;
+    std::vector<PipeStreams *> &sets = mine.sets;
     for (PipeStreams *p : sets)
         if (p->device == device) {
             *out = p;
             return FMX_OK;
         }
+    {
+        PipePool &pool = pipe_pool();
+        std::lock_guard<std::mutex> lock(pool.mutex);
+        for (size_t i = 0; i < pool.idle.size(); ++i)
+            if (pool.idle[i]->device == device) {  // (its thread drained its streams before it returned from its last call)
+                sets.push_back(pool.idle[i]);
+                pool.idle.erase(pool.idle.begin() + (ptrdiff_t)i);
+                *out = sets.back();
+                return FMX_OK;
+            }
+    }
     std::unique_ptr<PipeStreams> ps(new PipeStreams());
     auto undo = [&]() {  // a set that could not be completed is taken apart again
         for (int i = 0; i < kPipeStreams; ++i)
@@ -908,7 +950,8 @@ static void build_suffix_table(fmx_index *idx) {
     idx->dev.suffix_shift = geometry.suffix_shift;
     idx->dev.suffix_mask = slots - 1;
     // order-1 statistics of the two-character strings for the plan's sort key (small alphabets; not having them is no error)
-    if (key_bits == 8 && idx->hdr.wt_sigma <= fmx::kOrder1MaxSigma) {
+    if (key_bits == 8 && idx->hdr.wt_sigma <= fmx::kOrder1MaxSigma &&
+        fmx::order1_lds_bytes(fmx::kPlanDefaultBins, idx->hdr.wt_sigma) <= fmx::kPlanCodesLdsMax) {
         void *d_o1 = nullptr;
         const size_t bytes = (size_t)idx->hdr.wt_sigma * idx->hdr.wt_sigma * 2 * sizeof(float);
         if (hipMalloc(&d_o1, bytes) == hipSuccess) {
@@ -1014,12 +1057,18 @@ int fmx_host_register(void *p, size_t bytes) {
     return guarded([&]() -> int {
     if (!p || bytes == 0) return fail(FMX_E_ARG, "bad arguments");
     HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    std::lock_guard<std::mutex> lock(g_registered_mutex);
+    g_registered[reinterpret_cast<uintptr_t>(p)] = bytes;
     return FMX_OK;
     });
 }
 int fmx_host_unregister(void *p) {
     return guarded([&]() -> int {
     if (!p) return fail(FMX_E_ARG, "bad arguments");
+    {
+        std::lock_guard<std::mutex> lock(g_registered_mutex);
+        g_registered.erase(reinterpret_cast<uintptr_t>(p));
+    }
     HIP_TRY(hipHostUnregister(p));
     return FMX_OK;
     });
@@ -1103,6 +1152,17 @@ int fmx_count_plan_dev(const fmx_index *idx, const uint16_t *d_pat, const int32_
     *d_plan = plan.plan.recs;
     return FMX_OK;
     });
+}
+
+// what the library decides for a batch of n queries (tests/test_gpu_policy.py pins the thresholds):
+// kind 0 = count(): is the batch planned (fmx_count_batch_is_planned); 1 = locate(): are the hits walked by the first row of
+// their ranges (walk_order_min); 2 = extractUntilBoundary: are the queries taken by text position (boundary_order_min)
+int fmx_batch_policy(const fmx_index *idx, int kind, int64_t n) {
+    if (!idx || n <= 0 || n > INT32_MAX) return 0;
+    if (kind == 0) return fmx_count_batch_is_planned(idx, (int32_t)n);
+    if (kind == 1) return k_walk_workspace_bytes(idx, idx->dev, (int32_t)n) != 0 ? 1 : 0;
+    if (kind == 2) return k_boundary_order_bytes(idx, idx->dev, n) != 0 ? 1 : 0;
+    return 0;
 }
 
 int fmx_count_batch_is_planned(const fmx_index *idx, int32_t n) {
@@ -1385,9 +1445,13 @@ int fmx_count_segments_dev(const fmx_index *const *segs, int32_t n_segs, const u
     });
 }
 
+// d_counts (nullable; with it d_lf_steps, nullable): ALSO the count() of every pattern summed over the segments — the range
+// search of a segment yields both the count and the SA range the hits are located from, so a caller that wants count() and
+// locate() of one batch (BASELINE configs[4]) pays ONE k_count per segment instead of two (fmx_count_locate_segments_dev)
 static int locate_segments_impl(const fmx_index *const *segs, int32_t n_segs, const int64_t *seg_base, const uint16_t *d_pat,
                                 const int32_t *d_pat_off, int32_t n, int32_t max_matches, int64_t *d_locs, int32_t *d_found,
-                                int32_t *d_status, int32_t *d_tmp, Scratch &scratch) {
+                                int32_t *d_status, int32_t *d_tmp, Scratch &scratch, int64_t *d_counts = nullptr,
+                                int64_t *d_lf_steps = nullptr) {
     if (n < 0 || max_matches < 1 || !seg_base || (int64_t)n * max_matches > INT32_MAX ||
         (n > 0 && (!d_pat_off || !d_locs || !d_found || !d_tmp)))
         return fail(FMX_E_ARG, "bad arguments");
@@ -1420,9 +1484,23 @@ static int locate_segments_impl(const fmx_index *const *segs, int32_t n_segs, co
             set_range[1] = set_found[1] + 2 * (size_t)n;
         }
     }
+    // (the counts of a segment, and its LF-steps, in buffers of their own — two sets beside the side stream — when the caller
+    // wants count() as well: the walk overwrites `found`)
+    int32_t *set_cnt[2] = {nullptr, nullptr}, *set_lf[2] = {nullptr, nullptr};
+    if (d_counts) {
+        void *extra = nullptr;
+        rc = scratch.get(kWsSegCounts, (size_t)n * 4 * sizeof(int32_t), &extra);
+        if (rc) return rc;
+        for (int b = 0; b < 2; ++b) {
+            set_cnt[b] = static_cast<int32_t *>(extra) + (size_t)b * 2 * (size_t)n;
+            set_lf[b] = set_cnt[b] + n;
+        }
+    }
     auto count_into = [&](int32_t s, hipStream_t on) {
-        return k_launch_count(segs[s], segs[s]->dev, segs[s]->n_cu, d_pat, d_pat_off, &plan, s != 0, n, set_found[lane ? s & 1 : 0],
-                              nullptr, set_status[lane ? s & 1 : 0], set_range[lane ? s & 1 : 0], on);
+        const int b = lane ? s & 1 : 0;
+        return k_launch_count(segs[s], segs[s]->dev, segs[s]->n_cu, d_pat, d_pat_off, &plan, s != 0, n,
+                              d_counts ? set_cnt[b] : set_found[b], (d_counts && d_lf_steps) ? set_lf[b] : nullptr, set_status[b],
+                              set_range[b], on);
     };
     // (events of the lane: [0] = the plan is made, [1 + s] = segment s's ranges are there, [1 + n_segs + s] = segment s is appended)
     auto ev = [&](size_t i) { return lane->ev[i]; };
@@ -1444,6 +1522,10 @@ static int locate_segments_impl(const fmx_index *const *segs, int32_t n_segs, co
             if (e) return fail(FMX_E_HIP, std::string("k_count launch: ") + hipGetErrorString((hipError_t)e));
         }
         if (lane && s >= 1) HIP_TRY(hipStreamWaitEvent(st, ev(1 + (size_t)s), 0));
+        if (d_counts) {
+            e = fmx::launch_segment_add_counts(d_counts, d_lf_steps, nullptr, set_cnt[b], set_lf[b], nullptr, n, s == 0, st);
+            if (e) return fail(FMX_E_HIP, std::string("k_segment_add_counts launch: ") + hipGetErrorString((hipError_t)e));
+        }
         // like the caller's loop `n += seg.locate(p, 0, len, locations, maxMatches - n)`: hits already
         // taken from earlier segments shrink this segment's limit
         e = k_launch_locate_walk(segs[s], segs[s]->dev, segs[s]->n_cu, set_range[b], n, max_matches, seg_locs, max_matches,
@@ -1469,6 +1551,19 @@ int fmx_locate_segments_dev(const fmx_index *const *segs, int32_t n_segs, const 
     Scratch scratch(segs[0], stream, false);
     return locate_segments_impl(segs, n_segs, seg_base, d_pat, d_pat_off, n, max_matches, d_locs, d_found, d_status, d_tmp,
                                 scratch);
+    });
+}
+
+int fmx_count_locate_segments_dev(const fmx_index *const *segs, int32_t n_segs, const int64_t *seg_base, const uint16_t *d_pat,
+                                  const int32_t *d_pat_off, int32_t n, int32_t max_matches, int64_t *d_counts, int64_t *d_lf_steps,
+                                  int64_t *d_locs, int32_t *d_found, int32_t *d_status, int32_t *d_tmp, void *stream) {
+    return guarded([&]() -> int {
+    int rc = segments_ok(segs, n_segs);
+    if (rc) return rc;
+    if (n > 0 && !d_counts) return fail(FMX_E_ARG, "bad arguments");
+    Scratch scratch(segs[0], stream, false);
+    return locate_segments_impl(segs, n_segs, seg_base, d_pat, d_pat_off, n, max_matches, d_locs, d_found, d_status, d_tmp,
+                                scratch, d_counts, d_lf_steps);
     });
 }
 
@@ -1573,18 +1668,27 @@ static bool is_pinned(const void *p) {
     return a.type == hipMemoryTypeHost;
 }
 
-// device address of a registered (mapped) host array, or nullptr: BOTH ends of [p, p + bytes) must be mapped, one range (a caller
-// that registered only the head of an array must not have a kernel write past it)
+// device address of a registered (mapped) host array, or nullptr.  [p, p + bytes) must lie inside ONE range registered through
+// fmx_host_register (g_registered): probing the two ends with hipHostGetDevicePointer, as round 4 did, proves nothing on ROCm —
+// a registered array's device pointer IS its host address, so two separate registrations with an unmapped gap between them
+// looked like one range, and a kernel reading or writing the gap faults (with XNACK off that aborts the process: a JVM under
+// JNI).  Arrays the caller pinned some other way simply take the staged path.
 static void *mapped_range(const void *p, size_t bytes) {
     if (!p || bytes == 0) return nullptr;
-    void *lo = nullptr, *hi = nullptr;
-    const char *c = static_cast<const char *>(p);
-    if (hipHostGetDevicePointer(&lo, const_cast<char *>(c), 0) != hipSuccess ||
-        hipHostGetDevicePointer(&hi, const_cast<char *>(c) + bytes - 1, 0) != hipSuccess) {
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(p);
+    {
+        std::lock_guard<std::mutex> lock(g_registered_mutex);
+        auto it = g_registered.upper_bound(lo);  // the last registration that starts at or below p
+        if (it == g_registered.begin()) return nullptr;
+        --it;
+        if (lo - it->first > it->second || bytes > it->second - (lo - it->first)) return nullptr;
+    }
+    void *dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, const_cast<void *>(p), 0) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }
-    return static_cast<char *>(hi) - static_cast<char *>(lo) == (ptrdiff_t)(bytes - 1) ? lo : nullptr;
+    return dev;
 }
 
 // fmx_count_batch with EVERY array registered (option "host_mapped", default 1): no copies at all — k_count reads the characters

@@ -89,7 +89,18 @@ struct DevIndex {
     // this index's DevIndex as the API layer keeps it in HBM (no LDS cache, no launch option applied): what a cold route reads
     const DevIndex *self;
 };
-constexpr int kOrder1MaxSigma = 90;  // 90^2 pairs of two floats = 64,800 bytes of LDS in k_plan_codes
+constexpr int kOrder1MaxSigma = 90;  // hard cap of the order-1 table (90^2 pairs of two floats = 64,800 bytes)
+// The plan kernels stage that table in LDS BEHIND their histogram (`bins` words): it is only used — and only built — where both
+// fit the kernels' dynamic LDS: sigma <= 78 at the default 4,096 bins (between 79 and 90 the table used to be built
+// and never read).
+constexpr size_t kPlanCodesLdsMax = 64 << 10;
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+constexpr size_t order1_lds_bytes(int bins, int sigma) {
+    return (size_t)bins * 4 + (size_t)sigma * sigma * 8 + ((size_t)sigma + 1) * 4;
+}
+constexpr int kPlanDefaultBins = 1 << 12;
 struct SuffixSlot {
     uint64_t key;  // kSuffixEmpty: free
     uint32_t start, end;

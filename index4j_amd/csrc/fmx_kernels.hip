@@ -888,11 +888,8 @@ FMX_KERNEL(kBlock) void k_rrr_access(DevIndex ix, const int32_t *__restrict__ po
 //      sort of each workgroup's 256 records on 10 key bits, in LDS.
 // Two short kernels (round 1: memset + four kernels with a tile-local radix sort, 76 us at 1 M patterns).
 
-// dynamic LDS of k_plan_codes with the order-1 table staged behind the histogram (the launcher and the kernel decide alike)
-constexpr size_t kPlanCodesLdsMax = 64 << 10;
-__host__ __device__ constexpr size_t order1_lds_bytes(int bins, int sigma) {
-    return (size_t)bins * 4 + (size_t)sigma * sigma * 8 + ((size_t)sigma + 1) * 4;
-}
+// (dynamic LDS of k_plan_codes with the order-1 table staged behind the histogram: order1_lds_bytes / kPlanCodesLdsMax in
+// fmx_device.hpp — the launcher, the kernel and the table's builder decide alike)
 
 // what the plan kernels keep in LDS beside their histogram (k_plan_codes, k_plan_fused)
 struct PlanTables {
@@ -1515,8 +1512,10 @@ static std::atomic<int> g_plan_fine{1};  // 0 = skip the window-local fine order
 // 0 = order by the trailing characters' codes even where a suffix table exists; 1 = by the SA row the table answers; 2 = by an
 // estimate of that row from the table's two-character strings (SortShape.sa_key)
 static std::atomic<int> g_plan_sa_key{2};
-// 1 = the plan stage of a batch of at most one tile per CU is ONE launch (k_plan_fused); 0 = k_plan_codes + k_plan_scatter (A/B)
-static std::atomic<int> g_plan_fused{1};
+// 1 = the plan stage of a batch of at most one tile per CU is ONE launch (k_plan_fused); 0 (default) = k_plan_codes +
+// k_plan_scatter.  Measured (round 5, configs[1]): step 0.1365 -> 0.1339 ms (-2 %), with two batches in flight 0.109 -> 0.117
+// (+7 %: workgroups waiting at the barrier hold their CUs) — not worth a spinning kernel by default.
+static std::atomic<int> g_plan_fused{0};
 static std::atomic<int> g_plan_spin_limit{4096};  // polls of k_plan_fused's barrier before a workgroup aborts the order (~1 us each)
 // locate: batches at least this large walk their hits by the first row of the patterns' SA ranges (0 = always in the caller's
 // order).  Measured on configs[1]'s index, <= 16 hits per pattern (tools/locate_order_probe.py): 16,384 patterns +8 % (the two

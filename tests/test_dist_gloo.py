@@ -114,6 +114,9 @@ def _check_contract_line(stdout, detail):
         if k not in ("config", "roofline", "cpu_baseline"):
             assert c[k] == detail[k], k
     assert isinstance(c["config"]["workload"], str) and "model" not in c["config"]
+    # process start -> timed loop (index build + image broadcasts): on the line, so that a first real multi-GPU run that is slow to
+    # set up shows where the time went
+    assert isinstance(c.get("setup_s"), float) and c["setup_s"] >= 0.0
 
 
 def test_bench_launches_itself_and_reports_the_ranks_that_really_ran():

@@ -427,6 +427,30 @@ def test_segment_set_count_and_locate_vs_oracle_and_brute_force():
             assert (locs[i, found[i]:] == -1).all()
             for x in exp:
                 assert (t16[x:x + len(p)] == p).all()
+    # count() and locate() of the batch in ONE pass over the segments (fmx_count_locate_segments_dev): the outputs of the two calls
+    import torch
+
+    dev = torch.device("cuda", 0)
+    n, mm = len(off) - 1, 5
+    d_pat = torch.from_numpy(np.ascontiguousarray(ch).view(np.int16)).to(dev)
+    d_off = torch.from_numpy(off).to(dev)
+    d_cnt = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_lf = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_locs = torch.full((n * mm,), -1, dtype=torch.int64, device=dev)
+    d_found = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_tmp = torch.zeros(n * (4 + mm), dtype=torch.int32, device=dev)
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = ia.lib.fmx_count_locate_segments_dev(sf.handles, K, sf.base_array.ctypes.data, d_pat.data_ptr(), d_off.data_ptr(), n, mm,
+                                              d_cnt.data_ptr(), d_lf.data_ptr(), d_locs.data_ptr(), d_found.data_ptr(), d_st.data_ptr(),
+                                              d_tmp.data_ptr(), sp)
+    assert rc == 0, ia.lib.fmx_last_error()
+    torch.cuda.synchronize()
+    locs, found, st2 = sf.locate_batch(ch, off, mm)
+    assert (d_cnt.cpu().numpy() == cnt).all() and (d_lf.cpu().numpy() == lf).all() and (d_st.cpu().numpy() == st).all()
+    got = d_locs.cpu().numpy().reshape(n, mm)
+    live = np.arange(mm)[None, :] < found[:, None]
+    assert (d_found.cpu().numpy() == found).all() and (got[live] == locs[live]).all()
 
 
 def test_segment_set_with_mixed_alphabet_sizes_long_patterns():

@@ -82,6 +82,7 @@ def main():
         ctx.ia, ctx.torch, ctx.dry, ctx.world, ctx.rank, ctx.local_rank = ia, torch, False, 1, 0, 0
         ctx.dev = ctx.cdev = dev
         ctx.dist, ctx.shared = None, False
+        ctx.t_start = __import__('time').time()
         seg = argparse.Namespace(segments=8, pattern_len=8, patterns_total=bench.SHARE_PATTERNS, segment_log2=args.text_log2,
                                  sample_rate=32, steps=args.calls, warmup=0, gpus=1, no_cpu_baseline=True, segments_check=0)
         bench.run_segments(ctx, seg)
