@@ -37,7 +37,8 @@
                      int32_t *, int32_t *, int32_t *, hipStream_t);                                                     \
     size_t count_workspace_bytes(const fmx::DevIndex &, int32_t n);                                                     \
     int launch_locate_walk(const fmx::DevIndex &, int, const int32_t *, int32_t, int32_t, int32_t *, int32_t, int32_t *, \
-                           int32_t *, int32_t *, const int32_t *, void *, size_t, bool, hipStream_t);                   \
+                           int32_t *, int32_t *, const int32_t *, void *, size_t, bool, hipStream_t, int64_t *, int64_t); \
+    int launch_segment_commit(int32_t *, int32_t *, const int32_t *, const int32_t *, int32_t, int32_t, int, hipStream_t); \
     size_t walk_workspace_bytes(const fmx::DevIndex &, int32_t n);                                                      \
     int launch_extract(const fmx::DevIndex &, int, const int32_t *, const int32_t *, int64_t, uint16_t *, int32_t, int32_t, \
                        int32_t *, int32_t *, int32_t *, const int32_t *, int32_t, int32_t, void *, size_t, bool, hipStream_t); \
@@ -260,6 +261,7 @@ int require_device(const fmx_index *idx, bool rrr_handle = false) {
 }
 
 constexpr int kWsPlan = 0, kWsBoundary = 1, kWsWalk = 2, kWsSegRange = 3, kWsSegCounts = 4;  // (kWsWalk: the walk order of locate, a plan-like head; kWsSegRange: a segment set's second {found, status, range} buffers)
+std::atomic<int> g_segments_direct{1};   // option "segments_direct": 0 = every segment's hits staged and appended (A/B)
 std::atomic<int> g_segments_overlap{1};  // option "segments_overlap": 0 = a segment set's kernels all on the caller's stream (A/B)
 
 // the side stream of `stream` with at least n_events events (nullptr: could not be made — the caller stays on one stream)
@@ -683,6 +685,10 @@ int fmx_set_option(const char *name, int value) {
     if (!name) return fail(FMX_E_ARG, "unknown option or bad value");
     if (!strcmp(name, "suffix_table")) g_suffix_table_in_use = value != 0;
     if (!strcmp(name, "plan_sa_key") && value >= 0 && value <= 2) g_plan_sa_key_api = value;
+    if (!strcmp(name, "segments_direct")) {
+        g_segments_direct = value != 0;
+        return FMX_OK;
+    }
     if (!strcmp(name, "segments_overlap")) {
         g_segments_overlap = value != 0;
         return FMX_OK;
@@ -1231,7 +1237,7 @@ static int walk_hits(const fmx_index *idx, const int32_t *d_range, int32_t n, in
     int rc = scratch.get(kWsWalk, ws_bytes, &ws);
     if (rc) return rc;
     int e = k_launch_locate_walk(idx, idx->dev, idx->n_cu, d_range, n, max_matches, d_locs, loc_cap, d_found, d_lf_steps,
-                                 d_status, d_taken, ws, ws_bytes, !scratch.per_call, st);
+                                 d_status, d_taken, ws, ws_bytes, !scratch.per_call, st, nullptr, 0);
     if (e) {
         // (an order that stopped half way leaves its histogram in the head of a per-stream workspace: clear it)
         if (ws && !scratch.per_call) (void)hipMemsetAsync(ws, 0, fmx::kPlanHeadBytes, st);
@@ -1528,15 +1534,21 @@ static int locate_segments_impl(const fmx_index *const *segs, int32_t n_segs, co
         }
         // like the caller's loop `n += seg.locate(p, 0, len, locations, maxMatches - n)`: hits already
         // taken from earlier segments shrink this segment's limit
+        // (from the second segment on the hits go straight into the set's rows behind those already taken, and a commit of a few
+        // bytes per pattern replaces the append of every hit: option "segments_direct" = 0 keeps the staged form, also used for
+        // the first segment — nothing is taken yet, its kernel needs no `taken` array)
+        const bool direct = g_segments_direct.load() && s > 0;
         e = k_launch_locate_walk(segs[s], segs[s]->dev, segs[s]->n_cu, set_range[b], n, max_matches, seg_locs, max_matches,
-                                 set_found[b], nullptr, set_status[b], s ? d_found : nullptr, ws, ws_bytes, !scratch.per_call, st);
+                                 set_found[b], nullptr, set_status[b], s ? d_found : nullptr, ws, ws_bytes, !scratch.per_call, st,
+                                 direct ? d_locs : nullptr, direct ? seg_base[s] : 0);
         if (e) {
             if (ws && !scratch.per_call) (void)hipMemsetAsync(ws, 0, fmx::kPlanHeadBytes, st);
             return fail(FMX_E_HIP, std::string("k_locate_walk launch: ") + hipGetErrorString((hipError_t)e));
         }
-        e = fmx::launch_segment_append_hits(d_locs, d_found, d_status, seg_locs, set_found[b], set_status[b], n, max_matches,
-                                            seg_base[s], s == 0, st);
-        if (e) return fail(FMX_E_HIP, std::string("k_segment_append_hits launch: ") + hipGetErrorString((hipError_t)e));
+        e = direct ? fmx::launch_segment_commit(d_found, d_status, set_found[b], set_status[b], n, max_matches, 0, st)
+                   : fmx::launch_segment_append_hits(d_locs, d_found, d_status, seg_locs, set_found[b], set_status[b], n, max_matches,
+                                                     seg_base[s], s == 0, st);
+        if (e) return fail(FMX_E_HIP, std::string("k_segment_append_hits / k_segment_commit launch: ") + hipGetErrorString((hipError_t)e));
         if (lane && s + 2 < n_segs) HIP_TRY(hipEventRecord(ev(1 + (size_t)n_segs + (size_t)s), st));
     }
     return FMX_OK;

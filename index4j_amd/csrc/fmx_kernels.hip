@@ -626,7 +626,11 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix_global, const int32_t *__
                                                         int32_t *__restrict__ status_out,
                                                         const int32_t *__restrict__ taken,
                                                         const PlanRec *__restrict__ order,
-                                                        const uint32_t *__restrict__ order_idle) {
+                                                        const uint32_t *__restrict__ order_idle,
+                                                        int64_t *__restrict__ set_locs, int64_t set_base) {
+    // set_locs (nullable; segment sets, with `taken`): the hits go straight into the SET's rows — int64 text positions moved by
+    // this segment's start, behind the taken[p] hits of the earlier segments — instead of into `locs` for a kernel that appends
+    // them (8 x 0.5 ms per step of configs[4]); k_segment_commit then advances the set's `found` by what was located here.
     FMX_FM_INV(ix_global);
     FMX_WITH_SB_CACHE(ix_global, ix);
     // order (nullable): the batch's records {start, end, pattern} by the first row of their ranges (k_walk_hist); its first
@@ -675,7 +679,11 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix_global, const int32_t *__
         for (; k < located; k += step) {
             int status = ST_OK;
             int32_t distance;
-            locs[(int64_t)p * loc_cap + k] = fm_locate_hit(ix, s_inv, start, k, distance, status);
+            const int32_t at = fm_locate_hit(ix, s_inv, start, k, distance, status);
+            if (set_locs)
+                set_locs[(int64_t)p * loc_cap + taken[p] + k] = set_base + at;
+            else
+                locs[(int64_t)p * loc_cap + k] = at;
             if (lf_steps && distance) atomicAdd(&lf_steps[p], distance);
             if (status && status_out) atomicOr(&status_out[p], status);
         }
@@ -1258,6 +1266,19 @@ __device__ __forceinline__ int2 walk_pair(const int32_t *__restrict__ range, con
     return make_int2(f, f < INT32_MAX ? f + 1 : f);
 }
 
+// A slot of an LDS counter for every lane that asks (`take`), ONE atomic per wave: the zero bin of the walk order takes most of a
+// batch's records in the later segments of a set (patterns whose maxMatches are already found), and 4,096 single adds to one LDS
+// word serialised (k_walk_hist 0.7-1.0 ms per 8 M patterns, 5.6 ms per step of configs[4]: profiles/r05_*segments*).
+__device__ __forceinline__ uint32_t wave_ticket(uint32_t *ctr, bool take) {
+    const uint64_t m = __ballot(take);
+    if (!m) return 0;
+    const int lane = threadIdx.x & 63, leader = __ffsll((unsigned long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(ctr, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
 // bins: the zero bin + 2^coarse_bits
 __global__ __launch_bounds__(kTileThreads) void k_walk_hist(const int32_t *__restrict__ range, int32_t n, int bins, int below,
                                                             const int32_t *__restrict__ taken, int32_t max_matches,
@@ -1270,9 +1291,13 @@ __global__ __launch_bounds__(kTileThreads) void k_walk_hist(const int32_t *__res
 #pragma unroll
     for (int k = 0; k < kTileItems; ++k) {
         const int64_t p = base + (int64_t)k * kTileThreads + threadIdx.x;
-        if (p >= n) continue;
-        const int2 r = walk_pair(range, froms, slot_found, slots, p);
-        atomicAdd(&s_hist[walk_bin(walk_key(r.x, r.y, taken, max_matches, p), below, bins)], 1u);
+        uint32_t b = 0xffffffffu;  // (no `continue`: every lane of the wave reaches the ballot)
+        if (p < n) {
+            const int2 r = walk_pair(range, froms, slot_found, slots, p);
+            b = walk_bin(walk_key(r.x, r.y, taken, max_matches, p), below, bins);
+        }
+        (void)wave_ticket(&s_hist[0], b == 0u);  // (the zero bin: one add per wave)
+        if (b != 0u && b != 0xffffffffu) atomicAdd(&s_hist[b], 1u);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < bins; i += kTileThreads) {
@@ -1334,8 +1359,10 @@ __global__ __launch_bounds__(kTileThreads) void k_plan_scatter(const PlanRec *__
         }
     }
 #pragma unroll
-    for (int k = 0; k < kTileItems; ++k)
-        if (bin[k] != 0xffffffffu) atomicAdd(&s_cnt[bin[k]], 1u);
+    for (int k = 0; k < kTileItems; ++k) {
+        if constexpr (kFromRange) (void)wave_ticket(&s_cnt[0], bin[k] == 0u);  // (the walk order's zero bin: one add per wave)
+        if (bin[k] != 0xffffffffu && !(kFromRange && bin[k] == 0u)) atomicAdd(&s_cnt[bin[k]], 1u);
+    }
     // exclusive scan of the histogram: per-thread chunks of consecutive bins, wave scan, wave totals through LDS
     const int per = (bins + kTileThreads - 1) / kTileThreads;
     const int lo = (int)threadIdx.x * per;
@@ -1375,8 +1402,12 @@ __global__ __launch_bounds__(kTileThreads) void k_plan_scatter(const PlanRec *__
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < kTileItems; ++k)
-        if (bin[k] != 0xffffffffu) *reinterpret_cast<Quad *>(recs_out + atomicAdd(&s_cnt[bin[k]], 1u)) = mine[k];
+    for (int k = 0; k < kTileItems; ++k) {
+        uint32_t slot = 0;
+        if constexpr (kFromRange) slot = wave_ticket(&s_cnt[0], bin[k] == 0u);
+        if (bin[k] != 0xffffffffu && !(kFromRange && bin[k] == 0u)) slot = atomicAdd(&s_cnt[bin[k]], 1u);
+        if (bin[k] != 0xffffffffu) *reinterpret_cast<Quad *>(recs_out + slot) = mine[k];
+    }
     // The last workgroup leaves histogram, cursors and ticket zeroed for the next plan in this workspace.  No fence:
     // every workgroup's histogram loads and cursor atomics have returned before it takes its ticket, and the zeroes
     // only have to be visible to the NEXT kernel on the stream (a __threadfence here writes the L2 back: 75 us).
@@ -1482,6 +1513,24 @@ __global__ __launch_bounds__(256) void k_segment_append_hits(int64_t *__restrict
     int32_t k = 0;
     for (; k < add && have + k < cap; ++k) locs[i * (int64_t)cap + have + k] = base + seg_locs[i * (int64_t)cap + k];
     found[i] = have + k;
+    if (status_total) {
+        const int32_t prev = first ? 0 : status_total[i];
+        status_total[i] = prev ? prev : st;
+    }
+}
+
+// a segment's hits are already in the set's rows (k_locate_walk, set_locs): advance `found` by them — unless the segment raised a
+// status for the pattern, whose hits then do not count (as k_segment_append_hits would not have appended them)
+__global__ __launch_bounds__(256) void k_segment_commit(int32_t *__restrict__ found, int32_t *__restrict__ status_total,
+                                                       const int32_t *__restrict__ seg_found,
+                                                       const int32_t *__restrict__ seg_status, int32_t n, int32_t cap, int first) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t have = first ? 0 : found[i];
+    const int32_t st = seg_status[i];
+    int32_t add = st ? 0 : seg_found[i];
+    if (add > cap - have) add = cap - have;
+    found[i] = have + (add > 0 ? add : 0);
     if (status_total) {
         const int32_t prev = first ? 0 : status_total[i];
         status_total[i] = prev ? prev : st;
@@ -1796,7 +1845,9 @@ size_t walk_workspace_bytes(const DevIndex &ix, int32_t n) {
 // workspace (nullable): walk_workspace_bytes(ix, n) — the patterns are then walked by the first row of their ranges
 int launch_locate_walk(const DevIndex &ix, int n_cu, const int32_t *range, int32_t n, int32_t max_matches,
                        int32_t *locs, int32_t loc_cap, int32_t *found, int32_t *lf, int32_t *status,
-                       const int32_t *taken, void *workspace, size_t workspace_bytes, bool head_is_zero, hipStream_t st) {
+                       const int32_t *taken, void *workspace, size_t workspace_bytes, bool head_is_zero, hipStream_t st,
+                       int64_t *set_locs, int64_t set_base) {
+    if (set_locs && !taken) return (int)hipErrorInvalidValue;  // (the set's rows are addressed behind the hits already taken)
     if (n <= 0) return 0;
     int32_t slots = (max_matches > 0 && max_matches < loc_cap) ? max_matches : loc_cap;
     if (slots < 1) slots = 1;
@@ -1830,7 +1881,7 @@ int launch_locate_walk(const DevIndex &ix, int n_cu, const int32_t *range, int32
         order_idle = ticket + 1;
     }
     FMX_DISPATCH(k_locate_walk, (int64_t)n * (slots < kWalkLanes ? slots : kWalkLanes), ix, range, n, max_matches, locs, loc_cap,
-                 slots, found, lf, status, taken, order, order_idle);
+                 slots, found, lf, status, taken, order, order_idle, set_locs, set_base);
     return (int)hipGetLastError();
 }
 
@@ -1859,6 +1910,14 @@ int launch_segment_append_hits(int64_t *locs, int32_t *found, int32_t *status_to
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_segment_append_hits, dim3((n + 255) / 256), dim3(256), 0, st, locs, found, status_total, seg_locs,
                        seg_found, seg_status, n, cap, base, first);
+    return (int)hipGetLastError();
+}
+
+int launch_segment_commit(int32_t *found, int32_t *status_total, const int32_t *seg_found, const int32_t *seg_status, int32_t n,
+                          int32_t cap, int first, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_segment_commit, dim3((n + 255) / 256), dim3(256), 0, st, found, status_total, seg_found, seg_status, n, cap,
+                       first);
     return (int)hipGetLastError();
 }
 

@@ -83,6 +83,9 @@ def main():
                 "walk_order_min": rnd.choice([1, 1, 0, 32768]),  # locate: hits walked by the first row of the ranges from this batch size on
                 "walk_fine": rnd.choice([1, 1, 0]),
                 "boundary_order_min": rnd.choice([1, 1, 0, 32768]),  # extractUntilBoundary: queries by text position from this batch size on
+                "plan_fused": rnd.choice([0, 0, 1]),  # the plan stage as one launch (round 5) ...
+                "plan_spin_limit": rnd.choice([4096, 4096, 0]),  # ... whose barrier gives up at once: records in the caller's order
+                "boundary_first_fill": rnd.choice([2, 2, 0]),  # extractUntilBoundary: a lane's two walks interleaved / one after the other
                 "regroup_by_length": rnd.choice([1, 1, 0])}  # k_count: workgroups with mixed pattern lengths regroup by length  # the plan's order: estimated SA row / the table's answer / trailing codes
         check_seed = rnd.randrange(1 << 30)
         if args.only_case >= 0 and cases != args.only_case:
