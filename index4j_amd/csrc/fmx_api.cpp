@@ -1534,10 +1534,9 @@ static int locate_segments_impl(const fmx_index *const *segs, int32_t n_segs, co
         }
         // like the caller's loop `n += seg.locate(p, 0, len, locations, maxMatches - n)`: hits already
         // taken from earlier segments shrink this segment's limit
-        // (from the second segment on the hits go straight into the set's rows behind those already taken, and a commit of a few
-        // bytes per pattern replaces the append of every hit: option "segments_direct" = 0 keeps the staged form, also used for
-        // the first segment — nothing is taken yet, its kernel needs no `taken` array)
-        const bool direct = g_segments_direct.load() && s > 0;
+        // (the hits go straight into the set's rows behind those already taken, and a commit of a few bytes per pattern replaces
+        // the append of every hit; option "segments_direct" = 0 keeps the staged form)
+        const bool direct = g_segments_direct.load() != 0;
         e = k_launch_locate_walk(segs[s], segs[s]->dev, segs[s]->n_cu, set_range[b], n, max_matches, seg_locs, max_matches,
                                  set_found[b], nullptr, set_status[b], s ? d_found : nullptr, ws, ws_bytes, !scratch.per_call, st,
                                  direct ? d_locs : nullptr, direct ? seg_base[s] : 0);
@@ -1545,7 +1544,7 @@ static int locate_segments_impl(const fmx_index *const *segs, int32_t n_segs, co
             if (ws && !scratch.per_call) (void)hipMemsetAsync(ws, 0, fmx::kPlanHeadBytes, st);
             return fail(FMX_E_HIP, std::string("k_locate_walk launch: ") + hipGetErrorString((hipError_t)e));
         }
-        e = direct ? fmx::launch_segment_commit(d_found, d_status, set_found[b], set_status[b], n, max_matches, 0, st)
+        e = direct ? fmx::launch_segment_commit(d_found, d_status, set_found[b], set_status[b], n, max_matches, s == 0, st)
                    : fmx::launch_segment_append_hits(d_locs, d_found, d_status, seg_locs, set_found[b], set_status[b], n, max_matches,
                                                      seg_base[s], s == 0, st);
         if (e) return fail(FMX_E_HIP, std::string("k_segment_append_hits / k_segment_commit launch: ") + hipGetErrorString((hipError_t)e));

@@ -506,7 +506,11 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
         status |= __shfl_xor(status, 1);
         if (role == 0) {
             const int32_t d = end - start;
+#if defined(FMX_EXPERIMENT_STORE_Q)
+            counts[q] = d > 0 ? d : 0;  // (experiment: results in PROCESSING order — coalesced stores; what do the scattered ones cost?)
+#else
             counts[p] = d > 0 ? d : 0;  // FM:473
+#endif
             if (lf_steps) lf_steps[p] = steps;
             if (status_out) status_out[p] = status;
             if (range_out) {
@@ -628,8 +632,8 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix_global, const int32_t *__
                                                         const PlanRec *__restrict__ order,
                                                         const uint32_t *__restrict__ order_idle,
                                                         int64_t *__restrict__ set_locs, int64_t set_base) {
-    // set_locs (nullable; segment sets, with `taken`): the hits go straight into the SET's rows — int64 text positions moved by
-    // this segment's start, behind the taken[p] hits of the earlier segments — instead of into `locs` for a kernel that appends
+    // set_locs (nullable; segment sets): the hits go straight into the SET's rows — int64 text positions moved by this
+    // segment's start, behind the taken[p] hits of the earlier segments (none: the first segment) — instead of into `locs` for a kernel that appends
     // them (8 x 0.5 ms per step of configs[4]); k_segment_commit then advances the set's `found` by what was located here.
     FMX_FM_INV(ix_global);
     FMX_WITH_SB_CACHE(ix_global, ix);
@@ -681,7 +685,7 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix_global, const int32_t *__
             int32_t distance;
             const int32_t at = fm_locate_hit(ix, s_inv, start, k, distance, status);
             if (set_locs)
-                set_locs[(int64_t)p * loc_cap + taken[p] + k] = set_base + at;
+                set_locs[(int64_t)p * loc_cap + (taken ? taken[p] : 0) + k] = set_base + at;
             else
                 locs[(int64_t)p * loc_cap + k] = at;
             if (lf_steps && distance) atomicAdd(&lf_steps[p], distance);
@@ -1847,7 +1851,6 @@ int launch_locate_walk(const DevIndex &ix, int n_cu, const int32_t *range, int32
                        int32_t *locs, int32_t loc_cap, int32_t *found, int32_t *lf, int32_t *status,
                        const int32_t *taken, void *workspace, size_t workspace_bytes, bool head_is_zero, hipStream_t st,
                        int64_t *set_locs, int64_t set_base) {
-    if (set_locs && !taken) return (int)hipErrorInvalidValue;  // (the set's rows are addressed behind the hits already taken)
     if (n <= 0) return 0;
     int32_t slots = (max_matches > 0 && max_matches < loc_cap) ? max_matches : loc_cap;
     if (slots < 1) slots = 1;

@@ -18,7 +18,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 QUERY_KERNELS = ("k_count<", "k_plan_codes", "k_plan_scatter", "k_plan_fine", "k_plan_fused", "k_walk_hist", "k_locate_walk", "k_extract<",
-                 "k_extract_boundary", "k_segment_add_counts", "k_segment_append_hits", "k_fill_offsets")
+                 "k_extract_boundary", "k_segment_add_counts", "k_segment_append_hits", "k_segment_commit", "k_fill_offsets")
 NAMES = {"FETCH_SIZE": "FETCH_SIZE_KiB", "WRITE_SIZE": "WRITE_SIZE_KiB", "TCC_HIT_sum": "TCC_HIT", "TCC_MISS_sum": "TCC_MISS"}
 
 
@@ -73,8 +73,9 @@ def main():
             print("row %-34s  NO DATA (see %s/*.err)" % (key, d))
             continue
         rows[key] = row
-        traffic = (row["FETCH_SIZE_KiB"] * 2.0 + row["WRITE_SIZE_KiB"]) * 1024
-        print("row %-34s  calls %d  FETCH %.1f MiB x 2 + WRITE %.1f MiB = %.1f MB per call" % (
+        # (scattered 16-byte loads: a miss fills a 64-byte sector, which is what FETCH_SIZE tallies — tools/calibrate_fetch.py)
+        traffic = (row["FETCH_SIZE_KiB"] + row["WRITE_SIZE_KiB"]) * 1024
+        print("row %-34s  calls %d  FETCH %.1f MiB + WRITE %.1f MiB = %.1f MB per call" % (
             key, row["calls"], row["FETCH_SIZE_KiB"] / 1024, row["WRITE_SIZE_KiB"] / 1024, traffic / 1e6))
         for k, cs in row["kernels"].items():
             print("      %-44s x%-5.2f %s" % (k, cs["launches_per_call"], "  ".join(
