@@ -1907,70 +1907,100 @@ FMX_HD int32_t window_code_at(const DevIndex &ix, const uint16_t *inv, TextWindo
     return window_slot<G>(w, k)[(int64_t)(pos - k * w.s) * w.row_stride];
 }
 
+#if !defined(__HIPCC__)
+inline long g_marked_replays[3] = {0, 0, 0};
+#endif
 FMX_HD int fmx_clzll(uint64_t v) { return __builtin_clzll(v); }  // (v != 0)
 FMX_HD int fmx_ctzll(uint64_t v) { return __builtin_ctzll(v); }
 
-// The replay of extractUntilBoundary (mode 0, FM:640-759) for the common case, WITHOUT walking the text character by
-// character: the first fill's walks noted where their intervals hold the boundary and the sentinel (TextWindow.marks), so the
-// line's two ends are two bit searches and a group reduction, and what the reference's loops leave in `destination` is
+// The replay of extractUntilBoundary / ...Left / ...Right (FM:640-922) for the common case, WITHOUT walking the text character
+// by character: the first fill's walks noted where their intervals hold the boundary and the sentinel (TextWindow.marks), so
+// the line's two ends are two bit searches and a group reduction, and what the reference's loops leave in `destination` is
 // known in closed form —
-//   left part (FM:655-690): text(lb, from) is written at the END of destination going down, then moved to `offset`: both
-//     copies stay (the temporary one is part of the row the caller sees);
-//   right part (FM:692-758): whole +4 chunks text[from, E), E = the end of the chunk that holds the first boundary rb >= from
-//     (the characters behind rb inside that chunk are written too), at offset + downLen; return downLen + (rb - from).
+//   left part (modes 0 and 1, FM:655-690 / FM:788-828): text(lb, from) is written at the END of destination going down, then
+//     moved to `offset`: both copies stay (the temporary one is part of the row the caller sees); mode 1 starts one position
+//     further right (FM:774) and returns downLen;
+//   right part (modes 0 and 2, FM:692-758 / FM:853-921): whole +4 chunks text[from, E), E = the end of the chunk that holds the
+//     first boundary rb >= from (the characters behind rb inside that chunk are written too); mode 0 writes them at offset +
+//     downLen and returns downLen + (rb - from); mode 2 writes text(from, E) one slot lower (the character AT `from` is not
+//     written, FM:899-902) and returns rb - from - 1.
 // The G lanes of the group write those characters side by side (lane g: every G-th one) instead of ONE lane writing while
 // all G replay the same loops.  Anything else — an end outside the fetched windows, `from` on a boundary (FM:725-728), a line
-// that reaches the text's end (FM:745-752) or does not fit its destination with room to spare (FM:732-737 and overlapping
-// copies) — returns false and the literal replay below runs as before.  The result of the test is the same in every lane of
-// the group.
+// that reaches the text's end (FM:745-752), a destination the line does not fit with room to spare (FM:732-737, 816-821,
+// 893-898, and overlapping copies) — returns false and the literal replay below runs as before.  The result of the test is the
+// same in every lane of the group.  `from` is the position AFTER mode 1's increment.
 template <int G>
-FMX_HD bool fm_boundary_replay_marked(const DevIndex &ix, const TextWindow<G> &wl, const TextWindow<G> &wr, int32_t from,
+FMX_HD bool fm_boundary_replay_marked(const DevIndex &ix, int mode, const TextWindow<G> &wl, const TextWindow<G> &wr, int32_t from,
                                       int32_t k0, uint16_t *dest, int32_t dst_len, int32_t offset, int32_t &ret) {
     const int32_t s = wl.s;
     const int32_t o = from - k0 * s;  // 0 <= o < s <= 64
     const uint64_t below = (1ull << o) - 1ull;
-    // lb: the nearest position below `from` that holds the boundary or the sentinel (FM:674-680); -1 = the text's start
-    int32_t cand = -1;
-    if (wl.marks_k >= 0 && wl.marks_k <= k0) {
-        uint64_t m = wl.marks.boundary | wl.marks.zero;
-        if (wl.marks_k == k0) m &= below;
-        if (m) cand = wl.marks_k * s + 63 - fmx_clzll(m);
+    if (offset < 0) return false;
+    int32_t a = 0;  // downLen
+    int32_t lb = -1;
+    if (mode != 2) {
+        // lb: the nearest position below `from` that holds the boundary or the sentinel (FM:674-680); -1 = the text's start
+        int32_t cand = -1;
+        if (wl.marks_k >= 0 && wl.marks_k <= k0) {
+            uint64_t m = wl.marks.boundary | wl.marks.zero;
+            if (wl.marks_k == k0) m &= below;
+            if (m) cand = wl.marks_k * s + 63 - fmx_clzll(m);
+        }
+        lb = group_max<G>(cand);
+        if (lb < 0 && wl.k_lo != 0) return false;  // the line starts left of the window
+        a = from - lb - 1;
+        // mode 0 stops at dst_len characters (FM:664), mode 1 raises when the write position reaches `offset` (FM:816-821)
+        if (mode == 0 ? a >= dst_len : a >= dst_len - 1 - offset) return false;
     }
-    const int32_t lb = group_max<G>(cand);
-    if (lb < 0 && wl.k_lo != 0) return false;  // the line starts left of the window
-    // rb: the first position >= from that holds the boundary
-    int32_t rc = INT32_MAX;
-    if (wl.marks_k == k0) {
-        const uint64_t m = wl.marks.boundary & ~below;
-        if (m) rc = k0 * s + fmx_ctzll(m);
+    int64_t right_len = 0;
+    int32_t rb = 0;
+    if (mode != 1) {
+        // rb: the first position >= from that holds the boundary
+        int32_t rc = INT32_MAX;
+        if (wl.marks_k == k0) {
+            const uint64_t m = wl.marks.boundary & ~below;
+            if (m) rc = k0 * s + fmx_ctzll(m);
+        }
+        if (wr.marks_k > k0 && wr.marks.boundary) {
+            const int32_t r2 = wr.marks_k * s + fmx_ctzll(wr.marks.boundary);
+            rc = r2 < rc ? r2 : rc;
+        }
+        rb = group_min<G>(rc);
+        if (rb == INT32_MAX || rb <= from) return false;  // not in the windows / `from` itself is the boundary
+        const int64_t e = (int64_t)from + 4 * (int64_t)((rb - from) / 4 + 1);  // end of rb's chunk
+        if (e >= (int64_t)ix.length - 1) return false;  // the last chunk is clamped / ends the loop by itself (FM:745-752)
+        const int32_t k_last = (int32_t)((e - 1) / s);
+        if (k_last > k0 && (wr.k_lo < 0 || k_last >= wr.k_lo + wr.n)) return false;
+        right_len = e - from;
     }
-    if (wr.marks_k > k0 && wr.marks.boundary) {
-        const int32_t r2 = wr.marks_k * s + fmx_ctzll(wr.marks.boundary);
-        rc = r2 < rc ? r2 : rc;
+    // everything fits, and the final characters stay below the left part's temporary copy at the row's end
+    // (the capacity check of FM:732-737 / 893-898 looks at offset + downLen + r for every character r of the chunks, also in
+    // mode 2, which writes one slot lower)
+    const int64_t used = (int64_t)a + right_len;
+    if ((int64_t)offset + used > (int64_t)dst_len - a) return false;
+    if (mode != 2) {
+        uint16_t *tmp = dest + (dst_len - a);
+        for (int32_t i = wl.g; i < a; i += G) {
+            const int32_t pos = lb + 1 + i, k = pos / s;
+            const uint16_t ch = fm_char_of(ix, (int32_t)window_slot<G>(wl, k)[(int64_t)(pos - k * s) * wl.row_stride]);
+            tmp[i] = ch;            // FM:682 / 810
+            dest[offset + i] = ch;  // FM:690 / 828
+        }
     }
-    const int32_t rb = group_min<G>(rc);
-    if (rb == INT32_MAX || rb <= from) return false;  // not in the windows / `from` itself is the boundary
-    const int32_t a = from - lb - 1;  // downLen
-    const int64_t e = (int64_t)from + 4 * (int64_t)((rb - from) / 4 + 1);  // end of rb's chunk
-    if (e >= (int64_t)ix.length - 1) return false;  // the last chunk is clamped / ends the loop by itself (FM:745-752)
-    const int32_t k_last = (int32_t)((e - 1) / s);
-    if (k_last > k0 && (wr.k_lo < 0 || k_last >= wr.k_lo + wr.n)) return false;
-    const int64_t right_len = e - from;
-    if (offset < 0 || a >= dst_len || (int64_t)offset + a + right_len > (int64_t)dst_len - a) return false;
-    uint16_t *tmp = dest + (dst_len - a);
-    for (int32_t i = wl.g; i < a; i += G) {
-        const int32_t pos = lb + 1 + i, k = pos / s;
-        const uint16_t ch = fm_char_of(ix, (int32_t)window_slot<G>(wl, k)[(int64_t)(pos - k * s) * wl.row_stride]);
-        tmp[i] = ch;          // FM:682
-        dest[offset + i] = ch;  // FM:690
+    if (mode != 1) {
+        // mode 0: text[from + i] at offset + a + i; mode 2: text[from + i], i >= 1, at offset + i - 1
+        uint16_t *up = mode == 0 ? dest + offset + a : dest + offset - 1;
+        for (int32_t i = wl.g; i < (int32_t)right_len; i += G) {
+            if (mode == 2 && i == 0) continue;  // the character AT `from` is not part of (from, boundary]
+            const int32_t pos = from + i, k = pos / s;
+            const TextWindow<G> &w = k <= k0 ? wl : wr;
+            up[i] = fm_char_of(ix, (int32_t)window_slot<G>(w, k)[(int64_t)(pos - k * s) * w.row_stride]);  // FM:738-739 / 899-902
+        }
     }
-    uint16_t *up = dest + offset + a;
-    for (int32_t i = wl.g; i < (int32_t)right_len; i += G) {
-        const int32_t pos = from + i, k = pos / s;
-        const TextWindow<G> &w = k <= k0 ? wl : wr;
-        up[i] = fm_char_of(ix, (int32_t)window_slot<G>(w, k)[(int64_t)(pos - k * s) * w.row_stride]);  // FM:738-739
-    }
-    ret = a + (rb - from);  // FM:758
+    ret = mode == 0 ? a + (rb - from) : mode == 1 ? a : rb - from - 1;  // FM:758 / 830 / 921
+#if !defined(__HIPCC__)
+    ++g_marked_replays[mode];  // (host simulation only: the tests make sure this route is the one they exercise)
+#endif
     return true;
 }
 
@@ -2023,8 +2053,8 @@ FMX_HD int32_t fm_extract_boundary_group(const DevIndex &ix, const uint16_t *inv
         if (mode != 1) window_refill<G>(ix, inv, wr, k0 + 1, +1);   // [k0+1, k0+G]
     }
     int32_t ret = 0;
-    if (mode == 0 && s <= 64 && !wl.suspect && !wr.suspect &&
-        fm_boundary_replay_marked<G>(ix, wl, wr, from, k0, dest, dst_len, offset, ret)) {
+    if (s <= 64 && !wl.suspect && !wr.suspect &&
+        fm_boundary_replay_marked<G>(ix, mode, wl, wr, from, k0, dest, dst_len, offset, ret)) {
         steps = group_sum<G>(wl.steps + wr.steps);
         return ret;
     }

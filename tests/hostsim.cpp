@@ -277,3 +277,6 @@ void sim_extract_boundary(const uint8_t *blob, const int32_t *froms, int32_t n, 
     delete[] scratch;
 }
 }
+
+// how often the marked replay of extractUntilBoundary answered (per mode) since the library was loaded
+extern "C" long sim_marked_replays(int mode) { return (mode >= 0 && mode < 3) ? fmx::g_marked_replays[mode] : -1; }

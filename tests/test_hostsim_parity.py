@@ -1,6 +1,7 @@
 """The device source (index4j_amd/csrc/fmx_device.hpp) compiled for the host by tests/hostsim.cpp, checked
 against the oracle on CPU.  This is a test-only simulation used to debug without a GPU — the product
 never runs queries on the host; the real parity tests are in test_gpu_parity.py (-m gpu)."""
+import ctypes as C
 import random
 
 import numpy as np
@@ -223,3 +224,34 @@ def test_compact_images_on_the_host_simulation():
         assert ia.lib.fmx_set_option(b"image_compact", 0) == 0
     g = ia.FmIndex(HD[:30_000], 8, True, device=None)
     assert not hostsim.HostSim(g).compact
+
+
+def test_marked_replay_of_extract_until_boundary_is_the_route_taken_and_matches_the_oracle():
+    """Round 5: the group form of extractUntilBoundary{,Left,Right} finds a line's two ends from the marks its first fill's walks
+    left (fm_boundary_replay_marked) and writes the row in closed form; everything else falls back to the literal replay.  Short
+    lines at sample rates 32 / 64 keep whole lines inside the two intervals a group of ONE lane fetches (the host simulation), so the
+    route is exercised here in all three modes — whole destination rows (incl. the left part's temporary copy at the row's end),
+    lengths, statuses and aux against the oracle, with destinations that fit generously, barely, and not at all."""
+    rnd = random.Random(77)
+    words = ["alpha", "beta", "gamma", "delta", "x", "INFO", "blk_123", "10.0.0.7", "ok"]
+    lines = []
+    while sum(len(x) + 1 for x in lines) < 6000:
+        lines.append(" ".join(rnd.choice(words) for _ in range(rnd.randrange(1, 5))))
+    text = "\n".join(lines) + "\n"
+    L = hostsim.lib()
+    L.sim_marked_replays.restype = C.c_long
+    for sr in (32, 64):
+        f = ia.FmIndex(text, sr, True, device=None)
+        h = hostsim.HostSim(f)
+        o = orc.OracleFmIndex(text, sr, True)
+        froms = np.array([rnd.randrange(len(text)) for _ in range(400)] + [0, len(text) - 1, len(text) - 2], np.int32)
+        for mode in (0, 1, 2):
+            before = L.sim_marked_replays(mode)
+            for cap, offs in ((300, 0), (300, 7), (64, 0), (40, 3), (12, 0), (5, 1)):
+                for accel in (2, 3):
+                    dst = np.full((len(froms), cap), 0xABCD, np.uint16)
+                    dst, ol, st, aux, _lf = h.extract_boundary_batch(froms, "\n", mode, cap, offs, dst=dst, accelerate=accel)
+                    odst, olen, ost, oaux = o.extract_until_boundary_batch(mode, froms, "\n", cap, offset=offs, threads=4, fill=0xABCD)
+                    assert (st == ost).all() and (ol == olen).all() and (aux == oaux).all(), (sr, mode, cap, offs, accel)
+                    assert (dst == odst).all(), (sr, mode, cap, offs, accel)
+            assert L.sim_marked_replays(mode) - before > 400, "the marked replay answered too few of mode %d's queries" % mode
