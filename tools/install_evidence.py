@@ -26,8 +26,14 @@ def main():
     doc = json.load(open(pmc))
     doc["calibration"] = json.load(open(os.path.join(go, tag + "_fetch_calibration.json")))
     json.dump(doc, open(pmc, "w"), indent=1)
-    rows_report = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarize_rows.py"), os.path.join(go, "prof_rows_" + tag), "--update"],
-                                 capture_output=True, text=True, check=True).stdout
+    # the rows were summarised ON THE BOX (rows.json, summary.txt) before its largest counter CSVs were dropped from the hand-back
+    rows = json.load(open(os.path.join(go, "prof_rows_" + tag, "rows.json")))
+    doc = json.load(open(pmc))
+    doc.update(rows)
+    if doc["rows_kernel_source_sha"] != doc["kernel_source_sha"]:
+        raise SystemExit("the rows' counters and the headline's were taken on different kernel sources")
+    json.dump(doc, open(pmc, "w"), indent=1)
+    rows_report = open(os.path.join(go, "prof_rows_" + tag, "summary.txt")).read()
     open(os.path.join(prof, tag + "_rows_counters.txt"), "w").write(rows_report)
     copies = {os.path.join(go, "prof_" + tag, "summary.txt"): tag + "_final_summary.txt",
               os.path.join(go, tag + "_bench_stdout.txt"): tag + "_bench_unprofiled_stdout.txt",

@@ -26,5 +26,5 @@ while IFS= read -r row; do
 done < "$OUT/rows.txt"
 cd "$ROOT"
 python3 tools/summarize_rows.py "$OUT" > "$OUT/summary.txt" 2>&1
-find "$OUT" -name '*.csv' -size +4M -delete
+find "$OUT" -name '*.csv' -size +16M -delete
 cat "$OUT/summary.txt"
