@@ -808,7 +808,7 @@ def run_count(ctx, args):
                    "sample_rate": args.sample_rate, "batches": n_batches,
                    # the synthetic log repeats itself: windows drawn from it at random coincide.  Every pattern is searched (no
                    # result is shared between equal patterns); equal and near-equal patterns read the same lines, which is what the
-                   # plan's order and the caches turn into speed — a text of higher entropy gains less (DESIGN.md section 4).
+                   # plan's order and the caches turn into speed — a text of higher entropy gains less (DESIGN.md section 6).
                    "distinct_patterns_batch0": distinct_patterns,
                    "parallelism": "one batch of %d patterns sharded x%d (contiguous shards from rank 0), index image "
                                   "broadcast and replicated" % (world * n, world),

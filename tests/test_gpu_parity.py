@@ -219,7 +219,7 @@ def test_large_batch_properties_16mib():
     cnt2, _ = fm.count_batch(pat, off)
     assert (cnt2 == cnt).all()
     # extractUntilBoundary round trip: the line around each hit, vs a numpy scan for '\\n'.  Inside the
-    # unterminated LAST line the reference itself returns a length one short (FM:745-752),
+    # unterminated LAST line the reference itself returns a length one short (FM:745-752, docs/DESIGN_HISTORY.md Q12),
     # so those seeds are compared with the oracle instead of the scan.
     fr = np.concatenate([locs[:2000, 0], np.arange(n - 40, n, 3)]).astype(np.int32)
     dst, ol, st4, aux = fm.extract_boundary_batch(fr, "\n", 0, 1024)

@@ -27,7 +27,7 @@ def test_damaged_streams_and_images_never_leave_their_tables(tmp_path):
     An out-of-bounds read or an endless walk here would be a memory fault or a hung wave on the GPU."""
     csrc = os.path.join(ROOT, "index4j_amd", "csrc")
     # the expanded form (default images), and the same campaign over COMPACT images with the record-decoding device code
-    # (sized for the CPU suite; longer campaigns with other seeds: run the two binaries by hand — DESIGN.md 2)
+    # (sized for the CPU suite; longer campaigns with other seeds: run the two binaries by hand — docs/DESIGN_HISTORY.md 3)
     for name, defs, runs in (("fuzz_load", [], ((1, 1500),)), ("fuzz_load_compact", ["-DFMX_COMPACT=1"], ((3, 700),))):
         exe = str(tmp_path / name)
         cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-fno-omit-frame-pointer"] + defs + ["-I" + csrc,

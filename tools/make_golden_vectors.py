@@ -33,7 +33,7 @@ def cases_for(name, text, rnd, n_patterns):
     L = len(text)
     bch = "\n" if "\n" in text else " "
     # seeds at or behind the last boundary lie in an unterminated last field, where the reference itself returns a
-    # length one short (FM:745-752): kept out of the definitional vectors
+    # length one short (FM:745-752, docs/DESIGN_HISTORY.md Q12): kept out of the definitional vectors
     last_safe = max(1, L if text.endswith(bch) else text.rfind(bch) + 1)
     pats = set()
     while len(pats) < n_patterns:

@@ -303,7 +303,7 @@ def run_series(ia, torch, orc, dev, text_log2=28, queries=1 << 20, sample_rates=
             {"checked_vs_oracle": "all %d rows, lengths, statuses, LF-step total" % Q,
              "rows_where_the_reference_differs_from_the_text": q1_rows,
              "note": None if q1_rows == 0 else "WFBB:1332 masks the symbol of a run block to 8 bits: with more than 256 codes the "
-                                               "reference extracts other characters there; reproduced bit for bit (DESIGN.md Q1)"})
+                                               "reference extracts other characters there; reproduced bit for bit (docs/DESIGN_HISTORY.md Q1)"})
         rows[-1]["chars_per_s"] = Q * xl / rows[-1]["ms_per_batch"] * 1e3
         fm.close()
         del ref
