@@ -326,6 +326,8 @@ def compact_line(out):
         sec.append({"config": _short(str(cfg_name).replace("BASELINE.json ", ""), 48),
                     "ms": row.get("ms", row.get("ms_per_step")), "frac": rf.get("frac"), "alg": rf.get("frac_algorithmic"),
                     "tfrac": rf.get("traffic_frac")})
+        if row.get("error"):
+            sec[-1]["error"] = _short(row["error"], 120)
     if sec:
         c["secondary"] = sec
         c["secondary_keys"] = "frac = the row's roofline fraction (rule: ref_series.settle_frac), alg = by algorithmic bytes, tfrac = by counter traffic"
@@ -771,14 +773,26 @@ def run_count(ctx, args):
         ref_series_module().settle_frac(roof, kernel_ms, traffic, ratio_rule=False)
     secondary = None
     if world == 1 and ref is not None and not args.no_secondary:
-        secondary = run_secondary(ctx, args, q, ref, orc, text, host_batches[0], off_host)
+        try:
+            secondary = run_secondary(ctx, args, q, ref, orc, text, host_batches[0], off_host)
+        except Exception as e:  # noqa: BLE001 - the headline's line is printed whatever happens to the rows beside it, with the reason
+            log("[bench] secondary configs FAILED: %r" % (e,))
+            secondary = [{"config": "BASELINE.json configs[2] / [3]", "ms": None, "error": repr(e)[:300]}]
         if secondary is not None and not args.no_segments_share and not args.profiling:
-            secondary.append(segments_share_row(ctx, args))
+            try:
+                secondary.append(segments_share_row(ctx, args))
+            except Exception as e:  # noqa: BLE001 - as above: the headline's line survives a failed secondary block, and says so
+                log("[bench] configs[4] per-GPU share FAILED: %r" % (e,))
+                secondary.append({"config": "BASELINE.json configs[4] per-GPU share", "ms": None, "error": repr(e)[:300]})
     elif segments_line is not None:
         secondary = [segments_line]
     host_buffers = None
     if world == 1 and not ctx.dry and not args.profiling and oracle_checksum is not None:
-        host_buffers = measure_host_buffers(ctx, args, q, host_batches[0][: n * m], off_host, d_cnt[0].cpu().numpy(), ms_per_step)
+        try:
+            host_buffers = measure_host_buffers(ctx, args, q, host_batches[0][: n * m], off_host, d_cnt[0].cpu().numpy(), ms_per_step)
+        except Exception as e:  # noqa: BLE001 - never `value`: its failure is reported, not fatal
+            log("[bench] host-buffer measurement FAILED: %r" % (e,))
+            host_buffers = {"error": repr(e)[:300]}
     # LF-steps the suffix table answered over the timed steps
     executed_less = lf_total - lf_exec_total  # counted by the kernel itself, every batch of every rank
     if not ctx.dry and exec_steps_launch is not None and exec_steps_launch != lf_executed[0]:
@@ -1094,12 +1108,17 @@ def run_secondary(ctx, args, q, ref, orc, text, pat, off):
     # The DEFAULT run carries the published shape's six rows (count, locate 1 / 100, extract 32 at sampleRate 32; count and extract
     # at sampleRate 1: ref_series.DEFAULT_PLAN); --series runs all 18 (sampleRate 1 / 32 / 64 x maxMatches 1 / 10 / 100 / 1000).
     if not args.no_ref_series and not args.profiling:
-        res.append({"config": "reference_series: FmIndexThroughputBenchmark's count / locate / extract (32 chars), queries of 8..31 "
-                              "chars sampled from a ~1,100-symbol text (%s)" % ("all 18 rows" if args.series else "the default six rows"),
-                    "series": rs.run_series(
-                        ia, torch, orc, dev, text_log2=args.text_log2, queries=args.series_queries,
-                        plan=rs.full_plan() if args.series else rs.DEFAULT_PLAN,
-                        build_device=ctx.local_rank, log=log, traffic_lookup=traffic_of)})
+        name = ("reference_series: FmIndexThroughputBenchmark's count / locate / extract (32 chars), queries of 8..31 chars sampled "
+                "from a ~1,100-symbol text (%s)" % ("all 18 rows" if args.series else "the default six rows"))
+        try:
+            res.append({"config": name,
+                        "series": rs.run_series(
+                            ia, torch, orc, dev, text_log2=args.text_log2, queries=args.series_queries,
+                            plan=rs.full_plan() if args.series else rs.DEFAULT_PLAN,
+                            build_device=ctx.local_rank, log=log, traffic_lookup=traffic_of)})
+        except Exception as e:  # noqa: BLE001 - a secondary block must not take the headline's line down: the row says what happened
+            log("[bench] reference series FAILED: %r" % (e,))
+            res.append({"config": name, "ms": None, "error": repr(e)[:300]})
     if args.series_extras:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import series_extras
