@@ -402,10 +402,20 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
                                                   int32_t *__restrict__ status_out, int32_t *__restrict__ range_out,
                                                   const int32_t *__restrict__ plan_look_up, int32_t plan_sigma,
                                                   int steps_mode, int regroup, const uint32_t *__restrict__ plan_mixed,
-                                                  uint32_t plan_epoch) {
+                                                  uint32_t plan_epoch, int halve_uniform) {
     // kCodeBits: width of a code in the record's word and in the chunks — 8 when the alphabet fits (8 codes per word),
     // else 16 (the plan's alphabet in modes 1 / 2, this index's own in modes 0 / 3)
     constexpr int kPairs = kBlock / 2;
+    // A PLANNED batch of ONE length runs on HALF the grid (halve_uniform; the plan's flag says which kind it is, so the decision is
+    // taken here, on the device): every workgroup's start-up — character map, superblock headers, a barrier — is paid half as often
+    // (headline -4 %: 8 workgroups per CU x 2 tiles instead of 16 x 1), while a batch of MIXED lengths keeps the full grid — its
+    // tiles take different times, and on the smaller grid the reference-shaped series lost 16 % (round 5, tools/ab_options_rows.sh).
+    // The upper half of the grid leaves before it stages anything.
+    uint32_t grid_x = gridDim.x;
+    if (halve_uniform && plan_mixed && *plan_mixed != plan_epoch && grid_x >= 2) {
+        grid_x = (grid_x + 1) / 2;
+        if (blockIdx.x >= grid_x) return;
+    }
     diag_begin();
     __shared__ int16_t s_xlat[256];
     __shared__ int16_t s_map[256];  // this index's character map, characters below 256
@@ -426,11 +436,11 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
     const int role = threadIdx.x & 1;
     // codes the record's word carries (mode 3: a foreign plan with 16-bit codes gives the order only)
     constexpr int n_codes = kMode != 3 ? 64 / kCodeBits : 0;
-    const int32_t pairs_per_grid = (int32_t)gridDim.x * kPairs;  // 32-bit indices: n < 2^31, fewer live registers
+    const int32_t pairs_per_grid = (int32_t)grid_x * kPairs;  // 32-bit indices: n < 2^31, fewer live registers
     // (an XCD-aware block order — a contiguous eighth of the sorted batch per XCD — was measured slower:
     // profiles/r01_i_xcd_remap.txt)
 #if defined(FMX_DIAG_REVERSE)
-    for (int32_t q0 = (int32_t)(gridDim.x - 1 - blockIdx.x) * kPairs; q0 < n; q0 += pairs_per_grid) {
+    for (int32_t q0 = (int32_t)(grid_x - 1 - blockIdx.x) * kPairs; q0 < n; q0 += pairs_per_grid) {
 #else
     for (int32_t q0 = (int32_t)blockIdx.x * kPairs; q0 < n; q0 += pairs_per_grid) {
 #endif
@@ -499,12 +509,11 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
             else
                 count_one<kMode, kCodeBits, false>(ix, s_inv, s_map, s_xlat, pat, pat_off, p, m, ck, role, start, end, back, tabled, status);
         }
-        if (!live) continue;  // (whole lane pairs: q is the same for both lanes of a pair)
         // LF-steps of the pattern: two ranks per character after the first (steps_mode 1: only those evaluated here, without
         // the ones the suffix table answered — what bench.py counts as executed work)
         const int32_t steps = 2 * (steps_mode ? back - tabled : back);
         status |= __shfl_xor(status, 1);
-        if (role == 0) {
+        if (live && role == 0) {  // (whole lane pairs: q is the same for both lanes of a pair)
             const int32_t d = end - start;
 #if defined(FMX_EXPERIMENT_STORE_Q)
             counts[q] = d > 0 ? d : 0;  // (experiment: results in PROCESSING order — coalesced stores; what do the scattered ones cost?)
@@ -1565,6 +1574,10 @@ static std::atomic<int> g_plan_fine{1};  // 0 = skip the window-local fine order
 // 0 = order by the trailing characters' codes even where a suffix table exists; 1 = by the SA row the table answers; 2 = by an
 // estimate of that row from the table's two-character strings (SortShape.sa_key)
 static std::atomic<int> g_plan_sa_key{2};
+// planned k_count: a batch of one length runs on half the grid (decided on the device from the plan's flag; 0: A/B).
+// Tried first (round 5): tiles taken from a counter on a grid of 8 workgroups per CU — the barrier that hands a tile to a
+// workgroup's eight waves ties them together: headline 0.138 -> 0.151 ms, series count +3 %.  Dropped.
+static std::atomic<int> g_count_halve_uniform{1};
 // 1 = the plan stage of a batch of at most one tile per CU is ONE launch (k_plan_fused); 0 (default) = k_plan_codes +
 // k_plan_scatter.  Measured (round 5, configs[1]): step 0.1365 -> 0.1339 ms (-2 %), with two batches in flight 0.109 -> 0.117
 // (+7 %: workgroups waiting at the barrier hold their CUs) — not worth a spinning kernel by default.
@@ -1625,6 +1638,10 @@ int set_option(const char *name, int value) {
     if (!strcmp(name, "plan_sa_key")) {
         if (value < 0 || value > 2) return -1;
         g_plan_sa_key = value;
+        return 0;
+    }
+    if (!strcmp(name, "count_halve_uniform")) {
+        g_count_halve_uniform = value != 0;
         return 0;
     }
     if (!strcmp(name, "plan_fused")) {
@@ -1805,7 +1822,7 @@ int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_
     const int bits = (mode == 1 || mode == 2) ? pl.code_bits : plan_code_bits(ix.wt_sigma);
 #define FMX_COUNT_LAUNCH(BLOCK, MODE, BITS)                                                                           \
     hipLaunchKernelGGL((k_count<BLOCK, MODE, BITS>), grid__, dim3(BLOCK), (size_t)g_lds_pad_kb * 1024, st, ix_launch, pat, \
-                       off, recs, n, counts, lf, status, range, pl.look_up, pl.sigma, (int)g_steps_executed_only, (int)g_regroup_by_length, recs ? pl.mixed : nullptr, pl.epoch)
+                       off, recs, n, counts, lf, status, range, pl.look_up, pl.sigma, (int)g_steps_executed_only, (int)g_regroup_by_length, recs ? pl.mixed : nullptr, pl.epoch, (int)g_count_halve_uniform)
 #define FMX_COUNT_MODE(MODE)                                                                                       \
     do {                                                                                                           \
         const int blk__ = g_block;                                                                                 \
