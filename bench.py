@@ -1104,6 +1104,64 @@ def run_secondary(ctx, args, q, ref, orc, text, pat, off):
                 "checked_vs_oracle": "all %d queries: lengths, statuses, whole destination rows" % K})
     rs.settle_frac(res[-1]["roofline"], ms, traffic_of("configs[3]", K))
     fm64.close()
+    # ---- the headline's shape WITHOUT the generator's repetition: 1,048,576 DISTINCT 8-char patterns ----
+    # The synthetic log repeats itself (328,091 distinct patterns in the headline batch); equal patterns side by side share
+    # their sectors.  This row draws substrings until it has as many DISTINCT ones as the headline batch holds patterns.
+    try:
+        n_d = len(off) - 1
+        from index4j_amd import workload
+
+        pool = np.zeros((0, m), np.uint16)
+        for seed in range(1000, 1012):  # (draw, keep one of each, until there are enough)
+            cand, _o, _p = workload.count_batch_patterns(text, 2 * n_d, m, seed=seed)
+            pool = np.concatenate([pool, cand.reshape(-1, m)])
+            keys = np.ascontiguousarray(pool).view(np.dtype((np.void, 2 * m))).ravel()
+            _u, first = np.unique(keys, return_index=True)
+            pool = pool[np.sort(first)]  # first occurrences, in drawing order
+            if len(pool) >= n_d:
+                break
+        seen = min(len(pool), n_d)
+        if seen == n_d:
+            dpat = np.ascontiguousarray(pool[:n_d]).reshape(-1)
+            d_dp = torch.from_numpy(dpat.view(np.int16)).to(dev)
+            d_do = torch.from_numpy(np.ascontiguousarray(off)).to(dev)
+            d_dc = torch.zeros(n_d, dtype=torch.int32, device=dev)
+            d_dl = torch.zeros(n_d, dtype=torch.int32, device=dev)
+            d_ds = torch.zeros(n_d, dtype=torch.int32, device=dev)
+
+            def count_distinct(with_lf=False):
+                check_rc(ia, ia.lib.fmx_count_batch_dev(q.handle, d_dp.data_ptr(), d_do.data_ptr(), n_d, d_dc.data_ptr(),
+                                                        d_dl.data_ptr() if with_lf else None, d_ds.data_ptr() if with_lf else None, sp),
+                         "fmx_count_batch_dev")
+
+            ia.lib.fmx_set_option(b"lf_steps_executed_only", 1)
+            try:
+                count_distinct(True)
+                torch.cuda.synchronize()
+                lf_exec = int(d_dl.sum(dtype=torch.int64).item())
+            finally:
+                ia.lib.fmx_set_option(b"lf_steps_executed_only", 0)
+            orc.counters_reset()
+            oc, ost = ref.count_batch(dpat, off, threads=cores)
+            cd = orc.counters()
+            if not ((d_dc.cpu().numpy() == oc).all() and int(d_ds.max().item()) == 0):
+                raise RuntimeError("count of the distinct batch differs from the oracle")
+            ms = timed(count_distinct, 7)
+            alg_exec = cd["alg_bytes"] * (lf_exec / float(max(1, cd["lf_steps"])))
+            res.append({"config": "configs[1]'s shape with %d DISTINCT patterns (no two alike; the headline batch holds 328,091 distinct ones)" % n_d,
+                        "ms": ms, "patterns_per_s": n_d / ms * 1e3, "lf_steps_executed": lf_exec,
+                        "roofline": rs.settle_frac({"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                    "achieved": alg_exec / (ms * 1e-3) / 1e9,
+                                                    "frac": alg_exec / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                    "kernels": "plan stage + k_count (whole call)",
+                                                    "note": "algorithmic bytes of the executed LF-steps (the oracle's bytes per step x the steps "
+                                                            "the kernel executed) over the WHOLE call's time, plan stage included"},
+                                                   ms, traffic_of("configs[1] distinct", n_d)),
+                        "checked_vs_oracle": "all %d counts and statuses" % n_d})
+            del d_dp, d_dc, d_dl, d_ds
+    except Exception as e:  # noqa: BLE001 - an extra row: its failure is reported on the row
+        log("[bench] distinct-pattern row FAILED: %r" % (e,))
+        res.append({"config": "configs[1]'s shape with distinct patterns", "ms": None, "error": repr(e)[:300]})
     # ---- the reference's own benchmark shapes on a text with the published data set's alphabet size ----
     # The DEFAULT run carries the published shape's six rows (count, locate 1 / 100, extract 32 at sampleRate 32; count and extract
     # at sampleRate 1: ref_series.DEFAULT_PLAN); --series runs all 18 (sampleRate 1 / 32 / 64 x maxMatches 1 / 10 / 100 / 1000).
