@@ -81,6 +81,16 @@ double fmx_build_wavelet_seconds(const fmx_index *idx);
  * launches ignore it, for A/B).  *chars = 0: no table; *bytes = the table's size. */
 int fmx_suffix_table_info(const fmx_index *idx, int32_t *chars, int64_t *bytes);
 
+/* The window directory of a resident index (grown by fmx_to_device / fmx_attach_device_blob beside the image, like the suffix
+ * table; option "window_cells": 0 = none, 1 = always, 2 = where it fits a quarter of the device's free memory, the default): one
+ * 64-byte cell per 120 consecutive BWT positions holding, for the window's three most frequent symbols, their rank at the window
+ * start and the positions they stand at, plus every position's bit of sampledSuffixes (FM:123).  WaveletFixedBlockBoosting.rank
+ * (WFBB:1010-1285) of such a symbol, inverseSelect (WFBB:1305-1537) of such a position and the poll of FM:531 cost ONE 64-byte
+ * sector instead of a mapping entry, path records and a cell per tree level; everything else walks the tree as before.  Every
+ * entry was checked against the index's own rank() / inverseSelect() (all routes, all quirks) at every position of its window
+ * when it was made: results, statuses and LF-step counts do not depend on it.  *bytes = its size (0: none). */
+int fmx_window_cells_info(const fmx_index *idx, int64_t *bytes);
+
 /* FmIndex.read(ObjectInput) FM:983-1025; also accepts the ObjectOutputStream-framed form produced by
  * Serialization.writeToByteArray SER:67-79 (magic AC ED 00 05 + block-data records). */
 int fmx_load(const uint8_t *ser, size_t len, fmx_index **out);

@@ -31,6 +31,7 @@
     int launch_suffix_expand(const fmx::DevIndex &, int, const fmx::SuffixSlot *, uint32_t, int, int, fmx::SuffixSlot *, uint32_t *, uint32_t, hipStream_t); \
     int launch_suffix_insert(const fmx::DevIndex &, const fmx::SuffixSlot *, uint32_t, int, fmx::SuffixSlot *, hipStream_t); \
     int launch_suffix_order1(const fmx::DevIndex &, float *, hipStream_t);                                              \
+    int launch_win_build(const fmx::DevIndex &, int, uint32_t, fmx::Quad *, hipStream_t);                               \
     int launch_count_plan(const fmx::DevIndex &, int, const uint16_t *, const int32_t *, int32_t, void *, size_t, bool, fmx::CountPlan *, \
                           hipStream_t);                                                                                 \
     int launch_count(const fmx::DevIndex &, int, const uint16_t *, const int32_t *, const fmx::CountPlan *, bool, int32_t, int32_t *, \
@@ -77,6 +78,7 @@ FMX_DISPATCH_FN(launch_suffix_level1)
 FMX_DISPATCH_FN(launch_suffix_expand)
 FMX_DISPATCH_FN(launch_suffix_insert)
 FMX_DISPATCH_FN(launch_suffix_order1)
+FMX_DISPATCH_FN(launch_win_build)
 FMX_DISPATCH_FN(launch_count_plan)
 FMX_DISPATCH_FN(launch_count)
 FMX_DISPATCH_FN(count_workspace_bytes)
@@ -107,6 +109,8 @@ struct fmx_index {
     void *d_suffix_table = nullptr;     // DevIndex.suffix_table (owned, whoever owns the image)
     void *d_suffix_order1 = nullptr;    // DevIndex.suffix_order1 (owned likewise)
     void *d_self = nullptr;             // DevIndex.self: the resident copy of `dev` the kernels' cold routes read (owned likewise)
+    void *d_win = nullptr;              // DevIndex.win: the window directory (owned likewise)
+    size_t win_bytes = 0;
     size_t suffix_table_bytes = 0;
     uint32_t suffix_table_strings = 0;  // strings (of 2 .. suffix_chars codes) the table holds
     uint32_t suffix_table_deepest = 0;  // ... of which strings of suffix_chars codes: what a batch's patterns spread over after the lookup
@@ -150,6 +154,9 @@ std::atomic<int> g_plan_sa_min{786432};   // option "plan_sa_min" (plan_pays)
 std::atomic<int> g_plan_sa_key_api{2};     // mirror of the kernels' option "plan_sa_key"
 std::atomic<int> g_suffix_table_in_use{1};  // mirror of the kernels' A/B option "suffix_table": launches told to ignore the table plan as if there were none
 std::atomic<int> g_suffix_table_image_fraction{8};  // option "suffix_table_image_fraction": the table stays below image / this (0 = only the budget counts)
+// option "window_cells": indexes made resident afterwards grow a window directory (fmx_device.hpp "window directory": 64 bytes per
+// 120 text characters beside the image) — 0 = none, 1 = always, 2 (default) = where it fits a quarter of the device's free memory
+std::atomic<int> g_window_cells{2};
 // host-buffer count(): batches of at least this many patterns go through the pipeline (smaller ones: one copy in, kernels, one copy out)
 std::atomic<int> g_host_pipeline_min{131072};
 std::atomic<int> g_host_mapped{1};  // option "host_mapped": every array of a host-buffer count registered -> one launch over the mapped arrays, no copies
@@ -232,6 +239,7 @@ void make_dev_index(fmx_index *idx) {
     d.suffix_shift = 0;
     d.suffix_mask = 0;
     d.suffix_order1 = nullptr;
+    d.win = nullptr;
     d.sb_cache = nullptr;
     d.sb_cache_limit = g_sb_cache_limit;
     d.wt_size = (uint32_t)h.wt_size;
@@ -247,6 +255,7 @@ int publish_dev_index(fmx_index *idx) {
     copy.sb_cache = nullptr;
     copy.suffix_table = nullptr;
     copy.suffix_order1 = nullptr;
+    copy.win = nullptr;  // (a cold route is the tree walk itself; the directory is grown from its answers)
     HIP_TRY(hipMemcpy(idx->d_self, &copy, sizeof(copy), hipMemcpyHostToDevice));
     idx->dev.self = copy.self;
     return FMX_OK;
@@ -670,6 +679,11 @@ int fmx_set_option(const char *name, int value) {
         g_wavelet_on_device = value != 0;
         return FMX_OK;
     }
+    if (name && !strcmp(name, "window_cells")) {  // window directory of indexes made resident from now on: 0 none, 1 always, 2 if it fits
+        if (value < 0 || value > 2) return fail(FMX_E_ARG, "bad value");
+        g_window_cells = value;
+        return FMX_OK;
+    }
     if (name && !strcmp(name, "cells_split_blocks")) {  // tests: chunked decoding of short vectors too (same image)
         fmx::set_split_blocks(value);
         return FMX_OK;
@@ -806,6 +820,7 @@ void fmx_free(fmx_index *idx) {
     if (idx->d_suffix_table) (void)hipFree(idx->d_suffix_table);
     if (idx->d_suffix_order1) (void)hipFree(idx->d_suffix_order1);
     if (idx->d_self) (void)hipFree(idx->d_self);
+    if (idx->d_win) (void)hipFree(idx->d_win);
     for (auto &kv : idx->side) {
         for (hipEvent_t e : kv.second.ev) (void)hipEventDestroy(e);
         if (kv.second.s) {
@@ -823,6 +838,51 @@ int32_t fmx_alphabet_length(const fmx_index *idx) {
 int32_t fmx_sample_rate(const fmx_index *idx) { return idx->has_model ? idx->model.sample_rate : idx->hdr.sample_rate; }
 int32_t fmx_extract_enabled(const fmx_index *idx) {
     return idx->has_model ? (idx->model.enable_extract ? 1 : 0) : idx->hdr.enable_extract;
+}
+
+// The window directory of a resident FM-index (fmx_device.hpp "window directory"): one 64-byte cell per 120 BWT positions, made on
+// the device from the index's own rank() / inverseSelect() (win_build_cell: every entry checked against them).  Grown before the
+// suffix table (whose growth then already runs over it).  Not having one is never an error.
+static void build_window_cells(fmx_index *idx) {
+    if (idx->d_win) {
+        (void)hipFree(idx->d_win);
+        idx->d_win = nullptr;
+        idx->win_bytes = 0;
+    }
+    idx->dev.win = nullptr;
+    const int mode = g_window_cells.load();
+    if (mode == 0 || idx->rrr_only || idx->wavelet_only || idx->hdr.kind != 0 || idx->hdr.wt_size <= 0 || !idx->dev.self) return;
+    const size_t cells = fmx::win_cells_for((uint32_t)idx->hdr.wt_size);
+    const size_t bytes = cells * 64;
+    if (mode == 2) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 4) {
+            (void)hipGetLastError();
+            return;
+        }
+    }
+    void *d = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    if (k_launch_win_build(idx, idx->dev, idx->n_cu, (uint32_t)cells, static_cast<fmx::Quad *>(d), nullptr) != 0 ||
+        hipStreamSynchronize(nullptr) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(d);
+        return;
+    }
+    idx->d_win = d;
+    idx->win_bytes = bytes;
+    idx->dev.win = static_cast<const fmx::Quad *>(d);
+}
+
+int fmx_window_cells_info(const fmx_index *idx, int64_t *bytes) {
+    return guarded([&]() -> int {
+    if (!idx) return fail(FMX_E_ARG, "null index");
+    if (bytes) *bytes = (int64_t)idx->win_bytes;
+    return FMX_OK;
+    });
 }
 
 // The suffix table of a resident FM-index (fmx_device.hpp): grown level by level on the device — the strings of 2, 3, ... codes
@@ -1016,6 +1076,7 @@ int fmx_to_device(fmx_index *idx, int device) {
     idx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     make_dev_index(idx);
     if (int rc2 = publish_dev_index(idx)) return rc2;
+    build_window_cells(idx);
     build_suffix_table(idx);
     return FMX_OK;
     });
@@ -1051,6 +1112,7 @@ int fmx_attach_device_blob(void *device_blob, size_t len, int device, fmx_index 
     idx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     make_dev_index(idx.get());
     if (int rc2 = publish_dev_index(idx.get())) return rc2;
+    build_window_cells(idx.get());
     build_suffix_table(idx.get());
     *out = idx.release();
     return FMX_OK;

@@ -86,6 +86,12 @@ struct DevIndex {
     // ((s(xy) - C[x]) / n_x, |xy| / n_x; {0, 0}: "xy" does not occur).  k_plan_codes stages it in LDS and estimates from it
     // the SA row a pattern's search starts at: its sort key.  Results never depend on it.
     const float *suffix_order1;
+    // Window directory (nullptr: none; grown on the device when an index becomes resident, like the suffix table — "win_*"
+    // below): one 64-byte SECTOR per kWinW consecutive BWT positions that answers rank(c, position) for the window's three
+    // most frequent symbols and inverseSelect(position) (+ the sampled-row bit) for every position that holds one of them —
+    // one sector fill instead of {mapping entry, path records, a cell per tree level}.  Whatever it does not hold takes the
+    // path above.  Results never depend on it: every count in it was checked against rank() when it was grown.
+    const struct Quad *win;
     // this index's DevIndex as the API layer keeps it in HBM (no LDS cache, no launch option applied): what a cold route reads
     const DevIndex *self;
 };
@@ -631,6 +637,97 @@ FMX_HD uint16_t fm_char_of(const DevIndex &ix, int32_t c) {
 FMX_HD int32_t fm_c_or_zero(const DevIndex &ix, int32_t symbol) {
     return (symbol >= 0 && symbol < ix.n_c) ? ix.C[symbol] : 0;
 }
+// ---- window directory (DevIndex.win) -------------------------------------------------------------------------
+// What bounds every LF kernel is the number of 64-byte SECTORS a step makes the memory system fill: the
+// tree walk touches a mapping entry, often a path record and one cell per level of the symbol's code — different sectors
+// all.  A window cell packs what most steps need into ONE sector, addressed by the position alone:
+//   words 0..2   folded rank (C[c] + occurrences of c in BWT[0, window start)) of class 0, 1, 2
+//   word  3      symbol of class 0 | class 1 << 16            (kWinNone: the class is not used)
+//   word  4      symbol of class 2 | the planes' first 16 bits
+//   words 4..15  three bit planes of kWinW = 120 bits each, from bit 16 of word 4 on, back to back:
+//                plane 0 / 1 = low / high bit of the position's class (3 = "none of the three"), plane 2 = the position's
+//                bit in sampledSuffixes (FM:123: what locate polls before every step, FM:531)
+// rank(c, p) for a class symbol = its count + the class's positions before p in the window; inverseSelect(p) for a class
+// position = {symbol, the same sum}.  The classes of a window are its three most frequent symbols — on log text they cover
+// ~80 % of the positions and of the ranks a backward search asks for (the BWT around a pattern's rows mostly holds the
+// character the pattern continues with).  A miss costs the sector and then takes the tree walk as before.
+// A class is only entered where win_build_cell() found the reference's own rank() / inverseSelect() — every route, every
+// quirk — to return exactly these numbers with no status and no `suspect` at EVERY position of the window; anything else
+// (a masked run block Q1, a next-block path Q2 / Q11, a symbol the int16 cast of FM:532 would change) stays "none".
+constexpr uint32_t kWinW = 120;
+constexpr uint32_t kWinNone = 0xffffu;
+struct WinCell {
+    Quad q0, q1, q2, q3;
+};
+FMX_HD size_t win_cells_for(uint32_t wt_size) { return (size_t)(wt_size / kWinW) + 1; }  // rank(wt_size, c) has a cell too
+FMX_HD WinCell win_load(const DevIndex &ix, uint32_t position, uint32_t &r) {
+    const uint32_t w = position / kWinW;
+    r = position - w * kWinW;
+    const Quad *p = ix.win + 4 * (uint64_t)w;
+    WinCell c;
+    c.q0 = ld_quad(p);
+    c.q1 = ld_quad(p + 1);
+    c.q2 = ld_quad(p + 2);
+    c.q3 = ld_quad(p + 3);
+    FMX_PIN_QUAD(c.q0);
+    FMX_PIN_QUAD(c.q1);
+    FMX_PIN_QUAD(c.q2);
+    FMX_PIN_QUAD(c.q3);
+    return c;
+}
+// the positions of class k among the window's first r, from the two class planes
+struct WinPlanes {
+    uint64_t a_lo, a_hi, b_lo, b_hi;  // plane 0 / plane 1, positions 0..63 / 64..119 (+ 8 bits of whatever follows)
+};
+FMX_HD WinPlanes win_planes(const WinCell &c) {
+    WinPlanes p;
+    p.a_lo = (uint64_t)((c.q1.x >> 16) | (c.q1.y << 16)) | ((uint64_t)((c.q1.y >> 16) | (c.q1.z << 16)) << 32);
+    p.a_hi = (uint64_t)((c.q1.z >> 16) | (c.q1.w << 16)) | ((uint64_t)((c.q1.w >> 16) | (c.q2.x << 16)) << 32);
+    p.b_lo = (uint64_t)((c.q2.x >> 8) | (c.q2.y << 24)) | ((uint64_t)((c.q2.y >> 8) | (c.q2.z << 24)) << 32);
+    p.b_hi = (uint64_t)((c.q2.z >> 8) | (c.q2.w << 24)) | ((uint64_t)((c.q2.w >> 8) | (c.q3.x << 24)) << 32);
+    return p;
+}
+FMX_HD int32_t win_class_before(const WinPlanes &p, uint32_t k, uint32_t r) {
+    const uint64_t fa = (k & 1u) ? 0ull : ~0ull, fb = (k & 2u) ? 0ull : ~0ull;
+    const uint64_t m_lo = (p.a_lo ^ fa) & (p.b_lo ^ fb), m_hi = (p.a_hi ^ fa) & (p.b_hi ^ fb);
+    const uint32_t r_lo = r < 64u ? r : 64u, r_hi = r < 64u ? 0u : r - 64u;  // r <= kWinW: r_hi <= 56
+    const uint64_t k_lo = r_lo >= 64u ? ~0ull : ((1ull << r_lo) - 1ull);
+    return fmx_popcll(m_lo & k_lo) + fmx_popcll(m_hi & ((1ull << r_hi) - 1ull));
+}
+// rank(symbol, position) from the window of `position` (<= wt_size): true = value_out is C[symbol] + rank
+FMX_HD bool win_rank_from(const WinCell &c, uint32_t r, int32_t symbol, int32_t &value_out) {
+    const uint32_t s = (uint32_t)symbol;
+    const uint32_t id0 = c.q0.w & 0xffffu, id1 = c.q0.w >> 16, id2 = c.q1.x & 0xffffu;
+    if (s >= kWinNone || (s != id0 && s != id1 && s != id2)) return false;
+    const uint32_t k = s == id0 ? 0u : (s == id1 ? 1u : 2u);
+    value_out = (int32_t)(k == 0u ? c.q0.x : (k == 1u ? c.q0.y : c.q0.z)) + win_class_before(win_planes(c), k, r);
+    return true;
+}
+FMX_HD bool win_rank_try(const DevIndex &ix, uint32_t position, int32_t symbol, int32_t &value_out) {
+    uint32_t r;
+    const WinCell c = win_load(ix, position, r);
+    return win_rank_from(c, r, symbol, value_out);
+}
+// inverseSelect(position) (< wt_size) from its window: true = {symbol, C[symbol] + rank before}; sampled_out = the position's
+// bit in sampledSuffixes either way (positions beyond that vector: 0 — callers check the range first, as FM:531 would throw)
+FMX_HD bool win_inv_from(const WinCell &c, uint32_t r, int32_t &symbol_out, int32_t &rank_out, bool &sampled_out) {
+    const WinPlanes p = win_planes(c);
+    const uint32_t sh = r & 63u;
+    const uint32_t b0 = (uint32_t)((r < 64u ? p.a_lo : p.a_hi) >> sh) & 1u, b1 = (uint32_t)((r < 64u ? p.b_lo : p.b_hi) >> sh) & 1u;
+    const uint32_t sw = r < 32u ? c.q3.x : (r < 64u ? c.q3.y : (r < 96u ? c.q3.z : c.q3.w));
+    sampled_out = ((sw >> (r & 31u)) & 1u) != 0;
+    const uint32_t k = b0 | (b1 << 1);
+    if (k == 3u) return false;
+    symbol_out = (int32_t)(k == 0u ? (c.q0.w & 0xffffu) : (k == 1u ? (c.q0.w >> 16) : (c.q1.x & 0xffffu)));
+    rank_out = (int32_t)(k == 0u ? c.q0.x : (k == 1u ? c.q0.y : c.q0.z)) + win_class_before(p, k, r);
+    return true;
+}
+// block size log of a superblock (what fm_lf_finish asks): the LDS copy of the header, or the header itself
+FMX_HD int32_t sb_block_size_log(const DevIndex &ix, uint32_t sb_id) {
+    if (ix.sb_cache) return (int32_t)(int16_t)(ix.sb_cache[2 * sb_id].x >> 16);
+    return (int32_t)ix.sbd[sb_id].bsl;
+}
+
 // With the superblock's header at hand (ix.sb_cache, staged in LDS by the kernel) and the mapping rows indexed by
 // the global symbol, the mapping entry and the block header are requested together with the superblock entry:
 //   {superblock entry, mapping entry, block header} -> first cell -> ...
@@ -653,6 +750,10 @@ FMX_HD int32_t wt_rank_folded_t(const DevIndex &ix, const uint16_t *inv, uint32_
         status = ST_JAVA_AIOOBE;
         suspect = true;
         return fm_c_or_zero(ix, symbol);
+    }
+    if (ix.win) {  // the window of `position` first: one sector for the symbols it holds (win_* above)
+        int32_t v;
+        if (win_rank_try(ix, position, symbol, v)) return v;
     }
     // The loads of one rank form a dependent chain (superblock -> mapping -> block header -> leaf -> levels);
     // what a stage needs is requested as soon as its address is known, so that the chain is
@@ -1104,6 +1205,102 @@ FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32
     return c;
 }
 
+// One cell of the window directory (layout: "window directory" above), made from the index's OWN answers: `ix` must not carry
+// a directory itself (ix.win == nullptr: every value below comes from the tree walk, the reference's routes included).
+//   1. inverseSelect of every position of the window; a position is a candidate if its symbol is exact (no Q1 mask), survives
+//      the int16 cast of FM:532 and is below kWinNone;
+//   2. the three most frequent candidate symbols become the classes (ties: the one met first);
+//   3. per class, rank(c, position) is asked at EVERY position of the window (and at wt_size, if it lies in the window) and must
+//      be C[c] + the running count with no status and no `suspect`, and inverseSelect's own rank must agree wherever the symbol
+//      stands; a class that fails anywhere is dropped (its positions become "none").
+// `out` = the 16 words of the cell.
+FMX_HD void win_build_cell(const DevIndex &ix, uint32_t w, uint32_t *out) {
+    const uint64_t ws64 = (uint64_t)w * kWinW;
+    const uint32_t ws = (uint32_t)ws64;
+    const uint32_t n = ws64 >= ix.wt_size ? 0u : (ix.wt_size - ws < kWinW ? ix.wt_size - ws : kWinW);
+    uint16_t sym[kWinW];
+    int32_t before[kWinW];
+    uint32_t plane[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    RrrView sv = rrr_view_from(Quad{ix.sampled.off_rec, ix.sampled.off_bits, (uint32_t)ix.sampled.length, (uint32_t)ix.sampled.total_ones});
+    bv_bind(sv, ix, nullptr);
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint32_t p = ws + j;
+        int32_t rank_before = 0, bsl = 0;
+        bool exact = true;
+        const int32_t c = wt_inverse_select_folded<true>(ix, nullptr, p, rank_before, bsl, exact);
+        const bool candidate = exact && c >= 0 && c < 0x8000 && c < ix.wt_sigma && (uint32_t)c < kWinNone;
+        sym[j] = candidate ? (uint16_t)c : (uint16_t)kWinNone;
+        before[j] = rank_before;
+        if ((int32_t)p < sv.length) {
+            int st = ST_OK;
+            if (bv_access(ix.base, sv, (int32_t)p, st) && st == ST_OK) plane[2][j >> 5] |= 1u << (j & 31u);
+        }
+    }
+    uint32_t best_sym[3] = {kWinNone, kWinNone, kWinNone}, best_cnt[3] = {0, 0, 0};
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint32_t c = sym[j];
+        if (c == kWinNone) continue;
+        bool seen = false;
+        for (uint32_t i = 0; i < j && !seen; ++i) seen = sym[i] == c;
+        if (seen) continue;
+        uint32_t cnt = 1;
+        for (uint32_t i = j + 1; i < n; ++i) cnt += sym[i] == c ? 1u : 0u;
+        for (int k = 0; k < 3; ++k) {  // insertion, descending; a tie stays behind the earlier symbol
+            if (cnt > best_cnt[k]) {
+                for (int t = 2; t > k; --t) {
+                    best_cnt[t] = best_cnt[t - 1];
+                    best_sym[t] = best_sym[t - 1];
+                }
+                best_cnt[k] = cnt;
+                best_sym[k] = c;
+                break;
+            }
+        }
+    }
+    uint32_t base[3] = {0, 0, 0};
+    // rank is asked at positions ws .. ws + last (position wt_size itself belongs to the window it falls into)
+    const uint32_t last = ws64 > ix.wt_size ? 0u : (ix.wt_size - ws < kWinW ? ix.wt_size - ws : kWinW - 1u);
+    for (int k = 0; k < 3; ++k) {
+        if (best_sym[k] == kWinNone) continue;
+        const int32_t c = (int32_t)best_sym[k];
+        bool ok = true;
+        int32_t running = 0;
+        for (uint32_t j = 0; j <= last && ok; ++j) {
+            const ColdOut r = wt_rank_folded_cold(FMX_SELF(ix), ws + j, c);
+            if (j == 0) {
+                base[k] = (uint32_t)r.value;
+                running = r.value;
+            }
+            ok = r.aux == 0 && r.value == running;
+            if (j < n && sym[j] == (uint16_t)c) {
+                ok = ok && before[j] == running;
+                ++running;
+            }
+        }
+        if (!ok) {
+            best_sym[k] = kWinNone;
+            base[k] = 0;
+        }
+    }
+    for (uint32_t j = 0; j < kWinW; ++j) {
+        uint32_t k = 3;
+        if (j < n && sym[j] != kWinNone)
+            for (uint32_t t = 0; t < 3; ++t)
+                if (best_sym[t] == sym[j]) k = t;
+        if (k & 1u) plane[0][j >> 5] |= 1u << (j & 31u);
+        if (k & 2u) plane[1][j >> 5] |= 1u << (j & 31u);
+    }
+    // words 4..15 as one 384-bit string: plane t from bit 16 + 120 t on
+    uint32_t words[16] = {base[0], base[1], base[2], best_sym[0] | (best_sym[1] << 16), best_sym[2], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t t = 0; t < 3; ++t)
+        for (uint32_t j = 0; j < kWinW; ++j)
+            if ((plane[t][j >> 5] >> (j & 31u)) & 1u) {
+                const uint32_t bit = 16u + kWinW * t + j;
+                words[4 + (bit >> 5)] |= 1u << (bit & 31u);
+            }
+    for (int i = 0; i < 16; ++i) out[i] = words[i];
+}
+
 // ---- FmIndex helpers -----------------------------------------------------------------------
 
 FMX_HD int32_t fm_map(const DevIndex &ix, uint16_t ch) { return ix.char2code[ch]; }  // getOrDefault(ch, 0) FM:457
@@ -1138,6 +1335,16 @@ FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, 
     int32_t rank_before;
     int32_t bsl_i;
     bool exact_symbol;
+    if (ix.win) {  // the window of p: {symbol, rank} of a class position from one sector
+        uint32_t r;
+        const WinCell cell = win_load(ix, p, r);
+        int32_t wc;
+        bool sampled;
+        if (win_inv_from(cell, r, wc, rank_before, sampled)) {
+            c_out = wc;
+            return fm_lf_finish<kCold>(ix, inv, row, wc, rank_before, sb_block_size_log(ix, p >> 20), true, status, suspect);
+        }
+    }
     const int32_t c = (int32_t)(int16_t)wt_inverse_select_folded<kCold>(ix, inv, p, rank_before, bsl_i, exact_symbol);  // C[c] + rank
     c_out = c;
     return fm_lf_finish<kCold>(ix, inv, row, c, rank_before, bsl_i, exact_symbol, status, suspect);
@@ -1175,6 +1382,23 @@ FMX_HD void fm_lf_step2(const DevIndex &ix, const uint16_t *inv, LfChain &a, LfC
         lb = false;
     }
     if (!la && !lb) return;
+    if (ix.win) {  // the windows of both positions first (one sector each, requested together); a chain they answer is done
+        uint32_t ra = 0, rb = 0;
+        const WinCell wca = win_load(ix, la ? pa : 0u, ra), wcb = win_load(ix, lb ? pb : 0u, rb);
+        int32_t wc, wrank;
+        bool sampled;
+        if (la && win_inv_from(wca, ra, wc, wrank, sampled)) {
+            a.c = wc;
+            a.row = fm_lf_finish(ix, inv, a.row, wc, wrank, sb_block_size_log(ix, pa >> 20), true, status, suspect);
+            la = false;
+        }
+        if (lb && win_inv_from(wcb, rb, wc, wrank, sampled)) {
+            b.c = wc;
+            b.row = fm_lf_finish(ix, inv, b.row, wc, wrank, sb_block_size_log(ix, pb >> 20), true, status, suspect);
+            lb = false;
+        }
+        if (!la && !lb) return;
+    }
     const InvView va = wt_inv_view(ix, la ? pa >> 20 : 0u, inv), vb = wt_inv_view(ix, lb ? pb >> 20 : 0u, inv);
     Quad iha = {0, 0, 0, 0}, ihb = {0, 0, 0, 0};
     if (la) iha = ld_quad(wt_inv_hdr_ptr(ix, va, pa));
@@ -1384,18 +1608,39 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
             break;
         }
         // (p < length == the wavelet tree's size: validate_model / validate_blob)
-        const InvView v = wt_inv_view(ix, (uint32_t)p >> 20, inv);
-        Quad ihq = ld_quad(wt_inv_hdr_ptr(ix, v, (uint32_t)p));
-        scell = ld_quad(bv_cell_ptr(ix.base, sv, (uint32_t)p));
-        FMX_PIN_QUAD(ihq);
-        FMX_PIN_QUAD(scell);
-        bool sampled_row;
-        (void)bv_rank1_access_cell(sv, scell, p, sampled_row);
-        if (sampled_row) break;
-        int32_t rank_before;
-        bool exact, suspect = false;
-        const int32_t c = (int32_t)(int16_t)wt_inverse_select_from<false>(ix, (uint32_t)p, v, ihq, rank_before, exact);
-        j = fm_lf_finish<false>(ix, inv, j, c, rank_before, v.bsl, exact, status, suspect);  // FM:532-535
+        int32_t c = 0, rank_before = 0, bsl_p = 0;
+        bool exact = true, answered = false;
+        const bool windows = ix.win != nullptr && (uint32_t)p < ix.wt_size;
+        if (windows) {
+            // the window of p holds the row's sampled bit as well: a step of a walk is ONE sector where the symbol is one of the
+            // window's classes (the bitmap's own cell is fetched once, for the rank behind the loop)
+            uint32_t r;
+            const WinCell cell = win_load(ix, (uint32_t)p, r);
+            bool sampled_row;
+            answered = win_inv_from(cell, r, c, rank_before, sampled_row);
+            if (sampled_row) {
+                scell = ld_quad(bv_cell_ptr(ix.base, sv, (uint32_t)p));
+                FMX_PIN_QUAD(scell);
+                break;
+            }
+            bsl_p = sb_block_size_log(ix, (uint32_t)p >> 20);
+        }
+        if (!answered) {
+            const InvView v = wt_inv_view(ix, (uint32_t)p >> 20, inv);
+            Quad ihq = ld_quad(wt_inv_hdr_ptr(ix, v, (uint32_t)p));
+            if (!windows) scell = ld_quad(bv_cell_ptr(ix.base, sv, (uint32_t)p));
+            FMX_PIN_QUAD(ihq);
+            FMX_PIN_QUAD(scell);
+            if (!windows) {
+                bool sampled_row;
+                (void)bv_rank1_access_cell(sv, scell, p, sampled_row);
+                if (sampled_row) break;
+            }
+            c = (int32_t)(int16_t)wt_inverse_select_from<false>(ix, (uint32_t)p, v, ihq, rank_before, exact);
+            bsl_p = v.bsl;
+        }
+        bool suspect = false;
+        j = fm_lf_finish<false>(ix, inv, j, c, rank_before, bsl_p, exact, status, suspect);  // FM:532-535
         ++distance;
         if (distance > walk_limit) {  // bounds the walk on a damaged index (see walk_limit above)
             status = ST_JAVA_AIOOBE;
@@ -1460,6 +1705,392 @@ FMX_HD int32_t fm_extract(const DevIndex &ix, const uint16_t *inv, int32_t start
         ++distance;
     }
     return range;
+}
+
+// ---- hop-synchronous walks ("machines") -------------------------------------------------------------------------
+// The functions above take an LF-step the way a CPU would: a loop over the tree's levels inside a loop over the steps.  On a
+// 64-lane wave every such loop runs as long as its SLOWEST lane: a step of a wave costs the deepest code among 64 positions
+// (10+ levels with 1,000 symbols; the average position needs 1.8), and a lane the window directory answered in one load waits
+// for the neighbours that walk the tree (round 5, rocprofv3: k_extract issued 25.8 load instructions per wave-step).  A machine
+// turns the loops inside out: every lane carries its own state {what its next loads are, what they mean}; one pass of the
+// kernel's loop = every lane issues ITS next loads (one hop of whatever it is doing), waits once, digests them and works out
+// the next addresses.  Lanes never wait for each other's depth, only for the memory system; a lane that finishes a query
+// starts its next one while its neighbours are still walking.  Same loads, same arithmetic, same results as the functions
+// above — in another order.
+//
+// One LF-step (fm_lf_step / the loop body of fm_locate_hit) as a machine: phase kLfHead = the step's first loads (the window
+// cell of p = row - 1 and the block's InvHdr; without a directory the InvHdr and, for locate, the bitmap cell), kLfLevel =
+// {NodeRec, cell} of one level of the tree.
+enum : int32_t { kLfHead = 0, kLfLevel = 1 };
+struct LfLane {
+    int32_t row;    // the row whose step is in progress (the symbol looked for stands at p = row - 1)
+    int32_t phase;
+    const NodeRec *nodes;  // tree walk: the block's root record ...
+    uint32_t idx, node_b;  // ... the record of the node in flight, the ones before the node
+    int32_t pos, node_rank;
+};
+// the loads of ONE pass (never carried into the next): head = {window cell (d0..d3) | bitmap cell (d0), InvHdr (d4)}, level =
+// {NodeRec (d0), cell (d1)}; d4's first two words double as the 8 bytes of a packed-vector read (the lanes' seek / suffix phases)
+struct LfLoads {
+    Quad d0, d1, d2, d3, d4;
+};
+FMX_HD void lf_begin(LfLane &l, int32_t row) {
+    l.row = row;
+    l.phase = kLfHead;
+    l.nodes = nullptr;
+    l.idx = 0;
+}
+// Every lane issues the SAME five loads, from addresses picked by its phase (a lane with nothing to fetch reads the image's first
+// bytes): straight-line code — the loads of all phases leave together, nothing waits between them.  `active` = the lane is in a
+// step at all.  kPoll (locate): without a directory the head also fetches the row's cell of sampledSuffixes.
+template <bool kPoll>
+FMX_HD void lf_issue(const DevIndex &ix, const uint16_t *inv, const LfLane &l, LfLoads &m, bool active) {
+    const Quad *nothing = reinterpret_cast<const Quad *>(ix.base);
+    const bool head = l.phase == kLfHead;
+    uint32_t p = (uint32_t)(l.row - 1);
+    if (!active || p >= ix.wt_size) {  // (a row no well-formed index produces: lf_consume reports it)
+        active = false;
+        p = 0;
+    }
+    const InvView v = wt_inv_view(ix, p >> 20, inv);
+    const Quad *a0 = nothing, *a1 = nothing, *a2 = nothing, *a3 = nothing, *a4 = nothing;
+    if (active && head) {
+        a4 = reinterpret_cast<const Quad *>(wt_inv_hdr_ptr(ix, v, p));
+        if (ix.win) {
+            a0 = ix.win + 4 * (uint64_t)(p / kWinW);
+            a1 = a0 + 1;
+            a2 = a0 + 2;
+            a3 = a0 + 3;
+        } else if (kPoll) {
+            RrrView sv = rrr_view_from(Quad{ix.sampled.off_rec, ix.sampled.off_bits, (uint32_t)ix.sampled.length, (uint32_t)ix.sampled.total_ones});
+            bv_bind(sv, ix, inv);
+            a0 = reinterpret_cast<const Quad *>(bv_cell_ptr(ix.base, sv, bv_clamp(sv, (int32_t)p)));
+        }
+    } else if (active) {
+        a0 = reinterpret_cast<const Quad *>(l.nodes + l.idx);
+        a1 = reinterpret_cast<const Quad *>(bv_cell_ptr(ix.base, v.rv, bv_clamp(v.rv, l.pos)));
+    }
+    m.d0 = ld_quad(a0);
+    m.d1 = ld_quad(a1);
+    if (ix.win) {
+        m.d2 = ld_quad(a2);
+        m.d3 = ld_quad(a3);
+    }
+    m.d4 = ld_quad(a4);
+}
+FMX_HD void lf_pin(LfLoads &m) {
+    FMX_PIN_QUAD(m.d0);
+    FMX_PIN_QUAD(m.d1);
+    FMX_PIN_QUAD(m.d2);
+    FMX_PIN_QUAD(m.d3);
+    FMX_PIN_QUAD(m.d4);
+}
+// digests the loads of lf_issue.  Returns 0: the step goes on (next loads set up), 1: the step is taken — l.row is the row
+// before it in text order, c_out its symbol (what fm_lf_step returns) and the lane is at the head of the next step —, 2 (kPoll
+// only): row l.row - 1 is sampled, no step taken (FM:531; the caller ends its walk).
+template <bool kPoll, bool kCold>
+FMX_HD int lf_consume(const DevIndex &ix, const uint16_t *inv, LfLane &l, const LfLoads &m, int32_t &c_out, int &status, bool &suspect) {
+    const uint32_t p = (uint32_t)(l.row - 1);
+    int32_t c = 0, rank_before = 0, bsl = 0;
+    bool exact = true;
+    if (l.phase == kLfHead) {
+        if (p >= ix.wt_size) {  // as fm_lf_step: a row no well-formed index produces
+            status = ST_JAVA_AIOOBE;
+            c_out = 0;
+            l.row = 0;
+            return 1;
+        }
+        bool have = false;
+        if (ix.win) {
+            WinCell cell;
+            cell.q0 = m.d0;
+            cell.q1 = m.d1;
+            cell.q2 = m.d2;
+            cell.q3 = m.d3;
+            bool sampled;
+            have = win_inv_from(cell, p % kWinW, c, rank_before, sampled);
+            if (kPoll && sampled) return 2;
+            bsl = sb_block_size_log(ix, p >> 20);
+        } else if (kPoll) {
+            RrrView sv = rrr_view_from(Quad{ix.sampled.off_rec, ix.sampled.off_bits, (uint32_t)ix.sampled.length, (uint32_t)ix.sampled.total_ones});
+            bv_bind(sv, ix, inv);
+            bool sampled;
+            (void)bv_rank1_access_cell(sv, m.d0, (int32_t)p, sampled);
+            if (sampled) return 2;
+        }
+        if (!have) {
+            const InvView v = wt_inv_view(ix, p >> 20, inv);
+            bsl = v.bsl;
+            const uint32_t block_index = p & ((1u << v.bsl) - 1u);
+            const Quad ihq = m.d4;
+            if (ihq.x & kInvRun) {  // WFBB:1329-1355 (Q1: the stored symbol is masked to 8 bits)
+                exact = (ihq.x & kInvMasked) == 0;
+                rank_before = (int32_t)ihq.z + (int32_t)block_index;
+                c = (int32_t)ihq.y;
+            } else if (ihq.x & kInvSlow) {
+                c = kCold ? wt_inverse_select_route_rare(ix, p, rank_before, exact)
+                          : wt_inverse_select_reference_route(ix, p, v, rank_before, exact);
+            } else {
+                l.nodes = reinterpret_cast<const NodeRec *>(ix.base + ((uint64_t)v.rv.off_bits << 3)) + ihq.z;
+                l.idx = 0;
+                l.node_b = ihq.y;
+                l.pos = (int32_t)(ihq.x & 0xffffffu) + (int32_t)block_index;
+                l.node_rank = (int32_t)block_index;
+                l.phase = kLfLevel;
+                return 0;
+            }
+        }
+    } else {
+        const InvView v = wt_inv_view(ix, p >> 20, inv);
+        bsl = v.bsl;
+        bool bit;
+        const int32_t rank1 = bv_rank1_access_cell(v.rv, m.d1, l.pos, bit) - (int32_t)l.node_b;  // WFBB:1389-1393
+        l.node_rank = bit ? rank1 : l.node_rank - rank1;                                           // WFBB:1435-1470
+        const uint32_t lo = bit ? m.d0.z : m.d0.x, hi = bit ? m.d0.w : m.d0.y;
+        const uint32_t child = lo & 0xffffu;
+        if (child != 0) {
+            l.node_b = hi >> 8;
+            l.pos = (int32_t)((lo >> 16) | ((hi & 0xffu) << 16)) + l.node_rank;
+            l.idx = child;
+            return 0;
+        }
+        rank_before = (int32_t)hi + l.node_rank;  // leaf (WFBB:1495-1533)
+        c = (int32_t)(lo >> 16);
+    }
+    c = (int32_t)(int16_t)c;
+    c_out = c;
+    l.row = fm_lf_finish<kCold>(ix, inv, l.row, c, rank_before, bsl, exact, status, suspect);  // FM:532-535
+    l.phase = kLfHead;
+    return 1;
+}
+
+// FmIndex.extract (FM:564-608) as a machine: phase kXSeek = the sample of `positions` behind `stop` is in flight, kXWalk = the
+// walk (an LfLane), kXIdle = no query (the last one's status / ret / steps are in the lane).
+enum : int32_t { kXIdle = 0, kXSeek = 1, kXWalk = 2 };
+struct ExtractLane {
+    LfLane lf;
+    int32_t phase;
+    int32_t remaining, distance, skip, steps, range, ret, stop;
+    int status;
+    uint16_t *dest;
+};
+// the 8 bytes fm_packed_get / ld_bits read for entry `index` of a packed vector, and the entry out of them
+FMX_HD const uint32_t *fm_packed_ptr(const uint32_t *words, int64_t index, int width) {
+    return words + (((uint64_t)index * (uint32_t)width) >> 5);
+}
+FMX_HD int32_t fm_packed_from(uint64_t raw, int64_t index, int width) {
+    const uint64_t v = raw >> (((uint64_t)index * (uint32_t)width) & 31);
+    return (int32_t)(uint32_t)(v & ((width >= 32) ? 0xffffffffull : ((1ull << width) - 1ull)));
+}
+// the checks of FM:566-593 (the order among them is the reference's); false = the query is over (status set)
+FMX_HD bool extract_begin(const DevIndex &ix, ExtractLane &e, int32_t start, int32_t stop, uint16_t *dest, int32_t dst_len,
+                          int32_t offset) {
+    e.steps = 0;
+    e.status = ST_OK;
+    e.ret = 0;
+    e.phase = kXIdle;
+    e.dest = dest;
+    if (!ix.enable_extract) {
+        e.status = ST_NOT_ENABLED;  // FM:566-568
+        return false;
+    }
+    if (start < 0) {
+        e.status = ST_POS_NEGATIVE;  // FM:570-572
+        return false;
+    }
+    if (stop >= ix.length) {
+        e.status = ST_STOP_TOO_LONG;  // FM:574-576
+        return false;
+    }
+    if (stop / ix.sample_rate + 1 < 0) {
+        e.status = ST_JAVA_AIOOBE;  // negative IntVector index
+        return false;
+    }
+    e.range = stop - start;
+    if (dst_len - offset < e.range) {
+        e.status = ST_DEST_TOO_SMALL;  // FM:591-593 (behind the seek in the reference, which has no effect of its own)
+        return false;
+    }
+    e.stop = stop;
+    e.remaining = e.range;
+    e.distance = 0;
+    if (e.remaining <= 0) {  // FM:596: the loop does not run
+        e.ret = e.range;
+        return false;
+    }
+    e.phase = kXSeek;
+    return true;
+}
+// the lane's loads of this pass (straight-line: see lf_issue); raw = the 8 bytes of the `positions` sample of a lane that seeks
+FMX_HD void extract_issue(const DevIndex &ix, const uint16_t *inv, const ExtractLane &e, LfLoads &m, uint64_t &raw) {
+    const uint32_t *a = ix.pos_words;
+    if (e.phase == kXSeek) a = fm_packed_ptr(ix.pos_words, (int64_t)(e.stop / ix.sample_rate) + 1, ix.bw_positions);
+    memcpy(&raw, a, 8);
+    lf_issue<false>(ix, inv, e.lf, m, e.phase == kXWalk);
+}
+// true = the query is over: e.status / e.ret / e.steps are its results
+FMX_HD bool extract_consume(const DevIndex &ix, const uint16_t *inv, ExtractLane &e, LfLoads &m, uint64_t raw, int32_t dst_len,
+                            int32_t offset) {
+    FMX_OPAQUE64(raw);
+    lf_pin(m);
+    if (e.phase == kXSeek) {  // fm_seek_after
+        const int32_t s = ix.sample_rate, x = e.stop, q = x / s;
+        const int32_t row = fm_packed_from(raw, (int64_t)q + 1, ix.bw_positions) + 1;
+        int32_t skip = s - x % s;
+        if (q == ix.n_positions - 2) skip = ix.length - x;
+        if (skip > ix.length - x) skip = ix.length - x;
+        e.skip = skip;
+        lf_begin(e.lf, row);
+        e.phase = kXWalk;
+        return false;
+    }
+    if (e.phase != kXWalk) return true;
+    int32_t c;
+    bool suspect = false;
+    if (lf_consume<false, false>(ix, inv, e.lf, m, c, e.status, suspect) == 0) return false;
+    ++e.steps;  // FM:596-606
+    if (e.distance >= e.skip) {
+        const int32_t idx = e.remaining - 1 + offset;
+        if (idx < 0 || idx >= dst_len) {
+            e.status = ST_JAVA_AIOOBE;
+            e.ret = 0;
+            e.phase = kXIdle;
+            return true;
+        }
+        e.dest[idx] = fm_char_of(ix, c);
+        --e.remaining;
+    }
+    ++e.distance;
+    if (e.remaining > 0) return false;
+    e.ret = e.range;
+    e.phase = kXIdle;
+    return true;
+}
+// the whole query by one lane (the host simulation, and what the machine must equal: fm_extract)
+FMX_HD int32_t fm_extract_machine(const DevIndex &ix, const uint16_t *inv, int32_t start, int32_t stop, uint16_t *dest,
+                                  int32_t dst_len, int32_t offset, int32_t &steps, int &status) {
+    ExtractLane e;
+    lf_begin(e.lf, 1);
+    if (extract_begin(ix, e, start, stop, dest, dst_len, offset)) {
+        for (;;) {
+            LfLoads m = {};
+            uint64_t raw = 0;
+            extract_issue(ix, inv, e, m, raw);
+            if (extract_consume(ix, inv, e, m, raw, dst_len, offset)) break;
+        }
+    }
+    steps = e.steps;
+    status = e.status;
+    return e.ret;  // (as fm_extract: the range even where a step set a status; the kernel reports 0 then)
+}
+
+// One hit of FmIndex.locate (FM:526-548, fm_locate_hit) as a machine: kLWalk = the walk to the next sampled row (every head
+// polls sampledSuffixes: the window cell's third plane, or the bitmap's own cell), kLCell = the bitmap cell of the sampled row
+// is in flight (only behind a window: the rank of FM:541 needs it), kLSuffix = the two words of `suffixes` are in flight.
+enum : int32_t { kLIdle = 0, kLWalk = 1, kLCell = 2, kLSuffix = 3 };
+struct LocateLane {
+    LfLane lf;
+    int32_t phase, distance, at;
+    int status;
+    int32_t r;
+};
+// (fm_locate_hit: bounds a walk over a damaged index)
+FMX_HD int32_t fm_walk_limit(const DevIndex &ix) {
+    const int64_t stretches = (int64_t)ix.sample_rate * 256;
+    return (int32_t)(stretches < 4096 ? 4096 : (stretches < (int64_t)ix.length ? stretches : (int64_t)ix.length));
+}
+FMX_HD RrrView fm_sampled_view(const DevIndex &ix, const uint16_t *inv) {
+    RrrView sv = rrr_view_from(Quad{ix.sampled.off_rec, ix.sampled.off_bits, (uint32_t)ix.sampled.length, (uint32_t)ix.sampled.total_ones});
+    bv_bind(sv, ix, inv);
+    return sv;
+}
+FMX_HD void locate_begin(const DevIndex &ix, LocateLane &l, int32_t start, int32_t k) {
+    l.distance = 0;
+    l.status = ST_OK;
+    l.at = 0;
+    l.r = 0;
+    lf_begin(l.lf, start + 1 + k);  // FM:527-529
+    l.phase = kLWalk;
+}
+// the lane's loads of this pass: the walk's five (lf_issue), the sampled row's bitmap cell (scell) and the 8 bytes of its suffix
+FMX_HD void locate_issue(const DevIndex &ix, const uint16_t *inv, const LocateLane &l, LfLoads &m, Quad &scell, uint64_t &raw) {
+    const int32_t p = l.lf.row - 1;
+    const bool walking = l.phase == kLWalk && !(l.lf.phase == kLfHead && (p < 0 || p >= ix.sampled.length));  // (else: locate_consume reports it)
+    const uint32_t *a = ix.suffix_words;
+    if (l.phase == kLSuffix) a = fm_packed_ptr(ix.suffix_words, l.r, ix.bw_suffixes);
+    memcpy(&raw, a, 8);
+    const RrrView sv = fm_sampled_view(ix, inv);
+    scell = ld_quad(bv_cell_ptr(ix.base, sv, l.phase == kLCell ? bv_clamp(sv, p) : 0u));
+    lf_issue<true>(ix, inv, l.lf, m, walking);
+}
+// true = the hit is located: l.at = its text position, l.distance = LF-steps walked, l.status
+FMX_HD bool locate_consume(const DevIndex &ix, const uint16_t *inv, LocateLane &l, LfLoads &m, Quad scell, uint64_t raw,
+                           int32_t walk_limit) {
+    FMX_OPAQUE64(raw);
+    FMX_PIN_QUAD(scell);
+    lf_pin(m);
+    if (l.phase == kLSuffix) {
+        l.at = fm_packed_from(raw, l.r, ix.bw_suffixes) + l.distance;  // FM:538-542
+        l.phase = kLIdle;
+        return true;
+    }
+    if (l.phase == kLCell) {
+        const RrrView sv = fm_sampled_view(ix, inv);
+        l.r = bv_rank1_after_set_bit(sv, scell, l.lf.row - 1) - 1;  // FM:541 (rankOnes(j) = rankOnes(j - 1) + 1: row j - 1 is sampled)
+        l.phase = kLSuffix;
+        return false;
+    }
+    if (l.phase != kLWalk) return true;
+    bool derailed = false;
+    if (l.lf.phase == kLfHead) {
+        const int32_t p = l.lf.row - 1;
+        if (p < 0 || p >= ix.sampled.length) {  // RrrVector.access throws (RRR:316-323)
+            l.status = ST_JAVA_AIOOBE;
+            derailed = true;
+        }
+    }
+    if (!derailed) {
+        int32_t c;
+        bool suspect = false;
+        const int rc = lf_consume<true, false>(ix, inv, l.lf, m, c, l.status, suspect);
+        if (rc == 0) return false;
+        if (rc == 2) {  // the row is sampled
+            if (ix.win) {
+                l.phase = kLCell;
+                return false;
+            }
+            const RrrView sv = fm_sampled_view(ix, inv);
+            l.r = bv_rank1_after_set_bit(sv, m.d0, l.lf.row - 1) - 1;
+            l.phase = kLSuffix;
+            return false;
+        }
+        ++l.distance;
+        if (l.distance <= walk_limit) return false;
+        l.status = ST_JAVA_AIOOBE;  // bounds the walk on a damaged index
+    }
+    // (a walk that ended in a status — the reference throws — reports no position: the read only has to stay inside `suffixes`)
+    const RrrView sv = fm_sampled_view(ix, inv);
+    int32_t r = bv_rank1(ix.base, sv, l.lf.row) - 1;
+    if (r < 0) r = 0;
+    l.r = r;
+    l.phase = kLSuffix;
+    return false;
+}
+FMX_HD int32_t fm_locate_hit_machine(const DevIndex &ix, const uint16_t *inv, int32_t start, int32_t k, int32_t &distance,
+                                     int &status) {
+    LocateLane l;
+    locate_begin(ix, l, start, k);
+    const int32_t walk_limit = fm_walk_limit(ix);
+    for (;;) {
+        LfLoads m = {};
+        Quad scell = {0, 0, 0, 0};
+        uint64_t raw = 0;
+        locate_issue(ix, inv, l, m, scell, raw);
+        if (locate_consume(ix, inv, l, m, scell, raw, walk_limit)) break;
+    }
+    distance = l.distance;
+    status = l.status;
+    return l.at;
 }
 
 // ---- right part of extractUntilBoundary / extractUntilBoundaryRight (FM:692-758 / FM:853-921) ----------

@@ -25,6 +25,10 @@ def lib(compact=False):
         L = C.CDLL(so)
         L.sim_wt_rank.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p]
         L.sim_wt_inverse_select.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.sim_win_attach.argtypes = [C.c_void_p, C.c_void_p]
+        L.sim_win_attach.restype = C.c_int64
+        L.sim_win_detach.argtypes = [C.c_void_p]
+        L.sim_set_machines.argtypes = [C.c_int]
         _LIBS[compact] = L
     return _LIBS[compact]
 
@@ -78,6 +82,27 @@ class HostSim:
         # BlobHeader.compact (byte 152): the image's bit vectors are RRR records — the simulation compiled for that form
         self.compact = bool(int(np.frombuffer(self.blob, np.uint8)[152:156].view(np.int32)[0]))
         self.L = lib(self.compact)
+        self.windows = None
+
+    def attach_windows(self):
+        """grows the window directory (fmx_device.hpp: win_build_cell, what k_win_build runs when an index becomes resident) and
+        makes every later call of this simulation take it first, as the kernels do; returns (positions with a class, positions,
+        classes in use)"""
+        stats = np.zeros(3, np.int64)
+        self.L.sim_win_attach(C.c_void_p(self.p), C.c_void_p(stats.ctypes.data))
+        self.windows = tuple(int(v) for v in stats)
+        return self.windows
+
+    def detach_windows(self):
+        self.L.sim_win_detach(C.c_void_p(self.p))
+        self.windows = None
+
+    def __del__(self):
+        try:
+            if self.windows is not None:
+                self.L.sim_win_detach(C.c_void_p(self.p))
+        except Exception:
+            pass
 
     def wt_rank_batch(self, positions, symbols):
         st = np.zeros(1, np.int32)

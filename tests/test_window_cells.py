@@ -1,0 +1,168 @@
+"""The window directory (index4j_amd/csrc/fmx_device.hpp "window directory": what fmx_to_device grows beside a resident image)
+on the host simulation: the cells are made by the very function k_win_build runs (win_build_cell) and every query kind of the
+simulation then takes them first, as the kernels do — results, statuses and LF-step counts must still equal the oracle's, on
+the reference's fixture and on the quirk-heavy inputs of the other parity tests.  CPU only; the GPU suite runs the same
+checks on resident indexes (tests/test_gpu_parity.py with the library's default option window_cells = 2)."""
+import random
+
+import numpy as np
+import pytest
+
+import hostsim
+import index4j_amd as ia
+import orc
+from common import hdfs_text
+from parity_checks import check_all
+
+HD = hdfs_text()
+COVER = {}
+
+
+def make_sim_windows(text, sr):
+    h = hostsim.HostSim(ia.FmIndex(text, sr, True, device=None))
+    got, positions, classes = h.attach_windows()
+    COVER[(len(text), sr)] = got / max(1, positions)
+    return h
+
+
+@pytest.mark.parametrize("sr", [1, 4, 32, 64])
+def test_fixture_through_the_windows(sr):
+    check_all(make_sim_windows, HD, sr, random.Random(100 + sr))
+    # log text: the three most frequent symbols of a 120-position stretch of the BWT hold most of it
+    assert COVER[(len(HD), sr)] > 0.5
+
+
+def test_sentinels_small_texts_and_texts_shorter_than_a_window():
+    rnd = random.Random(12)
+    mod = list(HD[:40_000])
+    for _ in range(300):
+        mod[rnd.randrange(len(mod) - 2)] = "\0"
+    check_all(make_sim_windows, "".join(mod), 8, rnd, n_q=60)
+    check_all(make_sim_windows, "What a string!\nNow this is long, indeed\nBut others could be longer.", 2, rnd, n_q=40)
+    check_all(make_sim_windows, "a", 1, rnd, n_q=5)
+    check_all(make_sim_windows, "ab" * 59 + "c", 4, rnd, n_q=20)   # wt_size = 120: rank(wt_size) has a cell of its own
+    check_all(make_sim_windows, "ab" * 60, 4, rnd, n_q=20)
+
+
+def quirk_text():
+    rng = np.random.default_rng(3)
+    parts = []
+    for i in range(30):
+        parts.append("".join(chr(97 + int(x)) for x in rng.integers(0, 6 + i, 2500)))
+        parts.append("zq" * 3000)
+    return "".join(parts)
+
+
+def test_rank_and_inverse_select_at_every_kind_of_block():
+    """wt_rank / wt_inverse_select through the windows vs the oracle: absent symbols, next-block paths, run blocks (whose
+    symbol the reference masks to 8 bits: never a class), out-of-range positions — at EVERY position for the symbols around"""
+    text = quirk_text()
+    f = ia.FmIndex(text, 5, True, device=None)
+    o = orc.OracleFmIndex(text, 5, True)
+    h = hostsim.HostSim(f)
+    got, positions, classes = h.attach_windows()
+    assert 0 < got <= positions and classes > 0
+    L = f.getInputLength()
+    wh = o.wavelet_handle()
+    st = orc.C.c_int(0)
+    for pos in list(range(0, L + 1, 7)) + [L, L + 5]:
+        for sym in (0, 1, 2, 3, 5, 21, 30, 36, 37, 400):
+            st.value = 0
+            e = orc.lib().orc_wfbb_rank(wh, pos, sym, orc.C.byref(st))
+            r, s2 = h.wt_rank(pos, sym)
+            assert (r, s2) == (e, st.value), (pos, sym)
+    for pos in range(0, L, 3):
+        c, r = h.wt_inverse_select(pos)
+        t = orc.lib().orc_wfbb_inverse_select(wh, pos)
+        assert c == (t & 0xFFFF) and (pos == 0 or r == (t >> 32))
+    for row in range(1, L + 1, 11):  # the fused LF-step beside the reference's two calls (tests/test_fused_lf.py)
+        out = h.lf_step_both(row)
+        assert (out[0], out[1], out[4]) == (out[2], out[3], out[5]), row
+
+
+def test_large_alphabet_with_run_blocks_of_wide_symbols():
+    """symbols >= 256 in run blocks (Q1: inverseSelect reports them masked) and a 1,000-symbol alphabet: the directory must leave
+    every such position to the tree walk"""
+    rng = np.random.default_rng(9)
+    parts = []
+    for i in range(12):
+        parts.append("".join(chr(0x4E00 + int(x) * 7) for x in rng.integers(0, 900, 1500)))
+        parts.append(chr(0x30A1 + i) * 70_000)  # long runs of one wide symbol: run blocks
+        parts.append("log line %d\n" % i * 50)
+    text = "".join(parts)
+    check_all(make_sim_windows, text, 16, random.Random(5), n_q=60)
+
+
+def test_compact_image_through_the_windows():
+    assert ia.lib.fmx_set_option(b"image_compact", 1) == 0
+    try:
+        check_all(make_sim_windows, HD[:60_000], 32, random.Random(77), n_q=60)
+    finally:
+        ia.lib.fmx_set_option(b"image_compact", 0)
+
+
+def test_reference_route_image_through_the_windows():
+    """an image whose every block takes the reference's own routes: the directory is grown from THOSE answers"""
+    def make(text, sr):
+        h = hostsim.HostSim(hostsim.reference_route_index(text, sr))
+        h.attach_windows()
+        return h
+
+    check_all(make, HD[:50_000], 8, random.Random(31), n_q=50)
+
+
+# ---- the hop-synchronous machines (fmx_device.hpp "machines": what k_extract / k_locate_walk run) on one lane -----------------
+
+@pytest.fixture
+def machines():
+    hostsim.lib().sim_set_machines(1)
+    hostsim.lib(True).sim_set_machines(1)
+    try:
+        yield
+    finally:
+        hostsim.lib().sim_set_machines(0)
+        hostsim.lib(True).sim_set_machines(0)
+
+
+def make_sim_plain(text, sr):
+    return hostsim.HostSim(ia.FmIndex(text, sr, True, device=None))
+
+
+@pytest.mark.parametrize("windows", [False, True])
+@pytest.mark.parametrize("sr", [1, 4, 32, 64])
+def test_machines_on_the_fixture(machines, sr, windows):
+    check_all(make_sim_windows if windows else make_sim_plain, HD, sr, random.Random(200 + sr))
+
+
+@pytest.mark.parametrize("windows", [False, True])
+def test_machines_on_quirk_heavy_inputs(machines, windows):
+    make = make_sim_windows if windows else make_sim_plain
+    rnd = random.Random(13)
+    mod = list(HD[:40_000])
+    for _ in range(300):
+        mod[rnd.randrange(len(mod) - 2)] = "\0"
+    check_all(make, "".join(mod), 8, rnd, n_q=60)
+    check_all(make, "a", 1, rnd, n_q=5)
+    check_all(make, "ab" * 60, 4, rnd, n_q=20)
+    check_all(make, quirk_text(), 5, rnd, n_q=80)
+    rng = np.random.default_rng(9)
+    parts = []
+    for i in range(6):
+        parts.append("".join(chr(0x4E00 + int(x) * 7) for x in rng.integers(0, 900, 1500)))
+        parts.append(chr(0x30A1 + i) * 70_000)
+        parts.append("log line %d\n" % i * 50)
+    check_all(make, "".join(parts), 16, random.Random(6), n_q=60)
+
+
+def test_machines_on_compact_and_reference_route_images(machines):
+    assert ia.lib.fmx_set_option(b"image_compact", 1) == 0
+    try:
+        check_all(make_sim_windows, HD[:60_000], 32, random.Random(78), n_q=60)
+        check_all(make_sim_plain, HD[:60_000], 4, random.Random(79), n_q=60)
+    finally:
+        ia.lib.fmx_set_option(b"image_compact", 0)
+
+    def make(text, sr):
+        return hostsim.HostSim(hostsim.reference_route_index(text, sr))
+
+    check_all(make, HD[:50_000], 8, random.Random(32), n_q=50)
