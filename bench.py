@@ -552,6 +552,7 @@ def run_count(ctx, args):
     # The index's suffix table (fmx.h: fmx_suffix_table_info) answers the first 2 * (chars - 1) rank evaluations of every
     # pattern with one load.  The same steps once more with launches told to ignore it (option), for the record.
     table_chars, table_bytes = (0, 0) if ctx.dry else q.suffix_table_info()
+    window_bytes = 0 if ctx.dry else q.window_cells_bytes()  # the window directory (fmx.h: fmx_window_cells_info): used by the LF-walks, resident all the same
     without_table = None
     if not ctx.dry and table_chars and not args.profiling:
         ia.lib.fmx_set_option(b"suffix_table", 0)
@@ -766,8 +767,8 @@ def run_count(ctx, args):
                 if pmc and pmc.get("TCP_TOTAL_CACHE_ACCESSES") else None,
                 "l1_line_accesses_per_lf_step_note": "per EXECUTED LF-step of a launch",
                 "image_bytes": image_bytes, "image_bytes_per_text_byte": image_bytes / float(1 << args.text_log2),
-                "suffix_table_bytes": table_bytes,
-                "resident_bytes_per_text_byte": (image_bytes + table_bytes) / float(1 << args.text_log2),
+                "suffix_table_bytes": table_bytes, "window_directory_bytes": window_bytes,
+                "resident_bytes_per_text_byte": (image_bytes + table_bytes + window_bytes) / float(1 << args.text_log2),
                 "frac_reference_equivalent": alg_bytes_reference / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs}
         ref_series_module().settle_frac(roof, kernel_ms, traffic, ratio_rule=False)
@@ -1235,6 +1236,7 @@ def run_segments(ctx, args):
     sf = None if ctx.dry else ia.SegmentedFmIndex.from_segments(segs, bases.cpu().numpy())
     table_chars = [0] * K if ctx.dry else [f.suffix_table_info()[0] for f in segs]
     table_bytes = 0 if ctx.dry else sum(f.suffix_table_info()[1] for f in segs)
+    window_bytes = 0 if ctx.dry else sum(f.window_cells_bytes() for f in segs)
     pat = None
     if ctx.rank == 0:
         pat, _off = workload.segment_patterns(texts, total, m)
@@ -1421,7 +1423,8 @@ def run_segments(ctx, args):
                 "lf_steps_reference_per_pattern": {st: steps_ref[st] / float(k) for st in steps_ref},
                 "lf_steps_answered_by_tables_per_pattern": table_steps / float(k),
                 "image_bytes_per_text_byte": image_bytes / float(sum(len(t) for t in texts)),
-                "resident_bytes_per_text_byte": (image_bytes + table_bytes) / float(sum(len(t) for t in texts))}
+                "window_directory_bytes_per_text_byte": window_bytes / float(sum(len(t) for t in texts)),
+                "resident_bytes_per_text_byte": (image_bytes + table_bytes + window_bytes) / float(sum(len(t) for t in texts))}
         base = {"value": k1 / cpu_s, "unit": "patterns/s", "cores": 1, "kind": "port",
                 "sample": "count() + locate(maxMatches %d) of the first %d patterns over the %d oracle indexes "
                           "(oracle/index4j_oracle.c, C port of index4j's path), 1 thread, %.1f s" % (M, k1, K, cpu_s)}

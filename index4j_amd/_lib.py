@@ -24,7 +24,7 @@ ST_JAVA_AIOOBE = 9
 
 # every symbol include/fmx.h declares (tests/test_abi.py checks the .so exports all of them)
 SYMBOLS = [
-    "fmx_build", "fmx_build_on_device", "fmx_build_wavelet_seconds", "fmx_suffix_table_info", "fmx_load", "fmx_save", "fmx_save_key_order_modelled", "fmx_free_buffer", "fmx_free",
+    "fmx_build", "fmx_build_on_device", "fmx_build_wavelet_seconds", "fmx_suffix_table_info", "fmx_window_cells_info", "fmx_load", "fmx_save", "fmx_save_key_order_modelled", "fmx_free_buffer", "fmx_free",
     "fmx_input_length", "fmx_alphabet_length", "fmx_sample_rate", "fmx_extract_enabled",
     "fmx_blob", "fmx_to_device", "fmx_attach_device_blob", "fmx_device_blob", "fmx_host_register", "fmx_host_unregister",
     "fmx_count_batch", "fmx_locate_batch", "fmx_extract_batch", "fmx_extract_boundary_batch",
@@ -53,6 +53,7 @@ def _load():
     L.fmx_build_wavelet_seconds.argtypes = [vp]
     L.fmx_build_wavelet_seconds.restype = C.c_double
     L.fmx_suffix_table_info.argtypes = [vp, P(i32), P(C.c_int64)]
+    L.fmx_window_cells_info.argtypes = [vp, P(C.c_int64)]
     L.fmx_load.argtypes = [vp, sz, P(vp)]
     L.fmx_save.argtypes = [vp, C.c_int, P(vp), P(sz)]
     L.fmx_save_key_order_modelled.argtypes = [vp]

@@ -31,7 +31,8 @@
     int launch_suffix_expand(const fmx::DevIndex &, int, const fmx::SuffixSlot *, uint32_t, int, int, fmx::SuffixSlot *, uint32_t *, uint32_t, hipStream_t); \
     int launch_suffix_insert(const fmx::DevIndex &, const fmx::SuffixSlot *, uint32_t, int, fmx::SuffixSlot *, hipStream_t); \
     int launch_suffix_order1(const fmx::DevIndex &, float *, hipStream_t);                                              \
-    int launch_win_build(const fmx::DevIndex &, int, uint32_t, fmx::Quad *, hipStream_t);                               \
+    int launch_win_build(const fmx::DevIndex &, int, uint32_t, fmx::Quad *, uint32_t *, hipStream_t);                   \
+    int launch_win_other(const fmx::DevIndex &, int, uint32_t, fmx::Quad *, const uint32_t *, uint64_t *, hipStream_t); \
     int launch_count_plan(const fmx::DevIndex &, int, const uint16_t *, const int32_t *, int32_t, void *, size_t, bool, fmx::CountPlan *, \
                           hipStream_t);                                                                                 \
     int launch_count(const fmx::DevIndex &, int, const uint16_t *, const int32_t *, const fmx::CountPlan *, bool, int32_t, int32_t *, \
@@ -79,6 +80,7 @@ FMX_DISPATCH_FN(launch_suffix_expand)
 FMX_DISPATCH_FN(launch_suffix_insert)
 FMX_DISPATCH_FN(launch_suffix_order1)
 FMX_DISPATCH_FN(launch_win_build)
+FMX_DISPATCH_FN(launch_win_other)
 FMX_DISPATCH_FN(launch_count_plan)
 FMX_DISPATCH_FN(launch_count)
 FMX_DISPATCH_FN(count_workspace_bytes)
@@ -109,8 +111,9 @@ struct fmx_index {
     void *d_suffix_table = nullptr;     // DevIndex.suffix_table (owned, whoever owns the image)
     void *d_suffix_order1 = nullptr;    // DevIndex.suffix_order1 (owned likewise)
     void *d_self = nullptr;             // DevIndex.self: the resident copy of `dev` the kernels' cold routes read (owned likewise)
-    void *d_win = nullptr;              // DevIndex.win: the window directory (owned likewise)
-    size_t win_bytes = 0;
+    void *d_win = nullptr;              // DevIndex.win: the window directory's cells (owned likewise)
+    void *d_win_other = nullptr;        // DevIndex.win_other: ... and the entries of the positions no class holds
+    size_t win_bytes = 0;               // both together
     size_t suffix_table_bytes = 0;
     uint32_t suffix_table_strings = 0;  // strings (of 2 .. suffix_chars codes) the table holds
     uint32_t suffix_table_deepest = 0;  // ... of which strings of suffix_chars codes: what a batch's patterns spread over after the lookup
@@ -240,6 +243,7 @@ void make_dev_index(fmx_index *idx) {
     d.suffix_mask = 0;
     d.suffix_order1 = nullptr;
     d.win = nullptr;
+    d.win_other = nullptr;
     d.sb_cache = nullptr;
     d.sb_cache_limit = g_sb_cache_limit;
     d.wt_size = (uint32_t)h.wt_size;
@@ -256,6 +260,7 @@ int publish_dev_index(fmx_index *idx) {
     copy.suffix_table = nullptr;
     copy.suffix_order1 = nullptr;
     copy.win = nullptr;  // (a cold route is the tree walk itself; the directory is grown from its answers)
+    copy.win_other = nullptr;
     HIP_TRY(hipMemcpy(idx->d_self, &copy, sizeof(copy), hipMemcpyHostToDevice));
     idx->dev.self = copy.self;
     return FMX_OK;
@@ -821,6 +826,7 @@ void fmx_free(fmx_index *idx) {
     if (idx->d_suffix_order1) (void)hipFree(idx->d_suffix_order1);
     if (idx->d_self) (void)hipFree(idx->d_self);
     if (idx->d_win) (void)hipFree(idx->d_win);
+    if (idx->d_win_other) (void)hipFree(idx->d_win_other);
     for (auto &kv : idx->side) {
         for (hipEvent_t e : kv.second.ev) (void)hipEventDestroy(e);
         if (kv.second.s) {
@@ -840,41 +846,66 @@ int32_t fmx_extract_enabled(const fmx_index *idx) {
     return idx->has_model ? (idx->model.enable_extract ? 1 : 0) : idx->hdr.enable_extract;
 }
 
-// The window directory of a resident FM-index (fmx_device.hpp "window directory"): one 64-byte cell per 120 BWT positions, made on
-// the device from the index's own rank() / inverseSelect() (win_build_cell: every entry checked against them).  Grown before the
-// suffix table (whose growth then already runs over it).  Not having one is never an error.
+// The window directory of a resident FM-index (fmx_device.hpp "window directory"): one 64-byte cell per 112 BWT positions and an
+// 8-byte entry per position none of its window's three classes holds, made on the device from the index's own rank() /
+// inverseSelect() (win_build_cell / win_build_other: every number checked against them).  Grown before the suffix table (whose
+// growth then already runs over it).  Not having one is never an error.
 static void build_window_cells(fmx_index *idx) {
-    if (idx->d_win) {
-        (void)hipFree(idx->d_win);
-        idx->d_win = nullptr;
-        idx->win_bytes = 0;
-    }
+    if (idx->d_win) (void)hipFree(idx->d_win);
+    if (idx->d_win_other) (void)hipFree(idx->d_win_other);
+    idx->d_win = idx->d_win_other = nullptr;
+    idx->win_bytes = 0;
     idx->dev.win = nullptr;
+    idx->dev.win_other = nullptr;
     const int mode = g_window_cells.load();
     if (mode == 0 || idx->rrr_only || idx->wavelet_only || idx->hdr.kind != 0 || idx->hdr.wt_size <= 0 || !idx->dev.self) return;
     const size_t cells = fmx::win_cells_for((uint32_t)idx->hdr.wt_size);
     const size_t bytes = cells * 64;
-    if (mode == 2) {
+    if (mode == 2) {  // cells + (at worst) an entry per position must fit a quarter of what is free
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 4) {
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes + (size_t)idx->hdr.wt_size * 8 > free_b / 4) {
             (void)hipGetLastError();
             return;
         }
     }
-    void *d = nullptr;
-    if (hipMalloc(&d, bytes) != hipSuccess) {
+    void *d_cells = nullptr, *d_counts = nullptr, *d_entries = nullptr;
+    auto give_up = [&]() {
         (void)hipGetLastError();
-        return;
+        if (d_cells) (void)hipFree(d_cells);
+        if (d_counts) (void)hipFree(d_counts);
+        if (d_entries) (void)hipFree(d_entries);
+    };
+    if (hipMalloc(&d_cells, bytes) != hipSuccess || hipMalloc(&d_counts, cells * sizeof(uint32_t)) != hipSuccess) return give_up();
+    if (k_launch_win_build(idx, idx->dev, idx->n_cu, (uint32_t)cells, static_cast<fmx::Quad *>(d_cells), static_cast<uint32_t *>(d_counts),
+                           nullptr) != 0)
+        return give_up();
+    // every window's first entry = the class-3 positions of the windows before it (a prefix sum on the host: 4 bytes per window)
+    std::vector<uint32_t> first;
+    try {
+        first.resize(cells);
+    } catch (const std::exception &) {
+        return give_up();
     }
-    if (k_launch_win_build(idx, idx->dev, idx->n_cu, (uint32_t)cells, static_cast<fmx::Quad *>(d), nullptr) != 0 ||
-        hipStreamSynchronize(nullptr) != hipSuccess) {
-        (void)hipGetLastError();
-        (void)hipFree(d);
-        return;
+    if (hipMemcpy(first.data(), d_counts, cells * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return give_up();
+    uint64_t total = 0;
+    for (size_t w = 0; w < cells; ++w) {
+        const uint32_t c = first[w];
+        first[w] = (uint32_t)total;
+        total += c;
     }
-    idx->d_win = d;
-    idx->win_bytes = bytes;
-    idx->dev.win = static_cast<const fmx::Quad *>(d);
+    if (total > 0xffffffffull) return give_up();
+    if (hipMalloc(&d_entries, (size_t)(total ? total : 1) * sizeof(uint64_t)) != hipSuccess ||
+        hipMemcpy(d_counts, first.data(), cells * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
+        k_launch_win_other(idx, idx->dev, idx->n_cu, (uint32_t)cells, static_cast<fmx::Quad *>(d_cells), static_cast<const uint32_t *>(d_counts),
+                           static_cast<uint64_t *>(d_entries), nullptr) != 0 ||
+        hipStreamSynchronize(nullptr) != hipSuccess)
+        return give_up();
+    (void)hipFree(d_counts);
+    idx->d_win = d_cells;
+    idx->d_win_other = d_entries;
+    idx->win_bytes = bytes + (size_t)total * sizeof(uint64_t);
+    idx->dev.win = static_cast<const fmx::Quad *>(d_cells);
+    idx->dev.win_other = static_cast<const uint64_t *>(d_entries);
 }
 
 int fmx_window_cells_info(const fmx_index *idx, int64_t *bytes) {

@@ -92,6 +92,7 @@ struct DevIndex {
     // one sector fill instead of {mapping entry, path records, a cell per tree level}.  Whatever it does not hold takes the
     // path above.  Results never depend on it: every count in it was checked against rank() when it was grown.
     const struct Quad *win;
+    const uint64_t *win_other;  // the entries of the positions no class of their window holds (nullptr iff win is)
     // this index's DevIndex as the API layer keeps it in HBM (no LDS cache, no launch option applied): what a cold route reads
     const DevIndex *self;
 };
@@ -637,25 +638,30 @@ FMX_HD uint16_t fm_char_of(const DevIndex &ix, int32_t c) {
 FMX_HD int32_t fm_c_or_zero(const DevIndex &ix, int32_t symbol) {
     return (symbol >= 0 && symbol < ix.n_c) ? ix.C[symbol] : 0;
 }
-// ---- window directory (DevIndex.win) -------------------------------------------------------------------------
-// What bounds every LF kernel is the number of 64-byte SECTORS a step makes the memory system fill: the
-// tree walk touches a mapping entry, often a path record and one cell per level of the symbol's code — different sectors
-// all.  A window cell packs what most steps need into ONE sector, addressed by the position alone:
+// ---- window directory (DevIndex.win, DevIndex.win_other) --------------------------------------------------------
+// What a step of an LF-walk costs is the tree walk: a loop over the levels of the symbol's code that a 64-lane wave runs to the
+// DEEPEST code among its 64 positions (10+ levels with 1,000 symbols; the average position needs 1.8) — rocprofv3, round 5:
+// k_extract issued 25.8 load instructions and 620 VALU per wave-step.  The directory answers inverseSelect WITHOUT a loop, and
+// rank for the symbols that matter, from sectors addressed by the position alone.  One 64-byte cell per kWinW = 112 positions:
 //   words 0..2   folded rank (C[c] + occurrences of c in BWT[0, window start)) of class 0, 1, 2
 //   word  3      symbol of class 0 | class 1 << 16            (kWinNone: the class is not used)
-//   word  4      symbol of class 2 | the planes' first 16 bits
-//   words 4..15  three bit planes of kWinW = 120 bits each, from bit 16 of word 4 on, back to back:
-//                plane 0 / 1 = low / high bit of the position's class (3 = "none of the three"), plane 2 = the position's
-//                bit in sampledSuffixes (FM:123: what locate polls before every step, FM:531)
-// rank(c, p) for a class symbol = its count + the class's positions before p in the window; inverseSelect(p) for a class
-// position = {symbol, the same sum}.  The classes of a window are its three most frequent symbols — on log text they cover
-// ~80 % of the positions and of the ranks a backward search asks for (the BWT around a pattern's rows mostly holds the
-// character the pattern continues with).  A miss costs the sector and then takes the tree walk as before.
-// A class is only entered where win_build_cell() found the reference's own rank() / inverseSelect() — every route, every
-// quirk — to return exactly these numbers with no status and no `suspect` at EVERY position of the window; anything else
-// (a masked run block Q1, a next-block path Q2 / Q11, a symbol the int16 cast of FM:532 would change) stays "none".
-constexpr uint32_t kWinW = 120;
+//   word  4      index of the window's first entry in win_other
+//   word  5      symbol of class 2 | the planes' first 16 bits
+//   words 5..15  three bit planes of 112 bits each, from bit 16 of word 5 on, back to back: plane 0 / 1 = low / high bit of the
+//                position's class (3 = "none of the three"), plane 2 = the position's bit in sampledSuffixes (FM:123: what
+//                locate polls before every step, FM:531)
+// and one 8-byte entry {folded rank before the position, symbol | flags << 16} in win_other per position of class 3, in position
+// order.  inverseSelect(p): class position -> {symbol, count + the class's positions before p}: ONE sector; class 3 -> the entry
+// (index = the cell's first + the class-3 positions before p): a second, dependent load; an entry without kWinOtherValid (a masked
+// run block Q1, a symbol the int16 cast of FM:532 would change, a rank() that disagrees or raises a status) -> the tree walk.
+// rank(c, p) for a class symbol = its count + the class's positions before p; any other symbol walks the tree (the classes are
+// the window's three most frequent symbols: ~80 % of the positions and of the ranks a backward search asks once its range is
+// narrow — the BWT around a pattern's rows mostly holds the character the pattern continues with).
+// Every number in the directory was checked against the reference's own rank() / inverseSelect() — every route, every quirk —
+// when it was grown (win_build_cell, win_build_other): results never depend on it.
+constexpr uint32_t kWinW = 112;
 constexpr uint32_t kWinNone = 0xffffu;
+constexpr uint32_t kWinOtherValid = 0x10000u;
 struct WinCell {
     Quad q0, q1, q2, q3;
 };
@@ -675,29 +681,30 @@ FMX_HD WinCell win_load(const DevIndex &ix, uint32_t position, uint32_t &r) {
     FMX_PIN_QUAD(c.q3);
     return c;
 }
-// the positions of class k among the window's first r, from the two class planes
+// the two class planes, positions 0..63 / 64..111 (+ 16 bits of whatever follows)
 struct WinPlanes {
-    uint64_t a_lo, a_hi, b_lo, b_hi;  // plane 0 / plane 1, positions 0..63 / 64..119 (+ 8 bits of whatever follows)
+    uint64_t a_lo, a_hi, b_lo, b_hi;
 };
 FMX_HD WinPlanes win_planes(const WinCell &c) {
-    WinPlanes p;
-    p.a_lo = (uint64_t)((c.q1.x >> 16) | (c.q1.y << 16)) | ((uint64_t)((c.q1.y >> 16) | (c.q1.z << 16)) << 32);
-    p.a_hi = (uint64_t)((c.q1.z >> 16) | (c.q1.w << 16)) | ((uint64_t)((c.q1.w >> 16) | (c.q2.x << 16)) << 32);
-    p.b_lo = (uint64_t)((c.q2.x >> 8) | (c.q2.y << 24)) | ((uint64_t)((c.q2.y >> 8) | (c.q2.z << 24)) << 32);
-    p.b_hi = (uint64_t)((c.q2.z >> 8) | (c.q2.w << 24)) | ((uint64_t)((c.q2.w >> 8) | (c.q3.x << 24)) << 32);
+    WinPlanes p;  // words: q1 = {4, 5, 6, 7}, q2 = {8 .. 11}, q3 = {12 .. 15}; plane 0 from bit 16 of word 5, plane 1 = words 9 .. 12
+    p.a_lo = (uint64_t)((c.q1.y >> 16) | (c.q1.z << 16)) | ((uint64_t)((c.q1.z >> 16) | (c.q1.w << 16)) << 32);
+    p.a_hi = (uint64_t)((c.q1.w >> 16) | (c.q2.x << 16)) | ((uint64_t)((c.q2.x >> 16) | (c.q2.y << 16)) << 32);
+    p.b_lo = (uint64_t)c.q2.y | ((uint64_t)c.q2.z << 32);
+    p.b_hi = (uint64_t)c.q2.w | ((uint64_t)c.q3.x << 32);
     return p;
 }
+// positions of class k (0 .. 3) among the window's first r
 FMX_HD int32_t win_class_before(const WinPlanes &p, uint32_t k, uint32_t r) {
     const uint64_t fa = (k & 1u) ? 0ull : ~0ull, fb = (k & 2u) ? 0ull : ~0ull;
     const uint64_t m_lo = (p.a_lo ^ fa) & (p.b_lo ^ fb), m_hi = (p.a_hi ^ fa) & (p.b_hi ^ fb);
-    const uint32_t r_lo = r < 64u ? r : 64u, r_hi = r < 64u ? 0u : r - 64u;  // r <= kWinW: r_hi <= 56
+    const uint32_t r_lo = r < 64u ? r : 64u, r_hi = r < 64u ? 0u : r - 64u;  // r <= kWinW: r_hi <= 48
     const uint64_t k_lo = r_lo >= 64u ? ~0ull : ((1ull << r_lo) - 1ull);
     return fmx_popcll(m_lo & k_lo) + fmx_popcll(m_hi & ((1ull << r_hi) - 1ull));
 }
 // rank(symbol, position) from the window of `position` (<= wt_size): true = value_out is C[symbol] + rank
 FMX_HD bool win_rank_from(const WinCell &c, uint32_t r, int32_t symbol, int32_t &value_out) {
     const uint32_t s = (uint32_t)symbol;
-    const uint32_t id0 = c.q0.w & 0xffffu, id1 = c.q0.w >> 16, id2 = c.q1.x & 0xffffu;
+    const uint32_t id0 = c.q0.w & 0xffffu, id1 = c.q0.w >> 16, id2 = c.q1.y & 0xffffu;
     if (s >= kWinNone || (s != id0 && s != id1 && s != id2)) return false;
     const uint32_t k = s == id0 ? 0u : (s == id1 ? 1u : 2u);
     value_out = (int32_t)(k == 0u ? c.q0.x : (k == 1u ? c.q0.y : c.q0.z)) + win_class_before(win_planes(c), k, r);
@@ -708,19 +715,39 @@ FMX_HD bool win_rank_try(const DevIndex &ix, uint32_t position, int32_t symbol, 
     const WinCell c = win_load(ix, position, r);
     return win_rank_from(c, r, symbol, value_out);
 }
-// inverseSelect(position) (< wt_size) from its window: true = {symbol, C[symbol] + rank before}; sampled_out = the position's
-// bit in sampledSuffixes either way (positions beyond that vector: 0 — callers check the range first, as FM:531 would throw)
-FMX_HD bool win_inv_from(const WinCell &c, uint32_t r, int32_t &symbol_out, int32_t &rank_out, bool &sampled_out) {
+// inverseSelect(position) (< wt_size) from its window: true = {symbol, C[symbol] + rank before}; false = the position is of
+// class 3 and other_out is the index of its entry in win_other.  sampled_out = the position's bit in sampledSuffixes either way
+// (positions beyond that vector: 0 — callers check the range first, as FM:531 would throw)
+FMX_HD bool win_inv_from(const WinCell &c, uint32_t r, int32_t &symbol_out, int32_t &rank_out, bool &sampled_out, uint32_t &other_out) {
     const WinPlanes p = win_planes(c);
     const uint32_t sh = r & 63u;
     const uint32_t b0 = (uint32_t)((r < 64u ? p.a_lo : p.a_hi) >> sh) & 1u, b1 = (uint32_t)((r < 64u ? p.b_lo : p.b_hi) >> sh) & 1u;
-    const uint32_t sw = r < 32u ? c.q3.x : (r < 64u ? c.q3.y : (r < 96u ? c.q3.z : c.q3.w));
-    sampled_out = ((sw >> (r & 31u)) & 1u) != 0;
+    // plane 2 from bit 16 of word 12: positions 0..63 / 64..111
+    const uint64_t s_lo = (uint64_t)((c.q3.x >> 16) | (c.q3.y << 16)) | ((uint64_t)((c.q3.y >> 16) | (c.q3.z << 16)) << 32);
+    const uint64_t s_hi = (uint64_t)((c.q3.z >> 16) | (c.q3.w << 16)) | ((uint64_t)(c.q3.w >> 16) << 32);
+    sampled_out = (((r < 64u ? s_lo : s_hi) >> sh) & 1ull) != 0;
     const uint32_t k = b0 | (b1 << 1);
-    if (k == 3u) return false;
-    symbol_out = (int32_t)(k == 0u ? (c.q0.w & 0xffffu) : (k == 1u ? (c.q0.w >> 16) : (c.q1.x & 0xffffu)));
-    rank_out = (int32_t)(k == 0u ? c.q0.x : (k == 1u ? c.q0.y : c.q0.z)) + win_class_before(p, k, r);
+    const int32_t before = win_class_before(p, k, r);
+    if (k == 3u) {
+        other_out = c.q1.x + (uint32_t)before;
+        return false;
+    }
+    symbol_out = (int32_t)(k == 0u ? (c.q0.w & 0xffffu) : (k == 1u ? (c.q0.w >> 16) : (c.q1.y & 0xffffu)));
+    rank_out = (int32_t)(k == 0u ? c.q0.x : (k == 1u ? c.q0.y : c.q0.z)) + before;
     return true;
+}
+// the entry of a class-3 position: true = {symbol, C[symbol] + rank before} (false: the tree walk must answer)
+FMX_HD bool win_other_from(uint64_t entry, int32_t &symbol_out, int32_t &rank_out) {
+    const uint32_t hi = (uint32_t)(entry >> 32);
+    symbol_out = (int32_t)(hi & 0xffffu);
+    rank_out = (int32_t)(uint32_t)entry;
+    return (hi & kWinOtherValid) != 0;
+}
+FMX_HD uint64_t win_other_load(const DevIndex &ix, uint32_t index) {
+    uint64_t v;
+    memcpy(&v, ix.win_other + index, 8);
+    FMX_OPAQUE64(v);
+    return v;
 }
 // block size log of a superblock (what fm_lf_finish asks): the LDS copy of the header, or the header itself
 FMX_HD int32_t sb_block_size_log(const DevIndex &ix, uint32_t sb_id) {
@@ -740,7 +767,7 @@ FMX_COLD ColdOut wt_rank_folded_cold(const DevIndex *self, uint32_t position, in
 // route, the literal next-block arithmetic) by ONE call of the cold copy, which is this very function with kHot = false.
 template <bool kHot>
 FMX_HD int32_t wt_rank_folded_t(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t symbol, int &status,
-                                bool &suspect) {
+                                bool &suspect, bool use_win = true) {
     const Quad *sb_cache = ix.sb_cache;
     if (position == 0) return fm_c_or_zero(ix, symbol);                 // WFBB:1012-1014
     if (position > ix.wt_size) position = ix.wt_size;                   // WFBB:1015-1017
@@ -751,7 +778,7 @@ FMX_HD int32_t wt_rank_folded_t(const DevIndex &ix, const uint16_t *inv, uint32_
         suspect = true;
         return fm_c_or_zero(ix, symbol);
     }
-    if (ix.win) {  // the window of `position` first: one sector for the symbols it holds (win_* above)
+    if (ix.win && use_win) {  // the window of `position` first: one sector for the symbols it holds (win_* above)
         int32_t v;
         if (win_rank_try(ix, position, symbol, v)) return v;
     }
@@ -970,6 +997,11 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
 FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t symbol, int &status) {
     bool suspect = false;
     return wt_rank_folded_t<FMX_COUNT_COLD_ROUTE != 0>(ix, inv, position, symbol, status, suspect);
+}
+// ... told whether to ask the window of `position` first (k_count does not: see count_one)
+FMX_HD int32_t wt_rank_folded_choice(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t symbol, int &status, bool use_win) {
+    bool suspect = false;
+    return wt_rank_folded_t<FMX_COUNT_COLD_ROUTE != 0>(ix, inv, position, symbol, status, suspect, use_win);
 }
 // the whole of it by one call: the LF-walks need rank() only where a step crosses a block boundary or meets a quirk
 FMX_HD int32_t wt_rank_folded_rare(const DevIndex &ix, uint32_t position, int32_t symbol, int &status, bool &suspect) {
@@ -1212,9 +1244,12 @@ FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32
 //   2. the three most frequent candidate symbols become the classes (ties: the one met first);
 //   3. per class, rank(c, position) is asked at EVERY position of the window (and at wt_size, if it lies in the window) and must
 //      be C[c] + the running count with no status and no `suspect`, and inverseSelect's own rank must agree wherever the symbol
-//      stands; a class that fails anywhere is dropped (its positions become "none").
-// `out` = the 16 words of the cell.
-FMX_HD void win_build_cell(const DevIndex &ix, uint32_t w, uint32_t *out) {
+//      stands; a class that fails anywhere is dropped (its positions become class 3).
+// `out` = the 16 words of the cell, word 4 (the first win_other entry) left 0; returns the number of class-3 positions (entries).
+FMX_HD bool win_candidate(const DevIndex &ix, int32_t c, bool exact) {
+    return exact && c >= 0 && c < 0x8000 && c < ix.wt_sigma && (uint32_t)c < kWinNone;
+}
+FMX_HD uint32_t win_build_cell(const DevIndex &ix, uint32_t w, uint32_t *out) {
     const uint64_t ws64 = (uint64_t)w * kWinW;
     const uint32_t ws = (uint32_t)ws64;
     const uint32_t n = ws64 >= ix.wt_size ? 0u : (ix.wt_size - ws < kWinW ? ix.wt_size - ws : kWinW);
@@ -1228,8 +1263,7 @@ FMX_HD void win_build_cell(const DevIndex &ix, uint32_t w, uint32_t *out) {
         int32_t rank_before = 0, bsl = 0;
         bool exact = true;
         const int32_t c = wt_inverse_select_folded<true>(ix, nullptr, p, rank_before, bsl, exact);
-        const bool candidate = exact && c >= 0 && c < 0x8000 && c < ix.wt_sigma && (uint32_t)c < kWinNone;
-        sym[j] = candidate ? (uint16_t)c : (uint16_t)kWinNone;
+        sym[j] = win_candidate(ix, c, exact) ? (uint16_t)c : (uint16_t)kWinNone;
         before[j] = rank_before;
         if ((int32_t)p < sv.length) {
             int st = ST_OK;
@@ -1282,6 +1316,7 @@ FMX_HD void win_build_cell(const DevIndex &ix, uint32_t w, uint32_t *out) {
             base[k] = 0;
         }
     }
+    uint32_t others = 0;
     for (uint32_t j = 0; j < kWinW; ++j) {
         uint32_t k = 3;
         if (j < n && sym[j] != kWinNone)
@@ -1289,16 +1324,47 @@ FMX_HD void win_build_cell(const DevIndex &ix, uint32_t w, uint32_t *out) {
                 if (best_sym[t] == sym[j]) k = t;
         if (k & 1u) plane[0][j >> 5] |= 1u << (j & 31u);
         if (k & 2u) plane[1][j >> 5] |= 1u << (j & 31u);
+        if (k == 3u && j < n) ++others;
     }
-    // words 4..15 as one 384-bit string: plane t from bit 16 + 120 t on
-    uint32_t words[16] = {base[0], base[1], base[2], best_sym[0] | (best_sym[1] << 16), best_sym[2], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // words 5..15 as one string: plane t from bit 16 + 112 t on
+    uint32_t words[16] = {base[0], base[1], base[2], best_sym[0] | (best_sym[1] << 16), 0, best_sym[2], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t t = 0; t < 3; ++t)
         for (uint32_t j = 0; j < kWinW; ++j)
             if ((plane[t][j >> 5] >> (j & 31u)) & 1u) {
                 const uint32_t bit = 16u + kWinW * t + j;
-                words[4 + (bit >> 5)] |= 1u << (bit & 31u);
+                words[5 + (bit >> 5)] |= 1u << (bit & 31u);
             }
     for (int i = 0; i < 16; ++i) out[i] = words[i];
+    return others;
+}
+// The win_other entries of window w (cell = its 16 words as win_build_cell made them): one per position of class 3, in position
+// order, from entries[first] on: {folded rank before the position, symbol | kWinOtherValid} where inverseSelect's answer is exact,
+// survives the int16 cast and rank(symbol, position) — all routes — returns the same number with no status and no `suspect`;
+// otherwise an entry without the flag (the tree walk answers such a position).  Writes `first` into the cell's word 4.
+FMX_HD void win_build_other(const DevIndex &ix, uint32_t w, uint32_t *cell_words, uint32_t first, uint64_t *entries) {
+    const uint64_t ws64 = (uint64_t)w * kWinW;
+    const uint32_t ws = (uint32_t)ws64;
+    const uint32_t n = ws64 >= ix.wt_size ? 0u : (ix.wt_size - ws < kWinW ? ix.wt_size - ws : kWinW);
+    cell_words[4] = first;
+    WinCell cell;
+    memcpy(&cell, cell_words, 64);
+    uint32_t at = first;
+    for (uint32_t j = 0; j < n; ++j) {
+        int32_t wc, wrank;
+        bool sampled;
+        uint32_t other;
+        if (win_inv_from(cell, j, wc, wrank, sampled, other)) continue;
+        const uint32_t p = ws + j;
+        int32_t rank_before = 0, bsl = 0;
+        bool exact = true;
+        const int32_t c = wt_inverse_select_folded<true>(ix, nullptr, p, rank_before, bsl, exact);
+        bool valid = win_candidate(ix, c, exact);
+        if (valid) {
+            const ColdOut r = wt_rank_folded_cold(FMX_SELF(ix), p, c);
+            valid = r.aux == 0 && r.value == rank_before;
+        }
+        entries[at++] = (uint64_t)(uint32_t)rank_before | ((uint64_t)(((uint32_t)c & 0xffffu) | (valid ? kWinOtherValid : 0u)) << 32);
+    }
 }
 
 // ---- FmIndex helpers -----------------------------------------------------------------------
@@ -1335,12 +1401,14 @@ FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, 
     int32_t rank_before;
     int32_t bsl_i;
     bool exact_symbol;
-    if (ix.win) {  // the window of p: {symbol, rank} of a class position from one sector
-        uint32_t r;
+    if (ix.win) {  // the window of p: {symbol, rank} from one sector, or from the position's entry behind it — no tree walk
+        uint32_t r, other = 0;
         const WinCell cell = win_load(ix, p, r);
-        int32_t wc;
+        int32_t wc = 0;
         bool sampled;
-        if (win_inv_from(cell, r, wc, rank_before, sampled)) {
+        bool have = win_inv_from(cell, r, wc, rank_before, sampled, other);
+        if (!have) have = win_other_from(win_other_load(ix, other), wc, rank_before);
+        if (have) {
             c_out = wc;
             return fm_lf_finish<kCold>(ix, inv, row, wc, rank_before, sb_block_size_log(ix, p >> 20), true, status, suspect);
         }
@@ -1382,19 +1450,27 @@ FMX_HD void fm_lf_step2(const DevIndex &ix, const uint16_t *inv, LfChain &a, LfC
         lb = false;
     }
     if (!la && !lb) return;
-    if (ix.win) {  // the windows of both positions first (one sector each, requested together); a chain they answer is done
-        uint32_t ra = 0, rb = 0;
+    if (ix.win) {  // the windows of both positions first (one sector each, requested together), then the entries of class-3
+                   // positions (together as well); a chain they answer is done
+        uint32_t ra = 0, rb = 0, oa = 0, ob = 0;
         const WinCell wca = win_load(ix, la ? pa : 0u, ra), wcb = win_load(ix, lb ? pb : 0u, rb);
-        int32_t wc, wrank;
+        int32_t wca_c = 0, wcb_c = 0, ranka = 0, rankb = 0;
         bool sampled;
-        if (la && win_inv_from(wca, ra, wc, wrank, sampled)) {
-            a.c = wc;
-            a.row = fm_lf_finish(ix, inv, a.row, wc, wrank, sb_block_size_log(ix, pa >> 20), true, status, suspect);
+        bool ha = win_inv_from(wca, ra, wca_c, ranka, sampled, oa), hb = win_inv_from(wcb, rb, wcb_c, rankb, sampled, ob);
+        const bool ea = la && !ha, eb = lb && !hb;
+        if (ea || eb) {
+            const uint64_t va = win_other_load(ix, ea ? oa : 0u), vb = win_other_load(ix, eb ? ob : 0u);
+            if (ea) ha = win_other_from(va, wca_c, ranka);
+            if (eb) hb = win_other_from(vb, wcb_c, rankb);
+        }
+        if (la && ha) {
+            a.c = wca_c;
+            a.row = fm_lf_finish(ix, inv, a.row, wca_c, ranka, sb_block_size_log(ix, pa >> 20), true, status, suspect);
             la = false;
         }
-        if (lb && win_inv_from(wcb, rb, wc, wrank, sampled)) {
-            b.c = wc;
-            b.row = fm_lf_finish(ix, inv, b.row, wc, wrank, sb_block_size_log(ix, pb >> 20), true, status, suspect);
+        if (lb && hb) {
+            b.c = wcb_c;
+            b.row = fm_lf_finish(ix, inv, b.row, wcb_c, rankb, sb_block_size_log(ix, pb >> 20), true, status, suspect);
             lb = false;
         }
         if (!la && !lb) return;
@@ -1617,12 +1693,14 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
             uint32_t r;
             const WinCell cell = win_load(ix, (uint32_t)p, r);
             bool sampled_row;
-            answered = win_inv_from(cell, r, c, rank_before, sampled_row);
+            uint32_t other = 0;
+            answered = win_inv_from(cell, r, c, rank_before, sampled_row, other);
             if (sampled_row) {
                 scell = ld_quad(bv_cell_ptr(ix.base, sv, (uint32_t)p));
                 FMX_PIN_QUAD(scell);
                 break;
             }
+            if (!answered) answered = win_other_from(win_other_load(ix, other), c, rank_before);
             bsl_p = sb_block_size_log(ix, (uint32_t)p >> 20);
         }
         if (!answered) {
@@ -1661,6 +1739,15 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
     return fm_packed_get(ix.suffix_words, r, ix.bw_suffixes) + distance;  // FM:538-542
 }
 
+// up to four characters of one aligned 8-byte group of a destination row (mask: which of them): one store when all four are there
+FMX_HD void fm_flush_chars(uint16_t *group_at, uint64_t group, uint32_t mask) {
+    if (mask == 0xfu) {
+        memcpy(__builtin_assume_aligned(group_at, 8), &group, 8);
+        return;
+    }
+    for (uint32_t k = 0; k < 4; ++k)
+        if (mask & (1u << k)) group_at[k] = (uint16_t)(group >> (16u * k));
+}
 // FM:564-608.  Returns the reference's return value (0 when an exception status is set).
 FMX_HD int32_t fm_extract(const DevIndex &ix, const uint16_t *inv, int32_t start, int32_t stop, uint16_t *dest,
                           int32_t dst_len, int32_t offset, int32_t &steps, int &status) {
@@ -1689,6 +1776,13 @@ FMX_HD int32_t fm_extract(const DevIndex &ix, const uint16_t *inv, int32_t start
         return 0;
     }
     int32_t remaining = range, distance = 0;
+    // The characters arrive last to first.  A 2-byte store per character was a third of the kernel's memory requests (round 5:
+    // with the window directory a step is ~1.2 sector reads, and the chip serves ~56 G requests/s, reads and writes alike): four
+    // characters are gathered per aligned 8 bytes of the row and leave as ONE store; a group the range covers only in part (the
+    // row's other characters are the caller's) leaves character by character.
+    uint64_t group = 0;
+    uint32_t group_mask = 0;
+    uint16_t *group_at = dest;  // the group's first character
     while (remaining > 0) {  // FM:596-606
         int32_t c;
         row = fm_lf_step<false>(ix, inv, row, c, status);
@@ -1697,400 +1791,24 @@ FMX_HD int32_t fm_extract(const DevIndex &ix, const uint16_t *inv, int32_t start
             const int32_t idx = remaining - 1 + offset;
             if (idx < 0 || idx >= dst_len) {
                 status = ST_JAVA_AIOOBE;
+                fm_flush_chars(group_at, group, group_mask);
                 return 0;
             }
-            dest[idx] = fm_char_of(ix, c);
+            uint16_t *at = dest + idx;
+            const uint32_t slot = (uint32_t)(reinterpret_cast<uintptr_t>(at) >> 1) & 3u;
+            group |= (uint64_t)fm_char_of(ix, c) << (16u * slot);
+            group_mask |= 1u << slot;
+            group_at = at - slot;
             --remaining;
+            if (slot == 0u || remaining == 0) {
+                fm_flush_chars(group_at, group, group_mask);
+                group = 0;
+                group_mask = 0;
+            }
         }
         ++distance;
     }
     return range;
-}
-
-// ---- hop-synchronous walks ("machines") -------------------------------------------------------------------------
-// The functions above take an LF-step the way a CPU would: a loop over the tree's levels inside a loop over the steps.  On a
-// 64-lane wave every such loop runs as long as its SLOWEST lane: a step of a wave costs the deepest code among 64 positions
-// (10+ levels with 1,000 symbols; the average position needs 1.8), and a lane the window directory answered in one load waits
-// for the neighbours that walk the tree (round 5, rocprofv3: k_extract issued 25.8 load instructions per wave-step).  A machine
-// turns the loops inside out: every lane carries its own state {what its next loads are, what they mean}; one pass of the
-// kernel's loop = every lane issues ITS next loads (one hop of whatever it is doing), waits once, digests them and works out
-// the next addresses.  Lanes never wait for each other's depth, only for the memory system; a lane that finishes a query
-// starts its next one while its neighbours are still walking.  Same loads, same arithmetic, same results as the functions
-// above — in another order.
-//
-// One LF-step (fm_lf_step / the loop body of fm_locate_hit) as a machine: phase kLfHead = the step's first loads (the window
-// cell of p = row - 1 and the block's InvHdr; without a directory the InvHdr and, for locate, the bitmap cell), kLfLevel =
-// {NodeRec, cell} of one level of the tree.
-enum : int32_t { kLfHead = 0, kLfLevel = 1 };
-struct LfLane {
-    int32_t row;    // the row whose step is in progress (the symbol looked for stands at p = row - 1)
-    int32_t phase;
-    const NodeRec *nodes;  // tree walk: the block's root record ...
-    uint32_t idx, node_b;  // ... the record of the node in flight, the ones before the node
-    int32_t pos, node_rank;
-};
-// the loads of ONE pass (never carried into the next): head = {window cell (d0..d3) | bitmap cell (d0), InvHdr (d4)}, level =
-// {NodeRec (d0), cell (d1)}; d4's first two words double as the 8 bytes of a packed-vector read (the lanes' seek / suffix phases)
-struct LfLoads {
-    Quad d0, d1, d2, d3, d4;
-};
-FMX_HD void lf_begin(LfLane &l, int32_t row) {
-    l.row = row;
-    l.phase = kLfHead;
-    l.nodes = nullptr;
-    l.idx = 0;
-}
-// Every lane issues the SAME five loads, from addresses picked by its phase (a lane with nothing to fetch reads the image's first
-// bytes): straight-line code — the loads of all phases leave together, nothing waits between them.  `active` = the lane is in a
-// step at all.  kPoll (locate): without a directory the head also fetches the row's cell of sampledSuffixes.
-template <bool kPoll>
-FMX_HD void lf_issue(const DevIndex &ix, const uint16_t *inv, const LfLane &l, LfLoads &m, bool active) {
-    const Quad *nothing = reinterpret_cast<const Quad *>(ix.base);
-    const bool head = l.phase == kLfHead;
-    uint32_t p = (uint32_t)(l.row - 1);
-    if (!active || p >= ix.wt_size) {  // (a row no well-formed index produces: lf_consume reports it)
-        active = false;
-        p = 0;
-    }
-    const InvView v = wt_inv_view(ix, p >> 20, inv);
-    const Quad *a0 = nothing, *a1 = nothing, *a2 = nothing, *a3 = nothing, *a4 = nothing;
-    if (active && head) {
-        a4 = reinterpret_cast<const Quad *>(wt_inv_hdr_ptr(ix, v, p));
-        if (ix.win) {
-            a0 = ix.win + 4 * (uint64_t)(p / kWinW);
-            a1 = a0 + 1;
-            a2 = a0 + 2;
-            a3 = a0 + 3;
-        } else if (kPoll) {
-            RrrView sv = rrr_view_from(Quad{ix.sampled.off_rec, ix.sampled.off_bits, (uint32_t)ix.sampled.length, (uint32_t)ix.sampled.total_ones});
-            bv_bind(sv, ix, inv);
-            a0 = reinterpret_cast<const Quad *>(bv_cell_ptr(ix.base, sv, bv_clamp(sv, (int32_t)p)));
-        }
-    } else if (active) {
-        a0 = reinterpret_cast<const Quad *>(l.nodes + l.idx);
-        a1 = reinterpret_cast<const Quad *>(bv_cell_ptr(ix.base, v.rv, bv_clamp(v.rv, l.pos)));
-    }
-    m.d0 = ld_quad(a0);
-    m.d1 = ld_quad(a1);
-    if (ix.win) {
-        m.d2 = ld_quad(a2);
-        m.d3 = ld_quad(a3);
-    }
-    m.d4 = ld_quad(a4);
-}
-FMX_HD void lf_pin(LfLoads &m) {
-    FMX_PIN_QUAD(m.d0);
-    FMX_PIN_QUAD(m.d1);
-    FMX_PIN_QUAD(m.d2);
-    FMX_PIN_QUAD(m.d3);
-    FMX_PIN_QUAD(m.d4);
-}
-// digests the loads of lf_issue.  Returns 0: the step goes on (next loads set up), 1: the step is taken — l.row is the row
-// before it in text order, c_out its symbol (what fm_lf_step returns) and the lane is at the head of the next step —, 2 (kPoll
-// only): row l.row - 1 is sampled, no step taken (FM:531; the caller ends its walk).
-template <bool kPoll, bool kCold>
-FMX_HD int lf_consume(const DevIndex &ix, const uint16_t *inv, LfLane &l, const LfLoads &m, int32_t &c_out, int &status, bool &suspect) {
-    const uint32_t p = (uint32_t)(l.row - 1);
-    int32_t c = 0, rank_before = 0, bsl = 0;
-    bool exact = true;
-    if (l.phase == kLfHead) {
-        if (p >= ix.wt_size) {  // as fm_lf_step: a row no well-formed index produces
-            status = ST_JAVA_AIOOBE;
-            c_out = 0;
-            l.row = 0;
-            return 1;
-        }
-        bool have = false;
-        if (ix.win) {
-            WinCell cell;
-            cell.q0 = m.d0;
-            cell.q1 = m.d1;
-            cell.q2 = m.d2;
-            cell.q3 = m.d3;
-            bool sampled;
-            have = win_inv_from(cell, p % kWinW, c, rank_before, sampled);
-            if (kPoll && sampled) return 2;
-            bsl = sb_block_size_log(ix, p >> 20);
-        } else if (kPoll) {
-            RrrView sv = rrr_view_from(Quad{ix.sampled.off_rec, ix.sampled.off_bits, (uint32_t)ix.sampled.length, (uint32_t)ix.sampled.total_ones});
-            bv_bind(sv, ix, inv);
-            bool sampled;
-            (void)bv_rank1_access_cell(sv, m.d0, (int32_t)p, sampled);
-            if (sampled) return 2;
-        }
-        if (!have) {
-            const InvView v = wt_inv_view(ix, p >> 20, inv);
-            bsl = v.bsl;
-            const uint32_t block_index = p & ((1u << v.bsl) - 1u);
-            const Quad ihq = m.d4;
-            if (ihq.x & kInvRun) {  // WFBB:1329-1355 (Q1: the stored symbol is masked to 8 bits)
-                exact = (ihq.x & kInvMasked) == 0;
-                rank_before = (int32_t)ihq.z + (int32_t)block_index;
-                c = (int32_t)ihq.y;
-            } else if (ihq.x & kInvSlow) {
-                c = kCold ? wt_inverse_select_route_rare(ix, p, rank_before, exact)
-                          : wt_inverse_select_reference_route(ix, p, v, rank_before, exact);
-            } else {
-                l.nodes = reinterpret_cast<const NodeRec *>(ix.base + ((uint64_t)v.rv.off_bits << 3)) + ihq.z;
-                l.idx = 0;
-                l.node_b = ihq.y;
-                l.pos = (int32_t)(ihq.x & 0xffffffu) + (int32_t)block_index;
-                l.node_rank = (int32_t)block_index;
-                l.phase = kLfLevel;
-                return 0;
-            }
-        }
-    } else {
-        const InvView v = wt_inv_view(ix, p >> 20, inv);
-        bsl = v.bsl;
-        bool bit;
-        const int32_t rank1 = bv_rank1_access_cell(v.rv, m.d1, l.pos, bit) - (int32_t)l.node_b;  // WFBB:1389-1393
-        l.node_rank = bit ? rank1 : l.node_rank - rank1;                                           // WFBB:1435-1470
-        const uint32_t lo = bit ? m.d0.z : m.d0.x, hi = bit ? m.d0.w : m.d0.y;
-        const uint32_t child = lo & 0xffffu;
-        if (child != 0) {
-            l.node_b = hi >> 8;
-            l.pos = (int32_t)((lo >> 16) | ((hi & 0xffu) << 16)) + l.node_rank;
-            l.idx = child;
-            return 0;
-        }
-        rank_before = (int32_t)hi + l.node_rank;  // leaf (WFBB:1495-1533)
-        c = (int32_t)(lo >> 16);
-    }
-    c = (int32_t)(int16_t)c;
-    c_out = c;
-    l.row = fm_lf_finish<kCold>(ix, inv, l.row, c, rank_before, bsl, exact, status, suspect);  // FM:532-535
-    l.phase = kLfHead;
-    return 1;
-}
-
-// FmIndex.extract (FM:564-608) as a machine: phase kXSeek = the sample of `positions` behind `stop` is in flight, kXWalk = the
-// walk (an LfLane), kXIdle = no query (the last one's status / ret / steps are in the lane).
-enum : int32_t { kXIdle = 0, kXSeek = 1, kXWalk = 2 };
-struct ExtractLane {
-    LfLane lf;
-    int32_t phase;
-    int32_t remaining, distance, skip, steps, range, ret, stop;
-    int status;
-    uint16_t *dest;
-};
-// the 8 bytes fm_packed_get / ld_bits read for entry `index` of a packed vector, and the entry out of them
-FMX_HD const uint32_t *fm_packed_ptr(const uint32_t *words, int64_t index, int width) {
-    return words + (((uint64_t)index * (uint32_t)width) >> 5);
-}
-FMX_HD int32_t fm_packed_from(uint64_t raw, int64_t index, int width) {
-    const uint64_t v = raw >> (((uint64_t)index * (uint32_t)width) & 31);
-    return (int32_t)(uint32_t)(v & ((width >= 32) ? 0xffffffffull : ((1ull << width) - 1ull)));
-}
-// the checks of FM:566-593 (the order among them is the reference's); false = the query is over (status set)
-FMX_HD bool extract_begin(const DevIndex &ix, ExtractLane &e, int32_t start, int32_t stop, uint16_t *dest, int32_t dst_len,
-                          int32_t offset) {
-    e.steps = 0;
-    e.status = ST_OK;
-    e.ret = 0;
-    e.phase = kXIdle;
-    e.dest = dest;
-    if (!ix.enable_extract) {
-        e.status = ST_NOT_ENABLED;  // FM:566-568
-        return false;
-    }
-    if (start < 0) {
-        e.status = ST_POS_NEGATIVE;  // FM:570-572
-        return false;
-    }
-    if (stop >= ix.length) {
-        e.status = ST_STOP_TOO_LONG;  // FM:574-576
-        return false;
-    }
-    if (stop / ix.sample_rate + 1 < 0) {
-        e.status = ST_JAVA_AIOOBE;  // negative IntVector index
-        return false;
-    }
-    e.range = stop - start;
-    if (dst_len - offset < e.range) {
-        e.status = ST_DEST_TOO_SMALL;  // FM:591-593 (behind the seek in the reference, which has no effect of its own)
-        return false;
-    }
-    e.stop = stop;
-    e.remaining = e.range;
-    e.distance = 0;
-    if (e.remaining <= 0) {  // FM:596: the loop does not run
-        e.ret = e.range;
-        return false;
-    }
-    e.phase = kXSeek;
-    return true;
-}
-// the lane's loads of this pass (straight-line: see lf_issue); raw = the 8 bytes of the `positions` sample of a lane that seeks
-FMX_HD void extract_issue(const DevIndex &ix, const uint16_t *inv, const ExtractLane &e, LfLoads &m, uint64_t &raw) {
-    const uint32_t *a = ix.pos_words;
-    if (e.phase == kXSeek) a = fm_packed_ptr(ix.pos_words, (int64_t)(e.stop / ix.sample_rate) + 1, ix.bw_positions);
-    memcpy(&raw, a, 8);
-    lf_issue<false>(ix, inv, e.lf, m, e.phase == kXWalk);
-}
-// true = the query is over: e.status / e.ret / e.steps are its results
-FMX_HD bool extract_consume(const DevIndex &ix, const uint16_t *inv, ExtractLane &e, LfLoads &m, uint64_t raw, int32_t dst_len,
-                            int32_t offset) {
-    FMX_OPAQUE64(raw);
-    lf_pin(m);
-    if (e.phase == kXSeek) {  // fm_seek_after
-        const int32_t s = ix.sample_rate, x = e.stop, q = x / s;
-        const int32_t row = fm_packed_from(raw, (int64_t)q + 1, ix.bw_positions) + 1;
-        int32_t skip = s - x % s;
-        if (q == ix.n_positions - 2) skip = ix.length - x;
-        if (skip > ix.length - x) skip = ix.length - x;
-        e.skip = skip;
-        lf_begin(e.lf, row);
-        e.phase = kXWalk;
-        return false;
-    }
-    if (e.phase != kXWalk) return true;
-    int32_t c;
-    bool suspect = false;
-    if (lf_consume<false, false>(ix, inv, e.lf, m, c, e.status, suspect) == 0) return false;
-    ++e.steps;  // FM:596-606
-    if (e.distance >= e.skip) {
-        const int32_t idx = e.remaining - 1 + offset;
-        if (idx < 0 || idx >= dst_len) {
-            e.status = ST_JAVA_AIOOBE;
-            e.ret = 0;
-            e.phase = kXIdle;
-            return true;
-        }
-        e.dest[idx] = fm_char_of(ix, c);
-        --e.remaining;
-    }
-    ++e.distance;
-    if (e.remaining > 0) return false;
-    e.ret = e.range;
-    e.phase = kXIdle;
-    return true;
-}
-// the whole query by one lane (the host simulation, and what the machine must equal: fm_extract)
-FMX_HD int32_t fm_extract_machine(const DevIndex &ix, const uint16_t *inv, int32_t start, int32_t stop, uint16_t *dest,
-                                  int32_t dst_len, int32_t offset, int32_t &steps, int &status) {
-    ExtractLane e;
-    lf_begin(e.lf, 1);
-    if (extract_begin(ix, e, start, stop, dest, dst_len, offset)) {
-        for (;;) {
-            LfLoads m = {};
-            uint64_t raw = 0;
-            extract_issue(ix, inv, e, m, raw);
-            if (extract_consume(ix, inv, e, m, raw, dst_len, offset)) break;
-        }
-    }
-    steps = e.steps;
-    status = e.status;
-    return e.ret;  // (as fm_extract: the range even where a step set a status; the kernel reports 0 then)
-}
-
-// One hit of FmIndex.locate (FM:526-548, fm_locate_hit) as a machine: kLWalk = the walk to the next sampled row (every head
-// polls sampledSuffixes: the window cell's third plane, or the bitmap's own cell), kLCell = the bitmap cell of the sampled row
-// is in flight (only behind a window: the rank of FM:541 needs it), kLSuffix = the two words of `suffixes` are in flight.
-enum : int32_t { kLIdle = 0, kLWalk = 1, kLCell = 2, kLSuffix = 3 };
-struct LocateLane {
-    LfLane lf;
-    int32_t phase, distance, at;
-    int status;
-    int32_t r;
-};
-// (fm_locate_hit: bounds a walk over a damaged index)
-FMX_HD int32_t fm_walk_limit(const DevIndex &ix) {
-    const int64_t stretches = (int64_t)ix.sample_rate * 256;
-    return (int32_t)(stretches < 4096 ? 4096 : (stretches < (int64_t)ix.length ? stretches : (int64_t)ix.length));
-}
-FMX_HD RrrView fm_sampled_view(const DevIndex &ix, const uint16_t *inv) {
-    RrrView sv = rrr_view_from(Quad{ix.sampled.off_rec, ix.sampled.off_bits, (uint32_t)ix.sampled.length, (uint32_t)ix.sampled.total_ones});
-    bv_bind(sv, ix, inv);
-    return sv;
-}
-FMX_HD void locate_begin(const DevIndex &ix, LocateLane &l, int32_t start, int32_t k) {
-    l.distance = 0;
-    l.status = ST_OK;
-    l.at = 0;
-    l.r = 0;
-    lf_begin(l.lf, start + 1 + k);  // FM:527-529
-    l.phase = kLWalk;
-}
-// the lane's loads of this pass: the walk's five (lf_issue), the sampled row's bitmap cell (scell) and the 8 bytes of its suffix
-FMX_HD void locate_issue(const DevIndex &ix, const uint16_t *inv, const LocateLane &l, LfLoads &m, Quad &scell, uint64_t &raw) {
-    const int32_t p = l.lf.row - 1;
-    const bool walking = l.phase == kLWalk && !(l.lf.phase == kLfHead && (p < 0 || p >= ix.sampled.length));  // (else: locate_consume reports it)
-    const uint32_t *a = ix.suffix_words;
-    if (l.phase == kLSuffix) a = fm_packed_ptr(ix.suffix_words, l.r, ix.bw_suffixes);
-    memcpy(&raw, a, 8);
-    const RrrView sv = fm_sampled_view(ix, inv);
-    scell = ld_quad(bv_cell_ptr(ix.base, sv, l.phase == kLCell ? bv_clamp(sv, p) : 0u));
-    lf_issue<true>(ix, inv, l.lf, m, walking);
-}
-// true = the hit is located: l.at = its text position, l.distance = LF-steps walked, l.status
-FMX_HD bool locate_consume(const DevIndex &ix, const uint16_t *inv, LocateLane &l, LfLoads &m, Quad scell, uint64_t raw,
-                           int32_t walk_limit) {
-    FMX_OPAQUE64(raw);
-    FMX_PIN_QUAD(scell);
-    lf_pin(m);
-    if (l.phase == kLSuffix) {
-        l.at = fm_packed_from(raw, l.r, ix.bw_suffixes) + l.distance;  // FM:538-542
-        l.phase = kLIdle;
-        return true;
-    }
-    if (l.phase == kLCell) {
-        const RrrView sv = fm_sampled_view(ix, inv);
-        l.r = bv_rank1_after_set_bit(sv, scell, l.lf.row - 1) - 1;  // FM:541 (rankOnes(j) = rankOnes(j - 1) + 1: row j - 1 is sampled)
-        l.phase = kLSuffix;
-        return false;
-    }
-    if (l.phase != kLWalk) return true;
-    bool derailed = false;
-    if (l.lf.phase == kLfHead) {
-        const int32_t p = l.lf.row - 1;
-        if (p < 0 || p >= ix.sampled.length) {  // RrrVector.access throws (RRR:316-323)
-            l.status = ST_JAVA_AIOOBE;
-            derailed = true;
-        }
-    }
-    if (!derailed) {
-        int32_t c;
-        bool suspect = false;
-        const int rc = lf_consume<true, false>(ix, inv, l.lf, m, c, l.status, suspect);
-        if (rc == 0) return false;
-        if (rc == 2) {  // the row is sampled
-            if (ix.win) {
-                l.phase = kLCell;
-                return false;
-            }
-            const RrrView sv = fm_sampled_view(ix, inv);
-            l.r = bv_rank1_after_set_bit(sv, m.d0, l.lf.row - 1) - 1;
-            l.phase = kLSuffix;
-            return false;
-        }
-        ++l.distance;
-        if (l.distance <= walk_limit) return false;
-        l.status = ST_JAVA_AIOOBE;  // bounds the walk on a damaged index
-    }
-    // (a walk that ended in a status — the reference throws — reports no position: the read only has to stay inside `suffixes`)
-    const RrrView sv = fm_sampled_view(ix, inv);
-    int32_t r = bv_rank1(ix.base, sv, l.lf.row) - 1;
-    if (r < 0) r = 0;
-    l.r = r;
-    l.phase = kLSuffix;
-    return false;
-}
-FMX_HD int32_t fm_locate_hit_machine(const DevIndex &ix, const uint16_t *inv, int32_t start, int32_t k, int32_t &distance,
-                                     int &status) {
-    LocateLane l;
-    locate_begin(ix, l, start, k);
-    const int32_t walk_limit = fm_walk_limit(ix);
-    for (;;) {
-        LfLoads m = {};
-        Quad scell = {0, 0, 0, 0};
-        uint64_t raw = 0;
-        locate_issue(ix, inv, l, m, scell, raw);
-        if (locate_consume(ix, inv, l, m, scell, raw, walk_limit)) break;
-    }
-    distance = l.distance;
-    status = l.status;
-    return l.at;
 }
 
 // ---- right part of extractUntilBoundary / extractUntilBoundaryRight (FM:692-758 / FM:853-921) ----------

@@ -62,13 +62,6 @@ using namespace fmx;
     __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FMX_WALK_WAVES, 8)))
 #endif
 // k_extract: 49.8 ms at a budget for 8 waves, 47.7 ms at 6 (locate -> extract pipeline, tools/bench_pipeline.py)
-// the hop-synchronous machines keep a load in flight per lane at all times: fewer waves saturate the memory system, and their
-// lanes carry more state (the lane's place in its query AND in its step)
-#ifndef FMX_MACHINE_WAVES
-#define FMX_MACHINE_WAVES 4
-#endif
-#define FMX_MACHINE_KERNEL(BLOCK) \
-    __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FMX_MACHINE_WAVES, 8)))
 #ifndef FMX_EXTRACT_WAVES
 #define FMX_EXTRACT_WAVES 6
 #endif
@@ -344,7 +337,9 @@ __device__ __forceinline__ void count_one(const DevIndex &ix, const uint16_t *s_
             --back;
             break;
         }
-        const int32_t mine = wt_rank_folded(ix, s_inv, (uint32_t)(role ? end : start), c, status);  // C[c] + rank
+        // (the window directory is not asked here: a wave's lanes would split into those it answers and those that walk the tree,
+        // and the wave pays for both — measured round 5, profiles/r05_experiments.txt 8)
+        const int32_t mine = wt_rank_folded_choice(ix, s_inv, (uint32_t)(role ? end : start), c, status, false);  // C[c] + rank
         const int32_t other = __shfl_xor(mine, 1);
         start = role ? other : mine;  // FM:469
         end = role ? mine : other;    // FM:470
@@ -635,24 +630,52 @@ int launch_suffix_order1(const DevIndex &ix, float *out, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-// ---- growing the window directory (fmx_device.hpp: win_build_cell) when an index becomes resident: a lane per window ----
-__global__ __launch_bounds__(256) void k_win_build(DevIndex ix, uint32_t n_win, Quad *__restrict__ out) {
+// ---- growing the window directory (fmx_device.hpp: win_build_cell / win_build_other) when an index becomes resident: a lane
+// per window; first the cells and every window's number of class-3 positions, then — the caller has turned those counts into
+// each window's first entry — the entries ----
+__global__ __launch_bounds__(256) void k_win_build(DevIndex ix, uint32_t n_win, Quad *__restrict__ out, uint32_t *__restrict__ others) {
     for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < n_win; w += (uint64_t)gridDim.x * 256) {
         uint32_t words[16];
-        win_build_cell(ix, (uint32_t)w, words);
+        others[w] = win_build_cell(ix, (uint32_t)w, words);
         for (int i = 0; i < 4; ++i) out[4 * w + i] = Quad{words[4 * i], words[4 * i + 1], words[4 * i + 2], words[4 * i + 3]};
     }
 }
-int launch_win_build(const DevIndex &ix, int n_cu, uint32_t n_win, Quad *out, hipStream_t st) {
-    if (n_win == 0) return 0;
-    DevIndex plain = ix;  // the cells are made from the tree walk's own answers
+__global__ __launch_bounds__(256) void k_win_other(DevIndex ix, uint32_t n_win, Quad *__restrict__ cells, const uint32_t *__restrict__ first,
+                                                   uint64_t *__restrict__ entries) {
+    for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < n_win; w += (uint64_t)gridDim.x * 256) {
+        uint32_t words[16];
+        for (int i = 0; i < 4; ++i) {
+            const Quad q = cells[4 * w + i];
+            words[4 * i] = q.x;
+            words[4 * i + 1] = q.y;
+            words[4 * i + 2] = q.z;
+            words[4 * i + 3] = q.w;
+        }
+        win_build_other(ix, (uint32_t)w, words, first[w], entries);
+        cells[4 * w + 1].x = words[4];
+    }
+}
+static DevIndex win_plain_index(const DevIndex &ix) {
+    DevIndex plain = ix;  // the directory is made from the tree walk's own answers
     plain.sb_cache = nullptr;
     plain.suffix_table = nullptr;
     plain.win = nullptr;
+    plain.win_other = nullptr;
+    return plain;
+}
+static unsigned win_blocks(int n_cu, uint32_t n_win) {
     uint64_t blocks = ((uint64_t)n_win + 255) / 256;
     const uint64_t cap_blocks = (uint64_t)n_cu * 64;
-    if (blocks > cap_blocks) blocks = cap_blocks;
-    hipLaunchKernelGGL(k_win_build, dim3((unsigned)blocks), dim3(256), 0, st, plain, n_win, out);
+    return (unsigned)(blocks > cap_blocks ? cap_blocks : blocks);
+}
+int launch_win_build(const DevIndex &ix, int n_cu, uint32_t n_win, Quad *out, uint32_t *others, hipStream_t st) {
+    if (n_win == 0) return 0;
+    hipLaunchKernelGGL(k_win_build, dim3(win_blocks(n_cu, n_win)), dim3(256), 0, st, win_plain_index(ix), n_win, out, others);
+    return (int)hipGetLastError();
+}
+int launch_win_other(const DevIndex &ix, int n_cu, uint32_t n_win, Quad *cells, const uint32_t *first, uint64_t *entries, hipStream_t st) {
+    if (n_win == 0) return 0;
+    hipLaunchKernelGGL(k_win_other, dim3(win_blocks(n_cu, n_win)), dim3(256), 0, st, win_plain_index(ix), n_win, cells, first, entries);
     return (int)hipGetLastError();
 }
 
@@ -731,120 +754,6 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix_global, const int32_t *__
     }
 }
 
-// k_locate_walk as a hop-synchronous machine (fmx_device.hpp "machines"): the same tickets — (record, first hit, stride over
-// the record's hits) — but a lane that has located its hits takes its next ticket itself, and every pass of the loop moves every
-// lane one hop (the ticket's record, `taken`, a window cell + InvHdr, a tree level, the bitmap cell, the suffix words).
-enum : int32_t { kTNeed = 0, kTRecord = 1, kTTaken = 2, kTHit = 3, kTDone = 4 };
-template <int kBlock>
-FMX_MACHINE_KERNEL(kBlock) void k_locate_machine(DevIndex ix_global, const int32_t *__restrict__ range, int32_t n,
-                                              int32_t max_matches, int32_t *__restrict__ locs, int32_t loc_cap, int32_t slots,
-                                              int32_t *__restrict__ found, int32_t *__restrict__ lf_steps,
-                                              int32_t *__restrict__ status_out, const int32_t *__restrict__ taken,
-                                              const PlanRec *__restrict__ order, const uint32_t *__restrict__ order_idle,
-                                              int64_t *__restrict__ set_locs, int64_t set_base) {
-    FMX_FM_INV(ix_global);
-    FMX_WITH_SB_CACHE(ix_global, ix);
-    const int32_t lanes = slots < kWalkLanes ? slots : kWalkLanes;
-    const int64_t idle = order ? (int64_t)(*order_idle / (uint32_t)kFineWindow) * kFineWindow : 0;
-    const int64_t total = idle + ((int64_t)n - idle) * lanes;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    const int32_t walk_limit = fm_walk_limit(ix);
-    int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    int32_t tphase = kTNeed, p = 0, start = 0, end = 0, k = 0, step = 1, located = 0, taken_p = 0;
-    int64_t rec = 0;
-    LocateLane l;
-    locate_begin(ix, l, 0, 0);
-    l.phase = kLIdle;
-    Quad rq = {0, 0, 0, 0};
-    for (;;) {
-        if (tphase == kTNeed) {
-            if (t < total) {
-                rec = t;
-                k = 0;
-                step = 1;
-                if (t >= idle) {
-                    rec = idle + (t - idle) / lanes;
-                    k = (int32_t)((t - idle) - (rec - idle) * lanes);
-                    step = lanes;
-                }
-                t += stride;
-                tphase = kTRecord;
-            } else {
-                tphase = kTDone;
-            }
-        }
-        if (!__any(tphase != kTDone)) break;
-        // ---- every lane's loads of this pass (the same instructions for all: a lane without use for one reads element 0)
-        const int64_t frec = tphase == kTRecord ? rec : 0;
-        if (order) {
-            rq = ld_quad(order + frec);
-        } else {
-            rq.x = (uint32_t)range[2 * frec];
-            rq.y = (uint32_t)range[2 * frec + 1];
-            rq.z = (uint32_t)frec;
-        }
-        int32_t taken_in = 0;
-        if (taken) taken_in = taken[tphase == kTTaken ? p : 0];
-        LfLoads m;
-        Quad scell;
-        uint64_t raw;
-        locate_issue(ix, s_inv, l, m, scell, raw);
-        // ---- ... digested
-        FMX_PIN_QUAD(rq);
-        FMX_OPAQUE32(taken_in);
-        bool ready = false;  // the ticket's record is complete: its hits can be walked
-        if (tphase == kTRecord) {
-            start = (int32_t)rq.x;
-            end = (int32_t)rq.y;
-            p = (int32_t)rq.z;
-            taken_p = 0;
-            if (taken)
-                tphase = kTTaken;
-            else
-                ready = true;
-        } else if (tphase == kTTaken) {
-            taken_p = taken_in;
-            ready = true;
-        } else if (tphase == kTHit) {
-            if (locate_consume(ix, s_inv, l, m, scell, raw, walk_limit)) {
-                if (set_locs)
-                    set_locs[(int64_t)p * loc_cap + taken_p + k] = set_base + l.at;
-                else
-                    locs[(int64_t)p * loc_cap + k] = l.at;
-                if (lf_steps && l.distance) atomicAdd(&lf_steps[p], l.distance);
-                if (l.status && status_out) atomicOr(&status_out[p], l.status);
-                k += step;
-                if (k < located)
-                    locate_begin(ix, l, start, k);
-                else
-                    tphase = kTNeed;
-            }
-        }
-        if (ready) {
-            int32_t hits = start < end ? end - start : 0;
-            // segment sets: `taken[p]` hits came from earlier segments, the caller's loop passes maxMatches - taken
-            int32_t limit = max_matches;
-            if (taken) {
-                limit = max_matches - taken_p;
-                if (limit <= 0) hits = 0;
-            }
-            // the reference stops at maxMatches (FM:544-546) and overruns `locations` beyond its length (Java AIOOBE)
-            const int32_t wanted = (limit > 0 && hits > limit) ? limit : hits;
-            located = wanted < loc_cap ? wanted : loc_cap;
-            if (k == 0) {
-                found[p] = located;
-                if (wanted > loc_cap && status_out) atomicOr(&status_out[p], ST_JAVA_AIOOBE);
-            }
-            if (k < located) {
-                locate_begin(ix, l, start, k);
-                tphase = kTHit;
-            } else {
-                tphase = kTNeed;
-            }
-        }
-    }
-}
-
 // FM:564-608.  Pipeline form (slot_found != nullptr): query q is hit (q % slots) of pattern (q / slots) and
 // runs only if that hit exists; with stops == nullptr the stop position is min(inputLength, start + fixed_len)
 // (the reference's locateAndExtractBenchmark, FmIndexThroughputBenchmark.java:231-249).
@@ -876,60 +785,6 @@ FMX_EXTRACT_KERNEL(kBlock) void k_extract(DevIndex ix_global, const int32_t *__r
         out_len[q] = status ? 0 : ret;
         if (lf_steps) lf_steps[q] = steps;
         if (status_out) status_out[q] = status;
-    }
-}
-
-// The same queries as a hop-synchronous machine (fmx_device.hpp "machines"): a lane takes queries t, t + lanes, ... on its own —
-// one pass of the loop = every lane issues the next loads of whatever it is doing (its next query's operands, the sample of
-// `positions`, a window cell + InvHdr, a tree level) and digests them; no lane waits for a neighbour's deeper code or longer
-// extraction.  The plain form only (no hit slots, no position order: those keep k_extract).
-template <int kBlock>
-FMX_MACHINE_KERNEL(kBlock) void k_extract_machine(DevIndex ix_global, const int32_t *__restrict__ starts,
-                                                  const int32_t *__restrict__ stops, int64_t n, uint16_t *__restrict__ dst,
-                                                  int32_t dst_len, int32_t offset, int32_t *__restrict__ out_len,
-                                                  int32_t *__restrict__ lf_steps, int32_t *__restrict__ status_out,
-                                                  int32_t fixed_len) {
-    FMX_FM_INV(ix_global);
-    FMX_WITH_SB_CACHE(ix_global, ix);
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x, q = 0;
-    ExtractLane e;
-    e.phase = kXIdle;
-    lf_begin(e.lf, 1);
-    bool fetching = false;
-    for (;;) {
-        if (e.phase == kXIdle && !fetching && t < n) {
-            q = t;
-            t += stride;
-            fetching = true;
-        }
-        if (!__any(fetching || e.phase != kXIdle)) break;
-        // ---- every lane's loads of this pass (the same instructions for all: a lane without use for one reads element 0)
-        const int64_t fq = fetching ? q : 0;
-        int32_t in_start = starts[fq], in_stop = stops ? stops[fq] : 0;
-        LfLoads m;
-        uint64_t raw;
-        extract_issue(ix, s_inv, e, m, raw);
-        // ---- ... digested
-        FMX_OPAQUE32(in_start);
-        FMX_OPAQUE32(in_stop);
-        bool finished = false;
-        if (fetching) {
-            fetching = false;
-            int32_t stop = in_stop;
-            if (!stops) {
-                const int64_t end = (int64_t)in_start + fixed_len;
-                stop = end < ix.length ? (int32_t)end : ix.length;
-            }
-            finished = !extract_begin(ix, e, in_start, stop, dst + q * (int64_t)dst_len, dst_len, offset);
-        } else if (e.phase != kXIdle) {
-            finished = extract_consume(ix, s_inv, e, m, raw, dst_len, offset);
-        }
-        if (finished) {
-            out_len[q] = e.status ? 0 : e.ret;
-            if (lf_steps) lf_steps[q] = e.steps;
-            if (status_out) status_out[q] = e.status;
-        }
     }
 }
 
@@ -1752,10 +1607,6 @@ __global__ __launch_bounds__(256) void k_segment_commit(int32_t *__restrict__ fo
 // launch on one host thread may read them while another thread sets one (results are identical for every
 // setting, so a launch that sees a mix of old and new values is still correct).
 static std::atomic<int> g_block{512};
-// option "walk_machines": extract / locate walks run as hop-synchronous machines (k_extract_machine, k_locate_machine; 0: the
-// loop forms, A/B); "machine_waves": waves per SIMD their grids are sized for (a lane takes further queries itself)
-static std::atomic<int> g_walk_machines{0};
-static std::atomic<int> g_machine_waves{FMX_MACHINE_WAVES};
 static std::atomic<int> g_groups_per_cu{16};
 static std::atomic<int> g_boundary_accel{1};  // 0 = literal right walk of extractUntilBoundary (A/B and fallback)
 static std::atomic<int> g_boundary_group{4};  // lanes per query of extractUntilBoundary (0 = one lane per query)
@@ -1797,15 +1648,6 @@ int set_option(const char *name, int value) {
     if (!strcmp(name, "block")) {
         if (value != 512 && value != 1024) return -1;
         g_block = value;
-        return 0;
-    }
-    if (!strcmp(name, "walk_machines")) {
-        g_walk_machines = value != 0;
-        return 0;
-    }
-    if (!strcmp(name, "machine_waves")) {
-        if (value < 1 || value > 8) return -1;
-        g_machine_waves = value;
         return 0;
     }
     if (!strcmp(name, "groups_per_cu")) {
@@ -2110,20 +1952,6 @@ int launch_locate_walk(const DevIndex &ix, int n_cu, const int32_t *range, int32
         order_idle = ticket + 1;
     }
     const int64_t tickets = (int64_t)n * (slots < kWalkLanes ? slots : kWalkLanes);
-    if (g_walk_machines.load()) {
-        const int blk = g_block;
-        const int64_t cap = (int64_t)n_cu * 4 * g_machine_waves.load() * 64 / blk;
-        int64_t blocks = (tickets + blk - 1) / blk;
-        if (blocks > cap) blocks = cap;
-        if (blocks < 1) blocks = 1;
-        if (blk == 1024)
-            hipLaunchKernelGGL(k_locate_machine<1024>, dim3((unsigned)blocks), dim3(1024), 0, st, ix, range, n, max_matches, locs, loc_cap,
-                               slots, found, lf, status, taken, order, order_idle, set_locs, set_base);
-        else
-            hipLaunchKernelGGL(k_locate_machine<512>, dim3((unsigned)blocks), dim3(512), 0, st, ix, range, n, max_matches, locs, loc_cap,
-                               slots, found, lf, status, taken, order, order_idle, set_locs, set_base);
-        return (int)hipGetLastError();
-    }
     FMX_DISPATCH(k_locate_walk, tickets, ix, range, n, max_matches, locs, loc_cap,
                  slots, found, lf, status, taken, order, order_idle, set_locs, set_base);
     return (int)hipGetLastError();
@@ -2237,21 +2065,6 @@ int launch_extract(const DevIndex &ix, int n_cu, const int32_t *start, const int
         PlanRec *ordered = reinterpret_cast<PlanRec *>(static_cast<uint8_t *>(order_ws) + kPlanHeadBytes);
         if (int e = launch_position_order(ix, start, (int32_t)n, slot_found, slots, order_ws, head_is_zero, ordered, st)) return e;
         order = ordered;
-    }
-    if (!order && !slot_found && g_walk_machines.load()) {
-        // the plain form as a machine: fewer lanes than queries on purpose — a lane that finishes takes its next query itself
-        const int blk = g_block;
-        const int64_t cap = (int64_t)n_cu * 4 * g_machine_waves.load() * 64 / blk;
-        int64_t blocks = (n + blk - 1) / blk;
-        if (blocks > cap) blocks = cap;
-        if (blocks < 1) blocks = 1;
-        if (blk == 1024)
-            hipLaunchKernelGGL(k_extract_machine<1024>, dim3((unsigned)blocks), dim3(1024), 0, st, ix, start, stop, n, dst, dst_len, offset,
-                               out_len, lf, status, fixed_len);
-        else
-            hipLaunchKernelGGL(k_extract_machine<512>, dim3((unsigned)blocks), dim3(512), 0, st, ix, start, stop, n, dst, dst_len, offset,
-                               out_len, lf, status, fixed_len);
-        return (int)hipGetLastError();
     }
     FMX_DISPATCH(k_extract, n, ix, start, stop, n, dst, dst_len, offset, out_len, lf, status, slot_found, slots, fixed_len, order);
     return (int)hipGetLastError();

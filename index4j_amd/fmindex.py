@@ -190,6 +190,12 @@ class FmIndex:
             raise RuntimeError("Found a character that exceeds (32767): it was %d" % bad.value)
         return n
 
+    def window_cells_bytes(self):
+        """bytes of the resident index's window directory (0: none) — fmx_window_cells_info"""
+        nbytes = C.c_int64(0)
+        check(lib.fmx_window_cells_info(self._h, C.byref(nbytes)), "fmx_window_cells_info")
+        return nbytes.value
+
     def suffix_table_info(self):
         """(characters, bytes) of the resident index's suffix table (0, 0: none) — fmx_suffix_table_info"""
         chars, nbytes = C.c_int32(0), C.c_int64(0)

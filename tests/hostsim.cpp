@@ -16,8 +16,7 @@ using namespace fmx;
 
 // window directories attached to blobs (sim_win_attach): what fmx_to_device grows beside a resident image
 static std::map<const uint8_t *, std::vector<uint32_t>> g_windows;
-// 1: the queries run as the kernels' hop-synchronous machines do (fm_extract_machine, ...) instead of the loop forms
-static int g_machines = 0;
+static std::map<const uint8_t *, std::vector<uint64_t>> g_window_entries;
 
 static DevIndex make_index(const uint8_t *b) {
     BlobHeader h;
@@ -51,6 +50,8 @@ static DevIndex make_index(const uint8_t *b) {
     {
         auto it = g_windows.find(b);
         d.win = it == g_windows.end() ? nullptr : reinterpret_cast<const Quad *>(it->second.data());
+        auto e = g_window_entries.find(b);
+        d.win_other = e == g_window_entries.end() ? nullptr : e->second.data();
     }
     d.self = nullptr;
     d.suffix_chars = 0;
@@ -64,35 +65,48 @@ extern "C" {
 
 // grows the window directory of a blob with the very function k_win_build runs (win_build_cell) and attaches it: every sim_*
 // call on that blob then takes the windows first, as the kernels do on a resident index.  Returns the number of cells;
-// stats (nullable): {positions with a class, positions, classes in use}.
+// stats (nullable): {positions with a class, positions, classes in use, positions answered by their win_other entry}.
 int64_t sim_win_attach(const uint8_t *blob, int64_t *stats) {
     g_windows.erase(blob);
-    DevIndex ix = make_index(blob);  // (no directory: the cells are made from the tree walk's own answers)
+    g_window_entries.erase(blob);
+    DevIndex ix = make_index(blob);  // (no directory: it is made from the tree walk's own answers)
     const size_t cells = win_cells_for(ix.wt_size);
-    std::vector<uint32_t> words(cells * 16 + 4);
-    // (the vector's storage is 16-byte aligned for Quad loads through memcpy either way)
-    for (size_t w = 0; w < cells; ++w) win_build_cell(ix, (uint32_t)w, words.data() + 16 * w);
+    std::vector<uint32_t> words(cells * 16 + 4), first(cells + 1);
+    uint64_t total = 0;
+    for (size_t w = 0; w < cells; ++w) {
+        first[w] = (uint32_t)total;
+        total += win_build_cell(ix, (uint32_t)w, words.data() + 16 * w);
+    }
+    std::vector<uint64_t> entries(total + 1);
+    for (size_t w = 0; w < cells; ++w) win_build_other(ix, (uint32_t)w, words.data() + 16 * w, first[w], entries.data());
     if (stats) {
-        stats[0] = stats[1] = stats[2] = 0;
+        stats[0] = stats[1] = stats[2] = stats[3] = 0;
         for (size_t w = 0; w < cells; ++w) {
             const uint32_t *c = words.data() + 16 * w;
             WinCell cell;
             memcpy(&cell, c, 64);
-            const uint32_t ids[3] = {c[3] & 0xffffu, c[3] >> 16, c[4] & 0xffffu};
+            const uint32_t ids[3] = {c[3] & 0xffffu, c[3] >> 16, c[5] & 0xffffu};
             for (int k = 0; k < 3; ++k) stats[2] += ids[k] != kWinNone;
             for (uint32_t r = 0; r < kWinW && (uint64_t)w * kWinW + r < ix.wt_size; ++r) {
                 int32_t sym, rank;
                 bool sampled;
-                stats[0] += win_inv_from(cell, r, sym, rank, sampled) ? 1 : 0;
+                uint32_t other = 0;
+                if (win_inv_from(cell, r, sym, rank, sampled, other))
+                    ++stats[0];
+                else if (win_other_from(entries[other], sym, rank))
+                    ++stats[3];
                 ++stats[1];
             }
         }
     }
     g_windows[blob] = std::move(words);
+    g_window_entries[blob] = std::move(entries);
     return (int64_t)cells;
 }
-void sim_win_detach(const uint8_t *blob) { g_windows.erase(blob); }
-void sim_set_machines(int on) { g_machines = on; }
+void sim_win_detach(const uint8_t *blob) {
+    g_windows.erase(blob);
+    g_window_entries.erase(blob);
+}
 
 int32_t sim_wt_rank(const uint8_t *blob, uint32_t position, int32_t symbol, int32_t *status) {
     DevIndex ix = make_index(blob);
@@ -267,7 +281,7 @@ void sim_locate_walk(const uint8_t *blob, const int32_t *range, int32_t n, int32
             if (k >= located) continue;
             int status = ST_OK;
             int32_t distance;
-            locs[(int64_t)p * loc_cap + k] = (g_machines ? fm_locate_hit_machine : fm_locate_hit)(ix, ix.inv_global, start, k, distance, status);
+            locs[(int64_t)p * loc_cap + k] = fm_locate_hit(ix, ix.inv_global, start, k, distance, status);
             if (lf) lf[p] += distance;
             if (status && status_out) status_out[p] |= status;
         }
@@ -279,7 +293,7 @@ void sim_extract(const uint8_t *blob, const int32_t *starts, const int32_t *stop
     for (int32_t q = 0; q < n; ++q) {
         int status = ST_OK;
         int32_t steps;
-        const int32_t ret = (g_machines ? fm_extract_machine : fm_extract)(ix, ix.inv_global, starts[q], stops[q], dst + (int64_t)q * dst_len, dst_len,
+        const int32_t ret = fm_extract(ix, ix.inv_global, starts[q], stops[q], dst + (int64_t)q * dst_len, dst_len,
                                        offset, steps, status);
         out_len[q] = status ? 0 : ret;
         if (lf) lf[q] = steps;

@@ -28,7 +28,6 @@ def lib(compact=False):
         L.sim_win_attach.argtypes = [C.c_void_p, C.c_void_p]
         L.sim_win_attach.restype = C.c_int64
         L.sim_win_detach.argtypes = [C.c_void_p]
-        L.sim_set_machines.argtypes = [C.c_int]
         _LIBS[compact] = L
     return _LIBS[compact]
 
@@ -87,8 +86,8 @@ class HostSim:
     def attach_windows(self):
         """grows the window directory (fmx_device.hpp: win_build_cell, what k_win_build runs when an index becomes resident) and
         makes every later call of this simulation take it first, as the kernels do; returns (positions with a class, positions,
-        classes in use)"""
-        stats = np.zeros(3, np.int64)
+        classes in use, positions answered by their entry)"""
+        stats = np.zeros(4, np.int64)
         self.L.sim_win_attach(C.c_void_p(self.p), C.c_void_p(stats.ctypes.data))
         self.windows = tuple(int(v) for v in stats)
         return self.windows

@@ -1025,3 +1025,44 @@ def test_host_locate_keeps_the_callers_slots_beyond_the_hits():
             except IndexError:
                 assert st[i] == 9 and (locs[i, found[i]:] == keep[found[i]:]).all()
         assert st[-1] == 9 and found[-1] == 0
+
+
+def _window_bytes(f):
+    n = C.c_int64(-1)
+    assert ia.lib.fmx_window_cells_info(f.handle, C.byref(n)) == 0
+    return n.value
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_window_directory_changes_nothing_but_the_time(mode):
+    """option window_cells: every query kind vs the oracle with the directory grown (1) and without one (0) — on the fixture,
+    on texts with sentinels, run blocks of wide symbols (Q1: never a directory entry) and a 900-symbol alphabet, on a compact
+    image — and fmx_window_cells_info says which of the two an index got"""
+    rng = np.random.default_rng(9)
+    parts = []
+    for i in range(6):
+        parts.append("".join(chr(0x4E00 + int(x) * 7) for x in rng.integers(0, 900, 1500)))
+        parts.append(chr(0x30A1 + i) * 70_000)
+        parts.append("log line %d\n" % i * 50)
+    wide = "".join(parts)
+    rnd = random.Random(40 + mode)
+    mod = list(HD[:40_000])
+    for _ in range(300):
+        mod[rnd.randrange(len(mod) - 2)] = "\0"
+    try:
+        assert ia.lib.fmx_set_option(b"window_cells", mode) == 0
+        f = ia.FmIndex(HD[:20_000], 8, True, device=0)
+        assert (_window_bytes(f) > 0) == (mode == 1)
+        # 64 bytes per 112 positions + 8 per position none of its window's three classes holds
+        assert mode == 0 or 64 * (20_001 // 112) <= _window_bytes(f) <= 64 * (20_001 // 112 + 2) + 8 * 20_001
+        for sr in (1, 4, 32, 64):
+            check_all(make_gpu, HD, sr, rnd, n_q=100)
+        check_all(make_gpu, "".join(mod), 8, rnd, n_q=60)
+        check_all(make_gpu, wide, 16, rnd, n_q=60)
+        check_all(make_gpu, "ab" * 56, 4, rnd, n_q=20)  # wt_size = 113: the last position has a cell of its own
+        check_all(make_gpu, "a", 1, rnd, n_q=5)
+        assert ia.lib.fmx_set_option(b"image_compact", 1) == 0
+        check_all(make_gpu, HD[:60_000], 32, rnd, n_q=60)
+    finally:
+        ia.lib.fmx_set_option(b"image_compact", 0)
+        ia.lib.fmx_set_option(b"window_cells", 2)

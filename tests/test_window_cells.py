@@ -20,7 +20,7 @@ COVER = {}
 
 def make_sim_windows(text, sr):
     h = hostsim.HostSim(ia.FmIndex(text, sr, True, device=None))
-    got, positions, classes = h.attach_windows()
+    got, positions, classes, by_entry = h.attach_windows()
     COVER[(len(text), sr)] = got / max(1, positions)
     return h
 
@@ -40,7 +40,8 @@ def test_sentinels_small_texts_and_texts_shorter_than_a_window():
     check_all(make_sim_windows, "".join(mod), 8, rnd, n_q=60)
     check_all(make_sim_windows, "What a string!\nNow this is long, indeed\nBut others could be longer.", 2, rnd, n_q=40)
     check_all(make_sim_windows, "a", 1, rnd, n_q=5)
-    check_all(make_sim_windows, "ab" * 59 + "c", 4, rnd, n_q=20)   # wt_size = 120: rank(wt_size) has a cell of its own
+    check_all(make_sim_windows, "ab" * 55 + "c", 4, rnd, n_q=20)   # wt_size = 112: rank(wt_size) has a cell of its own
+    check_all(make_sim_windows, "ab" * 56, 4, rnd, n_q=20)
     check_all(make_sim_windows, "ab" * 60, 4, rnd, n_q=20)
 
 
@@ -60,8 +61,8 @@ def test_rank_and_inverse_select_at_every_kind_of_block():
     f = ia.FmIndex(text, 5, True, device=None)
     o = orc.OracleFmIndex(text, 5, True)
     h = hostsim.HostSim(f)
-    got, positions, classes = h.attach_windows()
-    assert 0 < got <= positions and classes > 0
+    got, positions, classes, by_entry = h.attach_windows()
+    assert 0 < got <= positions and classes > 0 and by_entry > 0
     L = f.getInputLength()
     wh = o.wavelet_handle()
     st = orc.C.c_int(0)
@@ -109,60 +110,3 @@ def test_reference_route_image_through_the_windows():
         return h
 
     check_all(make, HD[:50_000], 8, random.Random(31), n_q=50)
-
-
-# ---- the hop-synchronous machines (fmx_device.hpp "machines": what k_extract / k_locate_walk run) on one lane -----------------
-
-@pytest.fixture
-def machines():
-    hostsim.lib().sim_set_machines(1)
-    hostsim.lib(True).sim_set_machines(1)
-    try:
-        yield
-    finally:
-        hostsim.lib().sim_set_machines(0)
-        hostsim.lib(True).sim_set_machines(0)
-
-
-def make_sim_plain(text, sr):
-    return hostsim.HostSim(ia.FmIndex(text, sr, True, device=None))
-
-
-@pytest.mark.parametrize("windows", [False, True])
-@pytest.mark.parametrize("sr", [1, 4, 32, 64])
-def test_machines_on_the_fixture(machines, sr, windows):
-    check_all(make_sim_windows if windows else make_sim_plain, HD, sr, random.Random(200 + sr))
-
-
-@pytest.mark.parametrize("windows", [False, True])
-def test_machines_on_quirk_heavy_inputs(machines, windows):
-    make = make_sim_windows if windows else make_sim_plain
-    rnd = random.Random(13)
-    mod = list(HD[:40_000])
-    for _ in range(300):
-        mod[rnd.randrange(len(mod) - 2)] = "\0"
-    check_all(make, "".join(mod), 8, rnd, n_q=60)
-    check_all(make, "a", 1, rnd, n_q=5)
-    check_all(make, "ab" * 60, 4, rnd, n_q=20)
-    check_all(make, quirk_text(), 5, rnd, n_q=80)
-    rng = np.random.default_rng(9)
-    parts = []
-    for i in range(6):
-        parts.append("".join(chr(0x4E00 + int(x) * 7) for x in rng.integers(0, 900, 1500)))
-        parts.append(chr(0x30A1 + i) * 70_000)
-        parts.append("log line %d\n" % i * 50)
-    check_all(make, "".join(parts), 16, random.Random(6), n_q=60)
-
-
-def test_machines_on_compact_and_reference_route_images(machines):
-    assert ia.lib.fmx_set_option(b"image_compact", 1) == 0
-    try:
-        check_all(make_sim_windows, HD[:60_000], 32, random.Random(78), n_q=60)
-        check_all(make_sim_plain, HD[:60_000], 4, random.Random(79), n_q=60)
-    finally:
-        ia.lib.fmx_set_option(b"image_compact", 0)
-
-    def make(text, sr):
-        return hostsim.HostSim(hostsim.reference_route_index(text, sr))
-
-    check_all(make, HD[:50_000], 8, random.Random(32), n_q=50)

@@ -161,10 +161,12 @@ def run_series(ia, torch, orc, dev, text_log2=28, queries=1 << 20, sample_rates=
         ref = orc.OracleFmIndex.read(ser) if check else None
         image_bytes = fm.device_blob()[1]
         table_chars, table_bytes = fm.suffix_table_info()
+        window_bytes = fm.window_cells_bytes()
         info["indexes"].append({"sample_rate": s, "build_s": t_build, "flatten_upload_table_s": t_dev,
                                 "serialized_bytes_per_char": len(ser) / n_text, "image_bytes_per_char": image_bytes / n_text,
                                 "suffix_table_chars": table_chars, "suffix_table_bytes_per_char": table_bytes / n_text,
-                                "resident_bytes_per_char": (image_bytes + table_bytes) / n_text})
+                                "window_directory_bytes_per_char": window_bytes / n_text,
+                                "resident_bytes_per_char": (image_bytes + table_bytes + window_bytes) / n_text})
         del ser
         log("[series] sampleRate %d: built %.1fs, resident %.1fs, image %.3f B/char, table %d chars"
             % (s, t_build, t_dev, image_bytes / n_text, table_chars))
