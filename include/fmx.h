@@ -83,12 +83,14 @@ int fmx_suffix_table_info(const fmx_index *idx, int32_t *chars, int64_t *bytes);
 
 /* The window directory of a resident index (grown by fmx_to_device / fmx_attach_device_blob beside the image, like the suffix
  * table; option "window_cells": 0 = none, 1 = always, 2 = where it fits a quarter of the device's free memory, the default): one
- * 64-byte cell per 120 consecutive BWT positions holding, for the window's three most frequent symbols, their rank at the window
- * start and the positions they stand at, plus every position's bit of sampledSuffixes (FM:123).  WaveletFixedBlockBoosting.rank
- * (WFBB:1010-1285) of such a symbol, inverseSelect (WFBB:1305-1537) of such a position and the poll of FM:531 cost ONE 64-byte
- * sector instead of a mapping entry, path records and a cell per tree level; everything else walks the tree as before.  Every
- * entry was checked against the index's own rank() / inverseSelect() (all routes, all quirks) at every position of its window
- * when it was made: results, statuses and LF-step counts do not depend on it.  *bytes = its size (0: none). */
+ * 64-byte cell per 112 consecutive BWT positions holding, for the window's three most frequent symbols, their rank at the window
+ * start and the positions they stand at, plus every position's bit of sampledSuffixes (FM:123) — and one 8-byte entry {rank, symbol}
+ * per position that holds none of the three.  An LF-step of locate / extract / extractUntilBoundary — inverseSelect (WFBB:1305-1537)
+ * of a position, the poll of FM:531, the rank of FM:534 — then costs ONE 64-byte sector, or two, and no walk through the wavelet
+ * tree (whose loop over the levels of a code a 64-lane wave runs to the deepest code among its positions); count() does not use it.
+ * ~0.57 + 0.2 x 8 = 2.1 bytes per text byte on log text.  Every number in it was checked against the index's own rank() /
+ * inverseSelect() (all routes, all quirks) when it was made; what does not pass (a run block's masked symbol, Q1) is left to
+ * the tree walk: results, statuses and LF-step counts do not depend on it.  *bytes = its size (0: none). */
 int fmx_window_cells_info(const fmx_index *idx, int64_t *bytes);
 
 /* FmIndex.read(ObjectInput) FM:983-1025; also accepts the ObjectOutputStream-framed form produced by
@@ -330,8 +332,9 @@ int fmx_device_count(void);
  * sample intervals one after the other instead of interleaved (A/B; 2 = default).
  * Applied when an index is flattened or becomes resident afterwards: "suffix_table_mb" / "suffix_table_chars" (budget
  * and depth of the suffix table, 0 = none), "sb_cache_limit" (superblocks whose headers are staged in LDS), "map_by_symbol" / "map_fast" / "inv_fast"
- * (layout of the image: tests force the reference's own routes with them).  Applied by fmx_build_on_device:
- * "wavelet_on_device" = 0 encodes the wavelet tree on the host.
+ * (layout of the image: tests force the reference's own routes with them), "window_cells" (the window directory of
+ * fmx_window_cells_info: 0 none, 1 always, 2 where it fits a quarter of the device's free memory).  Applied by
+ * fmx_build_on_device: "wavelet_on_device" = 0 encodes the wavelet tree on the host.
  * Results are identical for every setting. */
 /* Image form (fmx_set_option("image_compact", 0 | 1), applies to images flattened afterwards: fmx_to_device / fmx_blob of an index
  * that has none yet).  0 (default): the bit vectors of the wavelet tree and the sampled-row bitmap are EXPANDED into 16-byte cells

@@ -32,7 +32,7 @@
     int launch_suffix_insert(const fmx::DevIndex &, const fmx::SuffixSlot *, uint32_t, int, fmx::SuffixSlot *, hipStream_t); \
     int launch_suffix_order1(const fmx::DevIndex &, float *, hipStream_t);                                              \
     int launch_win_build(const fmx::DevIndex &, int, uint32_t, fmx::Quad *, uint32_t *, hipStream_t);                   \
-    int launch_win_other(const fmx::DevIndex &, int, uint32_t, fmx::Quad *, const uint32_t *, uint64_t *, hipStream_t); \
+    int launch_win_other(const fmx::DevIndex &, int, uint32_t, fmx::Quad *, const uint32_t *, uint64_t *, uint32_t *, hipStream_t); \
     int launch_count_plan(const fmx::DevIndex &, int, const uint16_t *, const int32_t *, int32_t, void *, size_t, bool, fmx::CountPlan *, \
                           hipStream_t);                                                                                 \
     int launch_count(const fmx::DevIndex &, int, const uint16_t *, const int32_t *, const fmx::CountPlan *, bool, int32_t, int32_t *, \
@@ -244,6 +244,7 @@ void make_dev_index(fmx_index *idx) {
     d.suffix_order1 = nullptr;
     d.win = nullptr;
     d.win_other = nullptr;
+    d.win_complete = 0;
     d.sb_cache = nullptr;
     d.sb_cache_limit = g_sb_cache_limit;
     d.wt_size = (uint32_t)h.wt_size;
@@ -261,6 +262,7 @@ int publish_dev_index(fmx_index *idx) {
     copy.suffix_order1 = nullptr;
     copy.win = nullptr;  // (a cold route is the tree walk itself; the directory is grown from its answers)
     copy.win_other = nullptr;
+    copy.win_complete = 0;
     HIP_TRY(hipMemcpy(idx->d_self, &copy, sizeof(copy), hipMemcpyHostToDevice));
     idx->dev.self = copy.self;
     return FMX_OK;
@@ -857,6 +859,7 @@ static void build_window_cells(fmx_index *idx) {
     idx->win_bytes = 0;
     idx->dev.win = nullptr;
     idx->dev.win_other = nullptr;
+    idx->dev.win_complete = 0;
     const int mode = g_window_cells.load();
     if (mode == 0 || idx->rrr_only || idx->wavelet_only || idx->hdr.kind != 0 || idx->hdr.wt_size <= 0 || !idx->dev.self) return;
     const size_t cells = fmx::win_cells_for((uint32_t)idx->hdr.wt_size);
@@ -894,13 +897,18 @@ static void build_window_cells(fmx_index *idx) {
         total += c;
     }
     if (total > 0xffffffffull) return give_up();
-    if (hipMalloc(&d_entries, (size_t)(total ? total : 1) * sizeof(uint64_t)) != hipSuccess ||
+    // (the entries, and behind them the counter of entries left to the tree walk)
+    uint32_t open_entries = 0;
+    if (hipMalloc(&d_entries, (size_t)(total + 1) * sizeof(uint64_t)) != hipSuccess ||
+        hipMemset(static_cast<uint64_t *>(d_entries) + total, 0, sizeof(uint64_t)) != hipSuccess ||
         hipMemcpy(d_counts, first.data(), cells * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
         k_launch_win_other(idx, idx->dev, idx->n_cu, (uint32_t)cells, static_cast<fmx::Quad *>(d_cells), static_cast<const uint32_t *>(d_counts),
-                           static_cast<uint64_t *>(d_entries), nullptr) != 0 ||
-        hipStreamSynchronize(nullptr) != hipSuccess)
+                           static_cast<uint64_t *>(d_entries), reinterpret_cast<uint32_t *>(static_cast<uint64_t *>(d_entries) + total),
+                           nullptr) != 0 ||
+        hipMemcpy(&open_entries, static_cast<uint64_t *>(d_entries) + total, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
         return give_up();
     (void)hipFree(d_counts);
+    idx->dev.win_complete = open_entries == 0 ? 1 : 0;
     idx->d_win = d_cells;
     idx->d_win_other = d_entries;
     idx->win_bytes = bytes + (size_t)total * sizeof(uint64_t);

@@ -93,6 +93,7 @@ struct DevIndex {
     // path above.  Results never depend on it: every count in it was checked against rank() when it was grown.
     const struct Quad *win;
     const uint64_t *win_other;  // the entries of the positions no class of their window holds (nullptr iff win is)
+    int32_t win_complete;       // 1: every position's step is in the directory (no entry without kWinOtherValid)
     // this index's DevIndex as the API layer keeps it in HBM (no LDS cache, no launch option applied): what a cold route reads
     const DevIndex *self;
 };
@@ -638,11 +639,12 @@ FMX_HD uint16_t fm_char_of(const DevIndex &ix, int32_t c) {
 FMX_HD int32_t fm_c_or_zero(const DevIndex &ix, int32_t symbol) {
     return (symbol >= 0 && symbol < ix.n_c) ? ix.C[symbol] : 0;
 }
-// ---- window directory (DevIndex.win, DevIndex.win_other) --------------------------------------------------------
+// ---- window directory (DevIndex.win, DevIndex.win_other): an LF directory --------------------------------------
 // What a step of an LF-walk costs is the tree walk: a loop over the levels of the symbol's code that a 64-lane wave runs to the
 // DEEPEST code among its 64 positions (10+ levels with 1,000 symbols; the average position needs 1.8) — rocprofv3, round 5:
-// k_extract issued 25.8 load instructions and 620 VALU per wave-step.  The directory answers inverseSelect WITHOUT a loop, and
-// rank for the symbols that matter, from sectors addressed by the position alone.  One 64-byte cell per kWinW = 112 positions:
+// k_extract issued 25.8 load instructions and 620 VALU per wave-step.  The directory holds the step itself — for row j, the
+// symbol c = BWT[j - 1] and the row C[c] + rank(c, j) the reference's two calls (FM:532-535) arrive at — in sectors addressed
+// by the position p = j - 1 alone.  One 64-byte cell per kWinW = 112 positions:
 //   words 0..2   folded rank (C[c] + occurrences of c in BWT[0, window start)) of class 0, 1, 2
 //   word  3      symbol of class 0 | class 1 << 16            (kWinNone: the class is not used)
 //   word  4      index of the window's first entry in win_other
@@ -651,21 +653,21 @@ FMX_HD int32_t fm_c_or_zero(const DevIndex &ix, int32_t symbol) {
 //                position's class (3 = "none of the three"), plane 2 = the position's bit in sampledSuffixes (FM:123: what
 //                locate polls before every step, FM:531)
 // and one 8-byte entry {folded rank before the position, symbol | flags << 16} in win_other per position of class 3, in position
-// order.  inverseSelect(p): class position -> {symbol, count + the class's positions before p}: ONE sector; class 3 -> the entry
-// (index = the cell's first + the class-3 positions before p): a second, dependent load; an entry without kWinOtherValid (a masked
-// run block Q1, a symbol the int16 cast of FM:532 would change, a rank() that disagrees or raises a status) -> the tree walk.
-// rank(c, p) for a class symbol = its count + the class's positions before p; any other symbol walks the tree (the classes are
-// the window's three most frequent symbols: ~80 % of the positions and of the ranks a backward search asks once its range is
-// narrow — the BWT around a pattern's rows mostly holds the character the pattern continues with).
-// Every number in the directory was checked against the reference's own rank() / inverseSelect() — every route, every quirk —
-// when it was grown (win_build_cell, win_build_other): results never depend on it.
+// order.  The step from row p + 1: a class position -> {symbol, count + the class's positions before p + 1}: ONE sector; class 3
+// -> the entry (index = the cell's first + the class-3 positions before p): a second, dependent load; an entry without
+// kWinOtherValid -> the tree walk.  The classes are the window's three most frequent symbols (~80 % of the positions of log text).
+// Every step in the directory is the one fm_lf_step took over the tree — all of the reference's routes and quirks — when the
+// directory was grown, with no status and no `suspect` (win_build_cell, win_build_other); a step that raises either (a masked run
+// block Q1, a next-block path Q2 / Q11, a symbol the int16 cast of FM:532 changes) is left to the tree walk: results never depend
+// on the directory.  DevIndex.win_complete says that no entry was left open: walks over such an index (nearly every index)
+// carry no tree-walk code at all (kWinAlways below).
 constexpr uint32_t kWinW = 112;
 constexpr uint32_t kWinNone = 0xffffu;
 constexpr uint32_t kWinOtherValid = 0x10000u;
 struct WinCell {
     Quad q0, q1, q2, q3;
 };
-FMX_HD size_t win_cells_for(uint32_t wt_size) { return (size_t)(wt_size / kWinW) + 1; }  // rank(wt_size, c) has a cell too
+FMX_HD size_t win_cells_for(uint32_t wt_size) { return (size_t)(wt_size / kWinW) + 1; }
 FMX_HD WinCell win_load(const DevIndex &ix, uint32_t position, uint32_t &r) {
     const uint32_t w = position / kWinW;
     r = position - w * kWinW;
@@ -701,22 +703,8 @@ FMX_HD int32_t win_class_before(const WinPlanes &p, uint32_t k, uint32_t r) {
     const uint64_t k_lo = r_lo >= 64u ? ~0ull : ((1ull << r_lo) - 1ull);
     return fmx_popcll(m_lo & k_lo) + fmx_popcll(m_hi & ((1ull << r_hi) - 1ull));
 }
-// rank(symbol, position) from the window of `position` (<= wt_size): true = value_out is C[symbol] + rank
-FMX_HD bool win_rank_from(const WinCell &c, uint32_t r, int32_t symbol, int32_t &value_out) {
-    const uint32_t s = (uint32_t)symbol;
-    const uint32_t id0 = c.q0.w & 0xffffu, id1 = c.q0.w >> 16, id2 = c.q1.y & 0xffffu;
-    if (s >= kWinNone || (s != id0 && s != id1 && s != id2)) return false;
-    const uint32_t k = s == id0 ? 0u : (s == id1 ? 1u : 2u);
-    value_out = (int32_t)(k == 0u ? c.q0.x : (k == 1u ? c.q0.y : c.q0.z)) + win_class_before(win_planes(c), k, r);
-    return true;
-}
-FMX_HD bool win_rank_try(const DevIndex &ix, uint32_t position, int32_t symbol, int32_t &value_out) {
-    uint32_t r;
-    const WinCell c = win_load(ix, position, r);
-    return win_rank_from(c, r, symbol, value_out);
-}
-// inverseSelect(position) (< wt_size) from its window: true = {symbol, C[symbol] + rank before}; false = the position is of
-// class 3 and other_out is the index of its entry in win_other.  sampled_out = the position's bit in sampledSuffixes either way
+// The step from row position + 1 (position < wt_size) out of its window: true = {symbol, C[symbol] + rank before the position}
+// — the row the step arrives at is one more —; false = the position is of class 3 and other_out is the index of its entry.  sampled_out = the position's bit in sampledSuffixes either way
 // (positions beyond that vector: 0 — callers check the range first, as FM:531 would throw)
 FMX_HD bool win_inv_from(const WinCell &c, uint32_t r, int32_t &symbol_out, int32_t &rank_out, bool &sampled_out, uint32_t &other_out) {
     const WinPlanes p = win_planes(c);
@@ -736,7 +724,7 @@ FMX_HD bool win_inv_from(const WinCell &c, uint32_t r, int32_t &symbol_out, int3
     rank_out = (int32_t)(k == 0u ? c.q0.x : (k == 1u ? c.q0.y : c.q0.z)) + before;
     return true;
 }
-// the entry of a class-3 position: true = {symbol, C[symbol] + rank before} (false: the tree walk must answer)
+// the entry of a class-3 position: true = {symbol, C[symbol] + rank before the position} (false: the tree walk must answer)
 FMX_HD bool win_other_from(uint64_t entry, int32_t &symbol_out, int32_t &rank_out) {
     const uint32_t hi = (uint32_t)(entry >> 32);
     symbol_out = (int32_t)(hi & 0xffffu);
@@ -748,11 +736,6 @@ FMX_HD uint64_t win_other_load(const DevIndex &ix, uint32_t index) {
     memcpy(&v, ix.win_other + index, 8);
     FMX_OPAQUE64(v);
     return v;
-}
-// block size log of a superblock (what fm_lf_finish asks): the LDS copy of the header, or the header itself
-FMX_HD int32_t sb_block_size_log(const DevIndex &ix, uint32_t sb_id) {
-    if (ix.sb_cache) return (int32_t)(int16_t)(ix.sb_cache[2 * sb_id].x >> 16);
-    return (int32_t)ix.sbd[sb_id].bsl;
 }
 
 // With the superblock's header at hand (ix.sb_cache, staged in LDS by the kernel) and the mapping rows indexed by
@@ -767,7 +750,7 @@ FMX_COLD ColdOut wt_rank_folded_cold(const DevIndex *self, uint32_t position, in
 // route, the literal next-block arithmetic) by ONE call of the cold copy, which is this very function with kHot = false.
 template <bool kHot>
 FMX_HD int32_t wt_rank_folded_t(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t symbol, int &status,
-                                bool &suspect, bool use_win = true) {
+                                bool &suspect) {
     const Quad *sb_cache = ix.sb_cache;
     if (position == 0) return fm_c_or_zero(ix, symbol);                 // WFBB:1012-1014
     if (position > ix.wt_size) position = ix.wt_size;                   // WFBB:1015-1017
@@ -777,10 +760,6 @@ FMX_HD int32_t wt_rank_folded_t(const DevIndex &ix, const uint16_t *inv, uint32_
         status = ST_JAVA_AIOOBE;
         suspect = true;
         return fm_c_or_zero(ix, symbol);
-    }
-    if (ix.win && use_win) {  // the window of `position` first: one sector for the symbols it holds (win_* above)
-        int32_t v;
-        if (win_rank_try(ix, position, symbol, v)) return v;
     }
     // The loads of one rank form a dependent chain (superblock -> mapping -> block header -> leaf -> levels);
     // what a stage needs is requested as soon as its address is known, so that the chain is
@@ -997,11 +976,6 @@ FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t 
 FMX_HD int32_t wt_rank_folded(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t symbol, int &status) {
     bool suspect = false;
     return wt_rank_folded_t<FMX_COUNT_COLD_ROUTE != 0>(ix, inv, position, symbol, status, suspect);
-}
-// ... told whether to ask the window of `position` first (k_count does not: see count_one)
-FMX_HD int32_t wt_rank_folded_choice(const DevIndex &ix, const uint16_t *inv, uint32_t position, int32_t symbol, int &status, bool use_win) {
-    bool suspect = false;
-    return wt_rank_folded_t<FMX_COUNT_COLD_ROUTE != 0>(ix, inv, position, symbol, status, suspect, use_win);
 }
 // the whole of it by one call: the LF-walks need rank() only where a step crosses a block boundary or meets a quirk
 FMX_HD int32_t wt_rank_folded_rare(const DevIndex &ix, uint32_t position, int32_t symbol, int &status, bool &suspect) {
@@ -1237,136 +1211,6 @@ FMX_HD int32_t wt_inverse_select(const DevIndex &ix, const uint16_t *inv, uint32
     return c;
 }
 
-// One cell of the window directory (layout: "window directory" above), made from the index's OWN answers: `ix` must not carry
-// a directory itself (ix.win == nullptr: every value below comes from the tree walk, the reference's routes included).
-//   1. inverseSelect of every position of the window; a position is a candidate if its symbol is exact (no Q1 mask), survives
-//      the int16 cast of FM:532 and is below kWinNone;
-//   2. the three most frequent candidate symbols become the classes (ties: the one met first);
-//   3. per class, rank(c, position) is asked at EVERY position of the window (and at wt_size, if it lies in the window) and must
-//      be C[c] + the running count with no status and no `suspect`, and inverseSelect's own rank must agree wherever the symbol
-//      stands; a class that fails anywhere is dropped (its positions become class 3).
-// `out` = the 16 words of the cell, word 4 (the first win_other entry) left 0; returns the number of class-3 positions (entries).
-FMX_HD bool win_candidate(const DevIndex &ix, int32_t c, bool exact) {
-    return exact && c >= 0 && c < 0x8000 && c < ix.wt_sigma && (uint32_t)c < kWinNone;
-}
-FMX_HD uint32_t win_build_cell(const DevIndex &ix, uint32_t w, uint32_t *out) {
-    const uint64_t ws64 = (uint64_t)w * kWinW;
-    const uint32_t ws = (uint32_t)ws64;
-    const uint32_t n = ws64 >= ix.wt_size ? 0u : (ix.wt_size - ws < kWinW ? ix.wt_size - ws : kWinW);
-    uint16_t sym[kWinW];
-    int32_t before[kWinW];
-    uint32_t plane[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    RrrView sv = rrr_view_from(Quad{ix.sampled.off_rec, ix.sampled.off_bits, (uint32_t)ix.sampled.length, (uint32_t)ix.sampled.total_ones});
-    bv_bind(sv, ix, nullptr);
-    for (uint32_t j = 0; j < n; ++j) {
-        const uint32_t p = ws + j;
-        int32_t rank_before = 0, bsl = 0;
-        bool exact = true;
-        const int32_t c = wt_inverse_select_folded<true>(ix, nullptr, p, rank_before, bsl, exact);
-        sym[j] = win_candidate(ix, c, exact) ? (uint16_t)c : (uint16_t)kWinNone;
-        before[j] = rank_before;
-        if ((int32_t)p < sv.length) {
-            int st = ST_OK;
-            if (bv_access(ix.base, sv, (int32_t)p, st) && st == ST_OK) plane[2][j >> 5] |= 1u << (j & 31u);
-        }
-    }
-    uint32_t best_sym[3] = {kWinNone, kWinNone, kWinNone}, best_cnt[3] = {0, 0, 0};
-    for (uint32_t j = 0; j < n; ++j) {
-        const uint32_t c = sym[j];
-        if (c == kWinNone) continue;
-        bool seen = false;
-        for (uint32_t i = 0; i < j && !seen; ++i) seen = sym[i] == c;
-        if (seen) continue;
-        uint32_t cnt = 1;
-        for (uint32_t i = j + 1; i < n; ++i) cnt += sym[i] == c ? 1u : 0u;
-        for (int k = 0; k < 3; ++k) {  // insertion, descending; a tie stays behind the earlier symbol
-            if (cnt > best_cnt[k]) {
-                for (int t = 2; t > k; --t) {
-                    best_cnt[t] = best_cnt[t - 1];
-                    best_sym[t] = best_sym[t - 1];
-                }
-                best_cnt[k] = cnt;
-                best_sym[k] = c;
-                break;
-            }
-        }
-    }
-    uint32_t base[3] = {0, 0, 0};
-    // rank is asked at positions ws .. ws + last (position wt_size itself belongs to the window it falls into)
-    const uint32_t last = ws64 > ix.wt_size ? 0u : (ix.wt_size - ws < kWinW ? ix.wt_size - ws : kWinW - 1u);
-    for (int k = 0; k < 3; ++k) {
-        if (best_sym[k] == kWinNone) continue;
-        const int32_t c = (int32_t)best_sym[k];
-        bool ok = true;
-        int32_t running = 0;
-        for (uint32_t j = 0; j <= last && ok; ++j) {
-            const ColdOut r = wt_rank_folded_cold(FMX_SELF(ix), ws + j, c);
-            if (j == 0) {
-                base[k] = (uint32_t)r.value;
-                running = r.value;
-            }
-            ok = r.aux == 0 && r.value == running;
-            if (j < n && sym[j] == (uint16_t)c) {
-                ok = ok && before[j] == running;
-                ++running;
-            }
-        }
-        if (!ok) {
-            best_sym[k] = kWinNone;
-            base[k] = 0;
-        }
-    }
-    uint32_t others = 0;
-    for (uint32_t j = 0; j < kWinW; ++j) {
-        uint32_t k = 3;
-        if (j < n && sym[j] != kWinNone)
-            for (uint32_t t = 0; t < 3; ++t)
-                if (best_sym[t] == sym[j]) k = t;
-        if (k & 1u) plane[0][j >> 5] |= 1u << (j & 31u);
-        if (k & 2u) plane[1][j >> 5] |= 1u << (j & 31u);
-        if (k == 3u && j < n) ++others;
-    }
-    // words 5..15 as one string: plane t from bit 16 + 112 t on
-    uint32_t words[16] = {base[0], base[1], base[2], best_sym[0] | (best_sym[1] << 16), 0, best_sym[2], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t t = 0; t < 3; ++t)
-        for (uint32_t j = 0; j < kWinW; ++j)
-            if ((plane[t][j >> 5] >> (j & 31u)) & 1u) {
-                const uint32_t bit = 16u + kWinW * t + j;
-                words[5 + (bit >> 5)] |= 1u << (bit & 31u);
-            }
-    for (int i = 0; i < 16; ++i) out[i] = words[i];
-    return others;
-}
-// The win_other entries of window w (cell = its 16 words as win_build_cell made them): one per position of class 3, in position
-// order, from entries[first] on: {folded rank before the position, symbol | kWinOtherValid} where inverseSelect's answer is exact,
-// survives the int16 cast and rank(symbol, position) — all routes — returns the same number with no status and no `suspect`;
-// otherwise an entry without the flag (the tree walk answers such a position).  Writes `first` into the cell's word 4.
-FMX_HD void win_build_other(const DevIndex &ix, uint32_t w, uint32_t *cell_words, uint32_t first, uint64_t *entries) {
-    const uint64_t ws64 = (uint64_t)w * kWinW;
-    const uint32_t ws = (uint32_t)ws64;
-    const uint32_t n = ws64 >= ix.wt_size ? 0u : (ix.wt_size - ws < kWinW ? ix.wt_size - ws : kWinW);
-    cell_words[4] = first;
-    WinCell cell;
-    memcpy(&cell, cell_words, 64);
-    uint32_t at = first;
-    for (uint32_t j = 0; j < n; ++j) {
-        int32_t wc, wrank;
-        bool sampled;
-        uint32_t other;
-        if (win_inv_from(cell, j, wc, wrank, sampled, other)) continue;
-        const uint32_t p = ws + j;
-        int32_t rank_before = 0, bsl = 0;
-        bool exact = true;
-        const int32_t c = wt_inverse_select_folded<true>(ix, nullptr, p, rank_before, bsl, exact);
-        bool valid = win_candidate(ix, c, exact);
-        if (valid) {
-            const ColdOut r = wt_rank_folded_cold(FMX_SELF(ix), p, c);
-            valid = r.aux == 0 && r.value == rank_before;
-        }
-        entries[at++] = (uint64_t)(uint32_t)rank_before | ((uint64_t)(((uint32_t)c & 0xffffu) | (valid ? kWinOtherValid : 0u)) << 32);
-    }
-}
-
 // ---- FmIndex helpers -----------------------------------------------------------------------
 
 FMX_HD int32_t fm_map(const DevIndex &ix, uint16_t ch) { return ix.char2code[ch]; }  // getOrDefault(ch, 0) FM:457
@@ -1389,7 +1233,13 @@ FMX_HD int32_t fm_lf_finish(const DevIndex &ix, const uint16_t *inv, int32_t row
     if (kCold) return wt_rank_folded_rare(ix, (uint32_t)row, c, status, suspect);
     return wt_rank_folded_t<false>(ix, inv, (uint32_t)row, c, status, suspect);
 }
-template <bool kCold = true>
+// kWin — what a walk's code knows about the window directory at COMPILE time: kWinAsk = look at ix.win (both routes in the body:
+// the boundary kernels, the host simulation, an index whose directory left entries open), kWinNever = an index without one (the
+// tree walk alone: the kernels' bodies of round 4), kWinAlways = an index with a COMPLETE one (DevIndex.win_complete): window
+// cell / entry and nothing else — no tree walk, no call, none of their registers (k_locate_walk / k_extract are instantiated for
+// all three and the launcher picks).
+enum : int { kWinAsk = 0, kWinNever = 1, kWinAlways = 2 };
+template <bool kCold = true, int kWin = kWinAsk>
 FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, int32_t &c_out, int &status,
                           bool &suspect) {
     const uint32_t p = (uint32_t)(row - 1);
@@ -1401,7 +1251,8 @@ FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, 
     int32_t rank_before;
     int32_t bsl_i;
     bool exact_symbol;
-    if (ix.win) {  // the window of p: {symbol, rank} from one sector, or from the position's entry behind it — no tree walk
+    if (kWin == kWinAlways || (kWin == kWinAsk && ix.win)) {
+        // the window of p: {symbol, rank} from one sector, or from the position's entry behind it — no tree walk
         uint32_t r, other = 0;
         const WinCell cell = win_load(ix, p, r);
         int32_t wc = 0;
@@ -1410,19 +1261,23 @@ FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, 
         if (!have) have = win_other_from(win_other_load(ix, other), wc, rank_before);
         if (have) {
             c_out = wc;
-            return fm_lf_finish<kCold>(ix, inv, row, wc, rank_before, sb_block_size_log(ix, p >> 20), true, status, suspect);
+            return rank_before + 1;  // (the step fm_lf_step took over the tree when the directory was grown)
+        }
+        if (kWin == kWinAlways) {  // (unreachable: the launcher instantiates kWinAlways for complete directories only)
+            status = ST_JAVA_AIOOBE;
+            c_out = 0;
+            return 0;
         }
     }
     const int32_t c = (int32_t)(int16_t)wt_inverse_select_folded<kCold>(ix, inv, p, rank_before, bsl_i, exact_symbol);  // C[c] + rank
     c_out = c;
     return fm_lf_finish<kCold>(ix, inv, row, c, rank_before, bsl_i, exact_symbol, status, suspect);
 }
-template <bool kCold = true>
+template <bool kCold = true, int kWin = kWinAsk>
 FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, int32_t &c_out, int &status) {
     bool suspect = false;
-    return fm_lf_step<kCold>(ix, inv, row, c_out, status, suspect);
+    return fm_lf_step<kCold, kWin>(ix, inv, row, c_out, status, suspect);
 }
-
 // TWO independent LF-steps of one lane, their loads in flight together (round 3: extractUntilBoundary fetches the sample
 // intervals left and right of a position — two walks that know nothing of each other).  A chain whose flag is off is left
 // alone.  Both chains take the common path jointly — InvHdr, then per level {NodeRec, cell} — so that a level costs ONE round
@@ -1465,12 +1320,12 @@ FMX_HD void fm_lf_step2(const DevIndex &ix, const uint16_t *inv, LfChain &a, LfC
         }
         if (la && ha) {
             a.c = wca_c;
-            a.row = fm_lf_finish(ix, inv, a.row, wca_c, ranka, sb_block_size_log(ix, pa >> 20), true, status, suspect);
+            a.row = ranka + 1;
             la = false;
         }
         if (lb && hb) {
             b.c = wcb_c;
-            b.row = fm_lf_finish(ix, inv, b.row, wcb_c, rankb, sb_block_size_log(ix, pb >> 20), true, status, suspect);
+            b.row = rankb + 1;
             lb = false;
         }
         if (!la && !lb) return;
@@ -1576,6 +1431,125 @@ FMX_HD void fm_lf_step2(const DevIndex &ix, const uint16_t *inv, LfChain &a, LfC
     }
 }
 
+// One cell of the window directory (layout: "window directory" above), made from the index's OWN steps: `ix` must not carry a
+// directory itself (every value below comes from fm_lf_step over the tree, the reference's routes included).
+//   1. the step from row p + 1 for every position p of the window; a position is a candidate if the step raised no status and
+//      no `suspect` and its symbol (behind the int16 cast of FM:532) is in [0, kWinNone);
+//   2. the three most frequent candidate symbols become the classes (ties: the one met first);
+//   3. a class's count is the rank its FIRST position's step arrived at, less one, and every further position of the class must
+//      have arrived at that plus its number in the window — else the class is dropped (its positions become class 3).
+// `out` = the 16 words of the cell, word 4 (the first win_other entry) left 0; returns the number of class-3 positions (entries).
+FMX_HD uint32_t win_build_cell(const DevIndex &ix, uint32_t w, uint32_t *out) {
+    const uint64_t ws64 = (uint64_t)w * kWinW;
+    const uint32_t ws = (uint32_t)ws64;
+    const uint32_t n = ws64 >= ix.wt_size ? 0u : (ix.wt_size - ws < kWinW ? ix.wt_size - ws : kWinW);
+    uint16_t sym[kWinW];
+    int32_t next[kWinW];
+    uint32_t plane[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    RrrView sv = rrr_view_from(Quad{ix.sampled.off_rec, ix.sampled.off_bits, (uint32_t)ix.sampled.length, (uint32_t)ix.sampled.total_ones});
+    bv_bind(sv, ix, nullptr);
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint32_t p = ws + j;
+        int status = ST_OK;
+        bool suspect = false;
+        int32_t c = 0;
+        next[j] = fm_lf_step<true, kWinNever>(ix, nullptr, (int32_t)(p + 1u), c, status, suspect);
+        sym[j] = (status == ST_OK && !suspect && c >= 0 && (uint32_t)c < kWinNone) ? (uint16_t)c : (uint16_t)kWinNone;
+        if ((int32_t)p < sv.length) {
+            int st = ST_OK;
+            if (bv_access(ix.base, sv, (int32_t)p, st) && st == ST_OK) plane[2][j >> 5] |= 1u << (j & 31u);
+        }
+    }
+    uint32_t best_sym[3] = {kWinNone, kWinNone, kWinNone}, best_cnt[3] = {0, 0, 0};
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint32_t c = sym[j];
+        if (c == kWinNone) continue;
+        bool seen = false;
+        for (uint32_t i = 0; i < j && !seen; ++i) seen = sym[i] == c;
+        if (seen) continue;
+        uint32_t cnt = 1;
+        for (uint32_t i = j + 1; i < n; ++i) cnt += sym[i] == c ? 1u : 0u;
+        for (int k = 0; k < 3; ++k) {  // insertion, descending; a tie stays behind the earlier symbol
+            if (cnt > best_cnt[k]) {
+                for (int t = 2; t > k; --t) {
+                    best_cnt[t] = best_cnt[t - 1];
+                    best_sym[t] = best_sym[t - 1];
+                }
+                best_cnt[k] = cnt;
+                best_sym[k] = c;
+                break;
+            }
+        }
+    }
+    uint32_t base[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k) {
+        if (best_sym[k] == kWinNone) continue;
+        bool ok = true, first = true;
+        int32_t running = 0;
+        for (uint32_t j = 0; j < n && ok; ++j) {
+            if (sym[j] != (uint16_t)best_sym[k]) continue;
+            if (first) {
+                running = next[j] - 1;
+                base[k] = (uint32_t)running;
+                first = false;
+            }
+            ok = next[j] == running + 1;
+            ++running;
+        }
+        if (!ok) {
+            best_sym[k] = kWinNone;
+            base[k] = 0;
+        }
+    }
+    uint32_t others = 0;
+    for (uint32_t j = 0; j < kWinW; ++j) {
+        uint32_t k = 3;
+        if (j < n && sym[j] != kWinNone)
+            for (uint32_t t = 0; t < 3; ++t)
+                if (best_sym[t] == sym[j]) k = t;
+        if (k & 1u) plane[0][j >> 5] |= 1u << (j & 31u);
+        if (k & 2u) plane[1][j >> 5] |= 1u << (j & 31u);
+        if (k == 3u && j < n) ++others;
+    }
+    // words 5..15 as one string: plane t from bit 16 + 112 t on
+    uint32_t words[16] = {base[0], base[1], base[2], best_sym[0] | (best_sym[1] << 16), 0, best_sym[2], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t t = 0; t < 3; ++t)
+        for (uint32_t j = 0; j < kWinW; ++j)
+            if ((plane[t][j >> 5] >> (j & 31u)) & 1u) {
+                const uint32_t bit = 16u + kWinW * t + j;
+                words[5 + (bit >> 5)] |= 1u << (bit & 31u);
+            }
+    for (int i = 0; i < 16; ++i) out[i] = words[i];
+    return others;
+}
+// The win_other entries of window w (cell = its 16 words as win_build_cell made them): one per position of class 3, in position
+// order, from entries[first] on: {the row the position's step arrives at, less one; symbol | kWinOtherValid} where the step raised
+// no status and no `suspect` and its symbol is in [0, kWinNone) — otherwise an entry without the flag (the tree walk takes such
+// a step).  Writes `first` into the cell's word 4; returns the number of entries without the flag.
+FMX_HD uint32_t win_build_other(const DevIndex &ix, uint32_t w, uint32_t *cell_words, uint32_t first, uint64_t *entries) {
+    const uint64_t ws64 = (uint64_t)w * kWinW;
+    const uint32_t ws = (uint32_t)ws64;
+    const uint32_t n = ws64 >= ix.wt_size ? 0u : (ix.wt_size - ws < kWinW ? ix.wt_size - ws : kWinW);
+    cell_words[4] = first;
+    WinCell cell;
+    memcpy(&cell, cell_words, 64);
+    uint32_t at = first, open_entries = 0;
+    for (uint32_t j = 0; j < n; ++j) {
+        int32_t wc, wrank;
+        bool sampled;
+        uint32_t other;
+        if (win_inv_from(cell, j, wc, wrank, sampled, other)) continue;
+        int status = ST_OK;
+        bool suspect = false;
+        int32_t c = 0;
+        const int32_t next = fm_lf_step<true, kWinNever>(ix, nullptr, (int32_t)(ws + j + 1u), c, status, suspect);
+        const bool valid = status == ST_OK && !suspect && c >= 0 && (uint32_t)c < kWinNone;
+        if (!valid) ++open_entries;
+        entries[at++] = (uint64_t)(uint32_t)(next - 1) | ((uint64_t)(((uint32_t)c & 0xffffu) | (valid ? kWinOtherValid : 0u)) << 32);
+    }
+    return open_entries;
+}
+
 // IntVector.getValue on the packed `suffixes` / `positions` words (IV:129-143)
 FMX_HD int32_t fm_packed_get(const uint32_t *words, int64_t index, int width) {
     return (int32_t)ld_bits(words, (uint64_t)index * (uint32_t)width, width);
@@ -1662,6 +1636,7 @@ FMX_HD int fm_suffix_len(const DevIndex &ix, int32_t m) { return m < ix.suffix_c
 
 // FM:526-548 for one hit: SA row i = start + 1 + k; LF-walk until a sampled row.
 // Returns the text position; *distance = number of LF-steps walked.
+template <int kWin = kWinAsk>
 FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t start, int32_t k, int32_t &distance,
                              int &status) {
     int32_t j = start + 1 + k;  // FM:527-529
@@ -1685,11 +1660,11 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
         }
         // (p < length == the wavelet tree's size: validate_model / validate_blob)
         int32_t c = 0, rank_before = 0, bsl_p = 0;
-        bool exact = true, answered = false;
-        const bool windows = ix.win != nullptr && (uint32_t)p < ix.wt_size;
+        bool exact = true, answered = false, stepped = false;
+        const bool windows = (kWin == kWinAlways || (kWin == kWinAsk && ix.win != nullptr)) && (uint32_t)p < ix.wt_size;
         if (windows) {
             // the window of p holds the row's sampled bit as well: a step of a walk is ONE sector where the symbol is one of the
-            // window's classes (the bitmap's own cell is fetched once, for the rank behind the loop)
+            // window's classes, or two (the bitmap's own cell is fetched once, for the rank behind the loop)
             uint32_t r;
             const WinCell cell = win_load(ix, (uint32_t)p, r);
             bool sampled_row;
@@ -1701,24 +1676,34 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
                 break;
             }
             if (!answered) answered = win_other_from(win_other_load(ix, other), c, rank_before);
-            bsl_p = sb_block_size_log(ix, (uint32_t)p >> 20);
-        }
-        if (!answered) {
-            const InvView v = wt_inv_view(ix, (uint32_t)p >> 20, inv);
-            Quad ihq = ld_quad(wt_inv_hdr_ptr(ix, v, (uint32_t)p));
-            if (!windows) scell = ld_quad(bv_cell_ptr(ix.base, sv, (uint32_t)p));
-            FMX_PIN_QUAD(ihq);
-            FMX_PIN_QUAD(scell);
-            if (!windows) {
-                bool sampled_row;
-                (void)bv_rank1_access_cell(sv, scell, p, sampled_row);
-                if (sampled_row) break;
+            if (answered) {
+                j = rank_before + 1;  // (the step fm_lf_step took over the tree when the directory was grown)
+                stepped = true;
             }
-            c = (int32_t)(int16_t)wt_inverse_select_from<false>(ix, (uint32_t)p, v, ihq, rank_before, exact);
-            bsl_p = v.bsl;
         }
-        bool suspect = false;
-        j = fm_lf_finish<false>(ix, inv, j, c, rank_before, bsl_p, exact, status, suspect);  // FM:532-535
+        if (kWin == kWinAlways && !stepped) {  // (unreachable: kWinAlways is instantiated for complete directories, and p < the
+                                               // bitmap's length == the tree's size on every image validate_blob lets through)
+            status = ST_JAVA_AIOOBE;
+            break;
+        }
+        if (!stepped) {
+            if (kWin != kWinAlways && !answered) {
+                const InvView v = wt_inv_view(ix, (uint32_t)p >> 20, inv);
+                Quad ihq = ld_quad(wt_inv_hdr_ptr(ix, v, (uint32_t)p));
+                if (!windows) scell = ld_quad(bv_cell_ptr(ix.base, sv, (uint32_t)p));
+                FMX_PIN_QUAD(ihq);
+                FMX_PIN_QUAD(scell);
+                if (!windows) {
+                    bool sampled_row;
+                    (void)bv_rank1_access_cell(sv, scell, p, sampled_row);
+                    if (sampled_row) break;
+                }
+                c = (int32_t)(int16_t)wt_inverse_select_from<false>(ix, (uint32_t)p, v, ihq, rank_before, exact);
+                bsl_p = v.bsl;
+            }
+            bool suspect = false;
+            j = fm_lf_finish<false>(ix, inv, j, c, rank_before, bsl_p, exact, status, suspect);  // FM:532-535
+        }
         ++distance;
         if (distance > walk_limit) {  // bounds the walk on a damaged index (see walk_limit above)
             status = ST_JAVA_AIOOBE;
@@ -1749,6 +1734,7 @@ FMX_HD void fm_flush_chars(uint16_t *group_at, uint64_t group, uint32_t mask) {
         if (mask & (1u << k)) group_at[k] = (uint16_t)(group >> (16u * k));
 }
 // FM:564-608.  Returns the reference's return value (0 when an exception status is set).
+template <int kWin = kWinAsk>
 FMX_HD int32_t fm_extract(const DevIndex &ix, const uint16_t *inv, int32_t start, int32_t stop, uint16_t *dest,
                           int32_t dst_len, int32_t offset, int32_t &steps, int &status) {
     steps = 0;
@@ -1785,7 +1771,7 @@ FMX_HD int32_t fm_extract(const DevIndex &ix, const uint16_t *inv, int32_t start
     uint16_t *group_at = dest;  // the group's first character
     while (remaining > 0) {  // FM:596-606
         int32_t c;
-        row = fm_lf_step<false>(ix, inv, row, c, status);
+        row = fm_lf_step<false, kWin>(ix, inv, row, c, status);
         ++steps;
         if (distance >= skip) {
             const int32_t idx = remaining - 1 + offset;

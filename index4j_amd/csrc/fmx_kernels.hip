@@ -337,9 +337,10 @@ __device__ __forceinline__ void count_one(const DevIndex &ix, const uint16_t *s_
             --back;
             break;
         }
-        // (the window directory is not asked here: a wave's lanes would split into those it answers and those that walk the tree,
-        // and the wave pays for both — measured round 5, profiles/r05_experiments.txt 8)
-        const int32_t mine = wt_rank_folded_choice(ix, s_inv, (uint32_t)(role ? end : start), c, status, false);  // C[c] + rank
+        // (the window directory — an LF directory: fmx_device.hpp — has nothing for a rank of a GIVEN symbol; a form of it that had
+        // was measured: a wave's lanes split into those it answers and those that walk the tree, and the wave pays for both —
+        // profiles/r05_experiments.txt 7)
+        const int32_t mine = wt_rank_folded(ix, s_inv, (uint32_t)(role ? end : start), c, status);  // C[c] + rank
         const int32_t other = __shfl_xor(mine, 1);
         start = role ? other : mine;  // FM:469
         end = role ? mine : other;    // FM:470
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(256) void k_win_build(DevIndex ix, uint32_t n_win, 
     }
 }
 __global__ __launch_bounds__(256) void k_win_other(DevIndex ix, uint32_t n_win, Quad *__restrict__ cells, const uint32_t *__restrict__ first,
-                                                   uint64_t *__restrict__ entries) {
+                                                   uint64_t *__restrict__ entries, uint32_t *__restrict__ open_entries) {
     for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < n_win; w += (uint64_t)gridDim.x * 256) {
         uint32_t words[16];
         for (int i = 0; i < 4; ++i) {
@@ -651,8 +652,9 @@ __global__ __launch_bounds__(256) void k_win_other(DevIndex ix, uint32_t n_win, 
             words[4 * i + 2] = q.z;
             words[4 * i + 3] = q.w;
         }
-        win_build_other(ix, (uint32_t)w, words, first[w], entries);
+        const uint32_t open = win_build_other(ix, (uint32_t)w, words, first[w], entries);
         cells[4 * w + 1].x = words[4];
+        if (open) atomicAdd(open_entries, open);  // (entries the tree walk must answer: nearly never any)
     }
 }
 static DevIndex win_plain_index(const DevIndex &ix) {
@@ -661,6 +663,7 @@ static DevIndex win_plain_index(const DevIndex &ix) {
     plain.suffix_table = nullptr;
     plain.win = nullptr;
     plain.win_other = nullptr;
+    plain.win_complete = 0;
     return plain;
 }
 static unsigned win_blocks(int n_cu, uint32_t n_win) {
@@ -673,16 +676,18 @@ int launch_win_build(const DevIndex &ix, int n_cu, uint32_t n_win, Quad *out, ui
     hipLaunchKernelGGL(k_win_build, dim3(win_blocks(n_cu, n_win)), dim3(256), 0, st, win_plain_index(ix), n_win, out, others);
     return (int)hipGetLastError();
 }
-int launch_win_other(const DevIndex &ix, int n_cu, uint32_t n_win, Quad *cells, const uint32_t *first, uint64_t *entries, hipStream_t st) {
+int launch_win_other(const DevIndex &ix, int n_cu, uint32_t n_win, Quad *cells, const uint32_t *first, uint64_t *entries,
+                     uint32_t *open_entries, hipStream_t st) {
     if (n_win == 0) return 0;
-    hipLaunchKernelGGL(k_win_other, dim3(win_blocks(n_cu, n_win)), dim3(256), 0, st, win_plain_index(ix), n_win, cells, first, entries);
+    hipLaunchKernelGGL(k_win_other, dim3(win_blocks(n_cu, n_win)), dim3(256), 0, st, win_plain_index(ix), n_win, cells, first, entries,
+                       open_entries);
     return (int)hipGetLastError();
 }
 
 // FM:526-548: hit k of pattern p is SA row i = start + 1 + k; walk LF until a sampled row.
 constexpr int kRedoHead = 4;   // ints in front of a redo list's entries ({count, 0, 0, 0}: 16 bytes)
 constexpr int kWalkLanes = 128;  // lanes of k_locate_walk per pattern (at most): two waves
-template <int kBlock>
+template <int kBlock, int kWin>
 FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix_global, const int32_t *__restrict__ range, int32_t n,
                                                         int32_t max_matches, int32_t *__restrict__ locs,
                                                         int32_t loc_cap, int32_t slots, int32_t *__restrict__ found,
@@ -743,7 +748,7 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix_global, const int32_t *__
         for (; k < located; k += step) {
             int status = ST_OK;
             int32_t distance;
-            const int32_t at = fm_locate_hit(ix, s_inv, start, k, distance, status);
+            const int32_t at = fm_locate_hit<kWin>(ix, s_inv, start, k, distance, status);
             if (set_locs)
                 set_locs[(int64_t)p * loc_cap + (taken ? taken[p] : 0) + k] = set_base + at;
             else
@@ -757,7 +762,7 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix_global, const int32_t *__
 // FM:564-608.  Pipeline form (slot_found != nullptr): query q is hit (q % slots) of pattern (q / slots) and
 // runs only if that hit exists; with stops == nullptr the stop position is min(inputLength, start + fixed_len)
 // (the reference's locateAndExtractBenchmark, FmIndexThroughputBenchmark.java:231-249).
-template <int kBlock>
+template <int kBlock, int kWin>
 FMX_EXTRACT_KERNEL(kBlock) void k_extract(DevIndex ix_global, const int32_t *__restrict__ starts, const int32_t *__restrict__ stops,
                                   int64_t n, uint16_t *__restrict__ dst, int32_t dst_len, int32_t offset,
                                   int32_t *__restrict__ out_len, int32_t *__restrict__ lf_steps,
@@ -781,7 +786,7 @@ FMX_EXTRACT_KERNEL(kBlock) void k_extract(DevIndex ix_global, const int32_t *__r
             const int64_t e = (int64_t)start + fixed_len;
             stop = e < ix.length ? (int32_t)e : ix.length;
         }
-        const int32_t ret = fm_extract(ix, s_inv, start, stop, dst + q * (int64_t)dst_len, dst_len, offset, steps, status);
+        const int32_t ret = fm_extract<kWin>(ix, s_inv, start, stop, dst + q * (int64_t)dst_len, dst_len, offset, steps, status);
         out_len[q] = status ? 0 : ret;
         if (lf_steps) lf_steps[q] = steps;
         if (status_out) status_out[q] = status;
@@ -1759,6 +1764,30 @@ static int grid_for(int64_t lanes, int block, int n_cu) {
             hipLaunchKernelGGL(KERNEL<512>, grid__, dim3(512), (size_t)g_lds_pad_kb * 1024, st, __VA_ARGS__);                          \
     } while (0)
 
+// ... of a walk kernel instantiated for indexes with a complete window directory, one with open entries, none (fmx_device.hpp: kWin)
+#define FMX_DISPATCH_WIN(KERNEL, IX, LANES, ...)                                                                       \
+    do {                                                                                                               \
+        const int blk__ = g_block;                                                                                     \
+        const dim3 grid__(grid_for((LANES), blk__, n_cu));                                                             \
+        const size_t lds__ = (size_t)g_lds_pad_kb * 1024;                                                              \
+        if ((IX).win && (IX).win_complete) {                                                                           \
+            if (blk__ == 1024)                                                                                         \
+                hipLaunchKernelGGL((KERNEL<1024, kWinAlways>), grid__, dim3(1024), lds__, st, __VA_ARGS__);           \
+            else                                                                                                       \
+                hipLaunchKernelGGL((KERNEL<512, kWinAlways>), grid__, dim3(512), lds__, st, __VA_ARGS__);             \
+        } else if ((IX).win) {                                                                                         \
+            if (blk__ == 1024)                                                                                         \
+                hipLaunchKernelGGL((KERNEL<1024, kWinAsk>), grid__, dim3(1024), lds__, st, __VA_ARGS__);              \
+            else                                                                                                       \
+                hipLaunchKernelGGL((KERNEL<512, kWinAsk>), grid__, dim3(512), lds__, st, __VA_ARGS__);                \
+        } else {                                                                                                       \
+            if (blk__ == 1024)                                                                                         \
+                hipLaunchKernelGGL((KERNEL<1024, kWinNever>), grid__, dim3(1024), lds__, st, __VA_ARGS__);            \
+            else                                                                                                       \
+                hipLaunchKernelGGL((KERNEL<512, kWinNever>), grid__, dim3(512), lds__, st, __VA_ARGS__);              \
+        }                                                                                                              \
+    } while (0)
+
 static SortShape sort_shape(const DevIndex &ix) {
     SortShape sh;
     sh.bits = 1;
@@ -1952,8 +1981,8 @@ int launch_locate_walk(const DevIndex &ix, int n_cu, const int32_t *range, int32
         order_idle = ticket + 1;
     }
     const int64_t tickets = (int64_t)n * (slots < kWalkLanes ? slots : kWalkLanes);
-    FMX_DISPATCH(k_locate_walk, tickets, ix, range, n, max_matches, locs, loc_cap,
-                 slots, found, lf, status, taken, order, order_idle, set_locs, set_base);
+    FMX_DISPATCH_WIN(k_locate_walk, ix, tickets, ix, range, n, max_matches, locs, loc_cap,
+                     slots, found, lf, status, taken, order, order_idle, set_locs, set_base);
     return (int)hipGetLastError();
 }
 
@@ -2066,7 +2095,7 @@ int launch_extract(const DevIndex &ix, int n_cu, const int32_t *start, const int
         if (int e = launch_position_order(ix, start, (int32_t)n, slot_found, slots, order_ws, head_is_zero, ordered, st)) return e;
         order = ordered;
     }
-    FMX_DISPATCH(k_extract, n, ix, start, stop, n, dst, dst_len, offset, out_len, lf, status, slot_found, slots, fixed_len, order);
+    FMX_DISPATCH_WIN(k_extract, ix, n, ix, start, stop, n, dst, dst_len, offset, out_len, lf, status, slot_found, slots, fixed_len, order);
     return (int)hipGetLastError();
 }
 

@@ -17,6 +17,7 @@ using namespace fmx;
 // window directories attached to blobs (sim_win_attach): what fmx_to_device grows beside a resident image
 static std::map<const uint8_t *, std::vector<uint32_t>> g_windows;
 static std::map<const uint8_t *, std::vector<uint64_t>> g_window_entries;
+static std::map<const uint8_t *, bool> g_window_complete;
 
 static DevIndex make_index(const uint8_t *b) {
     BlobHeader h;
@@ -52,6 +53,7 @@ static DevIndex make_index(const uint8_t *b) {
         d.win = it == g_windows.end() ? nullptr : reinterpret_cast<const Quad *>(it->second.data());
         auto e = g_window_entries.find(b);
         d.win_other = e == g_window_entries.end() ? nullptr : e->second.data();
+        d.win_complete = (d.win && g_window_complete[b]) ? 1 : 0;
     }
     d.self = nullptr;
     d.suffix_chars = 0;
@@ -78,7 +80,9 @@ int64_t sim_win_attach(const uint8_t *blob, int64_t *stats) {
         total += win_build_cell(ix, (uint32_t)w, words.data() + 16 * w);
     }
     std::vector<uint64_t> entries(total + 1);
-    for (size_t w = 0; w < cells; ++w) win_build_other(ix, (uint32_t)w, words.data() + 16 * w, first[w], entries.data());
+    uint64_t open_entries = 0;
+    for (size_t w = 0; w < cells; ++w) open_entries += win_build_other(ix, (uint32_t)w, words.data() + 16 * w, first[w], entries.data());
+    g_window_complete[blob] = open_entries == 0;
     if (stats) {
         stats[0] = stats[1] = stats[2] = stats[3] = 0;
         for (size_t w = 0; w < cells; ++w) {
@@ -106,6 +110,7 @@ int64_t sim_win_attach(const uint8_t *blob, int64_t *stats) {
 void sim_win_detach(const uint8_t *blob) {
     g_windows.erase(blob);
     g_window_entries.erase(blob);
+    g_window_complete.erase(blob);
 }
 
 int32_t sim_wt_rank(const uint8_t *blob, uint32_t position, int32_t symbol, int32_t *status) {
@@ -281,7 +286,9 @@ void sim_locate_walk(const uint8_t *blob, const int32_t *range, int32_t n, int32
             if (k >= located) continue;
             int status = ST_OK;
             int32_t distance;
-            locs[(int64_t)p * loc_cap + k] = fm_locate_hit(ix, ix.inv_global, start, k, distance, status);
+            locs[(int64_t)p * loc_cap + k] = ix.win_complete ? fm_locate_hit<kWinAlways>(ix, ix.inv_global, start, k, distance, status)  // (as launch_locate_walk picks)
+                                             : ix.win        ? fm_locate_hit<kWinAsk>(ix, ix.inv_global, start, k, distance, status)
+                                                             : fm_locate_hit<kWinNever>(ix, ix.inv_global, start, k, distance, status);
             if (lf) lf[p] += distance;
             if (status && status_out) status_out[p] |= status;
         }
@@ -293,8 +300,10 @@ void sim_extract(const uint8_t *blob, const int32_t *starts, const int32_t *stop
     for (int32_t q = 0; q < n; ++q) {
         int status = ST_OK;
         int32_t steps;
-        const int32_t ret = fm_extract(ix, ix.inv_global, starts[q], stops[q], dst + (int64_t)q * dst_len, dst_len,
-                                       offset, steps, status);
+        uint16_t *row = dst + (int64_t)q * dst_len;
+        const int32_t ret = ix.win_complete ? fm_extract<kWinAlways>(ix, ix.inv_global, starts[q], stops[q], row, dst_len, offset, steps, status)  // (as launch_extract picks)
+                            : ix.win        ? fm_extract<kWinAsk>(ix, ix.inv_global, starts[q], stops[q], row, dst_len, offset, steps, status)
+                                            : fm_extract<kWinNever>(ix, ix.inv_global, starts[q], stops[q], row, dst_len, offset, steps, status);
         out_len[q] = status ? 0 : ret;
         if (lf) lf[q] = steps;
         if (status_out) status_out[q] = status;

@@ -1,6 +1,7 @@
 """The window directory (index4j_amd/csrc/fmx_device.hpp "window directory": what fmx_to_device grows beside a resident image)
-on the host simulation: the cells are made by the very function k_win_build runs (win_build_cell) and every query kind of the
-simulation then takes them first, as the kernels do — results, statuses and LF-step counts must still equal the oracle's, on
+on the host simulation: the cells and entries are made by the very functions k_win_build / k_win_other run (win_build_cell,
+win_build_other) and the LF-walks of the simulation then take their steps from them, as the kernels do (the instantiation the
+launchers pick: kWinAlways over a complete directory, kWinAsk over one that left entries to the tree walk) — results, statuses and LF-step counts must still equal the oracle's, on
 the reference's fixture and on the quirk-heavy inputs of the other parity tests.  CPU only; the GPU suite runs the same
 checks on resident indexes (tests/test_gpu_parity.py with the library's default option window_cells = 2)."""
 import random
@@ -76,7 +77,7 @@ def test_rank_and_inverse_select_at_every_kind_of_block():
         c, r = h.wt_inverse_select(pos)
         t = orc.lib().orc_wfbb_inverse_select(wh, pos)
         assert c == (t & 0xFFFF) and (pos == 0 or r == (t >> 32))
-    for row in range(1, L + 1, 11):  # the fused LF-step beside the reference's two calls (tests/test_fused_lf.py)
+    for row in range(1, L + 1):  # EVERY step through the directory beside the reference's two calls (tests/test_fused_lf.py)
         out = h.lf_step_both(row)
         assert (out[0], out[1], out[4]) == (out[2], out[3], out[5]), row
 
