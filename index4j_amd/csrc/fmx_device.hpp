@@ -1288,6 +1288,7 @@ struct LfChain {
     int32_t c;     // out: the symbol
     bool on;
 };
+template <int kWin = kWinAsk>
 FMX_HD void fm_lf_step2(const DevIndex &ix, const uint16_t *inv, LfChain &a, LfChain &b, int &status, bool &suspect) {
     // per chain: p = row - 1, the block's view and InvHdr
     const uint32_t pa = (uint32_t)(a.row - 1), pb = (uint32_t)(b.row - 1);
@@ -1305,7 +1306,7 @@ FMX_HD void fm_lf_step2(const DevIndex &ix, const uint16_t *inv, LfChain &a, LfC
         lb = false;
     }
     if (!la && !lb) return;
-    if (ix.win) {  // the windows of both positions first (one sector each, requested together), then the entries of class-3
+    if (kWin == kWinAlways || (kWin == kWinAsk && ix.win)) {  // the windows of both positions first (one sector each, requested together), then the entries of class-3
                    // positions (together as well); a chain they answer is done
         uint32_t ra = 0, rb = 0, oa = 0, ob = 0;
         const WinCell wca = win_load(ix, la ? pa : 0u, ra), wcb = win_load(ix, lb ? pb : 0u, rb);
@@ -1329,6 +1330,12 @@ FMX_HD void fm_lf_step2(const DevIndex &ix, const uint16_t *inv, LfChain &a, LfC
             lb = false;
         }
         if (!la && !lb) return;
+        if (kWin == kWinAlways) {  // (unreachable: kWinAlways is instantiated for complete directories only)
+            status = ST_JAVA_AIOOBE;
+            if (la) a.row = 0, a.c = 0;
+            if (lb) b.row = 0, b.c = 0;
+            return;
+        }
     }
     const InvView va = wt_inv_view(ix, la ? pa >> 20 : 0u, inv), vb = wt_inv_view(ix, lb ? pb >> 20 : 0u, inv);
     Quad iha = {0, 0, 0, 0}, ihb = {0, 0, 0, 0};
@@ -1900,6 +1907,7 @@ FMX_HD void marks_note(IntervalMarks &m, int32_t offset, int32_t c, int32_t mapp
     if (c == mapped_boundary) m.boundary |= bit;
     if (c == 0) m.zero |= bit;
 }
+template <int kWin = kWinAsk>
 FMX_HD bool fm_fetch_interval(const DevIndex &ix, const uint16_t *inv, int32_t k, uint16_t *buf, int64_t stride,
                               int32_t &steps, int &status, IntervalMarks *marks = nullptr, int32_t mapped_boundary = -1) {
     const int32_t s = ix.sample_rate;
@@ -1909,7 +1917,7 @@ FMX_HD bool fm_fetch_interval(const DevIndex &ix, const uint16_t *inv, int32_t k
     bool suspect = false;
     for (int32_t pos = top - 1; pos >= k * s; --pos) {
         int32_t c;
-        row = fm_lf_step(ix, inv, row, c, status, suspect);
+        row = fm_lf_step<true, kWin>(ix, inv, row, c, status, suspect);
         ++steps;
         buf[(pos - k * s) * stride] = (uint16_t)c;
         if (marks) marks_note(*marks, pos - k * s, (int32_t)(uint16_t)c, mapped_boundary);
@@ -1918,6 +1926,7 @@ FMX_HD bool fm_fetch_interval(const DevIndex &ix, const uint16_t *inv, int32_t k
 }
 
 // two intervals with the two walks interleaved (fm_lf_step2): ka / kb < 0 = nothing to fetch on that side
+template <int kWin = kWinAsk>
 FMX_HD bool fm_fetch_interval2(const DevIndex &ix, const uint16_t *inv, int32_t ka, uint16_t *bufa, int32_t kb, uint16_t *bufb,
                                int64_t stride, int32_t &steps_a, int32_t &steps_b, int &status, IntervalMarks *marks_a = nullptr,
                                IntervalMarks *marks_b = nullptr, int32_t mapped_boundary = -1) {
@@ -1939,7 +1948,7 @@ FMX_HD bool fm_fetch_interval2(const DevIndex &ix, const uint16_t *inv, int32_t 
     for (int32_t i = 0; i < n; ++i) {  // step i writes offset n_x - 1 - i of its interval
         a.on = i < na;
         b.on = i < nb;
-        fm_lf_step2(ix, inv, a, b, status, suspect);
+        fm_lf_step2<kWin>(ix, inv, a, b, status, suspect);
         if (a.on) bufa[(int64_t)(na - 1 - i) * stride] = (uint16_t)a.c;
         if (b.on) bufb[(int64_t)(nb - 1 - i) * stride] = (uint16_t)b.c;
         if (marks_a && a.on) marks_note(*marks_a, na - 1 - i, (int32_t)(uint16_t)a.c, mapped_boundary);
@@ -2172,7 +2181,7 @@ FMX_HD uint16_t *window_slot(const TextWindow<G> &w, int32_t k) {
 // make interval k resident.  Adjacent to a window that still has free slots: the window grows towards k by as many
 // intervals as it has free slots (what it holds — the interval of `from` above all — stays).  Otherwise the window is
 // replaced; dir > 0: [k, k+G), dir < 0: [k-G+1, k].  Every lane that fetches walks ONE interval.
-template <int G>
+template <int G, int kWin = kWinAsk>
 FMX_HD void window_refill(const DevIndex &ix, const uint16_t *inv, TextWindow<G> &w, int32_t k, int dir) {
     const int32_t k_max = (ix.length - 1) / w.s;  // last interval that holds text (incl. the sentinel)
     int32_t mine = -1;
@@ -2198,7 +2207,7 @@ FMX_HD void window_refill(const DevIndex &ix, const uint16_t *inv, TextWindow<G>
     bool ok = true;
     if (mine >= 0 && mine <= k_max) {
         int status = ST_OK;
-        ok = fm_fetch_interval(ix, inv, mine, window_slot<G>(w, mine), w.row_stride, w.steps, status,
+        ok = fm_fetch_interval<kWin>(ix, inv, mine, window_slot<G>(w, mine), w.row_stride, w.steps, status,
                                mine == w.marks_k ? &w.marks : nullptr, w.mapped_boundary);
     }
     if (group_any<G>(!ok)) w.suspect = true;
@@ -2206,7 +2215,7 @@ FMX_HD void window_refill(const DevIndex &ix, const uint16_t *inv, TextWindow<G>
 
 // The default first fill — G intervals on each side — with every lane's two walks interleaved (fm_fetch_interval2): what
 // window_refill(wl, k0, -1) followed by window_refill(wr, k0 + 1, +1) would fetch, in half the round trips.
-template <int G>
+template <int G, int kWin = kWinAsk>
 FMX_HD void window_fill_pairs(const DevIndex &ix, const uint16_t *inv, TextWindow<G> &wl, TextWindow<G> &wr, int32_t k0,
                               bool want_right) {
     const int32_t k_max = (ix.length - 1) / wl.s;
@@ -2226,7 +2235,7 @@ FMX_HD void window_fill_pairs(const DevIndex &ix, const uint16_t *inv, TextWindo
     wl.marks_k = mine_l;
     wr.marks_k = mine_r;
     wl.marks.boundary = wl.marks.zero = wr.marks.boundary = wr.marks.zero = 0;
-    const bool ok = fm_fetch_interval2(ix, inv, mine_l, window_slot<G>(wl, mine_l < 0 ? 0 : mine_l), mine_r,
+    const bool ok = fm_fetch_interval2<kWin>(ix, inv, mine_l, window_slot<G>(wl, mine_l < 0 ? 0 : mine_l), mine_r,
                                        window_slot<G>(wr, mine_r < 0 ? 0 : mine_r), wl.row_stride, wl.steps, wr.steps, status,
                                        &wl.marks, &wr.marks, wl.mapped_boundary);
     if (group_any<G>(!ok)) {
@@ -2235,10 +2244,10 @@ FMX_HD void window_fill_pairs(const DevIndex &ix, const uint16_t *inv, TextWindo
     }
 }
 
-template <int G>
+template <int G, int kWin = kWinAsk>
 FMX_HD int32_t window_code_at(const DevIndex &ix, const uint16_t *inv, TextWindow<G> &w, int32_t pos, int dir) {
     const int32_t k = pos / w.s;
-    if (w.k_lo < 0 || k < w.k_lo || k >= w.k_lo + w.n) window_refill<G>(ix, inv, w, k, dir);
+    if (w.k_lo < 0 || k < w.k_lo || k >= w.k_lo + w.n) window_refill<G, kWin>(ix, inv, w, k, dir);
     return window_slot<G>(w, k)[(int64_t)(pos - k * w.s) * w.row_stride];
 }
 
@@ -2345,7 +2354,7 @@ FMX_HD bool fm_boundary_replay_marked(const DevIndex &ix, int mode, const TextWi
 // Both windows are fetched up front, at ONE program point, so that all lanes of a wave walk their intervals
 // together; later refills (lines longer than a window) happen wherever the replay needs them.
 // kMode >= 0: the mode as a compile-time constant (the kernels: one instance per mode, each without the other two's code)
-template <int G, int kMode = -1>
+template <int G, int kMode = -1, int kWin = kWinAsk>
 FMX_HD int32_t fm_extract_boundary_group(const DevIndex &ix, const uint16_t *inv, int mode, int32_t from,
                                          int32_t mapped_boundary, uint16_t *dest, int32_t dst_len, int32_t offset,
                                          int32_t &steps, int &status, int32_t &aux, uint16_t *buf, int64_t row_stride,
@@ -2382,10 +2391,10 @@ FMX_HD int32_t fm_extract_boundary_group(const DevIndex &ix, const uint16_t *inv
     TextWindow<G> wl = {buf, row_stride, slot_stride, s, -1, 0, g, 0, false, mapped_boundary, -1, {0, 0}};               // intervals <= k0
     TextWindow<G> wr = {buf + win_stride, row_stride, slot_stride, s, -1, 0, g, 0, false, mapped_boundary, -1, {0, 0}};  // intervals > k0
     if (pair_walks) {
-        window_fill_pairs<G>(ix, inv, wl, wr, k0, mode != 1);       // the same two windows, a lane's two walks interleaved
+        window_fill_pairs<G, kWin>(ix, inv, wl, wr, k0, mode != 1);       // the same two windows, a lane's two walks interleaved
     } else {
-        window_refill<G>(ix, inv, wl, k0, -1);                      // [k0-G+1, k0]: the left part and text[from..]
-        if (mode != 1) window_refill<G>(ix, inv, wr, k0 + 1, +1);   // [k0+1, k0+G]
+        window_refill<G, kWin>(ix, inv, wl, k0, -1);                      // [k0-G+1, k0]: the left part and text[from..]
+        if (mode != 1) window_refill<G, kWin>(ix, inv, wr, k0 + 1, +1);   // [k0+1, k0+G]
     }
     int32_t ret = 0;
     if (s <= 64 && !wl.suspect && !wr.suspect &&
@@ -2399,7 +2408,7 @@ FMX_HD int32_t fm_extract_boundary_group(const DevIndex &ix, const uint16_t *inv
         int32_t down_pos = dst_len - 1;
         int32_t remaining = dst_len;
         for (int32_t pos = from - 1; mode == 1 || remaining > 0; --pos) {
-            const int32_t c = pos < 0 ? 0 : window_code_at<G>(ix, inv, wl, pos, -1);  // before text[0] the walk meets the sentinel
+            const int32_t c = pos < 0 ? 0 : window_code_at<G, kWin>(ix, inv, wl, pos, -1);  // before text[0] the walk meets the sentinel
             if (wl.suspect) break;
             if (c == mapped_boundary || c == 0) break;  // FM:674-680
             if (down_pos < 0) {                          // destination[-1]
@@ -2449,7 +2458,7 @@ FMX_HD int32_t fm_extract_boundary_group(const DevIndex &ix, const uint16_t *inv
             int32_t c4[4] = {0, 0, 0, 0};
             for (int32_t i = 0; i < remaining; ++i) {
                 const int32_t pos = prev_from + i;
-                c4[i] = (pos / s <= k0) ? window_code_at<G>(ix, inv, wl, pos, +1) : window_code_at<G>(ix, inv, wr, pos, +1);
+                c4[i] = (pos / s <= k0) ? window_code_at<G, kWin>(ix, inv, wl, pos, +1) : window_code_at<G, kWin>(ix, inv, wr, pos, +1);
             }
             if (wl.suspect || wr.suspect) break;
             for (int32_t i = remaining - 1; i >= 0 && !r.done; --i) {  // the reference emits from-1 first

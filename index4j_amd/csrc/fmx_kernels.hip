@@ -835,7 +835,7 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary(DevIndex ix_global, const in
 // kMode: the mode (0 / 1 / 2) as a compile-time constant — each instance carries one mode's replay.  A query whose walks met a
 // quirk path (`clean` false) is not answered here: its index goes onto the `redo` list ({count, 0, 0, 0, queries...}), which a
 // launch of the literal k_extract_boundary behind this kernel works off — the literal form is not part of this kernel's body.
-template <int kBlock, int G, int kMode>
+template <int kBlock, int G, int kMode, int kWin>
 FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix_global, const int32_t *__restrict__ froms, int64_t n,
                                                  uint16_t boundary, uint16_t *__restrict__ dst,
                                                  int32_t dst_len, int32_t offset, int32_t *__restrict__ out_len,
@@ -859,7 +859,7 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix_global, co
         int32_t steps, aux;
         bool clean;
         uint16_t *dest = dst + q * (int64_t)dst_len;
-        const int32_t ret = fm_extract_boundary_group<G, kMode>(ix, s_inv, kMode, froms[q], mapped_boundary, dest, dst_len, offset, steps,
+        const int32_t ret = fm_extract_boundary_group<G, kMode, kWin>(ix, s_inv, kMode, froms[q], mapped_boundary, dest, dst_len, offset, steps,
                                                                 status, aux, scratch + (lane - g), lanes, 1, lanes * (int64_t)ix.sample_rate, g,
                                                                 clean, pair_walks != 0);
         if (g == 0) {
@@ -2161,8 +2161,11 @@ int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, i
     int32_t *redo = (scratch && G > 0) ? reinterpret_cast<int32_t *>(static_cast<uint8_t *>(workspace) + ((windows_bytes + 15) & ~(size_t)15)) : nullptr;
     if (redo)
         if (hipError_t e = hipMemsetAsync(redo, 0, kRedoHead * sizeof(int32_t), st); e != hipSuccess) return (int)e;
-#define FMX_LAUNCH_GROUP_MODE(BLK, GG, MODE)                                                                              \
-    hipLaunchKernelGGL((k_extract_boundary_group<BLK, GG, MODE>), grid, dim3(BLK), 0, st, ix, from, n, boundary, dst, dst_len, \
+    // (kWinAsk: this kernel looks at ix.win itself.  An instantiation without the tree walk — kWinAlways, as k_locate_walk and
+    // k_extract have — was measured SLOWER here: 94 instead of 112 VGPRs, five waves per SIMD instead of four, 20 bytes of scratch
+    // in the walk's loop: 0.98 vs 0.78 ms on configs[3], round 5)
+#define FMX_LAUNCH_GROUP_MODE(BLK, GG, MODE)                                                                             \
+    hipLaunchKernelGGL((k_extract_boundary_group<BLK, GG, MODE, kWinAsk>), grid, dim3(BLK), 0, st, ix, from, n, boundary, dst, dst_len, \
                        offset, out_len, lf, status, aux, scratch, slot_found, slots, pair_walks, order, redo)
 #define FMX_LAUNCH_GROUP(GG)                                                                                            \
     do {                                                                                                                \

@@ -322,9 +322,14 @@ void sim_extract_boundary(const uint8_t *blob, const int32_t *froms, int32_t n, 
         int32_t ret;
         if (accelerate >= 2) {  // group-cooperative form with a group of one lane (3: the lane's two first walks interleaved)
             bool clean;
-            ret = fm_extract_boundary_group<1>(ix, ix.inv_global, mode, froms[q], mapped_boundary, dst + (int64_t)q * dst_len,
-                                               dst_len, offset, steps, status, aux, scratch, 1, 1, ix.sample_rate + 1, 0, clean,
-                                               accelerate == 3);
+            // (over a complete window directory: the instantiation without tree-walk code, as launch_extract_boundary picks)
+            ret = ix.win_complete
+                      ? fm_extract_boundary_group<1, -1, kWinAlways>(ix, ix.inv_global, mode, froms[q], mapped_boundary, dst + (int64_t)q * dst_len,
+                                                                     dst_len, offset, steps, status, aux, scratch, 1, 1, ix.sample_rate + 1, 0,
+                                                                     clean, accelerate == 3)
+                      : fm_extract_boundary_group<1>(ix, ix.inv_global, mode, froms[q], mapped_boundary, dst + (int64_t)q * dst_len,
+                                                     dst_len, offset, steps, status, aux, scratch, 1, 1, ix.sample_rate + 1, 0, clean,
+                                                     accelerate == 3);
             if (!clean) {
                 status = ST_OK;
                 ret = fm_extract_boundary(ix, ix.inv_global, mode, froms[q], mapped_boundary, dst + (int64_t)q * dst_len,
