@@ -280,7 +280,7 @@ def compact_line(out):
         c["roofline"].update(_pick(r, ("kernel_ms", "alg_bytes_executed_per_launch", "alg_bytes_per_lf_step",
                                        "lf_steps_executed_per_launch", "frac_whole_step", "traffic_frac", "frac_algorithmic", "step_ms_incl_plan",
                                        "fabric_line_fills_per_lf_step_executed", "resident_bytes_per_text_byte",
-                                       "stage_ms_this_rank")) or {})
+                                       "resident_bytes_count_path_per_text_byte", "stage_ms_this_rank")) or {})
         c["roofline"]["kernel"] = _short(r.get("kernel"), 60)
         if r.get("plan_stage") is not None:
             c["roofline"]["plan_stage"] = r["plan_stage"]
@@ -768,7 +768,10 @@ def run_count(ctx, args):
                 "l1_line_accesses_per_lf_step_note": "per EXECUTED LF-step of a launch",
                 "image_bytes": image_bytes, "image_bytes_per_text_byte": image_bytes / float(1 << args.text_log2),
                 "suffix_table_bytes": table_bytes, "window_directory_bytes": window_bytes,
+                # everything resident; the window directory serves the LF-walks only — count(), this line's workload, reads the image
+                # and the suffix table (resident_bytes_count_path_per_text_byte)
                 "resident_bytes_per_text_byte": (image_bytes + table_bytes + window_bytes) / float(1 << args.text_log2),
+                "resident_bytes_count_path_per_text_byte": (image_bytes + table_bytes) / float(1 << args.text_log2),
                 "frac_reference_equivalent": alg_bytes_reference / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs}
         ref_series_module().settle_frac(roof, kernel_ms, traffic, ratio_rule=False)

@@ -114,6 +114,7 @@ struct fmx_index {
     void *d_win = nullptr;              // DevIndex.win: the window directory's cells (owned likewise)
     void *d_win_other = nullptr;        // DevIndex.win_other: ... and the entries of the positions no class holds
     size_t win_bytes = 0;               // both together
+    uint32_t win_unclean = 0;           // entries that carry a status or `suspect` (statistics)
     size_t suffix_table_bytes = 0;
     uint32_t suffix_table_strings = 0;  // strings (of 2 .. suffix_chars codes) the table holds
     uint32_t suffix_table_deepest = 0;  // ... of which strings of suffix_chars codes: what a batch's patterns spread over after the lookup
@@ -244,7 +245,6 @@ void make_dev_index(fmx_index *idx) {
     d.suffix_order1 = nullptr;
     d.win = nullptr;
     d.win_other = nullptr;
-    d.win_complete = 0;
     d.sb_cache = nullptr;
     d.sb_cache_limit = g_sb_cache_limit;
     d.wt_size = (uint32_t)h.wt_size;
@@ -262,7 +262,6 @@ int publish_dev_index(fmx_index *idx) {
     copy.suffix_order1 = nullptr;
     copy.win = nullptr;  // (a cold route is the tree walk itself; the directory is grown from its answers)
     copy.win_other = nullptr;
-    copy.win_complete = 0;
     HIP_TRY(hipMemcpy(idx->d_self, &copy, sizeof(copy), hipMemcpyHostToDevice));
     idx->dev.self = copy.self;
     return FMX_OK;
@@ -859,7 +858,6 @@ static void build_window_cells(fmx_index *idx) {
     idx->win_bytes = 0;
     idx->dev.win = nullptr;
     idx->dev.win_other = nullptr;
-    idx->dev.win_complete = 0;
     const int mode = g_window_cells.load();
     if (mode == 0 || idx->rrr_only || idx->wavelet_only || idx->hdr.kind != 0 || idx->hdr.wt_size <= 0 || !idx->dev.self) return;
     const size_t cells = fmx::win_cells_for((uint32_t)idx->hdr.wt_size);
@@ -897,7 +895,7 @@ static void build_window_cells(fmx_index *idx) {
         total += c;
     }
     if (total > 0xffffffffull) return give_up();
-    // (the entries, and behind them the counter of entries left to the tree walk)
+    // (the entries, and behind them the counter of entries that carry a status or `suspect`: statistics)
     uint32_t open_entries = 0;
     if (hipMalloc(&d_entries, (size_t)(total + 1) * sizeof(uint64_t)) != hipSuccess ||
         hipMemset(static_cast<uint64_t *>(d_entries) + total, 0, sizeof(uint64_t)) != hipSuccess ||
@@ -908,7 +906,7 @@ static void build_window_cells(fmx_index *idx) {
         hipMemcpy(&open_entries, static_cast<uint64_t *>(d_entries) + total, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
         return give_up();
     (void)hipFree(d_counts);
-    idx->dev.win_complete = open_entries == 0 ? 1 : 0;
+    idx->win_unclean = open_entries;
     idx->d_win = d_cells;
     idx->d_win_other = d_entries;
     idx->win_bytes = bytes + (size_t)total * sizeof(uint64_t);

@@ -93,7 +93,6 @@ struct DevIndex {
     // path above.  Results never depend on it: every count in it was checked against rank() when it was grown.
     const struct Quad *win;
     const uint64_t *win_other;  // the entries of the positions no class of their window holds (nullptr iff win is)
-    int32_t win_complete;       // 1: every position's step is in the directory (no entry without kWinOtherValid)
     // this index's DevIndex as the API layer keeps it in HBM (no LDS cache, no launch option applied): what a cold route reads
     const DevIndex *self;
 };
@@ -652,18 +651,18 @@ FMX_HD int32_t fm_c_or_zero(const DevIndex &ix, int32_t symbol) {
 //   words 5..15  three bit planes of 112 bits each, from bit 16 of word 5 on, back to back: plane 0 / 1 = low / high bit of the
 //                position's class (3 = "none of the three"), plane 2 = the position's bit in sampledSuffixes (FM:123: what
 //                locate polls before every step, FM:531)
-// and one 8-byte entry {folded rank before the position, symbol | flags << 16} in win_other per position of class 3, in position
-// order.  The step from row p + 1: a class position -> {symbol, count + the class's positions before p + 1}: ONE sector; class 3
-// -> the entry (index = the cell's first + the class-3 positions before p): a second, dependent load; an entry without
-// kWinOtherValid -> the tree walk.  The classes are the window's three most frequent symbols (~80 % of the positions of log text).
+// and one 8-byte entry in win_other per position of class 3, in position order: {the row the step arrives at, symbol, status,
+// suspect} — everything fm_lf_step hands back for that row.  The step from row p + 1: a class position -> {symbol, count + the
+// class's positions before p + 1}: ONE sector; class 3 -> the entry (index = the cell's first + the class-3 positions before p):
+// a second, dependent load.  No tree walk either way.  The classes are the window's three most frequent symbols among the
+// positions whose step is CLEAN (no status, no `suspect`, a symbol the int16 cast of FM:532 leaves alone): ~80 % of the
+// positions of log text.
 // Every step in the directory is the one fm_lf_step took over the tree — all of the reference's routes and quirks — when the
-// directory was grown, with no status and no `suspect` (win_build_cell, win_build_other); a step that raises either (a masked run
-// block Q1, a next-block path Q2 / Q11, a symbol the int16 cast of FM:532 changes) is left to the tree walk: results never depend
-// on the directory.  DevIndex.win_complete says that no entry was left open: walks over such an index (nearly every index)
-// carry no tree-walk code at all (kWinAlways below).
+// directory was grown (win_build_cell, win_build_other): a class position's step must have arrived where the count says, and an
+// entry simply IS the function's answer for its row, status and `suspect` included (a masked run block Q1, a next-block path
+// Q2 / Q11, ...): results never depend on the directory, and a walk over an index that has one needs no tree-walk code at all.
 constexpr uint32_t kWinW = 112;
 constexpr uint32_t kWinNone = 0xffffu;
-constexpr uint32_t kWinOtherValid = 0x10000u;
 struct WinCell {
     Quad q0, q1, q2, q3;
 };
@@ -703,10 +702,10 @@ FMX_HD int32_t win_class_before(const WinPlanes &p, uint32_t k, uint32_t r) {
     const uint64_t k_lo = r_lo >= 64u ? ~0ull : ((1ull << r_lo) - 1ull);
     return fmx_popcll(m_lo & k_lo) + fmx_popcll(m_hi & ((1ull << r_hi) - 1ull));
 }
-// The step from row position + 1 (position < wt_size) out of its window: true = {symbol, C[symbol] + rank before the position}
-// — the row the step arrives at is one more —; false = the position is of class 3 and other_out is the index of its entry.  sampled_out = the position's bit in sampledSuffixes either way
-// (positions beyond that vector: 0 — callers check the range first, as FM:531 would throw)
-FMX_HD bool win_inv_from(const WinCell &c, uint32_t r, int32_t &symbol_out, int32_t &rank_out, bool &sampled_out, uint32_t &other_out) {
+// The step from row position + 1 (position < wt_size) out of its window: true = {symbol, the row the step arrives at}; false =
+// the position is of class 3 and other_out is the index of its entry.  sampled_out = the position's bit in sampledSuffixes
+// either way (positions beyond that vector: 0 — callers check the range first, as FM:531 would throw)
+FMX_HD bool win_inv_from(const WinCell &c, uint32_t r, int32_t &symbol_out, int32_t &row_out, bool &sampled_out, uint32_t &other_out) {
     const WinPlanes p = win_planes(c);
     const uint32_t sh = r & 63u;
     const uint32_t b0 = (uint32_t)((r < 64u ? p.a_lo : p.a_hi) >> sh) & 1u, b1 = (uint32_t)((r < 64u ? p.b_lo : p.b_hi) >> sh) & 1u;
@@ -721,15 +720,21 @@ FMX_HD bool win_inv_from(const WinCell &c, uint32_t r, int32_t &symbol_out, int3
         return false;
     }
     symbol_out = (int32_t)(k == 0u ? (c.q0.w & 0xffffu) : (k == 1u ? (c.q0.w >> 16) : (c.q1.y & 0xffffu)));
-    rank_out = (int32_t)(k == 0u ? c.q0.x : (k == 1u ? c.q0.y : c.q0.z)) + before;
+    row_out = (int32_t)(k == 0u ? c.q0.x : (k == 1u ? c.q0.y : c.q0.z)) + before + 1;
     return true;
 }
-// the entry of a class-3 position: true = {symbol, C[symbol] + rank before the position} (false: the tree walk must answer)
-FMX_HD bool win_other_from(uint64_t entry, int32_t &symbol_out, int32_t &rank_out) {
-    const uint32_t hi = (uint32_t)(entry >> 32);
-    symbol_out = (int32_t)(hi & 0xffffu);
-    rank_out = (int32_t)(uint32_t)entry;
-    return (hi & kWinOtherValid) != 0;
+// the entry of a class-3 position = what fm_lf_step hands back for its row: the row it arrives at in the low word, then the symbol
+// (16 bits, the int16 of FM:532), the status (8 bits) and `suspect` (1 bit)
+FMX_HD uint64_t win_other_make(int32_t row, int32_t c, int status, bool suspect) {
+    return (uint64_t)(uint32_t)row | ((uint64_t)((uint32_t)c & 0xffffu) << 32) | ((uint64_t)((uint32_t)status & 0xffu) << 48) |
+           ((uint64_t)(suspect ? 1u : 0u) << 56);
+}
+FMX_HD void win_other_from(uint64_t entry, int32_t &symbol_out, int32_t &row_out, int &status, bool &suspect) {
+    symbol_out = (int32_t)(int16_t)(uint16_t)(entry >> 32);
+    row_out = (int32_t)(uint32_t)entry;
+    const int st = (int)((entry >> 48) & 0xffu);
+    if (st) status = st;
+    if ((entry >> 56) & 1u) suspect = true;
 }
 FMX_HD uint64_t win_other_load(const DevIndex &ix, uint32_t index) {
     uint64_t v;
@@ -1234,10 +1239,9 @@ FMX_HD int32_t fm_lf_finish(const DevIndex &ix, const uint16_t *inv, int32_t row
     return wt_rank_folded_t<false>(ix, inv, (uint32_t)row, c, status, suspect);
 }
 // kWin — what a walk's code knows about the window directory at COMPILE time: kWinAsk = look at ix.win (both routes in the body:
-// the boundary kernels, the host simulation, an index whose directory left entries open), kWinNever = an index without one (the
-// tree walk alone: the kernels' bodies of round 4), kWinAlways = an index with a COMPLETE one (DevIndex.win_complete): window
-// cell / entry and nothing else — no tree walk, no call, none of their registers (k_locate_walk / k_extract are instantiated for
-// all three and the launcher picks).
+// the boundary kernels, the host simulation's default), kWinNever = an index without one (the tree walk alone: the kernels'
+// bodies of round 4), kWinAlways = an index with one: window cell / entry and nothing else — no tree walk, no call, none of
+// their registers (k_locate_walk / k_extract are instantiated for kWinNever and kWinAlways and the launcher picks by ix.win).
 enum : int { kWinAsk = 0, kWinNever = 1, kWinAlways = 2 };
 template <bool kCold = true, int kWin = kWinAsk>
 FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, int32_t &c_out, int &status,
@@ -1252,22 +1256,14 @@ FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, 
     int32_t bsl_i;
     bool exact_symbol;
     if (kWin == kWinAlways || (kWin == kWinAsk && ix.win)) {
-        // the window of p: {symbol, rank} from one sector, or from the position's entry behind it — no tree walk
+        // the window of p: {symbol, next row} from one sector, or from the position's entry behind it — no tree walk
         uint32_t r, other = 0;
         const WinCell cell = win_load(ix, p, r);
-        int32_t wc = 0;
+        int32_t wc = 0, next = 0;
         bool sampled;
-        bool have = win_inv_from(cell, r, wc, rank_before, sampled, other);
-        if (!have) have = win_other_from(win_other_load(ix, other), wc, rank_before);
-        if (have) {
-            c_out = wc;
-            return rank_before + 1;  // (the step fm_lf_step took over the tree when the directory was grown)
-        }
-        if (kWin == kWinAlways) {  // (unreachable: the launcher instantiates kWinAlways for complete directories only)
-            status = ST_JAVA_AIOOBE;
-            c_out = 0;
-            return 0;
-        }
+        if (!win_inv_from(cell, r, wc, next, sampled, other)) win_other_from(win_other_load(ix, other), wc, next, status, suspect);
+        c_out = wc;
+        return next;
     }
     const int32_t c = (int32_t)(int16_t)wt_inverse_select_folded<kCold>(ix, inv, p, rank_before, bsl_i, exact_symbol);  // C[c] + rank
     c_out = c;
@@ -1310,32 +1306,24 @@ FMX_HD void fm_lf_step2(const DevIndex &ix, const uint16_t *inv, LfChain &a, LfC
                    // positions (together as well); a chain they answer is done
         uint32_t ra = 0, rb = 0, oa = 0, ob = 0;
         const WinCell wca = win_load(ix, la ? pa : 0u, ra), wcb = win_load(ix, lb ? pb : 0u, rb);
-        int32_t wca_c = 0, wcb_c = 0, ranka = 0, rankb = 0;
+        int32_t wca_c = 0, wcb_c = 0, nexta = 0, nextb = 0;
         bool sampled;
-        bool ha = win_inv_from(wca, ra, wca_c, ranka, sampled, oa), hb = win_inv_from(wcb, rb, wcb_c, rankb, sampled, ob);
+        const bool ha = win_inv_from(wca, ra, wca_c, nexta, sampled, oa), hb = win_inv_from(wcb, rb, wcb_c, nextb, sampled, ob);
         const bool ea = la && !ha, eb = lb && !hb;
         if (ea || eb) {
             const uint64_t va = win_other_load(ix, ea ? oa : 0u), vb = win_other_load(ix, eb ? ob : 0u);
-            if (ea) ha = win_other_from(va, wca_c, ranka);
-            if (eb) hb = win_other_from(vb, wcb_c, rankb);
+            if (ea) win_other_from(va, wca_c, nexta, status, suspect);
+            if (eb) win_other_from(vb, wcb_c, nextb, status, suspect);
         }
-        if (la && ha) {
+        if (la) {
             a.c = wca_c;
-            a.row = ranka + 1;
-            la = false;
+            a.row = nexta;
         }
-        if (lb && hb) {
+        if (lb) {
             b.c = wcb_c;
-            b.row = rankb + 1;
-            lb = false;
+            b.row = nextb;
         }
-        if (!la && !lb) return;
-        if (kWin == kWinAlways) {  // (unreachable: kWinAlways is instantiated for complete directories only)
-            status = ST_JAVA_AIOOBE;
-            if (la) a.row = 0, a.c = 0;
-            if (lb) b.row = 0, b.c = 0;
-            return;
-        }
+        return;
     }
     const InvView va = wt_inv_view(ix, la ? pa >> 20 : 0u, inv), vb = wt_inv_view(ix, lb ? pb >> 20 : 0u, inv);
     Quad iha = {0, 0, 0, 0}, ihb = {0, 0, 0, 0};
@@ -1443,7 +1431,7 @@ FMX_HD void fm_lf_step2(const DevIndex &ix, const uint16_t *inv, LfChain &a, LfC
 //   1. the step from row p + 1 for every position p of the window; a position is a candidate if the step raised no status and
 //      no `suspect` and its symbol (behind the int16 cast of FM:532) is in [0, kWinNone);
 //   2. the three most frequent candidate symbols become the classes (ties: the one met first);
-//   3. a class's count is the rank its FIRST position's step arrived at, less one, and every further position of the class must
+//   3. a class's count is the row its FIRST position's step arrived at, less one, and every further position of the class must
 //      have arrived at that plus its number in the window — else the class is dropped (its positions become class 3).
 // `out` = the 16 words of the cell, word 4 (the first win_other entry) left 0; returns the number of class-3 positions (entries).
 FMX_HD uint32_t win_build_cell(const DevIndex &ix, uint32_t w, uint32_t *out) {
@@ -1530,9 +1518,8 @@ FMX_HD uint32_t win_build_cell(const DevIndex &ix, uint32_t w, uint32_t *out) {
     return others;
 }
 // The win_other entries of window w (cell = its 16 words as win_build_cell made them): one per position of class 3, in position
-// order, from entries[first] on: {the row the position's step arrives at, less one; symbol | kWinOtherValid} where the step raised
-// no status and no `suspect` and its symbol is in [0, kWinNone) — otherwise an entry without the flag (the tree walk takes such
-// a step).  Writes `first` into the cell's word 4; returns the number of entries without the flag.
+// order, from entries[first] on — what fm_lf_step hands back for the position's row (win_other_make).  Writes `first` into the
+// cell's word 4; returns the number of entries that carry a status or `suspect` (statistics: a handful per index).
 FMX_HD uint32_t win_build_other(const DevIndex &ix, uint32_t w, uint32_t *cell_words, uint32_t first, uint64_t *entries) {
     const uint64_t ws64 = (uint64_t)w * kWinW;
     const uint32_t ws = (uint32_t)ws64;
@@ -1540,21 +1527,20 @@ FMX_HD uint32_t win_build_other(const DevIndex &ix, uint32_t w, uint32_t *cell_w
     cell_words[4] = first;
     WinCell cell;
     memcpy(&cell, cell_words, 64);
-    uint32_t at = first, open_entries = 0;
+    uint32_t at = first, unclean = 0;
     for (uint32_t j = 0; j < n; ++j) {
-        int32_t wc, wrank;
+        int32_t wc, wnext;
         bool sampled;
         uint32_t other;
-        if (win_inv_from(cell, j, wc, wrank, sampled, other)) continue;
+        if (win_inv_from(cell, j, wc, wnext, sampled, other)) continue;
         int status = ST_OK;
         bool suspect = false;
         int32_t c = 0;
         const int32_t next = fm_lf_step<true, kWinNever>(ix, nullptr, (int32_t)(ws + j + 1u), c, status, suspect);
-        const bool valid = status == ST_OK && !suspect && c >= 0 && (uint32_t)c < kWinNone;
-        if (!valid) ++open_entries;
-        entries[at++] = (uint64_t)(uint32_t)(next - 1) | ((uint64_t)(((uint32_t)c & 0xffffu) | (valid ? kWinOtherValid : 0u)) << 32);
+        if (status != ST_OK || suspect) ++unclean;
+        entries[at++] = win_other_make(next, c, status, suspect);
     }
-    return open_entries;
+    return unclean;
 }
 
 // IntVector.getValue on the packed `suffixes` / `positions` words (IV:129-143)
@@ -1676,20 +1662,19 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
             const WinCell cell = win_load(ix, (uint32_t)p, r);
             bool sampled_row;
             uint32_t other = 0;
-            answered = win_inv_from(cell, r, c, rank_before, sampled_row, other);
+            int32_t next = 0;
+            answered = win_inv_from(cell, r, c, next, sampled_row, other);
             if (sampled_row) {
                 scell = ld_quad(bv_cell_ptr(ix.base, sv, (uint32_t)p));
                 FMX_PIN_QUAD(scell);
                 break;
             }
-            if (!answered) answered = win_other_from(win_other_load(ix, other), c, rank_before);
-            if (answered) {
-                j = rank_before + 1;  // (the step fm_lf_step took over the tree when the directory was grown)
-                stepped = true;
-            }
+            bool suspect = false;
+            if (!answered) win_other_from(win_other_load(ix, other), c, next, status, suspect);
+            j = next;  // (the step fm_lf_step took over the tree when the directory was grown)
+            stepped = true;
         }
-        if (kWin == kWinAlways && !stepped) {  // (unreachable: kWinAlways is instantiated for complete directories, and p < the
-                                               // bitmap's length == the tree's size on every image validate_blob lets through)
+        if (kWin == kWinAlways && !stepped) {  // (p < the bitmap's length == the tree's size on every image validate_blob lets through)
             status = ST_JAVA_AIOOBE;
             break;
         }

@@ -663,7 +663,6 @@ static DevIndex win_plain_index(const DevIndex &ix) {
     plain.suffix_table = nullptr;
     plain.win = nullptr;
     plain.win_other = nullptr;
-    plain.win_complete = 0;
     return plain;
 }
 static unsigned win_blocks(int n_cu, uint32_t n_win) {
@@ -1764,22 +1763,17 @@ static int grid_for(int64_t lanes, int block, int n_cu) {
             hipLaunchKernelGGL(KERNEL<512>, grid__, dim3(512), (size_t)g_lds_pad_kb * 1024, st, __VA_ARGS__);                          \
     } while (0)
 
-// ... of a walk kernel instantiated for indexes with a complete window directory, one with open entries, none (fmx_device.hpp: kWin)
+// ... of a walk kernel instantiated for indexes with a window directory and without one (fmx_device.hpp: kWinAlways / kWinNever)
 #define FMX_DISPATCH_WIN(KERNEL, IX, LANES, ...)                                                                       \
     do {                                                                                                               \
         const int blk__ = g_block;                                                                                     \
         const dim3 grid__(grid_for((LANES), blk__, n_cu));                                                             \
         const size_t lds__ = (size_t)g_lds_pad_kb * 1024;                                                              \
-        if ((IX).win && (IX).win_complete) {                                                                           \
+        if ((IX).win) {                                                                                                \
             if (blk__ == 1024)                                                                                         \
                 hipLaunchKernelGGL((KERNEL<1024, kWinAlways>), grid__, dim3(1024), lds__, st, __VA_ARGS__);           \
             else                                                                                                       \
                 hipLaunchKernelGGL((KERNEL<512, kWinAlways>), grid__, dim3(512), lds__, st, __VA_ARGS__);             \
-        } else if ((IX).win) {                                                                                         \
-            if (blk__ == 1024)                                                                                         \
-                hipLaunchKernelGGL((KERNEL<1024, kWinAsk>), grid__, dim3(1024), lds__, st, __VA_ARGS__);              \
-            else                                                                                                       \
-                hipLaunchKernelGGL((KERNEL<512, kWinAsk>), grid__, dim3(512), lds__, st, __VA_ARGS__);                \
         } else {                                                                                                       \
             if (blk__ == 1024)                                                                                         \
                 hipLaunchKernelGGL((KERNEL<1024, kWinNever>), grid__, dim3(1024), lds__, st, __VA_ARGS__);            \

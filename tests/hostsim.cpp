@@ -17,7 +17,7 @@ using namespace fmx;
 // window directories attached to blobs (sim_win_attach): what fmx_to_device grows beside a resident image
 static std::map<const uint8_t *, std::vector<uint32_t>> g_windows;
 static std::map<const uint8_t *, std::vector<uint64_t>> g_window_entries;
-static std::map<const uint8_t *, bool> g_window_complete;
+static std::map<const uint8_t *, uint64_t> g_window_unclean;
 
 static DevIndex make_index(const uint8_t *b) {
     BlobHeader h;
@@ -53,7 +53,6 @@ static DevIndex make_index(const uint8_t *b) {
         d.win = it == g_windows.end() ? nullptr : reinterpret_cast<const Quad *>(it->second.data());
         auto e = g_window_entries.find(b);
         d.win_other = e == g_window_entries.end() ? nullptr : e->second.data();
-        d.win_complete = (d.win && g_window_complete[b]) ? 1 : 0;
     }
     d.self = nullptr;
     d.suffix_chars = 0;
@@ -67,7 +66,7 @@ extern "C" {
 
 // grows the window directory of a blob with the very function k_win_build runs (win_build_cell) and attaches it: every sim_*
 // call on that blob then takes the windows first, as the kernels do on a resident index.  Returns the number of cells;
-// stats (nullable): {positions with a class, positions, classes in use, positions answered by their win_other entry}.
+// stats (nullable): {positions with a class, positions, classes in use, positions with an entry, entries with a status or suspect}.
 int64_t sim_win_attach(const uint8_t *blob, int64_t *stats) {
     g_windows.erase(blob);
     g_window_entries.erase(blob);
@@ -82,9 +81,10 @@ int64_t sim_win_attach(const uint8_t *blob, int64_t *stats) {
     std::vector<uint64_t> entries(total + 1);
     uint64_t open_entries = 0;
     for (size_t w = 0; w < cells; ++w) open_entries += win_build_other(ix, (uint32_t)w, words.data() + 16 * w, first[w], entries.data());
-    g_window_complete[blob] = open_entries == 0;
+    g_window_unclean[blob] = open_entries;
     if (stats) {
         stats[0] = stats[1] = stats[2] = stats[3] = 0;
+        stats[4] = (int64_t)open_entries;
         for (size_t w = 0; w < cells; ++w) {
             const uint32_t *c = words.data() + 16 * w;
             WinCell cell;
@@ -97,7 +97,7 @@ int64_t sim_win_attach(const uint8_t *blob, int64_t *stats) {
                 uint32_t other = 0;
                 if (win_inv_from(cell, r, sym, rank, sampled, other))
                     ++stats[0];
-                else if (win_other_from(entries[other], sym, rank))
+                else
                     ++stats[3];
                 ++stats[1];
             }
@@ -110,7 +110,7 @@ int64_t sim_win_attach(const uint8_t *blob, int64_t *stats) {
 void sim_win_detach(const uint8_t *blob) {
     g_windows.erase(blob);
     g_window_entries.erase(blob);
-    g_window_complete.erase(blob);
+    g_window_unclean.erase(blob);
 }
 
 int32_t sim_wt_rank(const uint8_t *blob, uint32_t position, int32_t symbol, int32_t *status) {
@@ -286,9 +286,8 @@ void sim_locate_walk(const uint8_t *blob, const int32_t *range, int32_t n, int32
             if (k >= located) continue;
             int status = ST_OK;
             int32_t distance;
-            locs[(int64_t)p * loc_cap + k] = ix.win_complete ? fm_locate_hit<kWinAlways>(ix, ix.inv_global, start, k, distance, status)  // (as launch_locate_walk picks)
-                                             : ix.win        ? fm_locate_hit<kWinAsk>(ix, ix.inv_global, start, k, distance, status)
-                                                             : fm_locate_hit<kWinNever>(ix, ix.inv_global, start, k, distance, status);
+            locs[(int64_t)p * loc_cap + k] = ix.win ? fm_locate_hit<kWinAlways>(ix, ix.inv_global, start, k, distance, status)  // (as launch_locate_walk picks)
+                                                    : fm_locate_hit<kWinNever>(ix, ix.inv_global, start, k, distance, status);
             if (lf) lf[p] += distance;
             if (status && status_out) status_out[p] |= status;
         }
@@ -301,9 +300,8 @@ void sim_extract(const uint8_t *blob, const int32_t *starts, const int32_t *stop
         int status = ST_OK;
         int32_t steps;
         uint16_t *row = dst + (int64_t)q * dst_len;
-        const int32_t ret = ix.win_complete ? fm_extract<kWinAlways>(ix, ix.inv_global, starts[q], stops[q], row, dst_len, offset, steps, status)  // (as launch_extract picks)
-                            : ix.win        ? fm_extract<kWinAsk>(ix, ix.inv_global, starts[q], stops[q], row, dst_len, offset, steps, status)
-                                            : fm_extract<kWinNever>(ix, ix.inv_global, starts[q], stops[q], row, dst_len, offset, steps, status);
+        const int32_t ret = ix.win ? fm_extract<kWinAlways>(ix, ix.inv_global, starts[q], stops[q], row, dst_len, offset, steps, status)  // (as launch_extract picks)
+                                   : fm_extract<kWinNever>(ix, ix.inv_global, starts[q], stops[q], row, dst_len, offset, steps, status);
         out_len[q] = status ? 0 : ret;
         if (lf) lf[q] = steps;
         if (status_out) status_out[q] = status;
@@ -323,7 +321,7 @@ void sim_extract_boundary(const uint8_t *blob, const int32_t *froms, int32_t n, 
         if (accelerate >= 2) {  // group-cooperative form with a group of one lane (3: the lane's two first walks interleaved)
             bool clean;
             // (over a complete window directory: the instantiation without tree-walk code, as launch_extract_boundary picks)
-            ret = ix.win_complete
+            ret = ix.win  // (the instantiation without the tree walk: not what the kernel runs, kept covered)
                       ? fm_extract_boundary_group<1, -1, kWinAlways>(ix, ix.inv_global, mode, froms[q], mapped_boundary, dst + (int64_t)q * dst_len,
                                                                      dst_len, offset, steps, status, aux, scratch, 1, 1, ix.sample_rate + 1, 0,
                                                                      clean, accelerate == 3)

@@ -86,8 +86,8 @@ class HostSim:
     def attach_windows(self):
         """grows the window directory (fmx_device.hpp: win_build_cell, what k_win_build runs when an index becomes resident) and
         makes every later call of this simulation take it first, as the kernels do; returns (positions with a class, positions,
-        classes in use, positions answered by their entry)"""
-        stats = np.zeros(4, np.int64)
+        classes in use, positions with an entry, entries that carry a status or `suspect`)"""
+        stats = np.zeros(5, np.int64)
         self.L.sim_win_attach(C.c_void_p(self.p), C.c_void_p(stats.ctypes.data))
         self.windows = tuple(int(v) for v in stats)
         return self.windows

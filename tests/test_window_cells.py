@@ -21,7 +21,8 @@ COVER = {}
 
 def make_sim_windows(text, sr):
     h = hostsim.HostSim(ia.FmIndex(text, sr, True, device=None))
-    got, positions, classes, by_entry = h.attach_windows()
+    got, positions, classes, by_entry, unclean = h.attach_windows()
+    assert got + by_entry == positions  # every position's step is in the directory
     COVER[(len(text), sr)] = got / max(1, positions)
     return h
 
@@ -62,8 +63,8 @@ def test_rank_and_inverse_select_at_every_kind_of_block():
     f = ia.FmIndex(text, 5, True, device=None)
     o = orc.OracleFmIndex(text, 5, True)
     h = hostsim.HostSim(f)
-    got, positions, classes, by_entry = h.attach_windows()
-    assert 0 < got <= positions and classes > 0 and by_entry > 0
+    got, positions, classes, by_entry, unclean = h.attach_windows()
+    assert 0 < got <= positions and classes > 0 and by_entry > 0 and got + by_entry == positions
     L = f.getInputLength()
     wh = o.wavelet_handle()
     st = orc.C.c_int(0)
@@ -92,6 +93,9 @@ def test_large_alphabet_with_run_blocks_of_wide_symbols():
         parts.append(chr(0x30A1 + i) * 70_000)  # long runs of one wide symbol: run blocks
         parts.append("log line %d\n" % i * 50)
     text = "".join(parts)
+    h = hostsim.HostSim(ia.FmIndex(text, 16, True, device=None))
+    got, positions, classes, by_entry, unclean = h.attach_windows()
+    assert unclean > 0 and got + by_entry == positions  # steps with `suspect` (Q1): kept in their entries as they are
     check_all(make_sim_windows, text, 16, random.Random(5), n_q=60)
 
 
