@@ -1115,6 +1115,10 @@ def run_secondary(ctx, args, q, ref, orc, text, pat, off):
     # The synthetic log repeats itself (328,091 distinct patterns in the headline batch); equal patterns side by side share
     # their sectors.  This row draws substrings until it has as many DISTINCT ones as the headline batch holds patterns.
     try:
+        if args.profiling:
+            # (tools/profile.sh averages the headline kernel's counters over its dispatches on the headline's GRID: this row runs
+            # the same kernel on the same grid — r05_y's first counter pass read 376 instead of 197 MB per launch because of it)
+            raise RuntimeError("not run under --profiling")
         n_d = len(off) - 1
         from index4j_amd import workload
 
