@@ -118,3 +118,19 @@ def test_count_answers_on_both_sides_of_plan_sa_min(index16, n):
     oc, ost = o.count_batch(pat, off, threads=8)
     assert (d_cnt.cpu().numpy() == oc).all() and (d_st.cpu().numpy() == ost).all()
     assert int(d_lf.sum(dtype=torch.int64).item()) == orc.counters()["lf_steps"]
+
+
+@pytest.mark.parametrize("sr", [1, 4, 32, 64])
+def test_every_query_kind_under_the_shipped_policy(sr):
+    """parity_checks.check_all (every query kind, error statuses, whole destination rows, vs the oracle) with NOTHING forced: small
+    batches take k_count in the caller's order with the code word made in the kernel, k_locate_walk without a walk order and
+    extractUntilBoundary in the caller's order — the paths a typical caller's small batches run (the rest of the GPU
+    suite forces the planned ones)."""
+    import random
+
+    from common import hdfs_text
+    from parity_checks import GpuEngine, check_all
+
+    hd = hdfs_text()
+    check_all(lambda text, s: GpuEngine(text, s), hd, sr, random.Random(900 + sr))
+    check_all(lambda text, s: GpuEngine(text, s), "".join(ch if ord(ch) < 128 else "?" for ch in hd[:150_000]), sr, random.Random(910 + sr), n_q=80)
