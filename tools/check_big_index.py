@@ -6,6 +6,7 @@ import index4j_amd as ia, orc
 n = (2**31 - 2) if (len(sys.argv) > 1 and sys.argv[1] == "max") else 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 29)
 t0=time.time(); t = ia.synth_log(n); print("text", time.time()-t0, flush=True)
 t0=time.time(); fm = ia.FmIndex(t, 32, True, device=0, build_device=0); print("build+to_device", time.time()-t0, fm.build_stats, flush=True)
+print("window directory MB", fm.window_cells_bytes() / 1e6, "suffix table", fm.suffix_table_info(), flush=True)
 # (the orders of round 4 forced on: the plan by SA row for every batch of sort_min patterns, the locate walk by range start)
 assert ia.lib.fmx_set_option(b"plan_sa_min", 0) == 0 and ia.lib.fmx_set_option(b"walk_order_min", 1) == 0
 pat, off, pos = ia.synth_patterns(t, 8, 200000)
