@@ -1716,6 +1716,57 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
     return fm_packed_get(ix.suffix_words, r, ix.bw_suffixes) + distance;  // FM:538-542
 }
 
+// One hit's walk over the window directory in INSTALMENTS (k_locate_walk_c: a wave walks until its longest walk meets a sampled
+// row — twice the average — so the workgroup packs the walks still under way into fewer waves now and then; the state that
+// travels is this).  fm_locate_steps_win: up to `budget` steps; true = the walk is over (row j - 1 is sampled, or a status ended
+// it).  fm_locate_finish_win: FM:538-542 for a finished walk.  Together: fm_locate_hit<kWinAlways>, step for step.
+struct WalkState {
+    int32_t j, distance;
+    int status;
+};
+// (fm_locate_hit: what bounds a walk over a damaged index)
+FMX_HD int32_t fm_walk_limit(const DevIndex &ix) {
+    const int64_t stretches = (int64_t)ix.sample_rate * 256;
+    return (int32_t)(stretches < 4096 ? 4096 : (stretches < (int64_t)ix.length ? stretches : (int64_t)ix.length));
+}
+FMX_HD bool fm_locate_steps_win(const DevIndex &ix, WalkState &w, int32_t budget, int32_t walk_limit) {
+    FMX_NO_UNROLL
+    for (int32_t n = 0; n < budget; ++n) {
+        const int32_t p = w.j - 1;
+        if (p < 0 || p >= ix.sampled.length || (uint32_t)p >= ix.wt_size) {  // RrrVector.access throws (RRR:316-323)
+            w.status = ST_JAVA_AIOOBE;
+            return true;
+        }
+        uint32_t r, other = 0;
+        const WinCell cell = win_load(ix, (uint32_t)p, r);
+        int32_t c = 0, next = 0;
+        bool sampled_row;
+        const bool answered = win_inv_from(cell, r, c, next, sampled_row, other);
+        if (sampled_row) return true;  // FM:531
+        bool suspect = false;
+        if (!answered) win_other_from(win_other_load(ix, other), c, next, w.status, suspect);
+        w.j = next;  // (the step fm_lf_step took over the tree when the directory was grown)
+        if (++w.distance > walk_limit) {  // bounds the walk on a damaged index
+            w.status = ST_JAVA_AIOOBE;
+            return true;
+        }
+    }
+    return false;
+}
+FMX_HD int32_t fm_locate_finish_win(const DevIndex &ix, const uint16_t *inv, const WalkState &w) {
+    RrrView sv = rrr_view_from(Quad{ix.sampled.off_rec, ix.sampled.off_bits, (uint32_t)ix.sampled.length, (uint32_t)ix.sampled.total_ones});
+    bv_bind(sv, ix, inv);
+    int32_t r;
+    if (w.status == ST_OK) {  // row j - 1 is sampled: rankOnes(j) = rankOnes(j - 1) + 1 (FM:541)
+        const Quad scell = ld_quad(bv_cell_ptr(ix.base, sv, (uint32_t)(w.j - 1)));
+        r = bv_rank1_after_set_bit(sv, scell, w.j - 1) - 1;
+    } else {  // (a walk that ended in a status reports no position: the read only has to stay inside `suffixes`)
+        r = bv_rank1(ix.base, sv, w.j) - 1;
+        if (r < 0) r = 0;
+    }
+    return fm_packed_get(ix.suffix_words, r, ix.bw_suffixes) + w.distance;  // FM:538-542
+}
+
 // up to four characters of one aligned 8-byte group of a destination row (mask: which of them): one store when all four are there
 FMX_HD void fm_flush_chars(uint16_t *group_at, uint64_t group, uint32_t mask) {
     if (mask == 0xfu) {

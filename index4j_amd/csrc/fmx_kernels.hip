@@ -758,6 +758,120 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix_global, const int32_t *__
     }
 }
 
+// k_locate_walk over an index with a window directory, with the walks still under way PACKED into fewer waves twice on their
+// way (after sample_rate / 2 and sample_rate * 3 / 4 steps).  The kernel is bound by VALU issue, and a wave walks until the longest
+// of its 64 walks meets a sampled row — sample_rate - 1 steps where the average walk takes half of that: half of the wave-steps ran
+// on lanes whose walk was over (profiles/r05_experiments.txt 12).  After an instalment every lane still walking writes its state
+// {row, distance, status, where the position goes} to LDS at its rank among them, the workgroup's first lanes take the states
+// over, and the waves behind them fall through the next instalment.  Same tickets, same stores as k_locate_walk.
+template <int kBlock>
+FMX_WALK_KERNEL(kBlock) void k_locate_walk_c(DevIndex ix_global, const int32_t *__restrict__ range, int32_t n,
+                                             int32_t max_matches, int32_t *__restrict__ locs, int32_t loc_cap, int32_t slots,
+                                             int32_t *__restrict__ found, int32_t *__restrict__ lf_steps,
+                                             int32_t *__restrict__ status_out, const int32_t *__restrict__ taken,
+                                             const PlanRec *__restrict__ order, const uint32_t *__restrict__ order_idle,
+                                             int64_t *__restrict__ set_locs, int64_t set_base) {
+    FMX_FM_INV(ix_global);
+    FMX_WITH_SB_CACHE(ix_global, ix);
+    __shared__ Quad s_state[kBlock];        // {row, distance, status, pattern}
+    __shared__ int64_t s_dest[kBlock];      // index of the hit's position in locs / set_locs
+    __shared__ uint32_t s_walking[kBlock / 64];
+    const int32_t lanes = slots < kWalkLanes ? slots : kWalkLanes;
+    const int64_t idle = order ? (int64_t)(*order_idle / (uint32_t)kFineWindow) * kFineWindow : 0;
+    const int64_t total = idle + ((int64_t)n - idle) * lanes;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int32_t walk_limit = fm_walk_limit(ix);
+    const int32_t first = ix.sample_rate / 2 > 0 ? ix.sample_rate / 2 : 1, second = ix.sample_rate / 4 > 0 ? ix.sample_rate / 4 : 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (every lane of the workgroup runs the same number of rounds: the barriers below are the workgroup's)
+    for (int64_t t0 = (int64_t)blockIdx.x * kBlock; t0 < total; t0 += stride) {
+        const int64_t t = t0 + threadIdx.x;
+        const bool have = t < total;
+        int64_t rec = have ? t : 0;
+        int32_t k = 0, step = 1;
+        if (have && t >= idle) {
+            rec = idle + (t - idle) / lanes;
+            k = (int32_t)((t - idle) - (rec - idle) * lanes);
+            step = lanes;
+        }
+        int32_t p = (int32_t)rec, start = 0, end = 0, taken_p = 0, located = 0;
+        if (have) {
+            if (order) {
+                const Quad r = ld_quad(order + rec);
+                start = (int32_t)r.x;
+                end = (int32_t)r.y;
+                p = (int32_t)r.z;
+            } else {
+                start = range[2 * p];
+                end = range[2 * p + 1];
+            }
+            int32_t hits = start < end ? end - start : 0;
+            int32_t limit = max_matches;
+            if (taken) {
+                taken_p = taken[p];
+                limit = max_matches - taken_p;
+                if (limit <= 0) hits = 0;
+            }
+            // the reference stops at maxMatches (FM:544-546) and overruns `locations` beyond its length (Java AIOOBE)
+            const int32_t wanted = (limit > 0 && hits > limit) ? limit : hits;
+            located = wanted < loc_cap ? wanted : loc_cap;
+            if (k == 0) {
+                found[p] = located;
+                if (wanted > loc_cap && status_out) atomicOr(&status_out[p], ST_JAVA_AIOOBE);
+            }
+        }
+        for (;; k += step) {  // this ticket's hits k, k + step, ...: a round of the workgroup per hit
+            const bool hit = have && k < located;
+            if (!__syncthreads_or(hit ? 1 : 0)) break;
+            // the walk this lane carries (after a packing: another lane's)
+            WalkState w = {start + 1 + k, 0, ST_OK};  // FM:527-529
+            int32_t wp = p;
+            int64_t dest = (int64_t)p * loc_cap + (set_locs ? taken_p : 0) + k;
+            bool walking = hit;
+            for (int phase = 0; phase < 3; ++phase) {
+                const int32_t budget = phase == 0 ? first : (phase == 1 ? second : 0x7fffffff);
+                if (walking && fm_locate_steps_win(ix, w, budget, walk_limit)) {
+                    const int32_t at = fm_locate_finish_win(ix, s_inv, w);
+                    if (set_locs)
+                        set_locs[dest] = set_base + at;
+                    else
+                        locs[dest] = at;
+                    if (lf_steps && w.distance) atomicAdd(&lf_steps[wp], w.distance);
+                    if (w.status && status_out) atomicOr(&status_out[wp], w.status);
+                    walking = false;
+                }
+                if (phase == 2) break;
+                // pack the walks still under way into the workgroup's first lanes
+                const unsigned long long ball = __ballot(walking ? 1 : 0);
+                if (lane == 0) s_walking[wave] = (uint32_t)__popcll(ball);
+                __syncthreads();
+                uint32_t before = 0, all = 0;
+                for (int i = 0; i < kBlock / 64; ++i) {
+                    const uint32_t c = s_walking[i];
+                    before += i < wave ? c : 0u;
+                    all += c;
+                }
+                if (walking) {
+                    const uint32_t at = before + (uint32_t)__popcll(ball & ((1ull << lane) - 1ull));
+                    s_state[at] = Quad{(uint32_t)w.j, (uint32_t)w.distance, (uint32_t)w.status, (uint32_t)wp};
+                    s_dest[at] = dest;
+                }
+                __syncthreads();
+                walking = threadIdx.x < all;
+                if (walking) {
+                    const Quad q = s_state[threadIdx.x];
+                    w.j = (int32_t)q.x;
+                    w.distance = (int32_t)q.y;
+                    w.status = (int)q.z;
+                    wp = (int32_t)q.w;
+                    dest = s_dest[threadIdx.x];
+                }
+                __syncthreads();  // (the arrays are written again in the next packing)
+            }
+        }
+    }
+}
+
 // FM:564-608.  Pipeline form (slot_found != nullptr): query q is hit (q % slots) of pattern (q / slots) and
 // runs only if that hit exists; with stops == nullptr the stop position is min(inputLength, start + fixed_len)
 // (the reference's locateAndExtractBenchmark, FmIndexThroughputBenchmark.java:231-249).
@@ -1612,6 +1726,7 @@ __global__ __launch_bounds__(256) void k_segment_commit(int32_t *__restrict__ fo
 // setting, so a launch that sees a mix of old and new values is still correct).
 static std::atomic<int> g_block{512};
 static std::atomic<int> g_groups_per_cu{16};
+static std::atomic<int> g_walk_pack{1};  // option "walk_pack": locate over a window directory packs the walks still under way into fewer waves (0: A/B)
 static std::atomic<int> g_boundary_accel{1};  // 0 = literal right walk of extractUntilBoundary (A/B and fallback)
 static std::atomic<int> g_boundary_group{4};  // lanes per query of extractUntilBoundary (0 = one lane per query)
 // first fill of extractUntilBoundary's two text windows: 0 = G intervals on each side, a lane walks one after the other;
@@ -1652,6 +1767,10 @@ int set_option(const char *name, int value) {
     if (!strcmp(name, "block")) {
         if (value != 512 && value != 1024) return -1;
         g_block = value;
+        return 0;
+    }
+    if (!strcmp(name, "walk_pack")) {
+        g_walk_pack = value != 0;
         return 0;
     }
     if (!strcmp(name, "groups_per_cu")) {
@@ -1975,6 +2094,11 @@ int launch_locate_walk(const DevIndex &ix, int n_cu, const int32_t *range, int32
         order_idle = ticket + 1;
     }
     const int64_t tickets = (int64_t)n * (slots < kWalkLanes ? slots : kWalkLanes);
+    if (ix.win && g_walk_pack.load() && ix.sample_rate >= 8) {  // a window directory: the packed form (k_locate_walk_c)
+        FMX_DISPATCH(k_locate_walk_c, tickets, ix, range, n, max_matches, locs, loc_cap, slots, found, lf, status, taken, order, order_idle,
+                     set_locs, set_base);
+        return (int)hipGetLastError();
+    }
     FMX_DISPATCH_WIN(k_locate_walk, ix, tickets, ix, range, n, max_matches, locs, loc_cap,
                      slots, found, lf, status, taken, order, order_idle, set_locs, set_base);
     return (int)hipGetLastError();

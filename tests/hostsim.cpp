@@ -18,6 +18,7 @@ using namespace fmx;
 static std::map<const uint8_t *, std::vector<uint32_t>> g_windows;
 static std::map<const uint8_t *, std::vector<uint64_t>> g_window_entries;
 static std::map<const uint8_t *, uint64_t> g_window_unclean;
+static int g_pack = 1;  // locate over a window directory: the instalment form (k_locate_walk_c) or fm_locate_hit<kWinAlways> (option walk_pack 0)
 
 static DevIndex make_index(const uint8_t *b) {
     BlobHeader h;
@@ -107,6 +108,7 @@ int64_t sim_win_attach(const uint8_t *blob, int64_t *stats) {
     g_window_entries[blob] = std::move(entries);
     return (int64_t)cells;
 }
+void sim_set_pack(int on) { g_pack = on; }
 void sim_win_detach(const uint8_t *blob) {
     g_windows.erase(blob);
     g_window_entries.erase(blob);
@@ -286,6 +288,17 @@ void sim_locate_walk(const uint8_t *blob, const int32_t *range, int32_t n, int32
             if (k >= located) continue;
             int status = ST_OK;
             int32_t distance;
+            if (ix.win && g_pack && ix.sample_rate >= 8) {
+                // (as launch_locate_walk picks over a window directory: k_locate_walk_c — the walk in instalments of sample_rate / 2,
+                // sample_rate / 4 steps and the rest, as the kernel takes them between its packings)
+                WalkState w = {start + 1 + k, 0, ST_OK};
+                const int32_t limit = fm_walk_limit(ix);
+                if (!fm_locate_steps_win(ix, w, ix.sample_rate / 2, limit) && !fm_locate_steps_win(ix, w, ix.sample_rate / 4, limit))
+                    (void)fm_locate_steps_win(ix, w, 0x7fffffff, limit);
+                locs[(int64_t)p * loc_cap + k] = fm_locate_finish_win(ix, ix.inv_global, w);
+                distance = w.distance;
+                status = w.status;
+            } else
             locs[(int64_t)p * loc_cap + k] = ix.win ? fm_locate_hit<kWinAlways>(ix, ix.inv_global, start, k, distance, status)  // (as launch_locate_walk picks)
                                                     : fm_locate_hit<kWinNever>(ix, ix.inv_global, start, k, distance, status);
             if (lf) lf[p] += distance;

@@ -28,6 +28,7 @@ def lib(compact=False):
         L.sim_win_attach.argtypes = [C.c_void_p, C.c_void_p]
         L.sim_win_attach.restype = C.c_int64
         L.sim_win_detach.argtypes = [C.c_void_p]
+        L.sim_set_pack.argtypes = [C.c_int]
         _LIBS[compact] = L
     return _LIBS[compact]
 

@@ -115,3 +115,17 @@ def test_reference_route_image_through_the_windows():
         return h
 
     check_all(make, HD[:50_000], 8, random.Random(31), n_q=50)
+
+
+def test_locate_without_instalments_over_the_directory_as_well():
+    """option walk_pack = 0: k_locate_walk<kWinAlways> (fm_locate_hit, one walk to its end) instead of k_locate_walk_c (the walk in
+    instalments between the workgroup's packings: fm_locate_steps_win + fm_locate_finish_win, what every other test of this file runs
+    at sample rates >= 8)"""
+    for compact in (False, True):
+        hostsim.lib(compact).sim_set_pack(0)
+    try:
+        check_all(make_sim_windows, HD, 32, random.Random(501))
+        check_all(make_sim_windows, quirk_text(), 8, random.Random(502), n_q=80)
+    finally:
+        for compact in (False, True):
+            hostsim.lib(compact).sim_set_pack(1)
