@@ -1651,19 +1651,18 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
             status = ST_JAVA_AIOOBE;
             break;
         }
-        // (p < length == the wavelet tree's size: validate_model / validate_blob)
-        int32_t c = 0, rank_before = 0, bsl_p = 0;
-        bool exact = true, answered = false, stepped = false;
-        const bool windows = (kWin == kWinAlways || (kWin == kWinAsk && ix.win != nullptr)) && (uint32_t)p < ix.wt_size;
-        if (windows) {
+        if (kWin == kWinAlways || (kWin == kWinAsk && ix.win != nullptr)) {
             // the window of p holds the row's sampled bit as well: a step of a walk is ONE sector where the symbol is one of the
             // window's classes, or two (the bitmap's own cell is fetched once, for the rank behind the loop)
-            uint32_t r;
+            if ((uint32_t)p >= ix.wt_size) {  // (p < the bitmap's length == the tree's size on every image validate_blob lets through)
+                status = ST_JAVA_AIOOBE;
+                break;
+            }
+            uint32_t r, other = 0;
             const WinCell cell = win_load(ix, (uint32_t)p, r);
+            int32_t c = 0, next = 0;
             bool sampled_row;
-            uint32_t other = 0;
-            int32_t next = 0;
-            answered = win_inv_from(cell, r, c, next, sampled_row, other);
+            const bool answered = win_inv_from(cell, r, c, next, sampled_row, other);
             if (sampled_row) {
                 scell = ld_quad(bv_cell_ptr(ix.base, sv, (uint32_t)p));
                 FMX_PIN_QUAD(scell);
@@ -1672,29 +1671,20 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
             bool suspect = false;
             if (!answered) win_other_from(win_other_load(ix, other), c, next, status, suspect);
             j = next;  // (the step fm_lf_step took over the tree when the directory was grown)
-            stepped = true;
-        }
-        if (kWin == kWinAlways && !stepped) {  // (p < the bitmap's length == the tree's size on every image validate_blob lets through)
-            status = ST_JAVA_AIOOBE;
-            break;
-        }
-        if (!stepped) {
-            if (kWin != kWinAlways && !answered) {
-                const InvView v = wt_inv_view(ix, (uint32_t)p >> 20, inv);
-                Quad ihq = ld_quad(wt_inv_hdr_ptr(ix, v, (uint32_t)p));
-                if (!windows) scell = ld_quad(bv_cell_ptr(ix.base, sv, (uint32_t)p));
-                FMX_PIN_QUAD(ihq);
-                FMX_PIN_QUAD(scell);
-                if (!windows) {
-                    bool sampled_row;
-                    (void)bv_rank1_access_cell(sv, scell, p, sampled_row);
-                    if (sampled_row) break;
-                }
-                c = (int32_t)(int16_t)wt_inverse_select_from<false>(ix, (uint32_t)p, v, ihq, rank_before, exact);
-                bsl_p = v.bsl;
-            }
-            bool suspect = false;
-            j = fm_lf_finish<false>(ix, inv, j, c, rank_before, bsl_p, exact, status, suspect);  // FM:532-535
+        } else {
+            // (p < length == the wavelet tree's size: validate_model / validate_blob)
+            const InvView v = wt_inv_view(ix, (uint32_t)p >> 20, inv);
+            Quad ihq = ld_quad(wt_inv_hdr_ptr(ix, v, (uint32_t)p));
+            scell = ld_quad(bv_cell_ptr(ix.base, sv, (uint32_t)p));
+            FMX_PIN_QUAD(ihq);
+            FMX_PIN_QUAD(scell);
+            bool sampled_row;
+            (void)bv_rank1_access_cell(sv, scell, p, sampled_row);
+            if (sampled_row) break;
+            int32_t rank_before;
+            bool exact, suspect = false;
+            const int32_t c = (int32_t)(int16_t)wt_inverse_select_from<false>(ix, (uint32_t)p, v, ihq, rank_before, exact);
+            j = fm_lf_finish<false>(ix, inv, j, c, rank_before, v.bsl, exact, status, suspect);  // FM:532-535
         }
         ++distance;
         if (distance > walk_limit) {  // bounds the walk on a damaged index (see walk_limit above)

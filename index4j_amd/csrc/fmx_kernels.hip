@@ -770,7 +770,7 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk_c(DevIndex ix_global, const int32_t *
                                              int32_t *__restrict__ found, int32_t *__restrict__ lf_steps,
                                              int32_t *__restrict__ status_out, const int32_t *__restrict__ taken,
                                              const PlanRec *__restrict__ order, const uint32_t *__restrict__ order_idle,
-                                             int64_t *__restrict__ set_locs, int64_t set_base) {
+                                             int64_t *__restrict__ set_locs, int64_t set_base, int packings) {
     FMX_FM_INV(ix_global);
     FMX_WITH_SB_CACHE(ix_global, ix);
     __shared__ Quad s_state[kBlock];        // {row, distance, status, pattern}
@@ -781,7 +781,8 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk_c(DevIndex ix_global, const int32_t *
     const int64_t total = idle + ((int64_t)n - idle) * lanes;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     const int32_t walk_limit = fm_walk_limit(ix);
-    const int32_t first = ix.sample_rate / 2 > 0 ? ix.sample_rate / 2 : 1, second = ix.sample_rate / 4 > 0 ? ix.sample_rate / 4 : 1;
+    // instalments: two packings — after sample_rate / 2 and 3 sample_rate / 4 steps — or three, after every quarter (option walk_pack)
+    const int32_t first = packings >= 3 ? ix.sample_rate / 4 : ix.sample_rate / 2, second = ix.sample_rate / 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // (every lane of the workgroup runs the same number of rounds: the barriers below are the workgroup's)
     for (int64_t t0 = (int64_t)blockIdx.x * kBlock; t0 < total; t0 += stride) {
@@ -828,8 +829,8 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk_c(DevIndex ix_global, const int32_t *
             int32_t wp = p;
             int64_t dest = (int64_t)p * loc_cap + (set_locs ? taken_p : 0) + k;
             bool walking = hit;
-            for (int phase = 0; phase < 3; ++phase) {
-                const int32_t budget = phase == 0 ? first : (phase == 1 ? second : 0x7fffffff);
+            for (int phase = 0; phase <= packings; ++phase) {
+                const int32_t budget = phase == packings ? 0x7fffffff : (phase == 0 ? first : second);
                 if (walking && fm_locate_steps_win(ix, w, budget, walk_limit)) {
                     const int32_t at = fm_locate_finish_win(ix, s_inv, w);
                     if (set_locs)
@@ -840,7 +841,7 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk_c(DevIndex ix_global, const int32_t *
                     if (w.status && status_out) atomicOr(&status_out[wp], w.status);
                     walking = false;
                 }
-                if (phase == 2) break;
+                if (phase == packings) break;
                 // pack the walks still under way into the workgroup's first lanes
                 const unsigned long long ball = __ballot(walking ? 1 : 0);
                 if (lane == 0) s_walking[wave] = (uint32_t)__popcll(ball);
@@ -1769,8 +1770,9 @@ int set_option(const char *name, int value) {
         g_block = value;
         return 0;
     }
-    if (!strcmp(name, "walk_pack")) {
-        g_walk_pack = value != 0;
+    if (!strcmp(name, "walk_pack")) {  // 0: k_locate_walk; 1 / 2: two packings; 3: three
+        if (value < 0 || value > 3) return -1;
+        g_walk_pack = value;
         return 0;
     }
     if (!strcmp(name, "groups_per_cu")) {
@@ -2095,8 +2097,9 @@ int launch_locate_walk(const DevIndex &ix, int n_cu, const int32_t *range, int32
     }
     const int64_t tickets = (int64_t)n * (slots < kWalkLanes ? slots : kWalkLanes);
     if (ix.win && g_walk_pack.load() && ix.sample_rate >= 8) {  // a window directory: the packed form (k_locate_walk_c)
+        const int packings = g_walk_pack.load() >= 3 ? 3 : 2;
         FMX_DISPATCH(k_locate_walk_c, tickets, ix, range, n, max_matches, locs, loc_cap, slots, found, lf, status, taken, order, order_idle,
-                     set_locs, set_base);
+                     set_locs, set_base, packings);
         return (int)hipGetLastError();
     }
     FMX_DISPATCH_WIN(k_locate_walk, ix, tickets, ix, range, n, max_matches, locs, loc_cap,
