@@ -175,6 +175,123 @@ public final class GpuFmIndex implements AutoCloseable {
     }
 
     /**
+     * This index on several GPUs of the node (fmx_replicate): FmIndex is immutable and @ThreadSafe (FmIndex.java:82) — index4j's
+     * own throughput benchmark gives every thread an index of its own (FmIndexThroughputState.java:30) — so the image is copied
+     * to every device named (peer copies out of this index's HBM over xGMI, all destinations at once) and a batch is cut into
+     * contiguous shards, one per replica: no exchange on the query path.  A device may be named more than once.  This index stays
+     * usable and is NOT one of the replicas; close both.
+     */
+    public Replicas replicate(int[] devices) {
+        return new Replicas(nativeReplicate(handle, devices));
+    }
+
+    /** The device ordinal this index is resident on (fmx_device_of). */
+    public int device() {
+        return nativeDeviceOf(handle);
+    }
+
+    /**
+     * A replica set: the batch surface of GpuFmIndex with the batch sharded over the replicas by the library
+     * (fmx_*_multi: shard r = fmx_shard_range(n, replicas, r) runs on replica r from a host thread of the library's own and
+     * stores into its slice of the caller's arrays).  Results equal those of the single index, entry by entry.
+     */
+    public static final class Replicas implements AutoCloseable {
+        private long[] handles; // fmx_index* per replica
+
+        private Replicas(long[] handles) {
+            this.handles = handles;
+        }
+
+        public int size() {
+            return handles.length;
+        }
+
+        public int[] countBatch(char[] chars, int[] offsets) {
+            int n = offsets.length - 1;
+            int[] counts = new int[n];
+            int[] status = new int[n];
+            nativeCountBatchMulti(handles, chars, offsets, n, counts, status);
+            for (int s : status) {
+                rethrow(s, 0);
+            }
+            return counts;
+        }
+
+        /** locations: n rows of maxMatches ints; returns the number located per pattern. */
+        public int[] locateBatch(char[] chars, int[] offsets, int maxMatches, int[] locations) {
+            int n = offsets.length - 1;
+            int[] found = new int[n];
+            int[] status = new int[n];
+            nativeLocateBatchMulti(handles, chars, offsets, n, maxMatches, locations, maxMatches, found, status);
+            for (int s : status) {
+                rethrow(s, 0);
+            }
+            return found;
+        }
+
+        /** extract(start[i], stop[i], row i, offset) for every i; rows: n rows of rowLength chars; returns the lengths. */
+        public int[] extractBatch(int[] start, int[] stop, char[] rows, int rowLength, int offset) {
+            int n = start.length;
+            int[] len = new int[n];
+            int[] status = new int[n];
+            nativeExtractBatchMulti(handles, start, stop, n, rows, rowLength, offset, len, status);
+            for (int s : status) {
+                rethrow(s, 0);
+            }
+            return len;
+        }
+
+        /** extractUntilBoundary (mode 0) / Left (1) / Right (2) of every from[i] into row i. */
+        public int[] extractUntilBoundaryBatch(int[] from, char boundary, int mode, char[] rows, int rowLength, int offset) {
+            int n = from.length;
+            int[] len = new int[n];
+            int[] status = new int[n];
+            int[] aux = new int[n];
+            nativeExtractBoundaryBatchMulti(handles, from, n, boundary, mode, rows, rowLength, offset, len, status, aux);
+            for (int i = 0; i < n; i++) {
+                rethrow(status[i], aux[i]);
+            }
+            return len;
+        }
+
+        /**
+         * count() and locate() of one batch over K indexes of one long text (a Java int cannot address 2^31 chars,
+         * FmIndex.java:131), every index replicated on the same devices: segments[s] = replicas of segment s, segmentBase[s] = its
+         * first char in the text.  counts: sums over the segments; locations: n rows of maxMatches longs, segment 0's hits first
+         * (fmx_count_locate_segments_multi).  Returns the number located per pattern.
+         */
+        public static int[] countLocateSegments(Replicas[] segments, long[] segmentBase, char[] chars, int[] offsets,
+                int maxMatches, long[] counts, long[] locations) {
+            int n = offsets.length - 1;
+            int replicas = segments[0].handles.length;
+            long[] flat = new long[replicas * segments.length]; // replica-major
+            for (int r = 0; r < replicas; r++) {
+                for (int s = 0; s < segments.length; s++) {
+                    flat[r * segments.length + s] = segments[s].handles[r];
+                }
+            }
+            int[] found = new int[n];
+            int[] status = new int[n];
+            nativeCountLocateSegmentsMulti(flat, replicas, segments.length, segmentBase, chars, offsets, n, maxMatches, counts,
+                    locations, found, status);
+            for (int s : status) {
+                rethrow(s, 0);
+            }
+            return found;
+        }
+
+        @Override
+        public void close() {
+            if (handles != null) {
+                for (long h : handles) {
+                    nativeFree(h);
+                }
+                handles = null;
+            }
+        }
+    }
+
+    /**
      * FmIndex.write(...) of this index as libfmx emits it (fmx_save): with {@code framed} the ObjectOutputStream form
      * Serialization.writeToByteArray produces (SER:67-79), else the bare DataOutput stream.  Readable by
      * Serialization.readFromByteArray(FmIndex::read, bytes).
@@ -264,6 +381,25 @@ public final class GpuFmIndex implements AutoCloseable {
             int[] status);
 
     private static native void nativeFree(long handle);
+
+    private static native long[] nativeReplicate(long handle, int[] devices);
+
+    private static native int nativeDeviceOf(long handle);
+
+    private static native void nativeCountBatchMulti(long[] handles, char[] chars, int[] offsets, int n, int[] counts,
+            int[] status);
+
+    private static native void nativeLocateBatchMulti(long[] handles, char[] chars, int[] offsets, int n, int maxMatches,
+            int[] locations, int locCap, int[] found, int[] status);
+
+    private static native void nativeExtractBatchMulti(long[] handles, int[] start, int[] stop, int n, char[] destination,
+            int dstLen, int offset, int[] outLen, int[] status);
+
+    private static native void nativeExtractBoundaryBatchMulti(long[] handles, int[] from, int n, char boundary, int mode,
+            char[] destination, int dstLen, int offset, int[] outLen, int[] status, int[] aux);
+
+    private static native void nativeCountLocateSegmentsMulti(long[] handles, int replicas, int segments, long[] segmentBase,
+            char[] chars, int[] offsets, int n, int maxMatches, long[] counts, long[] locations, int[] found, int[] status);
 
     private static native int nativeInputLength(long handle);
 

@@ -278,3 +278,189 @@ JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeCountSegments(
     (*env)->ReleaseIntArrayElements(env, status, ps, 0);
     if (rc != FMX_OK) throw_lib_error(env, rc);
 }
+
+/* ---- replicas: one index on several GPUs (fmx.h "replicas") ---------------------------------------------------------- */
+
+/* a long[] of handles as the array of fmx_index pointers the *_multi calls take (free() it); NULL + exception on failure */
+static const fmx_index **handle_table(JNIEnv *env, jlongArray handles, jlong need) {
+    if (handles == NULL || (*env)->GetArrayLength(env, handles) < 1 || (need > 0 && (jlong)(*env)->GetArrayLength(env, handles) != need)) {
+        bad_args(env, "no replicas, or not replicas x segments handles");
+        return NULL;
+    }
+    jsize k = (*env)->GetArrayLength(env, handles);
+    const fmx_index **t = (const fmx_index **)malloc((size_t)k * sizeof *t);
+    if (!t) {
+        (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/OutOfMemoryError"), "replica table");
+        return NULL;
+    }
+    jlong *ph = (*env)->GetLongArrayElements(env, handles, NULL);
+    for (jsize i = 0; i < k; ++i) t[i] = (const fmx_index *)(intptr_t)ph[i];
+    (*env)->ReleaseLongArrayElements(env, handles, ph, JNI_ABORT);
+    return t;
+}
+
+JNIEXPORT jlongArray JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeReplicate(JNIEnv *env, jclass c, jlong h, jintArray devices) {
+    if (devices == NULL || (*env)->GetArrayLength(env, devices) < 1) {
+        bad_args(env, "no devices");
+        return NULL;
+    }
+    jsize k = (*env)->GetArrayLength(env, devices);
+    fmx_index **made = (fmx_index **)calloc((size_t)k, sizeof *made);
+    if (!made) {
+        (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/OutOfMemoryError"), "replica table");
+        return NULL;
+    }
+    jint *pd = (*env)->GetIntArrayElements(env, devices, NULL);
+    int rc = fmx_replicate((const fmx_index *)(intptr_t)h, (const int32_t *)pd, (int32_t)k, made);
+    (*env)->ReleaseIntArrayElements(env, devices, pd, JNI_ABORT);
+    jlongArray out = NULL;
+    if (rc != FMX_OK) {
+        throw_lib_error(env, rc);
+    } else if ((out = (*env)->NewLongArray(env, k)) != NULL) {
+        jlong *po = (*env)->GetLongArrayElements(env, out, NULL);
+        for (jsize i = 0; i < k; ++i) po[i] = (jlong)(intptr_t)made[i];
+        (*env)->ReleaseLongArrayElements(env, out, po, 0);
+    } else {
+        for (jsize i = 0; i < k; ++i) fmx_free(made[i]);
+    }
+    free(made);
+    return out;
+}
+
+JNIEXPORT jint JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeDeviceOf(JNIEnv *env, jclass c, jlong h) {
+    return fmx_device_of((const fmx_index *)(intptr_t)h);
+}
+
+JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeCountBatchMulti(JNIEnv *env, jclass c, jlongArray handles,
+                                                                                 jcharArray chars, jintArray offsets, jint n,
+                                                                                 jintArray counts, jintArray status) {
+    if (bad_patterns(env, chars, offsets, n) || too_short(env, counts, n, "counts shorter than n") ||
+        too_short(env, status, n, "status shorter than n"))
+        return;
+    const fmx_index **reps = handle_table(env, handles, 0);
+    if (!reps) return;
+    jsize k = (*env)->GetArrayLength(env, handles);
+    jchar *pc = (*env)->GetCharArrayElements(env, chars, NULL);
+    jint *po = (*env)->GetIntArrayElements(env, offsets, NULL);
+    jint *pn = (*env)->GetIntArrayElements(env, counts, NULL);
+    jint *ps = (*env)->GetIntArrayElements(env, status, NULL);
+    int rc = fmx_count_batch_multi(reps, (int32_t)k, (const uint16_t *)pc, (const int32_t *)po, n, (int32_t *)pn, NULL, (int32_t *)ps);
+    free(reps);
+    (*env)->ReleaseCharArrayElements(env, chars, pc, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, offsets, po, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, counts, pn, 0);
+    (*env)->ReleaseIntArrayElements(env, status, ps, 0);
+    if (rc != FMX_OK) throw_lib_error(env, rc);
+}
+
+JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeLocateBatchMulti(JNIEnv *env, jclass c, jlongArray handles,
+                                                                                  jcharArray chars, jintArray offsets, jint n,
+                                                                                  jint maxMatches, jintArray locations, jint locCap,
+                                                                                  jintArray found, jintArray status) {
+    if (bad_patterns(env, chars, offsets, n) || locCap < 0 ||
+        too_short(env, locations, (jlong)n * locCap, "locations shorter than n * locCap") ||
+        too_short(env, found, n, "found shorter than n") || too_short(env, status, n, "status shorter than n"))
+        return;
+    const fmx_index **reps = handle_table(env, handles, 0);
+    if (!reps) return;
+    jsize k = (*env)->GetArrayLength(env, handles);
+    jchar *pc = (*env)->GetCharArrayElements(env, chars, NULL);
+    jint *po = (*env)->GetIntArrayElements(env, offsets, NULL);
+    jint *pl = (*env)->GetIntArrayElements(env, locations, NULL);
+    jint *pf = (*env)->GetIntArrayElements(env, found, NULL);
+    jint *ps = (*env)->GetIntArrayElements(env, status, NULL);
+    int rc = fmx_locate_batch_multi(reps, (int32_t)k, (const uint16_t *)pc, (const int32_t *)po, n, maxMatches, (int32_t *)pl, locCap,
+                                    (int32_t *)pf, NULL, (int32_t *)ps);
+    free(reps);
+    (*env)->ReleaseCharArrayElements(env, chars, pc, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, offsets, po, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, locations, pl, 0);
+    (*env)->ReleaseIntArrayElements(env, found, pf, 0);
+    (*env)->ReleaseIntArrayElements(env, status, ps, 0);
+    if (rc != FMX_OK) throw_lib_error(env, rc);
+}
+
+JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeExtractBatchMulti(JNIEnv *env, jclass c, jlongArray handles,
+                                                                                   jintArray start, jintArray stop, jint n,
+                                                                                   jcharArray dst, jint dstLen, jint offset,
+                                                                                   jintArray outLen, jintArray status) {
+    if (n < 0 || dstLen < 0 || too_short(env, start, n, "start shorter than n") || too_short(env, stop, n, "stop shorter than n") ||
+        too_short(env, dst, (jlong)n * dstLen, "dst shorter than n * dstLen") ||
+        too_short(env, outLen, n, "outLen shorter than n") || too_short(env, status, n, "status shorter than n"))
+        return;
+    const fmx_index **reps = handle_table(env, handles, 0);
+    if (!reps) return;
+    jsize k = (*env)->GetArrayLength(env, handles);
+    jint *pa = (*env)->GetIntArrayElements(env, start, NULL);
+    jint *pb = (*env)->GetIntArrayElements(env, stop, NULL);
+    jchar *pd = (*env)->GetCharArrayElements(env, dst, NULL);
+    jint *pl = (*env)->GetIntArrayElements(env, outLen, NULL);
+    jint *ps = (*env)->GetIntArrayElements(env, status, NULL);
+    int rc = fmx_extract_batch_multi(reps, (int32_t)k, (const int32_t *)pa, (const int32_t *)pb, n, (uint16_t *)pd, dstLen, offset,
+                                     (int32_t *)pl, NULL, (int32_t *)ps);
+    free(reps);
+    (*env)->ReleaseIntArrayElements(env, start, pa, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, stop, pb, JNI_ABORT);
+    (*env)->ReleaseCharArrayElements(env, dst, pd, 0);
+    (*env)->ReleaseIntArrayElements(env, outLen, pl, 0);
+    (*env)->ReleaseIntArrayElements(env, status, ps, 0);
+    if (rc != FMX_OK) throw_lib_error(env, rc);
+}
+
+JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeExtractBoundaryBatchMulti(
+    JNIEnv *env, jclass c, jlongArray handles, jintArray from, jint n, jchar boundary, jint mode, jcharArray dst, jint dstLen,
+    jint offset, jintArray outLen, jintArray status, jintArray aux) {
+    if (n < 0 || dstLen < 0 || too_short(env, from, n, "from shorter than n") ||
+        too_short(env, dst, (jlong)n * dstLen, "dst shorter than n * dstLen") || too_short(env, outLen, n, "outLen shorter than n") ||
+        too_short(env, status, n, "status shorter than n") || too_short(env, aux, n, "aux shorter than n"))
+        return;
+    const fmx_index **reps = handle_table(env, handles, 0);
+    if (!reps) return;
+    jsize k = (*env)->GetArrayLength(env, handles);
+    jint *pa = (*env)->GetIntArrayElements(env, from, NULL);
+    jchar *pd = (*env)->GetCharArrayElements(env, dst, NULL);
+    jint *pl = (*env)->GetIntArrayElements(env, outLen, NULL);
+    jint *ps = (*env)->GetIntArrayElements(env, status, NULL);
+    jint *px = (*env)->GetIntArrayElements(env, aux, NULL);
+    int rc = fmx_extract_boundary_batch_multi(reps, (int32_t)k, (const int32_t *)pa, n, (uint16_t)boundary, mode, (uint16_t *)pd, dstLen,
+                                              offset, (int32_t *)pl, NULL, (int32_t *)ps, (int32_t *)px);
+    free(reps);
+    (*env)->ReleaseIntArrayElements(env, from, pa, JNI_ABORT);
+    (*env)->ReleaseCharArrayElements(env, dst, pd, 0);
+    (*env)->ReleaseIntArrayElements(env, outLen, pl, 0);
+    (*env)->ReleaseIntArrayElements(env, status, ps, 0);
+    (*env)->ReleaseIntArrayElements(env, aux, px, 0);
+    if (rc != FMX_OK) throw_lib_error(env, rc);
+}
+
+/* BASELINE configs[4] from a Java host: handles = replicas x segments, replica-major (fmx_count_locate_segments_multi) */
+JNIEXPORT void JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeCountLocateSegmentsMulti(
+    JNIEnv *env, jclass c, jlongArray handles, jint replicas, jint segments, jlongArray segmentBase, jcharArray chars,
+    jintArray offsets, jint n, jint maxMatches, jlongArray counts, jlongArray locations, jintArray found, jintArray status) {
+    if (replicas < 1 || segments < 1 || maxMatches < 1 || bad_patterns(env, chars, offsets, n) ||
+        too_short(env, segmentBase, segments, "segmentBase shorter than the number of segments") ||
+        too_short(env, counts, n, "counts shorter than n") ||
+        too_short(env, locations, (jlong)n * maxMatches, "locations shorter than n * maxMatches") ||
+        too_short(env, found, n, "found shorter than n") || too_short(env, status, n, "status shorter than n"))
+        return;
+    const fmx_index **segs = handle_table(env, handles, (jlong)replicas * segments);
+    if (!segs) return;
+    jlong *pb = (*env)->GetLongArrayElements(env, segmentBase, NULL);
+    jchar *pc = (*env)->GetCharArrayElements(env, chars, NULL);
+    jint *po = (*env)->GetIntArrayElements(env, offsets, NULL);
+    jlong *pn = (*env)->GetLongArrayElements(env, counts, NULL);
+    jlong *pl = (*env)->GetLongArrayElements(env, locations, NULL);
+    jint *pf = (*env)->GetIntArrayElements(env, found, NULL);
+    jint *ps = (*env)->GetIntArrayElements(env, status, NULL);
+    int rc = fmx_count_locate_segments_multi(segs, replicas, segments, (const int64_t *)pb, (const uint16_t *)pc, (const int32_t *)po, n,
+                                             maxMatches, (int64_t *)pn, NULL, (int64_t *)pl, (int32_t *)pf, (int32_t *)ps);
+    free(segs);
+    (*env)->ReleaseLongArrayElements(env, segmentBase, pb, JNI_ABORT);
+    (*env)->ReleaseCharArrayElements(env, chars, pc, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, offsets, po, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, counts, pn, 0);
+    (*env)->ReleaseLongArrayElements(env, locations, pl, 0);
+    (*env)->ReleaseIntArrayElements(env, found, pf, 0);
+    (*env)->ReleaseIntArrayElements(env, status, ps, 0);
+    if (rc != FMX_OK) throw_lib_error(env, rc);
+}

@@ -83,15 +83,22 @@ int fmx_suffix_table_info(const fmx_index *idx, int32_t *chars, int64_t *bytes);
 
 /* The window directory of a resident index (grown by fmx_to_device / fmx_attach_device_blob beside the image, like the suffix
  * table; option "window_cells": 0 = none, 1 = always, 2 = where it fits a quarter of the device's free memory, the default): one
- * 64-byte cell per 112 consecutive BWT positions holding, for the window's three most frequent symbols, their rank at the window
- * start and the positions they stand at, plus every position's bit of sampledSuffixes (FM:123) — and one 8-byte entry {rank, symbol}
- * per position that holds none of the three.  An LF-step of locate / extract / extractUntilBoundary — inverseSelect (WFBB:1305-1537)
- * of a position, the poll of FM:531, the rank of FM:534 — then costs ONE 64-byte sector, or two, and no walk through the wavelet
- * tree (whose loop over the levels of a code a 64-lane wave runs to the deepest code among its positions); count() does not use it.
- * ~0.57 + 0.2 x 8 = 2.1 bytes per text byte on log text.  Every number in it was checked against the index's own rank() /
- * inverseSelect() (all routes, all quirks) when it was made; what does not pass (a run block's masked symbol, Q1) is left to
- * the tree walk: results, statuses and LF-step counts do not depend on it.  *bytes = its size (0: none). */
+ * 64-byte cell per 112 consecutive BWT positions holding, for the window's three most frequent symbols ("classes"), their folded
+ * rank at the window start and — in two bit planes — the positions they stand at, plus every position's bit of sampledSuffixes
+ * (FM:123) — and one 8-byte entry {next row, symbol, status, suspect} per position that holds none of the three: everything the
+ * LF-step of that row hands back, whatever route of the tree (and whichever of the reference's quirks) it takes.  An LF-step of
+ * locate / extract / extractUntilBoundary — inverseSelect (WFBB:1305-1537) of a position, the poll of FM:531, the rank of FM:534 —
+ * then costs ONE 64-byte sector, or two, and no walk through the wavelet tree, for EVERY row of the index (the tree's loop over
+ * the levels of a code is what a 64-lane wave runs to the deepest code among its positions); count() does not use it.
+ * 0.57 + 0.18 x 8 = 2.0 bytes per text byte on log text.  Every number in it is the step the index's own rank() / inverseSelect()
+ * took when the directory was grown: results, statuses and LF-step counts do not depend on having one.  Budget: option
+ * "window_cells_mb" (default 65,536) caps it in absolute terms beside the quarter-of-free-memory rule of "window_cells" = 2;
+ * fmx_resident_bytes says what an index took.  *bytes = its size (0: none). */
 int fmx_window_cells_info(const fmx_index *idx, int64_t *bytes);
+/* What a resident handle holds in its device's memory, in bytes (each pointer nullable): the image, the suffix table (with its
+ * order-1 statistics), the window directory.  All 0 for a handle that is not resident.  (index4j's own figure for comparison is
+ * the serialized size, FmIndexSerializedSizeBenchmark.java:57: 0.44-0.47 bytes per text byte.) */
+int fmx_resident_bytes(const fmx_index *idx, int64_t *image, int64_t *suffix_table, int64_t *window_directory);
 
 /* FmIndex.read(ObjectInput) FM:983-1025; also accepts the ObjectOutputStream-framed form produced by
  * Serialization.writeToByteArray SER:67-79 (magic AC ED 00 05 + block-data records). */
@@ -278,6 +285,65 @@ int fmx_locate_segments_dev(const fmx_index *const *segs, int32_t n_segs, const 
 int fmx_count_locate_segments_dev(const fmx_index *const *segs, int32_t n_segs, const int64_t *seg_base, const uint16_t *d_pat,
                                   const int32_t *d_pat_off, int32_t n, int32_t max_matches, int64_t *d_counts, int64_t *d_lf_steps,
                                   int64_t *d_locs, int32_t *d_found, int32_t *d_status, int32_t *d_tmp, void *stream);
+
+/* count() AND locate() over a segment set with host buffers (the host form of fmx_count_locate_segments_dev): counts / lf_steps
+ * int64 sums over the segments (lf_steps nullable), locs n rows of max_matches int64 (in / out), found, status (nullable). */
+int fmx_count_locate_segments(const fmx_index *const *segs, int32_t n_segs, const int64_t *seg_base, const uint16_t *pat,
+                              const int32_t *pat_off, int32_t n, int32_t max_matches, int64_t *counts, int64_t *lf_steps,
+                              int64_t *locs, int32_t *found, int32_t *status);
+
+/* ---- replicas: one immutable index on several GPUs, one host process ---------------------------------
+ * FmIndex is immutable and @ThreadSafe (FM:82; the reference's throughput benchmark gives every thread an index of its own,
+ * indices/src/jmh/java/com/dynatrace/fm/FmIndexThroughputState.java:30), and every query of a batch is an independent read: so
+ * the image is REPLICATED on the GPUs of a node and a batch is cut into contiguous shards, one per replica — no exchange on the
+ * query path, the "gather" is that every shard stores into its own slice of the caller's arrays (SURVEY 8e scheme (i)).
+ *
+ * fmx_replicate: out[i] = a new handle, resident on devices[i] (i < n_devices; a device may be named more than once — two
+ * replicas then share it).  The image goes from where `idx` has it — HBM of its device: one peer copy per destination over
+ * xGMI, all destinations at once (root egress over all links, no ring); the host otherwise — and every replica grows its own
+ * suffix table and window directory on its device, in parallel.  `idx` itself is unchanged (it may but need not be resident);
+ * a replica answers every query and accessor, keeps no host model (fmx_save / fmx_blob: FMX_E_ARG) and is freed with fmx_free.
+ * On failure nothing is left behind.  fmx_device_of: the device ordinal a handle is resident on, -1 = not resident. */
+int fmx_replicate(const fmx_index *idx, const int32_t *devices, int32_t n_devices, fmx_index **out);
+int fmx_device_of(const fmx_index *idx);
+/* The shard arithmetic of every *_multi call: items [*lo, *hi) of n belong to part `part` of `parts` (contiguous; sizes differ
+ * by at most one, the first n % parts parts hold the extra item). */
+void fmx_shard_range(int64_t n, int32_t parts, int32_t part, int64_t *lo, int64_t *hi);
+
+/* The host-buffer batch calls over a replica set: arguments as in the single-index forms; shard r — fmx_shard_range(n,
+ * n_replicas, r) — runs on replicas[r] from a host thread of its own (the library keeps one worker per replica slot of a device;
+ * the calling thread takes shard 0), all shards at once, each storing into rows / entries [lo, hi) of the caller's arrays.
+ * Results are those of the single-index call on the whole batch, entry by entry.  Returns the first failing shard's error
+ * (fmx_last_error: its message); the other shards still complete.  Replicas of DIFFERENT indexes are the caller's mistake. */
+int fmx_count_batch_multi(const fmx_index *const *replicas, int32_t n_replicas, const uint16_t *pat, const int32_t *pat_off,
+                          int32_t n, int32_t *counts, int32_t *lf_steps, int32_t *status);
+int fmx_locate_batch_multi(const fmx_index *const *replicas, int32_t n_replicas, const uint16_t *pat, const int32_t *pat_off,
+                           int32_t n, int32_t max_matches, int32_t *locs, int32_t loc_cap, int32_t *found, int32_t *lf_steps,
+                           int32_t *status);
+int fmx_extract_batch_multi(const fmx_index *const *replicas, int32_t n_replicas, const int32_t *start, const int32_t *stop,
+                            int32_t n, uint16_t *dst, int32_t dst_len, int32_t offset, int32_t *out_len, int32_t *lf_steps,
+                            int32_t *status);
+int fmx_extract_boundary_batch_multi(const fmx_index *const *replicas, int32_t n_replicas, const int32_t *from, int32_t n,
+                                     uint16_t boundary, int mode, uint16_t *dst, int32_t dst_len, int32_t offset,
+                                     int32_t *out_len, int32_t *lf_steps, int32_t *status, int32_t *aux);
+/* BASELINE configs[4]: segs = n_replicas x n_segs handles, replica-major (segs[r * n_segs + s] = segment s on replica r's
+ * device: fmx_replicate of every segment index onto the same device list); fmx_count_locate_segments per shard. */
+int fmx_count_locate_segments_multi(const fmx_index *const *segs, int32_t n_replicas, int32_t n_segs, const int64_t *seg_base,
+                                    const uint16_t *pat, const int32_t *pat_off, int32_t n, int32_t max_matches, int64_t *counts,
+                                    int64_t *lf_steps, int64_t *locs, int32_t *found, int32_t *status);
+/* Device-resident shards, asynchronous: entry r of every array is replica r's operand of fmx_count_batch_dev /
+ * fmx_count_locate_segments_dev, resident on that replica's device (n[r] patterns; streams[r] a hipStream_t of that device or
+ * NULL).  The launches of all replicas are issued at once, each from its device's worker thread; the call returns when they are
+ * ENQUEUED.  fmx_multi_synchronize waits for streams[r] on every replica's device.  (What bench.py --single-process times.) */
+int fmx_count_batch_multi_dev(const fmx_index *const *replicas, int32_t n_replicas, const uint16_t *const *d_pat,
+                              const int32_t *const *d_pat_off, const int32_t *n, int32_t *const *d_counts,
+                              int32_t *const *d_lf_steps, int32_t *const *d_status, void *const *streams);
+int fmx_count_locate_segments_multi_dev(const fmx_index *const *segs, int32_t n_replicas, int32_t n_segs, const int64_t *seg_base,
+                                        const uint16_t *const *d_pat, const int32_t *const *d_pat_off, const int32_t *n,
+                                        int32_t max_matches, int64_t *const *d_counts, int64_t *const *d_lf_steps,
+                                        int64_t *const *d_locs, int32_t *const *d_found, int32_t *const *d_status,
+                                        int32_t *const *d_tmp, void *const *streams);
+int fmx_multi_synchronize(const fmx_index *const *replicas, int32_t n_replicas, void *const *streams);
 
 /* ---- WaveletFixedBlockBoosting as a stand-alone structure (the reference's public class, WFBB:130-154) ----
  * `sequence` = symbols already mapped to small non-negative integers (short[] text of WFBB:130).  The handle

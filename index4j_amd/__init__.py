@@ -15,9 +15,10 @@ from .fmindex import (  # noqa: F401
     synth_log_multichar,
     synth_patterns,
 )
+from .replicas import ReplicaSet, SegmentReplicaSet, shard_range  # noqa: F401
 from .rrr import RrrVector  # noqa: F401
 from .segments import SegmentedFmIndex, cut_points  # noqa: F401
 from .wavelet import WaveletFixedBlockBoosting  # noqa: F401
 
-__all__ = ["WaveletFixedBlockBoosting", "RrrVector", "SegmentedFmIndex", "cut_points", "FmIndex", "FmIndexBuilder", "FmxError", "as_chars", "chars_to_str", "pack_patterns",
+__all__ = ["ReplicaSet", "SegmentReplicaSet", "shard_range", "WaveletFixedBlockBoosting", "RrrVector", "SegmentedFmIndex", "cut_points", "FmIndex", "FmIndexBuilder", "FmxError", "as_chars", "chars_to_str", "pack_patterns",
            "raise_for_status", "synth_log", "synth_log_multichar", "synth_patterns", "lib", "LIB_PATH", "SYMBOLS"]

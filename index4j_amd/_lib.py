@@ -31,6 +31,10 @@ SYMBOLS = [
     "fmx_count_batch_dev", "fmx_count_plan_dev", "fmx_count_ordered_dev", "fmx_count_batch_is_planned", "fmx_batch_policy", "fmx_locate_batch_dev", "fmx_extract_batch_dev", "fmx_extract_boundary_batch_dev",
     "fmx_locate_extract_batch", "fmx_locate_lines_batch", "fmx_locate_extract_batch_dev", "fmx_locate_lines_batch_dev",
     "fmx_count_segments", "fmx_locate_segments", "fmx_count_segments_dev", "fmx_locate_segments_dev", "fmx_count_locate_segments_dev",
+    "fmx_count_locate_segments", "fmx_resident_bytes",
+    "fmx_replicate", "fmx_device_of", "fmx_shard_range", "fmx_count_batch_multi", "fmx_locate_batch_multi", "fmx_extract_batch_multi",
+    "fmx_extract_boundary_batch_multi", "fmx_count_locate_segments_multi", "fmx_count_batch_multi_dev",
+    "fmx_count_locate_segments_multi_dev", "fmx_multi_synchronize",
     "fmx_wavelet_build", "fmx_wavelet_rank_batch", "fmx_wavelet_inverse_select_batch",
     "fmx_rrr_build", "fmx_rrr_rank_ones_batch", "fmx_rrr_access_batch", "fmx_rrr_rank_ones_batch_dev", "fmx_rrr_access_batch_dev",
     "fmx_convert_byte_pattern", "fmx_status_message", "fmx_status_kind", "fmx_last_error", "fmx_release_scratch", "fmx_device_count", "fmx_set_option",
@@ -91,6 +95,20 @@ def _load():
     L.fmx_count_segments_dev.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     L.fmx_locate_segments_dev.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
     L.fmx_count_locate_segments_dev.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.fmx_count_locate_segments.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
+    L.fmx_resident_bytes.argtypes = [vp, P(C.c_int64), P(C.c_int64), P(C.c_int64)]
+    L.fmx_replicate.argtypes = [vp, vp, i32, vp]
+    L.fmx_device_of.argtypes = [vp]
+    L.fmx_shard_range.argtypes = [C.c_int64, i32, i32, P(C.c_int64), P(C.c_int64)]
+    L.fmx_shard_range.restype = None
+    L.fmx_count_batch_multi.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp]
+    L.fmx_locate_batch_multi.argtypes = [vp, i32, vp, vp, i32, i32, vp, i32, vp, vp, vp]
+    L.fmx_extract_batch_multi.argtypes = [vp, i32, vp, vp, i32, vp, i32, i32, vp, vp, vp]
+    L.fmx_extract_boundary_batch_multi.argtypes = [vp, i32, vp, i32, u16, C.c_int, vp, i32, i32, vp, vp, vp, vp]
+    L.fmx_count_locate_segments_multi.argtypes = [vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
+    L.fmx_count_batch_multi_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.fmx_count_locate_segments_multi_dev.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.fmx_multi_synchronize.argtypes = [vp, i32, vp]
     L.fmx_wavelet_build.argtypes = [vp, C.c_int64, i32, P(vp)]
     L.fmx_wavelet_rank_batch.argtypes = [vp, vp, vp, i32, vp, vp]
     L.fmx_wavelet_inverse_select_batch.argtypes = [vp, vp, i32, vp, vp]

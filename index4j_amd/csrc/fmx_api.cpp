@@ -159,8 +159,11 @@ std::atomic<int> g_plan_sa_key_api{2};     // mirror of the kernels' option "pla
 std::atomic<int> g_suffix_table_in_use{1};  // mirror of the kernels' A/B option "suffix_table": launches told to ignore the table plan as if there were none
 std::atomic<int> g_suffix_table_image_fraction{8};  // option "suffix_table_image_fraction": the table stays below image / this (0 = only the budget counts)
 // option "window_cells": indexes made resident afterwards grow a window directory (fmx_device.hpp "window directory": 64 bytes per
-// 120 text characters beside the image) — 0 = none, 1 = always, 2 (default) = where it fits a quarter of the device's free memory
+// 112 text characters + 8 per position no class holds, beside the image) — 0 = none, 1 = always, 2 (default) = where it fits a
+// quarter of the device's free memory AND the absolute budget "window_cells_mb" (per index; default 65,536 MiB: a process that
+// holds many indexes lowers it, or the quarter rule shrinks what is free geometrically)
 std::atomic<int> g_window_cells{2};
+std::atomic<int> g_window_cells_mb{65536};
 // host-buffer count(): batches of at least this many patterns go through the pipeline (smaller ones: one copy in, kernels, one copy out)
 std::atomic<int> g_host_pipeline_min{131072};
 std::atomic<int> g_host_mapped{1};  // option "host_mapped": every array of a host-buffer count registered -> one launch over the mapped arrays, no copies
@@ -278,6 +281,7 @@ int require_device(const fmx_index *idx, bool rrr_handle = false) {
 constexpr int kWsPlan = 0, kWsBoundary = 1, kWsWalk = 2, kWsSegRange = 3, kWsSegCounts = 4;  // (kWsWalk: the walk order of locate, a plan-like head; kWsSegRange: a segment set's second {found, status, range} buffers)
 std::atomic<int> g_segments_direct{1};   // option "segments_direct": 0 = every segment's hits staged and appended (A/B)
 std::atomic<int> g_segments_overlap{1};  // option "segments_overlap": 0 = a segment set's kernels all on the caller's stream (A/B)
+std::atomic<int> g_segments_overlap_min{262144};  // option "segments_overlap_min": ... and only for batches at least this large
 
 // the side stream of `stream` with at least n_events events (nullptr: could not be made — the caller stays on one stream)
 fmx_index::SideLane *side_lane(const fmx_index *idx, void *stream, size_t n_events) {
@@ -335,6 +339,10 @@ int check_offsets(const int32_t *pat_off, int32_t n) {
 }
 
 #define H2D(dst, src, bytes) HIP_TRY(hipMemcpy((dst), (src), (bytes), hipMemcpyHostToDevice))
+// A batch refers to the characters [pat_off[0], pat_off[n]) of `pat`: only those travel, to the same element offsets of the device
+// copy — a shard of a larger batch (fmx_*_multi hands pat_off + lo to the single-index call) ships its own characters, not
+// everything before them.  (check_offsets has seen pat_off[0] >= 0.)
+static inline size_t first_char(const int32_t *pat_off) { return (size_t)(pat_off[0] > 0 ? pat_off[0] : 0); }
 #define D2H(dst, src, bytes) HIP_TRY(hipMemcpy((dst), (src), (bytes), hipMemcpyDeviceToHost))
 
 // Device scratch of the host-buffer entry points.  hipMalloc / hipFree cost more than a small batch's kernels, so
@@ -613,6 +621,11 @@ static int guarded(F &&body) {
     }
 }
 
+// fmx_multi.cpp: a shard's failure, reported by a worker thread, becomes the CALLING thread's fmx_last_error
+namespace fmx {
+int api_fail(int code, const std::string &msg) { return fail(code, msg); }
+}  // namespace fmx
+
 extern "C" {
 
 const char *fmx_last_error(void) { return g_err.c_str(); }
@@ -688,6 +701,16 @@ int fmx_set_option(const char *name, int value) {
     if (name && !strcmp(name, "window_cells")) {  // window directory of indexes made resident from now on: 0 none, 1 always, 2 if it fits
         if (value < 0 || value > 2) return fail(FMX_E_ARG, "bad value");
         g_window_cells = value;
+        return FMX_OK;
+    }
+    if (name && !strcmp(name, "window_cells_mb")) {  // absolute budget of one index's window directory under "window_cells" = 2
+        if (value < 0) return fail(FMX_E_ARG, "bad value");
+        g_window_cells_mb = value;
+        return FMX_OK;
+    }
+    if (name && !strcmp(name, "segments_overlap_min")) {  // smallest batch whose segment searches run beside the walks (side stream)
+        if (value < 0) return fail(FMX_E_ARG, "bad value");
+        g_segments_overlap_min = value;
         return FMX_OK;
     }
     if (name && !strcmp(name, "cells_split_blocks")) {  // tests: chunked decoding of short vectors too (same image)
@@ -817,17 +840,26 @@ int fmx_save_key_order_modelled(const fmx_index *idx) {
 
 void fmx_free_buffer(uint8_t *buf) { free(buf); }
 
-void fmx_free(fmx_index *idx) {
-    if (!idx) return;
+// Everything a handle owns on its device: freed on THAT device (fmx_free; fmx_to_device when the index moves to another GPU —
+// every one of these pointers, DevIndex.self included, is an address in the old device's HBM that a kernel on the new device
+// must never be handed).
+static void release_device_state(fmx_index *idx) {
     if (idx->device >= 0) (void)hipSetDevice(idx->device);
     for (auto &kv : idx->ws)
         if (kv.second.first) (void)hipFree(kv.second.first);
+    idx->ws.clear();
+    idx->plans.clear();
     if (idx->owns_device && idx->d_blob) (void)hipFree(idx->d_blob);
     if (idx->d_suffix_table) (void)hipFree(idx->d_suffix_table);
     if (idx->d_suffix_order1) (void)hipFree(idx->d_suffix_order1);
     if (idx->d_self) (void)hipFree(idx->d_self);
     if (idx->d_win) (void)hipFree(idx->d_win);
     if (idx->d_win_other) (void)hipFree(idx->d_win_other);
+    idx->d_blob = idx->d_suffix_table = idx->d_suffix_order1 = idx->d_self = idx->d_win = idx->d_win_other = nullptr;
+    idx->d_len = 0;
+    idx->win_bytes = idx->suffix_table_bytes = 0;
+    idx->owns_device = false;
+    idx->dev = fmx::DevIndex();
     for (auto &kv : idx->side) {
         for (hipEvent_t e : kv.second.ev) (void)hipEventDestroy(e);
         if (kv.second.s) {
@@ -835,6 +867,13 @@ void fmx_free(fmx_index *idx) {
             (void)hipStreamDestroy(kv.second.s);
         }
     }
+    idx->side.clear();
+    idx->device = -1;
+}
+
+void fmx_free(fmx_index *idx) {
+    if (!idx) return;
+    release_device_state(idx);
     delete idx;
 }
 
@@ -862,9 +901,10 @@ static void build_window_cells(fmx_index *idx) {
     if (mode == 0 || idx->rrr_only || idx->wavelet_only || idx->hdr.kind != 0 || idx->hdr.wt_size <= 0 || !idx->dev.self) return;
     const size_t cells = fmx::win_cells_for((uint32_t)idx->hdr.wt_size);
     const size_t bytes = cells * 64;
-    if (mode == 2) {  // cells + (at worst) an entry per position must fit a quarter of what is free
+    if (mode == 2) {  // cells + (at worst) an entry per position must fit a quarter of what is free, and the absolute budget
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes + (size_t)idx->hdr.wt_size * 8 > free_b / 4) {
+        const size_t worst = bytes + (size_t)idx->hdr.wt_size * 8;
+        if (worst > ((size_t)g_window_cells_mb.load() << 20) || hipMemGetInfo(&free_b, &total_b) != hipSuccess || worst > free_b / 4) {
             (void)hipGetLastError();
             return;
         }
@@ -921,6 +961,22 @@ int fmx_window_cells_info(const fmx_index *idx, int64_t *bytes) {
     return FMX_OK;
     });
 }
+
+int fmx_resident_bytes(const fmx_index *idx, int64_t *image, int64_t *suffix_table, int64_t *window_directory) {
+    return guarded([&]() -> int {
+    if (!idx) return fail(FMX_E_ARG, "null index");
+    const bool resident = idx->d_blob != nullptr;
+    if (image) *image = resident ? (int64_t)idx->d_len : 0;
+    if (suffix_table)
+        *suffix_table = resident ? (int64_t)idx->suffix_table_bytes +
+                                       (idx->d_suffix_order1 ? (int64_t)idx->hdr.wt_sigma * idx->hdr.wt_sigma * 2 * (int64_t)sizeof(float) : 0)
+                                 : 0;
+    if (window_directory) *window_directory = resident ? (int64_t)idx->win_bytes : 0;
+    return FMX_OK;
+    });
+}
+
+int fmx_device_of(const fmx_index *idx) { return (idx && idx->d_blob) ? idx->device : -1; }
 
 // The suffix table of a resident FM-index (fmx_device.hpp): grown level by level on the device — the strings of 2, 3, ... codes
 // that occur in the text, each with its SA interval — and ALL levels hashed into one table of 16-byte slots (a pattern shorter
@@ -1098,11 +1154,14 @@ int fmx_to_device(fmx_index *idx, int device) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(FMX_E_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= n) return fail(FMX_E_ARG, "device ordinal out of range");
-    HIP_TRY(hipSetDevice(device));
-    if (idx->owns_device && idx->d_blob) {
-        (void)hipFree(idx->d_blob);
-        idx->d_blob = nullptr;
+    // a handle that is already resident — here or on another GPU — first gives back what it holds THERE: the image, the suffix
+    // table, the window directory, DevIndex.self (the cold routes' resident copy) and the per-stream scratch are addresses in that
+    // device's memory.  (An attached image stays the caller's; the handle merely lets go of it.)
+    if (idx->device >= 0 || idx->d_blob) {
+        (void)hipDeviceSynchronize();
+        release_device_state(idx);
     }
+    HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipMalloc(&idx->d_blob, idx->blob.size()));
     idx->owns_device = true;
     idx->d_len = idx->blob.size();
@@ -1152,6 +1211,105 @@ int fmx_attach_device_blob(void *device_blob, size_t len, int device, fmx_index 
     build_window_cells(idx.get());
     build_suffix_table(idx.get());
     *out = idx.release();
+    return FMX_OK;
+    });
+}
+
+// One immutable index on several GPUs of the node (fmx.h "replicas").  Every destination is served by a host thread of its own:
+// allocation, the copy of the image — a peer copy out of the source's HBM where `src` is resident (the destinations pull at once:
+// the source's egress goes over all its xGMI links, no ring), from the host image otherwise — and the growth of the replica's
+// own window directory and suffix table.  The image needs no validation here: it is this process's own (an image from a caller's
+// bytes was validated when it was flattened or attached).
+int fmx_replicate(const fmx_index *src_c, const int32_t *devices, int32_t n_devices, fmx_index **out) {
+    return guarded([&]() -> int {
+    fmx_index *src = const_cast<fmx_index *>(src_c);
+    if (!src || !devices || !out || n_devices < 1) return fail(FMX_E_ARG, "bad arguments");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(FMX_E_NO_DEVICE, "no HIP device visible");
+    for (int32_t i = 0; i < n_devices; ++i)
+        if (devices[i] < 0 || devices[i] >= n_dev) return fail(FMX_E_ARG, "device ordinal out of range");
+    const bool from_device = src->d_blob != nullptr;
+    if (!from_device) {
+        int rc = ensure_blob(src);
+        if (rc) return rc;
+    }
+    const size_t len = from_device ? src->d_len : src->blob.size();
+    int caller_device = 0;
+    (void)hipGetDevice(&caller_device);
+    if (from_device) {  // whatever is still being written into the source image's neighbourhood is none of ours; its copy-in is done
+        HIP_TRY(hipSetDevice(src->device));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    std::vector<std::unique_ptr<fmx_index>> made((size_t)n_devices);
+    std::vector<int> rcs((size_t)n_devices, FMX_OK);
+    std::vector<std::string> errs((size_t)n_devices);
+    auto make_one = [&](int32_t i) {
+        auto failed = [&](int rc) {
+            rcs[(size_t)i] = rc;
+            errs[(size_t)i] = g_err;  // (this thread's message: handed to the caller's thread below)
+        };
+        std::unique_ptr<fmx_index> idx(new (std::nothrow) fmx_index());
+        if (!idx) return failed(fail(FMX_E_NOMEM, "out of memory"));
+        const int device = devices[i];
+        auto hip_ok = [&](hipError_t e, const char *what) {
+            if (e == hipSuccess) return true;
+            failed(fail(FMX_E_HIP, std::string(what) + ": " + hipGetErrorString(e)));
+            return false;
+        };
+        if (!hip_ok(hipSetDevice(device), "hipSetDevice")) return;
+        idx->hdr = src->hdr;
+        idx->rrr_only = src->rrr_only;
+        idx->wavelet_only = src->wavelet_only;
+        idx->device = device;
+        if (!hip_ok(hipMalloc(&idx->d_blob, len), "hipMalloc (replica image)")) {
+            idx->device = -1;
+            return;
+        }
+        idx->owns_device = true;
+        idx->d_len = len;
+        hipError_t e;
+        if (!from_device)
+            e = hipMemcpy(idx->d_blob, src->blob.data(), len, hipMemcpyHostToDevice);
+        else if (device == src->device)
+            e = hipMemcpy(idx->d_blob, src->d_blob, len, hipMemcpyDeviceToDevice);
+        else
+            e = hipMemcpyPeer(idx->d_blob, device, src->d_blob, src->device, len);
+        if (!hip_ok(e, "copy of the image to the replica's device")) {
+            release_device_state(idx.get());
+            return;
+        }
+        hipDeviceProp_t prop;
+        if (!hip_ok(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties")) {
+            release_device_state(idx.get());
+            return;
+        }
+        idx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        make_dev_index(idx.get());
+        if (int rc = publish_dev_index(idx.get())) {
+            failed(rc);
+            release_device_state(idx.get());
+            return;
+        }
+        build_window_cells(idx.get());
+        build_suffix_table(idx.get());
+        made[(size_t)i] = std::move(idx);
+    };
+    {
+        std::vector<std::thread> threads;
+        for (int32_t i = 1; i < n_devices; ++i) threads.emplace_back(make_one, i);
+        make_one(0);
+        for (std::thread &t : threads) t.join();
+    }
+    (void)hipSetDevice(caller_device);
+    for (int32_t i = 0; i < n_devices; ++i)
+        if (rcs[(size_t)i] != FMX_OK || !made[(size_t)i]) {
+            for (auto &m : made)
+                if (m) release_device_state(m.get());
+            (void)hipSetDevice(caller_device);
+            return fail(rcs[(size_t)i] ? rcs[(size_t)i] : FMX_E_HIP,
+                        "replica on device " + std::to_string(devices[i]) + ": " + errs[(size_t)i]);
+        }
+    for (int32_t i = 0; i < n_devices; ++i) out[i] = made[(size_t)i].release();
     return FMX_OK;
     });
 }
@@ -1578,11 +1736,11 @@ static int locate_segments_impl(const fmx_index *const *segs, int32_t n_segs, co
     // patterns: only for batches that large, and only for the per-stream form (a host call's own stream lives for one call).
     int32_t *set_found[2] = {seg_found, nullptr}, *set_status[2] = {seg_status, nullptr}, *set_range[2] = {range, nullptr};
     fmx_index::SideLane *lane = nullptr;
-    if (g_segments_overlap && !scratch.per_call && n_segs > 1 && n >= 262144) {
+    if (g_segments_overlap && !scratch.per_call && n_segs > 1 && n >= g_segments_overlap_min.load()) {
         void *second = nullptr;
         rc = scratch.get(kWsSegRange, (size_t)n * 4 * sizeof(int32_t), &second);
         if (rc) return rc;
-        lane = side_lane(segs[0], scratch.stream, 2 * (size_t)n_segs + 1);
+        lane = side_lane(segs[0], scratch.stream, 2 * (size_t)n_segs + 2);  // (+ 1: LaneJoin's own)
         if (lane) {
             set_found[1] = static_cast<int32_t *>(second);
             set_status[1] = set_found[1] + n;
@@ -1601,6 +1759,23 @@ static int locate_segments_impl(const fmx_index *const *segs, int32_t n_segs, co
             set_lf[b] = set_cnt[b] + n;
         }
     }
+    // Whatever leaves this function early (a failed launch, event or wait) must not leave the side stream's range search running
+    // on the set buffers and the plan records behind the caller's back: the caller's stream is made to wait for the side stream
+    // (the last event of the lane serves; failing that, the host waits), so that the next call on `st` — or
+    // fmx_release_scratch — finds them idle.
+    struct LaneJoin {
+        fmx_index::SideLane *lane;
+        hipStream_t st;
+        bool done = false;
+        ~LaneJoin() {
+            if (!lane || done) return;
+            hipEvent_t last = lane->ev.back();
+            if (hipEventRecord(last, lane->s) != hipSuccess || hipStreamWaitEvent(st, last, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(lane->s);
+            }
+        }
+    } lane_join{lane, st};
     auto count_into = [&](int32_t s, hipStream_t on) {
         const int b = lane ? s & 1 : 0;
         return k_launch_count(segs[s], segs[s]->dev, segs[s]->n_cu, d_pat, d_pat_off, &plan, s != 0, n,
@@ -1649,6 +1824,7 @@ static int locate_segments_impl(const fmx_index *const *segs, int32_t n_segs, co
         if (e) return fail(FMX_E_HIP, std::string("k_segment_append_hits / k_segment_commit launch: ") + hipGetErrorString((hipError_t)e));
         if (lane && s + 2 < n_segs) HIP_TRY(hipEventRecord(ev(1 + (size_t)n_segs + (size_t)s), st));
     }
+    lane_join.done = true;  // (every search of the side stream has been waited for by the walk that read its ranges)
     return FMX_OK;
 }
 
@@ -1701,7 +1877,7 @@ int fmx_count_segments(const fmx_index *const *segs, int32_t n_segs, const uint1
     HIP_TRY(d_lf.alloc((size_t)n * 8));
     HIP_TRY(d_st.alloc((size_t)n * 4));
     HIP_TRY(d_tmp.alloc((size_t)n * 12));
-    if (chars) H2D(d_pat.p, pat, chars * 2);
+    if (chars > first_char(pat_off)) H2D(d_pat.as<uint16_t>() + first_char(pat_off), pat + first_char(pat_off), (chars - first_char(pat_off)) * 2);
     H2D(d_off.p, pat_off, (size_t)(n + 1) * 4);
     rc = count_segments_impl(segs, n_segs, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, d_cnt.as<int64_t>(),
                              d_lf.as<int64_t>(), d_st.as<int32_t>(), d_tmp.as<int32_t>(), scratch);
@@ -1742,7 +1918,7 @@ int fmx_locate_segments(const fmx_index *const *segs, int32_t n_segs, const int6
     HIP_TRY(d_found.alloc((size_t)n * 4));
     HIP_TRY(d_st.alloc((size_t)n * 4));
     HIP_TRY(d_tmp.alloc(((size_t)n * 4 + slots) * 4));
-    if (chars) H2D(d_pat.p, pat, chars * 2);
+    if (chars > first_char(pat_off)) H2D(d_pat.as<uint16_t>() + first_char(pat_off), pat + first_char(pat_off), (chars - first_char(pat_off)) * 2);
     H2D(d_off.p, pat_off, (size_t)(n + 1) * 4);
     H2D(d_locs.p, locs, slots * 8);  // in/out: slots without a hit keep the caller's values
     rc = locate_segments_impl(segs, n_segs, seg_base, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, max_matches,
@@ -1750,6 +1926,53 @@ int fmx_locate_segments(const fmx_index *const *segs, int32_t n_segs, const int6
                               scratch);
     HIP_TRY(hipStreamSynchronize(hs.s));
     if (rc) return rc;
+    D2H(locs, d_locs.p, slots * 8);
+    D2H(found, d_found.p, (size_t)n * 4);
+    if (status) D2H(status, d_st.p, (size_t)n * 4);
+    return FMX_OK;
+    });
+}
+
+int fmx_count_locate_segments(const fmx_index *const *segs, int32_t n_segs, const int64_t *seg_base, const uint16_t *pat,
+                              const int32_t *pat_off, int32_t n, int32_t max_matches, int64_t *counts, int64_t *lf_steps,
+                              int64_t *locs, int32_t *found, int32_t *status) {
+    return guarded([&]() -> int {
+    int rc = segments_ok(segs, n_segs);
+    if (rc) return rc;
+    if (n < 0 || max_matches < 1 || !seg_base || (int64_t)n * max_matches > INT32_MAX ||
+        (n > 0 && (!pat_off || !locs || !found || !counts)))
+        return fail(FMX_E_ARG, "bad arguments");
+    if (n == 0) return FMX_OK;
+    HIP_TRY(hipSetDevice(segs[0]->device));
+    rc = check_offsets(pat_off, n);
+    if (rc) return rc;
+    const size_t chars = (size_t)(pat_off[n] > 0 ? pat_off[n] : 0);
+    const size_t slots = (size_t)n * (size_t)max_matches;
+    DevBuf d_pat, d_off, d_cnt, d_lf, d_locs, d_found, d_st, d_tmp;
+    HostCallStream hs;
+    rc = hs.init(segs[0]->device);
+    if (rc) return rc;
+    Scratch scratch(segs[0], hs.s, true);
+    HostCallStream wait_first;  // (destroyed before the scratch above: the stream is drained, then the blocks go back)
+    wait_first.s = hs.s;
+    HIP_TRY(d_pat.alloc(chars * 2 + 8));
+    HIP_TRY(d_off.alloc((size_t)(n + 1) * 4));
+    HIP_TRY(d_cnt.alloc((size_t)n * 8));
+    HIP_TRY(d_lf.alloc((size_t)n * 8));
+    HIP_TRY(d_locs.alloc(slots * 8));
+    HIP_TRY(d_found.alloc((size_t)n * 4));
+    HIP_TRY(d_st.alloc((size_t)n * 4));
+    HIP_TRY(d_tmp.alloc(((size_t)n * 4 + slots) * 4));
+    if (chars > first_char(pat_off)) H2D(d_pat.as<uint16_t>() + first_char(pat_off), pat + first_char(pat_off), (chars - first_char(pat_off)) * 2);
+    H2D(d_off.p, pat_off, (size_t)(n + 1) * 4);
+    H2D(d_locs.p, locs, slots * 8);  // in/out: slots without a hit keep the caller's values
+    rc = locate_segments_impl(segs, n_segs, seg_base, d_pat.as<uint16_t>(), d_off.as<int32_t>(), n, max_matches,
+                              d_locs.as<int64_t>(), d_found.as<int32_t>(), d_st.as<int32_t>(), d_tmp.as<int32_t>(), scratch,
+                              d_cnt.as<int64_t>(), lf_steps ? d_lf.as<int64_t>() : nullptr);
+    HIP_TRY(hipStreamSynchronize(hs.s));
+    if (rc) return rc;
+    D2H(counts, d_cnt.p, (size_t)n * 8);
+    if (lf_steps) D2H(lf_steps, d_lf.p, (size_t)n * 8);
     D2H(locs, d_locs.p, slots * 8);
     D2H(found, d_found.p, (size_t)n * 4);
     if (status) D2H(status, d_st.p, (size_t)n * 4);
@@ -2125,7 +2348,7 @@ int fmx_count_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pa
     HIP_TRY(d_cnt.alloc((size_t)n * 4));
     HIP_TRY(d_lf.alloc((size_t)n * 4));
     HIP_TRY(d_st.alloc((size_t)n * 4));
-    if (chars) H2D(d_pat.p, pat, chars * 2);
+    if (chars > first_char(pat_off)) H2D(d_pat.as<uint16_t>() + first_char(pat_off), pat + first_char(pat_off), (chars - first_char(pat_off)) * 2);
     H2D(d_off.p, pat_off, (size_t)(n + 1) * 4);
     HostCallStream hs;
     rc = hs.init(idx->device);
@@ -2183,7 +2406,8 @@ int fmx_locate_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *p
         hipStream_t s;   // return to their cache
         ~SyncOnExit() { (void)hipStreamSynchronize(s); }
     } sync_on_exit{st};
-    if (chars && !pat_mapped) HIP_TRY(hipMemcpyAsync(d_pat.p, pat, chars * 2, hipMemcpyHostToDevice, st));
+    if (chars > first_char(pat_off) && !pat_mapped)
+        HIP_TRY(hipMemcpyAsync(d_pat.as<uint16_t>() + first_char(pat_off), pat + first_char(pat_off), (chars - first_char(pat_off)) * 2, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_off.p, pat_off, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
     // `locations` is in/out (FM:504: the caller's array; slots beyond the hits keep the caller's values): unmapped it travels up
     // and down whole.  (Bringing the rows back through pinned staging and copying found[i] slots per row instead was measured
@@ -2242,7 +2466,7 @@ static int locate_pipeline_host(const fmx_index *idx, const uint16_t *pat, const
         hipStream_t s;
         ~SyncOnExit() { (void)hipStreamSynchronize(s); }
     } sync_on_exit{st};
-    if (chars) H2D(d_pat.p, pat, chars * 2);
+    if (chars > first_char(pat_off)) H2D(d_pat.as<uint16_t>() + first_char(pat_off), pat + first_char(pat_off), (chars - first_char(pat_off)) * 2);
     H2D(d_off.p, pat_off, (size_t)(n + 1) * 4);
     // rows and per-hit arrays are in/out like the reference's caller-owned arrays: slots without a hit keep
     // the caller's values

@@ -40,6 +40,7 @@ struct JNINativeInterface_ {
     jint (*ThrowNew)(JNIEnv *env, jclass clazz, const char *msg);
     jsize (*GetArrayLength)(JNIEnv *env, jarray array);
     jbyteArray (*NewByteArray)(JNIEnv *env, jsize len);
+    jlongArray (*NewLongArray)(JNIEnv *env, jsize len);
     jbyte *(*GetByteArrayElements)(JNIEnv *env, jbyteArray array, jboolean *isCopy);
     jchar *(*GetCharArrayElements)(JNIEnv *env, jcharArray array, jboolean *isCopy);
     jint *(*GetIntArrayElements)(JNIEnv *env, jintArray array, jboolean *isCopy);

@@ -105,6 +105,42 @@ def test_config1_unplanned_and_planned_paths_agree(idx32, batch):
         assert (c2 == cnt[lo:lo + k]).all() and (s2 == 0).all()
 
 
+
+def test_config1_over_two_replicas_through_the_c_abi(idx32, batch):
+    """the 1,048,576-pattern batch sharded over a replica set by the library (fmx_replicate + fmx_count_batch_multi
+    / fmx_locate_batch_multi): two replicas on the one GPU of the box = the code path of two GPUs (own images, tables, worker
+    threads), equal to the single-device call and to the oracle, entry by entry"""
+    pat, off, _ = batch
+    rs = ia.ReplicaSet(idx32.fm, [0, 0])
+    try:
+        res = rs.resident_bytes()
+        assert res[0] == res[1] and res[0][0] == idx32.fm.device_blob()[1] and res[0][1] > 0 and res[0][2] > 0
+        cnt, st, lf = rs.count_batch(pat, off, want_steps=True)
+        c1, s1, lf1 = idx32.fm.count_batch(pat, off, want_steps=True)
+        oc, ost = idx32.oracle.count_batch(pat, off, threads=CORES)
+        assert (cnt == c1).all() and (st == s1).all() and (lf == lf1).all()
+        assert (cnt == oc).all() and (st == ost).all()
+        K = 100_001  # configs[2] + 1: an odd batch
+        locs, found, st2 = rs.locate_batch(pat[: K * M], off[: K + 1], 16)
+        olocs, ofound, ost2 = idx32.oracle.locate_batch(pat[: K * M], off[: K + 1], 16, threads=CORES)
+        assert (found == ofound).all() and (st2 == ost2).all() and (locs == olocs).all()
+    finally:
+        rs.close()
+
+
+def test_host_builder_and_device_builder_give_the_same_bytes_at_2_to_28(idx32, text256):
+    """at 256 MiB the oracle reads the DEVICE builder's index.  The host builder (SA-IS, fmx_build) is an
+    independent construction — its serialized bytes equal the device builder's at this size too (byte identity of both with the
+    oracle's own builder is asserted up to 16 MiB in test_gpu_parity.py)"""
+    import hashlib
+
+    host = ia.FmIndex(text256, 32, True, device=None)
+    try:
+        assert hashlib.sha256(host.write(False)).hexdigest() == hashlib.sha256(idx32.ser).hexdigest()
+    finally:
+        host.close()
+
+
 def test_config2_locate_100k_every_position_in_sa_order(idx32, batch, text256):
     pat, off, _ = batch
     K = 100_000
@@ -208,7 +244,8 @@ def test_config3_extract_until_boundary_100k_on_sample_rate_64(text256, batch):
 def test_config4_share_over_8_segments_vs_8_oracle_indexes():
     """2 GiB as 8 segment indexes, all resident on this GPU (SURVEY §8e scheme (i)): counts summed over the
     segments and base-shifted hits of the whole per-GPU share of the 8M batch (1,048,576 patterns) against 8 oracle
-    indexes; segments 1..7 look their own suffix tables up with translated code words"""
+    indexes; segments 1..7 look their own suffix tables up with translated code words.  Then the same share over two replicas
+    of the segment set through the C ABI, and configs[4] held by ONE GPU (the whole 8,388,608-pattern batch in one call)."""
     K = 8
     texts = workload.segment_texts(K, 28)
     sf = workload.build_segment_set(texts, 32, device=0, build_device=0)
@@ -216,30 +253,89 @@ def test_config4_share_over_8_segments_vs_8_oracle_indexes():
         assert sum(len(t) for t in texts) > (1 << 31) - (1 << 20)  # a text one FmIndex cannot hold
         n = 1 << 20
         pat, off = workload.segment_patterns(texts, n, M)
+        # the 8M batch of configs[4] and the sample of it the oracles answer (every 419th pattern + the last one)
+        n8, mm = 1 << 23, 16
+        pat8, off8 = workload.segment_patterns(texts, n8, M, seed=workload.PATTERN_SEED + 1)
+        sample = np.unique(np.concatenate([np.arange(0, n8, 419), [n8 - 1]]))
+        assert len(sample) >= 20_000
+        spat = np.ascontiguousarray(pat8.reshape(n8, M)[sample]).reshape(-1)
+        soff = (np.arange(len(sample) + 1, dtype=np.int64) * M).astype(np.int32)
         assert all(f.suffix_table_info()[0] >= 2 for f in sf.segments)
         cnt, st, lf = sf.count_batch(pat, off, want_steps=True)
-        locs, found, st2 = sf.locate_batch(pat, off, 16)
-        exp_c = np.zeros(n, np.int64)
-        exp_l = np.full((n, 16), -1, np.int64)
-        exp_f = np.zeros(n, np.int32)
+        locs, found, st2 = sf.locate_batch(pat, off, mm)
+
+        class Expect:
+            def __init__(self, k):
+                self.c, self.l, self.f = np.zeros(k, np.int64), np.full((k, mm), -1, np.int64), np.zeros(k, np.int32)
+
+            def add(self, o, p, po, base):
+                oc, ost = o.count_batch(p, po, threads=CORES)
+                assert (ost == 0).all()
+                self.c += oc
+                # the caller's loop: segment s looks for the maxMatches - taken hits still missing
+                ol, of, _ = o.locate_batch(p, po, mm, threads=CORES)
+                for k in range(mm):
+                    sel = np.flatnonzero((of > k) & (self.f < mm))
+                    self.l[sel, self.f[sel]] = ol[sel, k].astype(np.int64) + base
+                    self.f[sel] += 1
+
+        exp, exp8 = Expect(n), Expect(len(sample))
         steps = 0
         for s in range(K):
             o = orc.OracleFmIndex.read(sf.segments[s].write(False))
             orc.counters_reset()
-            oc, ost = o.count_batch(pat, off, threads=CORES)
+            o.count_batch(pat, off, threads=CORES)
             steps += orc.counters()["lf_steps"]
-            assert (ost == 0).all()
-            exp_c += oc
-            # the caller's loop: segment s looks for the maxMatches - taken hits still missing
-            ol, of, _ = o.locate_batch(pat, off, 16, threads=CORES)
-            for k in range(16):
-                sel = np.flatnonzero((of > k) & (exp_f < 16))
-                exp_l[sel, exp_f[sel]] = ol[sel, k].astype(np.int64) + int(sf.bases[s])
-                exp_f[sel] += 1
+            exp.add(o, pat, off, int(sf.bases[s]))
+            exp8.add(o, spat, soff, int(sf.bases[s]))
             del o
-        assert (st == 0).all() and (cnt == exp_c).all() and int(lf.sum()) == steps
-        assert (st2 == 0).all() and (found == exp_f).all() and (locs == exp_l).all()
-        assert (found == np.minimum(cnt, 16)).all()
+        assert (st == 0).all() and (cnt == exp.c).all() and int(lf.sum()) == steps
+        assert (st2 == 0).all() and (found == exp.f).all() and (locs == exp.l).all()
+        assert (found == np.minimum(cnt, mm)).all()
+        # the same share over TWO replicas of the whole segment set through the C ABI (fmx_count_locate_segments_multi): what a
+        # Java host runs on a node's GPUs — here two replicas of all 8 images on the one device
+        srs = ia.SegmentReplicaSet(sf, [0, 0])
+        try:
+            c2, l2, f2, s2, lf2 = srs.count_locate_batch(pat, off, mm)
+            assert (s2 == 0).all() and (c2 == exp.c).all() and (f2 == exp.f).all() and (l2 == exp.l).all() and int(lf2.sum()) == steps
+        finally:
+            srs.close()
+        # configs[4] held by ONE GPU: all 8,388,608 patterns in one call (count + locate in one pass over the 8 images): the sample
+        # against the oracles, every pattern through what the domain offers (found = min(count, 16); a hit holds its pattern)
+        one = SegmentSetOnOneDevice(sf)
+        c8, l8, f8, s8 = one.count_locate_batch(pat8, off8, mm)
+        assert (s8 == 0).all() and (c8 >= 1).all() and (f8 == np.minimum(c8, mm)).all()
+        assert (c8[sample] == exp8.c).all() and (f8[sample] == exp8.f).all() and (l8[sample] == exp8.l).all()
+        bases = np.asarray(sf.bases, np.int64)
+        P8 = pat8.reshape(n8, M)
+        for k in (0, 7, 15):
+            sel = np.flatnonzero(f8 > k)[:: 64]
+            seg = np.searchsorted(bases, l8[sel, k], side="right") - 1
+            for sgm in range(K):
+                q = sel[seg == sgm]
+                if len(q):
+                    at = (l8[q, k] - bases[sgm])[:, None] + np.arange(M)[None, :]
+                    assert (texts[sgm][at] == P8[q]).all(), (k, sgm)
     finally:
         for f in sf.segments:
             f.close()
+
+
+class SegmentSetOnOneDevice:
+    """fmx_count_locate_segments (host buffers): count() and locate() of a batch over all segment indexes in one pass"""
+
+    def __init__(self, sf):
+        self.sf = sf
+
+    def count_locate_batch(self, pat, off, mm):
+        import ctypes as C  # noqa: F401
+
+        n = len(off) - 1
+        cnt = np.zeros(n, np.int64)
+        locs = np.full((n, mm), -1, np.int64)
+        found = np.zeros(n, np.int32)
+        st = np.zeros(n, np.int32)
+        rc = ia.lib.fmx_count_locate_segments(self.sf.handles, len(self.sf), self.sf.base_array.ctypes.data, pat.ctypes.data, off.ctypes.data,
+                                              n, mm, cnt.ctypes.data, None, locs.ctypes.data, found.ctypes.data, st.ctypes.data)
+        assert rc == 0, ia.lib.fmx_last_error()
+        return cnt, locs, found, st
