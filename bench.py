@@ -305,6 +305,12 @@ def compact_line(out):
                                        "ratio_registered_to_max_of_floor_and_device_step", "pcie_floor_ms_in", "stat"))
     if out.get("index_broadcast"):
         c["index_broadcast"] = _pick(out["index_broadcast"], ("broadcast_s", "fan_out_s", "kept", "bytes"))
+    if out.get("launch"):
+        c["launch"] = _short(out["launch"], 90)
+    if out.get("single_process"):
+        c["single_process"] = _sig(_pick(out["single_process"], ("ms_per_step", "patterns_per_s", "replicate_s", "devices", "skipped", "error")))
+        if c["single_process"].get("error"):
+            c["single_process"]["error"] = _short(c["single_process"]["error"], 120)
     sec = []
     for row in out.get("secondary") or []:
         if row is None:
@@ -434,6 +440,46 @@ def hand_out_patterns(ctx, pat_host, m, total):
         lo, hi = shard_range(total, ctx.world, ctx.rank)
         assert t.shape[0] == hi - lo
     return t.contiguous().view(torch.int16).reshape(-1)
+
+
+def single_process_leg(ctx, args, q, text, n, m, n_batches):
+    """At N > 1 in the launcher form: rank 0 ALSO measures the single-process form (fmx_replicate + fmx_count_batch_multi_dev from one
+    host process) over the same GPUs, so that one driver run yields both forms side by side.  The other ranks wait on the
+    rendezvous store — a host-side wait: no collective's kernel spins on their GPUs meanwhile — with their own work drained."""
+    import datetime
+
+    dist, torch, ia, world = ctx.dist, ctx.torch, ctx.ia, ctx.world
+    key = "fmx_single_process_leg_done"
+    result = None
+    barrier(ctx)
+    try:
+        store = dist.distributed_c10d._get_default_store()
+    except Exception as e:  # noqa: BLE001 - an optional leg: every rank sees the same failure and moves on
+        return {"skipped": "no rendezvous store to wait on: %r" % (e,)}
+    if ctx.rank == 0:
+        try:
+            spent = time.time() - ctx.t_start
+            if spent > 0.4 * args.time_budget:
+                result = {"skipped": "%.0f s of the %.0f s budget spent before it" % (spent, args.time_budget)}
+            elif not ctx.shared and torch.cuda.device_count() < world:
+                result = {"skipped": "rank 0 sees %d device(s): the launcher masks the others" % torch.cuda.device_count()}
+            else:
+                devices = [0] * world if ctx.shared else list(range(world))
+                r = single_process_steps(ia, torch, q, devices, text, n, m, n_batches, args.steps, args.warmup, host_call=False)
+                result = {"what": "the same steps from ONE host process: fmx_replicate + fmx_count_batch_multi_dev (the C ABI's replica "
+                                  "calls, per-device worker threads), measured by rank 0 while the other ranks idle",
+                          "devices": devices, "ms_per_step": r["ms_per_step"], "patterns_per_s": r["patterns_per_s"],
+                          "replicate_s": r["replicate_s"], "count_checksum_all_shards": r["count_checksums"][0]}
+                torch.cuda.set_device(ctx.local_rank)
+        except Exception as e:  # noqa: BLE001 - reported on the line, never fatal for the contract's own measurement
+            log("[bench] single-process leg FAILED: %r" % (e,))
+            result = {"error": repr(e)[:300]}
+        finally:
+            store.set(key, "1")
+    else:
+        store.wait([key], datetime.timedelta(seconds=max(60.0, args.time_budget)))
+    barrier(ctx)
+    return result
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -598,6 +644,9 @@ def run_count(ctx, args):
                 raise RuntimeError("counts changed in the overlapped run")
         overlapped = {"streams": len(side), "wall_s_this_rank": wall2}
 
+    single = None
+    if world > 1 and dist is not None and not ctx.dry and not args.no_single_process_leg and not args.profiling:
+        single = single_process_leg(ctx, args, q, text, n, m, n_batches)
     lf_local = sum(lf_steps[i % n_batches] for i in range(args.steps))
     lf_exec_local = sum(lf_executed[i % n_batches] for i in range(args.steps))
     seen = [[0, ctx.local_rank, ctx.local_rank]]
@@ -857,12 +906,170 @@ def run_count(ctx, args):
         "cpu_baseline": base,
         "host_buffers": host_buffers,
         "secondary": secondary,
+        "single_process": single,
     }
     if ctx.dry:
         out["dry_run"] = True
     if getattr(ctx, "shared", False):
         out["rehearsal"] = "N ranks sharing ONE GPU, collectives over gloo on host tensors: checks the N > 1 code path end to end, measures nothing"
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# --single-process: ONE host process drives N GPUs through the C ABI's replica calls (include/fmx.h "replicas") — what a Java
+# host does over JNI: fmx_replicate (peer copies of the image out of device 0's HBM, every replica growing its own tables),
+# then per step ONE fmx_count_batch_multi_dev call that has the library's per-device worker threads issue all shards' launches
+# at once.  No torch.distributed, no collective.  Same workload, same contract line as the launcher form.
+# ---------------------------------------------------------------------------------------------------------------
+def single_process_steps(ia, torch, fm, devices, text, n, m, n_batches, steps, warmup, check_oracle=None, cores=1, host_call=True):
+    """K steps of the headline workload over a replica set; returns a dict of measurements.  `fm` must be resident.
+    check_oracle: an OracleFmIndex — every pattern of batch 0 (all shards) is checked against it."""
+    from index4j_amd import workload
+
+    world = len(devices)
+    t0 = time.time()
+    rs = ia.ReplicaSet(fm, devices)
+    for d in sorted(set(devices)):
+        torch.cuda.synchronize(d)
+    replicate_s = time.time() - t0
+    out = {"devices": list(devices), "replicate_s": replicate_s, "resident_bytes_per_replica": rs.resident_bytes()[0]}
+    try:
+        vp = C.c_void_p * world
+        streams = [torch.cuda.Stream(device=torch.device("cuda", d)) for d in devices]
+        sp = vp(*[st.cuda_stream for st in streams])
+        off_host = (np.arange(n + 1, dtype=np.int64) * m).astype(np.int32)
+        d_off = [torch.from_numpy(off_host).to(torch.device("cuda", d)) for d in devices]
+        host_batches, d_pats, d_cnt = [], [], []
+        for b in range(n_batches):
+            pat, _off, _pos = workload.count_batch_patterns(text, world * n, m, seed=workload.PATTERN_SEED + b)
+            host_batches.append(pat)
+            rows = pat.view(np.int16).reshape(world, n * m)
+            d_pats.append([torch.from_numpy(rows[r].copy()).to(torch.device("cuda", devices[r])) for r in range(world)])
+            d_cnt.append([torch.zeros(n, dtype=torch.int32, device=torch.device("cuda", devices[r])) for r in range(world)])
+        d_lf = [torch.zeros(n, dtype=torch.int32, device=torch.device("cuda", d)) for d in devices]
+        d_st = [torch.zeros(n, dtype=torch.int32, device=torch.device("cuda", d)) for d in devices]
+        ns = (C.c_int32 * world)(*([n] * world))
+        a_off = vp(*[t.data_ptr() for t in d_off])
+        a_pat = [vp(*[t.data_ptr() for t in d_pats[b]]) for b in range(n_batches)]
+        a_cnt = [vp(*[t.data_ptr() for t in d_cnt[b]]) for b in range(n_batches)]
+        a_lf, a_st = vp(*[t.data_ptr() for t in d_lf]), vp(*[t.data_ptr() for t in d_st])
+
+        def sync():
+            check_rc(ia, ia.lib.fmx_multi_synchronize(rs.handles, world, sp), "fmx_multi_synchronize")
+
+        def step(b, with_steps=False):
+            check_rc(ia, ia.lib.fmx_count_batch_multi_dev(rs.handles, world, a_pat[b], a_off, ns, a_cnt[b], a_lf if with_steps else None,
+                                                          a_st if with_steps else None, sp), "fmx_count_batch_multi_dev")
+
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+        lf_steps, checksums = [], []
+        for b in range(n_batches):
+            step(b, True)
+            sync()
+            if max(int(t.max().item()) for t in d_st) != 0:
+                raise RuntimeError("unexpected per-query status in the benchmark batch")
+            lf_steps.append(sum(int(t.sum(dtype=torch.int64).item()) for t in d_lf))
+            checksums.append(sum(int(t.sum(dtype=torch.int64).item()) for t in d_cnt[b]))
+        for i in range(warmup):
+            step(i % n_batches)
+        sync()
+        t1 = time.perf_counter()
+        for i in range(steps):
+            step(i % n_batches)
+        sync()
+        wall = time.perf_counter() - t1
+        for b in range(n_batches):
+            if sum(int(t.sum(dtype=torch.int64).item()) for t in d_cnt[b]) != checksums[b]:
+                raise RuntimeError("counts changed between launches")
+        out.update({"wall_s": wall, "ms_per_step": wall * 1e3 / steps, "patterns_per_s": world * n * steps / wall,
+                    "lf_steps_per_s_reference_equivalent": sum(lf_steps[i % n_batches] for i in range(steps)) / wall,
+                    "count_checksums": checksums, "lf_steps_per_batch": lf_steps, "steps": steps, "warmup": warmup})
+        all0 = np.concatenate([t.cpu().numpy() for t in d_cnt[0]])
+        out["counts_batch0"] = all0
+        out["host_batch0"] = host_batches[0]
+        if check_oracle is not None:
+            off_all = (np.arange(world * n + 1, dtype=np.int64) * m).astype(np.int32)
+            oc, ost = check_oracle.count_batch(host_batches[0], off_all, threads=cores)
+            if not (all0 == oc).all() or int(ost.max()) != 0:
+                raise RuntimeError("single-process form: GPU counts differ from the oracle on batch 0")
+            out["patterns_checked_vs_oracle"] = world * n
+        if host_call:
+            # the host-buffer form of the same step (what a JNI caller's arrays cost: PCIe in and out; never `value`): ONE
+            # fmx_count_batch_multi over the whole world x n batch
+            off_all = (np.arange(world * n + 1, dtype=np.int64) * m).astype(np.int32)
+            cnt_h = np.zeros(world * n, np.int32)
+            times = []
+            for _ in range(5):
+                t2 = time.perf_counter()
+                check_rc(ia, ia.lib.fmx_count_batch_multi(rs.handles, world, host_batches[0].ctypes.data, off_all.ctypes.data, world * n,
+                                                          cnt_h.ctypes.data, None, None), "fmx_count_batch_multi")
+                times.append((time.perf_counter() - t2) * 1e3)
+            if not (cnt_h == all0).all():
+                raise RuntimeError("fmx_count_batch_multi differs from the device-resident form")
+            out["host_buffers_ms_per_call"] = float(np.median(times))
+    finally:
+        rs.close()
+    return out
+
+
+def run_single_process(args, t_start):
+    import torch
+
+    import index4j_amd as ia
+
+    if not torch.cuda.is_available() or ia.lib.fmx_device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    world = args.gpus
+    have = torch.cuda.device_count()
+    if args.share_one_gpu:
+        devices = [0] * world
+    elif have < world:
+        log("[bench] --gpus %d --single-process but only %d HIP device(s) visible: refusing to print a mislabelled line" % (world, have))
+        sys.exit(2)
+    else:
+        devices = list(range(world))
+    if args.image_compact:
+        check_rc(ia, ia.lib.fmx_set_option(b"image_compact", 1), "fmx_set_option")
+    torch.cuda.set_device(0)
+    m, n = args.pattern_len, args.patterns
+    text, fm, path = build_or_load_index(ia, args.text_log2, args.sample_rate, args.cache_dir, build_device=0)
+    fm.to_device(0)
+    ref = None
+    cores = os.cpu_count() or 1
+    if not args.no_cpu_baseline:
+        ref = oracle_module().OracleFmIndex.read(open(path, "rb").read())
+    setup_s = time.time() - t_start
+    r = single_process_steps(ia, torch, fm, devices, text, n, m, max(1, args.batches), args.steps, args.warmup, check_oracle=ref, cores=cores)
+    image, table, window = r["resident_bytes_per_replica"]
+    out = {
+        "metric": "patterns/sec + LF-steps/sec, 1M x 8-char count() on 256 MiB log index",
+        "value": r["patterns_per_s"], "unit": "patterns/s",
+        "lf_steps_per_sec_reference_equivalent": r["lf_steps_per_s_reference_equivalent"],
+        "n_gpus": world, "ranks_seen": [[k, k, d] for k, d in enumerate(devices)],
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "launch": "single-process: ONE host process, the C ABI's replica calls (fmx_replicate, fmx_count_batch_multi_dev: every shard's "
+                  "launches issued by the library's per-device worker threads; no torch.distributed, no collective)",
+        "setup_s": setup_s + r["replicate_s"],
+        "config": {"workload": "count() batch of %d random %d-char patterns per GPU on %d MiB synthetic log text, sampleRate=%d "
+                               "(BASELINE.json configs[1]); %d distinct batches rotate; single-process form over %d replica(s)"
+                               % (n, m, (1 << args.text_log2) >> 20, args.sample_rate, max(1, args.batches), world),
+                   "image": "compact" if args.image_compact else "expanded", "text_chars": 1 << args.text_log2, "patterns_per_gpu": n,
+                   "pattern_len": m, "sample_rate": args.sample_rate, "batches": max(1, args.batches),
+                   "count_checksum": r["count_checksums"][0], "patterns_checked_vs_oracle": r.get("patterns_checked_vs_oracle", 0)},
+        "index_broadcast": {"broadcast_s": r["replicate_s"], "bytes": image, "kept": "peer copies (fmx_replicate)",
+                            "note": "image copy + growth of each replica's suffix table and window directory, all replicas at once"},
+        "host_buffers": {"ms_per_call": r.get("host_buffers_ms_per_call"),
+                         "what": "fmx_count_batch_multi of the whole %d-pattern batch from pageable host arrays (median of 5)" % (world * n)},
+        "resident_bytes_per_replica": {"image": image, "suffix_table": table, "window_directory": window},
+        "roofline": None, "cpu_baseline": None,
+    }
+    if args.share_one_gpu:
+        out["rehearsal"] = "N replicas sharing ONE GPU: checks the single-process N > 1 code path end to end, measures nothing"
+    fm.close()
+    emit(out)
+
 
 
 SHARE_PATTERNS = 1 << 20  # configs[4]: 8,388,608 patterns over 8 GPUs
@@ -1515,6 +1722,11 @@ def main():
     ap.add_argument("--share-one-gpu", action="store_true",
                     help="REHEARSAL of the N > 1 code path on a one-GPU box: every rank queries on cuda:0, collectives run "
                          "over gloo on host tensors.  The line says so (`rehearsal`); it is not a measurement.")
+    ap.add_argument("--single-process", action="store_true",
+                    help="ONE host process drives all --gpus N devices through the C ABI's replica calls (fmx_replicate + "
+                         "fmx_count_batch_multi_dev) instead of one process per GPU over torch.distributed: the form a Java host uses")
+    ap.add_argument("--no-single-process-leg", action="store_true",
+                    help="at N > 1 (launcher form): skip rank 0's extra measurement of the single-process form over the same GPUs")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU-only rehearsal of the launch / broadcast / shard / gather plumbing over gloo: no queries, no numbers")
     ap.add_argument("--cache-dir", default=os.environ.get("FMX_CACHE", "/tmp/fmx_cache"))
@@ -1525,6 +1737,9 @@ def main():
     t_start = time.time()
 
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.single_process and not launched:
+        run_single_process(args, t_start)
+        return
     if args.gpus > 1 and not launched:
         sys.exit(self_launch(args, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -692,6 +692,19 @@ int flatten_model(const FmModel &m, std::vector<uint8_t> &blob, std::string &err
                     e.y = (uint32_t)bh.bv_offset | ((code & 0xffu) << 24);
                     e.z = (uint32_t)bh.bv_rank | ((code >> 8) << 24);
                     e.w = (uint32_t)(2 * (uint64_t)ents.size() + first_rec);
+                    if (len == 0) {
+                        // A run block has no path records.  Its entry's last word holds what the NEXT-BLOCK path of rank() reads
+                        // when it lands on this block from an absent entry to the left (WFBB:1072-1108 with tree height 0: the
+                        // u24 at var_off + (0 - 1) * 4 + 0 * 5 + 2 = var_off - 2, i.e. two bytes of the header BEFORE this
+                        // block's and one of its own: Q11) — a property of the block alone, evaluated here once instead of by
+                        // two dependent loads (block header, header bytes) per rank: kMapRunNext | u24, or kMapRunNextOutside
+                        // where the reference's read leaves the byte array (ArrayIndexOutOfBounds).
+                        const int64_t q = hdr - 2;
+                        if (q < 0 || q + 2 >= var_len)
+                            e.w = kMapRunNextOutside;
+                        else
+                            e.w = kMapRunNext | ld24(var.data() + q);
+                    }
                 }
             }
             d.path_len = (int32_t)path.size();

@@ -33,7 +33,7 @@
 namespace fmx {
 
 constexpr uint32_t kBlobMagic = 0x31584D46u;  // "FMX1"
-constexpr uint32_t kBlobVersion = 14;  // 14: RRR records address their offsets relative to the records; BlobHeader.compact
+constexpr uint32_t kBlobVersion = 15;  // 15: a run block's mapping entry carries the next-block path's word (MapEntry.w); 14: RRR records address their offsets relative to the records; BlobHeader.compact
 
 struct RrrRecord {         // 16 bytes: 16 blocks of 15 bits
     uint32_t ones_before;  // 1-bits in all earlier blocks
@@ -83,7 +83,9 @@ struct RrrDesc {           // 32 bytes; the first 16 are what a rank needs (one 
 //                     index), WFBB:466-471).  Used for codes longer than 16 bits and for clamped entries.
 //   y = A0[23:0] | code[7:0]  << 24        A0 = bit position of the root node in the superblock's bit vector
 //   z = B0[23:0] | code[15:8] << 24        B0 = one-bits before it       (BlockHeaderItem, WFBB:450-454)
-//   w = offset of the leaf's path records, in 8-byte units from the start of the superblock's mapping table
+//   w = offset of the leaf's path records, in 8-byte units from the start of the superblock's mapping table; in a RUN block's
+//       entry (tag 0: no records) the word the next-block path reads when it lands on this block (WFBB:1096-1108 at tree
+//       height 0, Q11): kMapRunNext | u24, or kMapRunNextOutside = the reference's read leaves the byte array (blob v15)
 // Path records (PathRec, 8 bytes, one per level d = 1 .. length-1 of the leaf's code, contiguous): the node the
 // walk visits at depth d starts at bit A_d of the superblock's bit vector, with B_d one-bits before it.  In the
 // reference these are `blockVectorOffset + leftTotalBvSize` and `blockVectorRank + leftOnes` of WFBB:1187-1278,
@@ -129,6 +131,8 @@ constexpr uint32_t kInvSlow = 0x20000000u;
 constexpr uint32_t kMapSlow = 0xffu;
 constexpr uint32_t kMapAbsent = 0xfeu;
 constexpr uint32_t kMapMaxLen = 16;
+constexpr uint32_t kMapRunNext = 0x01000000u;         // MapEntry.w of a run block's entry: the low 24 bits are the next-block path's u24
+constexpr uint32_t kMapRunNextOutside = 0x02000000u;  // ... that read falls outside the header bytes (the JVM raises AIOOBE)
 
 struct SbDesc {            // 64 bytes; bytes 0..15 = header of every rank, bytes 32..47 = its RRR vector
     int16_t sigma;         // WFBB:1623 (superblock alphabet size - 1)

@@ -240,9 +240,8 @@ __device__ __forceinline__ int32_t chunk_code(const CodeChunk &ck, int32_t j) {
 // k_count the register allocation of the whole kernel got worse (the headline batch, whose patterns never refill, ran
 // 1.2 % slower with the code merely present: profiles/r03_experiments.txt).
 template <int kCodeBits>
-__device__ __attribute__((noinline)) CodeChunk chunk_refill(const int16_t *__restrict__ char2code, const int16_t *s_map,
-                                                            const uint16_t *__restrict__ pat, int32_t beg, int32_t m,
-                                                            int32_t back) {
+__device__ __forceinline__ CodeChunk chunk_refill_body(const int16_t *__restrict__ char2code, const int16_t *s_map,
+                                                       const uint16_t *__restrict__ pat, int32_t beg, int32_t m, int32_t back) {
     const int32_t left = m - back;  // characters not yet consumed (>= 1)
     const TailWords t = pattern_tail_load(pat, beg, left);
     uint32_t ch[8];
@@ -264,6 +263,12 @@ __device__ __attribute__((noinline)) CodeChunk chunk_refill(const int16_t *__res
     ck.base = back;
     ck.n = left < 8 ? left : 8;
     return ck;
+}
+template <int kCodeBits>
+__device__ __attribute__((noinline)) CodeChunk chunk_refill(const int16_t *__restrict__ char2code, const int16_t *s_map,
+                                                            const uint16_t *__restrict__ pat, int32_t beg, int32_t m,
+                                                            int32_t back) {
+    return chunk_refill_body<kCodeBits>(char2code, s_map, pat, beg, m, back);
 }
 
 // The backward search of ONE pattern by a lane pair (FM:455-474): lane `role` 0 computes `start`, lane 1 `end`.
@@ -374,7 +379,7 @@ __device__ __forceinline__ void diag_end() {}
 // a counting sort in LDS on min(length, 63), longest first.  Both lanes of a pair pass the same record and get the same one
 // back.  A real call (as chunk_refill): inlined, its registers cost the batches of one length — which never get here — 2 %.
 template <int kBlock>
-__device__ __noinline__ Quad regroup_records(uint32_t *s_bin, Quad *s_rec, Quad mine) {
+__device__ __forceinline__ Quad regroup_records_body(uint32_t *s_bin, Quad *s_rec, Quad mine) {
     const int32_t m = (int32_t)mine.w;
     const int bin = mine.z == 0xffffffffu ? 0 : (m < 0 ? 0 : (m > 63 ? 63 : m));
     if (threadIdx.x < 64) s_bin[threadIdx.x] = 0;
@@ -396,16 +401,36 @@ __device__ __noinline__ Quad regroup_records(uint32_t *s_bin, Quad *s_rec, Quad 
     __syncthreads();
     return s_rec[threadIdx.x >> 1];
 }
+template <int kBlock>
+__device__ __noinline__ Quad regroup_records(uint32_t *s_bin, Quad *s_rec, Quad mine) {
+    return regroup_records_body<kBlock>(s_bin, s_rec, mine);
+}
 
+#ifndef FMX_COUNT_WAVES
+#define FMX_COUNT_WAVES 8
+#endif
+#if FMX_COMPACT
+#define FMX_COUNT_KERNEL(BLOCK) __global__ __launch_bounds__(BLOCK)
+#else
+#define FMX_COUNT_KERNEL(BLOCK) __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FMX_COUNT_WAVES, 8)))
+#endif
 template <int kBlock, int kMode, int kCodeBits>
-FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__ pat,
+FMX_COUNT_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__ pat,
                                                   const int32_t *__restrict__ pat_off,
                                                   const PlanRec *__restrict__ recs, int32_t n,
                                                   int32_t *__restrict__ counts, int32_t *__restrict__ lf_steps,
                                                   int32_t *__restrict__ status_out, int32_t *__restrict__ range_out,
                                                   const int32_t *__restrict__ plan_look_up, int32_t plan_sigma,
                                                   int steps_mode, int regroup, const uint32_t *__restrict__ plan_mixed,
-                                                  uint32_t plan_epoch, int halve_uniform) {
+                                                  uint32_t plan_epoch, int halve_uniform, const int32_t *__restrict__ redo_list,
+                                                  uint32_t *__restrict__ redo_count) {
+    // kMode 4 = LIST mode: the patterns are redo_list[0 .. *redo_count) — those k_count_lean met on a route it does not carry —
+    // searched as in mode 0 (the caller's order, every route inlined).  The list is usually empty: nothing is staged then.  The last
+    // workgroup to finish leaves the counters zero for the next launch.
+    if (kMode == 4) {
+        n = (int32_t)*reinterpret_cast<volatile uint32_t *>(redo_count);
+        if (n == 0) return;
+    }
     // kCodeBits: width of a code in the record's word and in the chunks — 8 when the alphabet fits (8 codes per word),
     // else 16 (the plan's alphabet in modes 1 / 2, this index's own in modes 0 / 3)
     constexpr int kPairs = kBlock / 2;
@@ -424,7 +449,7 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
     __shared__ int16_t s_map[256];  // this index's character map, characters below 256
     __shared__ uint32_t s_len_bin[64];     // regrouping by length: bins, then their first slots
     __shared__ Quad s_len_rec[kBlock / 2];  // ... and the workgroup's records in length order
-    constexpr bool planned = kMode != 0;
+    constexpr bool planned = kMode != 0 && kMode != 4;
     constexpr bool translate = kMode == 2;  // only offered for 8-bit code words (plan_sigma <= 256)
     // (staged in front of the superblock cache so that both share ONE barrier: a workgroup lives for a few hundred
     // patterns, its start-up is not free)
@@ -460,9 +485,10 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
                 m = (int32_t)(rq.w & kPlanLongPattern);
                 if (m == (int32_t)kPlanLongPattern) m = pat_off[p + 1] - pat_off[p];
             } else {
+                if (kMode == 4) p = redo_list[q];
                 const int32_t beg0 = pat_off[p];
                 m = pat_off[p + 1] - beg0;
-                if (kMode == 0 && m > 0) {
+                if ((kMode == 0 || kMode == 4) && m > 0) {
                     // the caller's order (no plan stage): the code word of the trailing characters is made here, as k_plan_codes
                     // makes it — one 16-byte fetch of the pattern's tail, characters mapped through the LDS copy of the map —
                     // so that short patterns take the lean loop of a planned batch
@@ -531,8 +557,328 @@ FMX_KERNEL(kBlock) void k_count(DevIndex ix_global, const uint16_t *__restrict__
             }
         }
     }
+    if (kMode == 4) {
+        __syncthreads();
+        if (threadIdx.x == 0 && atomicAdd(redo_count + 1, 1u) == gridDim.x - 1) {
+            redo_count[0] = 0;
+            redo_count[1] = 0;
+        }
+    }
     diag_end();
 }
+
+#if !FMX_COMPACT
+// ---- k_count_lean: the backward search of a PLANNED batch over an expanded image, written for instruction issue ---------------
+// Round 5 found k_count bound by VALU issue, not by memory: 331 vector instructions per wave-step for ONE rank, 77 spilled SGPRs
+// (every spill and reload is a v_writelane / v_readlane: vector issue slots), both arms of every uniform branch and the whole of
+// the reference's own route (block header, level table, cumulative counts: WFBB:1113-1279) inside the loop.  This kernel is the
+// same search (FM:455-474 over the fast route of WFBB.rank, fmx_device.hpp wt_rank_folded_t) with
+//   * its arguments as ONE small struct of what the loop reads — no DevIndex by value;
+//   * the image's shape in the template arguments (mapping rows by symbol or by superblock code), so no dead arm is live;
+//   * the superblock headers staged in LDS as ONE quad per superblock {sigma | blockSizeLog, mapping table, cells, vector length};
+//   * nothing but the fast routes inlined: symbol absent from the superblock (WFBB:1040-1042), run block (WFBB:1141-1146), next
+//     block to the right that holds the symbol (WFBB:1048-1110 through a fast entry), and the walk over cells and path records
+//     (WFBB:1187-1278 evaluated at flatten time).  Anything else — an entry on the reference's own route (codes longer than 16
+//     bits, clamped entries, Q2), position 0, Q3's superblock — makes the rank answer -1; the pair then leaves the loop and puts its
+//     pattern on a REDO LIST (an index and an atomic, in the plan's workspace) that k_count's list mode — every route inlined, as
+//     ever — works off in a second, small launch right behind this one (usually it finds the list empty and leaves).  No real call
+//     in this kernel: a call's caller-saved registers cost it 47 spilled VGPRs and ~25 scratch accesses per pattern when the cold
+//     route was a function (measured: 0.142 ms against k_count's 0.091).
+// Same counts, statuses, LF-step counts and ranges as k_count: the fast routes are its own, bit for bit.
+// What the loop over a pattern's characters reads stays in SGPRs (CountLeanHot); what a pattern needs once — where its record,
+// its first interval and its results live — is read from an LDS copy (CountLeanTile) at the point of use: as kernel arguments
+// those twenty-odd SGPRs were live across the whole kernel, and with its three real calls (chunk_refill, regroup_records, the cold
+// continuation) the allocator spilled ALL of them into VGPR lanes and reloaded them in the loop (311 v_readlane: vector
+// issue slots, the very thing this kernel is short of).
+struct CountLeanHot {
+    const uint8_t *base;  // the image
+    const SbcEntry *sbc;
+    int32_t wt_sigma, n_sb;
+    uint32_t wt_size;
+    int32_t n;
+};
+struct CountLeanTile {
+    const int32_t *C;
+    const SuffixSlot *suffix_table;  // nullptr: none (or launches told to ignore it)
+    const int16_t *char2code;
+    int32_t *redo_list;     // patterns that met a route this kernel does not carry (at most n of them) ...
+    uint32_t *redo_count;   // ... and how many: k_count's list mode works them off and leaves the counter zero again
+    const uint16_t *pat;
+    const int32_t *pat_off;
+    const PlanRec *recs;
+    int32_t *counts, *lf_steps, *status_out, *range_out;
+    int32_t suffix_chars;
+    uint32_t suffix_shift, suffix_mask;
+    int32_t steps_mode;
+    int32_t mixed;  // set by the kernel: the workgroups regroup their records by length (option on, batch of two lengths or more)
+};
+// the tile in LDS, addressed as LDS: a generic pointer to it made every field's address a VGPR PAIR kept across the kernel (32 VGPRs
+// for addresses of constants, 26-47 spilled registers); its offset is laundered once per pattern so that the loads stay where
+// they are used instead of being hoisted out of the loop into registers
+using CountLeanTileLds = const __attribute__((address_space(3))) CountLeanTile;
+__device__ __forceinline__ CountLeanTileLds *tile_lds(const CountLeanTile *generic) {
+    uint32_t off = (uint32_t)(uintptr_t)(CountLeanTileLds *)generic;
+    asm volatile("" : "+v"(off));
+    return (CountLeanTileLds *)(uintptr_t)off;
+}
+struct CountLeanArgs {
+    CountLeanHot hot;
+    CountLeanTile tile;
+    const SbDesc *sbd;
+    const uint32_t *plan_mixed;
+    uint32_t plan_epoch;
+    int32_t regroup, halve_uniform;
+};
+
+// C[c] + rank(c, position) over the fast routes, or -1
+template <bool kMapBySymbol>
+__device__ __forceinline__ int32_t rank_lean(const CountLeanHot &A, const Quad *s_sbl, uint32_t position, uint32_t c) {
+    const uint32_t sb_id = position >> 20;  // WFBB:1023
+    // position 0 (WFBB:1012-1014), beyond the tree (WFBB:1015-1017), Q3's superblock, a symbol outside the tree: cold
+    if (position - 1u >= A.wt_size || sb_id >= (uint32_t)A.n_sb || c >= (uint32_t)A.wt_sigma) return -1;
+    uint64_t sbc_raw;
+    memcpy(&sbc_raw, A.sbc + (uint64_t)sb_id * (uint32_t)A.wt_sigma + c, 8);  // WFBB:1024, 1034-1037
+    const Quad hq = s_sbl[sb_id];
+    const uint32_t bsl = hq.x >> 16;
+    const int32_t sb_sigma = (int32_t)(int16_t)(hq.x & 0xffffu);
+    const uint32_t blocks_log = 20u - bsl;
+    const uint32_t block_index = position & ((1u << bsl) - 1u);
+    uint32_t block_id = (position & 0xfffffu) >> bsl;
+    const MapEntry *mapping = reinterpret_cast<const MapEntry *>(A.base + ((uint64_t)hq.y << 3));
+    Quad mq;
+    uint32_t map_row = c << blocks_log;
+    if (kMapBySymbol) mq = ld_quad(mapping + map_row + block_id);  // WFBB:1044-1046: asked for together with the superblock entry
+    FMX_OPAQUE64(sbc_raw);
+    const int32_t e_rank = (int32_t)(uint32_t)sbc_raw;
+    const int32_t e_sbc = (int32_t)(int16_t)(uint16_t)(sbc_raw >> 32);
+    if (e_sbc >= sb_sigma + 1) return e_rank;  // WFBB:1040-1042
+    if (!kMapBySymbol) {
+        map_row = (uint32_t)e_sbc << blocks_log;
+        mq = ld_quad(mapping + map_row + block_id);
+    }
+    FMX_PIN_QUAD(mq);
+    const uint32_t tag = mq.x & 0xffu, value = mq.x >> 8;
+    if (tag == kMapAbsent) {  // WFBB:1048-1110
+        block_id += value;
+        if (block_id >= (1u << blocks_log)) {  // WFBB:1060-1069
+            int32_t next;
+            memcpy(&next, A.sbc + (uint64_t)(sb_id + 1u) * (uint32_t)A.wt_sigma + c, 4);
+            return next;
+        }
+        const Quad nq = ld_quad(mapping + map_row + block_id);
+        const uint32_t ntag = nq.x & 0xffu;
+        // WFBB:1096-1108 reads the u24 of leaf `mapping value` of that block: a fast entry of a block with a tree IS that leaf's
+        // u24; landing on a RUN block the reference reads 4 bytes early (Q11) — the word the flattener left in the entry
+        if (ntag >= 1u && ntag <= kMapMaxLen) return e_rank + (int32_t)(nq.x >> 8);
+        if (ntag == 0u && (nq.w >> 24) == (kMapRunNext >> 24)) return e_rank + (int32_t)(nq.w & 0xffffffu);
+        return -1;
+    }
+    if (tag > kMapMaxLen) return -1;                                       // the reference's own route
+    if (tag == 0u) return e_rank + (int32_t)value + (int32_t)block_index;  // run block, WFBB:1141-1146
+    const uint32_t code_length = tag;
+    const uint32_t code = (mq.y >> 24) | ((mq.z >> 24) << 8);
+    uint32_t node_a = mq.y & 0xffffffu, node_b = mq.z & 0xffffffu;
+    const PathRec *path = reinterpret_cast<const PathRec *>(mapping) + mq.w;
+    const uint8_t *cells = A.base + ((uint64_t)hq.z << 3);
+    const uint32_t bv_len = hq.w;
+    uint32_t pos = node_a + block_index;
+    pos = pos > bv_len ? bv_len : pos;  // (RRR:360-365: the rank at the clamped position IS the saturated value)
+    Quad pq = {0, 0, 0, 0};
+    if (code_length > 1u) pq = ld_quad(path);  // records of levels 1 and 2
+    Quad cell = ld_quad(cells + (uint64_t)(pos / kBvCellBits) * 16u);
+    FMX_PIN_QUAD(pq);
+    FMX_PIN_QUAD(cell);
+    uint32_t node_rank = block_index;
+    FMX_NO_UNROLL
+    for (uint32_t depth = 0; depth < code_length; ++depth) {
+        const uint32_t rank1 = cell.x + bv_cell_prefix(cell, pos % kBvCellBits) - node_b;  // WFBB:1216-1218
+        node_rank = (code >> (code_length - depth - 1u)) & 1u ? rank1 : node_rank - rank1;  // WFBB:1235-1244
+        if (depth + 1u != code_length) {
+            node_a = (depth & 1u) ? pq.z : pq.x;  // record `depth` = the node at level depth + 1
+            node_b = (depth & 1u) ? pq.w : pq.y;
+            pos = node_a + node_rank;
+            pos = pos > bv_len ? bv_len : pos;
+            cell = ld_quad(cells + (uint64_t)(pos / kBvCellBits) * 16u);
+            if ((depth & 1u) && depth + 2u < code_length) pq = ld_quad(path + depth + 1u);  // the next two levels
+            FMX_PIN_QUAD(cell);
+            FMX_PIN_QUAD(pq);
+        }
+    }
+    return e_rank + (int32_t)value + (int32_t)node_rank;  // WFBB:1281-1284
+}
+
+template <int kCodeBits, bool kChunks, bool kMapBySymbol>
+__device__ __forceinline__ void count_one_lean(const CountLeanHot &H, CountLeanTileLds *T, const Quad *s_sbl,
+                                               const int16_t *s_map, int32_t p, int32_t m, CodeChunk ck, int role, int32_t &start,
+                                               int32_t &end, int32_t &back, int32_t &tabled, bool &cold) {
+    constexpr uint32_t code_mask = (1u << kCodeBits) - 1u;
+    int32_t beg = 0;
+    if (kChunks && m > ck.n) beg = T->pat_off[p];
+    int32_t c = chunk_code<kCodeBits>(ck, 0);
+    if (c == 0) return;  // FM:458-460
+    {
+        uint64_t cc;
+        memcpy(&cc, T->C + c, 8);  // cumulativeCounts[c], [c + 1]
+        start = (int32_t)(uint32_t)cc;
+        end = (int32_t)(uint32_t)(cc >> 32);
+    }
+    const SuffixSlot *table = T->suffix_table;
+    int len = 0;
+    if (table) {
+        const int32_t chars = T->suffix_chars;
+        len = m < chars ? (int)m : (int)chars;
+    }
+    if (ck.n < len) len = ck.n;
+    if (len >= 2) {  // the interval after the last `len` characters is tabulated (count_one has the whole story)
+        const int bits = len * kCodeBits;
+        const uint64_t key = bits >= 64 ? ck.lo : (ck.lo & ((1ull << bits) - 1ull));
+        if ((uint32_t)(key >> (bits - kCodeBits)) != 0u && key != kSuffixEmpty) {
+            const uint32_t shift = T->suffix_shift, mask = T->suffix_mask;
+            const int top = bits - kCodeBits;  // fm_suffix_home
+            const uint64_t low6 = (key >> top) & (kSuffixGroup - 1);
+            const uint64_t hash = (key & ~((uint64_t)(kSuffixGroup - 1) << top)) * kSuffixHashMul;
+            const uint32_t group = (uint32_t)(hash >> shift);
+            const uint32_t turn = (uint32_t)(hash >> (shift - kSuffixGroupLog2)) & (kSuffixGroup - 1);
+            uint32_t h = (group * kSuffixGroup + ((uint32_t)low6 ^ turn)) & mask;
+            Quad q = ld_quad(table + h);
+            FMX_PIN_QUAD(q);
+            uint64_t k = (uint64_t)q.x | ((uint64_t)q.y << 32);
+            for (uint32_t probe = 0; k != key && k != kSuffixEmpty && probe < mask / kSuffixGroup; ++probe) {
+                h = (h + kSuffixGroup) & mask;
+                q = ld_quad(table + h);
+                k = (uint64_t)q.x | ((uint64_t)q.y << 32);
+            }
+            if (k == key) {
+                start = (int32_t)q.z;
+                end = (int32_t)q.w;
+                back = len - 1;
+            }
+        }
+        tabled = back;
+    }
+    while (start < end && back + 1 < m) {  // FM:464
+        ++back;
+        if (kChunks) {
+            if (back - ck.base >= ck.n) ck = chunk_refill_body<kCodeBits>(T->char2code, s_map, T->pat, beg, m, back);
+            c = chunk_code<kCodeBits>(ck, back - ck.base);
+        } else {
+            c = (int32_t)((uint32_t)(ck.lo >> (back * kCodeBits)) & code_mask);
+        }
+        if (c == 0) {  // FM:466-468
+            start = end = 0;
+            --back;
+            break;
+        }
+        const int32_t mine = rank_lean<kMapBySymbol>(H, s_sbl, (uint32_t)(role ? end : start), (uint32_t)c);
+        const int32_t other = __shfl_xor(mine, 1);
+        if ((mine | other) < 0) {  // one of the two ranks is off the fast routes: this character and the rest go to the cold continuation
+            --back;
+            cold = true;
+            break;
+        }
+        start = role ? other : mine;  // FM:469
+        end = role ? mine : other;    // FM:470
+    }
+}
+
+template <int kBlock, int kCodeBits, bool kMapBySymbol>
+FMX_COUNT_KERNEL(kBlock) void k_count_lean(CountLeanArgs A) {
+    constexpr int kPairs = kBlock / 2;
+    uint32_t grid_x = gridDim.x;
+    const bool batch_mixed = !A.plan_mixed || *A.plan_mixed == A.plan_epoch;
+    if (A.halve_uniform && !batch_mixed && grid_x >= 2) {  // (k_count: a batch of ONE length runs on half the grid)
+        grid_x = (grid_x + 1) / 2;
+        if (blockIdx.x >= grid_x) return;
+    }
+    __shared__ int16_t s_map[256];
+    __shared__ uint32_t s_len_bin[64];
+    __shared__ Quad s_len_rec[kBlock / 2];
+    __shared__ Quad s_sbl[kSbCacheMax];
+    __shared__ CountLeanTile s_tile;
+    if (threadIdx.x == 0) {
+        s_tile = A.tile;
+        s_tile.mixed = (A.regroup && batch_mixed) ? 1 : 0;
+    }
+    for (int c = threadIdx.x; c < 256; c += kBlock) s_map[c] = A.tile.char2code[c];
+    for (int i = threadIdx.x; i < A.hot.n_sb; i += kBlock) {
+        const Quad h = ld_quad(&A.sbd[i]), v = ld_quad(&A.sbd[i].rrr);
+        Quad q;
+        q.x = h.x;  // sigma | blockSizeLog << 16
+        q.y = h.y;  // off_mapping
+        q.z = v.x;  // off_rec: the superblock's cells
+        q.w = v.z;  // length of its bit vector
+        s_sbl[i] = q;
+    }
+    __syncthreads();
+    const CountLeanHot H = A.hot;
+    const int role = threadIdx.x & 1;
+    constexpr int n_codes = 64 / kCodeBits;
+    const int32_t n = H.n;
+    const int32_t pairs_per_grid = (int32_t)grid_x * kPairs;
+    for (int32_t q0 = (int32_t)blockIdx.x * kPairs; q0 < n; q0 += pairs_per_grid) {
+        const int32_t q = q0 + (int32_t)(threadIdx.x >> 1);
+        CountLeanTileLds *T = tile_lds(&s_tile);
+        bool live = q < n;
+        int32_t p = q, m = 0;
+        CodeChunk ck = {0ull, 0ull, 0, 0};
+        if (live) {
+            Quad rq = ld_quad(T->recs + q);
+            FMX_PIN_QUAD(rq);
+            ck.lo = (uint64_t)rq.x | ((uint64_t)rq.y << 32);
+            p = (int32_t)rq.z;
+            m = (int32_t)(rq.w & kPlanLongPattern);
+            if (m == (int32_t)kPlanLongPattern) {
+                const int32_t *off = T->pat_off;
+                m = off[p + 1] - off[p];
+            }
+        }
+        if (T->mixed) {  // mixed lengths: every wave gets patterns of (nearly) one (k_count)
+            const bool wave_mixed = __any(live && m != __shfl(m, 0)) != 0;
+            if (__syncthreads_or(wave_mixed ? 1 : 0)) {
+                Quad mine;
+                mine.x = (uint32_t)ck.lo;
+                mine.y = (uint32_t)(ck.lo >> 32);
+                mine.z = live ? (uint32_t)p : 0xffffffffu;
+                mine.w = (uint32_t)m;
+                const Quad r = regroup_records_body<kBlock>(s_len_bin, s_len_rec, mine);
+                ck.lo = (uint64_t)r.x | ((uint64_t)r.y << 32);
+                p = (int32_t)r.z;
+                m = (int32_t)r.w;
+                live = r.z != 0xffffffffu;
+            }
+        }
+        ck.n = m < n_codes ? m : n_codes;
+        int status = ST_OK;
+        int32_t start = 0, end = 0, back = 0, tabled = 0;
+        bool cold = false;
+        const bool chunks = __any(m > n_codes);  // one decision per wave
+        if (live && m <= 0) {
+            status = ST_JAVA_AIOOBE;  // pattern[-1], FM:456-457
+        } else if (live) {
+            if (chunks)
+                count_one_lean<kCodeBits, true, kMapBySymbol>(H, T, s_sbl, s_map, p, m, ck, role, start, end, back, tabled, cold);
+            else
+                count_one_lean<kCodeBits, false, kMapBySymbol>(H, T, s_sbl, s_map, p, m, ck, role, start, end, back, tabled, cold);
+        }
+        if (cold && role == 0) {  // the whole pattern goes on the redo list: k_count's list mode searches it over every route
+            uint32_t *redo_count = T->redo_count;
+            const uint32_t at = atomicAdd(redo_count, 1u);
+            T->redo_list[at] = p;
+        }
+        if (live && role == 0 && !cold) {
+            const int32_t d = end - start;
+            T->counts[p] = d > 0 ? d : 0;  // FM:473
+            int32_t *lf = T->lf_steps, *sto = T->status_out, *rng = T->range_out;
+            if (lf) lf[p] = 2 * (T->steps_mode ? back - tabled : back);
+            if (sto) sto[p] = status;
+            if (rng) {
+                rng[2 * (int64_t)p] = start;
+                rng[2 * (int64_t)p + 1] = end;
+            }
+        }
+    }
+}
+#endif  // !FMX_COMPACT
 
 // ---- growing the suffix table (fmx_device.hpp: fm_suffix_extend) when an index becomes resident ----
 // level 1: every character of the alphabet that occurs (its interval is cumulativeCounts' own)
@@ -1749,6 +2095,11 @@ static std::atomic<int> g_plan_sa_key{2};
 // Tried first (round 5): tiles taken from a counter on a grid of 8 workgroups per CU — the barrier that hands a tile to a
 // workgroup's eight waves ties them together: headline 0.138 -> 0.151 ms, series count +3 %.  Dropped.
 static std::atomic<int> g_count_halve_uniform{1};
+// option "count_lean": planned batches over expanded images run k_count_lean + k_count's list mode instead of k_count.  Default
+// OFF, by measurement (round 6, profiles/r06_experiments.txt 1): the lean kernel issues 20 % fewer vector instructions (26.0 M against
+// 32.5 M per headline launch, no spill at all) and takes the SAME time (89.0 against 90.9 us; + 4.6 us for the list pass that finds
+// its list empty) — k_count is not bound by instruction issue.  Kept as the A/B that showed it.
+static std::atomic<int> g_count_lean{0};
 // 1 = the plan stage of a batch of at most one tile per CU is ONE launch (k_plan_fused); 0 (default) = k_plan_codes +
 // k_plan_scatter.  Measured (round 5, configs[1]): step 0.1365 -> 0.1339 ms (-2 %), with two batches in flight 0.109 -> 0.117
 // (+7 %: workgroups waiting at the barrier hold their CUs) — not worth a spinning kernel by default.
@@ -1818,6 +2169,10 @@ int set_option(const char *name, int value) {
     }
     if (!strcmp(name, "count_halve_uniform")) {
         g_count_halve_uniform = value != 0;
+        return 0;
+    }
+    if (!strcmp(name, "count_lean")) {
+        g_count_lean = value != 0;
         return 0;
     }
     if (!strcmp(name, "plan_fused")) {
@@ -1988,6 +2343,10 @@ int launch_count_plan(const DevIndex &ix, int n_cu, const uint16_t *pat, const i
     if (g_plan_fine == 2 || (g_plan_fine == 1 && !sh.sa_key))
         hipLaunchKernelGGL(k_plan_fine, dim3((n + kFineWindow - 1) / kFineWindow), dim3(kFineThreads), 0, st, ordered, n);
     plan->recs = ordered;
+    // (the records by pattern are dead once the order is made: their place serves k_count_lean's redo list; its two counters sit
+    // in the head, zero between launches like the rest of it)
+    plan->redo_list = reinterpret_cast<int32_t *>(recs);
+    plan->redo_count = ticket + 8;
     plan->mixed = ticket + 2;
     plan->epoch = epoch;
     plan->n = n;
@@ -2017,7 +2376,7 @@ int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_
     const int bits = (mode == 1 || mode == 2) ? pl.code_bits : plan_code_bits(ix.wt_sigma);
 #define FMX_COUNT_LAUNCH(BLOCK, MODE, BITS)                                                                           \
     hipLaunchKernelGGL((k_count<BLOCK, MODE, BITS>), grid__, dim3(BLOCK), (size_t)g_lds_pad_kb * 1024, st, ix_launch, pat, \
-                       off, recs, n, counts, lf, status, range, pl.look_up, pl.sigma, (int)g_steps_executed_only, (int)g_regroup_by_length, recs ? pl.mixed : nullptr, pl.epoch, (int)g_count_halve_uniform)
+                       off, recs, n, counts, lf, status, range, pl.look_up, pl.sigma, (int)g_steps_executed_only, (int)g_regroup_by_length, recs ? pl.mixed : nullptr, pl.epoch, (int)g_count_halve_uniform, (const int32_t *)nullptr, (uint32_t *)nullptr)
 #define FMX_COUNT_MODE(MODE)                                                                                       \
     do {                                                                                                           \
         const int blk__ = g_block;                                                                                 \
@@ -2035,6 +2394,80 @@ int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_
     {
         const unsigned long long base = (unsigned long long)ix.base;
         (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_diag_base), &base, 8, 0, hipMemcpyHostToDevice, st);
+    }
+#endif
+#if !FMX_COMPACT
+    // a planned batch over an expanded image whose superblock headers fit LDS: the lean kernel (option "count_lean" = 0: A/B)
+    if (mode == 1 && g_count_lean && pl.redo_list && pl.redo_count && ix.n_sb <= kSbCacheMax && ix.n_sb <= ix.sb_cache_limit &&
+        (!ix_launch.suffix_table || pl.code_bits == ix.suffix_key_bits)) {
+        CountLeanArgs a;
+        a.hot.base = ix.base;
+        a.hot.sbc = ix.sbc;
+        a.hot.wt_sigma = ix.wt_sigma;
+        a.hot.n_sb = ix.n_sb;
+        a.hot.wt_size = ix.wt_size;
+        a.hot.n = n;
+        a.tile.C = ix.C;
+        a.tile.suffix_table = ix_launch.suffix_table;
+        a.tile.char2code = ix.char2code;
+        a.tile.redo_list = pl.redo_list;
+        a.tile.redo_count = pl.redo_count;
+        a.tile.pat = pat;
+        a.tile.pat_off = off;
+        a.tile.recs = recs;
+        a.tile.counts = counts;
+        a.tile.lf_steps = lf;
+        a.tile.status_out = status;
+        a.tile.range_out = range;
+        a.tile.suffix_chars = ix.suffix_chars;
+        a.tile.suffix_shift = ix.suffix_shift;
+        a.tile.suffix_mask = ix.suffix_mask;
+        a.tile.steps_mode = (int)g_steps_executed_only;
+        a.tile.mixed = 0;
+        a.sbd = ix.sbd;
+        a.plan_mixed = pl.mixed;
+        a.plan_epoch = pl.epoch;
+        a.regroup = (int)g_regroup_by_length;
+        a.halve_uniform = (int)g_count_halve_uniform;
+        const int blk = g_block;
+        const dim3 grid(grid_for(2 * (int64_t)n, blk, n_cu));
+        const size_t lds = (size_t)g_lds_pad_kb * 1024;
+#define FMX_LEAN_LAUNCH(BLOCK, BITS, BYSYM) hipLaunchKernelGGL((k_count_lean<BLOCK, BITS, BYSYM>), grid, dim3(BLOCK), lds, st, a)
+#define FMX_LEAN_SHAPE(BLOCK)                                    \
+    do {                                                         \
+        if (bits == 8 && ix.map_by_symbol)                       \
+            FMX_LEAN_LAUNCH(BLOCK, 8, true);                     \
+        else if (bits == 8)                                      \
+            FMX_LEAN_LAUNCH(BLOCK, 8, false);                    \
+        else if (ix.map_by_symbol)                               \
+            FMX_LEAN_LAUNCH(BLOCK, 16, true);                    \
+        else                                                     \
+            FMX_LEAN_LAUNCH(BLOCK, 16, false);                   \
+    } while (0)
+        if (blk == 1024)
+            FMX_LEAN_SHAPE(1024);
+        else
+            FMX_LEAN_SHAPE(512);
+#undef FMX_LEAN_SHAPE
+#undef FMX_LEAN_LAUNCH
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
+        // the redo list: k_count in list mode on a small grid (a workgroup per CU: the list is short, and mostly empty)
+        const int own_bits = plan_code_bits(ix.wt_sigma);
+        const dim3 redo_grid(n_cu > 0 ? (unsigned)n_cu : 256u);
+#define FMX_REDO_LAUNCH(BLOCK, BITS)                                                                                              \
+    hipLaunchKernelGGL((k_count<BLOCK, 4, BITS>), redo_grid, dim3(BLOCK), lds, st, ix_launch, pat, off, (const PlanRec *)nullptr, n, \
+                       counts, lf, status, range, (const int32_t *)nullptr, 0, (int)g_steps_executed_only, 0, (const uint32_t *)nullptr, \
+                       0u, 0, (const int32_t *)pl.redo_list, pl.redo_count)
+        if (blk == 1024 && own_bits == 8)
+            FMX_REDO_LAUNCH(1024, 8);
+        else if (blk == 1024)
+            FMX_REDO_LAUNCH(1024, 16);
+        else if (own_bits == 8)
+            FMX_REDO_LAUNCH(512, 8);
+        else
+            FMX_REDO_LAUNCH(512, 16);
+#undef FMX_REDO_LAUNCH
+        return (int)hipGetLastError();
     }
 #endif
     if (mode == 0)

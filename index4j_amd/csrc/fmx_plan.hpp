@@ -30,6 +30,10 @@ struct CountPlan {
     // two lengths; never reset — the next plan has another epoch).  k_count regroups its workgroups by length only then.
     const uint32_t *mixed = nullptr;
     uint32_t epoch = 0;
+    // k_count_lean's redo list (patterns that met a route it does not carry: room for n indices) and its counters {entries,
+    // workgroups of the list pass that are done} — both zero between launches; nullptr = no room (the general k_count runs)
+    int32_t *redo_list = nullptr;
+    uint32_t *redo_count = nullptr;
 };
 
 // head of the plan workspace: histogram, cursors, ticket — all zero between plans (k_plan_scatter restores that)
