@@ -2380,7 +2380,10 @@ FMX_HD bool fm_boundary_replay_marked(const DevIndex &ix, int mode, const TextWi
 // Both windows are fetched up front, at ONE program point, so that all lanes of a wave walk their intervals
 // together; later refills (lines longer than a window) happen wherever the replay needs them.
 // kMode >= 0: the mode as a compile-time constant (the kernels: one instance per mode, each without the other two's code)
-template <int G, int kMode = -1, int kWin = kWinAsk>
+// kDefer: the NARROW first round of a batch (G = 2: two sample intervals on each side of `from`, what most lines need) — a query the
+// marked replay cannot finish from those windows is not replayed literally here (its refills would hold the whole wave up) but
+// handed back like a suspect one (`clean` false): the caller puts it on a list that the wide form (G = 4) works off.
+template <int G, int kMode = -1, int kWin = kWinAsk, bool kDefer = false>
 FMX_HD int32_t fm_extract_boundary_group(const DevIndex &ix, const uint16_t *inv, int mode, int32_t from,
                                          int32_t mapped_boundary, uint16_t *dest, int32_t dst_len, int32_t offset,
                                          int32_t &steps, int &status, int32_t &aux, uint16_t *buf, int64_t row_stride,
@@ -2427,6 +2430,11 @@ FMX_HD int32_t fm_extract_boundary_group(const DevIndex &ix, const uint16_t *inv
         fm_boundary_replay_marked<G>(ix, mode, wl, wr, from, k0, dest, dst_len, offset, ret)) {
         steps = group_sum<G>(wl.steps + wr.steps);
         return ret;
+    }
+    if (kDefer) {
+        steps = group_sum<G>(wl.steps + wr.steps);
+        clean = false;
+        return 0;
     }
     bool finished = false;
     int32_t down_len = 0;

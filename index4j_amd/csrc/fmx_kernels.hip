@@ -1219,6 +1219,110 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk_c(DevIndex ix_global, const int32_t *
     }
 }
 
+// k_locate_walk over an index with a window directory as a TICKET QUEUE per wave (round 6).  A walk ends where it meets a sampled
+// row: after 0 .. sample_rate - 1 steps, so a wave that gives every lane ONE hit walks sample_rate - 1 steps with half of its lanes
+// done on average (k_locate_walk_c packs the unfinished walks of a workgroup through LDS twice on the way: three barriers a
+// packing).  Here a wave owns a run of `chunk` consecutive tickets and hands them out itself: every `burst` steps the lanes whose
+// walk is over take the next hit of their ticket, or the next tickets of the run (a ballot and a prefix count: no LDS, no
+// barrier), and walk on beside the lanes still under way.  A lane idles for half a burst per walk instead of half a walk.
+// Same tickets, same stores as k_locate_walk: which lane walks which hit is free (results go to the hit's own slot).
+template <int kBlock>
+FMX_WALK_KERNEL(kBlock) void k_locate_walk_q(DevIndex ix, const int32_t *__restrict__ range, int32_t n, int32_t max_matches,
+                                             int32_t *__restrict__ locs, int32_t loc_cap, int32_t slots,
+                                             int32_t *__restrict__ found, int32_t *__restrict__ lf_steps,
+                                             int32_t *__restrict__ status_out, const int32_t *__restrict__ taken,
+                                             const PlanRec *__restrict__ order, const uint32_t *__restrict__ order_idle,
+                                             int64_t *__restrict__ set_locs, int64_t set_base, int32_t chunk, int32_t burst) {
+    FMX_FM_INV(ix);
+    const int32_t lanes = slots < kWalkLanes ? slots : kWalkLanes;
+    const int64_t idle = order ? (int64_t)(*order_idle / (uint32_t)kFineWindow) * kFineWindow : 0;
+    const int64_t total = idle + ((int64_t)n - idle) * lanes;
+    const int32_t walk_limit = fm_walk_limit(ix);
+    const int64_t waves = (int64_t)gridDim.x * (kBlock / 64);
+    const int64_t wave_id = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1ull;
+    for (int64_t run = wave_id * chunk; run < total; run += waves * chunk) {
+        int64_t next = run;  // wave-uniform: the run's first ticket not handed out yet
+        const int64_t run_end = run + chunk < total ? run + chunk : total;
+        // the ticket a lane holds: hits k, k + step, ... < located of pattern p; and the walk it carries
+        int32_t p = 0, start = 0, k = 0, step = 1, located = 0, taken_p = 0;
+        bool walking = false;
+        WalkState w = {0, 0, ST_OK};
+        for (;;) {
+            // the hand-out (every lane votes: `next` stays the wave's): a lane whose walk is over moves on to the next hit of its
+            // ticket, and takes a new ticket when that one is done (or there was none yet)
+            bool need = false;
+            if (!walking) {
+                k += step;
+                need = k >= located;
+            }
+            const unsigned long long ball = __ballot(need ? 1 : 0);
+            const int64_t mine = next + (int64_t)__popcll(ball & below);
+            next += (int64_t)__popcll(ball);
+            if (need) {
+                located = 0;  // (no ticket left for this lane: it idles until the run is walked)
+                k = 0;
+                if (mine < run_end) {
+                    int64_t rec = mine;
+                    step = 1;
+                    if (mine >= idle) {
+                        rec = idle + (mine - idle) / lanes;
+                        k = (int32_t)((mine - idle) - (rec - idle) * lanes);
+                        step = lanes;
+                    }
+                    p = (int32_t)rec;
+                    int32_t end;
+                    if (order) {
+                        const Quad r = ld_quad(order + rec);
+                        start = (int32_t)r.x;
+                        end = (int32_t)r.y;
+                        p = (int32_t)r.z;
+                    } else {
+                        start = range[2 * p];
+                        end = range[2 * p + 1];
+                    }
+                    int32_t hits = start < end ? end - start : 0;
+                    int32_t limit = max_matches;
+                    taken_p = 0;
+                    if (taken) {  // segment sets: `taken[p]` hits came from earlier segments (the caller's loop passes maxMatches - taken)
+                        taken_p = taken[p];
+                        limit = max_matches - taken_p;
+                        if (limit <= 0) hits = 0;
+                    }
+                    // the reference stops at maxMatches (FM:544-546) and overruns `locations` beyond its length (Java AIOOBE)
+                    const int32_t wanted = (limit > 0 && hits > limit) ? limit : hits;
+                    located = wanted < loc_cap ? wanted : loc_cap;
+                    if (k == 0) {
+                        found[p] = located;
+                        if (wanted > loc_cap && status_out) atomicOr(&status_out[p], ST_JAVA_AIOOBE);
+                    }
+                }
+            }
+            if (!walking && k < located) {
+                w.j = start + 1 + k;  // FM:527-529
+                w.distance = 0;
+                w.status = ST_OK;
+                walking = true;
+            }
+            if (!__any(walking ? 1 : 0)) {
+                if (next >= run_end) break;
+                continue;
+            }
+            if (walking && fm_locate_steps_win(ix, w, burst, walk_limit)) {
+                const int32_t at = fm_locate_finish_win(ix, s_inv, w);
+                const int64_t dest = (int64_t)p * loc_cap + (set_locs ? taken_p : 0) + k;
+                if (set_locs)
+                    set_locs[dest] = set_base + at;
+                else
+                    locs[dest] = at;
+                if (lf_steps && w.distance) atomicAdd(&lf_steps[p], w.distance);
+                if (w.status && status_out) atomicOr(&status_out[p], w.status);
+                walking = false;
+            }
+        }
+    }
+}
+
 // FM:564-608.  Pipeline form (slot_found != nullptr): query q is hit (q % slots) of pattern (q / slots) and
 // runs only if that hit exists; with stops == nullptr the stop position is min(inputLength, start + fixed_len)
 // (the reference's locateAndExtractBenchmark, FmIndexThroughputBenchmark.java:231-249).
@@ -1295,14 +1399,22 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary(DevIndex ix_global, const in
 // kMode: the mode (0 / 1 / 2) as a compile-time constant — each instance carries one mode's replay.  A query whose walks met a
 // quirk path (`clean` false) is not answered here: its index goes onto the `redo` list ({count, 0, 0, 0, queries...}), which a
 // launch of the literal k_extract_boundary behind this kernel works off — the literal form is not part of this kernel's body.
-template <int kBlock, int G, int kMode, int kWin>
+// kDefer (the NARROW first round, G = 2): a query whose line does not lie inside the two intervals on each side of `from` goes onto
+// `redo` as well — which then is the `todo` list of a launch of the wide form (G = 4, kDefer false) behind this one.
+// todo (nullable): {count, 0, 0, 0, queries...} — only those queries are run, and their LF-steps are ADDED to what is there.
+template <int kBlock, int G, int kMode, int kWin, bool kDefer = false>
 FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix_global, const int32_t *__restrict__ froms, int64_t n,
                                                  uint16_t boundary, uint16_t *__restrict__ dst,
                                                  int32_t dst_len, int32_t offset, int32_t *__restrict__ out_len,
                                                  int32_t *__restrict__ lf_steps, int32_t *__restrict__ status_out,
                                                  int32_t *__restrict__ aux_out, uint16_t *__restrict__ scratch,
                                                  const int32_t *__restrict__ slot_found, int32_t slots, int pair_walks,
-                                                 const PlanRec *__restrict__ order, int32_t *__restrict__ redo) {
+                                                 const PlanRec *__restrict__ order, int32_t *__restrict__ redo,
+                                                 const int32_t *__restrict__ todo) {
+    if (todo) {
+        n = todo[0];
+        if (n <= 0) return;
+    }
     FMX_FM_INV(ix_global);
     FMX_WITH_SB_CACHE(ix_global, ix);
     const int64_t lanes = (int64_t)gridDim.x * kBlock;
@@ -1313,17 +1425,17 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix_global, co
     for (int64_t t = lane / G; t < n; t += groups) {
         // order (nullable): the queries by text position — equal and neighbouring `from` fetch the same sample intervals, and
         // walked by neighbouring groups those walks read the same lines (launch_extract_boundary)
-        const int64_t q = order ? (int64_t)ld_quad(order + t).z : t;
+        const int64_t q = todo ? (int64_t)todo[kRedoHead + t] : order ? (int64_t)ld_quad(order + t).z : t;
         if (slot_found && (int32_t)(q % slots) >= slot_found[q / slots]) continue;  // group-uniform
         int status = ST_OK;
         int32_t steps, aux;
         bool clean;
         uint16_t *dest = dst + q * (int64_t)dst_len;
-        const int32_t ret = fm_extract_boundary_group<G, kMode, kWin>(ix, s_inv, kMode, froms[q], mapped_boundary, dest, dst_len, offset, steps,
-                                                                status, aux, scratch + (lane - g), lanes, 1, lanes * (int64_t)ix.sample_rate, g,
-                                                                clean, pair_walks != 0);
+        const int32_t ret = fm_extract_boundary_group<G, kMode, kWin, kDefer>(ix, s_inv, kMode, froms[q], mapped_boundary, dest, dst_len, offset,
+                                                                        steps, status, aux, scratch + (lane - g), lanes, 1,
+                                                                        lanes * (int64_t)ix.sample_rate, g, clean, pair_walks != 0);
         if (g == 0) {
-            if (lf_steps) lf_steps[q] = steps;
+            if (lf_steps) lf_steps[q] = todo ? lf_steps[q] + steps : steps;
             if (!clean) {  // (rare) the literal form answers it: k_extract_boundary over the redo list
                 redo[kRedoHead + atomicAdd(&redo[0], 1)] = (int32_t)q;
             } else {
@@ -2073,12 +2185,20 @@ __global__ __launch_bounds__(256) void k_segment_commit(int32_t *__restrict__ fo
 // setting, so a launch that sees a mix of old and new values is still correct).
 static std::atomic<int> g_block{512};
 static std::atomic<int> g_groups_per_cu{16};
+static std::atomic<int> g_walk_queue{8};  // option "walk_queue": locate over a window directory hands its tickets out per wave, this many per lane and run (0: the packed form)
+static std::atomic<int> g_walk_queue_min_slots{32};  // option "walk_queue_min_slots": ... for calls with at least this many hit slots per pattern
+static std::atomic<int> g_walk_burst{0};  // option "walk_burst": LF-steps between two hand-outs (0 = sample_rate / 4, at least 2)
 static std::atomic<int> g_walk_pack{1};  // option "walk_pack": locate over a window directory packs the walks still under way into fewer waves (0: A/B)
 static std::atomic<int> g_boundary_accel{1};  // 0 = literal right walk of extractUntilBoundary (A/B and fallback)
 static std::atomic<int> g_boundary_group{4};  // lanes per query of extractUntilBoundary (0 = one lane per query)
 // first fill of extractUntilBoundary's two text windows: 0 = G intervals on each side, a lane walks one after the other;
 // 2 = the same with a lane's two walks interleaved (fm_lf_step2)
 static std::atomic<int> g_boundary_first_fill{2};
+// option "boundary_narrow" (default OFF, by measurement — round 6, profiles/r06_experiments.txt 2): the narrow first round walks 37.8 M
+// LF-steps where the wide form walks 50.9 M on configs[3] and takes 0.855 ms against 0.808: every pass costs a wave's lifetime (64
+// dependent steps of one or two HBM round trips: ~0.35 ms whatever the batch), and the second pass pays it again for a quarter of the queries
+static std::atomic<int> g_boundary_narrow{0};
+static std::atomic<int> g_boundary_narrow_min{4096};   // option "boundary_narrow_min": ... for batches at least this large
 static std::atomic<int> g_regroup_by_length{1};  // k_count: workgroups with mixed pattern lengths hand their records out again by length (0: A/B)
 static std::atomic<int> g_steps_executed_only{0};  // 1 = d_lf_steps of count() leave out what the suffix table answered
 static std::atomic<int> g_suffix_table_use{1};  // 0 = k_count ignores the index's suffix table (A/B)
@@ -2126,6 +2246,21 @@ int set_option(const char *name, int value) {
         g_walk_pack = value;
         return 0;
     }
+    if (!strcmp(name, "walk_queue")) {
+        if (value < 0 || value > 64) return -1;
+        g_walk_queue = value;
+        return 0;
+    }
+    if (!strcmp(name, "walk_queue_min_slots")) {
+        if (value < 0) return -1;
+        g_walk_queue_min_slots = value;
+        return 0;
+    }
+    if (!strcmp(name, "walk_burst")) {
+        if (value < 0 || value > 1024) return -1;
+        g_walk_burst = value;
+        return 0;
+    }
     if (!strcmp(name, "groups_per_cu")) {
         if (value < 1 || value > 64) return -1;
         g_groups_per_cu = value;
@@ -2151,6 +2286,15 @@ int set_option(const char *name, int value) {
     if (!strcmp(name, "boundary_first_fill")) {
         if (value != 0 && value != 2) return -1;  // (1, half-width windows, was measured slower in round 3 and is gone)
         g_boundary_first_fill = value;
+        return 0;
+    }
+    if (!strcmp(name, "boundary_narrow")) {
+        g_boundary_narrow = value != 0;
+        return 0;
+    }
+    if (!strcmp(name, "boundary_narrow_min")) {
+        if (value < 0) return -1;
+        g_boundary_narrow_min = value;
         return 0;
     }
     if (!strcmp(name, "suffix_table")) {
@@ -2529,6 +2673,20 @@ int launch_locate_walk(const DevIndex &ix, int n_cu, const int32_t *range, int32
         order_idle = ticket + 1;
     }
     const int64_t tickets = (int64_t)n * (slots < kWalkLanes ? slots : kWalkLanes);
+    // a window directory and many hits per pattern: the ticket-queue form (k_locate_walk_q).  Measured (round 6, profiles/r06_experiments.txt
+    // 3): locate(100) of the reference-shaped series 2.47 -> 2.14-2.26 ms; with <= 16 hits per pattern the hand-out's record loads cost
+    // more than the idle lanes they save (configs[2] 0.247 -> 0.34 ms, locate(1) 1.09 -> 1.14): those keep the packed form below
+    if (ix.win && g_walk_queue.load() && ix.sample_rate >= 4 && slots >= g_walk_queue_min_slots.load()) {
+        const int64_t waves = (tickets + 63) / 64;  // a lane per ticket would need this many waves: give each wave `per` lanes' worth
+        int32_t per = g_walk_queue.load();          // tickets per lane and run (option "walk_queue": 0 = off)
+        const int32_t chunk = 64 * per;
+        int32_t burst = g_walk_burst.load();
+        if (burst <= 0) burst = ix.sample_rate / 4 > 2 ? ix.sample_rate / 4 : 2;
+        (void)waves;
+        FMX_DISPATCH(k_locate_walk_q, (tickets + per - 1) / per, ix, range, n, max_matches, locs, loc_cap, slots, found, lf, status, taken, order,
+                     order_idle, set_locs, set_base, chunk, burst);
+        return (int)hipGetLastError();
+    }
     if (ix.win && g_walk_pack.load() && ix.sample_rate >= 8) {  // a window directory: the packed form (k_locate_walk_c)
         const int packings = g_walk_pack.load() >= 3 ? 3 : 2;
         FMX_DISPATCH(k_locate_walk_c, tickets, ix, range, n, max_matches, locs, loc_cap, slots, found, lf, status, taken, order, order_idle,
@@ -2673,7 +2831,8 @@ static size_t boundary_bytes_for_grid(const DevIndex &ix, int blocks, const Boun
 static size_t boundary_redo_bytes(int64_t n) { return ((size_t)kRedoHead + (size_t)n) * sizeof(int32_t) + 64; }
 static size_t boundary_bytes_for(const DevIndex &ix, int64_t n, int n_cu, const BoundaryShape &b) {
     if (!b.accel || n <= 0) return 0;
-    return boundary_bytes_for_grid(ix, grid_for(n * (b.group ? b.group : 1), b.block, n_cu), b) + boundary_redo_bytes(n);
+    // (two lists: the narrow round's `todo` for the wide form, and the wide form's redo for the literal one)
+    return boundary_bytes_for_grid(ix, grid_for(n * (b.group ? b.group : 1), b.block, n_cu), b) + 2 * boundary_redo_bytes(n) + 32;
 }
 size_t boundary_workspace_bytes(const DevIndex &ix, int64_t n, int n_cu) {
     // upper bound over the workgroup sizes: whatever shape the launch snapshots fits
@@ -2713,14 +2872,45 @@ int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, i
     const dim3 grid(scratch ? blocks_accel : grid_for(n, blk, n_cu));
     // the group kernel's redo list lives behind the windows; its count is cleared in front of every launch
     int32_t *redo = (scratch && G > 0) ? reinterpret_cast<int32_t *>(static_cast<uint8_t *>(workspace) + ((windows_bytes + 15) & ~(size_t)15)) : nullptr;
+    // The NARROW first round (option "boundary_narrow", default 1; the default group of 4, sample rates the marked replay serves,
+    // batches of "boundary_narrow_min" queries or more): the walks are what this costs (one sector per LF-step, at the chip's
+    // random-sector rate) and the wide form fetches 8 sample intervals per query where a line needs 3.1 — so every query first
+    // gets the two intervals on each side of `from` (G = 2, a lane's two walks interleaved: HALF the LF-steps), and only a query
+    // whose line does not end inside them (about one in seven of configs[3]) takes the wide form, off a list, in a launch behind.
+    int32_t *todo = nullptr;
+    if (redo && G == 4 && pair_walks && g_boundary_narrow && ix.sample_rate <= 64 && n >= g_boundary_narrow_min &&
+        workspace_bytes >= windows_bytes + 2 * boundary_redo_bytes(n) + 16) {
+        todo = redo;
+        redo = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(todo) + ((boundary_redo_bytes(n) + 15) & ~(size_t)15));
+        if (hipError_t e = hipMemsetAsync(todo, 0, kRedoHead * sizeof(int32_t), st); e != hipSuccess) return (int)e;
+    }
     if (redo)
         if (hipError_t e = hipMemsetAsync(redo, 0, kRedoHead * sizeof(int32_t), st); e != hipSuccess) return (int)e;
     // (kWinAsk: this kernel looks at ix.win itself.  An instantiation without the tree walk — kWinAlways, as k_locate_walk and
     // k_extract have — was measured SLOWER here: 94 instead of 112 VGPRs, five waves per SIMD instead of four, 20 bytes of scratch
     // in the walk's loop: 0.98 vs 0.78 ms on configs[3], round 5)
+#define FMX_LAUNCH_NARROW_MODE(BLK, MODE)                                                                                \
+    hipLaunchKernelGGL((k_extract_boundary_group<BLK, 2, MODE, kWinAsk, true>), narrow_grid, dim3(BLK), 0, st, ix, from, n, boundary, dst, \
+                       dst_len, offset, out_len, lf, status, aux, scratch, slot_found, slots, pair_walks, order, todo,          \
+                       (const int32_t *)nullptr)
+    if (todo) {
+        const dim3 narrow_grid(grid_for(n * 2, blk, n_cu));  // (never more lanes than the windows were sized for: the wide form's grid)
+        if (blk == 1024) {
+            if (mode == 0) FMX_LAUNCH_NARROW_MODE(1024, 0);
+            else if (mode == 1) FMX_LAUNCH_NARROW_MODE(1024, 1);
+            else FMX_LAUNCH_NARROW_MODE(1024, 2);
+        } else {
+            if (mode == 0) FMX_LAUNCH_NARROW_MODE(512, 0);
+            else if (mode == 1) FMX_LAUNCH_NARROW_MODE(512, 1);
+            else FMX_LAUNCH_NARROW_MODE(512, 2);
+        }
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
+    }
+#undef FMX_LAUNCH_NARROW_MODE
 #define FMX_LAUNCH_GROUP_MODE(BLK, GG, MODE)                                                                             \
     hipLaunchKernelGGL((k_extract_boundary_group<BLK, GG, MODE, kWinAsk>), grid, dim3(BLK), 0, st, ix, from, n, boundary, dst, dst_len, \
-                       offset, out_len, lf, status, aux, scratch, slot_found, slots, pair_walks, order, redo)
+                       offset, out_len, lf, status, aux, scratch, slot_found, slots, pair_walks, todo ? nullptr : order, redo,  \
+                       (const int32_t *)todo)
 #define FMX_LAUNCH_GROUP(GG)                                                                                            \
     do {                                                                                                                \
         if (blk == 1024) {                                                                                              \
