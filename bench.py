@@ -103,6 +103,11 @@ def ref_series_module():
     return ref_series
 
 
+def index_cache_path(text, text_log2, sample_rate, cache_dir):
+    key = hashlib.sha256(text[: 1 << 16].tobytes() + b"%d-%d-v1" % (1 << text_log2, sample_rate)).hexdigest()[:16]
+    return os.path.join(cache_dir, "fmx_%s.ser" % key)
+
+
 def build_or_load_index(ia, text_log2, sample_rate, cache_dir, build_device=0, seed=42):
     """index of 2^text_log2 chars of synthetic log; the serialized form is cached under cache_dir.
     Construction runs its suffix-array stage on GPU `build_device` (same index, byte for byte: fmx_build_on_device);
@@ -110,8 +115,7 @@ def build_or_load_index(ia, text_log2, sample_rate, cache_dir, build_device=0, s
     n = 1 << text_log2
     t0 = time.time()
     text = ia.synth_log(n, seed=seed)
-    key = hashlib.sha256(text[: 1 << 16].tobytes() + b"%d-%d-v1" % (n, sample_rate)).hexdigest()[:16]
-    path = os.path.join(cache_dir, "fmx_%s.ser" % key)
+    path = index_cache_path(text, text_log2, sample_rate, cache_dir)
     t1 = time.time()
     if os.path.exists(path):
         fm = ia.FmIndex.read(open(path, "rb").read(), device=None)
@@ -325,6 +329,12 @@ def compact_line(out):
                 sec.append({"config": _short(sr.get("key") or name, 44), "ms": sr.get("ms_per_batch", None if sr.get("build_s") is None else sr["build_s"] * 1e3),
                             "frac": rf.get("frac"), "alg": rf.get("frac_algorithmic"), "tfrac": rf.get("traffic_frac")})
             continue
+        if row.get("forms"):  # the footprint block: [form, resident bytes per text byte (s = 32 / 64), configs[2] ms, configs[3] ms]
+            c["footprint"] = _sig([[_short(f["form"], 28), f.get("resident_bytes_per_text_byte"), f.get("resident_bytes_per_text_byte_s64"),
+                                    f.get("configs2_ms"), f.get("configs3_ms")] for f in row["forms"]], 3)
+            c["footprint_keys"] = "form, resident B per text B (s=32, s=64), configs[2] ms, configs[3] ms; index4j serialized: %.2f" % (
+                row.get("index4j_serialized_bytes_per_text_byte") or 0.0)
+            continue
         cfg_name = row.get("config") or row.get("metric")
         if isinstance(cfg_name, dict):  # a whole line of another workload (configs[4] inside the N > 1 default run)
             cfg_name = "configs[4] segments: " + str(cfg_name.get("workload"))
@@ -347,7 +357,7 @@ def compact_line(out):
     c["detail"] = "gpurun_out/bench_detail.json (+ the stdout line before this one)"
     line = json.dumps(c, separators=(",", ":"))
     if len(line) >= COMPACT_LIMIT:  # never let an over-long line out again: shed the optional blocks, largest first
-        for k in ("secondary", "host_buffers", "index_broadcast", "suffix_table", "ranks_seen"):
+        for k in ("secondary", "footprint", "host_buffers", "index_broadcast", "suffix_table", "ranks_seen"):
             if k in c and len(line) >= COMPACT_LIMIT:
                 c[k] = "see detail"
                 line = json.dumps(c, separators=(",", ":"))
@@ -1317,6 +1327,71 @@ def run_secondary(ctx, args, q, ref, orc, text, pat, off):
                                      "(one re-seek per 4 characters, FM:697-743) over the same time"},
                 "checked_vs_oracle": "all %d queries: lengths, statuses, whole destination rows" % K})
     rs.settle_frac(res[-1]["roofline"], ms, traffic_of("configs[3]", K))
+    ms3_default = ms
+    # ---- footprint: what is resident per text byte against what it buys ----
+    # index4j exists for the space / time trade (README.md: the serialized index is 0.44-0.47 of the text,
+    # FmIndexSerializedSizeBenchmark.java:57).  Three forms of the resident index, each with its bytes per text byte
+    # (fmx_resident_bytes) and the time of configs[2] and configs[3] over it: the compact image (index4j's own RRR compression kept),
+    # the expanded image, and — the default, the rows above — the expanded image with the window directory.  Every form's
+    # results are compared with the default form's (which the oracle checked above).
+    if not args.profiling:
+        try:
+            text_bytes = float(1 << args.text_log2)
+            path = index_cache_path(text, args.text_log2, args.sample_rate, args.cache_dir)  # (the headline's index, cached by run_count)
+            locate(q, False)
+            torch.cuda.synchronize()
+            want_locs, want_found = d_locs.cpu().numpy().copy(), d_found.cpu().numpy().copy()
+            want_dst, want_len = d_dst.cpu().numpy().copy(), d_len.cpu().numpy().copy()
+
+            def resident(index):
+                a, b, c3 = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+                check_rc(ia, ia.lib.fmx_resident_bytes(index.handle, C.byref(a), C.byref(b), C.byref(c3)), "fmx_resident_bytes")
+                return a.value, b.value, c3.value
+
+            forms = [{"form": "expanded image + window directory (the default: the rows above)", "configs2_ms": res[-2]["ms"],
+                      "configs3_ms": ms3_default, "resident": resident(q), "resident64": resident(fm64)}]
+            for form, compact, cells in (("expanded image, no directory", 0, 0), ("compact image (RRR records), no directory", 1, 0)):
+                check_rc(ia, ia.lib.fmx_set_option(b"image_compact", compact), "fmx_set_option")
+                check_rc(ia, ia.lib.fmx_set_option(b"window_cells", cells), "fmx_set_option")
+                try:
+                    a32 = ia.FmIndex.read(open(path, "rb").read(), device=ctx.local_rank)
+                    a64 = ia.FmIndex.read(open(path64, "rb").read(), device=ctx.local_rank)
+                finally:
+                    ia.lib.fmx_set_option(b"image_compact", 1 if args.image_compact else 0)
+                    ia.lib.fmx_set_option(b"window_cells", 2)
+                try:
+                    d_locs.zero_()
+                    locate(a32, False)
+                    torch.cuda.synchronize()
+                    if not ((d_found.cpu().numpy() == want_found).all() and (d_locs.cpu().numpy() == want_locs).all()):
+                        raise RuntimeError("locate over the %s differs from the default form's" % form)
+                    ms2_f = timed(lambda: locate(a32, False), 3)
+                    d_dst.zero_()
+                    check_rc(ia, ia.lib.fmx_extract_boundary_batch_dev(a64.handle, d_from.data_ptr(), K, 10, 0, d_dst.data_ptr(), cap, 0,
+                                                                       d_len.data_ptr(), None, d_st.data_ptr(), d_aux.data_ptr(), sp),
+                             "fmx_extract_boundary_batch_dev")
+                    torch.cuda.synchronize()
+                    if not ((d_len.cpu().numpy() == want_len).all() and (d_dst.cpu().numpy() == want_dst).all()):
+                        raise RuntimeError("extractUntilBoundary over the %s differs from the default form's" % form)
+                    ms3_f = timed(lambda: check_rc(ia, ia.lib.fmx_extract_boundary_batch_dev(
+                        a64.handle, d_from.data_ptr(), K, 10, 0, d_dst.data_ptr(), cap, 0, d_len.data_ptr(), None, d_st.data_ptr(),
+                        d_aux.data_ptr(), sp), "fmx_extract_boundary_batch_dev"), 3)
+                    forms.append({"form": form, "configs2_ms": ms2_f, "configs3_ms": ms3_f, "resident": resident(a32), "resident64": resident(a64)})
+                finally:
+                    a32.close()
+                    a64.close()
+            for f in forms:
+                f["resident_bytes_per_text_byte"] = sum(f["resident"]) / text_bytes              # the sampleRate-32 index (configs[2])
+                f["resident_bytes_per_text_byte_s64"] = sum(f["resident64"]) / text_bytes        # the sampleRate-64 index (configs[3])
+                f["image_suffix_table_directory_bytes"] = list(f.pop("resident"))
+                f.pop("resident64")
+            res.append({"config": "footprint: resident bytes per text byte of three forms of the index and what each costs configs[2] / [3]",
+                        "ms": None, "forms": forms,
+                        "index4j_serialized_bytes_per_text_byte": os.path.getsize(path) / text_bytes,
+                        "checked": "every form's located positions and destination rows equal the default form's (oracle-checked above)"})
+        except Exception as e:  # noqa: BLE001 - an extra row: its failure is reported on the row
+            log("[bench] footprint rows FAILED: %r" % (e,))
+            res.append({"config": "footprint: resident bytes per text byte of three forms of the index", "ms": None, "error": repr(e)[:300]})
     fm64.close()
     # ---- the headline's shape WITHOUT the generator's repetition: 1,048,576 DISTINCT 8-char patterns ----
     # The synthetic log repeats itself (328,091 distinct patterns in the headline batch); equal patterns side by side share

@@ -14,6 +14,8 @@
 #include <atomic>
 #include <chrono>
 #include <climits>
+#include <condition_variable>
+#include <deque>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -451,6 +453,71 @@ struct PinBuf {
     }
 };
 
+// Staging of PAGEABLE caller arrays (what a JVM heap array behind GetPrimitiveArrayCritical is): a plain hipMemcpy from pageable
+// memory is staged by the runtime on the calling thread at a fraction of the link's rate (1 M x 8 chars: 1.0 ms per call against a
+// PCIe floor of 0.34).  Here the bytes go through pinned staging of the library's own, copied by a few host threads side by side —
+// a chunk's copy beside the DMA of the chunk before it — and travel by asynchronous DMA at the link's rate.
+// A small pool of copy threads, started on first use and never stopped (like the per-device workers of fmx_multi.cpp).
+struct CopyPool {
+    struct Task {
+        char *dst;
+        const char *src;
+        size_t bytes;
+        std::atomic<int> *open;
+    };
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Task> q;
+    int started = 0;
+    void worker() {
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> lock(m);
+                cv.wait(lock, [&] { return !q.empty(); });
+                t = q.front();
+                q.pop_front();
+            }
+            memcpy(t.dst, t.src, t.bytes);
+            t.open->fetch_sub(1, std::memory_order_release);
+        }
+    }
+    // dst[0 .. bytes) = src[0 .. bytes) by `threads` threads (the caller is one of them); returns when all of it is there
+    void copy(void *dst, const void *src, size_t bytes, int threads) {
+        constexpr size_t kMinPart = (size_t)256 << 10;
+        int parts = threads;
+        if ((size_t)parts > bytes / kMinPart) parts = (int)(bytes / kMinPart);
+        if (parts <= 1) {
+            memcpy(dst, src, bytes);
+            return;
+        }
+        const size_t per = ((bytes / (size_t)parts) + 63) & ~(size_t)63;
+        std::atomic<int> open{parts - 1};
+        {
+            std::lock_guard<std::mutex> lock(m);
+            while (started < threads - 1) {  // (thread creation may throw: the entry points' guard reports it)
+                std::thread(&CopyPool::worker, this).detach();
+                ++started;
+            }
+            for (int i = 1; i < parts; ++i) {
+                const size_t lo = (size_t)i * per, hi = i + 1 == parts ? bytes : std::min(bytes, lo + per);
+                q.push_back(Task{static_cast<char *>(dst) + lo, static_cast<const char *>(src) + lo, hi > lo ? hi - lo : 0, &open});
+            }
+        }
+        cv.notify_all();
+        memcpy(dst, src, std::min(per, bytes));
+        while (open.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    }
+};
+CopyPool &copy_pool() {
+    static CopyPool *pool = new CopyPool();  // leaked on purpose: its threads outlive every static destructor
+    return *pool;
+}
+// option "host_stage_threads": host threads that stage a pageable array into pinned memory (0 / 1 = the runtime's own staging, the
+// default BY MEASUREMENT: with the result copies gone — below — a 1 M-pattern call takes 0.58 ms with the runtime's staging and
+// 0.70-0.73 with 3-6 threads of this pool: the runtime's copy is not what the call was waiting for; profiles/r06_experiments.txt 4)
+std::atomic<int> g_host_stage_threads{0};
+
 // Three streams per (host thread, device) for the pipelined host-buffer entry points.  Created on first use and never
 // destroyed (a thread_local destructor would run while the HIP runtime may already be shutting down).
 constexpr int kPipeStreams = 3;  // copies in, kernels, copies out
@@ -667,6 +734,11 @@ int fmx_set_option(const char *name, int value) {
     if (name && !strcmp(name, "host_pipeline_min")) {  // host-buffer count(): batches at least this large are pipelined (0 = never)
         if (value < 0) return fail(FMX_E_ARG, "bad value");
         g_host_pipeline_min = value;
+        return FMX_OK;
+    }
+    if (name && !strcmp(name, "host_stage_threads")) {  // host threads staging a pageable array into pinned memory (0 / 1: the runtime's own staging)
+        if (value < 0 || value > 64) return fail(FMX_E_ARG, "bad value");
+        g_host_stage_threads = value;
         return FMX_OK;
     }
     if (name && !strcmp(name, "host_pipeline_chunk")) {
@@ -2074,6 +2146,7 @@ static int count_batch_mapped(const fmx_index *idx, const uint16_t *pat, const i
 // while this one keeps feeding the pipeline (a pageable source makes hipMemcpyAsync stage on the calling thread).
 static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n, int32_t *counts,
                                  int32_t *lf_steps, int32_t *status) {
+    const double t_enter = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
     if (pat_off[0] < 0 || pat_off[n] < pat_off[0]) return fail(FMX_E_ARG, "pattern offsets start below 0 or decrease");
     const int64_t total_chars = pat_off[n];
     PipeStreams *ps = nullptr;
@@ -2089,6 +2162,7 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
                             (!status || is_pinned_range(status, (size_t)n * 4));
     DevBuf d_pat, d_off, d_cnt, d_lf, d_st;
     PinBuf h_cnt, h_lf, h_st;
+    PinBuf h_pat;  // pinned staging of the characters of a pageable source (option host_stage_threads >= 2); lives until the streams are drained
     HIP_TRY(d_pat.alloc((size_t)total_chars * 2 + 8));
     HIP_TRY(d_off.alloc(((size_t)n + 1 + (size_t)n_chunks) * 4));  // every chunk its own run of offsets (n_c + 1 entries)
     int32_t *o_cnt = counts, *o_lf = lf_steps, *o_st = status;  // where the D2H copies land
@@ -2112,9 +2186,21 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
     int32_t *m_cnt = nullptr, *m_lf = nullptr, *m_st = nullptr;
     bool stores_out = false;
     if (g_host_direct_stores.load()) {
-        m_cnt = static_cast<int32_t *>(mapped_range(o_cnt, (size_t)n * 4));
-        m_lf = lf_steps ? static_cast<int32_t *>(mapped_range(o_lf, (size_t)n * 4)) : nullptr;
-        m_st = status ? static_cast<int32_t *>(mapped_range(o_st, (size_t)n * 4)) : nullptr;
+        // (a caller's array must lie inside one range registered through fmx_host_register: mapped_range; the library's own pinned
+        // staging is mapped by construction — round 5's stricter mapped_range had silently sent it back to result COPIES, eight
+        // device-to-host copies of 1 MB at 148 us each per 1 M-pattern call: 1.2 of the call's 1.75 ms, round 6)
+        auto mapped_out = [&](int32_t *host) -> int32_t * {
+            if (direct_out) return static_cast<int32_t *>(mapped_range(host, (size_t)n * 4));
+            void *dev = nullptr;
+            if (hipHostGetDevicePointer(&dev, host, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                return nullptr;
+            }
+            return static_cast<int32_t *>(dev);
+        };
+        m_cnt = mapped_out(o_cnt);
+        m_lf = lf_steps ? mapped_out(o_lf) : nullptr;
+        m_st = status ? mapped_out(o_st) : nullptr;
         stores_out = m_cnt && (!lf_steps || m_lf) && (!status || m_st);
     }
     if (!stores_out) {
@@ -2202,14 +2288,29 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
     std::atomic<bool> feed_stop{false};
     std::thread feeder;
     JoinOnExit join_feeder{feeder, feed_stop};
+    const int stage_threads = g_host_stage_threads.load();
+    const bool staged_in = !in_pinned && stage_threads >= 2 && total_chars > pat_off[0] &&
+                           h_pat.alloc((size_t)(total_chars - pat_off[0]) * 2) == hipSuccess;
+    if (!staged_in) (void)hipGetLastError();
     if (!in_pinned) {
         const int device = idx->device;
         feeder = std::thread([&, device]() {
             (void)hipSetDevice(device);
+            const int64_t first = pat_off[0];
             for (int32_t c = 0; c < n_chunks && !feed_stop.load(); ++c) {
                 const int64_t c0 = pat_off[bounds[(size_t)c]], c1 = pat_off[bounds[(size_t)c + 1]];
-                if (c1 > c0 && hipMemcpy(d_pat.as<uint16_t>() + c0, pat + c0, (size_t)(c1 - c0) * 2, hipMemcpyHostToDevice) != hipSuccess)
-                    feed_error = 1;
+                if (c1 > c0) {
+                    if (staged_in) {
+                        // this chunk's characters into the pinned staging by several threads, then DMA behind the chunk before it
+                        uint16_t *stage = h_pat.as<uint16_t>() + (c0 - first);
+                        copy_pool().copy(stage, pat + c0, (size_t)(c1 - c0) * 2, stage_threads);
+                        if (hipMemcpyAsync(d_pat.as<uint16_t>() + c0, stage, (size_t)(c1 - c0) * 2, hipMemcpyHostToDevice, s_in) != hipSuccess)
+                            feed_error = 1;
+                    } else if (hipMemcpy(d_pat.as<uint16_t>() + c0, pat + c0, (size_t)(c1 - c0) * 2, hipMemcpyHostToDevice) != hipSuccess) {
+                        feed_error = 1;
+                    }
+                }
+                if (staged_in && hipEventRecord(ps->in[c % kPipeEvents], s_in) != hipSuccess) feed_error = 1;
                 fed.store(c + 1, std::memory_order_release);
             }
         });
@@ -2250,9 +2351,10 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
             else
                 e = hipMemcpyAsync(d_off_c, pat_off + lo, (size_t)(n_c + 1) * 4, hipMemcpyHostToDevice, s_k);
         }
-        if (!in_pinned) {  // the feeder has this chunk's characters in HBM?
+        if (!in_pinned) {  // the feeder has this chunk's characters in HBM (or, staged: on their way, behind the chunk's event)?
             while (fed.load(std::memory_order_acquire) <= c) std::this_thread::yield();
             if (feed_error) e = hipErrorUnknown;
+            if (e == hipSuccess && staged_in) e = hipStreamWaitEvent(s_k, ps->in[slot], 0);
         }
         if (e == hipSuccess && in_pinned) {
             e = hipEventRecord(ps->in[slot], s_in);
@@ -2313,9 +2415,10 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
     // (also on failure: the per-call blocks go back to the cache when this call ends, nothing may still use them)
     if (!drain()) out_error = 1;
     if (timing)
-        fprintf(stderr, "[fmx pipe] %d chunks: alloc %.0f us | scan %.0f | copy-in calls %.0f | kernel launches %.0f | copy-out calls %.0f | "
-                        "issue loop %.0f | helper join +%.0f | drain +%.0f (direct_out %d)\n",
-                n_chunks, 0.0, t_scan, t_in, t_launch, t_out, t_issued - t_begin, t_joined - t_issued, now() - t_joined, (int)direct_out);
+        fprintf(stderr, "[fmx pipe] %d chunks: setup %.0f us | scan %.0f | copy-in calls %.0f | kernel launches %.0f | copy-out calls %.0f | "
+                        "issue loop %.0f | helper join +%.0f | drain +%.0f (direct_out %d, staged_in %d)\n",
+                n_chunks, t_begin - t_enter, t_scan, t_in, t_launch, t_out, t_issued - t_begin, t_joined - t_issued, now() - t_joined, (int)direct_out,
+                (int)staged_in);
     if (failed) return failed;
     if (out_error) return fail(FMX_E_HIP, "host-buffer pipeline: a stage failed");
     return FMX_OK;
@@ -2323,6 +2426,15 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
 
 int fmx_count_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n, int32_t *counts,
                     int32_t *lf_steps, int32_t *status) {
+    static const bool timing = getenv("FMX_PIPE_TIMING") != nullptr;
+    const auto t_call = std::chrono::steady_clock::now();
+    struct Report {
+        bool on;
+        std::chrono::steady_clock::time_point t0;
+        ~Report() {
+            if (on) fprintf(stderr, "[fmx pipe] whole call %.0f us\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+        }
+    } report{timing, t_call};
     return guarded([&]() -> int {
     int rc = require_device(idx);
     if (rc) return rc;
