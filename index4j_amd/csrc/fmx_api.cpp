@@ -158,6 +158,7 @@ std::atomic<int> g_suffix_table_chars{8};  // option "suffix_table_chars": its d
 std::atomic<int> g_plan_min_per_string{16};
 std::atomic<int> g_plan_sa_min{786432};   // option "plan_sa_min" (plan_pays)
 std::atomic<int> g_plan_sa_key_api{2};     // mirror of the kernels' option "plan_sa_key"
+std::atomic<int> g_code_bits_12_api{1};   // mirror of the kernels' option "code_bits_12": the key width of suffix tables grown from now on
 std::atomic<int> g_suffix_table_in_use{1};  // mirror of the kernels' A/B option "suffix_table": launches told to ignore the table plan as if there were none
 std::atomic<int> g_suffix_table_image_fraction{8};  // option "suffix_table_image_fraction": the table stays below image / this (0 = only the budget counts)
 // option "window_cells": indexes made resident afterwards grow a window directory (fmx_device.hpp "window directory": 64 bytes per
@@ -244,7 +245,7 @@ void make_dev_index(fmx_index *idx) {
     d.map_by_symbol = h.map_by_symbol;
     d.suffix_table = nullptr;
     d.suffix_chars = 0;
-    d.suffix_key_bits = h.wt_sigma <= 256 ? 8 : 16;
+    d.suffix_key_bits = fmx::fmx_code_bits_for(h.wt_sigma, g_code_bits_12_api.load() != 0);
     d.suffix_shift = 0;
     d.suffix_mask = 0;
     d.suffix_order1 = nullptr;
@@ -800,6 +801,7 @@ int fmx_set_option(const char *name, int value) {
     if (!name) return fail(FMX_E_ARG, "unknown option or bad value");
     if (!strcmp(name, "suffix_table")) g_suffix_table_in_use = value != 0;
     if (!strcmp(name, "plan_sa_key") && value >= 0 && value <= 2) g_plan_sa_key_api = value;
+    if (!strcmp(name, "code_bits_12")) g_code_bits_12_api = value != 0;
     if (!strcmp(name, "segments_direct")) {
         g_segments_direct = value != 0;
         return FMX_OK;
@@ -1069,7 +1071,7 @@ static void build_suffix_table(fmx_index *idx) {
     idx->dev.suffix_table = nullptr;
     idx->dev.suffix_order1 = nullptr;
     idx->dev.suffix_chars = 0;
-    idx->dev.suffix_key_bits = idx->hdr.wt_sigma <= 256 ? 8 : 16;
+    idx->dev.suffix_key_bits = fmx::fmx_code_bits_for(idx->hdr.wt_sigma, g_code_bits_12_api.load() != 0);
     idx->dev.suffix_shift = 0;
     idx->dev.suffix_mask = 0;
     if (idx->rrr_only || idx->wavelet_only || idx->hdr.kind != 0) return;

@@ -72,7 +72,7 @@ struct DevIndex {
     uint32_t wt_size;
     // Suffix table (nullptr: none): the SA interval of every string of 2 .. `suffix_chars` codes THAT OCCURS IN THE TEXT,
     // i.e. the state of FM:455-474 after a pattern's last characters — an open-addressing hash table of 16-byte
-    // slots {key, start, end}; key = the codes, the LAST character in the low bits, `suffix_key_bits` (8 or 16, by this
+    // slots {key, start, end}; key = the codes, the LAST character in the low bits, `suffix_key_bits` (8, 12 or 16, by this
     // index's alphabet) each: the low bits of a plan record's code word as they stand (codes beyond the string: 0).  A string
     // that is not in the table (it does not occur, holds a code of 0, or its search raised a status) is simply looked for
     // with the loop.
@@ -96,6 +96,9 @@ struct DevIndex {
     // this index's DevIndex as the API layer keeps it in HBM (no LDS cache, no launch option applied): what a cold route reads
     const DevIndex *self;
 };
+// width of one alphabet code in a plan record's word and in a suffix-table key: 8 bits while the alphabet fits, 12 for alphabets
+// of up to 4,096 codes (five codes per 64-bit word, keys of five characters), else 16
+inline int fmx_code_bits_for(int32_t sigma, bool allow_12 = true) { return sigma <= 256 ? 8 : ((allow_12 && sigma <= 4096) ? 12 : 16); }
 constexpr int kOrder1MaxSigma = 90;  // hard cap of the order-1 table (90^2 pairs of two floats = 64,800 bytes)
 // The plan kernels stage that table in LDS BEHIND their histogram (`bins` words): it is only used — and only built — where both
 // fit the kernels' dynamic LDS: sigma <= 78 at the default 4,096 bins (between 79 and 90 the table used to be built

@@ -39,6 +39,7 @@
 
 namespace FMX_KNS {
 using namespace fmx;
+static std::atomic<int> g_code_bits_12{1};  // option "code_bits_12" (plan_code_bits)
 
 // Workgroup size is a template parameter (512 / 1024 threads).  Only the stand-alone RrrVector kernels stage the
 // 32 KiB value-of-offset table in LDS.
@@ -90,7 +91,10 @@ __device__ __forceinline__ void stage_inverse_table(uint16_t *s_inv, const uint1
 // in the same SA intervals (same sectors, broadcast loads); results land at the original index.
 // The plan stage hands k_count one 64-bit word per pattern with the codes of its trailing characters, the last
 // character in the low bits: 8 codes of 8 bits when the alphabet fits (sigma <= 256), else 4 codes of 16 bits.
-__host__ __device__ inline int plan_code_bits(int32_t sigma) { return sigma <= 256 ? 8 : 16; }
+// 12 bits for alphabets of 257 .. 4,096 codes (round 6): FIVE codes per word instead of four and a suffix table one character
+// deeper (60-bit keys) — the shape of the data set the reference's published numbers are quoted on (> 1,000 symbols,
+// README.md:291-292).  fmx_code_bits_for (fmx_device.hpp) is the one rule; option "code_bits_12" = 0 gives 16 bits there (A/B).
+inline int plan_code_bits(int32_t sigma) { return fmx_code_bits_for(sigma, g_code_bits_12.load() != 0); }
 
 // The header quad and the bit-vector view quad of every superblock (32 bytes each) are staged in LDS when the
 // index has at most kSbCacheMax superblocks (335 M symbols): the first stage of every rank / inverseSelect then
@@ -232,6 +236,10 @@ __device__ __forceinline__ int32_t chunk_code(const CodeChunk &ck, int32_t j) {
     constexpr uint32_t code_mask = (1u << kCodeBits) - 1u;
     const uint32_t pos = (uint32_t)j * (uint32_t)kCodeBits;
     if (kCodeBits == 8) return (int32_t)((uint32_t)(ck.lo >> pos) & code_mask);  // 8 codes of 8 bits: one word
+    if (kCodeBits == 12) {  // five codes per word (no code straddles the two)
+        const uint32_t jj = (uint32_t)j;
+        return (int32_t)((uint32_t)((jj < 5u ? ck.lo : ck.hi) >> ((jj < 5u ? jj : jj - 5u) * 12u)) & code_mask);
+    }
     const uint64_t w = pos < 64u ? ck.lo : ck.hi;
     return (int32_t)((uint32_t)(w >> (pos & 63u)) & code_mask);
 }
@@ -251,6 +259,13 @@ __device__ __forceinline__ CodeChunk chunk_refill_body(const int16_t *__restrict
     for (int j = 0; j < 8; ++j) {
         uint32_t c = 0;
         if (j < left) c = (uint32_t)(uint16_t)(ch[j] < 256u ? s_map[ch[j]] : char2code[ch[j]]);
+        if (kCodeBits == 12) {  // (chunk_code: five codes per word)
+            if (j < 5)
+                lo |= (uint64_t)c << (j * 12);
+            else
+                hi |= (uint64_t)c << ((j - 5) * 12);
+            continue;
+        }
         const uint32_t pos = (uint32_t)(j * kCodeBits);
         if (pos < 64u)
             lo |= (uint64_t)c << pos;
@@ -2315,6 +2330,10 @@ int set_option(const char *name, int value) {
         g_count_halve_uniform = value != 0;
         return 0;
     }
+    if (!strcmp(name, "code_bits_12")) {
+        g_code_bits_12 = value != 0;
+        return 0;
+    }
     if (!strcmp(name, "count_lean")) {
         g_count_lean = value != 0;
         return 0;
@@ -2468,12 +2487,18 @@ int launch_count_plan(const DevIndex &ix, int n_cu, const uint16_t *pat, const i
         if (code_bits == 8)
             hipLaunchKernelGGL(k_plan_fused<8>, dim3(tiles), dim3(kTileThreads), lds_fused, st, ix, pat, off, n, sh, ordered, ghist, ticket,
                                ticket + 2, epoch, spin_limit);
+        else if (code_bits == 12)
+            hipLaunchKernelGGL(k_plan_fused<12>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 8, st, ix, pat, off, n, sh, ordered, ghist,
+                               ticket, ticket + 2, epoch, spin_limit);
         else
             hipLaunchKernelGGL(k_plan_fused<16>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 8, st, ix, pat, off, n, sh, ordered, ghist,
                                ticket, ticket + 2, epoch, spin_limit);
     } else {
     if (code_bits == 8)
         hipLaunchKernelGGL(k_plan_codes<8>, dim3(tiles), dim3(kTileThreads), lds_codes, st, ix, pat, off, n, sh, recs,
+                           ghist, ticket + 2, epoch);
+    else if (code_bits == 12)
+        hipLaunchKernelGGL(k_plan_codes<12>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 4, st, ix, pat, off, n, sh, recs,
                            ghist, ticket + 2, epoch);
     else
         hipLaunchKernelGGL(k_plan_codes<16>, dim3(tiles), dim3(kTileThreads), (size_t)bins * 4, st, ix, pat, off, n, sh, recs,
@@ -2527,10 +2552,14 @@ int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_
         const dim3 grid__(grid_for(2 * (int64_t)n, blk__, n_cu));                                                  \
         if (blk__ == 1024 && bits == 8)                                                                            \
             FMX_COUNT_LAUNCH(1024, MODE, 8);                                                                       \
+        else if (blk__ == 1024 && bits == 12)                                                                      \
+            FMX_COUNT_LAUNCH(1024, MODE, 12);                                                                      \
         else if (blk__ == 1024)                                                                                    \
             FMX_COUNT_LAUNCH(1024, MODE, 16);                                                                      \
         else if (bits == 8)                                                                                        \
             FMX_COUNT_LAUNCH(512, MODE, 8);                                                                        \
+        else if (bits == 12)                                                                                       \
+            FMX_COUNT_LAUNCH(512, MODE, 12);                                                                       \
         else                                                                                                       \
             FMX_COUNT_LAUNCH(512, MODE, 16);                                                                       \
     } while (0)
@@ -2583,6 +2612,10 @@ int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_
             FMX_LEAN_LAUNCH(BLOCK, 8, true);                     \
         else if (bits == 8)                                      \
             FMX_LEAN_LAUNCH(BLOCK, 8, false);                    \
+        else if (bits == 12 && ix.map_by_symbol)                 \
+            FMX_LEAN_LAUNCH(BLOCK, 12, true);                    \
+        else if (bits == 12)                                     \
+            FMX_LEAN_LAUNCH(BLOCK, 12, false);                   \
         else if (ix.map_by_symbol)                               \
             FMX_LEAN_LAUNCH(BLOCK, 16, true);                    \
         else                                                     \
@@ -2604,10 +2637,14 @@ int launch_count(const DevIndex &ix, int n_cu, const uint16_t *pat, const int32_
                        0u, 0, (const int32_t *)pl.redo_list, pl.redo_count)
         if (blk == 1024 && own_bits == 8)
             FMX_REDO_LAUNCH(1024, 8);
+        else if (blk == 1024 && own_bits == 12)
+            FMX_REDO_LAUNCH(1024, 12);
         else if (blk == 1024)
             FMX_REDO_LAUNCH(1024, 16);
         else if (own_bits == 8)
             FMX_REDO_LAUNCH(512, 8);
+        else if (own_bits == 12)
+            FMX_REDO_LAUNCH(512, 12);
         else
             FMX_REDO_LAUNCH(512, 16);
 #undef FMX_REDO_LAUNCH

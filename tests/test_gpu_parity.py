@@ -504,17 +504,17 @@ def test_segment_set_with_mixed_alphabet_sizes_long_patterns():
         assert found[i] == len(e) and list(locs[i, :found[i]]) == e, i
 
 
-@pytest.mark.parametrize("sigma", [40, 255, 256, 700])
+@pytest.mark.parametrize("sigma", [40, 255, 256, 257, 700, 1100, 4090, 4096, 4097, 4110])
 def test_planned_batches_vs_oracle_across_alphabet_sizes(sigma):
-    """batches large enough to take the planned path (suffix order + per-pattern code words, 8 codes of 8 bits
-    or 4 of 16 bits by alphabet size), with patterns shorter and longer than the planned codes, absent
-    characters and empty patterns — counts, statuses and located hits against the oracle"""
+    """batches large enough to take the planned path (suffix order + per-pattern code words: 8 codes of 8 bits, 5 of 12 bits —
+    alphabets of 257 .. 4,096 codes, round 6 — or 4 of 16 bits, by alphabet size; sizes on both sides of both thresholds), with
+    patterns shorter and longer than the planned codes, absent characters and empty patterns — counts, statuses, LF-steps and
+    located hits against the oracle; with the default suffix table and with one grown as deep as its keys allow (5 characters of
+    12 bits); and, for the 12-bit alphabets, the same index under option code_bits_12 = 0 (16-bit words and keys)"""
     rnd = random.Random(sigma)
     n = 150_000
     arr = np.array([rnd.randrange(1, sigma) if rnd.random() < 0.9 else 10 for _ in range(n)], dtype=np.uint16) + 32
-    fm = ia.FmIndex(arr, 16, True, device=0)
     o = orc.OracleFmIndex(arr, 16, True)
-    assert fm.getAlphabetLength() == o.getAlphabetLength()
     N = 20_000  # > sort_min
     pats = []
     for i in range(N):
@@ -527,13 +527,31 @@ def test_planned_batches_vs_oracle_across_alphabet_sizes(sigma):
         pats.append(p)
     ch, off = ia.pack_patterns(pats)
     off = np.concatenate([off, [off[-1]]]).astype(np.int32)  # + an EMPTY pattern
-    cnt, st, lf = fm.count_batch(ch, off, want_steps=True)
+    orc.counters_reset()
     oc, ost = o.count_batch(ch, off, threads=8)
-    assert (st == ost).all() and (cnt == oc).all() and st[-1] == 9
-    locs, found, st2 = fm.locate_batch(ch, off, 4)
-    for i in range(0, N, 37):
-        k, l = o.locate(pats[i], max_matches=4, cap=4)
-        assert found[i] == k and (locs[i, :k] == l).all(), i
+    steps = orc.counters()["lf_steps"]
+    wide = 258 <= o.getAlphabetLength() <= 4000  # (safely inside the 12-bit range)
+    variants = [(8, 1)] + ([(0, 1)] if sigma > 256 or wide else []) + ([(0, 0)] if wide else [])  # (table's image fraction, code_bits_12)
+    depths = {}
+    try:
+        for frac, bits12 in variants:
+            assert ia.lib.fmx_set_option(b"suffix_table_image_fraction", frac) == 0 and ia.lib.fmx_set_option(b"code_bits_12", bits12) == 0
+            fm = ia.FmIndex(arr, 16, True, device=0)
+            assert fm.getAlphabetLength() == o.getAlphabetLength()
+            depths[(frac, bits12)] = fm.suffix_table_info()[0]
+            cnt, st, lf = fm.count_batch(ch, off, want_steps=True)
+            assert (st == ost).all() and (cnt == oc).all() and st[-1] == 9, (sigma, frac, bits12)
+            assert int(lf.astype(np.int64).sum()) == steps, (sigma, frac, bits12)
+            locs, found, st2 = fm.locate_batch(ch, off, 4)
+            for i in range(0, N, 37):
+                k, l = o.locate(pats[i], max_matches=4, cap=4)
+                assert found[i] == k and (locs[i, :k] == l).all(), (sigma, frac, bits12, i)
+            fm.close()
+    finally:
+        ia.lib.fmx_set_option(b"suffix_table_image_fraction", 8)
+        ia.lib.fmx_set_option(b"code_bits_12", 1)
+    if wide:  # five characters fit a 12-bit key, four a 16-bit one
+        assert depths[(0, 1)] == 5 and depths[(0, 0)] == 4, depths
 
 
 def test_suffix_table_changes_nothing_but_the_time():
