@@ -16,6 +16,7 @@ package com.dynatrace.fm.gpu;
 import static org.junit.jupiter.api.Assertions.assertArrayEquals;
 import static org.junit.jupiter.api.Assertions.assertEquals;
 import static org.junit.jupiter.api.Assertions.assertThrows;
+import static org.junit.jupiter.api.Assertions.assertTrue;
 
 import com.dynatrace.fm.FmIndex;
 import com.dynatrace.fm.FmIndexBuilder;
@@ -61,7 +62,9 @@ class GpuFmIndexParityTest {
             FmIndex ref = new FmIndexBuilder().setSampleRate(sampleRate).setEnableExtraction(extract).build(TEXT);
             byte[] expected = Serialization.writeToByteArray(FmIndex::write, ref); // SER:67-79 over FM:948-975
             try (GpuFmIndex gpu = GpuFmIndex.fromSerialized(expected, 0)) {
-                // (byte identity is only claimed where the character map's HashMap order is the replayed one: no tree bins)
+                // (byte identity is only claimed where the character map's HashMap order is the replayed one: no tree bins —
+                // and THIS text's map has none, so the comparison below cannot be skipped silently: ADVICE r5)
+                assertTrue(gpu.isSerializedFormVerified(), "the fixture's 763-key map makes no tree bin");
                 if (gpu.isSerializedFormVerified()) {
                     assertArrayEquals(expected, gpu.toSerialized(true), "fmx_load -> fmx_save(framed)");
                 }
@@ -225,6 +228,16 @@ class GpuFmIndexParityTest {
             int[] counts = gpu.countBatch(all, offsets);
             for (int i = 0; i < n; i += 37) {
                 assertEquals(ref.count(all, offsets[i], offsets[i + 1] - offsets[i]), counts[i]);
+            }
+            // the same batch sharded over replicas of the index (here: three replicas on device 0; on a node: one per GPU):
+            // FmIndex is immutable and @ThreadSafe (FmIndex.java:82), every shard stores into its slice of the arrays
+            try (GpuFmIndex.Replicas replicas = gpu.replicate(new int[] {0, 0, 0})) {
+                assertEquals(3, replicas.size());
+                assertArrayEquals(counts, replicas.countBatch(all, offsets));
+                int[] rows = new int[n * 4];
+                int[] rowsOne = new int[n * 4];
+                assertArrayEquals(gpu.locateBatch(all, offsets, 4, rowsOne), replicas.locateBatch(all, offsets, 4, rows));
+                assertArrayEquals(rowsOne, rows);
             }
         }
     }

@@ -266,6 +266,9 @@ int fmx_locate_lines_batch_dev(const fmx_index *idx, const uint16_t *d_pat, cons
  *               found[i] = number written (max_matches >= 1)
  *   status[i] = first non-zero per-segment status (an empty pattern fails the same way in every segment)
  * Occurrences that span a cut are not occurrences in any segment, exactly as with K Java objects.
+ * Slots of a row at and beyond found[i] keep the caller's values — except in the row of a pattern whose status is non-zero, which is
+ * unspecified from found[i] on (a segment's hits are stored straight into the set's rows before its status is known: option
+ * "segments_direct").
  * Device forms: d_tmp = 3*n ints (count) / 4*n + n*max_matches ints (locate); d_lf_steps / d_status may be NULL. */
 int fmx_count_segments(const fmx_index *const *segs, int32_t n_segs, const uint16_t *pat, const int32_t *pat_off,
                        int32_t n, int64_t *counts, int64_t *lf_steps, int32_t *status);

@@ -294,6 +294,52 @@ private:
     int buildDevice_ = -1;
 };
 
+// One FmIndex on several GPUs of a node (fmx.h "replicas"): FmIndex is immutable and @ThreadSafe (FM:82), index4j's throughput
+// benchmark gives every thread an index of its own (FmIndexThroughputState.java:30) — the image is copied to every device named
+// (fmx_replicate: peer copies, all destinations at once) and a batch is cut into contiguous shards, one per replica, each stored
+// into its own slice of the caller's arrays (fmx_*_multi): no exchange on the query path.  A device may be named more than once.
+class FmIndexReplicas {
+public:
+    FmIndexReplicas(const FmIndex &source, const std::vector<int32_t> &devices) : handles_(devices.size(), nullptr) {
+        detail::check(fmx_replicate(source.handle(), devices.data(), (int32_t)devices.size(), handles_.data()), "fmx_replicate");
+    }
+    FmIndexReplicas(const FmIndexReplicas &) = delete;
+    FmIndexReplicas &operator=(const FmIndexReplicas &) = delete;
+    ~FmIndexReplicas() {
+        for (fmx_index *h : handles_) fmx_free(h);
+    }
+    size_t size() const { return handles_.size(); }
+    int deviceOf(size_t replica) const { return fmx_device_of(handles_[replica]); }
+    std::vector<int32_t> countBatch(const std::vector<std::u16string> &patterns) const {
+        std::vector<uint16_t> chars;
+        std::vector<int32_t> off;
+        FmIndex::packPatterns(patterns, chars, off);
+        std::vector<int32_t> counts(patterns.size()), status(patterns.size());
+        detail::check(fmx_count_batch_multi(handles_.data(), (int32_t)handles_.size(), chars.data(), off.data(), (int32_t)patterns.size(),
+                                            counts.data(), nullptr, status.data()),
+                      "fmx_count_batch_multi");
+        for (int s : status) detail::raise_for_status(s);
+        return counts;
+    }
+    // returns found[i]; locations is patterns.size() rows of maxMatches ints
+    std::vector<int32_t> locateBatch(const std::vector<std::u16string> &patterns, int maxMatches, std::vector<int32_t> &locations) const {
+        std::vector<uint16_t> chars;
+        std::vector<int32_t> off;
+        FmIndex::packPatterns(patterns, chars, off);
+        const int32_t n = (int32_t)patterns.size();
+        locations.assign((size_t)n * (size_t)maxMatches, 0);
+        std::vector<int32_t> found(patterns.size()), status(patterns.size());
+        detail::check(fmx_locate_batch_multi(handles_.data(), (int32_t)handles_.size(), chars.data(), off.data(), n, maxMatches,
+                                             locations.data(), maxMatches, found.data(), nullptr, status.data()),
+                      "fmx_locate_batch_multi");
+        for (int s : status) detail::raise_for_status(s);
+        return found;
+    }
+
+private:
+    std::vector<fmx_index *> handles_;
+};
+
 // One long text as K FmIndex objects over consecutive pieces (a Java int cannot address 2^31 chars, FM:131):
 // count = sum over the pieces, hits = piece start + local position, in piece order — what a caller's loop over K
 // indexes computes, as one device call (fmx_count_segments / fmx_locate_segments).  All pieces on one GPU.

@@ -170,6 +170,16 @@ int main(int argc, char **argv) {
         CHECK(counts[0] == 1920 && counts[1] == (int)occurrences(hdfs, u"WARN") &&
               counts[2] == (int)occurrences(hdfs, u"blk_") && counts[3] == 0);
     }
+    // the same batches sharded over replicas of the index (fmx_replicate + fmx_*_multi: three replicas on device 0)
+    {
+        FmIndexReplicas reps(fmi, {0, 0, 0});
+        CHECK(reps.size() == 3 && reps.deviceOf(2) == 0);
+        const std::vector<std::u16string> pats = {u"INFO", u"WARN", u"blk_", u"zzzzzz", u"dfs.DataNode", u"e", u"src: /10."};
+        CHECK(reps.countBatch(pats) == fmi.countBatch(pats));
+        std::vector<int32_t> one, many;
+        CHECK(reps.locateBatch(pats, 6, many) == fmi.locateBatch(pats, 6, one));
+        CHECK(one == many);
+    }
     // the index built with its suffix-array stage on the GPU is the same bytes
     {
         FmIndex onGpu = FmIndexBuilder().setDevice(-1).setBuildDevice(0).build(hdfs);
