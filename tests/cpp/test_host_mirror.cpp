@@ -11,6 +11,7 @@
 
 using index4j::FmIndex;
 using index4j::FmIndexBuilder;
+using index4j::FmIndexReplicas;
 
 static int failures = 0;
 #define CHECK(cond)                                                        \
