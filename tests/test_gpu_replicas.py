@@ -324,3 +324,45 @@ def test_segment_set_side_stream_and_direct_stores_toggled(n_segs):
         L.fmx_set_option(b"segments_overlap_min", 262144)
         for f in sf.segments:
             f.close()
+
+
+def test_several_host_threads_share_one_replica_set():
+    """the sharded calls from four host threads at once on ONE replica set (a JVM's request threads): the library's workers are per
+    (device, replica slot), so concurrent calls queue behind each other on a worker — every call still gets its own results"""
+    import threading
+
+    t = ia.synth_log(1 << 21)
+    fm = ia.FmIndex(t, 16, True, device=0)
+    o = orc.OracleFmIndex.read(fm.write(False))
+    rs = ia.ReplicaSet(fm, [0, 0, 0])
+    work = []
+    for k, n in enumerate([50_001, 7, 20_000, 140_000]):
+        pat, off, pos = ia.synth_patterns(t, 8, n, seed=300 + k)
+        oc, ost = o.count_batch(pat, off, threads=8)
+        ol, of, _ = o.locate_batch(pat[: min(n, 3000) * 8], off[: min(n, 3000) + 1], 8, threads=8)
+        work.append((pat, off, oc, ost, ol, of))
+    errors = []
+    gate = threading.Barrier(len(work))
+
+    def run(k):
+        try:
+            pat, off, oc, ost, ol, of = work[k]
+            m = len(of)
+            gate.wait()
+            for _ in range(5):
+                c, s = rs.count_batch(pat, off)
+                assert (c == oc).all() and (s == ost).all(), "count, thread %d" % k
+                locs, found, st = rs.locate_batch(pat[: m * 8], off[: m + 1], 8)
+                live = np.arange(8)[None, :] < found[:, None]
+                assert (found == of).all() and (locs[live] == ol[live]).all(), "locate, thread %d" % k
+        except BaseException as e:  # noqa: BLE001 - reported to the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(len(work))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    rs.close()
+    fm.close()
+    assert not errors, errors[0]
