@@ -309,6 +309,8 @@ def compact_line(out):
                                        "ratio_registered_to_max_of_floor_and_device_step", "pcie_floor_ms_in", "stat"))
     if out.get("index_broadcast"):
         c["index_broadcast"] = _pick(out["index_broadcast"], ("broadcast_s", "fan_out_s", "kept", "bytes"))
+    if out.get("plan_net"):
+        c["plan_net_ms"] = _sig([out["plan_net"]["planned_ms_per_step"], out["plan_net"]["callers_order_ms_per_step"]], 4)
     if out.get("launch"):
         c["launch"] = _short(out["launch"], 90)
     if out.get("single_process"):
@@ -629,6 +631,32 @@ def run_count(ctx, args):
         finally:
             ia.lib.fmx_set_option(b"suffix_table", 1)
 
+    # What the plan stage buys NET: the same K steps with the batch counted in the caller's order (no plan
+    # stage: k_count maps the characters itself) — the library's policy plans this batch because that is the faster of the two.
+    plan_net = None
+    if not ctx.dry and planned and not args.profiling:
+        ia.lib.fmx_set_option(b"plan_sa_min", 2**31 - 1)
+        try:
+            for i in range(max(2, args.warmup)):
+                step(i % n_batches)
+            torch.cuda.synchronize()
+            e0, e1 = hip_events(torch)
+            e0.record(stream)
+            for i in range(args.steps):
+                step(i % n_batches)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            unplanned_ms = e0.elapsed_time(e1) / args.steps
+            for b in range(n_batches):
+                if int(d_cnt[b].sum(dtype=torch.int64).item()) != checksums[b]:
+                    raise RuntimeError("counts differ in the caller's order")
+            plan_net = {"planned_ms_per_step": step_ms, "callers_order_ms_per_step": unplanned_ms,
+                        "plan_stage_saves": 1.0 - step_ms / unplanned_ms,
+                        "what": "the timed step (plan stage + k_count over the plan's order) against the same batches counted in the "
+                                "caller's order (one k_count launch, no plan stage), one stream"}
+        finally:
+            ia.lib.fmx_set_option(b"plan_sa_min", 786432)
+
     # Beside the contract's line (one batch after the other on one stream): the same K steps with TWO batches in
     # flight — step i on stream i mod 2, as a service with several clients would issue them — so that one batch's plan
     # stage overlaps the other's k_count.  Reported as `overlapped`, never as `value`.
@@ -917,6 +945,7 @@ def run_count(ctx, args):
         "host_buffers": host_buffers,
         "secondary": secondary,
         "single_process": single,
+        "plan_net": plan_net,
     }
     if ctx.dry:
         out["dry_run"] = True
