@@ -34,7 +34,7 @@
     int launch_suffix_insert(const fmx::DevIndex &, const fmx::SuffixSlot *, uint32_t, int, fmx::SuffixSlot *, hipStream_t); \
     int launch_suffix_order1(const fmx::DevIndex &, float *, hipStream_t);                                              \
     int launch_win_build(const fmx::DevIndex &, int, uint32_t, fmx::Quad *, uint32_t *, hipStream_t);                   \
-    int launch_win_other(const fmx::DevIndex &, int, uint32_t, fmx::Quad *, const uint32_t *, uint64_t *, uint32_t *, hipStream_t); \
+    int launch_win_other(const fmx::DevIndex &, int, uint32_t, fmx::Quad *, const uint32_t *, uint16_t *, uint32_t *, hipStream_t); \
     int launch_count_plan(const fmx::DevIndex &, int, const uint16_t *, const int32_t *, int32_t, void *, size_t, bool, fmx::CountPlan *, \
                           hipStream_t);                                                                                 \
     int launch_count(const fmx::DevIndex &, int, const uint16_t *, const int32_t *, const fmx::CountPlan *, bool, int32_t, int32_t *, \
@@ -977,7 +977,7 @@ static void build_window_cells(fmx_index *idx) {
     const size_t bytes = cells * 64;
     if (mode == 2) {  // cells + (at worst) an entry per position must fit a quarter of what is free, and the absolute budget
         size_t free_b = 0, total_b = 0;
-        const size_t worst = bytes + (size_t)idx->hdr.wt_size * 8;
+        const size_t worst = bytes + (size_t)idx->hdr.wt_size * fmx::kWinEntryWords * sizeof(uint16_t);
         if (worst > ((size_t)g_window_cells_mb.load() << 20) || hipMemGetInfo(&free_b, &total_b) != hipSuccess || worst > free_b / 4) {
             (void)hipGetLastError();
             return;
@@ -1009,23 +1009,26 @@ static void build_window_cells(fmx_index *idx) {
         total += c;
     }
     if (total > 0xffffffffull) return give_up();
-    // (the entries, and behind them the counter of entries that carry a status or `suspect`: statistics)
-    uint32_t open_entries = 0;
-    if (hipMalloc(&d_entries, (size_t)(total + 1) * sizeof(uint64_t)) != hipSuccess ||
-        hipMemset(static_cast<uint64_t *>(d_entries) + total, 0, sizeof(uint64_t)) != hipSuccess ||
+    // (the entries — six bytes each — and behind them, 8-byte aligned, two words: how many carry a status or `suspect`
+    // (statistics), and whether some step's answer did not fit an entry: no directory then)
+    const size_t entry_bytes = ((size_t)total * fmx::kWinEntryWords * sizeof(uint16_t) + 7) & ~(size_t)7;
+    uint32_t tail[2] = {0, 0};
+    if (hipMalloc(&d_entries, entry_bytes + 16) != hipSuccess ||
+        hipMemset(static_cast<uint8_t *>(d_entries) + entry_bytes, 0, 16) != hipSuccess ||
         hipMemcpy(d_counts, first.data(), cells * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
         k_launch_win_other(idx, idx->dev, idx->n_cu, (uint32_t)cells, static_cast<fmx::Quad *>(d_cells), static_cast<const uint32_t *>(d_counts),
-                           static_cast<uint64_t *>(d_entries), reinterpret_cast<uint32_t *>(static_cast<uint64_t *>(d_entries) + total),
+                           static_cast<uint16_t *>(d_entries), reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(d_entries) + entry_bytes),
                            nullptr) != 0 ||
-        hipMemcpy(&open_entries, static_cast<uint64_t *>(d_entries) + total, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+        hipMemcpy(tail, static_cast<uint8_t *>(d_entries) + entry_bytes, sizeof tail, hipMemcpyDeviceToHost) != hipSuccess ||
+        tail[1] != 0)
         return give_up();
     (void)hipFree(d_counts);
-    idx->win_unclean = open_entries;
+    idx->win_unclean = tail[0];
     idx->d_win = d_cells;
     idx->d_win_other = d_entries;
-    idx->win_bytes = bytes + (size_t)total * sizeof(uint64_t);
+    idx->win_bytes = bytes + (size_t)total * fmx::kWinEntryWords * sizeof(uint16_t);
     idx->dev.win = static_cast<const fmx::Quad *>(d_cells);
-    idx->dev.win_other = static_cast<const uint64_t *>(d_entries);
+    idx->dev.win_other = static_cast<const uint16_t *>(d_entries);
 }
 
 int fmx_window_cells_info(const fmx_index *idx, int64_t *bytes) {

@@ -92,7 +92,7 @@ struct DevIndex {
     // one sector fill instead of {mapping entry, path records, a cell per tree level}.  Whatever it does not hold takes the
     // path above.  Results never depend on it: every count in it was checked against rank() when it was grown.
     const struct Quad *win;
-    const uint64_t *win_other;  // the entries of the positions no class of their window holds (nullptr iff win is)
+    const uint16_t *win_other;  // the entries (three 16-bit words each) of the positions no class of their window holds (nullptr iff win is)
     // this index's DevIndex as the API layer keeps it in HBM (no LDS cache, no launch option applied): what a cold route reads
     const DevIndex *self;
 };
@@ -654,7 +654,7 @@ FMX_HD int32_t fm_c_or_zero(const DevIndex &ix, int32_t symbol) {
 //   words 5..15  three bit planes of 112 bits each, from bit 16 of word 5 on, back to back: plane 0 / 1 = low / high bit of the
 //                position's class (3 = "none of the three"), plane 2 = the position's bit in sampledSuffixes (FM:123: what
 //                locate polls before every step, FM:531)
-// and one 8-byte entry in win_other per position of class 3, in position order: {the row the step arrives at, symbol, status,
+// and one 6-byte entry in win_other per position of class 3, in position order: {the row the step arrives at, symbol, status,
 // suspect} — everything fm_lf_step hands back for that row.  The step from row p + 1: a class position -> {symbol, count + the
 // class's positions before p + 1}: ONE sector; class 3 -> the entry (index = the cell's first + the class-3 positions before p):
 // a second, dependent load.  No tree walk either way.  The classes are the window's three most frequent symbols among the
@@ -726,24 +726,41 @@ FMX_HD bool win_inv_from(const WinCell &c, uint32_t r, int32_t &symbol_out, int3
     row_out = (int32_t)(k == 0u ? c.q0.x : (k == 1u ? c.q0.y : c.q0.z)) + before + 1;
     return true;
 }
-// the entry of a class-3 position = what fm_lf_step hands back for its row: the row it arrives at in the low word, then the symbol
-// (16 bits, the int16 of FM:532), the status (8 bits) and `suspect` (1 bit)
+// the entry of a class-3 position = what fm_lf_step hands back for its row, in SIX bytes (round 6; eight before): the row it
+// arrives at (31 bits: rows are Java ints >= 0) with `suspect` in bit 31, then the symbol (15 bits: an alphabet has at most 32,767
+// codes, FM:423-426, and validate_blob holds every leaf symbol below wt_sigma) with "the step raised a status" in bit 15 — the only
+// status a step can raise is the JVM's ArrayIndexOutOfBounds (every `status =` on the path of fm_lf_step).  0.18 x 6 bytes per
+// position: the directory takes 1.65 instead of 2.0 bytes per text byte of log text.
+constexpr uint32_t kWinEntryWords = 3;  // 16-bit words per entry
 FMX_HD uint64_t win_other_make(int32_t row, int32_t c, int status, bool suspect) {
-    return (uint64_t)(uint32_t)row | ((uint64_t)((uint32_t)c & 0xffffu) << 32) | ((uint64_t)((uint32_t)status & 0xffu) << 48) |
-           ((uint64_t)(suspect ? 1u : 0u) << 56);
+    return (uint64_t)(((uint32_t)row & 0x7fffffffu) | (suspect ? 0x80000000u : 0u)) |
+           ((uint64_t)(((uint32_t)c & 0x7fffu) | (status != ST_OK ? 0x8000u : 0u)) << 32);
+}
+// false: this step's answer does not fit an entry (a row below 0, a symbol outside 15 bits, a status other than the one above —
+// none of which a validated index produces): the directory is not offered for such an index
+FMX_HD bool win_other_fits(int32_t row, int32_t c, int status) {
+    return row >= 0 && c >= 0 && c <= 0x7fff && (status == ST_OK || status == ST_JAVA_AIOOBE);
 }
 FMX_HD void win_other_from(uint64_t entry, int32_t &symbol_out, int32_t &row_out, int &status, bool &suspect) {
-    symbol_out = (int32_t)(int16_t)(uint16_t)(entry >> 32);
-    row_out = (int32_t)(uint32_t)entry;
-    const int st = (int)((entry >> 48) & 0xffu);
-    if (st) status = st;
-    if ((entry >> 56) & 1u) suspect = true;
+    const uint32_t lo = (uint32_t)entry, hi = (uint32_t)(entry >> 32);
+    symbol_out = (int32_t)(hi & 0x7fffu);
+    row_out = (int32_t)(lo & 0x7fffffffu);
+    if (hi & 0x8000u) status = ST_JAVA_AIOOBE;
+    if (lo >> 31) suspect = true;
+}
+FMX_HD void win_other_store(uint16_t *entries, uint32_t index, uint64_t v) {
+    uint16_t *p = entries + (uint64_t)index * kWinEntryWords;
+    p[0] = (uint16_t)v;
+    p[1] = (uint16_t)(v >> 16);
+    p[2] = (uint16_t)(v >> 32);
 }
 FMX_HD uint64_t win_other_load(const DevIndex &ix, uint32_t index) {
-    uint64_t v;
-    memcpy(&v, ix.win_other + index, 8);
-    FMX_OPAQUE64(v);
-    return v;
+    const uint16_t *p = ix.win_other + (uint64_t)index * kWinEntryWords;
+    uint32_t a = p[0], b = p[1], c = p[2];  // three 2-byte loads (an entry is 2-byte aligned), one wait
+    FMX_OPAQUE32(a);
+    FMX_OPAQUE32(b);
+    FMX_OPAQUE32(c);
+    return (uint64_t)(a | (b << 16)) | ((uint64_t)c << 32);
 }
 
 // With the superblock's header at hand (ix.sb_cache, staged in LDS by the kernel) and the mapping rows indexed by
@@ -1521,9 +1538,10 @@ FMX_HD uint32_t win_build_cell(const DevIndex &ix, uint32_t w, uint32_t *out) {
     return others;
 }
 // The win_other entries of window w (cell = its 16 words as win_build_cell made them): one per position of class 3, in position
-// order, from entries[first] on — what fm_lf_step hands back for the position's row (win_other_make).  Writes `first` into the
-// cell's word 4; returns the number of entries that carry a status or `suspect` (statistics: a handful per index).
-FMX_HD uint32_t win_build_other(const DevIndex &ix, uint32_t w, uint32_t *cell_words, uint32_t first, uint64_t *entries) {
+// order, from entry `first` on — what fm_lf_step hands back for the position's row (win_other_make).  Writes `first` into the
+// cell's word 4; returns the number of entries that carry a status or `suspect` (statistics: a handful per index), bit 31 set if
+// some step's answer does not fit an entry (win_other_fits).
+FMX_HD uint32_t win_build_other(const DevIndex &ix, uint32_t w, uint32_t *cell_words, uint32_t first, uint16_t *entries) {
     const uint64_t ws64 = (uint64_t)w * kWinW;
     const uint32_t ws = (uint32_t)ws64;
     const uint32_t n = ws64 >= ix.wt_size ? 0u : (ix.wt_size - ws < kWinW ? ix.wt_size - ws : kWinW);
@@ -1541,7 +1559,8 @@ FMX_HD uint32_t win_build_other(const DevIndex &ix, uint32_t w, uint32_t *cell_w
         int32_t c = 0;
         const int32_t next = fm_lf_step<true, kWinNever>(ix, nullptr, (int32_t)(ws + j + 1u), c, status, suspect);
         if (status != ST_OK || suspect) ++unclean;
-        entries[at++] = win_other_make(next, c, status, suspect);
+        if (!win_other_fits(next, c, status)) unclean |= 0x80000000u;  // (never on a validated index: the caller drops the directory)
+        win_other_store(entries, at++, win_other_make(next, c, status, suspect));
     }
     return unclean;
 }

@@ -1003,7 +1003,7 @@ __global__ __launch_bounds__(256) void k_win_build(DevIndex ix, uint32_t n_win, 
     }
 }
 __global__ __launch_bounds__(256) void k_win_other(DevIndex ix, uint32_t n_win, Quad *__restrict__ cells, const uint32_t *__restrict__ first,
-                                                   uint64_t *__restrict__ entries, uint32_t *__restrict__ open_entries) {
+                                                   uint16_t *__restrict__ entries, uint32_t *__restrict__ open_entries) {
     for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < n_win; w += (uint64_t)gridDim.x * 256) {
         uint32_t words[16];
         for (int i = 0; i < 4; ++i) {
@@ -1015,7 +1015,8 @@ __global__ __launch_bounds__(256) void k_win_other(DevIndex ix, uint32_t n_win, 
         }
         const uint32_t open = win_build_other(ix, (uint32_t)w, words, first[w], entries);
         cells[4 * w + 1].x = words[4];
-        if (open) atomicAdd(open_entries, open);  // (entries the tree walk must answer: nearly never any)
+        if (open & 0x7fffffffu) atomicAdd(open_entries, open & 0x7fffffffu);  // (entries that carry a status or `suspect`: statistics)
+        if (open >> 31) atomicOr(open_entries + 1, 1u);  // an answer that does not fit an entry: the caller drops the directory
     }
 }
 static DevIndex win_plain_index(const DevIndex &ix) {
@@ -1036,7 +1037,7 @@ int launch_win_build(const DevIndex &ix, int n_cu, uint32_t n_win, Quad *out, ui
     hipLaunchKernelGGL(k_win_build, dim3(win_blocks(n_cu, n_win)), dim3(256), 0, st, win_plain_index(ix), n_win, out, others);
     return (int)hipGetLastError();
 }
-int launch_win_other(const DevIndex &ix, int n_cu, uint32_t n_win, Quad *cells, const uint32_t *first, uint64_t *entries,
+int launch_win_other(const DevIndex &ix, int n_cu, uint32_t n_win, Quad *cells, const uint32_t *first, uint16_t *entries,
                      uint32_t *open_entries, hipStream_t st) {
     if (n_win == 0) return 0;
     hipLaunchKernelGGL(k_win_other, dim3(win_blocks(n_cu, n_win)), dim3(256), 0, st, win_plain_index(ix), n_win, cells, first, entries,

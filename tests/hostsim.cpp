@@ -16,7 +16,7 @@ using namespace fmx;
 
 // window directories attached to blobs (sim_win_attach): what fmx_to_device grows beside a resident image
 static std::map<const uint8_t *, std::vector<uint32_t>> g_windows;
-static std::map<const uint8_t *, std::vector<uint64_t>> g_window_entries;
+static std::map<const uint8_t *, std::vector<uint16_t>> g_window_entries;
 static std::map<const uint8_t *, uint64_t> g_window_unclean;
 static int g_pack = 1;  // locate over a window directory: the instalment form (k_locate_walk_c) or fm_locate_hit<kWinAlways> (option walk_pack 0)
 
@@ -79,9 +79,9 @@ int64_t sim_win_attach(const uint8_t *blob, int64_t *stats) {
         first[w] = (uint32_t)total;
         total += win_build_cell(ix, (uint32_t)w, words.data() + 16 * w);
     }
-    std::vector<uint64_t> entries(total + 1);
+    std::vector<uint16_t> entries((total + 1) * kWinEntryWords);
     uint64_t open_entries = 0;
-    for (size_t w = 0; w < cells; ++w) open_entries += win_build_other(ix, (uint32_t)w, words.data() + 16 * w, first[w], entries.data());
+    for (size_t w = 0; w < cells; ++w) open_entries += win_build_other(ix, (uint32_t)w, words.data() + 16 * w, first[w], entries.data()) & 0x7fffffffu;
     g_window_unclean[blob] = open_entries;
     if (stats) {
         stats[0] = stats[1] = stats[2] = stats[3] = 0;
