@@ -1,7 +1,9 @@
 /*
  * fmx_jni.c — JNI glue between com.dynatrace.fm.gpu.GpuFmIndex and libfmx.so (include/fmx.h).
- * SOURCE ONLY: never compiled against a JDK here (none in the build image; only a syntax pass against a throw-away
- * stub of jni.h outside the repository).  Build on a JDK host with bindings/build.sh, or by hand:
+ * Never compiled against a JDK here (none in the build image).  What the test suites do instead: a syntax pass against a
+ * test-local declaration of the JNI entries used (tests/jni_stub/jni.h, tests/test_abi.py), and every entry point below RUN
+ * against a mock JNIEnv with copy-always array semantics (tests/jni_stub/mock_jnienv.c; tests/test_jni_glue.py on the CPU,
+ * tests/test_gpu_jni_glue.py on the GPU against the oracle).  Build on a JDK host with bindings/build.sh, or by hand:
  *   cc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude \
  *      bindings/jni/fmx_jni.c -Lindex4j_amd -lfmx -o libfmx_jni.so
  * Java `char` is an unsigned 16-bit UTF-16 code unit == the uint16_t the C ABI takes; `int` == int32_t.
@@ -34,10 +36,15 @@ static int too_short(JNIEnv *env, jarray a, jlong need, const char *what) {
     if (a == NULL || (jlong)(*env)->GetArrayLength(env, a) < need) return bad_args(env, what);
     return 0;
 }
+static jlong null_argument(JNIEnv *env, const char *what) {
+    (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/NullPointerException"), what);
+    return 0;
+}
 /* offsets has n + 1 entries, starts at 0, never decreases and ends inside chars */
 static int bad_patterns(JNIEnv *env, jcharArray chars, jintArray offsets, jint n) {
     if (n < 0) return bad_args(env, "negative batch size");
-    if (too_short(env, offsets, (jlong)n + 1, "offsets shorter than n + 1") || chars == NULL) return 1;
+    if (chars == NULL) return bad_args(env, "chars is null");
+    if (too_short(env, offsets, (jlong)n + 1, "offsets shorter than n + 1")) return 1;
     jint *po = (*env)->GetIntArrayElements(env, offsets, NULL);
     jsize n_chars = (*env)->GetArrayLength(env, chars);
     int bad = po[0] != 0 || po[n] > n_chars;
@@ -47,6 +54,7 @@ static int bad_patterns(JNIEnv *env, jcharArray chars, jintArray offsets, jint n
 }
 
 JNIEXPORT jlong JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeLoad(JNIEnv *env, jclass c, jbyteArray ser, jint device) {
+    if (ser == NULL) return null_argument(env, "serialized");
     jsize len = (*env)->GetArrayLength(env, ser);
     jbyte *p = (*env)->GetByteArrayElements(env, ser, NULL);
     fmx_index *idx = NULL;
@@ -90,6 +98,7 @@ JNIEXPORT jboolean JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeSavedOrder
 JNIEXPORT jlong JNICALL Java_com_dynatrace_fm_gpu_GpuFmIndex_nativeBuild(JNIEnv *env, jclass c, jcharArray text,
                                                                         jint sampleRate, jboolean extract, jint device,
                                                                         jboolean buildOnGpu) {
+    if (text == NULL) return null_argument(env, "text");
     jsize n = (*env)->GetArrayLength(env, text);
     jchar *p = (*env)->GetCharArrayElements(env, text, NULL);
     fmx_index *idx = NULL;
