@@ -2147,8 +2147,8 @@ static int count_batch_mapped(const fmx_index *idx, const uint16_t *pat, const i
 // to the GPU in chunks, chunk c's transfer overlapping the kernels of chunk c - 1 and the return of chunk c - 2 (three streams); offsets of equal-length
 // runs are made on the device instead of being shipped; the offsets are validated chunk by chunk on the way (the same
 // pass finds the equal-length runs).  Results of a chunk return as soon as its stage is done: straight into the
-// caller's arrays when those are pinned (fmx_host_register), else through pinned staging, copied out by a helper thread
-// while this one keeps feeding the pipeline (a pageable source makes hipMemcpyAsync stage on the calling thread).
+// caller's arrays when those are pinned (fmx_host_register), else through pinned staging the kernels store into, copied
+// out in parts by whichever of the call's threads is idle (helper, feeder, this one).
 static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n, int32_t *counts,
                                  int32_t *lf_steps, int32_t *status) {
     const double t_enter = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -2229,19 +2229,53 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
             for (int i = 0; i < kPipeStreams; ++i) (void)hipStreamSynchronize(ps->s[i]);
         }
     } drain_on_exit{ps};
-    // chunk b's results: pinned staging -> the caller's arrays, once its stage is done
+    // registered result arrays: chunk b's results are in them once its stage is done
     auto copy_out = [&](int32_t b) {
-        const int32_t blo = bounds[(size_t)b], bhi = bounds[(size_t)b + 1];
-        if (hipEventSynchronize(ps->done[b % kPipeEvents]) != hipSuccess) {
-            out_error = 1;
-            return;
-        }
-        if (direct_out) return;
-        memcpy(counts + blo, o_cnt + blo, (size_t)(bhi - blo) * 4);
-        if (lf_steps) memcpy(lf_steps + blo, o_lf + blo, (size_t)(bhi - blo) * 4);
-        if (status) memcpy(status + blo, o_st + blo, (size_t)(bhi - blo) * 4);
+        if (hipEventSynchronize(ps->done[b % kPipeEvents]) != hipSuccess) out_error = 1;
     };
     std::atomic<int32_t> copied{0};
+    // Plain result arrays: a chunk's results leave the pinned staging in PARTS of kOutPart patterns, taken by whichever of this
+    // call's three threads has nothing else to do — the helper, the feeder once the last characters are in HBM, this thread while
+    // it waits and after the last launch.  (One thread copying a 262,144-pattern chunk out takes as long as the link takes to
+    // bring the next one in, and the LAST chunk's copy overlaps nothing: 230 us of a 670 us call, round 6.)
+    constexpr int32_t kOutPart = 32768;
+    std::vector<int64_t> item_begin((size_t)n_chunks + 1, 0);  // parts of chunk b: items [item_begin[b], item_begin[b + 1])
+    for (int32_t b = 0; b < n_chunks; ++b)
+        item_begin[(size_t)b + 1] = item_begin[(size_t)b] + (bounds[(size_t)b + 1] - bounds[(size_t)b] + kOutPart - 1) / kOutPart;
+    std::unique_ptr<std::atomic<int32_t>[]> parts_left(new std::atomic<int32_t>[(size_t)n_chunks]);
+    for (int32_t b = 0; b < n_chunks; ++b) parts_left[(size_t)b].store((int32_t)(item_begin[(size_t)b + 1] - item_begin[(size_t)b]));
+    std::atomic<int64_t> next_item{0};
+    // one part, if one can be had: of a chunk that has been issued and (wait: once) its stage is done.  false: nothing to take now.
+    auto take_item = [&](bool wait) -> bool {
+        for (;;) {
+            int64_t it = next_item.load(std::memory_order_acquire);
+            const int32_t have = issued.load(std::memory_order_acquire);
+            if (it >= item_begin[(size_t)have]) return false;
+            int32_t b = copied.load(std::memory_order_acquire);
+            while (it >= item_begin[(size_t)b + 1]) ++b;
+            hipEvent_t ev = ps->done[b % kPipeEvents];
+            if (wait) {  // (polling the event instead: no faster)
+                if (hipEventSynchronize(ev) != hipSuccess) out_error = 1;  // (the part is still taken: the call fails as a whole)
+            } else if (hipEventQuery(ev) != hipSuccess) {
+                (void)hipGetLastError();  // not ready
+                return false;
+            }
+            if (!next_item.compare_exchange_strong(it, it + 1, std::memory_order_acq_rel)) continue;
+            const int32_t plo = bounds[(size_t)b] + (int32_t)(it - item_begin[(size_t)b]) * kOutPart;
+            const int32_t phi = std::min(bounds[(size_t)b + 1], plo + kOutPart);
+            memcpy(counts + plo, o_cnt + plo, (size_t)(phi - plo) * 4);
+            if (lf_steps) memcpy(lf_steps + plo, o_lf + plo, (size_t)(phi - plo) * 4);
+            if (status) memcpy(status + plo, o_st + plo, (size_t)(phi - plo) * 4);
+            if (parts_left[(size_t)b].fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                for (;;) {  // `copied` = the chunks before it are out, whole
+                    int32_t c = copied.load(std::memory_order_acquire);
+                    if (c >= n_chunks || parts_left[(size_t)c].load(std::memory_order_acquire) != 0) break;
+                    copied.compare_exchange_strong(c, c + 1, std::memory_order_acq_rel);
+                }
+            }
+            return true;
+        }
+    };
     // (whatever leaves this function — an exception included — first stops and joins its threads: they work on this frame)
     struct JoinOnExit {
         std::thread &t;
@@ -2258,12 +2292,9 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
         helper = std::thread([&, device]() {
             (void)hipSetDevice(device);
             for (;;) {
-                const int32_t have = issued.load(std::memory_order_acquire);
-                if (copied.load() < have) {
-                    copy_out(copied.load());
-                    copied.fetch_add(1, std::memory_order_release);
-                } else if (stop.load()) {
-                    if (copied.load() >= issued.load(std::memory_order_acquire)) return;
+                if (take_item(true)) continue;
+                if (stop.load()) {
+                    if (next_item.load(std::memory_order_acquire) >= item_begin[(size_t)issued.load(std::memory_order_acquire)]) return;
                 } else {
                     std::this_thread::yield();
                 }
@@ -2288,7 +2319,8 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
             return fail(FMX_E_ARG, "pattern offsets decrease or leave the batch");
         }
     }
-    std::atomic<int32_t> fed{0};
+    std::unique_ptr<std::atomic<uint8_t>[]> fed(new std::atomic<uint8_t>[(size_t)n_chunks]);  // chunk c's characters are in HBM (staged: on their way)
+    for (int32_t c = 0; c < n_chunks; ++c) fed[(size_t)c].store(0);
     std::atomic<int> feed_error{0};
     std::atomic<bool> feed_stop{false};
     std::thread feeder;
@@ -2297,6 +2329,7 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
     const bool staged_in = !in_pinned && stage_threads >= 2 && total_chars > pat_off[0] &&
                            h_pat.alloc((size_t)(total_chars - pat_off[0]) * 2) == hipSuccess;
     if (!staged_in) (void)hipGetLastError();
+    // (ONE feeder: two threads with every other chunk each are no faster — the runtime serialises plain copies — and the tail grows)
     if (!in_pinned) {
         const int device = idx->device;
         feeder = std::thread([&, device]() {
@@ -2316,8 +2349,10 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
                     }
                 }
                 if (staged_in && hipEventRecord(ps->in[c % kPipeEvents], s_in) != hipSuccess) feed_error = 1;
-                fed.store(c + 1, std::memory_order_release);
+                fed[(size_t)c].store(1, std::memory_order_release);
             }
+            while (!direct_out && !feed_stop.load())  // the characters are in: results out, beside the helper
+                if (!take_item(false)) std::this_thread::yield();
         });
     }
     for (int32_t c = 0; c < n_chunks && !failed; ++c) {
@@ -2329,7 +2364,7 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
             if (direct_out) {
                 copy_out(copied.load());
                 copied.fetch_add(1);
-            } else {
+            } else if (!take_item(false)) {
                 std::this_thread::yield();
             }
         }
@@ -2357,7 +2392,8 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
                 e = hipMemcpyAsync(d_off_c, pat_off + lo, (size_t)(n_c + 1) * 4, hipMemcpyHostToDevice, s_k);
         }
         if (!in_pinned) {  // the feeder has this chunk's characters in HBM (or, staged: on their way, behind the chunk's event)?
-            while (fed.load(std::memory_order_acquire) <= c) std::this_thread::yield();
+            while (!fed[(size_t)c].load(std::memory_order_acquire))
+                if (direct_out || !take_item(false)) std::this_thread::yield();
             if (feed_error) e = hipErrorUnknown;
             if (e == hipSuccess && staged_in) e = hipStreamWaitEvent(s_k, ps->in[slot], 0);
         }
@@ -2408,6 +2444,9 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
         t_out += now() - t0;
     }
     const double t_issued = now();
+    if (!direct_out)
+        while (take_item(true)) {
+        }
     feed_stop = true;
     if (feeder.joinable()) feeder.join();
     stop = true;
