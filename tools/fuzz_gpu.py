@@ -86,7 +86,16 @@ def main():
                 "plan_fused": rnd.choice([0, 0, 1]),  # the plan stage as one launch (round 5) ...
                 "plan_spin_limit": rnd.choice([4096, 4096, 0]),  # ... whose barrier gives up at once: records in the caller's order
                 "boundary_first_fill": rnd.choice([2, 2, 0]),  # extractUntilBoundary: a lane's two walks interleaved / one after the other
-                "regroup_by_length": rnd.choice([1, 1, 0])}  # k_count: workgroups with mixed pattern lengths regroup by length  # the plan's order: estimated SA row / the table's answer / trailing codes
+                "regroup_by_length": rnd.choice([1, 1, 0]),  # k_count: workgroups with mixed pattern lengths regroup by length
+                # round 6
+                "code_bits_12": rnd.choice([1, 1, 0]),  # alphabets of 257..4,096 codes: five codes per plan word / 16-bit codes
+                "count_lean": rnd.choice([0, 0, 1]),  # k_count_lean + the list pass (fast routes inlined, everything else on a redo list)
+                "window_cells": rnd.choice([2, 2, 1, 0]),  # the window directory: by the memory rule / always / never
+                "walk_queue": rnd.choice([8, 8, 4, 0]),  # locate: tickets per lane of the per-wave queue (0: the packed form)
+                "walk_queue_min_slots": rnd.choice([32, 1, 1, 8]),  # ... from this many hit slots per pattern on
+                "walk_burst": rnd.choice([0, 0, 1, 3, 8]),  # ... steps between two hand-outs (0: sampleRate / 4)
+                "boundary_narrow": rnd.choice([0, 0, 1]),  # extractUntilBoundary: a narrow first round + the wide form over the list
+                "boundary_narrow_min": rnd.choice([4096, 1, 1])}
         check_seed = rnd.randrange(1 << 30)
         if args.only_case >= 0 and cases != args.only_case:
             if cases % 3 == 1:
