@@ -34,7 +34,7 @@
     int launch_suffix_insert(const fmx::DevIndex &, const fmx::SuffixSlot *, uint32_t, int, fmx::SuffixSlot *, hipStream_t); \
     int launch_suffix_order1(const fmx::DevIndex &, float *, hipStream_t);                                              \
     int launch_win_build(const fmx::DevIndex &, int, uint32_t, fmx::Quad *, uint32_t *, hipStream_t);                   \
-    int launch_win_other(const fmx::DevIndex &, int, uint32_t, fmx::Quad *, const uint32_t *, uint16_t *, uint32_t *, hipStream_t); \
+    int launch_win_other(const fmx::DevIndex &, int, uint32_t, fmx::Quad *, const uint32_t *, uint16_t *, uint32_t *, int, uint64_t *, uint32_t, hipStream_t); \
     int launch_count_plan(const fmx::DevIndex &, int, const uint16_t *, const int32_t *, int32_t, void *, size_t, bool, fmx::CountPlan *, \
                           hipStream_t);                                                                                 \
     int launch_count(const fmx::DevIndex &, int, const uint16_t *, const int32_t *, const fmx::CountPlan *, bool, int32_t, int32_t *, \
@@ -167,6 +167,9 @@ std::atomic<int> g_suffix_table_image_fraction{8};  // option "suffix_table_imag
 // holds many indexes lowers it, or the quarter rule shrinks what is free geometrically)
 std::atomic<int> g_window_cells{2};
 std::atomic<int> g_window_cells_mb{65536};
+// option "window_entry_bytes": the directory's entries — 0 = four bytes (the row; the symbol by a search over cumulativeCounts) where
+// those fit LDS (fmx::kWinSymbolSearchMax), six bytes otherwise; 4 / 6 = that form whatever the alphabet (tests, A/B)
+std::atomic<int> g_window_entry_bytes{0};
 // host-buffer count(): batches of at least this many patterns go through the pipeline (smaller ones: one copy in, kernels, one copy out)
 std::atomic<int> g_host_pipeline_min{131072};
 std::atomic<int> g_host_mapped{1};  // option "host_mapped": every array of a host-buffer count registered -> one launch over the mapped arrays, no copies
@@ -251,6 +254,11 @@ void make_dev_index(fmx_index *idx) {
     d.suffix_order1 = nullptr;
     d.win = nullptr;
     d.win_other = nullptr;
+    d.win_full = nullptr;
+    d.win_entry4 = 0;
+    d.c_lds = nullptr;
+    d.c_lut = nullptr;
+    d.c_lut_shift = 0;
     d.sb_cache = nullptr;
     d.sb_cache_limit = g_sb_cache_limit;
     d.wt_size = (uint32_t)h.wt_size;
@@ -268,6 +276,10 @@ int publish_dev_index(fmx_index *idx) {
     copy.suffix_order1 = nullptr;
     copy.win = nullptr;  // (a cold route is the tree walk itself; the directory is grown from its answers)
     copy.win_other = nullptr;
+    copy.win_full = nullptr;
+    copy.win_entry4 = 0;
+    copy.c_lds = nullptr;
+    copy.c_lut = nullptr;
     HIP_TRY(hipMemcpy(idx->d_self, &copy, sizeof(copy), hipMemcpyHostToDevice));
     idx->dev.self = copy.self;
     return FMX_OK;
@@ -776,6 +788,11 @@ int fmx_set_option(const char *name, int value) {
         g_window_cells = value;
         return FMX_OK;
     }
+    if (name && !strcmp(name, "window_entry_bytes")) {  // entries of the window directories grown from now on: 0 by the alphabet, 4, 6
+        if (value != 0 && value != 4 && value != 6) return fail(FMX_E_ARG, "bad value");
+        g_window_entry_bytes = value;
+        return FMX_OK;
+    }
     if (name && !strcmp(name, "window_cells_mb")) {  // absolute budget of one index's window directory under "window_cells" = 2
         if (value < 0) return fail(FMX_E_ARG, "bad value");
         g_window_cells_mb = value;
@@ -971,6 +988,8 @@ static void build_window_cells(fmx_index *idx) {
     idx->win_bytes = 0;
     idx->dev.win = nullptr;
     idx->dev.win_other = nullptr;
+    idx->dev.win_full = nullptr;
+    idx->dev.win_entry4 = 0;
     const int mode = g_window_cells.load();
     if (mode == 0 || idx->rrr_only || idx->wavelet_only || idx->hdr.kind != 0 || idx->hdr.wt_size <= 0 || !idx->dev.self) return;
     const size_t cells = fmx::win_cells_for((uint32_t)idx->hdr.wt_size);
@@ -1009,26 +1028,46 @@ static void build_window_cells(fmx_index *idx) {
         total += c;
     }
     if (total > 0xffffffffull) return give_up();
-    // (the entries — six bytes each — and behind them, 8-byte aligned, two words: how many carry a status or `suspect`
-    // (statistics), and whether some step's answer did not fit an entry: no directory then)
-    const size_t entry_bytes = ((size_t)total * fmx::kWinEntryWords * sizeof(uint16_t) + 7) & ~(size_t)7;
-    uint32_t tail[2] = {0, 0};
-    if (hipMalloc(&d_entries, entry_bytes + 16) != hipSuccess ||
-        hipMemset(static_cast<uint8_t *>(d_entries) + entry_bytes, 0, 16) != hipSuccess ||
-        hipMemcpy(d_counts, first.data(), cells * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
-        k_launch_win_other(idx, idx->dev, idx->n_cu, (uint32_t)cells, static_cast<fmx::Quad *>(d_cells), static_cast<const uint32_t *>(d_counts),
-                           static_cast<uint16_t *>(d_entries), reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(d_entries) + entry_bytes),
-                           nullptr) != 0 ||
-        hipMemcpy(tail, static_cast<uint8_t *>(d_entries) + entry_bytes, sizeof tail, hipMemcpyDeviceToHost) != hipSuccess ||
-        tail[1] != 0)
-        return give_up();
-    (void)hipFree(d_counts);
-    idx->win_unclean = tail[0];
-    idx->d_win = d_cells;
-    idx->d_win_other = d_entries;
-    idx->win_bytes = bytes + (size_t)total * fmx::kWinEntryWords * sizeof(uint16_t);
-    idx->dev.win = static_cast<const fmx::Quad *>(d_cells);
-    idx->dev.win_other = static_cast<const uint16_t *>(d_entries);
+    // The entries — four bytes each where cumulativeCounts fit LDS (the row alone: the symbol is found by a search), six otherwise —
+    // and behind them, 8-byte aligned, four words: how many carry a status or `suspect` (statistics), whether some step's answer
+    // did not fit (no directory in that form then), how many of the four-byte form's slots are taken; then those slots (eight
+    // bytes each: the few answers that are more than a row).  A four-byte directory that runs out of slots is made again with
+    // six-byte entries.
+    const int want = g_window_entry_bytes.load();
+    bool entry4 = want == 4 || (want == 0 && idx->hdr.n_c <= fmx::kWinSymbolSearchMax);
+    for (;;) {
+        const size_t per_entry = entry4 ? 4 : fmx::kWinEntryWords * sizeof(uint16_t);
+        const size_t entry_bytes = ((size_t)total * per_entry + 7) & ~(size_t)7;
+        const uint32_t full_cap = entry4 ? (uint32_t)std::min<uint64_t>(4096 + total / 512, 0x7fffffffu) : 0u;
+        uint32_t tail[4] = {0, 0, 0, 0};
+        uint8_t *e8 = nullptr;
+        if (hipMalloc(&d_entries, entry_bytes + 16 + (size_t)full_cap * 8) != hipSuccess) return give_up();
+        e8 = static_cast<uint8_t *>(d_entries);
+        if (hipMemset(e8 + entry_bytes, 0, 16) != hipSuccess ||
+            hipMemcpy(d_counts, first.data(), cells * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
+            k_launch_win_other(idx, idx->dev, idx->n_cu, (uint32_t)cells, static_cast<fmx::Quad *>(d_cells), static_cast<const uint32_t *>(d_counts),
+                               static_cast<uint16_t *>(d_entries), reinterpret_cast<uint32_t *>(e8 + entry_bytes), entry4 ? 1 : 0,
+                               reinterpret_cast<uint64_t *>(e8 + entry_bytes + 16), full_cap, nullptr) != 0 ||
+            hipMemcpy(tail, e8 + entry_bytes, sizeof tail, hipMemcpyDeviceToHost) != hipSuccess)
+            return give_up();
+        if (tail[1] != 0) {
+            if (!entry4) return give_up();
+            (void)hipFree(d_entries);  // (out of slots, or an answer that fits neither form: the six-byte form decides)
+            d_entries = nullptr;
+            entry4 = false;
+            continue;
+        }
+        (void)hipFree(d_counts);
+        idx->win_unclean = tail[0];
+        idx->d_win = d_cells;
+        idx->d_win_other = d_entries;
+        idx->win_bytes = bytes + (size_t)total * per_entry + (entry4 ? (size_t)tail[2] * 8 : 0);
+        idx->dev.win = static_cast<const fmx::Quad *>(d_cells);
+        idx->dev.win_other = static_cast<const uint16_t *>(d_entries);
+        idx->dev.win_entry4 = entry4 ? 1 : 0;
+        idx->dev.win_full = entry4 ? reinterpret_cast<const uint64_t *>(e8 + entry_bytes + 16) : nullptr;
+        return;
+    }
 }
 
 int fmx_window_cells_info(const fmx_index *idx, int64_t *bytes) {

@@ -92,7 +92,14 @@ struct DevIndex {
     // one sector fill instead of {mapping entry, path records, a cell per tree level}.  Whatever it does not hold takes the
     // path above.  Results never depend on it: every count in it was checked against rank() when it was grown.
     const struct Quad *win;
-    const uint16_t *win_other;  // the entries (three 16-bit words each) of the positions no class of their window holds (nullptr iff win is)
+    const uint16_t *win_other;  // the entries of the positions no class of their window holds (nullptr iff win is): six bytes each,
+                                // or — win_entry4 — four (win_other_load)
+    const uint64_t *win_full;   // four-byte entries: the few answers that are more than a row (a status, `suspect`, a symbol the row does
+                                // not give away), eight bytes each, pointed at by their entries
+    int32_t win_entry4;         // 1: four-byte entries
+    const int32_t *c_lds;       // cumulativeCounts staged in LDS by the kernel (nullptr: read C) — win_symbol_of_row
+    const uint16_t *c_lut;      // ... and, beside them, where to start looking: kWinLutBuckets + 1 symbols (nullptr: the whole range)
+    int32_t c_lut_shift;        // row >> c_lut_shift = the row's bucket
     // this index's DevIndex as the API layer keeps it in HBM (no LDS cache, no launch option applied): what a cold route reads
     const DevIndex *self;
 };
@@ -726,12 +733,19 @@ FMX_HD bool win_inv_from(const WinCell &c, uint32_t r, int32_t &symbol_out, int3
     row_out = (int32_t)(k == 0u ? c.q0.x : (k == 1u ? c.q0.y : c.q0.z)) + before + 1;
     return true;
 }
-// the entry of a class-3 position = what fm_lf_step hands back for its row, in SIX bytes (round 6; eight before): the row it
+// the entry of a class-3 position = what fm_lf_step hands back for its row.  SIX bytes (round 6; eight before): the row it
 // arrives at (31 bits: rows are Java ints >= 0) with `suspect` in bit 31, then the symbol (15 bits: an alphabet has at most 32,767
 // codes, FM:423-426, and validate_blob holds every leaf symbol below wt_sigma) with "the step raised a status" in bit 15 — the only
-// status a step can raise is the JVM's ArrayIndexOutOfBounds (every `status =` on the path of fm_lf_step).  0.18 x 6 bytes per
-// position: the directory takes 1.65 instead of 2.0 bytes per text byte of log text.
-constexpr uint32_t kWinEntryWords = 3;  // 16-bit words per entry
+// status a step can raise is the JVM's ArrayIndexOutOfBounds (every `status =` on the path of fm_lf_step).
+// FOUR bytes (DevIndex.win_entry4, alphabets whose cumulativeCounts fit LDS: kWinSymbolSearchMax): the row alone.  A clean step
+// with symbol c arrives at C[c] + rank, a row in (C[c], C[c + 1]]: the symbol is the largest c with C[c] < row — a search over
+// cumulativeCounts (win_symbol_of_row; the kernels that want symbols stage C in LDS, locate never asks).  An answer that is more
+// than that — a status, `suspect`, a row that does not give its symbol away (none on a well-formed index outside the quirk rows) —
+// lives as a six-byte answer in an eight-byte slot of DevIndex.win_full, and its entry is bit 31 + the slot's index.
+// 0.18 x 6 (4) bytes per position: the directory takes 1.65 (1.29) instead of 2.0 bytes per text byte of log text.
+constexpr uint32_t kWinEntryWords = 3;  // 16-bit words per six-byte entry
+constexpr int32_t kWinSymbolSearchMax = 2050;  // entries of cumulativeCounts up to which the four-byte form is offered (8 KB of LDS)
+constexpr uint32_t kWinEntryEscape = 0x80000000u;
 FMX_HD uint64_t win_other_make(int32_t row, int32_t c, int status, bool suspect) {
     return (uint64_t)(((uint32_t)row & 0x7fffffffu) | (suspect ? 0x80000000u : 0u)) |
            ((uint64_t)(((uint32_t)c & 0x7fffu) | (status != ST_OK ? 0x8000u : 0u)) << 32);
@@ -741,12 +755,41 @@ FMX_HD uint64_t win_other_make(int32_t row, int32_t c, int status, bool suspect)
 FMX_HD bool win_other_fits(int32_t row, int32_t c, int status) {
     return row >= 0 && c >= 0 && c <= 0x7fff && (status == ST_OK || status == ST_JAVA_AIOOBE);
 }
-FMX_HD void win_other_from(uint64_t entry, int32_t &symbol_out, int32_t &row_out, int &status, bool &suspect) {
+FMX_HD void win_other_unpack(uint64_t entry, int32_t &symbol_out, int32_t &row_out, int &status, bool &suspect) {
     const uint32_t lo = (uint32_t)entry, hi = (uint32_t)(entry >> 32);
     symbol_out = (int32_t)(hi & 0x7fffu);
     row_out = (int32_t)(lo & 0x7fffffffu);
     if (hi & 0x8000u) status = ST_JAVA_AIOOBE;
     if (lo >> 31) suspect = true;
+}
+// the largest c with C[c] < row: the symbol of a clean step that arrives at `row` (C = cumulativeCounts: n_c entries, ascending)
+// (a kernel that has C in LDS also has a table of kWinLutBuckets + 1 symbols there: entry b = the largest c with C[c] < b << shift,
+// so that a row of bucket b has its symbol in [lut[b], lut[b + 1]] — one symbol, or two, for most rows of any text: the search
+// that is left takes no step, or one)
+constexpr int32_t kWinLutBuckets = 256;
+FMX_HD int32_t win_lut_shift(int32_t length) {
+    int32_t shift = 0;
+    while ((length >> shift) >= kWinLutBuckets) ++shift;
+    return shift;
+}
+FMX_HD int32_t win_symbol_of_row(const DevIndex &ix, int32_t row) {
+    const int32_t *C = ix.c_lds ? ix.c_lds : ix.C;
+    int32_t lo = 0, hi = ix.n_c - 1;
+    if (ix.c_lut) {
+        const int32_t b = row >> ix.c_lut_shift;  // (0 <= row <= length: an entry's row is a row of the index)
+        if ((uint32_t)b < (uint32_t)kWinLutBuckets) {
+            lo = ix.c_lut[b];
+            hi = ix.c_lut[b + 1];
+        }
+    }
+    while (lo < hi) {
+        const int32_t mid = (lo + hi + 1) >> 1;
+        if (C[mid] < row)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    return lo;
 }
 FMX_HD void win_other_store(uint16_t *entries, uint32_t index, uint64_t v) {
     uint16_t *p = entries + (uint64_t)index * kWinEntryWords;
@@ -754,13 +797,34 @@ FMX_HD void win_other_store(uint16_t *entries, uint32_t index, uint64_t v) {
     p[1] = (uint16_t)(v >> 16);
     p[2] = (uint16_t)(v >> 32);
 }
+// an entry as stored (four-byte form: in the low word)
 FMX_HD uint64_t win_other_load(const DevIndex &ix, uint32_t index) {
+    if (ix.win_entry4) {
+        uint32_t e = reinterpret_cast<const uint32_t *>(ix.win_other)[index];
+        FMX_OPAQUE32(e);
+        return e;
+    }
     const uint16_t *p = ix.win_other + (uint64_t)index * kWinEntryWords;
     uint32_t a = p[0], b = p[1], c = p[2];  // three 2-byte loads (an entry is 2-byte aligned), one wait
     FMX_OPAQUE32(a);
     FMX_OPAQUE32(b);
     FMX_OPAQUE32(c);
     return (uint64_t)(a | (b << 16)) | ((uint64_t)c << 32);
+}
+// ... and what it says.  kSymbol false: the caller does not read symbol_out (locate), so nothing is searched for.
+template <bool kSymbol = true>
+FMX_HD void win_other_from(const DevIndex &ix, uint64_t entry, int32_t &symbol_out, int32_t &row_out, int &status, bool &suspect) {
+    if (ix.win_entry4) {
+        const uint32_t e = (uint32_t)entry;
+        if (e & kWinEntryEscape) {
+            win_other_unpack(ix.win_full[e & ~kWinEntryEscape], symbol_out, row_out, status, suspect);
+            return;
+        }
+        row_out = (int32_t)e;
+        if (kSymbol) symbol_out = win_symbol_of_row(ix, (int32_t)e);
+        return;
+    }
+    win_other_unpack(entry, symbol_out, row_out, status, suspect);
 }
 
 // With the superblock's header at hand (ix.sb_cache, staged in LDS by the kernel) and the mapping rows indexed by
@@ -1281,7 +1345,7 @@ FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, 
         const WinCell cell = win_load(ix, p, r);
         int32_t wc = 0, next = 0;
         bool sampled;
-        if (!win_inv_from(cell, r, wc, next, sampled, other)) win_other_from(win_other_load(ix, other), wc, next, status, suspect);
+        if (!win_inv_from(cell, r, wc, next, sampled, other)) win_other_from(ix, win_other_load(ix, other), wc, next, status, suspect);
         c_out = wc;
         return next;
     }
@@ -1332,8 +1396,8 @@ FMX_HD void fm_lf_step2(const DevIndex &ix, const uint16_t *inv, LfChain &a, LfC
         const bool ea = la && !ha, eb = lb && !hb;
         if (ea || eb) {
             const uint64_t va = win_other_load(ix, ea ? oa : 0u), vb = win_other_load(ix, eb ? ob : 0u);
-            if (ea) win_other_from(va, wca_c, nexta, status, suspect);
-            if (eb) win_other_from(vb, wcb_c, nextb, status, suspect);
+            if (ea) win_other_from(ix, va, wca_c, nexta, status, suspect);
+            if (eb) win_other_from(ix, vb, wcb_c, nextb, status, suspect);
         }
         if (la) {
             a.c = wca_c;
@@ -1540,8 +1604,19 @@ FMX_HD uint32_t win_build_cell(const DevIndex &ix, uint32_t w, uint32_t *out) {
 // The win_other entries of window w (cell = its 16 words as win_build_cell made them): one per position of class 3, in position
 // order, from entry `first` on — what fm_lf_step hands back for the position's row (win_other_make).  Writes `first` into the
 // cell's word 4; returns the number of entries that carry a status or `suspect` (statistics: a handful per index), bit 31 set if
-// some step's answer does not fit an entry (win_other_fits).
-FMX_HD uint32_t win_build_other(const DevIndex &ix, uint32_t w, uint32_t *cell_words, uint32_t first, uint16_t *entries) {
+// some step's answer does not fit an entry (win_other_fits) or — four-byte form — the slots for the answers that are more than a
+// row have run out.
+// Four-byte form (entry4): full / full_cap / full_count = the eight-byte slots, how many there are, how many are taken (an atomic
+// counter on the device; FMX_WIN_TAKE_SLOT).  An entry is the row alone exactly when the search gives the symbol back.
+#ifndef FMX_WIN_TAKE_SLOT
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FMX_WIN_TAKE_SLOT(counter) atomicAdd((counter), 1u)
+#else
+#define FMX_WIN_TAKE_SLOT(counter) ((*(counter))++)
+#endif
+#endif
+FMX_HD uint32_t win_build_other(const DevIndex &ix, uint32_t w, uint32_t *cell_words, uint32_t first, uint16_t *entries,
+                                bool entry4 = false, uint64_t *full = nullptr, uint32_t full_cap = 0, uint32_t *full_count = nullptr) {
     const uint64_t ws64 = (uint64_t)w * kWinW;
     const uint32_t ws = (uint32_t)ws64;
     const uint32_t n = ws64 >= ix.wt_size ? 0u : (ix.wt_size - ws < kWinW ? ix.wt_size - ws : kWinW);
@@ -1560,7 +1635,20 @@ FMX_HD uint32_t win_build_other(const DevIndex &ix, uint32_t w, uint32_t *cell_w
         const int32_t next = fm_lf_step<true, kWinNever>(ix, nullptr, (int32_t)(ws + j + 1u), c, status, suspect);
         if (status != ST_OK || suspect) ++unclean;
         if (!win_other_fits(next, c, status)) unclean |= 0x80000000u;  // (never on a validated index: the caller drops the directory)
-        win_other_store(entries, at++, win_other_make(next, c, status, suspect));
+        if (!entry4) {
+            win_other_store(entries, at++, win_other_make(next, c, status, suspect));
+            continue;
+        }
+        uint32_t e = (uint32_t)next;
+        if (status != ST_OK || suspect || next < 0 || win_symbol_of_row(ix, next) != c) {
+            const uint32_t slot = FMX_WIN_TAKE_SLOT(full_count);
+            if (slot < full_cap)
+                full[slot] = win_other_make(next, c, status, suspect);
+            else
+                unclean |= 0x80000000u;
+            e = kWinEntryEscape | slot;
+        }
+        reinterpret_cast<uint32_t *>(entries)[at++] = e;
     }
     return unclean;
 }
@@ -1691,7 +1779,7 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
                 break;
             }
             bool suspect = false;
-            if (!answered) win_other_from(win_other_load(ix, other), c, next, status, suspect);
+            if (!answered) win_other_from<false>(ix, win_other_load(ix, other), c, next, status, suspect);  // (locate never reads the symbol)
             j = next;  // (the step fm_lf_step took over the tree when the directory was grown)
         } else {
             // (p < length == the wavelet tree's size: validate_model / validate_blob)
@@ -1756,7 +1844,7 @@ FMX_HD bool fm_locate_steps_win(const DevIndex &ix, WalkState &w, int32_t budget
         const bool answered = win_inv_from(cell, r, c, next, sampled_row, other);
         if (sampled_row) return true;  // FM:531
         bool suspect = false;
-        if (!answered) win_other_from(win_other_load(ix, other), c, next, w.status, suspect);
+        if (!answered) win_other_from<false>(ix, win_other_load(ix, other), c, next, w.status, suspect);  // (locate never reads the symbol)
         w.j = next;  // (the step fm_lf_step took over the tree when the directory was grown)
         if (++w.distance > walk_limit) {  // bounds the walk on a damaged index
             w.status = ST_JAVA_AIOOBE;

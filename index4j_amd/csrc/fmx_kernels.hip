@@ -112,6 +112,32 @@ __device__ __forceinline__ const Quad *stage_sb_cache(Quad *s_sb, const DevIndex
     DevIndex LOCAL_IX = GLOBAL_IX;                  \
     LOCAL_IX.sb_cache = stage_sb_cache(s_sb, GLOBAL_IX)
 
+// cumulativeCounts in LDS for the kernels that read SYMBOLS out of a window directory with four-byte entries (win_symbol_of_row:
+// an entry is the row a step arrives at, its symbol the largest c with C[c] < row) — extract and extractUntilBoundary; locate
+// never asks.  Alphabets beyond kWinSymbolSearchMax entries keep six-byte entries (or, forced to four, search C where it lies).
+__device__ __forceinline__ void stage_c_lds(int32_t *s_c, uint16_t *s_lut, DevIndex &ix) {
+    ix.c_lds = nullptr;
+    ix.c_lut = nullptr;
+    ix.c_lut_shift = 0;
+    if (!ix.win || !ix.win_entry4 || ix.n_c > kWinSymbolSearchMax) return;
+    for (int i = threadIdx.x; i < ix.n_c; i += blockDim.x) s_c[i] = ix.C[i];
+    __syncthreads();
+    ix.c_lds = s_c;
+    // where a row's search starts: entry b = the largest c with C[c] < b << shift (win_symbol_of_row)
+    const int32_t shift = win_lut_shift(ix.length);
+    for (int b = threadIdx.x; b <= kWinLutBuckets; b += blockDim.x) {
+        const int64_t row = (int64_t)b << shift;
+        s_lut[b] = (uint16_t)win_symbol_of_row(ix, row > 0x7fffffff ? 0x7fffffff : (int32_t)row);
+    }
+    __syncthreads();
+    ix.c_lut = s_lut;
+    ix.c_lut_shift = shift;
+}
+#define FMX_WITH_C_LDS(IX, KWIN)                                                  \
+    __shared__ int32_t s_c_lds[(KWIN) == kWinNever ? 1 : kWinSymbolSearchMax];    \
+    __shared__ uint16_t s_c_lut[(KWIN) == kWinNever ? 1 : kWinLutBuckets + 2];    \
+    if ((KWIN) != kWinNever) stage_c_lds(s_c_lds, s_c_lut, IX)
+
 // geometry of the plan kernels' workgroups, measured on configs[1] (codes / scatter kernel, us): 512 x 8: 19.3 / 19.9,
 // 256 x 4: 27.3 / 41.2 (four times the workgroups, each zeroing, flushing and scanning all bins), 1024 x 4: 15.7 / 17.5
 #ifndef FMX_TILE_THREADS
@@ -1003,7 +1029,8 @@ __global__ __launch_bounds__(256) void k_win_build(DevIndex ix, uint32_t n_win, 
     }
 }
 __global__ __launch_bounds__(256) void k_win_other(DevIndex ix, uint32_t n_win, Quad *__restrict__ cells, const uint32_t *__restrict__ first,
-                                                   uint16_t *__restrict__ entries, uint32_t *__restrict__ open_entries) {
+                                                   uint16_t *__restrict__ entries, uint32_t *__restrict__ open_entries, int entry4,
+                                                   uint64_t *__restrict__ full, uint32_t full_cap) {
     for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < n_win; w += (uint64_t)gridDim.x * 256) {
         uint32_t words[16];
         for (int i = 0; i < 4; ++i) {
@@ -1013,7 +1040,7 @@ __global__ __launch_bounds__(256) void k_win_other(DevIndex ix, uint32_t n_win, 
             words[4 * i + 2] = q.z;
             words[4 * i + 3] = q.w;
         }
-        const uint32_t open = win_build_other(ix, (uint32_t)w, words, first[w], entries);
+        const uint32_t open = win_build_other(ix, (uint32_t)w, words, first[w], entries, entry4 != 0, full, full_cap, open_entries + 2);
         cells[4 * w + 1].x = words[4];
         if (open & 0x7fffffffu) atomicAdd(open_entries, open & 0x7fffffffu);  // (entries that carry a status or `suspect`: statistics)
         if (open >> 31) atomicOr(open_entries + 1, 1u);  // an answer that does not fit an entry: the caller drops the directory
@@ -1025,6 +1052,11 @@ static DevIndex win_plain_index(const DevIndex &ix) {
     plain.suffix_table = nullptr;
     plain.win = nullptr;
     plain.win_other = nullptr;
+    plain.win_full = nullptr;
+    plain.win_entry4 = 0;
+    plain.c_lds = nullptr;
+    plain.c_lut = nullptr;
+    plain.c_lut_shift = 0;
     return plain;
 }
 static unsigned win_blocks(int n_cu, uint32_t n_win) {
@@ -1038,10 +1070,10 @@ int launch_win_build(const DevIndex &ix, int n_cu, uint32_t n_win, Quad *out, ui
     return (int)hipGetLastError();
 }
 int launch_win_other(const DevIndex &ix, int n_cu, uint32_t n_win, Quad *cells, const uint32_t *first, uint16_t *entries,
-                     uint32_t *open_entries, hipStream_t st) {
+                     uint32_t *open_entries, int entry4, uint64_t *full, uint32_t full_cap, hipStream_t st) {
     if (n_win == 0) return 0;
     hipLaunchKernelGGL(k_win_other, dim3(win_blocks(n_cu, n_win)), dim3(256), 0, st, win_plain_index(ix), n_win, cells, first, entries,
-                       open_entries);
+                       open_entries, entry4, full, full_cap);
     return (int)hipGetLastError();
 }
 
@@ -1350,6 +1382,7 @@ FMX_EXTRACT_KERNEL(kBlock) void k_extract(DevIndex ix_global, const int32_t *__r
                                   int32_t slots, int32_t fixed_len, const PlanRec *__restrict__ order) {
     FMX_FM_INV(ix_global);
     FMX_WITH_SB_CACHE(ix_global, ix);
+    FMX_WITH_C_LDS(ix, kWin);
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < n; t += stride) {
         // order (nullable; the pipeline form): the hits by text position — hits of equal patterns are equal positions, and equal
@@ -1392,6 +1425,7 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary(DevIndex ix_global, const in
     }
     FMX_FM_INV(ix_global);
     FMX_WITH_SB_CACHE(ix_global, ix);
+    FMX_WITH_C_LDS(ix, kWinAsk);
     const int64_t lanes = (int64_t)gridDim.x * kBlock;
     const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int32_t mapped_boundary = fm_map(ix, boundary);  // FM:658
@@ -1433,6 +1467,7 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix_global, co
     }
     FMX_FM_INV(ix_global);
     FMX_WITH_SB_CACHE(ix_global, ix);
+    FMX_WITH_C_LDS(ix, kWin);
     const int64_t lanes = (int64_t)gridDim.x * kBlock;
     const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int g = threadIdx.x % G;

@@ -18,6 +18,10 @@ using namespace fmx;
 static std::map<const uint8_t *, std::vector<uint32_t>> g_windows;
 static std::map<const uint8_t *, std::vector<uint16_t>> g_window_entries;
 static std::map<const uint8_t *, uint64_t> g_window_unclean;
+static std::map<const uint8_t *, std::vector<uint64_t>> g_window_full;  // four-byte entries: the answers that are more than a row
+static std::map<const uint8_t *, int> g_window_entry4;
+static std::map<const uint8_t *, std::vector<uint16_t>> g_window_lut;  // ... and where a symbol search starts (the kernels make it in LDS)
+static int g_entry_bytes = 0;  // sim_set_entry_bytes: 0 = by the alphabet (as fmx_to_device), 4, 6
 static int g_pack = 1;  // locate over a window directory: the instalment form (k_locate_walk_c) or fm_locate_hit<kWinAlways> (option walk_pack 0)
 
 static DevIndex make_index(const uint8_t *b) {
@@ -54,6 +58,14 @@ static DevIndex make_index(const uint8_t *b) {
         d.win = it == g_windows.end() ? nullptr : reinterpret_cast<const Quad *>(it->second.data());
         auto e = g_window_entries.find(b);
         d.win_other = e == g_window_entries.end() ? nullptr : e->second.data();
+        auto f = g_window_full.find(b);
+        d.win_full = f == g_window_full.end() ? nullptr : f->second.data();
+        auto k = g_window_entry4.find(b);
+        d.win_entry4 = k == g_window_entry4.end() ? 0 : k->second;
+        d.c_lds = nullptr;
+        auto l = g_window_lut.find(b);
+        d.c_lut = l == g_window_lut.end() ? nullptr : l->second.data();
+        d.c_lut_shift = win_lut_shift(h.length);
     }
     d.self = nullptr;
     d.suffix_chars = 0;
@@ -67,10 +79,14 @@ extern "C" {
 
 // grows the window directory of a blob with the very function k_win_build runs (win_build_cell) and attaches it: every sim_*
 // call on that blob then takes the windows first, as the kernels do on a resident index.  Returns the number of cells;
-// stats (nullable): {positions with a class, positions, classes in use, positions with an entry, entries with a status or suspect}.
+// stats (nullable, 6 slots): {positions with a class, positions, classes in use, positions with an entry, entries with a status or
+// suspect, four-byte form: entries that point at an eight-byte slot (-1: six-byte form)}.
 int64_t sim_win_attach(const uint8_t *blob, int64_t *stats) {
     g_windows.erase(blob);
     g_window_entries.erase(blob);
+    g_window_full.erase(blob);
+    g_window_entry4.erase(blob);
+    g_window_lut.erase(blob);
     DevIndex ix = make_index(blob);  // (no directory: it is made from the tree walk's own answers)
     const size_t cells = win_cells_for(ix.wt_size);
     std::vector<uint32_t> words(cells * 16 + 4), first(cells + 1);
@@ -80,9 +96,16 @@ int64_t sim_win_attach(const uint8_t *blob, int64_t *stats) {
         total += win_build_cell(ix, (uint32_t)w, words.data() + 16 * w);
     }
     std::vector<uint16_t> entries((total + 1) * kWinEntryWords);
+    const bool entry4 = g_entry_bytes == 4 || (g_entry_bytes == 0 && ix.n_c <= kWinSymbolSearchMax);
+    std::vector<uint64_t> full(entry4 ? total + 1 : 1);  // (room for every entry: the host simulation never runs out of slots)
+    uint32_t full_count = 0;
     uint64_t open_entries = 0;
-    for (size_t w = 0; w < cells; ++w) open_entries += win_build_other(ix, (uint32_t)w, words.data() + 16 * w, first[w], entries.data()) & 0x7fffffffu;
+    for (size_t w = 0; w < cells; ++w)
+        open_entries += win_build_other(ix, (uint32_t)w, words.data() + 16 * w, first[w], entries.data(), entry4, full.data(),
+                                        (uint32_t)full.size(), &full_count) & 0x7fffffffu;
     g_window_unclean[blob] = open_entries;
+    g_window_entry4[blob] = entry4 ? 1 : 0;
+    if (stats) stats[5] = entry4 ? (int64_t)full_count : -1;
     if (stats) {
         stats[0] = stats[1] = stats[2] = stats[3] = 0;
         stats[4] = (int64_t)open_entries;
@@ -106,13 +129,27 @@ int64_t sim_win_attach(const uint8_t *blob, int64_t *stats) {
     }
     g_windows[blob] = std::move(words);
     g_window_entries[blob] = std::move(entries);
+    g_window_full[blob] = std::move(full);
+    if (entry4) {  // as stage_c_lds does per workgroup
+        std::vector<uint16_t> lut(kWinLutBuckets + 2);
+        const int32_t shift = win_lut_shift(ix.length);
+        for (int32_t b = 0; b <= kWinLutBuckets; ++b) {
+            const int64_t row = (int64_t)b << shift;
+            lut[(size_t)b] = (uint16_t)win_symbol_of_row(ix, row > 0x7fffffff ? 0x7fffffff : (int32_t)row);
+        }
+        g_window_lut[blob] = std::move(lut);
+    }
     return (int64_t)cells;
 }
 void sim_set_pack(int on) { g_pack = on; }
+void sim_set_entry_bytes(int bytes) { g_entry_bytes = bytes; }
 void sim_win_detach(const uint8_t *blob) {
     g_windows.erase(blob);
     g_window_entries.erase(blob);
     g_window_unclean.erase(blob);
+    g_window_full.erase(blob);
+    g_window_entry4.erase(blob);
+    g_window_lut.erase(blob);
 }
 
 int32_t sim_wt_rank(const uint8_t *blob, uint32_t position, int32_t symbol, int32_t *status) {

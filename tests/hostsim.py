@@ -29,6 +29,7 @@ def lib(compact=False):
         L.sim_win_attach.restype = C.c_int64
         L.sim_win_detach.argtypes = [C.c_void_p]
         L.sim_set_pack.argtypes = [C.c_int]
+        L.sim_set_entry_bytes.argtypes = [C.c_int]
         _LIBS[compact] = L
     return _LIBS[compact]
 
@@ -84,13 +85,19 @@ class HostSim:
         self.L = lib(self.compact)
         self.windows = None
 
-    def attach_windows(self):
+    def attach_windows(self, entry_bytes=0):
         """grows the window directory (fmx_device.hpp: win_build_cell, what k_win_build runs when an index becomes resident) and
         makes every later call of this simulation take it first, as the kernels do; returns (positions with a class, positions,
-        classes in use, positions with an entry, entries that carry a status or `suspect`)"""
-        stats = np.zeros(5, np.int64)
-        self.L.sim_win_attach(C.c_void_p(self.p), C.c_void_p(stats.ctypes.data))
-        self.windows = tuple(int(v) for v in stats)
+        classes in use, positions with an entry, entries that carry a status or `suspect`).  entry_bytes: 0 = the form fmx_to_device
+        picks by the alphabet (four-byte entries where cumulativeCounts fit LDS), 4 / 6 = that form"""
+        stats = np.zeros(6, np.int64)
+        self.L.sim_set_entry_bytes(int(entry_bytes))
+        try:
+            self.L.sim_win_attach(C.c_void_p(self.p), C.c_void_p(stats.ctypes.data))
+        finally:
+            self.L.sim_set_entry_bytes(0)
+        self.windows = tuple(int(v) for v in stats[:5])
+        self.window_slots = int(stats[5])  # four-byte entries: how many point at an eight-byte slot (-1: six-byte entries)
         return self.windows
 
     def detach_windows(self):

@@ -1051,11 +1051,13 @@ def _window_bytes(f):
     return n.value
 
 
-@pytest.mark.parametrize("mode", [0, 1])
-def test_window_directory_changes_nothing_but_the_time(mode):
+@pytest.mark.parametrize("mode,entry_bytes", [(0, 0), (1, 0), (1, 4), (1, 6)])
+def test_window_directory_changes_nothing_but_the_time(mode, entry_bytes):
     """option window_cells: every query kind vs the oracle with the directory grown (1) and without one (0) — on the fixture,
     on texts with sentinels, run blocks of wide symbols (Q1: never a directory entry) and a 900-symbol alphabet, on a compact
-    image — and fmx_window_cells_info says which of the two an index got"""
+    image — and fmx_window_cells_info says which of the two an index got.  entry_bytes (option window_entry_bytes): the directory's
+    entries in the form picked by the alphabet (0: four bytes — the row, its symbol found by a search over cumulativeCounts — up
+    to 2,048 symbols, six beyond: the fixture has 2,061), all in four, all in six"""
     rng = np.random.default_rng(9)
     parts = []
     for i in range(6):
@@ -1069,10 +1071,20 @@ def test_window_directory_changes_nothing_but_the_time(mode):
         mod[rnd.randrange(len(mod) - 2)] = "\0"
     try:
         assert ia.lib.fmx_set_option(b"window_cells", mode) == 0
+        assert ia.lib.fmx_set_option(b"window_entry_bytes", entry_bytes) == 0
         f = ia.FmIndex(HD[:20_000], 8, True, device=0)
         assert (_window_bytes(f) > 0) == (mode == 1)
-        # 64 bytes per 112 positions + 8 per position none of its window's three classes holds
-        assert mode == 0 or 64 * (20_001 // 112) <= _window_bytes(f) <= 64 * (20_001 // 112 + 2) + 8 * 20_001
+        # 64 bytes per 112 positions + 6 (4) per position none of its window's three classes holds
+        assert mode == 0 or 64 * (20_001 // 112) <= _window_bytes(f) <= 64 * (20_001 // 112 + 2) + 6 * 20_001
+        if mode == 1 and entry_bytes:
+            other = {4: 6, 6: 4}[entry_bytes]
+            assert ia.lib.fmx_set_option(b"window_entry_bytes", other) == 0
+            g = ia.FmIndex(HD[:20_000], 8, True, device=0)
+            assert ia.lib.fmx_set_option(b"window_entry_bytes", entry_bytes) == 0
+            cells = 64 * (20_001 // 112 + 1)
+            small, big = sorted((_window_bytes(f), _window_bytes(g)))
+            assert 1.45 < (big - cells) / (small - cells) < 1.51  # the entries: six bytes against four (+ a few eight-byte slots)
+            g.close()
         for sr in (1, 4, 32, 64):
             check_all(make_gpu, HD, sr, rnd, n_q=100)
         check_all(make_gpu, "".join(mod), 8, rnd, n_q=60)
@@ -1084,3 +1096,4 @@ def test_window_directory_changes_nothing_but_the_time(mode):
     finally:
         ia.lib.fmx_set_option(b"image_compact", 0)
         ia.lib.fmx_set_option(b"window_cells", 2)
+        ia.lib.fmx_set_option(b"window_entry_bytes", 0)

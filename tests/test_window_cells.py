@@ -19,12 +19,30 @@ HD = hdfs_text()
 COVER = {}
 
 
+ENTRY_BYTES = [0]  # the form of the directory's entries make_sim_windows asks for (0: by the alphabet, as fmx_to_device)
+
+
 def make_sim_windows(text, sr):
     h = hostsim.HostSim(ia.FmIndex(text, sr, True, device=None))
-    got, positions, classes, by_entry, unclean = h.attach_windows()
+    got, positions, classes, by_entry, unclean = h.attach_windows(ENTRY_BYTES[0])
     assert got + by_entry == positions  # every position's step is in the directory
+    assert (h.window_slots >= 0) == (ENTRY_BYTES[0] == 4 or (ENTRY_BYTES[0] == 0 and h.fm.getAlphabetLength() + 2 <= 2050))
+    # four-byte entries: an entry points at an eight-byte slot at least where its step carries a status or `suspect`
+    assert h.window_slots < 0 or unclean <= h.window_slots <= by_entry
     COVER[(len(text), sr)] = got / max(1, positions)
+    SLOTS[(len(text), sr)] = (h.window_slots, by_entry)
     return h
+
+
+SLOTS = {}
+
+
+@pytest.fixture(params=[4, 6])
+def entry_bytes(request):
+    """both forms of the directory's entries, whatever the alphabet (option window_entry_bytes of the library)"""
+    ENTRY_BYTES[0] = request.param
+    yield request.param
+    ENTRY_BYTES[0] = 0
 
 
 @pytest.mark.parametrize("sr", [1, 4, 32, 64])
@@ -32,6 +50,26 @@ def test_fixture_through_the_windows(sr):
     check_all(make_sim_windows, HD, sr, random.Random(100 + sr))
     # log text: the three most frequent symbols of a 120-position stretch of the BWT hold most of it
     assert COVER[(len(HD), sr)] > 0.5
+
+
+@pytest.mark.parametrize("sr", [2, 32])
+def test_fixture_through_both_forms_of_the_entries(sr, entry_bytes):
+    """the fixture has 2,061 symbols: past what the four-byte form is offered for by default, so it is forced here (the symbol of an
+    entry then comes out of a search over cumulativeCounts where they lie) beside the six-byte form"""
+    check_all(make_sim_windows, HD, sr, random.Random(300 + sr))
+    slots, by_entry = SLOTS[(len(HD), sr)]
+    if entry_bytes == 4:
+        assert 0 <= slots < by_entry // 50  # nearly every entry is the row alone
+
+
+def test_quirk_texts_through_both_forms_of_the_entries(entry_bytes):
+    check_all(make_sim_windows, quirk_text(), 8, random.Random(41), n_q=80)
+    check_all(make_sim_windows, "ab" * 55 + "c", 4, random.Random(42), n_q=20)
+    rnd = random.Random(43)
+    mod = list(HD[:30_000])
+    for _ in range(200):
+        mod[rnd.randrange(len(mod) - 2)] = "\0"
+    check_all(make_sim_windows, "".join(mod), 8, rnd, n_q=60)
 
 
 def test_sentinels_small_texts_and_texts_shorter_than_a_window():
