@@ -85,12 +85,15 @@ int fmx_suffix_table_info(const fmx_index *idx, int32_t *chars, int64_t *bytes);
  * table; option "window_cells": 0 = none, 1 = always, 2 = where it fits a quarter of the device's free memory, the default): one
  * 64-byte cell per 112 consecutive BWT positions holding, for the window's three most frequent symbols ("classes"), their folded
  * rank at the window start and — in two bit planes — the positions they stand at, plus every position's bit of sampledSuffixes
- * (FM:123) — and one 6-byte entry {next row, symbol, status, suspect} per position that holds none of the three: everything the
- * LF-step of that row hands back, whatever route of the tree (and whichever of the reference's quirks) it takes.  An LF-step of
+ * (FM:123) — and one entry per position that holds none of the three: everything the LF-step of that row hands back, whatever
+ * route of the tree (and whichever of the reference's quirks) it takes.  An entry is 4 bytes for alphabets of up to 2,048 symbols
+ * (the row the step arrives at; its symbol is the largest c with cumulativeCounts[c] < row, found by a search the kernels run in
+ * LDS; the few answers that are more than a row — a status, a quirk — sit in 8-byte slots behind the entries) and 6 bytes beyond
+ * {next row, symbol, status, suspect}; option "window_entry_bytes" = 4 / 6 forces a form (0, the default: by the alphabet).  An LF-step of
  * locate / extract / extractUntilBoundary — inverseSelect (WFBB:1305-1537) of a position, the poll of FM:531, the rank of FM:534 —
  * then costs ONE 64-byte sector, or two, and no walk through the wavelet tree, for EVERY row of the index (the tree's loop over
  * the levels of a code is what a 64-lane wave runs to the deepest code among its positions); count() does not use it.
- * 0.57 + 0.18 x 6 = 1.65 bytes per text byte on log text.  Every number in it is the step the index's own rank() / inverseSelect()
+ * 0.57 + 0.18 x 4 = 1.27 bytes per text byte on log text (1.65 with 6-byte entries).  Every number in it is the step the index's own rank() / inverseSelect()
  * took when the directory was grown: results, statuses and LF-step counts do not depend on having one.  Budget: option
  * "window_cells_mb" (default 65,536) caps it in absolute terms beside the quarter-of-free-memory rule of "window_cells" = 2;
  * fmx_resident_bytes says what an index took.  *bytes = its size (0: none). */
