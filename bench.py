@@ -303,6 +303,9 @@ def compact_line(out):
         st = out["suffix_table"]
         c["suffix_table"] = {"chars": st.get("chars"), "bytes": st.get("bytes"),
                              "ms_per_step_without": (st.get("without_it") or {}).get("ms_per_step")}
+        dp = st.get("one_level_deeper") or {}
+        if dp.get("ms_per_step"):  # [characters, bytes, ms per step] under suffix_table_image_fraction = 2
+            c["suffix_table"]["deeper"] = [dp["chars"], dp["bytes"], dp["ms_per_step"]]
     hb = out.get("host_buffers")
     if hb:
         c["host_buffers"] = _pick(hb, ("ms_per_call", "ms_per_call_registered_buffers", "ratio_to_max_of_floor_and_device_step",
@@ -631,6 +634,44 @@ def run_count(ctx, args):
         finally:
             ia.lib.fmx_set_option(b"suffix_table", 1)
 
+    # ... and with a table one level DEEPER (option suffix_table_image_fraction 2: the table may take half the image's bytes instead
+    # of an eighth — a deployment's choice of bytes against time, like the window directory): the same index made resident once
+    # more under that option, the same K steps, counts checked.  N = 1 only (rank 0 holds the serialized index).
+    deeper_table = None
+    if not ctx.dry and path and world == 1 and not args.profiling:
+        q2 = None
+        try:
+            check_rc(ia, ia.lib.fmx_set_option(b"suffix_table_image_fraction", 2), "fmx_set_option")
+            try:
+                q2 = ia.FmIndex.read(open(path, "rb").read(), device=ctx.local_rank)
+            finally:
+                ia.lib.fmx_set_option(b"suffix_table_image_fraction", 8)
+            chars2, bytes2 = q2.suffix_table_info()
+            if chars2 > table_chars:
+                def step2(b):
+                    check_rc(ia, ia.lib.fmx_count_batch_dev(q2.handle, d_pats[b].data_ptr(), d_off.data_ptr(), n, d_cnt[b].data_ptr(),
+                                                            None, None, sp), "fmx_count_batch_dev")
+                for i in range(max(2, args.warmup)):
+                    step2(i % n_batches)
+                torch.cuda.synchronize()
+                e0, e1 = hip_events(torch)
+                e0.record(stream)
+                for i in range(args.steps):
+                    step2(i % n_batches)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                for b in range(n_batches):
+                    if int(d_cnt[b].sum(dtype=torch.int64).item()) != checksums[b]:
+                        raise RuntimeError("counts differ with the deeper suffix table")
+                deeper_table = {"chars": chars2, "bytes": bytes2, "ms_per_step": e0.elapsed_time(e1) / args.steps,
+                                "option": "suffix_table_image_fraction = 2 (default 8)"}
+        except Exception as e:  # noqa: BLE001 - an extra figure: reported, never fatal
+            log("[bench] deeper-table leg FAILED: %r" % (e,))
+            deeper_table = {"error": repr(e)[:200]}
+        finally:
+            if q2 is not None:
+                q2.close()
+
     # What the plan stage buys NET: the same K steps with the batch counted in the caller's order (no plan
     # stage: k_count maps the characters itself) — the library's policy plans this batch because that is the faster of the two.
     plan_net = None
@@ -929,7 +970,8 @@ def run_count(ctx, args):
             "lf_steps_answered_per_launch": int(table_steps) if bytes_per_step and exec_steps_launch is not None else None,
             "without_it": None if not without_table else {
                 "ms_per_step": without_table["ms_per_step"],
-                "patterns_per_s": n / (without_table["ms_per_step"] * 1e-3)}},
+                "patterns_per_s": n / (without_table["ms_per_step"] * 1e-3)},
+            "one_level_deeper": deeper_table},
         "index_broadcast": getattr(ctx, "broadcast_times", None),
         "setup_s": getattr(ctx, "setup_s", None),
         "segments_block": segments_skipped,
