@@ -154,10 +154,19 @@ void mutate_model(fmx::FmModel &m, Rng &r) {
     }
 }
 
-// every query kind over an accepted image, copied into an exact-size heap block (ASan sees the first byte past it)
-void query_everything(const std::vector<uint8_t> &blob, const std::vector<uint16_t> &text, Rng &r) {
+// every query kind over an accepted image, copied into an exact-size heap block (ASan sees the first byte past it).
+// directory: 0 = the tree walks alone; 4 / 6 = with the window directory grown over the image first, as fmx_to_device does by
+// default (win_build_cell / win_build_other, entries of four or six bytes), so that locate / extract / extractUntilBoundary take
+// their steps from it: a directory made from a damaged tree holds arbitrary rows, and the walks over it must stay inside it.
+void query_everything(const std::vector<uint8_t> &blob, const std::vector<uint16_t> &text, Rng &r, int directory = 0) {
     uint8_t *img = new uint8_t[blob.size()];
     memcpy(img, blob.data(), blob.size());
+    if (directory) {
+        g_where = "growing the window directory";
+        sim_set_entry_bytes(directory);
+        (void)sim_win_attach(img, nullptr);
+        sim_set_entry_bytes(0);
+    }
     BlobHeader h;
     memcpy(&h, img, sizeof h);
     const int n = 24;
@@ -215,6 +224,7 @@ void query_everything(const std::vector<uint8_t> &blob, const std::vector<uint16
                                      st.data(), aux.data(), acc);
             }
     }
+    if (directory) sim_win_detach(img);
     delete[] img;
 }
 
@@ -250,6 +260,8 @@ int main(int argc, char **argv) {
         if (fmx::flatten_model(m, b.blob, err)) return printf("flatten failed: %s\n", err.c_str()), 2;
         if (fmx::validate_blob(b.blob.data(), b.blob.size(), err)) return printf("a fresh image fails validation: %s\n", err.c_str()), 2;
         query_everything(b.blob, b.text, r);  // the undamaged image first
+        query_everything(b.blob, b.text, r, 4);
+        query_everything(b.blob, b.text, r, 6);
         b.model = std::move(m);
         bases.push_back(std::move(b));
     }
@@ -290,6 +302,7 @@ int main(int argc, char **argv) {
                 continue;
             }
             query_everything(blob, base.text, r);
+            query_everything(blob, base.text, r, (g_iter & 1) ? 4 : 6);
         } else {  // door B: a damaged image with a matching checksum
             ++b_runs;
             std::vector<uint8_t> blob = base.blob;
@@ -304,6 +317,7 @@ int main(int argc, char **argv) {
             if (fmx::validate_blob(blob.data(), blob.size(), err)) continue;
             ++images_accepted;
             query_everything(blob, base.text, r);
+            query_everything(blob, base.text, r, (g_iter & 1) ? 4 : 6);
         }
     }
     alarm(0);

@@ -23,7 +23,9 @@ def test_host_code_and_oracle_are_sanitizer_clean(tmp_path):
 def test_damaged_streams_and_images_never_leave_their_tables(tmp_path):
     """tests/cpp/fuzz_load.cpp: mutated index4j streams (bytes of the stream, fields of the model) and mutated images with
     a matching checksum go through the product's validators; whatever is accepted is queried with the DEVICE code compiled
-    for the host under AddressSanitizer (count, locate, extract, extractUntilBoundary x 3 modes x 3 forms) with a watchdog.
+    for the host under AddressSanitizer (count, locate, extract, extractUntilBoundary x 3 modes x 3 forms) with a watchdog —
+    over the tree alone and, as a resident index is queried by default, over the window directory grown from that very image
+    (entries of four and of six bytes: a directory made from a damaged tree holds arbitrary rows).
     An out-of-bounds read or an endless walk here would be a memory fault or a hung wave on the GPU."""
     csrc = os.path.join(ROOT, "index4j_amd", "csrc")
     # the expanded form (default images), and the same campaign over COMPACT images with the record-decoding device code
