@@ -48,6 +48,13 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def env_options(ia):
+    """options FMX_OPTIONS set at import (index4j_amd/_lib.py): what a block that changes one for a while puts back"""
+    import index4j_amd._lib as il
+
+    return getattr(il, "ENV_OPTIONS", {})
+
+
 def kernel_source_sha():
     """digest of the sources that decide what k_count reads and how (stamped into profiles/pmc_latest.json)"""
     h = hashlib.sha256()
@@ -1403,7 +1410,8 @@ def run_secondary(ctx, args, q, ref, orc, text, pat, off):
     # index4j exists for the space / time trade (README.md: the serialized index is 0.44-0.47 of the text,
     # FmIndexSerializedSizeBenchmark.java:57).  Three forms of the resident index, each with its bytes per text byte
     # (fmx_resident_bytes) and the time of configs[2] and configs[3] over it: the compact image (index4j's own RRR compression kept),
-    # the expanded image, and — the default, the rows above — the expanded image with the window directory.  Every form's
+    # the expanded image, — the default, the rows above — the expanded image with the window directory, and that directory in its
+    # FLAT form (a word per position: every step of a walk one sector; option window_cells = 3).  Every form's
     # results are compared with the default form's (which the oracle checked above).
     if not args.profiling:
         try:
@@ -1421,7 +1429,8 @@ def run_secondary(ctx, args, q, ref, orc, text, pat, off):
 
             forms = [{"form": "expanded image + window directory (the default: the rows above)", "configs2_ms": res[-2]["ms"],
                       "configs3_ms": ms3_default, "resident": resident(q), "resident64": resident(fm64)}]
-            for form, compact, cells in (("expanded image, no directory", 0, 0), ("compact image (RRR records), no directory", 1, 0)):
+            for form, compact, cells in (("expanded image + FLAT directory (window_cells 3)", 0, 3), ("expanded image, no directory", 0, 0),
+                                         ("compact image (RRR records), no directory", 1, 0)):
                 check_rc(ia, ia.lib.fmx_set_option(b"image_compact", compact), "fmx_set_option")
                 check_rc(ia, ia.lib.fmx_set_option(b"window_cells", cells), "fmx_set_option")
                 try:
@@ -1429,7 +1438,7 @@ def run_secondary(ctx, args, q, ref, orc, text, pat, off):
                     a64 = ia.FmIndex.read(open(path64, "rb").read(), device=ctx.local_rank)
                 finally:
                     ia.lib.fmx_set_option(b"image_compact", 1 if args.image_compact else 0)
-                    ia.lib.fmx_set_option(b"window_cells", 2)
+                    ia.lib.fmx_set_option(b"window_cells", env_options(ia).get("window_cells", 2))
                 try:
                     d_locs.zero_()
                     locate(a32, False)
@@ -1456,13 +1465,13 @@ def run_secondary(ctx, args, q, ref, orc, text, pat, off):
                 f["resident_bytes_per_text_byte_s64"] = sum(f["resident64"]) / text_bytes        # the sampleRate-64 index (configs[3])
                 f["image_suffix_table_directory_bytes"] = list(f.pop("resident"))
                 f.pop("resident64")
-            res.append({"config": "footprint: resident bytes per text byte of three forms of the index and what each costs configs[2] / [3]",
+            res.append({"config": "footprint: resident bytes per text byte of four forms of the index and what each costs configs[2] / [3]",
                         "ms": None, "forms": forms,
                         "index4j_serialized_bytes_per_text_byte": os.path.getsize(path) / text_bytes,
                         "checked": "every form's located positions and destination rows equal the default form's (oracle-checked above)"})
         except Exception as e:  # noqa: BLE001 - an extra row: its failure is reported on the row
             log("[bench] footprint rows FAILED: %r" % (e,))
-            res.append({"config": "footprint: resident bytes per text byte of three forms of the index", "ms": None, "error": repr(e)[:300]})
+            res.append({"config": "footprint: resident bytes per text byte of four forms of the index", "ms": None, "error": repr(e)[:300]})
     fm64.close()
     # ---- the headline's shape WITHOUT the generator's repetition: 1,048,576 DISTINCT 8-char patterns ----
     # The synthetic log repeats itself (328,091 distinct patterns in the headline batch); equal patterns side by side share

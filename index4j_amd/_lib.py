@@ -134,10 +134,12 @@ def _load():
 lib = _load()
 
 # experiments: FMX_OPTIONS="coarse_bits=10,groups_per_cu=8" applies fmx_set_option at import (tools/, profiling runs)
+ENV_OPTIONS = {}  # what FMX_OPTIONS set (a caller that changes one of these for a while puts THIS value back, not the library's default)
 for _kv in filter(None, os.environ.get("FMX_OPTIONS", "").split(",")):
     _k, _, _v = _kv.partition("=")
     if lib.fmx_set_option(_k.strip().encode(), int(_v)) != 0:
         raise ValueError("FMX_OPTIONS: bad option %r" % _kv)
+    ENV_OPTIONS[_k.strip()] = int(_v)
 
 
 class FmxError(RuntimeError):

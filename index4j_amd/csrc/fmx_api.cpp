@@ -35,6 +35,7 @@
     int launch_suffix_order1(const fmx::DevIndex &, float *, hipStream_t);                                              \
     int launch_win_build(const fmx::DevIndex &, int, uint32_t, fmx::Quad *, uint32_t *, hipStream_t);                   \
     int launch_win_other(const fmx::DevIndex &, int, uint32_t, fmx::Quad *, const uint32_t *, uint16_t *, uint32_t *, int, uint64_t *, uint32_t, hipStream_t); \
+    int launch_win_flat(const fmx::DevIndex &, int, uint32_t, uint32_t *, uint32_t *, uint64_t *, uint32_t, hipStream_t);           \
     int launch_count_plan(const fmx::DevIndex &, int, const uint16_t *, const int32_t *, int32_t, void *, size_t, bool, fmx::CountPlan *, \
                           hipStream_t);                                                                                 \
     int launch_count(const fmx::DevIndex &, int, const uint16_t *, const int32_t *, const fmx::CountPlan *, bool, int32_t, int32_t *, \
@@ -83,6 +84,7 @@ FMX_DISPATCH_FN(launch_suffix_insert)
 FMX_DISPATCH_FN(launch_suffix_order1)
 FMX_DISPATCH_FN(launch_win_build)
 FMX_DISPATCH_FN(launch_win_other)
+FMX_DISPATCH_FN(launch_win_flat)
 FMX_DISPATCH_FN(launch_count_plan)
 FMX_DISPATCH_FN(launch_count)
 FMX_DISPATCH_FN(count_workspace_bytes)
@@ -256,6 +258,7 @@ void make_dev_index(fmx_index *idx) {
     d.win_other = nullptr;
     d.win_full = nullptr;
     d.win_entry4 = 0;
+    d.win_flat = 0;
     d.c_lds = nullptr;
     d.c_lut = nullptr;
     d.c_lut_shift = 0;
@@ -278,6 +281,7 @@ int publish_dev_index(fmx_index *idx) {
     copy.win_other = nullptr;
     copy.win_full = nullptr;
     copy.win_entry4 = 0;
+    copy.win_flat = 0;
     copy.c_lds = nullptr;
     copy.c_lut = nullptr;
     HIP_TRY(hipMemcpy(idx->d_self, &copy, sizeof(copy), hipMemcpyHostToDevice));
@@ -783,8 +787,8 @@ int fmx_set_option(const char *name, int value) {
         g_wavelet_on_device = value != 0;
         return FMX_OK;
     }
-    if (name && !strcmp(name, "window_cells")) {  // window directory of indexes made resident from now on: 0 none, 1 always, 2 if it fits
-        if (value < 0 || value > 2) return fail(FMX_E_ARG, "bad value");
+    if (name && !strcmp(name, "window_cells")) {  // window directory of indexes made resident from now on: 0 none, 1 always, 2 if it fits, 3 the flat form
+        if (value < 0 || value > 3) return fail(FMX_E_ARG, "bad value");
         g_window_cells = value;
         return FMX_OK;
     }
@@ -990,8 +994,41 @@ static void build_window_cells(fmx_index *idx) {
     idx->dev.win_other = nullptr;
     idx->dev.win_full = nullptr;
     idx->dev.win_entry4 = 0;
+    idx->dev.win_flat = 0;
     const int mode = g_window_cells.load();
     if (mode == 0 || idx->rrr_only || idx->wavelet_only || idx->hdr.kind != 0 || idx->hdr.wt_size <= 0 || !idx->dev.self) return;
+    if (mode == 3) {
+        // THE FLAT FORM (fmx_device.hpp win_step): one 32-bit word per position instead of cells and entries — 4 bytes per text
+        // byte, every step of a walk ONE sector.  Asked for by name only; texts of 2^30 characters and more keep the cells.
+        const uint64_t n_pos = (uint64_t)idx->hdr.wt_size;
+        if (n_pos <= 0x3fffffffull) {
+            const size_t flat_bytes = ((size_t)n_pos * 4 + 7) & ~(size_t)7;
+            const uint32_t full_cap = (uint32_t)std::min<uint64_t>(4096 + n_pos / 512, 0x3fffffffu);
+            void *d_flat = nullptr;
+            uint32_t tail[4] = {0, 0, 0, 0};
+            if (hipMalloc(&d_flat, flat_bytes + 16 + (size_t)full_cap * 8) == hipSuccess) {
+                uint8_t *f8 = static_cast<uint8_t *>(d_flat);
+                if (hipMemset(f8 + flat_bytes, 0, 16) == hipSuccess &&
+                    k_launch_win_flat(idx, idx->dev, idx->n_cu, (uint32_t)n_pos, static_cast<uint32_t *>(d_flat),
+                                      reinterpret_cast<uint32_t *>(f8 + flat_bytes), reinterpret_cast<uint64_t *>(f8 + flat_bytes + 16),
+                                      full_cap, nullptr) == 0 &&
+                    hipMemcpy(tail, f8 + flat_bytes, sizeof tail, hipMemcpyDeviceToHost) == hipSuccess && tail[1] == 0) {
+                    idx->win_unclean = tail[0];
+                    idx->d_win = d_flat;
+                    idx->win_bytes = (size_t)n_pos * 4 + (size_t)tail[2] * 8;
+                    idx->dev.win = static_cast<const fmx::Quad *>(d_flat);
+                    idx->dev.win_other = static_cast<const uint16_t *>(d_flat);  // (never read in this form; non-null like win)
+                    idx->dev.win_full = reinterpret_cast<const uint64_t *>(f8 + flat_bytes + 16);
+                    idx->dev.win_entry4 = 1;  // (the kernels that want symbols stage cumulativeCounts for the search, as for four-byte entries)
+                    idx->dev.win_flat = 1;
+                    return;
+                }
+                (void)hipFree(d_flat);
+            }
+            (void)hipGetLastError();
+        }
+        // (does not fit, or an answer that fits nowhere: the cells' form decides)
+    }
     const size_t cells = fmx::win_cells_for((uint32_t)idx->hdr.wt_size);
     const size_t bytes = cells * 64;
     if (mode == 2) {  // cells + (at worst) an entry per position must fit a quarter of what is free, and the absolute budget

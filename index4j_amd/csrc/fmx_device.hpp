@@ -97,6 +97,8 @@ struct DevIndex {
     const uint64_t *win_full;   // four-byte entries: the few answers that are more than a row (a status, `suspect`, a symbol the row does
                                 // not give away), eight bytes each, pointed at by their entries
     int32_t win_entry4;         // 1: four-byte entries
+    int32_t win_flat;           // 1: `win` is not cells but the FLAT form — one 32-bit word per BWT position (win_step): a step of a walk
+                                // is ONE sector for every position, at 4 bytes per text byte (option window_cells = 3)
     const int32_t *c_lds;       // cumulativeCounts staged in LDS by the kernel (nullptr: read C) — win_symbol_of_row
     const uint16_t *c_lut;      // ... and, beside them, where to start looking: kWinLutBuckets + 1 symbols (nullptr: the whole range)
     int32_t c_lut_shift;        // row >> c_lut_shift = the row's bucket
@@ -827,6 +829,55 @@ FMX_HD void win_other_from(const DevIndex &ix, uint64_t entry, int32_t &symbol_o
     win_other_unpack(entry, symbol_out, row_out, status, suspect);
 }
 
+// THE FLAT FORM of the directory (DevIndex.win_flat; option window_cells = 3, never picked by itself): no cells — one 32-bit word
+// per BWT position p: the row the step from row p + 1 arrives at (30 bits: texts below 2^30 characters), bit 30 = the position's bit
+// in sampledSuffixes, bit 31 = "more than a row": the low bits are then the index of an eight-byte slot in win_full, as with the
+// four-byte entries.  A step of a walk is ONE random sector for EVERY position (the cells' form: 1.18 on log text, the second
+// one dependent on the first) at 4 bytes per text byte instead of 1.26: the fast end of the space / time trade.
+constexpr uint32_t kWinFlatEscape = 0x80000000u, kWinFlatSampled = 0x40000000u, kWinFlatRow = 0x3fffffffu;
+FMX_HD uint32_t win_flat_load(const DevIndex &ix, uint32_t p) {
+    uint32_t e = reinterpret_cast<const uint32_t *>(ix.win)[p];
+    FMX_OPAQUE32(e);
+    return e;
+}
+template <bool kSymbol = true>
+FMX_HD void win_flat_from(const DevIndex &ix, uint32_t e, int32_t &symbol_out, int32_t &row_out, bool &sampled_out, int &status,
+                          bool &suspect) {
+    sampled_out = (e & kWinFlatSampled) != 0;
+    if (e & kWinFlatEscape) {
+        win_other_unpack(ix.win_full[e & kWinFlatRow], symbol_out, row_out, status, suspect);
+        return;
+    }
+    row_out = (int32_t)(e & kWinFlatRow);
+    if (kSymbol) symbol_out = win_symbol_of_row(ix, row_out);
+}
+// The step from row p + 1 (p < wt_size) out of the directory, whichever form it has: {symbol, the row it arrives at, the position's
+// bit in sampledSuffixes} and whatever status / `suspect` the step carries.  kSymbol false: the caller does not read symbol_out.
+// kStopAtSampled (locate, FM:531): a sampled position's step is not looked at — true is returned before the second load.
+// kForm: what the caller knows about the directory's form at COMPILE time — kFormAsk = look at ix.win_flat, kFormCells / kFormFlat =
+// that form and no code for the other (the walk kernels of locate / extract are instantiated per form: a body that carries both
+// measured 2.5 % slower over the cells).
+enum : int { kFormAsk = 0, kFormCells = 1, kFormFlat = 2 };
+template <bool kSymbol = true, bool kStopAtSampled = false, int kForm = kFormAsk>
+FMX_HD bool win_step(const DevIndex &ix, uint32_t p, int32_t &symbol_out, int32_t &row_out, bool &sampled_out, int &status,
+                     bool &suspect) {
+    if (kForm == kFormFlat || (kForm == kFormAsk && ix.win_flat)) {
+        const uint32_t e = win_flat_load(ix, p);
+        if (kStopAtSampled && (e & kWinFlatSampled)) {  // (whatever the step carries is not looked at)
+            sampled_out = true;
+            return true;
+        }
+        win_flat_from<kSymbol>(ix, e, symbol_out, row_out, sampled_out, status, suspect);
+        return false;
+    }
+    uint32_t r, other = 0;
+    const WinCell cell = win_load(ix, p, r);
+    const bool answered = win_inv_from(cell, r, symbol_out, row_out, sampled_out, other);
+    if (kStopAtSampled && sampled_out) return true;
+    if (!answered) win_other_from<kSymbol>(ix, win_other_load(ix, other), symbol_out, row_out, status, suspect);
+    return false;
+}
+
 // With the superblock's header at hand (ix.sb_cache, staged in LDS by the kernel) and the mapping rows indexed by
 // the global symbol, the mapping entry and the block header are requested together with the superblock entry:
 //   {superblock entry, mapping entry, block header} -> first cell -> ...
@@ -1326,7 +1377,9 @@ FMX_HD int32_t fm_lf_finish(const DevIndex &ix, const uint16_t *inv, int32_t row
 // the boundary kernels, the host simulation's default), kWinNever = an index without one (the tree walk alone: the kernels'
 // bodies of round 4), kWinAlways = an index with one: window cell / entry and nothing else — no tree walk, no call, none of
 // their registers (k_locate_walk / k_extract are instantiated for kWinNever and kWinAlways and the launcher picks by ix.win).
-enum : int { kWinAsk = 0, kWinNever = 1, kWinAlways = 2 };
+enum : int { kWinAsk = 0, kWinNever = 1, kWinAlways = 2, kWinFlat = 3 };  // (kWinFlat: an index whose directory has the flat form)
+// the directory's form a walk instantiated for kWin may meet
+#define FMX_FORM_OF(KWIN) ((KWIN) == kWinFlat ? kFormFlat : ((KWIN) == kWinAlways ? kFormCells : kFormAsk))
 template <bool kCold = true, int kWin = kWinAsk>
 FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, int32_t &c_out, int &status,
                           bool &suspect) {
@@ -1339,13 +1392,11 @@ FMX_HD int32_t fm_lf_step(const DevIndex &ix, const uint16_t *inv, int32_t row, 
     int32_t rank_before;
     int32_t bsl_i;
     bool exact_symbol;
-    if (kWin == kWinAlways || (kWin == kWinAsk && ix.win)) {
+    if (kWin == kWinAlways || kWin == kWinFlat || (kWin == kWinAsk && ix.win)) {
         // the window of p: {symbol, next row} from one sector, or from the position's entry behind it — no tree walk
-        uint32_t r, other = 0;
-        const WinCell cell = win_load(ix, p, r);
         int32_t wc = 0, next = 0;
         bool sampled;
-        if (!win_inv_from(cell, r, wc, next, sampled, other)) win_other_from(ix, win_other_load(ix, other), wc, next, status, suspect);
+        (void)win_step<true, false, FMX_FORM_OF(kWin)>(ix, p, wc, next, sampled, status, suspect);
         c_out = wc;
         return next;
     }
@@ -1386,12 +1437,26 @@ FMX_HD void fm_lf_step2(const DevIndex &ix, const uint16_t *inv, LfChain &a, LfC
         lb = false;
     }
     if (!la && !lb) return;
-    if (kWin == kWinAlways || (kWin == kWinAsk && ix.win)) {  // the windows of both positions first (one sector each, requested together), then the entries of class-3
+    if (kWin == kWinAlways || kWin == kWinFlat || (kWin == kWinAsk && ix.win)) {  // the windows of both positions first (one sector each, requested together), then the entries of class-3
                    // positions (together as well); a chain they answer is done
-        uint32_t ra = 0, rb = 0, oa = 0, ob = 0;
-        const WinCell wca = win_load(ix, la ? pa : 0u, ra), wcb = win_load(ix, lb ? pb : 0u, rb);
         int32_t wca_c = 0, wcb_c = 0, nexta = 0, nextb = 0;
         bool sampled;
+        if (kWin == kWinFlat || (kWin != kWinAlways && ix.win_flat)) {  // (the flat form: both words requested together)
+            const uint32_t fa = win_flat_load(ix, la ? pa : 0u), fb = win_flat_load(ix, lb ? pb : 0u);
+            if (la) {
+                win_flat_from(ix, fa, wca_c, nexta, sampled, status, suspect);
+                a.c = wca_c;
+                a.row = nexta;
+            }
+            if (lb) {
+                win_flat_from(ix, fb, wcb_c, nextb, sampled, status, suspect);
+                b.c = wcb_c;
+                b.row = nextb;
+            }
+            return;
+        }
+        uint32_t ra = 0, rb = 0, oa = 0, ob = 0;
+        const WinCell wca = win_load(ix, la ? pa : 0u, ra), wcb = win_load(ix, lb ? pb : 0u, rb);
         const bool ha = win_inv_from(wca, ra, wca_c, nexta, sampled, oa), hb = win_inv_from(wcb, rb, wcb_c, nextb, sampled, ob);
         const bool ea = la && !ha, eb = lb && !hb;
         if (ea || eb) {
@@ -1653,6 +1718,36 @@ FMX_HD uint32_t win_build_other(const DevIndex &ix, uint32_t w, uint32_t *cell_w
     return unclean;
 }
 
+// The flat form's word of position p (win_step): the step fm_lf_step takes from row p + 1 over the tree, the position's bit of
+// sampledSuffixes, and — where the answer is more than a row, or the row does not fit 30 bits — an eight-byte slot (full /
+// full_cap / full_count as in win_build_other).  Returns what win_build_other returns: 1 for an unclean step, bit 31 if the
+// answer fits nowhere.
+FMX_HD uint32_t win_build_flat(const DevIndex &ix, uint32_t p, uint32_t *flat, uint64_t *full, uint32_t full_cap, uint32_t *full_count) {
+    int status = ST_OK;
+    bool suspect = false;
+    int32_t c = 0;
+    const int32_t next = fm_lf_step<true, kWinNever>(ix, nullptr, (int32_t)(p + 1u), c, status, suspect);
+    uint32_t unclean = (status != ST_OK || suspect) ? 1u : 0u;
+    if (!win_other_fits(next, c, status)) unclean |= 0x80000000u;
+    uint32_t e = (uint32_t)next;
+    if (status != ST_OK || suspect || next < 0 || (uint32_t)next > kWinFlatRow || win_symbol_of_row(ix, next) != c) {
+        const uint32_t slot = FMX_WIN_TAKE_SLOT(full_count);
+        if (slot < full_cap && slot <= kWinFlatRow)
+            full[slot] = win_other_make(next, c, status, suspect);
+        else
+            unclean |= 0x80000000u;
+        e = kWinFlatEscape | (slot & kWinFlatRow);
+    }
+    RrrView sv = rrr_view_from(Quad{ix.sampled.off_rec, ix.sampled.off_bits, (uint32_t)ix.sampled.length, (uint32_t)ix.sampled.total_ones});
+    bv_bind(sv, ix, nullptr);
+    if ((int32_t)p < sv.length) {
+        int st = ST_OK;
+        if (bv_access(ix.base, sv, (int32_t)p, st) && st == ST_OK) e |= kWinFlatSampled;
+    }
+    flat[p] = e;
+    return unclean;
+}
+
 // IntVector.getValue on the packed `suffixes` / `positions` words (IV:129-143)
 FMX_HD int32_t fm_packed_get(const uint32_t *words, int64_t index, int width) {
     return (int32_t)ld_bits(words, (uint64_t)index * (uint32_t)width, width);
@@ -1761,25 +1856,20 @@ FMX_HD int32_t fm_locate_hit(const DevIndex &ix, const uint16_t *inv, int32_t st
             status = ST_JAVA_AIOOBE;
             break;
         }
-        if (kWin == kWinAlways || (kWin == kWinAsk && ix.win != nullptr)) {
+        if (kWin == kWinAlways || kWin == kWinFlat || (kWin == kWinAsk && ix.win != nullptr)) {
             // the window of p holds the row's sampled bit as well: a step of a walk is ONE sector where the symbol is one of the
             // window's classes, or two (the bitmap's own cell is fetched once, for the rank behind the loop)
             if ((uint32_t)p >= ix.wt_size) {  // (p < the bitmap's length == the tree's size on every image validate_blob lets through)
                 status = ST_JAVA_AIOOBE;
                 break;
             }
-            uint32_t r, other = 0;
-            const WinCell cell = win_load(ix, (uint32_t)p, r);
             int32_t c = 0, next = 0;
-            bool sampled_row;
-            const bool answered = win_inv_from(cell, r, c, next, sampled_row, other);
-            if (sampled_row) {
+            bool sampled_row, suspect = false;
+            if (win_step<false, true, FMX_FORM_OF(kWin)>(ix, (uint32_t)p, c, next, sampled_row, status, suspect)) {  // (locate never reads the symbol)
                 scell = ld_quad(bv_cell_ptr(ix.base, sv, (uint32_t)p));
                 FMX_PIN_QUAD(scell);
                 break;
             }
-            bool suspect = false;
-            if (!answered) win_other_from<false>(ix, win_other_load(ix, other), c, next, status, suspect);  // (locate never reads the symbol)
             j = next;  // (the step fm_lf_step took over the tree when the directory was grown)
         } else {
             // (p < length == the wavelet tree's size: validate_model / validate_blob)
@@ -1829,6 +1919,7 @@ FMX_HD int32_t fm_walk_limit(const DevIndex &ix) {
     const int64_t stretches = (int64_t)ix.sample_rate * 256;
     return (int32_t)(stretches < 4096 ? 4096 : (stretches < (int64_t)ix.length ? stretches : (int64_t)ix.length));
 }
+template <int kForm = kFormAsk>
 FMX_HD bool fm_locate_steps_win(const DevIndex &ix, WalkState &w, int32_t budget, int32_t walk_limit) {
     FMX_NO_UNROLL
     for (int32_t n = 0; n < budget; ++n) {
@@ -1837,14 +1928,9 @@ FMX_HD bool fm_locate_steps_win(const DevIndex &ix, WalkState &w, int32_t budget
             w.status = ST_JAVA_AIOOBE;
             return true;
         }
-        uint32_t r, other = 0;
-        const WinCell cell = win_load(ix, (uint32_t)p, r);
         int32_t c = 0, next = 0;
-        bool sampled_row;
-        const bool answered = win_inv_from(cell, r, c, next, sampled_row, other);
-        if (sampled_row) return true;  // FM:531
-        bool suspect = false;
-        if (!answered) win_other_from<false>(ix, win_other_load(ix, other), c, next, w.status, suspect);  // (locate never reads the symbol)
+        bool sampled_row, suspect = false;
+        if (win_step<false, true, kForm>(ix, (uint32_t)p, c, next, sampled_row, w.status, suspect)) return true;  // FM:531 (locate never reads the symbol)
         w.j = next;  // (the step fm_lf_step took over the tree when the directory was grown)
         if (++w.distance > walk_limit) {  // bounds the walk on a damaged index
             w.status = ST_JAVA_AIOOBE;

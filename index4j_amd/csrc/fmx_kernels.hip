@@ -1046,6 +1046,15 @@ __global__ __launch_bounds__(256) void k_win_other(DevIndex ix, uint32_t n_win, 
         if (open >> 31) atomicOr(open_entries + 1, 1u);  // an answer that does not fit an entry: the caller drops the directory
     }
 }
+// the flat form (fmx_device.hpp win_build_flat): a lane per position
+__global__ __launch_bounds__(256) void k_win_flat(DevIndex ix, uint32_t n_pos, uint32_t *__restrict__ flat, uint32_t *__restrict__ tail,
+                                                  uint64_t *__restrict__ full, uint32_t full_cap) {
+    for (uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x; p < n_pos; p += (uint64_t)gridDim.x * 256) {
+        const uint32_t open = win_build_flat(ix, (uint32_t)p, flat, full, full_cap, tail + 2);
+        if (open & 0x7fffffffu) atomicAdd(tail, open & 0x7fffffffu);
+        if (open >> 31) atomicOr(tail + 1, 1u);
+    }
+}
 static DevIndex win_plain_index(const DevIndex &ix) {
     DevIndex plain = ix;  // the directory is made from the tree walk's own answers
     plain.sb_cache = nullptr;
@@ -1054,6 +1063,7 @@ static DevIndex win_plain_index(const DevIndex &ix) {
     plain.win_other = nullptr;
     plain.win_full = nullptr;
     plain.win_entry4 = 0;
+    plain.win_flat = 0;
     plain.c_lds = nullptr;
     plain.c_lut = nullptr;
     plain.c_lut_shift = 0;
@@ -1074,6 +1084,13 @@ int launch_win_other(const DevIndex &ix, int n_cu, uint32_t n_win, Quad *cells, 
     if (n_win == 0) return 0;
     hipLaunchKernelGGL(k_win_other, dim3(win_blocks(n_cu, n_win)), dim3(256), 0, st, win_plain_index(ix), n_win, cells, first, entries,
                        open_entries, entry4, full, full_cap);
+    return (int)hipGetLastError();
+}
+
+int launch_win_flat(const DevIndex &ix, int n_cu, uint32_t n_pos, uint32_t *flat, uint32_t *tail, uint64_t *full, uint32_t full_cap,
+                    hipStream_t st) {
+    if (n_pos == 0) return 0;
+    hipLaunchKernelGGL(k_win_flat, dim3(win_blocks(n_cu, n_pos)), dim3(256), 0, st, win_plain_index(ix), n_pos, flat, tail, full, full_cap);
     return (int)hipGetLastError();
 }
 
@@ -1158,7 +1175,7 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk(DevIndex ix_global, const int32_t *__
 // on lanes whose walk was over (profiles/r05_experiments.txt 12).  After an instalment every lane still walking writes its state
 // {row, distance, status, where the position goes} to LDS at its rank among them, the workgroup's first lanes take the states
 // over, and the waves behind them fall through the next instalment.  Same tickets, same stores as k_locate_walk.
-template <int kBlock>
+template <int kBlock, int kForm>
 FMX_WALK_KERNEL(kBlock) void k_locate_walk_c(DevIndex ix_global, const int32_t *__restrict__ range, int32_t n,
                                              int32_t max_matches, int32_t *__restrict__ locs, int32_t loc_cap, int32_t slots,
                                              int32_t *__restrict__ found, int32_t *__restrict__ lf_steps,
@@ -1225,7 +1242,7 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk_c(DevIndex ix_global, const int32_t *
             bool walking = hit;
             for (int phase = 0; phase <= packings; ++phase) {
                 const int32_t budget = phase == packings ? 0x7fffffff : (phase == 0 ? first : second);
-                if (walking && fm_locate_steps_win(ix, w, budget, walk_limit)) {
+                if (walking && fm_locate_steps_win<kForm>(ix, w, budget, walk_limit)) {
                     const int32_t at = fm_locate_finish_win(ix, s_inv, w);
                     if (set_locs)
                         set_locs[dest] = set_base + at;
@@ -1274,7 +1291,7 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk_c(DevIndex ix_global, const int32_t *
 // walk is over take the next hit of their ticket, or the next tickets of the run (a ballot and a prefix count: no LDS, no
 // barrier), and walk on beside the lanes still under way.  A lane idles for half a burst per walk instead of half a walk.
 // Same tickets, same stores as k_locate_walk: which lane walks which hit is free (results go to the hit's own slot).
-template <int kBlock>
+template <int kBlock, int kForm>
 FMX_WALK_KERNEL(kBlock) void k_locate_walk_q(DevIndex ix, const int32_t *__restrict__ range, int32_t n, int32_t max_matches,
                                              int32_t *__restrict__ locs, int32_t loc_cap, int32_t slots,
                                              int32_t *__restrict__ found, int32_t *__restrict__ lf_steps,
@@ -1356,7 +1373,7 @@ FMX_WALK_KERNEL(kBlock) void k_locate_walk_q(DevIndex ix, const int32_t *__restr
                 if (next >= run_end) break;
                 continue;
             }
-            if (walking && fm_locate_steps_win(ix, w, burst, walk_limit)) {
+            if (walking && fm_locate_steps_win<kForm>(ix, w, burst, walk_limit)) {
                 const int32_t at = fm_locate_finish_win(ix, s_inv, w);
                 const int64_t dest = (int64_t)p * loc_cap + (set_locs ? taken_p : 0) + k;
                 if (set_locs)
@@ -2438,13 +2455,38 @@ static int grid_for(int64_t lanes, int block, int n_cu) {
             hipLaunchKernelGGL(KERNEL<512>, grid__, dim3(512), (size_t)g_lds_pad_kb * 1024, st, __VA_ARGS__);                          \
     } while (0)
 
-// ... of a walk kernel instantiated for indexes with a window directory and without one (fmx_device.hpp: kWinAlways / kWinNever)
+// ... of a kernel that only runs over a window directory, instantiated per form of it (fmx_device.hpp: kFormCells / kFormFlat)
+#define FMX_DISPATCH_FORM(KERNEL, IX, LANES, ...)                                                                      \
+    do {                                                                                                               \
+        const int blk__ = g_block;                                                                                     \
+        const dim3 grid__(grid_for((LANES), blk__, n_cu));                                                             \
+        const size_t lds__ = (size_t)g_lds_pad_kb * 1024;                                                              \
+        if ((IX).win_flat) {                                                                                           \
+            if (blk__ == 1024)                                                                                         \
+                hipLaunchKernelGGL((KERNEL<1024, kFormFlat>), grid__, dim3(1024), lds__, st, __VA_ARGS__);            \
+            else                                                                                                       \
+                hipLaunchKernelGGL((KERNEL<512, kFormFlat>), grid__, dim3(512), lds__, st, __VA_ARGS__);              \
+        } else {                                                                                                       \
+            if (blk__ == 1024)                                                                                         \
+                hipLaunchKernelGGL((KERNEL<1024, kFormCells>), grid__, dim3(1024), lds__, st, __VA_ARGS__);           \
+            else                                                                                                       \
+                hipLaunchKernelGGL((KERNEL<512, kFormCells>), grid__, dim3(512), lds__, st, __VA_ARGS__);             \
+        }                                                                                                              \
+    } while (0)
+
+// ... of a walk kernel instantiated for indexes with a window directory (in either form) and without one (fmx_device.hpp: kWinAlways /
+// kWinFlat / kWinNever)
 #define FMX_DISPATCH_WIN(KERNEL, IX, LANES, ...)                                                                       \
     do {                                                                                                               \
         const int blk__ = g_block;                                                                                     \
         const dim3 grid__(grid_for((LANES), blk__, n_cu));                                                             \
         const size_t lds__ = (size_t)g_lds_pad_kb * 1024;                                                              \
-        if ((IX).win) {                                                                                                \
+        if ((IX).win && (IX).win_flat) {                                                                               \
+            if (blk__ == 1024)                                                                                         \
+                hipLaunchKernelGGL((KERNEL<1024, kWinFlat>), grid__, dim3(1024), lds__, st, __VA_ARGS__);             \
+            else                                                                                                       \
+                hipLaunchKernelGGL((KERNEL<512, kWinFlat>), grid__, dim3(512), lds__, st, __VA_ARGS__);               \
+        } else if ((IX).win) {                                                                                         \
             if (blk__ == 1024)                                                                                         \
                 hipLaunchKernelGGL((KERNEL<1024, kWinAlways>), grid__, dim3(1024), lds__, st, __VA_ARGS__);           \
             else                                                                                                       \
@@ -2756,13 +2798,13 @@ int launch_locate_walk(const DevIndex &ix, int n_cu, const int32_t *range, int32
         int32_t burst = g_walk_burst.load();
         if (burst <= 0) burst = ix.sample_rate / 4 > 2 ? ix.sample_rate / 4 : 2;
         (void)waves;
-        FMX_DISPATCH(k_locate_walk_q, (tickets + per - 1) / per, ix, range, n, max_matches, locs, loc_cap, slots, found, lf, status, taken, order,
+        FMX_DISPATCH_FORM(k_locate_walk_q, ix, (tickets + per - 1) / per, ix, range, n, max_matches, locs, loc_cap, slots, found, lf, status, taken, order,
                      order_idle, set_locs, set_base, chunk, burst);
         return (int)hipGetLastError();
     }
     if (ix.win && g_walk_pack.load() && ix.sample_rate >= 8) {  // a window directory: the packed form (k_locate_walk_c)
         const int packings = g_walk_pack.load() >= 3 ? 3 : 2;
-        FMX_DISPATCH(k_locate_walk_c, tickets, ix, range, n, max_matches, locs, loc_cap, slots, found, lf, status, taken, order, order_idle,
+        FMX_DISPATCH_FORM(k_locate_walk_c, ix, tickets, ix, range, n, max_matches, locs, loc_cap, slots, found, lf, status, taken, order, order_idle,
                      set_locs, set_base, packings);
         return (int)hipGetLastError();
     }

@@ -155,8 +155,8 @@ void mutate_model(fmx::FmModel &m, Rng &r) {
 }
 
 // every query kind over an accepted image, copied into an exact-size heap block (ASan sees the first byte past it).
-// directory: 0 = the tree walks alone; 4 / 6 = with the window directory grown over the image first, as fmx_to_device does by
-// default (win_build_cell / win_build_other, entries of four or six bytes), so that locate / extract / extractUntilBoundary take
+// directory: 0 = the tree walks alone; 4 / 6 / -1 = with the window directory grown over the image first, as fmx_to_device does by
+// default (win_build_cell / win_build_other, entries of four or six bytes; -1: the flat form, win_build_flat), so that locate / extract / extractUntilBoundary take
 // their steps from it: a directory made from a damaged tree holds arbitrary rows, and the walks over it must stay inside it.
 void query_everything(const std::vector<uint8_t> &blob, const std::vector<uint16_t> &text, Rng &r, int directory = 0) {
     uint8_t *img = new uint8_t[blob.size()];
@@ -262,6 +262,7 @@ int main(int argc, char **argv) {
         query_everything(b.blob, b.text, r);  // the undamaged image first
         query_everything(b.blob, b.text, r, 4);
         query_everything(b.blob, b.text, r, 6);
+        query_everything(b.blob, b.text, r, -1);
         b.model = std::move(m);
         bases.push_back(std::move(b));
     }
@@ -302,7 +303,7 @@ int main(int argc, char **argv) {
                 continue;
             }
             query_everything(blob, base.text, r);
-            query_everything(blob, base.text, r, (g_iter & 1) ? 4 : 6);
+            query_everything(blob, base.text, r, g_iter % 3 == 0 ? 4 : (g_iter % 3 == 1 ? 6 : -1));
         } else {  // door B: a damaged image with a matching checksum
             ++b_runs;
             std::vector<uint8_t> blob = base.blob;
@@ -317,7 +318,7 @@ int main(int argc, char **argv) {
             if (fmx::validate_blob(blob.data(), blob.size(), err)) continue;
             ++images_accepted;
             query_everything(blob, base.text, r);
-            query_everything(blob, base.text, r, (g_iter & 1) ? 4 : 6);
+            query_everything(blob, base.text, r, g_iter % 3 == 0 ? 4 : (g_iter % 3 == 1 ? 6 : -1));
         }
     }
     alarm(0);

@@ -20,6 +20,7 @@ static std::map<const uint8_t *, std::vector<uint16_t>> g_window_entries;
 static std::map<const uint8_t *, uint64_t> g_window_unclean;
 static std::map<const uint8_t *, std::vector<uint64_t>> g_window_full;  // four-byte entries: the answers that are more than a row
 static std::map<const uint8_t *, int> g_window_entry4;
+static std::map<const uint8_t *, int> g_window_flat;  // the directory of this blob is the flat form (sim_set_entry_bytes(-1))
 static std::map<const uint8_t *, std::vector<uint16_t>> g_window_lut;  // ... and where a symbol search starts (the kernels make it in LDS)
 static int g_entry_bytes = 0;  // sim_set_entry_bytes: 0 = by the alphabet (as fmx_to_device), 4, 6
 static int g_pack = 1;  // locate over a window directory: the instalment form (k_locate_walk_c) or fm_locate_hit<kWinAlways> (option walk_pack 0)
@@ -62,6 +63,8 @@ static DevIndex make_index(const uint8_t *b) {
         d.win_full = f == g_window_full.end() ? nullptr : f->second.data();
         auto k = g_window_entry4.find(b);
         d.win_entry4 = k == g_window_entry4.end() ? 0 : k->second;
+        auto fl = g_window_flat.find(b);
+        d.win_flat = fl == g_window_flat.end() ? 0 : fl->second;
         d.c_lds = nullptr;
         auto l = g_window_lut.find(b);
         d.c_lut = l == g_window_lut.end() ? nullptr : l->second.data();
@@ -87,7 +90,36 @@ int64_t sim_win_attach(const uint8_t *blob, int64_t *stats) {
     g_window_full.erase(blob);
     g_window_entry4.erase(blob);
     g_window_lut.erase(blob);
+    g_window_flat.erase(blob);
     DevIndex ix = make_index(blob);  // (no directory: it is made from the tree walk's own answers)
+    if (g_entry_bytes == -1) {  // the flat form (fmx_to_device under window_cells = 3): a word per position, win_build_flat
+        std::vector<uint32_t> flat((size_t)ix.wt_size + 4);
+        std::vector<uint64_t> full((size_t)ix.wt_size + 1);
+        uint32_t full_count = 0;
+        uint64_t open_entries = 0;
+        for (uint32_t p = 0; p < ix.wt_size; ++p)
+            open_entries += win_build_flat(ix, p, flat.data(), full.data(), (uint32_t)full.size(), &full_count) & 0x7fffffffu;
+        g_window_unclean[blob] = open_entries;
+        if (stats) {
+            stats[0] = stats[2] = 0;
+            stats[1] = stats[3] = (int64_t)ix.wt_size;
+            stats[4] = (int64_t)open_entries;
+            stats[5] = (int64_t)full_count;
+        }
+        std::vector<uint16_t> lut(kWinLutBuckets + 2);
+        const int32_t shift = win_lut_shift(ix.length);
+        for (int32_t b = 0; b <= kWinLutBuckets; ++b) {
+            const int64_t row = (int64_t)b << shift;
+            lut[(size_t)b] = (uint16_t)win_symbol_of_row(ix, row > 0x7fffffff ? 0x7fffffff : (int32_t)row);
+        }
+        g_windows[blob] = std::move(flat);
+        g_window_entries[blob] = std::vector<uint16_t>(4);
+        g_window_full[blob] = std::move(full);
+        g_window_entry4[blob] = 1;
+        g_window_flat[blob] = 1;
+        g_window_lut[blob] = std::move(lut);
+        return (int64_t)ix.wt_size;
+    }
     const size_t cells = win_cells_for(ix.wt_size);
     std::vector<uint32_t> words(cells * 16 + 4), first(cells + 1);
     uint64_t total = 0;
@@ -150,6 +182,7 @@ void sim_win_detach(const uint8_t *blob) {
     g_window_full.erase(blob);
     g_window_entry4.erase(blob);
     g_window_lut.erase(blob);
+    g_window_flat.erase(blob);
 }
 
 int32_t sim_wt_rank(const uint8_t *blob, uint32_t position, int32_t symbol, int32_t *status) {
@@ -330,14 +363,18 @@ void sim_locate_walk(const uint8_t *blob, const int32_t *range, int32_t n, int32
                 // sample_rate / 4 steps and the rest, as the kernel takes them between its packings)
                 WalkState w = {start + 1 + k, 0, ST_OK};
                 const int32_t limit = fm_walk_limit(ix);
-                if (!fm_locate_steps_win(ix, w, ix.sample_rate / 2, limit) && !fm_locate_steps_win(ix, w, ix.sample_rate / 4, limit))
-                    (void)fm_locate_steps_win(ix, w, 0x7fffffff, limit);
+                // (the kernel's instantiation for the directory's form: FMX_DISPATCH_FORM)
+                auto steps = [&](int32_t budget) {
+                    return ix.win_flat ? fm_locate_steps_win<kFormFlat>(ix, w, budget, limit) : fm_locate_steps_win<kFormCells>(ix, w, budget, limit);
+                };
+                if (!steps(ix.sample_rate / 2) && !steps(ix.sample_rate / 4)) (void)steps(0x7fffffff);
                 locs[(int64_t)p * loc_cap + k] = fm_locate_finish_win(ix, ix.inv_global, w);
                 distance = w.distance;
                 status = w.status;
             } else
-            locs[(int64_t)p * loc_cap + k] = ix.win ? fm_locate_hit<kWinAlways>(ix, ix.inv_global, start, k, distance, status)  // (as launch_locate_walk picks)
-                                                    : fm_locate_hit<kWinNever>(ix, ix.inv_global, start, k, distance, status);
+            locs[(int64_t)p * loc_cap + k] = ix.win_flat ? fm_locate_hit<kWinFlat>(ix, ix.inv_global, start, k, distance, status)  // (as launch_locate_walk picks)
+                                             : ix.win    ? fm_locate_hit<kWinAlways>(ix, ix.inv_global, start, k, distance, status)
+                                                         : fm_locate_hit<kWinNever>(ix, ix.inv_global, start, k, distance, status);
             if (lf) lf[p] += distance;
             if (status && status_out) status_out[p] |= status;
         }
@@ -350,8 +387,9 @@ void sim_extract(const uint8_t *blob, const int32_t *starts, const int32_t *stop
         int status = ST_OK;
         int32_t steps;
         uint16_t *row = dst + (int64_t)q * dst_len;
-        const int32_t ret = ix.win ? fm_extract<kWinAlways>(ix, ix.inv_global, starts[q], stops[q], row, dst_len, offset, steps, status)  // (as launch_extract picks)
-                                   : fm_extract<kWinNever>(ix, ix.inv_global, starts[q], stops[q], row, dst_len, offset, steps, status);
+        const int32_t ret = ix.win_flat ? fm_extract<kWinFlat>(ix, ix.inv_global, starts[q], stops[q], row, dst_len, offset, steps, status)  // (as launch_extract picks)
+                            : ix.win    ? fm_extract<kWinAlways>(ix, ix.inv_global, starts[q], stops[q], row, dst_len, offset, steps, status)
+                                        : fm_extract<kWinNever>(ix, ix.inv_global, starts[q], stops[q], row, dst_len, offset, steps, status);
         out_len[q] = status ? 0 : ret;
         if (lf) lf[q] = steps;
         if (status_out) status_out[q] = status;
@@ -371,7 +409,11 @@ void sim_extract_boundary(const uint8_t *blob, const int32_t *froms, int32_t n, 
         if (accelerate >= 2) {  // group-cooperative form with a group of one lane (3: the lane's two first walks interleaved)
             bool clean;
             // (over a complete window directory: the instantiation without tree-walk code, as launch_extract_boundary picks)
-            ret = ix.win  // (the instantiation without the tree walk: not what the kernel runs, kept covered)
+            ret = ix.win_flat
+                      ? fm_extract_boundary_group<1, -1, kWinFlat>(ix, ix.inv_global, mode, froms[q], mapped_boundary, dst + (int64_t)q * dst_len,
+                                                                   dst_len, offset, steps, status, aux, scratch, 1, 1, ix.sample_rate + 1, 0,
+                                                                   clean, accelerate == 3)
+                  : ix.win  // (the instantiation without the tree walk: not what the kernel runs, kept covered)
                       ? fm_extract_boundary_group<1, -1, kWinAlways>(ix, ix.inv_global, mode, froms[q], mapped_boundary, dst + (int64_t)q * dst_len,
                                                                      dst_len, offset, steps, status, aux, scratch, 1, 1, ix.sample_rate + 1, 0,
                                                                      clean, accelerate == 3)

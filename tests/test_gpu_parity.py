@@ -1051,13 +1051,14 @@ def _window_bytes(f):
     return n.value
 
 
-@pytest.mark.parametrize("mode,entry_bytes", [(0, 0), (1, 0), (1, 4), (1, 6)])
+@pytest.mark.parametrize("mode,entry_bytes", [(0, 0), (1, 0), (1, 4), (1, 6), (3, 0)])
 def test_window_directory_changes_nothing_but_the_time(mode, entry_bytes):
     """option window_cells: every query kind vs the oracle with the directory grown (1) and without one (0) — on the fixture,
     on texts with sentinels, run blocks of wide symbols (Q1: never a directory entry) and a 900-symbol alphabet, on a compact
     image — and fmx_window_cells_info says which of the two an index got.  entry_bytes (option window_entry_bytes): the directory's
     entries in the form picked by the alphabet (0: four bytes — the row, its symbol found by a search over cumulativeCounts — up
-    to 2,048 symbols, six beyond: the fixture has 2,061), all in four, all in six"""
+    to 2,048 symbols, six beyond: the fixture has 2,061), all in four, all in six.  mode 3: the FLAT form of the directory (a word
+    per position, 4 bytes per text byte: every step of a walk one sector)"""
     rng = np.random.default_rng(9)
     parts = []
     for i in range(6):
@@ -1073,9 +1074,10 @@ def test_window_directory_changes_nothing_but_the_time(mode, entry_bytes):
         assert ia.lib.fmx_set_option(b"window_cells", mode) == 0
         assert ia.lib.fmx_set_option(b"window_entry_bytes", entry_bytes) == 0
         f = ia.FmIndex(HD[:20_000], 8, True, device=0)
-        assert (_window_bytes(f) > 0) == (mode == 1)
-        # 64 bytes per 112 positions + 6 (4) per position none of its window's three classes holds
-        assert mode == 0 or 64 * (20_001 // 112) <= _window_bytes(f) <= 64 * (20_001 // 112 + 2) + 6 * 20_001
+        assert (_window_bytes(f) > 0) == (mode != 0)
+        # 64 bytes per 112 positions + 6 (4) per position none of its window's three classes holds; the flat form: 4 per position
+        assert mode != 1 or 64 * (20_001 // 112) <= _window_bytes(f) <= 64 * (20_001 // 112 + 2) + 6 * 20_001
+        assert mode != 3 or 4 * 20_001 <= _window_bytes(f) <= 4 * 20_001 + 8 * 200
         if mode == 1 and entry_bytes:
             other = {4: 6, 6: 4}[entry_bytes]
             assert ia.lib.fmx_set_option(b"window_entry_bytes", other) == 0

@@ -26,7 +26,7 @@ def make_sim_windows(text, sr):
     h = hostsim.HostSim(ia.FmIndex(text, sr, True, device=None))
     got, positions, classes, by_entry, unclean = h.attach_windows(ENTRY_BYTES[0])
     assert got + by_entry == positions  # every position's step is in the directory
-    assert (h.window_slots >= 0) == (ENTRY_BYTES[0] == 4 or (ENTRY_BYTES[0] == 0 and h.fm.getAlphabetLength() + 2 <= 2050))
+    assert (h.window_slots >= 0) == (ENTRY_BYTES[0] in (4, -1) or (ENTRY_BYTES[0] == 0 and h.fm.getAlphabetLength() + 2 <= 2050))
     # four-byte entries: an entry points at an eight-byte slot at least where its step carries a status or `suspect`
     assert h.window_slots < 0 or unclean <= h.window_slots <= by_entry
     COVER[(len(text), sr)] = got / max(1, positions)
@@ -37,9 +37,10 @@ def make_sim_windows(text, sr):
 SLOTS = {}
 
 
-@pytest.fixture(params=[4, 6])
+@pytest.fixture(params=[4, 6, -1])
 def entry_bytes(request):
-    """both forms of the directory's entries, whatever the alphabet (option window_entry_bytes of the library)"""
+    """both forms of the directory's entries, whatever the alphabet (option window_entry_bytes of the library), and the FLAT form
+    of the directory (-1: a word per position instead of cells and entries, option window_cells = 3)"""
     ENTRY_BYTES[0] = request.param
     yield request.param
     ENTRY_BYTES[0] = 0
