@@ -317,6 +317,9 @@ def compact_line(out):
     if hb:
         c["host_buffers"] = _pick(hb, ("ms_per_call", "ms_per_call_registered_buffers", "ratio_to_max_of_floor_and_device_step",
                                        "ratio_registered_to_max_of_floor_and_device_step", "pcie_floor_ms_in", "stat"))
+        sc = hb.get("scalar_call_us") or {}
+        if sc.get("count"):  # microseconds per call of ONE query: count, locate (16 slots), extract (64 characters)
+            c["host_buffers"]["scalar_us"] = _sig([sc["count"], sc.get("locate16"), sc.get("extract64")], 3)
     if out.get("index_broadcast"):
         c["index_broadcast"] = _pick(out["index_broadcast"], ("broadcast_s", "fan_out_s", "kept", "bytes"))
     if out.get("plan_net"):
@@ -1244,6 +1247,33 @@ def measure_host_buffers(ctx, args, q, pat, off, expect, step_ms):
     finally:
         for a in regs:
             ia.lib.fmx_host_unregister(a.ctypes.data)
+    # what ONE query costs through the host entry points — a Java caller's count(char[]) / locate / extract is a batch of one:
+    # microseconds per call (through one mapped pinned block: no copy calls; index4j's own count() of 8 characters is ~14 us on a core)
+    scalar = None
+    try:
+        one_pat, one_off = pat[: off[1]].copy(), off[:2].copy()
+        c1, s1 = np.zeros(1, np.int32), np.zeros(1, np.int32)
+        l1, f1 = np.zeros(16, np.int32), np.zeros(1, np.int32)
+        a1, b1 = np.array([1000], np.int32), np.array([1064], np.int32)
+        d1, n1 = np.zeros(64, np.uint16), np.zeros(1, np.int32)
+        calls = {
+            "count": lambda: ia.lib.fmx_count_batch(q.handle, one_pat.ctypes.data, one_off.ctypes.data, 1, c1.ctypes.data, None, s1.ctypes.data),
+            "locate16": lambda: ia.lib.fmx_locate_batch(q.handle, one_pat.ctypes.data, one_off.ctypes.data, 1, 16, l1.ctypes.data, 16,
+                                                        f1.ctypes.data, None, s1.ctypes.data),
+            "extract64": lambda: ia.lib.fmx_extract_batch(q.handle, a1.ctypes.data, b1.ctypes.data, 1, d1.ctypes.data, 64, 0, n1.ctypes.data,
+                                                          None, s1.ctypes.data)}
+        scalar = {}
+        for name, f in calls.items():
+            for _ in range(20):
+                check_rc(ia, f(), name)
+            t0 = time.perf_counter()
+            for _ in range(200):
+                f()
+            scalar[name] = (time.perf_counter() - t0) / 200 * 1e6
+        if int(c1[0]) != int(expect[0]):
+            raise RuntimeError("the scalar count differs from the batch's first count")
+    except Exception as e:  # noqa: BLE001 - an extra figure
+        scalar = {"error": repr(e)[:200]}
     # PCIe rates of this box: pinned copies of 64 MiB, each direction
     hp = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
     dd = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
@@ -1270,6 +1300,7 @@ def measure_host_buffers(ctx, args, q, pat, off, expect, step_ms):
                        min(registered_all)),
             "ms_per_call_all": [round(x, 3) for x in piped_all], "ms_per_call_registered_buffers_all": [round(x, 3) for x in registered_all],
             "ms_per_call_median": float(np.median(piped_all)), "ms_per_call_registered_buffers_median": float(np.median(registered_all)),
+            "scalar_call_us": scalar,
             "patterns": n, "ms_per_call": piped, "patterns_per_s": n / piped * 1e3,
             "ms_per_call_unpipelined": plain, "ms_per_call_registered_buffers": registered,
             "ratio_registered_to_max_of_floor_and_device_step": registered / floor,

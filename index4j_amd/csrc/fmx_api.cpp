@@ -173,6 +173,7 @@ std::atomic<int> g_window_cells_mb{65536};
 // those fit LDS (fmx::kWinSymbolSearchMax), six bytes otherwise; 4 / 6 = that form whatever the alphabet (tests, A/B)
 std::atomic<int> g_window_entry_bytes{0};
 // host-buffer count(): batches of at least this many patterns go through the pipeline (smaller ones: one copy in, kernels, one copy out)
+std::atomic<int> g_host_small_max{2048};  // option "host_small_max": host-array calls of at most this many patterns / queries go through one mapped pinned block (0: off)
 std::atomic<int> g_host_pipeline_min{131072};
 std::atomic<int> g_host_mapped{1};  // option "host_mapped": every array of a host-buffer count registered -> one launch over the mapped arrays, no copies
 std::atomic<int> g_host_direct_stores{1};  // option "host_direct_stores": the pipeline's kernels store results straight into registered arrays
@@ -470,6 +471,37 @@ struct PinBuf {
     }
 };
 
+constexpr size_t kHostSmallBytes = 1 << 20;  // ... and at most this much in one block (rows of extract / locate included)
+// the one pinned block of a small call: pieces handed out 16-byte aligned, each with the address the device sees it at
+struct SmallBlock {
+    PinBuf buf;
+    uint8_t *h = nullptr, *d = nullptr;
+    size_t used = 0;
+    static size_t up(size_t v) { return (v + 15) & ~(size_t)15; }
+    // FMX_OK; -1 = pinned memory is not mapped here (the caller takes the copying path); < -1 = a HIP failure
+    int init(size_t total) {
+        if (buf.alloc(total + 16) != hipSuccess) {
+            (void)hipGetLastError();
+            return -1;
+        }
+        h = buf.as<uint8_t>();
+        void *dv = nullptr;
+        if (hipHostGetDevicePointer(&dv, h, 0) != hipSuccess || !dv) {
+            (void)hipGetLastError();
+            return -1;
+        }
+        d = static_cast<uint8_t *>(dv);
+        return FMX_OK;
+    }
+    template <typename T>
+    T *take(size_t count, T **device) {
+        T *host = reinterpret_cast<T *>(h + used);
+        *device = reinterpret_cast<T *>(d + used);
+        used += up(count * sizeof(T));
+        return host;
+    }
+};
+
 // Staging of PAGEABLE caller arrays (what a JVM heap array behind GetPrimitiveArrayCritical is): a plain hipMemcpy from pageable
 // memory is staged by the runtime on the calling thread at a fraction of the link's rate (1 M x 8 chars: 1.0 ms per call against a
 // PCIe floor of 0.34).  Here the bytes go through pinned staging of the library's own, copied by a few host threads side by side —
@@ -751,6 +783,11 @@ int fmx_set_option(const char *name, int value) {
     if (name && !strcmp(name, "host_pipeline_min")) {  // host-buffer count(): batches at least this large are pipelined (0 = never)
         if (value < 0) return fail(FMX_E_ARG, "bad value");
         g_host_pipeline_min = value;
+        return FMX_OK;
+    }
+    if (name && !strcmp(name, "host_small_max")) {  // batches of at most this many patterns go through one mapped pinned block (0: off)
+        if (value < 0) return fail(FMX_E_ARG, "bad value");
+        g_host_small_max = value;
         return FMX_OK;
     }
     if (name && !strcmp(name, "host_stage_threads")) {  // host threads staging a pageable array into pinned memory (0 / 1: the runtime's own staging)
@@ -2544,6 +2581,48 @@ static int count_batch_pipelined(const fmx_index *idx, const uint16_t *pat, cons
     return FMX_OK;
 }
 
+// fmx_count_batch for SMALL batches — a Java caller's count(char[]) is a batch of one, and what it costs is not the search but the
+// calls around it: five blocking copies and a launch (91 us per call for one 8-character pattern; index4j's own count() takes 14 us
+// on a host core).  Here everything a small call moves goes through ONE pinned block the kernels read and write where it lies (it
+// is mapped into the device's address space: a few hundred bytes over the link, no copy call at all): memcpy in, one launch
+// sequence, one wait, memcpy out.  option "host_small_max" (patterns; 0 = off).
+constexpr size_t kHostSmallChars = 65536;
+static int count_batch_small(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n, int32_t *counts,
+                             int32_t *lf_steps, int32_t *status) {
+    const int64_t first = first_char(pat_off);
+    const size_t chars = (size_t)(pat_off[n] > first ? pat_off[n] - first : 0);
+    // [characters | offsets (rebased to the block's characters) | counts | LF-steps | statuses], each 16-byte aligned
+    auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_off = up(chars * 2 + 8), o_cnt = o_off + up(((size_t)n + 1) * 4), o_lf = o_cnt + up((size_t)n * 4),
+                 o_st = o_lf + up((size_t)n * 4), total = o_st + up((size_t)n * 4);
+    PinBuf block;
+    HIP_TRY(block.alloc(total));
+    uint8_t *h = block.as<uint8_t>();
+    void *dv = nullptr;
+    if (hipHostGetDevicePointer(&dv, h, 0) != hipSuccess || !dv) {
+        (void)hipGetLastError();
+        return -1;  // (not mapped on this platform: the caller takes the copying path)
+    }
+    uint8_t *d = static_cast<uint8_t *>(dv);
+    if (chars) memcpy(h, pat + first, chars * 2);
+    int32_t *h_off = reinterpret_cast<int32_t *>(h + o_off);
+    for (int32_t i = 0; i <= n; ++i) h_off[i] = (int32_t)(pat_off[i] - first);
+    HostCallStream hs;
+    int rc = hs.init(idx->device);
+    if (rc) return rc;
+    Scratch scratch(idx, hs.s, true);
+    HostCallStream wait_first;  // (destroyed before the scratch above and the block: the stream is drained, then they go back)
+    wait_first.s = hs.s;
+    rc = count_impl(idx, reinterpret_cast<const uint16_t *>(d), reinterpret_cast<const int32_t *>(d + o_off), n,
+                    reinterpret_cast<int32_t *>(d + o_cnt), reinterpret_cast<int32_t *>(d + o_lf), reinterpret_cast<int32_t *>(d + o_st), scratch);
+    HIP_TRY(hipStreamSynchronize(hs.s));
+    if (rc) return rc;
+    memcpy(counts, h + o_cnt, (size_t)n * 4);
+    if (lf_steps) memcpy(lf_steps, h + o_lf, (size_t)n * 4);
+    if (status) memcpy(status, h + o_st, (size_t)n * 4);
+    return FMX_OK;
+}
+
 int fmx_count_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n, int32_t *counts,
                     int32_t *lf_steps, int32_t *status) {
     static const bool timing = getenv("FMX_PIPE_TIMING") != nullptr;
@@ -2574,6 +2653,10 @@ int fmx_count_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pa
     rc = check_offsets(pat_off, n);
     if (rc) return rc;
     const size_t chars = (size_t)(pat_off[n] > 0 ? pat_off[n] : 0);
+    if (n <= g_host_small_max.load() && chars - (size_t)first_char(pat_off) <= kHostSmallChars) {
+        const int r = count_batch_small(idx, pat, pat_off, n, counts, lf_steps, status);
+        if (r != -1) return r;
+    }
     DevBuf d_pat, d_off, d_cnt, d_lf, d_st;
     HIP_TRY(d_pat.alloc(chars * 2 + 8));
     HIP_TRY(d_off.alloc((size_t)(n + 1) * 4));
@@ -2612,6 +2695,54 @@ int fmx_locate_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *p
     if (rc) return rc;
     const size_t chars = (size_t)(pat_off[n] > 0 ? pat_off[n] : 0);
     const size_t loc_bytes = (size_t)n * (size_t)loc_cap * 4;
+    // a small call (a Java caller's locate(char[], ...) is a batch of one): characters, offsets and the in / out `locations` rows in
+    // ONE mapped pinned block the kernels read and write where it lies; found / LF-steps / statuses — updated with atomics — stay
+    // in HBM and come down by three asynchronous copies into the block; one wait (count_batch_small has the story)
+    if (n <= g_host_small_max.load() && chars - first_char(pat_off) <= kHostSmallChars && loc_bytes <= kHostSmallBytes) {
+        const size_t first = first_char(pat_off), own = chars - first;
+        SmallBlock blk;
+        if (blk.init(SmallBlock::up(own * 2 + 8) + SmallBlock::up(((size_t)n + 1) * 4) + SmallBlock::up(loc_bytes) + 3 * SmallBlock::up((size_t)n * 4)) ==
+            FMX_OK) {
+            uint16_t *dp;
+            int32_t *doff, *dl, *dfound, *dlf, *dst_;
+            uint16_t *hp = blk.take<uint16_t>(own + 4, &dp);
+            int32_t *hoff = blk.take<int32_t>((size_t)n + 1, &doff);
+            int32_t *hl = blk.take<int32_t>((size_t)n * (size_t)loc_cap, &dl);
+            int32_t *hfound = blk.take<int32_t>((size_t)n, &dfound), *hlf = blk.take<int32_t>((size_t)n, &dlf), *hst = blk.take<int32_t>((size_t)n, &dst_);
+            (void)dfound;
+            (void)dlf;
+            (void)dst_;
+            if (own) memcpy(hp, pat + first, own * 2);
+            for (int32_t i = 0; i <= n; ++i) hoff[i] = (int32_t)((size_t)pat_off[i] - first);
+            if (loc_bytes) memcpy(hl, locs, loc_bytes);
+            DevBuf k_found, k_lf, k_st, k_ws;
+            HIP_TRY(k_found.alloc((size_t)n * 4));
+            HIP_TRY(k_lf.alloc((size_t)n * 4));
+            HIP_TRY(k_st.alloc((size_t)n * 4));
+            HIP_TRY(k_ws.alloc((size_t)n * 8));
+            PipeStreams *ps = nullptr;
+            rc = pipe_streams(idx->device, &ps);
+            if (rc) return rc;
+            hipStream_t st = ps->s[1];
+            Scratch scratch(idx, st, true);
+            struct SyncOnExit {
+                hipStream_t s;
+                ~SyncOnExit() { (void)hipStreamSynchronize(s); }
+            } sync_on_exit{st};
+            rc = locate_impl(idx, dp, doff, n, max_matches, dl, loc_cap, k_found.as<int32_t>(), lf_steps ? k_lf.as<int32_t>() : nullptr,
+                             status ? k_st.as<int32_t>() : nullptr, k_ws.as<int32_t>(), scratch);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(hfound, k_found.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+            if (lf_steps) HIP_TRY(hipMemcpyAsync(hlf, k_lf.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+            if (status) HIP_TRY(hipMemcpyAsync(hst, k_st.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (loc_bytes) memcpy(locs, hl, loc_bytes);
+            memcpy(found, hfound, (size_t)n * 4);
+            if (lf_steps) memcpy(lf_steps, hlf, (size_t)n * 4);
+            if (status) memcpy(status, hst, (size_t)n * 4);
+            return FMX_OK;
+        }
+    }
     DevBuf d_pat, d_off, d_locs, d_found, d_lf, d_st, d_ws;
     // Registered `locations` / pattern arrays (fmx_host_register) are mapped into the device's address space: k_locate_walk then
     // stores the hits straight into the caller's rows — only the slots it fills travel, and they travel once (the array is in /
@@ -2833,6 +2964,30 @@ int fmx_extract_batch(const fmx_index *idx, const int32_t *start, const int32_t 
     if (n == 0) return FMX_OK;
     HIP_TRY(hipSetDevice(idx->device));
     const size_t dst_bytes = (size_t)n * (size_t)dst_len * 2;
+    if (n <= g_host_small_max.load() && dst_bytes <= kHostSmallBytes) {  // a small call: one mapped pinned block (count_batch_small)
+        SmallBlock blk;
+        if (blk.init(5 * SmallBlock::up((size_t)n * 4) + SmallBlock::up(dst_bytes)) == FMX_OK) {
+            int32_t *da, *db, *dlen, *dlf, *dst_;
+            uint16_t *ddst;
+            int32_t *ha = blk.take<int32_t>((size_t)n, &da), *hb = blk.take<int32_t>((size_t)n, &db);
+            uint16_t *hdst = blk.take<uint16_t>((size_t)n * (size_t)dst_len, &ddst);
+            int32_t *hlen = blk.take<int32_t>((size_t)n, &dlen), *hlf = blk.take<int32_t>((size_t)n, &dlf), *hst = blk.take<int32_t>((size_t)n, &dst_);
+            memcpy(ha, start, (size_t)n * 4);
+            memcpy(hb, stop, (size_t)n * 4);
+            if (dst_bytes) memcpy(hdst, dst, dst_bytes);  // (rows are in / out: what a query does not write keeps the caller's values)
+            HostCallStream hs;
+            rc = hs.init(idx->device);
+            if (rc) return rc;
+            rc = fmx_extract_batch_dev(idx, da, db, n, ddst, dst_len, offset, dlen, dlf, dst_, hs.s);
+            HIP_TRY(hipStreamSynchronize(hs.s));
+            if (rc) return rc;
+            if (dst_bytes) memcpy(dst, hdst, dst_bytes);
+            memcpy(out_len, hlen, (size_t)n * 4);
+            if (lf_steps) memcpy(lf_steps, hlf, (size_t)n * 4);
+            if (status) memcpy(status, hst, (size_t)n * 4);
+            return FMX_OK;
+        }
+    }
     DevBuf d_a, d_b, d_dst, d_len, d_lf, d_st;
     HIP_TRY(d_a.alloc((size_t)n * 4));
     HIP_TRY(d_b.alloc((size_t)n * 4));
@@ -2862,6 +3017,35 @@ int fmx_extract_boundary_batch(const fmx_index *idx, const int32_t *from, int32_
     if (n == 0) return FMX_OK;
     HIP_TRY(hipSetDevice(idx->device));
     const size_t dst_bytes = (size_t)n * (size_t)dst_len * 2;
+    if (n <= g_host_small_max.load() && dst_bytes <= kHostSmallBytes) {  // a small call: one mapped pinned block (count_batch_small)
+        SmallBlock blk;
+        if (blk.init(5 * SmallBlock::up((size_t)n * 4) + SmallBlock::up(dst_bytes)) == FMX_OK) {
+            int32_t *da, *dlen, *dlf, *dst_, *daux;
+            uint16_t *ddst;
+            int32_t *ha = blk.take<int32_t>((size_t)n, &da);
+            uint16_t *hdst = blk.take<uint16_t>((size_t)n * (size_t)dst_len, &ddst);
+            int32_t *hlen = blk.take<int32_t>((size_t)n, &dlen), *hlf = blk.take<int32_t>((size_t)n, &dlf), *hst = blk.take<int32_t>((size_t)n, &dst_),
+                    *haux = blk.take<int32_t>((size_t)n, &daux);
+            memcpy(ha, from, (size_t)n * 4);
+            if (dst_bytes) memcpy(hdst, dst, dst_bytes);
+            if (aux) memcpy(haux, aux, (size_t)n * 4);  // (in / out like the rows: only a query that does not fit writes it)
+            HostCallStream hs;
+            rc = hs.init(idx->device);
+            if (rc) return rc;
+            Scratch scratch(idx, hs.s, true);
+            HostCallStream wait_first;  // (drained before the scratch and the block go back)
+            wait_first.s = hs.s;
+            rc = boundary_impl(idx, da, n, boundary, mode, ddst, dst_len, offset, dlen, dlf, dst_, daux, nullptr, 0, scratch);
+            HIP_TRY(hipStreamSynchronize(hs.s));
+            if (rc) return rc;
+            if (dst_bytes) memcpy(dst, hdst, dst_bytes);
+            memcpy(out_len, hlen, (size_t)n * 4);
+            if (lf_steps) memcpy(lf_steps, hlf, (size_t)n * 4);
+            if (status) memcpy(status, hst, (size_t)n * 4);
+            if (aux) memcpy(aux, haux, (size_t)n * 4);
+            return FMX_OK;
+        }
+    }
     DevBuf d_a, d_dst, d_len, d_lf, d_st, d_aux;
     HIP_TRY(d_a.alloc((size_t)n * 4));
     HIP_TRY(d_dst.alloc(dst_bytes));

@@ -1099,3 +1099,37 @@ def test_window_directory_changes_nothing_but_the_time(mode, entry_bytes):
         ia.lib.fmx_set_option(b"image_compact", 0)
         ia.lib.fmx_set_option(b"window_cells", 2)
         ia.lib.fmx_set_option(b"window_entry_bytes", 0)
+
+
+@pytest.mark.parametrize("small_max", [0, 50, 2048])
+def test_small_host_calls_through_one_mapped_block_change_nothing(small_max):
+    """option host_small_max: host-array calls of at most that many patterns / queries go through ONE pinned block mapped into the
+    device's address space (no copy calls: a scalar count() 104 -> 26 us) — every query kind against the oracle with the path off
+    (0: the copying paths, as before round 6), on for part of check_all's batches (50) and on for all of them (the default);
+    in / out arrays keep what a query does not write in every form"""
+    rnd = random.Random(900 + small_max)
+    try:
+        assert ia.lib.fmx_set_option(b"host_small_max", small_max) == 0
+        check_all(make_gpu, HD[:90_000], 16, rnd, n_q=100)
+        fm = ia.FmIndex(HD[:90_000], 16, True, device=0)
+        o = orc.OracleFmIndex(HD[:90_000], 16, True)
+        t16 = ia.as_chars(HD[:90_000])
+        pats = [t16[s:s + 9] for s in range(0, 40_000, 997)] + [ia.as_chars("zzzz")]
+        ch, off = ia.pack_patterns(pats)
+        n = len(pats)
+        pre = np.full((n, 7), -5, np.int32)
+        locs, found, st = fm.locate_batch(ch, off, 4, 7, locs=pre.copy())
+        ol, of, os_ = o.locate_batch(ch, off, 4, 7, fill=-5)
+        assert (locs == ol).all() and (found == of).all() and (st == os_).all()  # whole rows: the slots beyond the hits too
+        a = np.arange(n, dtype=np.int32) * 501
+        dst, ol2, st2 = fm.extract_batch(a, a + 20, 30, 3, dst=np.full((n, 30), 7, np.uint16))
+        od, on, oe = o.extract_batch(a, a + 20, 30, 3, fill=7)
+        assert (dst == od).all() and (ol2 == on).all() and (st2 == oe).all()
+        for mode in (0, 1, 2):
+            got = fm.extract_boundary_batch(a, "\n", mode, 48, 2, dst=np.full((n, 48), 7, np.uint16))
+            exp = o.extract_until_boundary_batch(mode, a, "\n", 48, 2, fill=7)
+            assert (got[0] == exp[0]).all() and (got[2] == exp[2]).all() and (got[1][exp[2] == 0] == exp[1][exp[2] == 0]).all()
+            assert (got[3][exp[2] == 8] == exp[3][exp[2] == 8]).all()
+        fm.close()
+    finally:
+        ia.lib.fmx_set_option(b"host_small_max", 2048)

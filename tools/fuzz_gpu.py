@@ -90,6 +90,7 @@ def main():
                 # round 6
                 "code_bits_12": rnd.choice([1, 1, 0]),  # alphabets of 257..4,096 codes: five codes per plan word / 16-bit codes
                 "count_lean": rnd.choice([0, 0, 1]),  # k_count_lean + the list pass (fast routes inlined, everything else on a redo list)
+                "host_small_max": rnd.choice([2048, 2048, 0, 40]),  # host-array calls through one mapped pinned block up to this many queries
                 "window_entry_bytes": rnd.choice([0, 0, 4, 6]),  # the directory's entries: by the alphabet / the row alone / row + symbol
                 "window_cells": rnd.choice([2, 2, 1, 0, 3]),  # ... 3: the flat form (a word per position)  # the window directory: by the memory rule / always / never
                 "walk_queue": rnd.choice([8, 8, 4, 0]),  # locate: tickets per lane of the per-wave queue (0: the packed form)
