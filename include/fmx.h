@@ -160,8 +160,8 @@ int fmx_host_unregister(void *p);
  * (FM:469-470). status[i] (nullable) is FMX_ST_JAVA_AIOOBE for an empty pattern.
  * Batches of >= 131,072 patterns (option "host_pipeline_min") travel in chunks of 262,144 patterns, a chunk's transfer
  * overlapping the kernels of the one before; pat_off must start at >= 0 and never decrease (FMX_E_ARG otherwise).
- * Small calls — up to 2,048 patterns (option "host_small_max"; the same holds for fmx_locate_batch, fmx_extract_batch and
- * fmx_extract_boundary_batch): everything the call moves goes through one pinned block the kernels read and write where it lies
+ * Small calls — up to 2,048 patterns (option "host_small_max"; the same holds for fmx_locate_batch, fmx_extract_batch,
+ * fmx_extract_boundary_batch, fmx_locate_extract_batch and fmx_locate_lines_batch): everything the call moves goes through one pinned block the kernels read and write where it lies
  * (no copy calls): a batch of ONE — a Java caller's count(char[]) — costs ~25 us (locate ~50, extract of 64 characters ~70). */
 int fmx_count_batch(const fmx_index *idx, const uint16_t *pat, const int32_t *pat_off, int32_t n,
                     int32_t *counts, int32_t *lf_steps, int32_t *status);

@@ -2806,6 +2806,65 @@ static int locate_pipeline_host(const fmx_index *idx, const uint16_t *pat, const
     const size_t chars = (size_t)(pat_off[n] > 0 ? pat_off[n] : 0);
     const size_t slots = (size_t)n * (size_t)max_matches;
     const size_t dst_bytes = slots * (size_t)row_len * 2;
+    // a small call: characters, offsets, the in / out rows and per-hit arrays in ONE mapped pinned block (count_batch_small has the
+    // story); found / LF-steps / statuses — updated with atomics — stay in HBM and come down by asynchronous copies into the block
+    if (n <= g_host_small_max.load() && chars - first_char(pat_off) <= kHostSmallChars && dst_bytes + slots * 16 <= kHostSmallBytes) {
+        const size_t first = first_char(pat_off), own = chars - first;
+        SmallBlock blk;
+        if (blk.init(SmallBlock::up(own * 2 + 8) + SmallBlock::up(((size_t)n + 1) * 4) + 4 * SmallBlock::up(slots * 4) + SmallBlock::up(dst_bytes) +
+                     3 * SmallBlock::up((size_t)n * 4)) == FMX_OK) {
+            uint16_t *dp, *ddst;
+            int32_t *doff, *dl, *dlen, *dhst, *daux, *unused;
+            uint16_t *hp = blk.take<uint16_t>(own + 4, &dp);
+            int32_t *hoff = blk.take<int32_t>((size_t)n + 1, &doff);
+            int32_t *hl = blk.take<int32_t>(slots, &dl);
+            uint16_t *hdst = blk.take<uint16_t>(slots * (size_t)row_len, &ddst);
+            int32_t *hlen = blk.take<int32_t>(slots, &dlen), *hhst = blk.take<int32_t>(slots, &dhst), *haux = blk.take<int32_t>(slots, &daux);
+            int32_t *hfound = blk.take<int32_t>((size_t)n, &unused), *hlf = blk.take<int32_t>((size_t)n, &unused),
+                    *hst = blk.take<int32_t>((size_t)n, &unused);
+            if (own) memcpy(hp, pat + first, own * 2);
+            for (int32_t i = 0; i <= n; ++i) hoff[i] = (int32_t)((size_t)pat_off[i] - first);
+            memcpy(hl, locs, slots * 4);  // (rows and per-hit arrays are in / out: slots without a hit keep the caller's values)
+            if (dst_bytes) memcpy(hdst, dst, dst_bytes);
+            memcpy(hlen, out_len, slots * 4);
+            if (hit_status) memcpy(hhst, hit_status, slots * 4);
+            if (hit_aux) memcpy(haux, hit_aux, slots * 4);
+            DevBuf k_found, k_lf, k_st, k_ws;
+            HIP_TRY(k_found.alloc((size_t)n * 4));
+            HIP_TRY(k_lf.alloc((size_t)n * 4));
+            HIP_TRY(k_st.alloc((size_t)n * 4));
+            HIP_TRY(k_ws.alloc((size_t)n * 8));
+            PipeStreams *ps = nullptr;
+            rc = pipe_streams(idx->device, &ps);
+            if (rc) return rc;
+            hipStream_t st = ps->s[1];
+            Scratch scratch(idx, st, true);
+            struct SyncOnExit {
+                hipStream_t s;
+                ~SyncOnExit() { (void)hipStreamSynchronize(s); }
+            } sync_on_exit{st};
+            if (mode < 0)
+                rc = locate_extract_impl(idx, dp, doff, n, max_matches, row_len, dl, k_found.as<int32_t>(), ddst, dlen, k_lf.as<int32_t>(),
+                                         k_st.as<int32_t>(), dhst, k_ws.as<int32_t>(), scratch);
+            else
+                rc = locate_lines_impl(idx, dp, doff, n, max_matches, boundary, mode, row_len, dl, k_found.as<int32_t>(), ddst, dlen,
+                                       k_lf.as<int32_t>(), k_st.as<int32_t>(), dhst, daux, k_ws.as<int32_t>(), scratch);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(hfound, k_found.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(hlf, k_lf.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(hst, k_st.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            memcpy(locs, hl, slots * 4);
+            memcpy(found, hfound, (size_t)n * 4);
+            if (dst_bytes) memcpy(dst, hdst, dst_bytes);
+            memcpy(out_len, hlen, slots * 4);
+            if (lf_steps) memcpy(lf_steps, hlf, (size_t)n * 4);
+            if (status) memcpy(status, hst, (size_t)n * 4);
+            if (hit_status) memcpy(hit_status, hhst, slots * 4);
+            if (hit_aux) memcpy(hit_aux, haux, slots * 4);
+            return FMX_OK;
+        }
+    }
     DevBuf d_pat, d_off, d_locs, d_found, d_dst, d_len, d_lf, d_st, d_hst, d_aux, d_ws;
     HIP_TRY(d_pat.alloc(chars * 2 + 8));
     HIP_TRY(d_off.alloc((size_t)(n + 1) * 4));

@@ -1130,6 +1130,15 @@ def test_small_host_calls_through_one_mapped_block_change_nothing(small_max):
             exp = o.extract_until_boundary_batch(mode, a, "\n", 48, 2, fill=7)
             assert (got[0] == exp[0]).all() and (got[2] == exp[2]).all() and (got[1][exp[2] == 0] == exp[1][exp[2] == 0]).all()
             assert (got[3][exp[2] == 8] == exp[3][exp[2] == 8]).all()
+        # the fused pipelines (locate -> extract, locate -> extractUntilBoundary): every array against the copying path's
+        # (which test_locate_extract_pipeline_vs_oracle holds to the oracle)
+        here = [fm.locate_extract_batch(ch, off, 3, 24, fill=9), fm.locate_lines_batch(ch, off, 3, "\n", 60, 0, fill=9)]
+        assert ia.lib.fmx_set_option(b"host_small_max", 0) == 0
+        there = [fm.locate_extract_batch(ch, off, 3, 24, fill=9), fm.locate_lines_batch(ch, off, 3, "\n", 60, 0, fill=9)]
+        for x, y in zip(here, there):
+            for key in x:
+                assert (x[key] == y[key]).all(), key
+        assert int(here[0]["found"].sum()) > 20
         fm.close()
     finally:
         ia.lib.fmx_set_option(b"host_small_max", 2048)

@@ -28,3 +28,4 @@ for n in (1, 1000):
     print("locate  n=%4d: %7.1f us per call (maxMatches 16)" % (n, per_call(lambda: fm.locate_batch(p, o, 16))))
     a = np.arange(n, dtype=np.int32) * 1000
     print("extract n=%4d: %7.1f us per call (64 characters)" % (n, per_call(lambda: fm.extract_batch(a, a + 64, 64))))
+    print("locate -> extract n=%4d: %7.1f us per call (4 hits x 32 characters)" % (n, per_call(lambda: fm.locate_extract_batch(p, o, 4, 32))))
