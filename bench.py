@@ -1441,8 +1441,8 @@ def run_secondary(ctx, args, q, ref, orc, text, pat, off):
     # index4j exists for the space / time trade (README.md: the serialized index is 0.44-0.47 of the text,
     # FmIndexSerializedSizeBenchmark.java:57).  Three forms of the resident index, each with its bytes per text byte
     # (fmx_resident_bytes) and the time of configs[2] and configs[3] over it: the compact image (index4j's own RRR compression kept),
-    # the expanded image, — the default, the rows above — the expanded image with the window directory, and that directory in its
-    # FLAT form (a word per position: every step of a walk one sector; option window_cells = 3).  Every form's
+    # the expanded image, — the default, the rows above — the expanded image with the window directory in the form the default rule
+    # gives it (here: the FLAT one, a word per position: every step of a walk one sector), and with the directory in cells.  Every form's
     # results are compared with the default form's (which the oracle checked above).
     if not args.profiling:
         try:
@@ -1458,9 +1458,11 @@ def run_secondary(ctx, args, q, ref, orc, text, pat, off):
                 check_rc(ia, ia.lib.fmx_resident_bytes(index.handle, C.byref(a), C.byref(b), C.byref(c3)), "fmx_resident_bytes")
                 return a.value, b.value, c3.value
 
-            forms = [{"form": "expanded image + window directory (the default: the rows above)", "configs2_ms": res[-2]["ms"],
+            forms = [{"form": "expanded image + window directory (the default rule's form: the rows above)", "configs2_ms": res[-2]["ms"],
                       "configs3_ms": ms3_default, "resident": resident(q), "resident64": resident(fm64)}]
-            for form, compact, cells in (("expanded image + FLAT directory (window_cells 3)", 0, 3), ("expanded image, no directory", 0, 0),
+            # (the default rule gives a text of this size the directory's FLAT form — 4 bytes per text byte, every step one sector;
+            # window_cells = 1 asks for the cells' form — 1.26 bytes per text byte — by name)
+            for form, compact, cells in (("expanded image + directory in CELLS (window_cells 1)", 0, 1), ("expanded image, no directory", 0, 0),
                                          ("compact image (RRR records), no directory", 1, 0)):
                 check_rc(ia, ia.lib.fmx_set_option(b"image_compact", compact), "fmx_set_option")
                 check_rc(ia, ia.lib.fmx_set_option(b"window_cells", cells), "fmx_set_option")

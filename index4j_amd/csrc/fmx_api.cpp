@@ -172,6 +172,9 @@ std::atomic<int> g_window_cells_mb{65536};
 // option "window_entry_bytes": the directory's entries — 0 = four bytes (the row; the symbol by a search over cumulativeCounts) where
 // those fit LDS (fmx::kWinSymbolSearchMax), six bytes otherwise; 4 / 6 = that form whatever the alphabet (tests, A/B)
 std::atomic<int> g_window_entry_bytes{0};
+// option "window_flat_fraction": under window_cells = 2 the directory takes its FLAT form (4 bytes per text byte, every step of a walk
+// one sector) where that costs at most 1 / this of the device's memory (default 128); 0 = never by itself (window_cells = 3 asks by name)
+std::atomic<int> g_window_flat_fraction{128};
 // host-buffer count(): batches of at least this many patterns go through the pipeline (smaller ones: one copy in, kernels, one copy out)
 std::atomic<int> g_host_small_max{2048};  // option "host_small_max": host-array calls of at most this many patterns / queries go through one mapped pinned block (0: off)
 std::atomic<int> g_host_pipeline_min{131072};
@@ -829,6 +832,11 @@ int fmx_set_option(const char *name, int value) {
         g_window_cells = value;
         return FMX_OK;
     }
+    if (name && !strcmp(name, "window_flat_fraction")) {  // the flat form by itself up to 1 / value of the device's memory (0: never)
+        if (value < 0) return fail(FMX_E_ARG, "bad value");
+        g_window_flat_fraction = value;
+        return FMX_OK;
+    }
     if (name && !strcmp(name, "window_entry_bytes")) {  // entries of the window directories grown from now on: 0 by the alphabet, 4, 6
         if (value != 0 && value != 4 && value != 6) return fail(FMX_E_ARG, "bad value");
         g_window_entry_bytes = value;
@@ -1034,9 +1042,22 @@ static void build_window_cells(fmx_index *idx) {
     idx->dev.win_flat = 0;
     const int mode = g_window_cells.load();
     if (mode == 0 || idx->rrr_only || idx->wavelet_only || idx->hdr.kind != 0 || idx->hdr.wt_size <= 0 || !idx->dev.self) return;
-    if (mode == 3) {
-        // THE FLAT FORM (fmx_device.hpp win_step): one 32-bit word per position instead of cells and entries — 4 bytes per text
-        // byte, every step of a walk ONE sector.  Asked for by name only; texts of 2^30 characters and more keep the cells.
+    // THE FLAT FORM (fmx_device.hpp win_step): one 32-bit word per position instead of cells and entries — 4 bytes per text
+    // byte, every step of a walk ONE sector (locate 18-24 % faster, extract 10 %).  Asked for by name (window_cells = 3), or
+    // taken by the default rule (window_cells = 2) where it is SMALL against the device: at most 1 / window_flat_fraction of the
+    // device's memory (default 128: 2.25 GB of 288 — texts up to 512 Mi characters), and like the cells' form inside a quarter of
+    // what is free and the per-index budget.  Texts of 2^30 characters and more keep the cells.
+    bool flat = mode == 3;
+    if (mode == 2 && g_window_flat_fraction.load() > 0 && (uint64_t)idx->hdr.wt_size <= 0x3fffffffull) {
+        size_t free_b = 0, total_b = 0;
+        const size_t need = (size_t)idx->hdr.wt_size * 4 + ((size_t)4096 + (size_t)idx->hdr.wt_size / 512) * 8 + 64;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            flat = need <= total_b / (size_t)g_window_flat_fraction.load() && need <= free_b / 4 &&
+                   need <= ((size_t)g_window_cells_mb.load() << 20);
+        else
+            (void)hipGetLastError();
+    }
+    if (flat) {
         const uint64_t n_pos = (uint64_t)idx->hdr.wt_size;
         if (n_pos <= 0x3fffffffull) {
             const size_t flat_bytes = ((size_t)n_pos * 4 + 7) & ~(size_t)7;

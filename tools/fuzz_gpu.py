@@ -92,7 +92,8 @@ def main():
                 "count_lean": rnd.choice([0, 0, 1]),  # k_count_lean + the list pass (fast routes inlined, everything else on a redo list)
                 "host_small_max": rnd.choice([2048, 2048, 0, 40]),  # host-array calls through one mapped pinned block up to this many queries
                 "window_entry_bytes": rnd.choice([0, 0, 4, 6]),  # the directory's entries: by the alphabet / the row alone / row + symbol
-                "window_cells": rnd.choice([2, 2, 1, 0, 3]),  # ... 3: the flat form (a word per position)  # the window directory: by the memory rule / always / never
+                "window_cells": rnd.choice([2, 2, 1, 0, 3]),  # ... 3: the flat form (a word per position); 2: the rule picks (texts of this size: flat)
+                "window_flat_fraction": rnd.choice([128, 0]),  # ... unless the rule may not (0): the cells' form  # the window directory: by the memory rule / always / never
                 "walk_queue": rnd.choice([8, 8, 4, 0]),  # locate: tickets per lane of the per-wave queue (0: the packed form)
                 "walk_queue_min_slots": rnd.choice([32, 1, 1, 8]),  # ... from this many hit slots per pattern on
                 "walk_burst": rnd.choice([0, 0, 1, 3, 8]),  # ... steps between two hand-outs (0: sampleRate / 4)
