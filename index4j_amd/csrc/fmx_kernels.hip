@@ -3022,10 +3022,21 @@ int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, i
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
     }
 #undef FMX_LAUNCH_NARROW_MODE
-#define FMX_LAUNCH_GROUP_MODE(BLK, GG, MODE)                                                                             \
-    hipLaunchKernelGGL((k_extract_boundary_group<BLK, GG, MODE, kWinAsk>), grid, dim3(BLK), 0, st, ix, from, n, boundary, dst, dst_len, \
+#define FMX_LAUNCH_GROUP_MODE_WIN(BLK, GG, MODE, KWIN)                                                                   \
+    hipLaunchKernelGGL((k_extract_boundary_group<BLK, GG, MODE, KWIN>), grid, dim3(BLK), 0, st, ix, from, n, boundary, dst, dst_len, \
                        offset, out_len, lf, status, aux, scratch, slot_found, slots, pair_walks, todo ? nullptr : order, redo,  \
                        (const int32_t *)todo)
+// (over the directory's FLAT form extractUntilBoundaryLeft — mode 1, the default group of 4 — runs the instantiation that has no tree
+// walk in its body: 0.464 -> 0.392 ms per 100,000 queries; modes 0 and 2 measured slower / equal that way, 0.720 -> 0.776 / 0.656 ->
+// 0.660, and keep the one that looks at ix.win itself: tools/boundary_probe.py, round 6)
+#define FMX_LAUNCH_GROUP_MODE(BLK, GG, MODE)                                                                             \
+    do {                                                                                                                \
+        if (GG == 4 && MODE == 1 && ix.win_flat)                                                                         \
+            FMX_LAUNCH_GROUP_MODE_WIN(BLK, ((GG == 4 && MODE == 1) ? 4 : 1), ((GG == 4 && MODE == 1) ? 1 : 0),          \
+                                      ((GG == 4 && MODE == 1) ? kWinFlat : kWinAsk));                                  \
+        else                                                                                                            \
+            FMX_LAUNCH_GROUP_MODE_WIN(BLK, GG, MODE, kWinAsk);                                                          \
+    } while (0)
 #define FMX_LAUNCH_GROUP(GG)                                                                                            \
     do {                                                                                                                \
         if (blk == 1024) {                                                                                              \
