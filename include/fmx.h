@@ -84,7 +84,7 @@ int fmx_suffix_table_info(const fmx_index *idx, int32_t *chars, int64_t *bytes);
 /* The window directory of a resident index (grown by fmx_to_device / fmx_attach_device_blob beside the image, like the suffix
  * table; option "window_cells": 0 = none, 1 = always, in cells, 2 = the default rule: where it fits a quarter of the device's free
  * memory — and in its FLAT form where that costs at most 1/128 of the device's memory (option "window_flat_fraction"; 0 = never by
- * itself), 3 = the flat form by name.  Flat = one 32-bit word per BWT position instead of cells and entries: every step of a walk is
+ * itself) and the alphabet has at most 2,048 symbols (the symbol search then runs in LDS), 3 = the flat form by name.  Flat = one 32-bit word per BWT position instead of cells and entries: every step of a walk is
  * ONE sector, at 4 bytes per text byte; locate 20-25 % faster, extract / extractUntilBoundary 10 %; texts below 2^30 characters.
  * Cells: one
  * 64-byte cell per 112 consecutive BWT positions holding, for the window's three most frequent symbols ("classes"), their folded

@@ -1048,7 +1048,10 @@ static void build_window_cells(fmx_index *idx) {
     // device's memory (default 128: 2.25 GB of 288 — texts up to 512 Mi characters), and like the cells' form inside a quarter of
     // what is free and the per-index budget.  Texts of 2^30 characters and more keep the cells.
     bool flat = mode == 3;
-    if (mode == 2 && g_window_flat_fraction.load() > 0 && (uint64_t)idx->hdr.wt_size <= 0x3fffffffull) {
+    // (by itself only for alphabets whose cumulativeCounts fit LDS: the flat form's words are rows, and a kernel that wants the symbol
+    // searches for it — over 8 KB of LDS, not over a table of up to 32,768 entries in memory)
+    if (mode == 2 && g_window_flat_fraction.load() > 0 && (uint64_t)idx->hdr.wt_size <= 0x3fffffffull &&
+        idx->hdr.n_c <= fmx::kWinSymbolSearchMax) {
         size_t free_b = 0, total_b = 0;
         const size_t need = (size_t)idx->hdr.wt_size * 4 + ((size_t)4096 + (size_t)idx->hdr.wt_size / 512) * 8 + 64;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)

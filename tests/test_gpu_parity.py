@@ -538,6 +538,10 @@ def test_planned_batches_vs_oracle_across_alphabet_sizes(sigma):
             assert ia.lib.fmx_set_option(b"suffix_table_image_fraction", frac) == 0 and ia.lib.fmx_set_option(b"code_bits_12", bits12) == 0
             fm = ia.FmIndex(arr, 16, True, device=0)
             assert fm.getAlphabetLength() == o.getAlphabetLength()
+            # the default rule's form of the window directory: flat (a word per position) while the symbol search runs over
+            # cumulativeCounts in LDS (up to 2,048 symbols), cells with six-byte entries beyond
+            per_position = _window_bytes(fm) / (len(arr) + 1)
+            assert (3.99 < per_position < 4.1) if sigma + 2 <= 2050 else (0.57 < per_position < 6.6 and not 3.99 < per_position < 4.1), (sigma, per_position)
             depths[(frac, bits12)] = fm.suffix_table_info()[0]
             cnt, st, lf = fm.count_batch(ch, off, want_steps=True)
             assert (st == ost).all() and (cnt == oc).all() and st[-1] == 9, (sigma, frac, bits12)
