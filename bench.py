@@ -317,6 +317,10 @@ def compact_line(out):
     if hb:
         c["host_buffers"] = _pick(hb, ("ms_per_call", "ms_per_call_registered_buffers", "ratio_to_max_of_floor_and_device_step",
                                        "ratio_registered_to_max_of_floor_and_device_step", "pcie_floor_ms_in", "stat"))
+        if hb.get("ms_per_call_all") and hb.get("ms_per_call_registered_buffers_all"):  # (the detail record keeps the long form)
+            c["host_buffers"]["stat"] = "means of 7 calls; medians %.3f / %.3f, minima %.3f / %.3f ms (pageable / registered)" % (
+                hb.get("ms_per_call_median", 0), hb.get("ms_per_call_registered_buffers_median", 0), min(hb["ms_per_call_all"]),
+                min(hb["ms_per_call_registered_buffers_all"]))
         sc = hb.get("scalar_call_us") or {}
         if sc.get("count"):  # microseconds per call of ONE query: count, locate (16 slots), extract (64 characters)
             c["host_buffers"]["scalar_us"] = _sig([sc["count"], sc.get("locate16"), sc.get("extract64")], 3)
