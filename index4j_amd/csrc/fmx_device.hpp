@@ -2354,6 +2354,9 @@ struct TextWindow {
     int32_t mapped_boundary;
     int32_t marks_k;
     IntervalMarks marks;
+    // ... and of the SECOND round of a fill in rounds (window_fill_round): the lane's second interval of this window
+    int32_t marks2_k = -1;
+    IntervalMarks marks2 = {0, 0};
 };
 
 template <int G>
@@ -2466,6 +2469,64 @@ FMX_HD void window_fill_pairs(const DevIndex &ix, const uint16_t *inv, TextWindo
     }
 }
 
+// THE FILL IN ROUNDS (round 6; G = 4, extractUntilBoundary both ways): a line of log text needs 3.1 of the 8 sample intervals the
+// first fill above fetches, and three quarters of the lines end inside the TWO intervals on each side of `from`.  Round 0 fetches
+// those four — ONE walk per lane: lanes 0, 1 the intervals k0 - 1, k0 of the left window, lanes 2, 3 the intervals k0 + 1, k0 + 2
+// of the right one — and the marked replay is tried; a group whose line does not end inside them runs round 1: the two intervals
+// further out on each side, into the windows' free slots, their marks beside the first round's (TextWindow.marks2).  After
+// round 1 the windows hold what window_fill_pairs fetches, marks of all eight intervals included: the same replay, the same rows.
+template <int G, int kWin = kWinAsk>
+FMX_HD void window_fill_round(const DevIndex &ix, const uint16_t *inv, TextWindow<G> &wl, TextWindow<G> &wr, int32_t k0, int round) {
+    static_assert(G == 4, "the fill in rounds is the group of four's");
+    const int32_t k_max = (ix.length - 1) / wl.s;
+    const bool left_lane = wl.g < 2;
+    const int32_t j = wl.g & 1;
+    int32_t mine;
+    if (round == 0) {
+        const int32_t lo = k0 >= 1 ? k0 - 1 : 0;
+        wl.k_lo = lo;
+        wl.n = k0 - lo + 1;  // [lo, k0]: two intervals, or one at the text's start
+        wr.k_lo = k0 + 1;
+        wr.n = 2;
+        mine = left_lane ? (lo + j <= k0 ? lo + j : -1) : k0 + 1 + j;
+    } else {
+        const int32_t e = wl.k_lo < 2 ? wl.k_lo : 2;  // the left window grows by two intervals (not below interval 0)
+        const int32_t new_lo = wl.k_lo - e;
+        mine = left_lane ? (j < e ? new_lo + j : -1) : wr.k_lo + wr.n + j;
+        wl.k_lo = new_lo;
+        wl.n += e;
+        wr.n += 2;
+    }
+    if (mine > k_max) mine = -1;
+    IntervalMarks m = {0, 0};
+    int status = ST_OK;
+    int32_t walked = 0;
+    bool ok = true;
+    if (mine >= 0) {
+        uint16_t *slot = (left_lane ? wl.buf : wr.buf) + (int64_t)(mine & (G - 1)) * wl.slot_stride;
+        ok = fm_fetch_interval<kWin>(ix, inv, mine, slot, wl.row_stride, walked, status, &m, wl.mapped_boundary);
+    }
+    if (left_lane)
+        wl.steps += walked;
+    else
+        wr.steps += walked;
+    const IntervalMarks none = {0, 0};
+    if (round == 0) {
+        wl.marks_k = left_lane ? mine : -1;
+        wl.marks = left_lane ? m : none;
+        wr.marks_k = left_lane ? -1 : mine;
+        wr.marks = left_lane ? none : m;
+        wl.marks2_k = wr.marks2_k = -1;
+        wl.marks2 = wr.marks2 = none;
+    } else {
+        wl.marks2_k = left_lane ? mine : -1;
+        wl.marks2 = left_lane ? m : none;
+        wr.marks2_k = left_lane ? -1 : mine;
+        wr.marks2 = left_lane ? none : m;
+    }
+    if (group_any<G>(!ok)) wl.suspect = wr.suspect = true;
+}
+
 template <int G, int kWin = kWinAsk>
 FMX_HD int32_t window_code_at(const DevIndex &ix, const uint16_t *inv, TextWindow<G> &w, int32_t pos, int dir) {
     const int32_t k = pos / w.s;
@@ -2512,6 +2573,13 @@ FMX_HD bool fm_boundary_replay_marked(const DevIndex &ix, int mode, const TextWi
             if (wl.marks_k == k0) m &= below;
             if (m) cand = wl.marks_k * s + 63 - fmx_clzll(m);
         }
+        if (wl.marks2_k >= 0 && wl.marks2_k < k0) {  // (a fill in rounds: the lane's second interval, further left)
+            const uint64_t m = wl.marks2.boundary | wl.marks2.zero;
+            if (m) {
+                const int32_t c2 = wl.marks2_k * s + 63 - fmx_clzll(m);
+                cand = c2 > cand ? c2 : cand;
+            }
+        }
         lb = group_max<G>(cand);
         if (lb < 0 && wl.k_lo != 0) return false;  // the line starts left of the window
         a = from - lb - 1;
@@ -2529,6 +2597,10 @@ FMX_HD bool fm_boundary_replay_marked(const DevIndex &ix, int mode, const TextWi
         }
         if (wr.marks_k > k0 && wr.marks.boundary) {
             const int32_t r2 = wr.marks_k * s + fmx_ctzll(wr.marks.boundary);
+            rc = r2 < rc ? r2 : rc;
+        }
+        if (wr.marks2_k > k0 && wr.marks2.boundary) {  // (a fill in rounds: the lane's second interval, further right)
+            const int32_t r2 = wr.marks2_k * s + fmx_ctzll(wr.marks2.boundary);
             rc = r2 < rc ? r2 : rc;
         }
         rb = group_min<G>(rc);
@@ -2579,7 +2651,7 @@ FMX_HD bool fm_boundary_replay_marked(const DevIndex &ix, int mode, const TextWi
 // kDefer: the NARROW first round of a batch (G = 2: two sample intervals on each side of `from`, what most lines need) — a query the
 // marked replay cannot finish from those windows is not replayed literally here (its refills would hold the whole wave up) but
 // handed back like a suspect one (`clean` false): the caller puts it on a list that the wide form (G = 4) works off.
-template <int G, int kMode = -1, int kWin = kWinAsk, bool kDefer = false>
+template <int G, int kMode = -1, int kWin = kWinAsk, bool kDefer = false, bool kRounds = false>
 FMX_HD int32_t fm_extract_boundary_group(const DevIndex &ix, const uint16_t *inv, int mode, int32_t from,
                                          int32_t mapped_boundary, uint16_t *dest, int32_t dst_len, int32_t offset,
                                          int32_t &steps, int &status, int32_t &aux, uint16_t *buf, int64_t row_stride,
@@ -2615,7 +2687,22 @@ FMX_HD int32_t fm_extract_boundary_group(const DevIndex &ix, const uint16_t *inv
     const int32_t k0 = from / s;
     TextWindow<G> wl = {buf, row_stride, slot_stride, s, -1, 0, g, 0, false, mapped_boundary, -1, {0, 0}};               // intervals <= k0
     TextWindow<G> wr = {buf + win_stride, row_stride, slot_stride, s, -1, 0, g, 0, false, mapped_boundary, -1, {0, 0}};  // intervals > k0
-    if (pair_walks) {
+    bool filled = false;
+    if constexpr (kRounds && G == 4) {
+        if (mode == 0 && s <= 64) {
+            // the fill in rounds (window_fill_round): the four intervals next to `from` first; the replay decides who needs the rest
+            int32_t ret0 = 0;
+            window_fill_round<G, kWin>(ix, inv, wl, wr, k0, 0);
+            if (!wl.suspect && !wr.suspect && fm_boundary_replay_marked<G>(ix, mode, wl, wr, from, k0, dest, dst_len, offset, ret0)) {
+                steps = group_sum<G>(wl.steps + wr.steps);
+                return ret0;
+            }
+            if (!wl.suspect && !wr.suspect) window_fill_round<G, kWin>(ix, inv, wl, wr, k0, 1);
+            filled = true;
+        }
+    }
+    if (filled) {
+    } else if (pair_walks) {
         window_fill_pairs<G, kWin>(ix, inv, wl, wr, k0, mode != 1);       // the same two windows, a lane's two walks interleaved
     } else {
         window_refill<G, kWin>(ix, inv, wl, k0, -1);                      // [k0-G+1, k0]: the left part and text[from..]

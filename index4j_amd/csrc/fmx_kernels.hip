@@ -1469,7 +1469,7 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary(DevIndex ix_global, const in
 // kDefer (the NARROW first round, G = 2): a query whose line does not lie inside the two intervals on each side of `from` goes onto
 // `redo` as well — which then is the `todo` list of a launch of the wide form (G = 4, kDefer false) behind this one.
 // todo (nullable): {count, 0, 0, 0, queries...} — only those queries are run, and their LF-steps are ADDED to what is there.
-template <int kBlock, int G, int kMode, int kWin, bool kDefer = false>
+template <int kBlock, int G, int kMode, int kWin, bool kDefer = false, bool kRounds = false>
 FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix_global, const int32_t *__restrict__ froms, int64_t n,
                                                  uint16_t boundary, uint16_t *__restrict__ dst,
                                                  int32_t dst_len, int32_t offset, int32_t *__restrict__ out_len,
@@ -1499,7 +1499,7 @@ FMX_BOUNDARY_KERNEL(kBlock) void k_extract_boundary_group(DevIndex ix_global, co
         int32_t steps, aux;
         bool clean;
         uint16_t *dest = dst + q * (int64_t)dst_len;
-        const int32_t ret = fm_extract_boundary_group<G, kMode, kWin, kDefer>(ix, s_inv, kMode, froms[q], mapped_boundary, dest, dst_len, offset,
+        const int32_t ret = fm_extract_boundary_group<G, kMode, kWin, kDefer, kRounds>(ix, s_inv, kMode, froms[q], mapped_boundary, dest, dst_len, offset,
                                                                         steps, status, aux, scratch + (lane - g), lanes, 1,
                                                                         lanes * (int64_t)ix.sample_rate, g, clean, pair_walks != 0);
         if (g == 0) {
@@ -2288,6 +2288,9 @@ static std::atomic<int> g_count_halve_uniform{1};
 // 32.5 M per headline launch, no spill at all) and takes the SAME time (89.0 against 90.9 us; + 4.6 us for the list pass that finds
 // its list empty) — k_count is not bound by instruction issue.  Kept as the A/B that showed it.
 static std::atomic<int> g_count_lean{0};
+// option "boundary_rounds": extractUntilBoundary (both ways, the group of four) fetches the four sample intervals next to `from`
+// first and the four further out only for the groups whose line does not end inside those (fmx_device.hpp window_fill_round)
+static std::atomic<int> g_boundary_rounds{1};
 // 1 = the plan stage of a batch of at most one tile per CU is ONE launch (k_plan_fused); 0 (default) = k_plan_codes +
 // k_plan_scatter.  Measured (round 5, configs[1]): step 0.1365 -> 0.1339 ms (-2 %), with two batches in flight 0.109 -> 0.117
 // (+7 %: workgroups waiting at the barrier hold their CUs) — not worth a spinning kernel by default.
@@ -2385,6 +2388,10 @@ int set_option(const char *name, int value) {
     }
     if (!strcmp(name, "code_bits_12")) {
         g_code_bits_12 = value != 0;
+        return 0;
+    }
+    if (!strcmp(name, "boundary_rounds")) {
+        g_boundary_rounds = value != 0;
         return 0;
     }
     if (!strcmp(name, "count_lean")) {
@@ -3031,7 +3038,12 @@ int launch_extract_boundary(const DevIndex &ix, int n_cu, const int32_t *from, i
 // 0.660, and keep the one that looks at ix.win itself: tools/boundary_probe.py, round 6)
 #define FMX_LAUNCH_GROUP_MODE(BLK, GG, MODE)                                                                             \
     do {                                                                                                                \
-        if (GG == 4 && MODE == 1 && ix.win_flat)                                                                         \
+        if (GG == 4 && MODE == 0 && g_boundary_rounds && pair_walks && !todo)                                            \
+            hipLaunchKernelGGL((k_extract_boundary_group<BLK, ((GG == 4 && MODE == 0) ? 4 : 1), 0, kWinAsk, false,       \
+                                                         (GG == 4 && MODE == 0)>),                                      \
+                               grid, dim3(BLK), 0, st, ix, from, n, boundary, dst, dst_len, offset, out_len, lf, status, aux, scratch, \
+                               slot_found, slots, pair_walks, order, redo, (const int32_t *)nullptr);                   \
+        else if (GG == 4 && MODE == 1 && ix.win_flat)                                                                    \
             FMX_LAUNCH_GROUP_MODE_WIN(BLK, ((GG == 4 && MODE == 1) ? 4 : 1), ((GG == 4 && MODE == 1) ? 1 : 0),          \
                                       ((GG == 4 && MODE == 1) ? kWinFlat : kWinAsk));                                  \
         else                                                                                                            \

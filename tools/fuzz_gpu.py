@@ -97,6 +97,7 @@ def main():
                 "walk_queue": rnd.choice([8, 8, 4, 0]),  # locate: tickets per lane of the per-wave queue (0: the packed form)
                 "walk_queue_min_slots": rnd.choice([32, 1, 1, 8]),  # ... from this many hit slots per pattern on
                 "walk_burst": rnd.choice([0, 0, 1, 3, 8]),  # ... steps between two hand-outs (0: sampleRate / 4)
+                "boundary_rounds": rnd.choice([1, 1, 0]),  # extractUntilBoundary: the four intervals next to `from` first, the rest for who needs them
                 "boundary_narrow": rnd.choice([0, 0, 1]),  # extractUntilBoundary: a narrow first round + the wide form over the list
                 "boundary_narrow_min": rnd.choice([4096, 1, 1])}
         check_seed = rnd.randrange(1 << 30)
